@@ -1,0 +1,73 @@
+"""Compiler driver: builds the in-tree shared objects.
+
+  libzkw.so          hipcc --offload-arch=gfx950  (the product: HIP kernels + C ABI)
+  libzkw_isa.so      g++   (host-only ISA helpers of include/zkw.h, also linked into libzkw.so)
+  oracle/_build/...  g++   (TEST INFRASTRUCTURE: CPU restatement of the reference)
+"""
+import os
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libzkw.so")
+ISA_LIB = os.path.join(PKG, "libzkw_isa.so")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "_build", "libzkw_oracle.so")
+
+HIP_SOURCES = ["zkw_kernels.hip", "zkw_runtime.cpp", "isa_default.cpp"]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def _run(cmd, cwd=None):
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def hip_deps():
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps.append(os.path.join(ROOT, "include", "zkw.h"))
+    return deps
+
+
+def build_lib(force=False, extra_flags=()):
+    """hipcc -> libzkw.so (gfx950). Cross-compiles without a GPU."""
+    if force or _stale(LIB, hip_deps()):
+        srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"),
+               "-o", LIB] + list(extra_flags) + srcs
+        _run(cmd)
+    return LIB
+
+
+def build_isa(force=False):
+    src = os.path.join(CSRC, "isa_default.cpp")
+    if force or _stale(ISA_LIB, [src, os.path.join(ROOT, "include", "zkw.h")]):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", ISA_LIB, src])
+    return ISA_LIB
+
+
+def build_oracle(force=False, native=False):
+    """TEST INFRASTRUCTURE ONLY. `native=True` builds the -march=native flavour bench.py times."""
+    out = ORACLE_LIB if not native else ORACLE_LIB.replace(".so", "_native.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("vm.cpp", "zkwo_api.cpp")]
+    deps = srcs + [os.path.join(ORACLE_DIR, f) for f in ("vm.hpp", "u256.hpp", "hashes.hpp")] + [os.path.join(ROOT, "include", "zkw.h")]
+    if force or _stale(out, deps):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        flags = ["-O3", "-std=c++17", "-fPIC", "-shared", "-pthread"] + (["-march=native"] if native else [])
+        _run(["g++"] + flags + ["-o", out] + srcs)
+    return out
+
+
+def build_all(force=False):
+    build_isa(force)
+    build_lib(force)
+    build_oracle(force)

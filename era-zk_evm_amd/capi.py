@@ -1,0 +1,353 @@
+"""ctypes / numpy binding of include/zkw.h.
+
+`Backend` wraps one shared library and one symbol prefix, so the same harness drives
+  * the product  — libzkw.so,  prefix `zkw_`  (HIP kernels; needs a GPU to run), and
+  * the oracle   — oracle/_build/libzkw_oracle.so, prefix `zkwo_` (TEST INFRASTRUCTURE; only
+    tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it).
+Structs are mirrored as numpy structured dtypes (byte-exact with the C layout; checked by
+tests/test_capi_layout.py through zkw_abi_sizeof).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+# ----------------------------------------------------------------------------------------
+# constants of zkw.h
+# ----------------------------------------------------------------------------------------
+OK = 0
+ERR_INVALID, ERR_DEVICE, ERR_LIMIT, ERR_NOT_RUN = -1, -2, -3, -4
+STATUS_RUNNING, STATUS_ENDED, STATUS_UNKNOWN_CODE_HASH, STATUS_REFERENCE_PANIC, STATUS_LIMIT = 0, 1, 2, 3, 4
+(OP_INVALID, OP_NOP, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_JUMP, OP_CONTEXT, OP_SHIFT, OP_BINOP, OP_PTR, OP_NEAR_CALL, OP_LOG, OP_FAR_CALL,
+ OP_RET, OP_UMA) = range(16)
+(CTX_THIS, CTX_CALLER, CTX_CODE_ADDRESS, CTX_META, CTX_ERGS_LEFT, CTX_SP, CTX_GET_CONTEXT_U128, CTX_SET_CONTEXT_U128,
+ CTX_SET_ERGS_PER_PUBDATA, CTX_INC_TX_NUMBER) = range(10)
+SHIFT_SHL, SHIFT_SHR, SHIFT_ROL, SHIFT_ROR = range(4)
+BINOP_XOR, BINOP_AND, BINOP_OR = range(3)
+PTR_ADD, PTR_SUB, PTR_PACK, PTR_SHRINK = range(4)
+LOG_STORAGE_READ, LOG_STORAGE_WRITE, LOG_TO_L1, LOG_EVENT, LOG_PRECOMPILE = range(5)
+FAR_NORMAL, FAR_DELEGATE, FAR_MIMIC = range(3)
+RET_OK, RET_REVERT, RET_PANIC = range(3)
+UMA_HEAP_READ, UMA_HEAP_WRITE, UMA_AUX_READ, UMA_AUX_WRITE, UMA_FAT_PTR_READ = range(5)
+MODE_REG, MODE_STACK_PP, MODE_STACK_OFF, MODE_STACK_ABS, MODE_IMM, MODE_CODE = range(6)
+PROP_EXPLICIT_PANIC, PROP_KERNEL_ONLY, PROP_STATIC_OK, PROP_SWAP, PROP_SRC0_PTR_OK, PROP_SRC1_PTR_OK = 1, 2, 4, 8, 16, 32
+COND_ALWAYS, COND_GT, COND_LT, COND_EQ, COND_GE, COND_LE, COND_NE, COND_GT_OR_LT = range(8)
+MEM_STACK, MEM_CODE, MEM_HEAP, MEM_AUX_HEAP, MEM_FAT_PTR = range(5)
+MQ_TYPE_MASK, MQ_IS_PTR, MQ_RW, MQ_KIND_SHIFT = 0x07, 0x08, 0x10, 5
+LQ_LOG, LQ_REFUND = 0, 1
+LQ_RW, LQ_ROLLBACK, LQ_IS_SERVICE = 1, 2, 4
+AUX_FRAME_START, AUX_FRAME_FINISH, AUX_DECOMMIT, AUX_COLD_STATE = 1, 2, 3, 4
+ISA_TABLE_SIZE = 2048
+QUEUE_MEMORY, QUEUE_LOG, QUEUE_DECOMMIT, QUEUE_COUNT = 0, 1, 2, 3
+
+# ----------------------------------------------------------------------------------------
+# numpy dtypes (explicit offsets, itemsize = C sizeof)
+# ----------------------------------------------------------------------------------------
+U256 = np.dtype(("<u8", (4,)))
+
+
+def _dt(fields, itemsize):
+    names, formats, offsets = zip(*fields)
+    return np.dtype({"names": list(names), "formats": list(formats), "offsets": list(offsets), "itemsize": itemsize})
+
+
+ISA_ENTRY = _dt([("opcode", "u1", 0), ("variant", "u1", 1), ("src0_mode", "u1", 2), ("dst0_mode", "u1", 3), ("flags", "u1", 4), ("props", "u1", 5),
+                 ("reserved", "<u2", 6), ("price", "<u4", 8)], 12)
+ISA_CONSTS = _dt([("nop_encoding", "<u8", 0), ("exception_revert_encoding", "<u8", 8), ("panic_variant_idx", "<u4", 16), ("nop_variant_idx", "<u4", 20),
+                  ("clip_mode", "<u4", 24), ("time_delta_per_cycle", "<u4", 28), ("new_memory_pages_per_far_call", "<u4", 32),
+                  ("vm_max_stack_depth", "<u4", 36), ("initial_sp_on_far_call", "<u4", 40), ("new_frame_memory_stipend", "<u4", 44),
+                  ("memory_growth_ergs_per_byte", "<u4", 48), ("ergs_per_code_word_decommittment", "<u4", 52),
+                  ("initial_storage_write_pubdata_bytes", "<u4", 56), ("l1_message_pubdata_bytes", "<u4", 60), ("max_offset_to_deref_low", "<u4", 64),
+                  ("deployer_address_low", "<u4", 68), ("keccak_precompile_address", "<u4", 72), ("sha256_precompile_address", "<u4", 76),
+                  ("ecrecover_precompile_address", "<u4", 80), ("storage_aux_byte", "u1", 84), ("event_aux_byte", "u1", 85),
+                  ("l1_message_aux_byte", "u1", 86), ("precompile_aux_byte", "u1", 87), ("reserved", ("<u4", 8), 88)], 120)
+ISA_TABLE = _dt([("entries", (ISA_ENTRY, ISA_TABLE_SIZE), 0), ("consts", ISA_CONSTS, 12 * ISA_TABLE_SIZE)], 12 * ISA_TABLE_SIZE + 120)
+
+CALLSTACK_ENTRY = _dt([("this_address", ("u1", 20), 0), ("msg_sender", ("u1", 20), 20), ("code_address", ("u1", 20), 40), ("base_memory_page", "<u4", 60),
+                       ("code_page", "<u4", 64), ("sp", "<u2", 68), ("pc", "<u2", 70), ("exception_handler_location", "<u2", 72), ("is_static", "u1", 74),
+                       ("is_local_frame", "u1", 75), ("ergs_remaining", "<u4", 76), ("this_shard_id", "u1", 80), ("caller_shard_id", "u1", 81),
+                       ("code_shard_id", "u1", 82), ("reserved0", "u1", 83), ("reserved1", "<u4", 84), ("context_u128_value", ("<u8", 2), 88),
+                       ("heap_bound", "<u4", 104), ("aux_heap_bound", "<u4", 108)], 112)
+VM_LOCAL_STATE = _dt([("previous_code_word", U256, 0), ("registers", (U256, 15), 32), ("register_ptr_bitmap", "<u2", 512), ("flags", "u1", 514),
+                      ("pending_exception", "u1", 515), ("previous_code_memory_page", "<u4", 516), ("timestamp", "<u4", 520),
+                      ("monotonic_cycle_counter", "<u4", 524), ("spent_pubdata_counter", "<u4", 528), ("memory_page_counter", "<u4", 532),
+                      ("absolute_execution_step", "<u4", 536), ("current_ergs_per_pubdata_byte", "<u4", 540), ("tx_number_in_block", "<u2", 544),
+                      ("previous_super_pc", "<u2", 546), ("callstack_depth", "<u4", 548), ("context_u128_register", ("<u8", 2), 552),
+                      ("current", CALLSTACK_ENTRY, 568)], 680)
+BLOCK_PROPERTIES = _dt([("default_aa_code_hash", U256, 0), ("zkporter_is_available", "<u4", 32), ("reserved0", "<u4", 36)], 40)
+STORAGE_SLOT = _dt([("key", U256, 0), ("value", U256, 32), ("address", ("u1", 20), 64), ("shard_id", "u1", 84), ("reserved0", ("u1", 3), 85)], 88)
+LIMITS = _dt([("max_cycles", "<u4", 0), ("max_far_frames", "<u4", 4), ("max_callstack_depth", "<u4", 8), ("stack_words", "<u4", 12), ("heap_words", "<u4", 16),
+              ("aux_heap_words", "<u4", 20), ("storage_slots", "<u4", 24), ("storage_journal", "<u4", 28), ("max_mem_queries", "<u4", 32),
+              ("max_log_queries", "<u4", 36), ("max_aux_events", "<u4", 40), ("lanes_per_wave", "<u4", 44), ("reserved", ("<u4", 4), 48)], 64)
+CYCLE_TAIL = _dt([("register_ptr_bitmap", "<u2", 0), ("flags", "u1", 2), ("reserved0", "u1", 3), ("pc", "<u2", 4), ("sp", "<u2", 6), ("ergs_remaining", "<u4", 8),
+                  ("timestamp", "<u4", 12), ("heap_bound", "<u4", 16), ("aux_heap_bound", "<u4", 20), ("callstack_depth", "<u2", 24),
+                  ("previous_super_pc", "<u2", 26), ("event_counts", "<u4", 28)], 32)
+CYCLE_RECORD = _dt([("registers", (U256, 15), 0), ("tail", CYCLE_TAIL, 480)], 512)
+MEM_QUERY = _dt([("timestamp", "<u4", 0), ("page", "<u4", 4), ("index", "<u4", 8), ("lane", "u1", 12), ("seq", "u1", 13), ("meta", "u1", 14), ("reserved0", "u1", 15),
+                 ("value", U256, 16)], 48)
+LOG_QUERY = _dt([("key", U256, 0), ("read_value", U256, 32), ("written_value", U256, 64), ("address", ("u1", 20), 96), ("timestamp", "<u4", 116),
+                 ("tx_number_in_block", "<u2", 120), ("aux_byte", "u1", 122), ("shard_id", "u1", 123), ("bools", "u1", 124), ("kind", "u1", 125),
+                 ("lane", "u1", 126), ("seq", "u1", 127)], 128)
+AUX_EVENT = _dt([("type", "u1", 0), ("lane", "u1", 1), ("seq", "u1", 2), ("flag", "u1", 3), ("a", "<u4", 4), ("b", "<u4", 8), ("c", "<u4", 12),
+                 ("raw", ("u1", 240), 16)], 256)
+RUN_STATS = _dt([("cycles", "<u8", 0), ("mem_queries", "<u8", 8), ("log_queries", "<u8", 16), ("aux_events", "<u8", 24), ("instances_ended", "<u8", 32),
+                 ("instances_failed", "<u8", 40), ("kernel_ms", "<f8", 48), ("reserved0", "<f8", 56)], 64)
+
+
+class InstanceTraceC(C.Structure):
+    _fields_ = [("status", C.c_uint32), ("n_cycles", C.c_uint32), ("n_mem", C.c_uint32), ("n_log", C.c_uint32), ("n_aux", C.c_uint32),
+                ("reserved0", C.c_uint32), ("records", C.c_void_p), ("mem", C.c_void_p), ("log", C.c_void_p), ("aux", C.c_void_p),
+                ("mem_off", C.c_void_p), ("log_off", C.c_void_p), ("aux_off", C.c_void_p), ("final_state", C.c_uint8 * 680)]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _from_ptr(ptr, count, dtype):
+    if count == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_uint8 * (count * dtype.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+
+# ----------------------------------------------------------------------------------------
+# ISA helpers (host-only library)
+# ----------------------------------------------------------------------------------------
+_isa_lib = None
+
+
+def isa_lib():
+    global _isa_lib
+    if _isa_lib is None:
+        path = _build.ISA_LIB
+        if not os.path.exists(path):
+            _build.build_isa()
+        _isa_lib = C.CDLL(path)
+        _isa_lib.zkw_isa_encode.restype = C.c_uint64
+        _isa_lib.zkw_isa_encode.argtypes = [C.c_uint32] * 8
+        _isa_lib.zkw_isa_find.restype = C.c_int32
+        _isa_lib.zkw_isa_find.argtypes = [C.c_void_p] + [C.c_uint32] * 5
+    return _isa_lib
+
+
+class Isa:
+    """The ISA table + instruction encoder used by the synthetic tape generator."""
+
+    def __init__(self, table=None):
+        if table is None:
+            table = np.zeros(1, dtype=ISA_TABLE)
+            rc = isa_lib().zkw_isa_default(_ptr(table))
+            assert rc == OK
+        self.table = table
+        self._cache = {}
+
+    @property
+    def consts(self):
+        return self.table["consts"][0]
+
+    def find(self, opcode, variant=0, src0=MODE_REG, dst0=MODE_REG, flags=0):
+        key = (opcode, variant, src0, dst0, flags)
+        if key not in self._cache:
+            e = self.table["entries"][0]
+            m = (e["opcode"] == opcode) & (e["variant"] == variant) & (e["src0_mode"] == src0) & (e["dst0_mode"] == dst0) & (e["flags"] == flags)
+            idx = np.flatnonzero(m)
+            if len(idx) == 0:
+                raise KeyError("no ISA variant for %r" % (key,))
+            self._cache[key] = int(idx[0])
+        return self._cache[key]
+
+    def enc(self, opcode, variant=0, src0_mode=MODE_REG, dst0_mode=MODE_REG, flags=0, cond=COND_ALWAYS, src0=0, src1=0, dst0=0, dst1=0, imm0=0, imm1=0):
+        idx = self.find(opcode, variant, src0_mode, dst0_mode, flags)
+        return (idx & 0x7FF) | ((cond & 7) << 13) | ((src0 & 15) << 16) | ((src1 & 15) << 20) | ((dst0 & 15) << 24) | ((dst1 & 15) << 28) | (
+            (imm0 & 0xFFFF) << 32) | ((imm1 & 0xFFFF) << 48)
+
+
+def pack_code(opcodes):
+    """list of u64 encodings -> code words (U256, 4 opcodes each; opcode k of a word is limb 3-k,
+    the BE sub-word order of cycle.rs:86-94)."""
+    n = (len(opcodes) + 3) // 4
+    words = np.zeros((n, 4), dtype="<u8")
+    for i, op in enumerate(opcodes):
+        words[i // 4, 3 - (i % 4)] = op
+    return words
+
+
+def u256_from_int(v):
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype="<u8")
+
+
+def u256_to_int(a):
+    a = np.asarray(a, dtype="<u8").reshape(-1)
+    return sum(int(a[i]) << (64 * i) for i in range(4))
+
+
+def address_bytes(v):
+    return np.frombuffer(int(v).to_bytes(20, "little"), dtype="u1").copy()
+
+
+# ----------------------------------------------------------------------------------------
+# Backend
+# ----------------------------------------------------------------------------------------
+class ZkwError(RuntimeError):
+    pass
+
+
+class Backend:
+    def __init__(self, path, prefix):
+        if not os.path.exists(path):
+            raise ZkwError("shared library %s is missing — run __graft_entry__.build() (the product has no CPU fallback)" % path)
+        self.lib = C.CDLL(path)
+        self.prefix = prefix
+        self.path = path
+        self.ctx = C.c_void_p()
+        f = self.fn("last_error")
+        f.restype = C.c_char_p
+        f.argtypes = [C.c_void_p]
+
+    def fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def call(self, name, *args):
+        rc = self.fn(name)(*args)
+        if rc != OK:
+            msg = self.fn("last_error")(self.ctx if self.ctx else None)
+            raise ZkwError("%s%s -> %d: %s" % (self.prefix, name, rc, (msg or b"").decode()))
+        return rc
+
+    def open(self, isa, device=0):
+        self.call("ctx_create", C.c_int(device), C.byref(self.ctx))
+        self.call("ctx_set_isa", self.ctx, _ptr(isa.table))
+        return self
+
+    def close(self):
+        if self.ctx:
+            self.fn("ctx_destroy")(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def create_batch(self, workload):
+        return Batch(self, workload)
+
+
+def load_product():
+    """libzkw.so — the HIP library. Raises if it has not been built; never falls back."""
+    return Backend(_build.LIB, "zkw_")
+
+
+def load_oracle(native=False):
+    """TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py cpu_baseline)."""
+    path = _build.build_oracle(native=native)
+    return Backend(path, "zkwo_")
+
+
+class Batch:
+    """One staged + uploaded batch (see synth.Workload for the inputs)."""
+
+    def __init__(self, backend, wl):
+        self.be = backend
+        self.wl = wl
+        self.h = C.c_void_p()
+        limits = np.zeros(1, dtype=LIMITS)
+        for k, v in wl.limits.items():
+            limits[k] = v
+        self.limits = limits
+        be = backend
+        be.call("batch_create", be.ctx, C.c_uint32(wl.n_instances), _ptr(limits), C.byref(self.h))
+        blob_ids = []
+        for words in wl.blobs:
+            words = np.ascontiguousarray(words, dtype="<u8").reshape(-1, 4)
+            bid = C.c_uint32()
+            be.call("batch_add_code_blob", self.h, _ptr(words), C.c_uint32(len(words)), C.byref(bid))
+            blob_ids.append(bid.value)
+        self.blob_ids = blob_ids
+        for h, bi in wl.preimages:
+            hh = np.ascontiguousarray(h, dtype="<u8")
+            be.call("batch_add_decommit_preimage", self.h, _ptr(hh), C.c_uint32(blob_ids[bi]))
+        for first, count, page, bi in wl.code_pages:
+            be.call("batch_set_code_page", self.h, C.c_uint32(first), C.c_uint32(count), C.c_uint32(page), C.c_uint32(blob_ids[bi]))
+        states = np.ascontiguousarray(wl.states)
+        inner = np.ascontiguousarray(wl.inner)
+        assert states.dtype == VM_LOCAL_STATE and inner.dtype == CALLSTACK_ENTRY
+        depth = inner.shape[1] if inner.ndim == 2 else 0
+        be.call("batch_set_state", self.h, C.c_uint32(0), C.c_uint32(wl.n_instances), _ptr(states), _ptr(inner), C.c_uint32(depth))
+        if wl.heaps is not None:
+            heaps = np.ascontiguousarray(wl.heaps, dtype="<u8")  # [n, words, 4]
+            for i in range(wl.n_instances):
+                be.call("batch_set_heap", self.h, C.c_uint32(i), _ptr(heaps[i]), C.c_uint32(heaps.shape[1]))
+        if wl.storage is not None:
+            for i in range(wl.n_instances):
+                s = np.ascontiguousarray(wl.storage[i])
+                if len(s):
+                    assert s.dtype == STORAGE_SLOT
+                    be.call("batch_set_storage", self.h, C.c_uint32(i), _ptr(s), C.c_uint32(len(s)))
+        props = np.zeros(1, dtype=BLOCK_PROPERTIES)
+        props["default_aa_code_hash"][0] = wl.default_aa_code_hash
+        props["zkporter_is_available"] = wl.zkporter_is_available
+        be.call("batch_set_block_properties", self.h, _ptr(props))
+        be.call("batch_upload", self.h)
+
+    def reset(self, stream=None):
+        self.be.call("batch_reset", self.h, C.c_void_p(stream))
+
+    def run(self, max_cycles, stream=None):
+        self.be.call("batch_run", self.h, C.c_uint32(max_cycles), C.c_void_p(stream))
+
+    def sync(self):
+        self.be.call("batch_sync", self.h)
+
+    def stats(self):
+        st = np.zeros(1, dtype=RUN_STATS)
+        self.be.call("batch_get_stats", self.h, _ptr(st))
+        return st[0]
+
+    def trace(self, i):
+        t = InstanceTraceC()
+        self.be.call("batch_get_instance_trace", self.h, C.c_uint32(i), C.byref(t))
+        n = t.n_cycles
+        return {
+            "status": t.status,
+            "n_cycles": n,
+            "records": _from_ptr(t.records, n, CYCLE_RECORD),
+            "mem": _from_ptr(t.mem, t.n_mem, MEM_QUERY),
+            "log": _from_ptr(t.log, t.n_log, LOG_QUERY),
+            "aux": _from_ptr(t.aux, t.n_aux, AUX_EVENT),
+            "mem_off": _from_ptr(t.mem_off, n + 1, np.dtype("<u4")),
+            "log_off": _from_ptr(t.log_off, n + 1, np.dtype("<u4")),
+            "aux_off": _from_ptr(t.aux_off, n + 1, np.dtype("<u4")),
+            "final_state": np.frombuffer(bytes(t.final_state), dtype=VM_LOCAL_STATE, count=1).copy()[0],
+        }
+
+    def commitments(self):
+        out = np.zeros((self.wl.n_instances, QUEUE_COUNT, 4), dtype="<u8")
+        self.be.call("batch_get_commitments", self.h, _ptr(out))
+        return out
+
+    def destroy(self):
+        if self.h:
+            self.be.fn("batch_destroy")(self.h)
+            self.h = C.c_void_p()
+
+
+TRACE_ARRAYS = ("records", "mem", "log", "aux", "mem_off", "log_off", "aux_off")
+
+
+def traces_equal(a, b):
+    """Bit-exact comparison of two per-instance traces; returns (ok, first difference)."""
+    for k in ("status", "n_cycles"):
+        if a[k] != b[k]:
+            return False, "%s: %r != %r" % (k, a[k], b[k])
+    for k in TRACE_ARRAYS:
+        x, y = a[k], b[k]
+        if x.shape != y.shape:
+            return False, "%s: shape %r != %r" % (k, x.shape, y.shape)
+        if x.tobytes() != y.tobytes():
+            xb = np.frombuffer(x.tobytes(), dtype="u1").reshape(len(x), -1)
+            yb = np.frombuffer(y.tobytes(), dtype="u1").reshape(len(y), -1)
+            row = int(np.flatnonzero((xb != yb).any(axis=1))[0])
+            col = int(np.flatnonzero(xb[row] != yb[row])[0])
+            return False, "%s[%d] differs at byte %d: %r vs %r" % (k, row, col, x[row], y[row])
+    if a["final_state"].tobytes() != b["final_state"].tobytes():
+        return False, "final_state: %r vs %r" % (a["final_state"], b["final_state"])
+    return True, ""

@@ -1,0 +1,443 @@
+"""Synthetic workloads of SURVEY.md §8d / BASELINE.json `configs`.
+
+Every instance runs in kernel mode (`this_address = 0x8001`) so that fat-pointer metadata
+erasure (reference cycle.rs:381) and the privilege check (cycle.rs:174) never fire, starts with
+2^32-1 ergs, and shares one opcode tape; register files, heaps and storage are per instance.
+Randomness: xoshiro256** streams seeded from `0x5eed0000 + cfg` through splitmix64.
+
+  cfg 0   1 x 1024      alternating NOP / ADD r1,r2->r3                      (CPU plumbing)
+  cfg 1   256 x 256     ADD/SUB/MUL/DIV reg-reg, 1/64 DIV by r0, 50% set_flags, 1/8 predicated
+  cfg 2   4096 x 256    ALU + unaligned heap ld/st + stack operands + jumps + 2 far_call->ret
+                        pairs (2 fresh decommits of 512-word bytecodes) per instance
+"""
+import hashlib
+
+import numpy as np
+
+from . import capi as K
+
+M64 = (1 << 64) - 1
+
+
+# ----------------------------------------------------------------------------------------
+# xoshiro256** (vectorised over independent streams)
+# ----------------------------------------------------------------------------------------
+def _splitmix(x):
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        z = x
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return x, z
+
+
+class Xoshiro:
+    def __init__(self, seed, n_streams=1):
+        x = (np.uint64(seed) + np.arange(n_streams, dtype=np.uint64) * np.uint64(0xD1342543DE82EF95)).astype(np.uint64)
+        s = []
+        for _ in range(4):
+            x, z = _splitmix(x)
+            s.append(z)
+        self.s = s
+
+    def next(self):
+        s0, s1, s2, s3 = self.s
+        with np.errstate(over="ignore"):
+            r = s1 * np.uint64(5)
+            r = ((r << np.uint64(7)) | (r >> np.uint64(57))) * np.uint64(9)
+            t = s1 << np.uint64(17)
+            s2 = s2 ^ s0
+            s3 = s3 ^ s1
+            s1 = s1 ^ s2
+            s0 = s0 ^ s3
+            s2 = s2 ^ t
+            s3 = (s3 << np.uint64(45)) | (s3 >> np.uint64(19))
+        self.s = [s0, s1, s2, s3]
+        return r
+
+    def words(self, n_words):
+        """[n_streams, n_words, 4] u64"""
+        out = np.empty((len(self.s[0]), n_words, 4), dtype="<u8")
+        for w in range(n_words):
+            for l in range(4):
+                out[:, w, l] = self.next()
+        return out
+
+
+class ScalarRng:
+    def __init__(self, seed):
+        self.x = Xoshiro(seed, 1)
+
+    def u64(self):
+        return int(self.x.next()[0])
+
+    def below(self, n):
+        return self.u64() % n
+
+    def chance(self, num, den):
+        return self.below(den) < num
+
+
+# ----------------------------------------------------------------------------------------
+# workload container
+# ----------------------------------------------------------------------------------------
+class Workload:
+    def __init__(self, name, n_instances, n_cycles):
+        self.name = name
+        self.n_instances = n_instances
+        self.n_cycles = n_cycles
+        self.blobs = []       # list of [n_words, 4] u64
+        self.preimages = []   # (hash[4] u64, blob index)
+        self.code_pages = []  # (first, count, page, blob index)
+        self.states = None
+        self.inner = None
+        self.heaps = None     # [n, words, 4] u64
+        self.storage = None   # list of STORAGE_SLOT arrays
+        self.default_aa_code_hash = np.zeros(4, dtype="<u8")
+        self.zkporter_is_available = 0
+        self.limits = dict(max_cycles=n_cycles, max_far_frames=4, max_callstack_depth=8, stack_words=128, heap_words=512, aux_heap_words=64,
+                           storage_slots=16, storage_journal=16, max_mem_queries=0, max_log_queries=0, max_aux_events=0, lanes_per_wave=0)
+
+
+BOOTLOADER_BASE_PAGE = 8
+BOOTLOADER_CODE_PAGE = 8
+STARTING_TIMESTAMP = 1024
+KERNEL_ADDRESS = 0x8001
+
+
+def initial_states(n, registers, heap_bound=4096, ergs=0xFFFFFFFF, first_dynamic_page=16):
+    """VmLocalState right after `push_bootloader_context` (helpers.rs:289-316): callstack =
+    [empty_context (execution_stack.rs:35-55), bootloader frame]."""
+    st = np.zeros(n, dtype=K.VM_LOCAL_STATE)
+    st["registers"] = registers
+    st["timestamp"] = STARTING_TIMESTAMP
+    st["memory_page_counter"] = first_dynamic_page
+    st["callstack_depth"] = 1
+    cur = st["current"]
+    cur["this_address"] = K.address_bytes(KERNEL_ADDRESS)
+    cur["code_address"] = K.address_bytes(KERNEL_ADDRESS)
+    cur["base_memory_page"] = BOOTLOADER_BASE_PAGE
+    cur["code_page"] = BOOTLOADER_CODE_PAGE
+    cur["ergs_remaining"] = ergs
+    cur["heap_bound"] = heap_bound
+    cur["aux_heap_bound"] = heap_bound
+    inner = np.zeros((n, 1), dtype=K.CALLSTACK_ENTRY)
+    inner["ergs_remaining"] = 0xFFFFFFFF - ergs  # VM_INITIAL_FRAME_ERGS - passed
+    return st, inner
+
+
+# ----------------------------------------------------------------------------------------
+# cfg 0 / cfg 1
+# ----------------------------------------------------------------------------------------
+def config0(isa, n_cycles=1024, seed=0x5EED0000):
+    wl = Workload("cfg0_nop_add", 1, n_cycles)
+    ops = []
+    n_add = 0
+    for k in range(n_cycles):
+        if k % 2 == 0:
+            ops.append(isa.enc(K.OP_NOP))
+        else:
+            ops.append(isa.enc(K.OP_ADD, flags=n_add % 2, src0=1, src1=2, dst0=3))
+            n_add += 1
+    wl.blobs.append(K.pack_code(ops))
+    wl.code_pages.append((0, 1, BOOTLOADER_CODE_PAGE, 0))
+    regs = Xoshiro(seed, 1).words(15)
+    regs[:, 2:] = 0
+    wl.states, wl.inner = initial_states(1, regs)
+    return wl
+
+
+def arith_tape(isa, n_cycles, rng):
+    ops = []
+    for k in range(n_cycles):
+        which = rng.below(4)
+        set_flags = rng.below(2)
+        cond = (1 + rng.below(3)) if rng.chance(1, 8) else K.COND_ALWAYS
+        src0 = 1 + rng.below(15)
+        src1 = 1 + rng.below(15)
+        dst0 = 3 + (k % 13)
+        dst1 = 3 + rng.below(13)
+        if which == 0:
+            ops.append(isa.enc(K.OP_ADD, flags=set_flags, cond=cond, src0=src0, src1=src1, dst0=dst0))
+        elif which == 1:
+            ops.append(isa.enc(K.OP_SUB, flags=set_flags | (rng.below(2) << 1), cond=cond, src0=src0, src1=src1, dst0=dst0))
+        elif which == 2:
+            ops.append(isa.enc(K.OP_MUL, flags=set_flags, cond=cond, src0=src0, src1=src1, dst0=dst0, dst1=dst1))
+        else:
+            if rng.chance(1, 64):
+                src1 = 0  # divisor forced to r0 == 0
+            ops.append(isa.enc(K.OP_DIV, flags=set_flags, cond=cond, src0=src0, src1=src1, dst0=dst0, dst1=dst1))
+    return ops
+
+
+def config1(isa, n_instances=256, n_cycles=256, seed=0x5EED0001):
+    wl = Workload("cfg1_arith", n_instances, n_cycles)
+    ops = arith_tape(isa, n_cycles, ScalarRng(seed))
+    wl.blobs.append(K.pack_code(ops))
+    wl.code_pages.append((0, n_instances, BOOTLOADER_CODE_PAGE, 0))
+    regs = Xoshiro(seed ^ 0xABCDEF, n_instances).words(15)
+    # a quarter of the registers are short (64..192 bit) so that DIV sees non-trivial quotients
+    regs[:, 5::4, 3] = 0
+    regs[:, 6::4, 2:] = 0
+    wl.states, wl.inner = initial_states(n_instances, regs)
+    return wl
+
+
+# ----------------------------------------------------------------------------------------
+# cfg 2
+# ----------------------------------------------------------------------------------------
+CONST_BASE = 2000  # word index of the constant pool inside every code page
+HEAP_BYTES = 8192
+CALLEE_CODE_WORDS = 512
+ADDR_A, ADDR_B = 0x10001, 0x10002  # user-space callee addresses (>= 2^16)
+CALLEE_CYCLES = 16
+RELOAD_CYCLES = 14
+
+
+def versioned_code_hash(words):
+    """ContractCodeSha256 versioned hash (far_call.rs:169-252 consumes it): byte0 = 1,
+    byte1 = 0 (at rest), bytes 2-3 = length in words (BE), rest = sha256 tail."""
+    raw = words.astype(">u8")[:, ::-1].tobytes()  # 32-byte big-endian words
+    digest = hashlib.sha256(raw).digest()
+    be = bytes([1, 0, (len(words) >> 8) & 0xFF, len(words) & 0xFF]) + digest[4:]
+    return K.u256_from_int(int.from_bytes(be, "big"))
+
+
+def far_call_abi(start, length, ergs_passed, forwarding_mode=0):
+    v = (start << 64) | (length << 96) | (ergs_passed << 192) | (forwarding_mode << 224)
+    return K.u256_from_int(v)
+
+
+def ret_abi(start, length, forwarding_mode=0):
+    return K.u256_from_int((start << 64) | (length << 96) | (forwarding_mode << 224))
+
+
+class TapeBuilder:
+    """Emits a straight-line program and tracks the pc so that forward jumps can be placed."""
+
+    def __init__(self, isa, rng):
+        self.isa = isa
+        self.rng = rng
+        self.ops = []
+        self.executed = 0
+        self.sp = 0
+        self.k = 0
+
+    def emit(self, op):
+        self.ops.append(op)
+        self.executed += 1
+
+    def filler(self):
+        r = self.rng
+        return self.isa.enc(K.OP_ADD, src0=1 + r.below(12), src1=1 + r.below(12), dst0=3 + r.below(9))
+
+    def src(self):
+        return 1 + self.rng.below(12)
+
+    def dst(self):
+        self.k += 1
+        return 3 + (self.k % 9)  # r3..r11; r12 is the heap cursor
+
+    def alu(self):
+        r, isa = self.rng, self.isa
+        which = r.below(8)
+        sf = r.below(2)
+        a, b, d = self.src(), self.src(), self.dst()
+        if which == 0:
+            self.emit(isa.enc(K.OP_ADD, flags=sf, src0=a, src1=b, dst0=d))
+        elif which == 1:
+            self.emit(isa.enc(K.OP_SUB, flags=sf | (r.below(2) << 1), src0=a, src1=b, dst0=d))
+        elif which == 2:
+            self.emit(isa.enc(K.OP_MUL, flags=sf, src0=a, src1=b, dst0=d, dst1=3 + r.below(9)))
+        elif which == 3:
+            self.emit(isa.enc(K.OP_DIV, flags=sf | (r.below(2) << 1), src0=a, src1=b, dst0=d, dst1=3 + r.below(9)))
+        elif which == 4:
+            self.emit(isa.enc(K.OP_SHIFT, variant=r.below(4), flags=sf | (r.below(2) << 1), src0=a, src1=b, dst0=d))
+        elif which == 5:
+            self.emit(isa.enc(K.OP_BINOP, variant=r.below(3), flags=sf, src0=a, src1=b, dst0=d))
+        elif which == 6:  # constant from the code page (UseCodePage operand)
+            self.emit(isa.enc(K.OP_ADD, src0_mode=K.MODE_CODE, flags=sf, src0=0, imm0=CONST_BASE + 4 + r.below(4), src1=b, dst0=d))
+        else:  # 16-bit immediate operand
+            self.emit(isa.enc(K.OP_SUB, src0_mode=K.MODE_IMM, flags=sf, imm0=r.below(65536), src1=b, dst0=d))
+
+    def heap_offset(self):
+        r = self.rng
+        if r.below(2):
+            return 32 * r.below(HEAP_BYTES // 32)
+        return r.below(HEAP_BYTES)
+
+    def heap_ld(self):
+        r, isa = self.rng, self.isa
+        if r.chance(1, 4):  # register-addressed with post-increment: set the cursor, then load through it
+            self.emit(isa.enc(K.OP_UMA, variant=K.UMA_HEAP_READ, src0_mode=K.MODE_REG, flags=1, src0=12, dst0=self.dst(), dst1=12))
+        else:
+            self.emit(isa.enc(K.OP_UMA, variant=K.UMA_HEAP_READ, src0_mode=K.MODE_IMM, flags=0, imm0=self.heap_offset(), dst0=self.dst()))
+
+    def heap_st(self):
+        r, isa = self.rng, self.isa
+        if r.chance(1, 4):
+            self.emit(isa.enc(K.OP_UMA, variant=K.UMA_HEAP_WRITE, src0_mode=K.MODE_REG, flags=1, src0=12, src1=self.src(), dst0=12))
+        else:
+            self.emit(isa.enc(K.OP_UMA, variant=K.UMA_HEAP_WRITE, src0_mode=K.MODE_IMM, flags=0, imm0=self.heap_offset(), src1=self.src()))
+
+    def set_cursor(self):
+        # r12 := imm16 (heap cursor for the register-addressed UMA forms)
+        self.emit(self.isa.enc(K.OP_ADD, src0_mode=K.MODE_IMM, imm0=self.heap_offset() & 0x1FFF, src1=0, dst0=12))
+
+    def stack_op(self):
+        r, isa = self.rng, self.isa
+        choice = r.below(4)
+        if self.sp == 0 or choice == 0:  # push
+            self.emit(isa.enc(K.OP_ADD, dst0_mode=K.MODE_STACK_PP, src0=self.src(), src1=self.src(), dst0=0, imm1=1))
+            self.sp += 1
+        elif choice == 1:  # pop
+            self.emit(isa.enc(K.OP_ADD, src0_mode=K.MODE_STACK_PP, src0=0, imm0=1, src1=self.src(), dst0=self.dst()))
+            self.sp -= 1
+        elif choice == 2:  # sp-relative read
+            self.emit(isa.enc(K.OP_BINOP, variant=K.BINOP_XOR, src0_mode=K.MODE_STACK_OFF, src0=0, imm0=1 + r.below(self.sp), src1=self.src(), dst0=self.dst()))
+        else:  # absolute write
+            self.emit(isa.enc(K.OP_SUB, dst0_mode=K.MODE_STACK_ABS, src0=self.src(), src1=self.src(), dst0=0, imm1=r.below(self.sp)))
+
+    def jump(self):
+        skip = self.rng.below(4)
+        target = len(self.ops) + 1 + skip
+        self.emit(self.isa.enc(K.OP_JUMP, src0_mode=K.MODE_IMM, imm0=target))
+        for _ in range(skip):
+            self.ops.append(self.filler())  # never executed
+
+    def random_segment(self, n):
+        # 40% ALU, 20% heap ld, 20% heap st, 10% stack operands, 10% jumps
+        self.set_cursor()
+        for _ in range(n - 1):
+            x = self.rng.below(10)
+            if x < 4:
+                if self.rng.chance(1, 6):
+                    self.set_cursor()
+                else:
+                    self.alu()
+            elif x < 6:
+                self.heap_ld()
+            elif x < 8:
+                self.heap_st()
+            elif x < 9:
+                self.stack_op()
+            else:
+                self.jump()
+
+    def reload(self, abi_const, dest_const):
+        """After a far-call return every register but r1 is zero (ret.rs:213-233): refill r2..r11 from
+        the (per-instance) heap and r13/r14 from code constants. RELOAD_CYCLES ops."""
+        isa = self.isa
+        for d in range(2, 12):
+            self.emit(isa.enc(K.OP_UMA, variant=K.UMA_HEAP_READ, src0_mode=K.MODE_IMM, imm0=32 * (d * 7 % 200), dst0=d))
+        self.emit(isa.enc(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=CONST_BASE + abi_const, src1=0, dst0=13))
+        self.emit(isa.enc(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=CONST_BASE + dest_const, src1=0, dst0=14))
+        # read the first returndata word through the fat pointer in r1
+        self.emit(isa.enc(K.OP_UMA, variant=K.UMA_FAT_PTR_READ, flags=0, src0=1, dst0=12))
+        self.set_cursor()
+
+    def far_call(self, variant=K.FAR_NORMAL):
+        handler = len(self.ops) + 1  # exception handler = fall through
+        self.emit(self.isa.enc(K.OP_FAR_CALL, variant=variant, src0=13, src1=14, imm0=handler))
+
+
+def callee_program(isa, rng, ret_variant):
+    """CALLEE_CYCLES executed ops: calldata reads through the fat pointer, ALU, own-heap writes,
+    stack traffic, then ret with a 64-byte heap slice as returndata."""
+    ops = []
+    for d in (3, 4, 5):
+        ops.append(isa.enc(K.OP_UMA, variant=K.UMA_FAT_PTR_READ, flags=1, src0=1, dst0=d, dst1=1))
+    ops.append(isa.enc(K.OP_MUL, flags=1, src0=3, src1=4, dst0=6, dst1=7))
+    ops.append(isa.enc(K.OP_ADD, flags=0, src0=5, src1=6, dst0=8))
+    ops.append(isa.enc(K.OP_DIV, flags=1, src0=7, src1=5, dst0=9, dst1=10))
+    ops.append(isa.enc(K.OP_SHIFT, variant=K.SHIFT_ROL, flags=0, src0=8, src1=9, dst0=11))
+    ops.append(isa.enc(K.OP_BINOP, variant=K.BINOP_XOR, flags=1, src0=11, src1=3, dst0=12))
+    ops.append(isa.enc(K.OP_UMA, variant=K.UMA_HEAP_WRITE, src0_mode=K.MODE_IMM, imm0=0, src1=6))
+    ops.append(isa.enc(K.OP_UMA, variant=K.UMA_HEAP_WRITE, src0_mode=K.MODE_IMM, imm0=32, src1=8))
+    ops.append(isa.enc(K.OP_UMA, variant=K.UMA_HEAP_WRITE, src0_mode=K.MODE_IMM, imm0=40 + rng.below(16), src1=12))
+    ops.append(isa.enc(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=CONST_BASE + 0, src1=0, dst0=13))  # r13 := ret ABI
+    ops.append(isa.enc(K.OP_ADD, dst0_mode=K.MODE_STACK_PP, src0=9, src1=10, dst0=0, imm1=1))   # push
+    ops.append(isa.enc(K.OP_ADD, src0_mode=K.MODE_STACK_PP, src0=0, imm0=1, src1=11, dst0=14))  # pop
+    ops.append(isa.enc(K.OP_SUB, flags=1, src0=14, src1=12, dst0=15))
+    ops.append(isa.enc(K.OP_RET, variant=ret_variant, flags=0, src0=13))
+    assert len(ops) == CALLEE_CYCLES
+    return ops
+
+
+def config2(isa, n_instances=4096, n_cycles=256, seed=0x5EED0002):
+    assert n_cycles >= 2 * (1 + CALLEE_CYCLES + RELOAD_CYCLES) + 12
+    wl = Workload("cfg2_mixed", n_instances, n_cycles)
+    rng = ScalarRng(seed)
+    tb = TapeBuilder(isa, rng)
+    budget = n_cycles - 2 * (1 + CALLEE_CYCLES + RELOAD_CYCLES)
+    s1 = budget // 3
+    s2 = budget // 3
+    s3 = budget - s1 - s2
+    # bootloader constants: [0]=far-call ABI A, [1]=dest A, [2]=far-call ABI B, [3]=dest B, [4..8) random words
+    rnd = Xoshiro(seed ^ 0x77, 1).words(4)[0]
+    consts = [far_call_abi(64, 256, 100000), K.u256_from_int(ADDR_A), far_call_abi(512, 96, 50000), K.u256_from_int(ADDR_B), rnd[0], rnd[1], rnd[2], rnd[3]]
+    tb.random_segment(s1)
+    tb.far_call()
+    tb.executed += CALLEE_CYCLES
+    tb.reload(2, 3)
+    tb.random_segment(s2)
+    tb.far_call()
+    tb.executed += CALLEE_CYCLES
+    tb.reload(0, 1)
+    tb.random_segment(s3)
+    assert tb.executed == n_cycles, (tb.executed, n_cycles)
+    boot_words = np.zeros((CONST_BASE + len(consts), 4), dtype="<u8")
+    code = K.pack_code(tb.ops)
+    assert len(code) < CONST_BASE
+    boot_words[: len(code)] = code
+    for i, c in enumerate(consts):
+        boot_words[CONST_BASE + i] = c
+    wl.blobs.append(boot_words)
+    wl.code_pages.append((0, n_instances, BOOTLOADER_CODE_PAGE, 0))
+    # callee bytecodes: 512 words each, constant pool in the last words
+    callee_blobs = []
+    for which, retv in ((0, K.RET_OK), (1, K.RET_REVERT)):
+        ops = callee_program(isa, rng, retv)
+        words = np.zeros((CALLEE_CODE_WORDS, 4), dtype="<u8")
+        code = K.pack_code(ops)
+        words[: len(code)] = code
+        # filler so the preimage is not mostly zeros
+        fill = Xoshiro(seed ^ (0x1000 + which), 1).words(CALLEE_CODE_WORDS - 64)[0]
+        words[32 : 32 + len(fill)] = fill
+        words[CALLEE_CODE_WORDS - 8 :] = 0
+        callee_blobs.append((ops, words))
+    # the callee's `add code[CONST_BASE + 0]` must resolve inside its own 512-word page: index 2000 > 512 reads zero => ret ABI = empty slice.
+    # put the ret ABI where the callee looks for it by using a page-local constant index instead:
+    for which, (ops, words) in enumerate(callee_blobs):
+        local = CALLEE_CODE_WORDS - 8
+        ops[11] = isa.enc(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=local, src1=0, dst0=13)
+        code = K.pack_code(ops)
+        words[: len(code)] = code
+        words[local] = ret_abi(0, 64)
+        wl.blobs.append(words)
+        h = versioned_code_hash(words)
+        wl.preimages.append((h, 1 + which))
+    # storage: DEPLOYER[callee address] = versioned code hash
+    slots = np.zeros(2, dtype=K.STORAGE_SLOT)
+    for which, addr in enumerate((ADDR_A, ADDR_B)):
+        slots[which]["key"] = K.u256_from_int(addr)
+        slots[which]["value"] = wl.preimages[which][0]
+        slots[which]["address"] = K.address_bytes(0x8002)
+        slots[which]["shard_id"] = 0
+    wl.storage = [slots] * n_instances
+    regs = Xoshiro(seed ^ 0xABCDEF, n_instances).words(15)
+    regs[:, 5::4, 3] = 0
+    regs[:, 6::4, 2:] = 0
+    regs[:, 11] = 0  # r12 = heap cursor, set by the tape
+    regs[:, 12] = consts[0]  # r13 = far-call ABI A
+    regs[:, 13] = consts[1]  # r14 = dest A
+    regs[:, 14] = 0
+    wl.states, wl.inner = initial_states(n_instances, regs)
+    wl.heaps = Xoshiro(seed ^ 0x4EA9, n_instances).words(HEAP_BYTES // 32)
+    wl.limits.update(max_far_frames=3, heap_words=320, stack_words=128, aux_heap_words=8, storage_slots=8, storage_journal=4)
+    return wl
+
+
+def make(cfg, isa, **kw):
+    return {0: config0, 1: config1, 2: config2}[cfg](isa, **kw)

@@ -1,0 +1,446 @@
+/*
+ * zkw.h — C ABI of the MI355X-native out-of-circuit EraVM witness generator.
+ *
+ * This header is the drop-in boundary.  The reference crate
+ * (matter-labs/era-zk_evm, `zk_evm` v1.4.1) has no FFI of its own: its boundary is the
+ * Rust generic `VmState<S,M,EV,PP,DP,WT,N,E>` (reference src/vm_state/mod.rs:157-175)
+ * whose only entry point is `cycle()` (src/vm_state/cycle.rs:257-429).  A Rust shim that
+ * keeps that trait surface binds the functions below (INTEGRATION.md shows the stub);
+ * the C++ mirror in era-zk_evm_amd/host/ and the Python ctypes loader bind the same
+ * symbols.  Every struct here is plain-old-data, little-endian, naturally aligned.
+ *
+ * Data-model summary
+ *   U256            4 x u64 little-endian limbs (`.0[0]` lowest; mul.rs:36-39, uma.rs:337)
+ *   Address         20 bytes, little-endian integer (byte 0 = least significant); the
+ *                   Rust shim converts to/from H160 big-endian bytes
+ *   one batch     = N independent VM instances (each what the reference calls a VmState
+ *                   with its own Memory/Storage/Decommitter oracles, mod.rs:167-174)
+ *   one run       = every instance executes `cycle()` until execution_has_ended()
+ *                   (mod.rs:214-216) or max_cycles
+ *   output        = per instance: one 512-byte CycleRecord per executed cycle + three
+ *                   ordered query logs (memory / log / aux), which together carry exactly
+ *                   what the 10 VmWitnessTracer callbacks receive
+ *                   (src/witness_trace/mod.rs:11-72), in SURVEY Appendix-A order.
+ */
+#ifndef ZKW_H
+#define ZKW_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------ */
+/* Scalars                                                                               */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct zkw_u256 {
+  uint64_t l[4];
+} zkw_u256;
+
+#define ZKW_REGISTERS_COUNT 15 /* zkevm_opcode_defs::REGISTERS_COUNT; r0 is constant zero (helpers.rs:318-334) */
+
+/* return codes of every entry point */
+#define ZKW_OK 0
+#define ZKW_ERR_INVALID (-1)  /* bad argument / call order                           */
+#define ZKW_ERR_DEVICE (-2)   /* HIP runtime error (no GPU, OOM, launch failure)      */
+#define ZKW_ERR_LIMIT (-3)    /* a zkw_limits capacity was exceeded while staging     */
+#define ZKW_ERR_NOT_RUN (-4)  /* results requested before a run                       */
+
+/* per-instance status after a run (reference panics / Err map here) */
+#define ZKW_STATUS_RUNNING 0           /* stopped at max_cycles, execution not ended          */
+#define ZKW_STATUS_ENDED 1             /* callstack empty: execution_has_ended()              */
+#define ZKW_STATUS_UNKNOWN_CODE_HASH 2 /* decommitter.rs:54-56 -> cycle() returned Err       */
+#define ZKW_STATUS_REFERENCE_PANIC 3   /* an assert!/unwrap/expect of the reference would fire */
+#define ZKW_STATUS_LIMIT 4             /* a zkw_limits capacity was exceeded on device        */
+
+/* ------------------------------------------------------------------------------------ */
+/* ISA table (uploaded by the host)                        */
+/* ------------------------------------------------------------------------------------ */
+
+/* opcode families, order of zkevm_opcode_defs::Opcode / parsing.rs:61-78 */
+enum {
+  ZKW_OP_INVALID = 0,
+  ZKW_OP_NOP = 1,
+  ZKW_OP_ADD = 2,
+  ZKW_OP_SUB = 3,
+  ZKW_OP_MUL = 4,
+  ZKW_OP_DIV = 5,
+  ZKW_OP_JUMP = 6,
+  ZKW_OP_CONTEXT = 7,
+  ZKW_OP_SHIFT = 8,
+  ZKW_OP_BINOP = 9,
+  ZKW_OP_PTR = 10,
+  ZKW_OP_NEAR_CALL = 11,
+  ZKW_OP_LOG = 12,
+  ZKW_OP_FAR_CALL = 13,
+  ZKW_OP_RET = 14,
+  ZKW_OP_UMA = 15
+};
+
+/* inner variants */
+enum { ZKW_CTX_THIS = 0, ZKW_CTX_CALLER, ZKW_CTX_CODE_ADDRESS, ZKW_CTX_META, ZKW_CTX_ERGS_LEFT, ZKW_CTX_SP,
+       ZKW_CTX_GET_CONTEXT_U128, ZKW_CTX_SET_CONTEXT_U128, ZKW_CTX_SET_ERGS_PER_PUBDATA, ZKW_CTX_INC_TX_NUMBER };
+enum { ZKW_SHIFT_SHL = 0, ZKW_SHIFT_SHR, ZKW_SHIFT_ROL, ZKW_SHIFT_ROR };
+enum { ZKW_BINOP_XOR = 0, ZKW_BINOP_AND, ZKW_BINOP_OR };
+enum { ZKW_PTR_ADD = 0, ZKW_PTR_SUB, ZKW_PTR_PACK, ZKW_PTR_SHRINK };
+enum { ZKW_LOG_STORAGE_READ = 0, ZKW_LOG_STORAGE_WRITE, ZKW_LOG_TO_L1, ZKW_LOG_EVENT, ZKW_LOG_PRECOMPILE };
+enum { ZKW_FAR_NORMAL = 0, ZKW_FAR_DELEGATE, ZKW_FAR_MIMIC };
+enum { ZKW_RET_OK = 0, ZKW_RET_REVERT, ZKW_RET_PANIC };
+enum { ZKW_UMA_HEAP_READ = 0, ZKW_UMA_HEAP_WRITE, ZKW_UMA_AUX_READ, ZKW_UMA_AUX_WRITE, ZKW_UMA_FAT_PTR_READ };
+
+/* operand addressing modes = ImmMemHandlerFlags (mem_ops.rs:37-122) */
+enum {
+  ZKW_MODE_REG = 0,        /* RegOnly | Full(UseRegOnly) | RegOrImm(UseRegOnly) */
+  ZKW_MODE_STACK_PP = 1,   /* UseStackWithPushPop   */
+  ZKW_MODE_STACK_OFF = 2,  /* UseStackWithOffset    */
+  ZKW_MODE_STACK_ABS = 3,  /* UseAbsoluteOnStack    */
+  ZKW_MODE_IMM = 4,        /* UseImm16Only (src only) */
+  ZKW_MODE_CODE = 5        /* UseCodePage  (src only) */
+};
+
+/* zkw_isa_entry.props bits = the per-variant accessors cycle.rs uses */
+#define ZKW_PROP_EXPLICIT_PANIC 0x01  /* variant.is_explicit_panic()            cycle.rs:142 */
+#define ZKW_PROP_KERNEL_ONLY 0x02     /* variant.requires_kernel_mode()         cycle.rs:174 */
+#define ZKW_PROP_STATIC_OK 0x04       /* variant.can_be_used_in_static_context() cycle.rs:178 */
+#define ZKW_PROP_SWAP 0x08            /* variant.swap_operands()                cycle.rs:341 */
+#define ZKW_PROP_SRC0_PTR_OK 0x10     /* opcode.src0_can_be_pointer()           cycle.rs:375 */
+#define ZKW_PROP_SRC1_PTR_OK 0x20     /* opcode.src1_can_be_pointer()           cycle.rs:386 */
+
+typedef struct zkw_isa_entry {
+  uint8_t opcode;    /* ZKW_OP_*                         */
+  uint8_t variant;   /* inner variant of the family       */
+  uint8_t src0_mode; /* ZKW_MODE_*                        */
+  uint8_t dst0_mode; /* ZKW_MODE_REG..ZKW_MODE_STACK_ABS  */
+  uint8_t flags;     /* bit i = variant.flags[i]          */
+  uint8_t props;     /* ZKW_PROP_*                        */
+  uint16_t reserved;
+  uint32_t price;    /* OPCODES_PRICES[idx]  cycle.rs:147-148 */
+} zkw_isa_entry;
+
+#define ZKW_ISA_TABLE_SIZE 2048 /* 1 << OPCODES_TABLE_WIDTH (11) */
+
+/* scalar constants of zkevm_opcode_defs / zk_evm_abstractions the path reads (Appendix B) */
+typedef struct zkw_isa_consts {
+  uint64_t nop_encoding;              /* E::nop_encoding()               cycle.rs:126 */
+  uint64_t exception_revert_encoding; /* E::exception_revert_encoding()  cycle.rs:115 */
+  uint32_t panic_variant_idx;         /* variant DecodedOpcode::mask_into_panic() installs */
+  uint32_t nop_variant_idx;           /* variant DecodedOpcode::mask_into_nop() installs   */
+  uint32_t clip_mode;                 /* AllowedPcOrImm::from_u64_clipped: 0 = saturate at 0xffff, 1 = truncate */
+  uint32_t time_delta_per_cycle;      /* TIME_DELTA_PER_CYCLE (4)                mod.rs:233 */
+  uint32_t new_memory_pages_per_far_call; /* NEW_MEMORY_PAGES_PER_FAR_CALL (8)   mod.rs:239 */
+  uint32_t vm_max_stack_depth;        /* VM_MAX_STACK_DEPTH          execution_stack.rs:120 */
+  uint32_t initial_sp_on_far_call;    /* INITIAL_SP_ON_FAR_CALL (0)      far_call.rs:543    */
+  uint32_t new_frame_memory_stipend;  /* NEW_FRAME_MEMORY_STIPEND (4096) far_call.rs:553    */
+  uint32_t memory_growth_ergs_per_byte; /* MEMORY_GROWTH_ERGS_PER_BYTE (1) uma.rs:197       */
+  uint32_t ergs_per_code_word_decommittment; /* ERGS_PER_CODE_WORD_DECOMMITTMENT far_call.rs:424 */
+  uint32_t initial_storage_write_pubdata_bytes; /* log.rs:107 */
+  uint32_t l1_message_pubdata_bytes;  /* log.rs:123 */
+  uint32_t max_offset_to_deref_low;   /* uma::MAX_OFFSET_TO_DEREF = 2^32-33      uma.rs:127 */
+  uint32_t deployer_address_low;      /* DEPLOYER_SYSTEM_CONTRACT_ADDRESS (0x8002) far_call.rs:136 */
+  uint32_t keccak_precompile_address; /* 0x8010 */
+  uint32_t sha256_precompile_address; /* 0x02   */
+  uint32_t ecrecover_precompile_address; /* 0x01 */
+  uint8_t storage_aux_byte, event_aux_byte, l1_message_aux_byte, precompile_aux_byte; /* log.rs:6-8 */
+  uint32_t reserved[8];
+} zkw_isa_consts;
+
+typedef struct zkw_isa_table {
+  zkw_isa_entry entries[ZKW_ISA_TABLE_SIZE];
+  zkw_isa_consts consts;
+} zkw_isa_table;
+
+/* ------------------------------------------------------------------------------------ */
+/* VM state (input: initial state; output: final state)                                  */
+/* ------------------------------------------------------------------------------------ */
+
+/* CallStackEntry, execution_stack.rs:6-24 */
+typedef struct zkw_callstack_entry {
+  uint8_t this_address[20];
+  uint8_t msg_sender[20];
+  uint8_t code_address[20];
+  uint32_t base_memory_page;
+  uint32_t code_page;
+  uint16_t sp;
+  uint16_t pc;
+  uint16_t exception_handler_location;
+  uint8_t is_static;
+  uint8_t is_local_frame;
+  uint32_t ergs_remaining;
+  uint8_t this_shard_id;
+  uint8_t caller_shard_id;
+  uint8_t code_shard_id;
+  uint8_t reserved0;
+  uint32_t reserved1;
+  uint64_t context_u128_value[2]; /* little-endian u128 */
+  uint32_t heap_bound;
+  uint32_t aux_heap_bound;
+} zkw_callstack_entry; /* 112 bytes */
+
+/* VmLocalState, mod.rs:54-73 (callstack.inner passed separately) */
+typedef struct zkw_vm_local_state {
+  zkw_u256 previous_code_word;
+  zkw_u256 registers[ZKW_REGISTERS_COUNT];
+  uint16_t register_ptr_bitmap; /* bit i = registers[i].is_pointer */
+  uint8_t flags;                /* bit0 overflow_or_less_than, bit1 equality, bit2 greater_than (flags.rs:4-8) */
+  uint8_t pending_exception;
+  uint32_t previous_code_memory_page;
+  uint32_t timestamp;
+  uint32_t monotonic_cycle_counter;
+  uint32_t spent_pubdata_counter;
+  uint32_t memory_page_counter;
+  uint32_t absolute_execution_step;
+  uint32_t current_ergs_per_pubdata_byte;
+  uint16_t tx_number_in_block;
+  uint16_t previous_super_pc;
+  uint32_t callstack_depth; /* callstack.inner.len(); 0 => execution_has_ended() */
+  uint64_t context_u128_register[2];
+  zkw_callstack_entry current; /* callstack.current */
+} zkw_vm_local_state; /* 512 + 4 + 28 + 4 + 4 + 16 + 112 = 680 bytes */
+
+/* BlockProperties, block_properties/mod.rs:4-7 */
+typedef struct zkw_block_properties {
+  zkw_u256 default_aa_code_hash;
+  uint32_t zkporter_is_available;
+  uint32_t reserved0;
+} zkw_block_properties;
+
+/* one pre-populated storage slot, testing/storage.rs:25-31 `populate` */
+typedef struct zkw_storage_slot {
+  zkw_u256 key;
+  zkw_u256 value;
+  uint8_t address[20];
+  uint8_t shard_id;
+  uint8_t reserved0[3];
+} zkw_storage_slot; /* 88 bytes */
+
+/* capacities of one batch; every per-instance arena is sized from these */
+typedef struct zkw_limits {
+  uint32_t max_cycles;            /* cycles recorded per instance and per run                      */
+  uint32_t max_far_frames;        /* far-call frames (incl. the bootloader frame) opened per run   */
+  uint32_t max_callstack_depth;   /* near + far frames alive at once                                */
+  uint32_t stack_words;           /* words per stack page   (reference: 65536, memory.rs:177-179)  */
+  uint32_t heap_words;            /* words per heap page    (reference: grows on demand)            */
+  uint32_t aux_heap_words;        /* words per aux-heap page                                        */
+  uint32_t storage_slots;         /* distinct (shard,address,key) per instance, power of two        */
+  uint32_t storage_journal;       /* storage writes per instance and per run                        */
+  uint32_t max_mem_queries;       /* MemoryQuery records per instance and per run; 0 = 6*max_cycles */
+  uint32_t max_log_queries;       /* LogQuery records per instance and per run; 0 = 2*max_cycles    */
+  uint32_t max_aux_events;        /* aux events per instance and per run; 0 = derived               */
+  uint32_t lanes_per_wave;        /* 0 = let the library choose (1..64, power of two)               */
+  uint32_t reserved[4];
+} zkw_limits;
+
+/* ------------------------------------------------------------------------------------ */
+/* Witness trace records (output)                                                        */
+/* ------------------------------------------------------------------------------------ */
+
+/* CycleRecord: the state after `end_execution_cycle` of one cycle (cycle.rs:413); the state
+ * before cycle k is the record of cycle k-1 (or the initial state).  512 bytes:
+ *   [0,480)   registers[15] values
+ *   [480,512) zkw_cycle_tail
+ * Everything else of VmLocalState is either constant inside a frame (restored from the
+ * FRAME_START/FRAME_FINISH aux events), derivable (monotonic_cycle_counter = initial + k + 1,
+ * previous_code_word = value of the cycle's code read, previous_code_memory_page = code page
+ * current at cycle start) or rare (COLD_STATE aux event). */
+typedef struct zkw_cycle_tail {
+  uint16_t register_ptr_bitmap;
+  uint8_t flags;  /* bits 0..2 = lt,eq,gt; bit 3 = pending_exception */
+  uint8_t reserved0;
+  uint16_t pc;    /* current frame after the cycle */
+  uint16_t sp;
+  uint32_t ergs_remaining;
+  uint32_t timestamp;
+  uint32_t heap_bound;
+  uint32_t aux_heap_bound;
+  uint16_t callstack_depth;
+  uint16_t previous_super_pc;
+  uint32_t event_counts; /* bits 0-7 mem queries, 8-15 log records, 16-23 aux events emitted this cycle (saturating) */
+} zkw_cycle_tail; /* 32 bytes */
+
+typedef struct zkw_cycle_record {
+  zkw_u256 registers[ZKW_REGISTERS_COUNT];
+  zkw_cycle_tail tail;
+} zkw_cycle_record; /* 512 bytes */
+
+/* MemoryType (zk_evm_abstractions::vm::MemoryType) */
+enum { ZKW_MEM_STACK = 0, ZKW_MEM_CODE = 1, ZKW_MEM_HEAP = 2, ZKW_MEM_AUX_HEAP = 3, ZKW_MEM_FAT_PTR = 4 };
+
+/* zkw_mem_query.meta bits */
+#define ZKW_MQ_TYPE_MASK 0x07 /* ZKW_MEM_*                                             */
+#define ZKW_MQ_IS_PTR 0x08    /* value_is_pointer                                      */
+#define ZKW_MQ_RW 0x10        /* rw_flag (1 = write)                                   */
+#define ZKW_MQ_KIND_SHIFT 5   /* 0 = add_memory_query; 1 = precompile read; 2 = precompile write */
+
+/* MemoryQuery {timestamp, location{memory_type,page,index}, value, value_is_pointer, rw_flag}
+ * (field set pinned by helpers.rs:26-32) */
+typedef struct zkw_mem_query {
+  uint32_t timestamp;
+  uint32_t page;
+  uint32_t index;
+  uint8_t lane; /* device stream only: lane of the owning instance inside its wave; 0 in per-instance views */
+  uint8_t seq;  /* order of this record among all records of its instance in its cycle (saturates at 255) */
+  uint8_t meta;
+  uint8_t reserved0;
+  zkw_u256 value;
+} zkw_mem_query; /* 48 bytes */
+
+/* zkw_log_query.kind */
+enum {
+  ZKW_LQ_LOG = 0,    /* WT.add_log_query                                      */
+  ZKW_LQ_REFUND = 1  /* WT.record_refund_for_query (log.rs:99-102); refund in `refund_*` */
+};
+#define ZKW_LQ_RW 0x01
+#define ZKW_LQ_ROLLBACK 0x02
+#define ZKW_LQ_IS_SERVICE 0x04
+
+/* LogQuery (field set pinned by log.rs:85-97) */
+typedef struct zkw_log_query {
+  zkw_u256 key;
+  zkw_u256 read_value;
+  zkw_u256 written_value;
+  uint8_t address[20];
+  uint32_t timestamp;
+  uint16_t tx_number_in_block;
+  uint8_t aux_byte;
+  uint8_t shard_id;
+  uint8_t bools; /* ZKW_LQ_RW | ZKW_LQ_ROLLBACK | ZKW_LQ_IS_SERVICE */
+  uint8_t kind;  /* ZKW_LQ_* */
+  uint8_t lane;
+  uint8_t seq;
+} zkw_log_query; /* 128 bytes */
+
+/* aux events */
+enum {
+  ZKW_AUX_FRAME_START = 1,  /* WT.start_new_execution_context(cc, &prev, &new)  helpers.rs:237-241 */
+  ZKW_AUX_FRAME_FINISH = 2, /* WT.finish_execution_context(cc, panicked)        helpers.rs:258-259 */
+  ZKW_AUX_DECOMMIT = 3,     /* DP.decommit_into_memory result (+ WT.add_decommittment) helpers.rs:164-194 */
+  ZKW_AUX_COLD_STATE = 4    /* rare VmLocalState fields after this cycle                            */
+};
+
+typedef struct zkw_aux_event {
+  uint8_t type; /* ZKW_AUX_* */
+  uint8_t lane;
+  uint8_t seq;
+  uint8_t flag; /* FRAME_START: 1 = far call; FRAME_FINISH: panicked; DECOMMIT: is_fresh */
+  uint32_t a;   /* DECOMMIT: timestamp;   COLD_STATE: spent_pubdata_counter          */
+  uint32_t b;   /* DECOMMIT: memory_page; COLD_STATE: current_ergs_per_pubdata_byte  */
+  uint32_t c;   /* DECOMMIT: decommitted_length | code blob id << 16; COLD_STATE: tx_number_in_block */
+  union {
+    struct {
+      zkw_callstack_entry previous; /* callstack.current at the call, i.e. what gets pushed */
+      zkw_callstack_entry next;
+    } frame;                         /* FRAME_START  */
+    zkw_u256 hash;                   /* DECOMMIT     */
+    struct {
+      uint64_t context_u128_register[2];
+      uint32_t memory_page_counter;
+    } cold;                          /* COLD_STATE   */
+    uint8_t raw[240];
+  } u;
+} zkw_aux_event; /* 256 bytes */
+
+/* per-instance view of a finished run; arrays are library-owned, valid until the next
+ * run/reset/destroy of the batch.  `*_off[k]..*_off[k+1]` are the records of cycle k. */
+typedef struct zkw_instance_trace {
+  uint32_t status;   /* ZKW_STATUS_* */
+  uint32_t n_cycles; /* executed cycles */
+  uint32_t n_mem, n_log, n_aux;
+  uint32_t reserved0;
+  const zkw_cycle_record* records; /* [n_cycles] */
+  const zkw_mem_query* mem;        /* [n_mem] */
+  const zkw_log_query* log;        /* [n_log] */
+  const zkw_aux_event* aux;        /* [n_aux] */
+  const uint32_t* mem_off;         /* [n_cycles + 1] */
+  const uint32_t* log_off;         /* [n_cycles + 1] */
+  const uint32_t* aux_off;         /* [n_cycles + 1] */
+  zkw_vm_local_state final_state;  /* VmLocalState after the last executed cycle */
+} zkw_instance_trace;
+
+/* aggregate counters of a run (also the payload of the multi-GPU all-reduce) */
+typedef struct zkw_run_stats {
+  uint64_t cycles;      /* sum over instances of executed cycles */
+  uint64_t mem_queries;
+  uint64_t log_queries;
+  uint64_t aux_events;
+  uint64_t instances_ended;
+  uint64_t instances_failed; /* status >= ZKW_STATUS_UNKNOWN_CODE_HASH */
+  double kernel_ms;     /* device time of the last run's cycle kernel (HIP events on the run stream) */
+  double reserved0;
+} zkw_run_stats;
+
+/* ------------------------------------------------------------------------------------ */
+/* Entry points                                                                          */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct zkw_ctx zkw_ctx;     /* one per (thread, GPU); not thread-safe */
+typedef struct zkw_batch zkw_batch; /* N instances + their arenas + output streams */
+
+/* Fills `out` with the build's recollection of zkevm_opcode_defs v1.4.1 (UNVERIFIED, the
+ * crate is not on disk — SURVEY Appendix B).  A Rust shim overrides it with the real
+ * OPCODES_TABLE / OPCODES_PRICES.  Host-only, needs no GPU. */
+int zkw_isa_default(zkw_isa_table* out);
+/* Encodes one instruction in EncodingModeProduction layout (bits 0-10 variant, 13-15
+ * condition, 16-31 src0|src1|dst0|dst1, 32-47 imm0, 48-63 imm1). Host-only. */
+uint64_t zkw_isa_encode(uint32_t variant_idx, uint32_t condition, uint32_t src0, uint32_t src1, uint32_t dst0,
+                        uint32_t dst1, uint32_t imm0, uint32_t imm1);
+/* Finds the variant index of (opcode, variant, src0_mode, dst0_mode, flags); -1 if absent. Host-only. */
+int32_t zkw_isa_find(const zkw_isa_table* t, uint32_t opcode, uint32_t variant, uint32_t src0_mode, uint32_t dst0_mode,
+                     uint32_t flags);
+
+int zkw_ctx_create(int device, zkw_ctx** out);
+void zkw_ctx_destroy(zkw_ctx* ctx);
+const char* zkw_last_error(zkw_ctx* ctx); /* ctx may be NULL: last error of a failed zkw_ctx_create */
+int zkw_ctx_set_isa(zkw_ctx* ctx, const zkw_isa_table* table); /* copies */
+
+int zkw_batch_create(zkw_ctx* ctx, uint32_t n_instances, const zkw_limits* limits, zkw_batch** out);
+void zkw_batch_destroy(zkw_batch* batch);
+
+/* --- staging of the initial oracle state (caller-owned inputs are copied) --- */
+
+/* registers bytecode words (reference: SimpleMemory::populate_code memory.rs:271-284 /
+ * SimpleDecommitter::populate decommitter.rs:23-28); shared by all instances */
+int zkw_batch_add_code_blob(zkw_batch* batch, const zkw_u256* words, uint32_t n_words, uint32_t* blob_id);
+/* known_hashes[hash] = blob (decommitter.rs:23-28) */
+int zkw_batch_add_decommit_preimage(zkw_batch* batch, const zkw_u256* hash, uint32_t blob_id);
+/* code_pages[page] = blob for instances [first, first+count) (memory.rs:271-284) */
+int zkw_batch_set_code_page(zkw_batch* batch, uint32_t first, uint32_t count, uint32_t page, uint32_t blob_id);
+/* VmLocalState + callstack.inner (inner_depth entries per instance, oldest first) for
+ * instances [first, first+count).  Mirrors VmState::empty_state + push_bootloader_context
+ * (mod.rs:188-207, helpers.rs:289-316) having been called by the host. */
+int zkw_batch_set_state(zkw_batch* batch, uint32_t first, uint32_t count, const zkw_vm_local_state* states,
+                        const zkw_callstack_entry* inner, uint32_t inner_depth);
+/* heap of the current (bootloader) frame (memory.rs:287-291 populate_heap) */
+int zkw_batch_set_heap(zkw_batch* batch, uint32_t instance, const zkw_u256* words, uint32_t n_words);
+/* storage snapshot (testing/storage.rs:25-31) */
+int zkw_batch_set_storage(zkw_batch* batch, uint32_t instance, const zkw_storage_slot* slots, uint32_t n_slots);
+int zkw_batch_set_block_properties(zkw_batch* batch, const zkw_block_properties* props);
+
+/* uploads everything staged so far; afterwards zkw_batch_reset restores it on device */
+int zkw_batch_upload(zkw_batch* batch);
+/* working state := staged initial state (device-side copy, async on `stream`; NULL = default stream) */
+int zkw_batch_reset(zkw_batch* batch, void* hip_stream);
+/* every instance cycles until ended or `max_cycles` more cycles (<= limits.max_cycles);
+ * async on `stream` (hipStream_t; NULL = default stream) */
+int zkw_batch_run(zkw_batch* batch, uint32_t max_cycles, void* hip_stream);
+/* waits for the run, downloads the streams and builds the per-instance views */
+int zkw_batch_sync(zkw_batch* batch);
+int zkw_batch_get_stats(zkw_batch* batch, zkw_run_stats* out);
+int zkw_batch_get_instance_trace(zkw_batch* batch, uint32_t instance, zkw_instance_trace* out);
+
+/* --- queue commitments (the build's own sponge spec) --- */
+#define ZKW_QUEUE_MEMORY 0
+#define ZKW_QUEUE_LOG 1
+#define ZKW_QUEUE_DECOMMIT 2
+#define ZKW_QUEUE_COUNT 3
+/* digests[instance][queue] : 4 x u64 Goldilocks elements each, computed on device from the
+ * streams of the last run; `out` holds n_instances * ZKW_QUEUE_COUNT * 4 u64 */
+int zkw_batch_get_commitments(zkw_batch* batch, uint64_t* out);
+/* device pointer (n_instances * ZKW_QUEUE_COUNT * 4 u64) for the RCCL all-gather */
+int zkw_batch_commitments_device_ptr(zkw_batch* batch, void** dptr, uint64_t* n_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKW_H */

@@ -1,0 +1,137 @@
+"""Pins the oracle's precompile restatement against the reference's own tests.
+
+keccak256: the 8 live tests of reference src/testing/tests/precompiles/keccak256.rs:144-196 —
+inputs 0/50/136/200 bytes of 0x7b, unalignment 0 and 31, output read back from word
+`num_words_used` of the output page (:103-111,132-139).  The reference computes the expected
+digest with `sha3::Keccak256`; here the literals are the SURVEY Appendix C values, cross-checked
+against an independent Keccak (hashlib.sha3_256 differs only in the pad byte) below.
+sha256: inputs of the stale reference tests (sha256.rs:119-136) vs hashlib.
+"""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+from era_zk_evm_amd import capi as K
+
+KECCAK_KATS = {
+    0: "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470",
+    50: "c6205629f21bc9e31b3591e9c660d74748d5eae00835de09fdc68dc0f460cd45",
+    136: "400b2d67c65e3292bcad1e49b0c58e81edba99aa5f48940500373ec622dfdf2f",
+    200: "a053e7bae2b11f67ec3dce2f383a8965397413683e7dccb7028820b4851fe522",
+}
+
+
+def bytes_to_words(data, unalignment):
+    """keccak256.rs:10-37 bytes_to_u256_words"""
+    raw = b"\xff" * unalignment + data
+    words = []
+    for i in range(0, len(raw), 32):
+        chunk = raw[i:i + 32].ljust(32, b"\0")
+        words.append(K.u256_from_int(int.from_bytes(chunk, "big")))
+    return np.array(words, dtype="<u8").reshape(-1, 4)
+
+
+def abi_key(in_off, in_len, out_off, out_len, page_r, page_w, extra=0):
+    return K.u256_from_int(in_off | (in_len << 32) | (out_off << 64) | (out_len << 96) | (page_r << 128) | (page_w << 160) | (extra << 192))
+
+
+def run_precompile(lib, which, words, key, out_index, page=4):
+    out = np.zeros(4, dtype="<u8")
+    nr, nw = C.c_uint32(), C.c_uint32()
+    words = np.ascontiguousarray(words, dtype="<u8")
+    rc = lib.zkwo_precompile_test(C.c_int(which), C.c_uint32(page), words.ctypes.data_as(C.c_void_p), C.c_uint32(len(words)),
+                                  key.ctypes.data_as(C.c_void_p), C.c_uint32(out_index), out.ctypes.data_as(C.c_void_p), C.byref(nr), C.byref(nw))
+    assert rc == 0
+    return K.u256_to_int(out).to_bytes(32, "big"), nr.value, nw.value
+
+
+@pytest.mark.parametrize("length", [0, 50, 136, 200])
+@pytest.mark.parametrize("unalignment", [0, 31])
+def test_keccak256_reference_tests(oracle, length, unalignment):
+    data = bytes([123]) * length
+    words = bytes_to_words(data, unalignment)
+    n_words = len(words)
+    key = abi_key(unalignment, length, n_words, 0, 4, 4)
+    digest, n_reads, n_writes = run_precompile(oracle.lib, 0, words, key, n_words)
+    assert digest.hex() == KECCAK_KATS[length]
+    first, last = unalignment // 32, (unalignment + length + 31) // 32
+    assert n_reads == (last - first if length else 0) and n_writes == 1
+
+
+def _keccak256_py(data):
+    """independent Keccak-256 (pad 0x01) built on the same permutation hashlib.sha3_256 uses"""
+    RC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808A, 0x8000000080008000, 0x000000000000808B, 0x0000000080000001, 0x8000000080008081,
+          0x8000000000008009, 0x000000000000008A, 0x0000000000000088, 0x0000000080008009, 0x000000008000000A, 0x000000008000808B, 0x800000000000008B,
+          0x8000000000008089, 0x8000000000008003, 0x8000000000008002, 0x8000000000000080, 0x000000000000800A, 0x800000008000000A, 0x8000000080008081,
+          0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
+    R = [[0, 36, 3, 41, 18], [1, 44, 10, 45, 2], [62, 6, 43, 15, 61], [28, 55, 25, 21, 56], [27, 20, 39, 8, 14]]
+    M64 = (1 << 64) - 1
+    rol = lambda x, n: ((x << n) | (x >> (64 - n))) & M64 if n else x
+
+    def f(A):
+        for rc in RC:
+            Cc = [A[x][0] ^ A[x][1] ^ A[x][2] ^ A[x][3] ^ A[x][4] for x in range(5)]
+            D = [Cc[(x - 1) % 5] ^ rol(Cc[(x + 1) % 5], 1) for x in range(5)]
+            A = [[A[x][y] ^ D[x] for y in range(5)] for x in range(5)]
+            B = [[0] * 5 for _ in range(5)]
+            for x in range(5):
+                for y in range(5):
+                    B[y][(2 * x + 3 * y) % 5] = rol(A[x][y], R[x][y])
+            A = [[B[x][y] ^ ((~B[(x + 1) % 5][y]) & B[(x + 2) % 5][y]) for y in range(5)] for x in range(5)]
+            A[0][0] ^= rc
+        return A
+
+    def run(pad):
+        msg = bytearray(data)
+        msg.append(pad)
+        while len(msg) % 136:
+            msg.append(0)
+        msg[-1] |= 0x80
+        A = [[0] * 5 for _ in range(5)]
+        for off in range(0, len(msg), 136):
+            for i in range(17):
+                A[i % 5][i // 5] ^= int.from_bytes(msg[off + 8 * i: off + 8 * i + 8], "little")
+            A = f(A)
+        return b"".join(A[i % 5][i // 5].to_bytes(8, "little") for i in range(4))
+
+    assert run(0x06) == hashlib.sha3_256(data).digest()  # ties the permutation to hashlib
+    return run(0x01)
+
+
+def test_keccak_kats_match_independent_keccak():
+    for length, hexd in KECCAK_KATS.items():
+        assert _keccak256_py(bytes([123]) * length).hex() == hexd
+
+
+@pytest.mark.parametrize("length,unalignment", [(1, 0), (31, 1), (32, 0), (33, 17), (135, 5), (137, 31), (271, 13), (272, 0), (1000, 29), (136 * 8, 31)])
+def test_keccak256_more_lengths(oracle, length, unalignment):
+    data = bytes((7 * i + 3) & 0xFF for i in range(length))
+    words = bytes_to_words(data, unalignment)
+    key = abi_key(unalignment, length, len(words), 0, 4, 4)
+    digest, _, _ = run_precompile(oracle.lib, 0, words, key, len(words))
+    assert digest == _keccak256_py(data)
+
+
+def sha256_pad(data):
+    """sha256.rs:5-69 pad_and_fill_memory (the caller pads; the precompile only compresses)"""
+    padded = bytearray(data) + b"\x80"
+    while len(padded) % 64 != 56:
+        padded.append(0)
+    padded += (8 * len(data)).to_bytes(8, "big")
+    return bytes(padded)
+
+
+@pytest.mark.parametrize("data", [b"", b"\xff" * 256, b"\xff" * 10000], ids=["empty", "ff256", "ff10000"])
+def test_sha256_stale_reference_inputs(oracle, data):
+    padded = sha256_pad(data)
+    words = bytes_to_words(padded, 0)
+    rounds = len(padded) // 64
+    n = len(words)
+    if n + 1 > 1024:
+        pytest.skip("reference harness page is 1024 words")
+    key = abi_key(0, 0, n, 0, 4, 4, extra=rounds)
+    digest, n_reads, n_writes = run_precompile(oracle.lib, 1, words, key, n)
+    assert digest == hashlib.sha256(data).digest()
+    assert n_reads == 2 * rounds and n_writes == 1
