@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""bench.py — witnessed VM cycles/sec on the 1M-cycle synthetic batch (BASELINE.json configs[2]).
+
+One "step" = one pass of the hot path (zkw_batch_run: every instance replays its opcode tape and
+emits its witness trace) over one batch whose inputs are already resident in HBM.  Each step runs on
+its own freshly reset batch state (reset = device-side restore of the pristine images, outside the
+step).  Prints ONE JSON line (contract in the task description) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--instances", type=int, default=4096, help="VM instances per GPU (weak scaling)")
+    ap.add_argument("--cycles", type=int, default=256)
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per wave (0 = library default)")
+    ap.add_argument("--cfg", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from era_zk_evm_amd import capi as K, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    isa = K.Isa()
+    prod = K.load_product().open(isa, device=local_rank)
+    # shard: every rank owns `instances` independent VM instances (different seeds), no data-path collective
+    wl = synth.make(args.cfg, isa, n_instances=args.instances, n_cycles=args.cycles, seed=0x5EED0000 + args.cfg + 0x100 * rank)
+    wl.limits["lanes_per_wave"] = args.lanes
+    batch = prod.create_batch(wl)
+    stream = torch.cuda.Stream(device=local_rank)
+    sptr = stream.cuda_stream
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.reset(sptr)
+        batch.run(wl.n_cycles, sptr)
+        batch.sync()
+    # timed region: K steps; resets are queued between steps on the same stream (they restore the inputs
+    # for the next step and are charged to the wall clock, not to the kernel's own HIP-event time)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.reset(sptr)
+        batch.run(wl.n_cycles, sptr)
+    batch.sync()  # one host sync for all K steps; per-run HIP event pairs give the kernel's own mean time
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st = batch.stats()
+    cycles_per_step = int(st["cycles"])
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    c = torch.tensor([float(cycles_per_step)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    total_cycles_per_step = float(c.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = total_cycles_per_step * args.steps / elapsed
+        # roofline: algorithmic bytes per cycle x cycles of one launch / kernel time
+        n_mem = float(st["mem_queries"]) / max(1, cycles_per_step)
+        n_log = float(st["log_queries"]) / max(1, cycles_per_step)
+        heap_words = 0.9 if args.cfg == 2 else 0.0
+        b_cycle = 8 + 512 + 48 * n_mem + 128 * n_log + 32 * heap_words
+        k_ms = float(st["kernel_ms"])  # mean over the K timed launches (HIP events on the run stream)
+        achieved = b_cycle * cycles_per_step / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "witnessed VM cycles/sec (1M-cycle synthetic batch)",
+            "value": value, "unit": "cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u256 (8 x u32 limbs)", "data": "synthetic",
+            "config": {"workload": "cfg%d: %d instances x %d cycles per GPU (%s)" % (args.cfg, args.instances, args.cycles, wl.name),
+                       "instances_per_gpu": args.instances, "cycles_per_instance": args.cycles, "lanes_per_wave": int(batch.limits["lanes_per_wave"][0])},
+            "kernel_ms": k_ms,
+            "kernel_cycles_per_s": cycles_per_step / (k_ms * 1e-3),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "bytes_per_cycle": b_cycle},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(isa, args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(isa, args):
+    """The oracle (C++ restatement of zk_evm v1.4.1 cycle(), -O3 -march=native) timed on this box's
+    host cores on a bounded sample of the same workload."""
+    from era_zk_evm_amd import capi as K, synth
+    import ctypes as C
+
+    cores = os.cpu_count() or 1
+    orc = K.load_oracle(native=True).open(isa)
+    n = 1024
+    wl = synth.make(args.cfg, isa, n_instances=n, n_cycles=args.cycles)
+    b = orc.create_batch(wl)
+    res = {}
+    for label, threads in (("1", 1), ("all", cores)):
+        orc.lib.zkwo_batch_set_threads(b.h, C.c_uint32(threads))
+        best = None
+        reps = 0
+        t_start = time.perf_counter()
+        while reps < 3 or time.perf_counter() - t_start < 4.0:
+            b.reset()
+            b.run(wl.n_cycles)
+            ms = float(b.stats()["kernel_ms"])
+            best = ms if best is None else min(best, ms)
+            reps += 1
+            if reps >= 50:
+                break
+        res[label] = n * wl.n_cycles / (best * 1e-3)
+    return {"value": res["all"], "unit": "cycles/s", "cores": cores, "kind": "port", "single_core_value": res["1"],
+            "sample": "%d instances x %d cycles of the same cfg-%d tape, best of repeated runs, one instance per worker thread" % (n, wl.n_cycles, args.cfg)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,135 @@
+// Device-side data layout shared by the HIP kernels (zkw_kernels.hip) and the host runtime
+// (zkw_runtime.cpp).  See DESIGN.md §"Data layout in HBM".
+//
+// Mapping: VM instance i  ->  wave w = i / L, lane l = i % L   (L = lanes per wave, 1..64).
+// Everything a wave touches every cycle is interleaved across its lanes so that the 64 lanes of
+// one load/store instruction hit consecutive 16/32-byte units (coalesced), e.g. the register file
+// snapshot of cycle k is `rec[((w*max_cycles + k)*32 + chunk)*L + l]` (16-byte units).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/zkw.h"
+
+#define ZKW_WAVE 64            /* CDNA wavefront width */
+#define ZKW_REC_CHUNKS 32      /* 512-byte CycleRecord = 32 x 16 B */
+#define ZKW_REG_CHUNKS 30      /* 15 registers x 2 halves */
+
+/* packed ISA entry: .x = attributes, .y = price */
+#define ZKW_ATTR_OPCODE(a) ((a)&15u)
+#define ZKW_ATTR_VARIANT(a) (((a) >> 4) & 15u)
+#define ZKW_ATTR_SRC0(a) (((a) >> 8) & 7u)
+#define ZKW_ATTR_DST0(a) (((a) >> 11) & 3u)
+#define ZKW_ATTR_FLAGS(a) (((a) >> 13) & 3u)
+#define ZKW_ATTR_PROPS(a) (((a) >> 15) & 63u)
+#define ZKW_ATTR_PACK(op, var, s0, d0, fl, pr) \
+  ((uint32_t)(op) | ((uint32_t)(var) << 4) | ((uint32_t)(s0) << 8) | ((uint32_t)(d0) << 11) | ((uint32_t)(fl) << 13) | ((uint32_t)(pr) << 15))
+
+/* callstack entry as kept on device: the ABI struct + what the device needs to re-enter the frame */
+typedef struct zkw_dev_entry {
+  zkw_callstack_entry e; /* 112 B */
+  uint32_t code_blob;    /* blob backing e.code_page                                  */
+  uint32_t frame_slot;   /* memory arena slot of the far frame this entry lives in     */
+  uint32_t journal_mark; /* storage journal length when the frame started              */
+  uint32_t reserved;
+} zkw_dev_entry; /* 128 B */
+
+/* per-instance scalar state (everything of VmLocalState that is not the register file or the
+ * callstack), plus run bookkeeping.  Loaded into VGPRs at kernel start, stored at kernel end. */
+typedef struct zkw_dev_scalars {
+  uint32_t prev_code_word[8];
+  uint32_t ctx_u128_reg[4];
+  uint32_t ptr_bitmap;          /* bit i = registers[i].is_pointer */
+  uint32_t flags;               /* bits 0..2 lt/eq/gt, bit 3 pending_exception */
+  uint32_t prev_code_page;
+  uint32_t timestamp;
+  uint32_t cycle_counter;       /* monotonic_cycle_counter */
+  uint32_t spent_pubdata;
+  uint32_t memory_page_counter;
+  uint32_t absolute_execution_step;
+  uint32_t ergs_per_pubdata;
+  uint32_t tx_number;
+  uint32_t prev_super_pc;
+  uint32_t depth;               /* callstack.inner.len() */
+  uint32_t status;              /* ZKW_STATUS_* */
+  uint32_t n_cycles;            /* cycles executed since reset */
+  uint32_t first_dynamic_page;  /* memory_page_counter at reset: far call j gets base page first + 8 j */
+  uint32_t n_initial_slots;     /* arena slots taken by the frames alive at reset */
+  uint32_t next_slot;           /* next free arena slot */
+  uint32_t journal_len;         /* storage journal length */
+  uint32_t n_history;           /* decommitter history length */
+  uint32_t reserved[1];
+} zkw_dev_scalars; /* 32 x 4 = 128 B */
+
+/* per (instance, arena slot): lazily-zeroed pages: words >= hwm read as zero */
+typedef struct zkw_dev_frame_meta {
+  uint32_t base_page;
+  uint32_t stack_hwm;
+  uint32_t heap_hwm;
+  uint32_t aux_hwm;
+} zkw_dev_frame_meta;
+
+typedef struct zkw_dev_storage_entry {
+  uint32_t key[8];
+  uint32_t value[8];
+  uint32_t address[5];
+  uint32_t shard_state; /* bits 0-7 shard id, bit 8 occupied, bit 9 warm */
+  uint32_t reserved[2];
+} zkw_dev_storage_entry; /* 96 B */
+
+typedef struct zkw_dev_journal_entry {
+  uint32_t old_value[8];
+  uint32_t slot;
+  uint32_t reserved[3];
+} zkw_dev_journal_entry; /* 48 B */
+
+typedef struct zkw_dev_preimage {
+  uint32_t hash[8];
+  uint32_t blob;
+  uint32_t reserved[3];
+} zkw_dev_preimage; /* 48 B */
+
+typedef struct zkw_dev_history {
+  uint32_t preimage; /* index into the preimage table */
+  uint32_t page;
+} zkw_dev_history;
+
+/* kernel parameter block */
+typedef struct zkw_kparams {
+  uint32_t n_instances;
+  uint32_t L;          /* lanes per wave */
+  uint32_t n_waves;
+  uint32_t max_cycles; /* limits.max_cycles (record capacity per instance) */
+  uint32_t cycle_base; /* wave-cycle index of the first cycle of this run */
+  uint32_t run_cycles;
+  uint32_t F, D, S, H, A; /* max_far_frames, max_callstack_depth, stack/heap/aux words */
+  uint32_t storage_slots, storage_journal;
+  uint32_t cap_mem, cap_log, cap_aux; /* stream capacity per wave (records) */
+  uint32_t n_blobs, n_preimages;
+  uint32_t wave_threads; /* threads per workgroup = hardware wave width (64 on gfx950) */
+  zkw_isa_consts consts;
+  zkw_block_properties props;
+  const uint2* isa;            /* [2048] packed */
+  /* state */
+  uint4* regs;                 /* [n_waves][30][L]                      */
+  zkw_dev_scalars* scalars;    /* [n_instances]                          */
+  zkw_dev_entry* callstack;    /* [n_instances][D + 1]                   */
+  zkw_dev_frame_meta* frames;  /* [n_instances][F]                       */
+  uint4* stack_vals;           /* [n_waves][F][S][L][2]                  */
+  uint8_t* stack_ptrs;         /* [n_waves][F][S][L]                     */
+  uint4* heap;                 /* [n_waves][F][H][L][2]                  */
+  uint4* aux_heap;             /* [n_waves][F][A][L][2]                  */
+  zkw_dev_storage_entry* storage;  /* [n_instances][storage_slots]       */
+  zkw_dev_journal_entry* journal;  /* [n_instances][storage_journal]     */
+  zkw_dev_history* history;        /* [n_instances][F]                   */
+  /* read-only inputs */
+  const uint4* blob_words;     /* all code blobs, 2 x uint4 per word     */
+  const uint2* blob_dir;       /* [n_blobs] (first word, n_words)        */
+  const zkw_dev_preimage* preimages; /* [n_preimages]                    */
+  /* outputs */
+  uint4* rec;                  /* [n_waves][max_cycles][32][L]           */
+  uint4* mem_stream;           /* [n_waves][cap_mem][3]                  */
+  uint4* log_stream;           /* [n_waves][cap_log][8]                  */
+  uint4* aux_stream;           /* [n_waves][cap_aux][16]                 */
+  uint32_t* dir;               /* [n_waves][max_cycles + 1][4] (mem, log, aux cursors at cycle start) */
+  uint32_t* cursors;           /* [n_waves][4] persistent stream cursors */
+} zkw_kparams;

@@ -1,0 +1,1622 @@
+// EraVM batch witness kernel for MI355X (gfx950).
+//
+// One VM instance per lane, one wave per workgroup.  Every active lane of a wave executes
+// `cycle()` of the reference (src/vm_state/cycle.rs:257-429) once per loop iteration, in lockstep:
+//   * the 15 x 256-bit register file of each lane lives in LDS, laid out [chunk][lane] in 16-byte
+//     units so that lanes using the same register index hit consecutive banks (conflict-free
+//     ds_read/write_b128) and so that the per-cycle snapshot is a straight LDS -> HBM copy;
+//   * the opcode stream is fetched from HBM as 32-byte code words (4 opcodes), cached in VGPRs
+//     exactly like `previous_code_word` (cycle.rs:53-101);
+//   * the packed ISA table (host-uploaded, 2048 x 8 B) is staged in LDS once per workgroup;
+//   * stack / heap / aux-heap pages are interleaved across the lanes of a wave ([word][lane]) so a
+//     shared tape gives fully coalesced 32-byte accesses; pages are lazily zeroed through a
+//     per-page high-water mark instead of memsets;
+//   * the sparse per-cycle query logs (memory / log / aux) are compacted per wave with
+//     ballot + popcount prefix sums into dense streams (lane- and sequence-tagged records);
+//   * one 512-byte CycleRecord per lane and cycle goes out as 32 fully coalesced 16-byte stores.
+// No MFMA: there is no dense contraction on this path (256-bit integer ALU, byte shuffles, hashes).
+//
+// Reference citations (file:line) are relative to /root/reference/src.
+#include <hip/hip_runtime.h>
+
+#include "zkw_device.h"
+#include "zkw_u256.hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// per-lane execution context (lives in VGPRs; every helper below is force-inlined)
+// ---------------------------------------------------------------------------------------------
+struct Lane {
+  // identity
+  u32 inst, wave, lane;
+  // VmLocalState scalars (mod.rs:54-73)
+  u32 pcw[8];  // previous_code_word
+  u32 ctx_reg[4];
+  u32 ptr_bitmap, flags, prev_code_page, timestamp, cycle_counter, spent_pubdata, mpc, ergs_pp, tx_number, prev_super_pc, depth;
+  // run bookkeeping
+  u32 status, n_cycles, first_dyn, n_initial_slots, next_slot, journal_len, n_history;
+  // hot fields of callstack.current (execution_stack.rs:6-24)
+  u32 base_page, code_page, sp, pc, ergs, heap_bound, aux_bound;
+  u32 is_kernel, is_static, is_local;
+  u32 code_off, code_len, code_blob, slot;
+  u32 stack_hwm, heap_hwm, aux_hwm;
+  // per-cycle
+  u32 seq, n_mem, n_log, n_aux, cold_dirty;
+};
+
+#define FLAG_LT 1u
+#define FLAG_EQ 2u
+#define FLAG_GT 4u
+#define FLAG_PENDING 8u
+
+// dword offsets inside zkw_callstack_entry / zkw_dev_entry
+#define E_THIS 0
+#define E_SENDER 5
+#define E_CODE_ADDR 10
+#define E_BASE_PAGE 15
+#define E_CODE_PAGE 16
+#define E_SP_PC 17
+#define E_EH_FLAGS 18
+#define E_ERGS 19
+#define E_SHARDS 20
+#define E_CTX 22
+#define E_HEAP_BOUND 26
+#define E_AUX_BOUND 27
+#define E_CODE_BLOB 28
+#define E_SLOT 29
+#define E_JOURNAL_MARK 30
+
+ZD void lane_fail(Lane& s, u32 status) {
+  if (s.status == ZKW_STATUS_RUNNING) s.status = status;
+}
+ZD bool lane_ok(const Lane& s) { return s.status == ZKW_STATUS_RUNNING; }
+
+// ---------------------------------------------------------------------------------------------
+// wave-level stream compaction: every lane that reaches this point (possibly under divergence)
+// gets a unique, dense slot of the wave's stream: ballot -> rank by popcount of lower lanes ->
+// one LDS atomic by the leader -> broadcast.
+// ---------------------------------------------------------------------------------------------
+ZD u32 stream_alloc(u32* cursor) {
+  const u64 mask = __ballot(1);
+  const u32 lane = threadIdx.x & (ZKW_WAVE - 1);
+  const u32 leader = (u32)__ffsll((long long)mask) - 1u;
+  const u32 rank = (u32)__popcll(mask & ((1ull << lane) - 1ull));
+  u32 base = 0;
+  if (lane == leader) base = atomicAdd(cursor, (u32)__popcll(mask));
+  base = (u32)__shfl((int)base, (int)leader);
+  return base + rank;
+}
+
+// LDS view of one workgroup (= one wave).  Dynamic size: 16 KB ISA + (30*16 + 34*4) B per lane.
+struct Shared {
+  uint2* isa;     // [2048] packed ISA table
+  u32* cursor;    // [4] stream cursors of this wave
+  uint4* regs;    // [30][L] register file, 16-byte chunks, lane-minor
+  u32* krow;      // [34][L] Keccak rate block assembly rows
+  u32 L;
+};
+ZD uint4& sh_reg(Shared& sh, u32 chunk, u32 lane) { return sh.regs[chunk * sh.L + lane]; }
+
+ZD u32 next_seq(Lane& s) {
+  u32 q = s.seq > 255u ? 255u : s.seq;
+  s.seq++;
+  return q;
+}
+
+// WT.add_memory_query (witness_trace/mod.rs:19) / payload of add_precompile_call_result (:43-50)
+ZD void emit_mem(const zkw_kparams& P, Shared& sh, Lane& s, u32 ts, u32 type, u32 page, u32 index, const u256& value, bool is_ptr, bool rw, u32 kind) {
+  const u32 pos = stream_alloc(sh.cursor + 0);
+  const u32 seq = next_seq(s);
+  s.n_mem++;
+  if (pos >= P.cap_mem) {
+    lane_fail(s, ZKW_STATUS_LIMIT);
+    return;
+  }
+  const u32 meta = (type & ZKW_MQ_TYPE_MASK) | (is_ptr ? ZKW_MQ_IS_PTR : 0u) | (rw ? ZKW_MQ_RW : 0u) | (kind << ZKW_MQ_KIND_SHIFT);
+  uint4* dst = P.mem_stream + ((u64)s.wave * P.cap_mem + pos) * 3;
+  dst[0] = make_uint4(ts, page, index, s.lane | (seq << 8) | (meta << 16));
+  dst[1] = u256_lo4(value);
+  dst[2] = u256_hi4(value);
+}
+
+struct LogQ {  // LogQuery (log.rs:85-97)
+  u256 key, read_value, written_value;
+  u32 address[5];
+  u32 timestamp, tx_number, aux_byte, shard_id;
+  bool rw, rollback, is_service;
+};
+
+// WT.add_log_query / WT.record_refund_for_query (witness_trace/mod.rs:22-33)
+ZD void emit_log(const zkw_kparams& P, Shared& sh, Lane& s, const LogQ& q, u32 kind) {
+  const u32 pos = stream_alloc(sh.cursor + 1);
+  const u32 seq = next_seq(s);
+  s.n_log++;
+  if (pos >= P.cap_log) {
+    lane_fail(s, ZKW_STATUS_LIMIT);
+    return;
+  }
+  uint4* dst = P.log_stream + ((u64)s.wave * P.cap_log + pos) * 8;
+  dst[0] = u256_lo4(q.key);
+  dst[1] = u256_hi4(q.key);
+  dst[2] = u256_lo4(q.read_value);
+  dst[3] = u256_hi4(q.read_value);
+  dst[4] = u256_lo4(q.written_value);
+  dst[5] = u256_hi4(q.written_value);
+  dst[6] = make_uint4(q.address[0], q.address[1], q.address[2], q.address[3]);
+  const u32 bools = (q.rw ? ZKW_LQ_RW : 0u) | (q.rollback ? ZKW_LQ_ROLLBACK : 0u) | (q.is_service ? ZKW_LQ_IS_SERVICE : 0u);
+  dst[7] = make_uint4(q.address[4], q.timestamp, (q.tx_number & 0xffffu) | (q.aux_byte << 16) | (q.shard_id << 24),
+                      bools | (kind << 8) | (s.lane << 16) | (seq << 24));
+}
+
+// aux events: header + up to 60 payload dwords
+ZD uint4* aux_alloc(const zkw_kparams& P, Shared& sh, Lane& s, u32 type, u32 flag, u32 a, u32 b, u32 c) {
+  const u32 pos = stream_alloc(sh.cursor + 2);
+  const u32 seq = next_seq(s);
+  s.n_aux++;
+  if (pos >= P.cap_aux) {
+    lane_fail(s, ZKW_STATUS_LIMIT);
+    return nullptr;
+  }
+  uint4* dst = P.aux_stream + ((u64)s.wave * P.cap_aux + pos) * 16;
+  dst[0] = make_uint4(type | (s.lane << 8) | (seq << 16) | (flag << 24), a, b, c);
+  return dst;
+}
+
+// ---------------------------------------------------------------------------------------------
+// register file (LDS) — select_register_value / update_register_value (helpers.rs:318-334)
+// ---------------------------------------------------------------------------------------------
+ZD u256 reg_read(Shared& sh, const Lane& s, u32 idx, bool& is_ptr) {
+  if (idx == 0) {
+    is_ptr = false;
+    return u256_zero();
+  }
+  const u32 r = idx - 1;
+  is_ptr = (s.ptr_bitmap >> r) & 1u;
+  return u256_from_uint4(sh_reg(sh, 2 * r, s.lane), sh_reg(sh, 2 * r + 1, s.lane));
+}
+ZD void reg_write(Shared& sh, Lane& s, u32 idx, const u256& v, bool is_ptr) {
+  if (idx == 0) return;
+  const u32 r = idx - 1;
+  sh_reg(sh, 2 * r, s.lane) = u256_lo4(v);
+  sh_reg(sh, 2 * r + 1, s.lane) = u256_hi4(v);
+  s.ptr_bitmap = (s.ptr_bitmap & ~(1u << r)) | ((is_ptr ? 1u : 0u) << r);
+}
+
+// ---------------------------------------------------------------------------------------------
+// memory arenas — the device-side SimpleMemory (reference_impls/memory.rs:403-528)
+// ---------------------------------------------------------------------------------------------
+ZD u64 page_word_index(const zkw_kparams& P, const Lane& s, u32 slot, u32 words_per_page, u32 idx) {
+  return (((u64)s.wave * P.F + slot) * words_per_page + idx) * P.L + s.lane;
+}
+
+// MemoryType::Stack read of the current frame (memory.rs:427-436)
+ZD u256 stack_read(const zkw_kparams& P, Lane& s, u32 idx, bool& is_ptr) {
+  is_ptr = false;
+  if (idx >= P.S) {
+    lane_fail(s, ZKW_STATUS_LIMIT);
+    return u256_zero();
+  }
+  if (idx >= s.stack_hwm) return u256_zero();
+  const u64 w = page_word_index(P, s, s.slot, P.S, idx);
+  is_ptr = P.stack_ptrs[w] != 0;
+  return u256_from_uint4(P.stack_vals[2 * w], P.stack_vals[2 * w + 1]);
+}
+// MemoryType::Stack write (memory.rs:413-425)
+ZD void stack_write(const zkw_kparams& P, Lane& s, u32 idx, const u256& v, bool is_ptr) {
+  if (idx >= P.S) {
+    lane_fail(s, ZKW_STATUS_LIMIT);
+    return;
+  }
+  for (u32 g = s.stack_hwm; g < idx; g++) {  // lazily zero the gap
+    const u64 w = page_word_index(P, s, s.slot, P.S, g);
+    P.stack_vals[2 * w] = make_uint4(0, 0, 0, 0);
+    P.stack_vals[2 * w + 1] = make_uint4(0, 0, 0, 0);
+    P.stack_ptrs[w] = 0;
+  }
+  const u64 w = page_word_index(P, s, s.slot, P.S, idx);
+  P.stack_vals[2 * w] = u256_lo4(v);
+  P.stack_vals[2 * w + 1] = u256_hi4(v);
+  P.stack_ptrs[w] = is_ptr ? 1 : 0;
+  if (idx >= s.stack_hwm) s.stack_hwm = idx + 1;
+}
+
+// heap / aux heap of an arbitrary arena slot; `hwm` is that page's high-water mark
+ZD u256 heap_read_at(const zkw_kparams& P, Lane& s, bool is_aux, u32 slot, u32 hwm, u32 idx) {
+  const u32 words = is_aux ? P.A : P.H;
+  if (idx >= hwm) {
+    if (idx >= words) lane_fail(s, ZKW_STATUS_LIMIT);  // the reference would grow the page (memory.rs:464,468)
+    return u256_zero();
+  }
+  const uint4* base = is_aux ? P.aux_heap : P.heap;
+  const u64 w = page_word_index(P, s, slot, words, idx);
+  return u256_from_uint4(base[2 * w], base[2 * w + 1]);
+}
+// MemoryType::Heap / AuxHeap of the current frame (memory.rs:439-473; the page number of the query
+// is only debug_assert'ed there, i.e. ignored in release builds)
+ZD u256 heap_read_cur(const zkw_kparams& P, Lane& s, bool is_aux, u32 idx) {
+  return heap_read_at(P, s, is_aux, s.slot, is_aux ? s.aux_hwm : s.heap_hwm, idx);
+}
+ZD void heap_write_cur(const zkw_kparams& P, Lane& s, bool is_aux, u32 idx, const u256& v) {
+  const u32 words = is_aux ? P.A : P.H;
+  if (idx >= words) {
+    lane_fail(s, ZKW_STATUS_LIMIT);
+    return;
+  }
+  uint4* base = is_aux ? P.aux_heap : P.heap;
+  u32 hwm = is_aux ? s.aux_hwm : s.heap_hwm;
+  for (u32 g = hwm; g < idx; g++) {
+    const u64 w = page_word_index(P, s, s.slot, words, g);
+    base[2 * w] = make_uint4(0, 0, 0, 0);
+    base[2 * w + 1] = make_uint4(0, 0, 0, 0);
+  }
+  const u64 w = page_word_index(P, s, s.slot, words, idx);
+  base[2 * w] = u256_lo4(v);
+  base[2 * w + 1] = u256_hi4(v);
+  if (idx >= hwm) hwm = idx + 1;
+  if (is_aux) s.aux_hwm = hwm; else s.heap_hwm = hwm;
+}
+
+// MemoryType::FatPointer read (memory.rs:475-521): resolve the page to an arena slot.
+// Page 0 is Indirection::Empty; pages that never were a heap/aux page of a frame of this
+// instance are "unreachable memory" (the reference's expect() at :478-481).
+ZD u256 fat_ptr_read(const zkw_kparams& P, Lane& s, u32 page, u32 idx) {
+  if (page == 0) return u256_zero();
+  u32 slot, kind;
+  bool found = false;
+  if (page >= s.first_dyn) {
+    const u32 rel = page - s.first_dyn;
+    const u32 stride = P.consts.new_memory_pages_per_far_call;
+    slot = s.n_initial_slots + rel / stride;
+    kind = rel % stride;
+    found = slot < s.next_slot;
+  } else {
+    slot = 0;
+    kind = 0;
+    for (u32 i = 0; i < s.n_initial_slots; i++) {
+      const u32 bp = P.frames[(u64)s.inst * P.F + i].base_page;
+      if (page >= bp && page < bp + 4) {
+        slot = i;
+        kind = page - bp;
+        found = true;
+      }
+    }
+  }
+  if (!found || (kind != 2 && kind != 3)) {
+    lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
+    return u256_zero();
+  }
+  const bool is_aux = kind == 3;
+  u32 hwm;
+  if (slot == s.slot) {
+    hwm = is_aux ? s.aux_hwm : s.heap_hwm;
+  } else {
+    const zkw_dev_frame_meta fm = P.frames[(u64)s.inst * P.F + slot];
+    hwm = is_aux ? fm.aux_hwm : fm.heap_hwm;
+  }
+  const u32 words = is_aux ? P.A : P.H;
+  if (idx >= hwm || idx >= words) return u256_zero();  // `.get(index).unwrap_or(zero)` (:490-495)
+  const uint4* base = is_aux ? P.aux_heap : P.heap;
+  const u64 w = page_word_index(P, s, slot, words, idx);
+  return u256_from_uint4(base[2 * w], base[2 * w + 1]);
+}
+
+// read_code_query (memory.rs:556-569) against the blob backing the current code page
+ZD u256 code_read(const zkw_kparams& P, const Lane& s, u32 idx) {
+  if (idx >= s.code_len) return u256_zero();
+  const u64 w = (u64)s.code_off + idx;
+  return u256_from_uint4(P.blob_words[2 * w], P.blob_words[2 * w + 1]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// callstack entries in HBM ([inst][depth] x 8 uint4)
+// ---------------------------------------------------------------------------------------------
+ZD uint4* entry_ptr(const zkw_kparams& P, const Lane& s, u32 depth) { return (uint4*)(P.callstack + ((u64)s.inst * (P.D + 1) + depth)); }
+ZD u32 entry_dword(const zkw_kparams& P, const Lane& s, u32 depth, u32 d) { return ((const u32*)entry_ptr(P, s, depth))[d]; }
+
+// write the hot fields of callstack.current back into its HBM entry
+ZD void frame_writeback(const zkw_kparams& P, const Lane& s) {
+  u32* e = (u32*)entry_ptr(P, s, s.depth);
+  e[E_SP_PC] = (s.sp & 0xffffu) | (s.pc << 16);
+  e[E_ERGS] = s.ergs;
+  e[E_HEAP_BOUND] = s.heap_bound;
+  e[E_AUX_BOUND] = s.aux_bound;
+}
+ZD void hwm_writeback(const zkw_kparams& P, const Lane& s) {
+  zkw_dev_frame_meta* fm = P.frames + (u64)s.inst * P.F + s.slot;
+  fm->stack_hwm = s.stack_hwm;
+  fm->heap_hwm = s.heap_hwm;
+  fm->aux_hwm = s.aux_hwm;
+}
+// load the hot fields of entry `s.depth` into the lane
+ZD void frame_load(const zkw_kparams& P, Lane& s) {
+  const u32* e = (const u32*)entry_ptr(P, s, s.depth);
+  s.base_page = e[E_BASE_PAGE];
+  s.code_page = e[E_CODE_PAGE];
+  const u32 sppc = e[E_SP_PC];
+  s.sp = sppc & 0xffffu;
+  s.pc = sppc >> 16;
+  const u32 ehf = e[E_EH_FLAGS];
+  s.is_static = (ehf >> 16) & 0xffu;
+  s.is_local = (ehf >> 24) & 0xffu;
+  s.ergs = e[E_ERGS];
+  s.heap_bound = e[E_HEAP_BOUND];
+  s.aux_bound = e[E_AUX_BOUND];
+  s.is_kernel = (e[E_THIS] < 0x10000u && (e[E_THIS + 1] | e[E_THIS + 2] | e[E_THIS + 3] | e[E_THIS + 4]) == 0) ? 1u : 0u;  // execution_stack.rs:83-87
+  s.code_blob = e[E_CODE_BLOB];
+  const u32 new_slot = e[E_SLOT];
+  const uint2 bd = P.blob_dir[s.code_blob];
+  s.code_off = bd.x;
+  s.code_len = bd.y;
+  s.slot = new_slot;
+  const zkw_dev_frame_meta fm = P.frames[(u64)s.inst * P.F + new_slot];
+  s.stack_hwm = fm.stack_hwm;
+  s.heap_hwm = fm.heap_hwm;
+  s.aux_hwm = fm.aux_hwm;
+}
+
+// ---------------------------------------------------------------------------------------------
+// storage — the device-side InMemoryStorage (testing/storage.rs:79-186): open addressing + journal
+// ---------------------------------------------------------------------------------------------
+ZD u32 storage_hash(u32 shard, const u32 addr[5], const u256& key) {
+  u32 h = 0x9e3779b9u * (shard + 1);
+#pragma unroll
+  for (int i = 0; i < 8; i++) h = (h ^ key.w[i]) * 0x85ebca6bu, h ^= h >> 15;
+#pragma unroll
+  for (int i = 0; i < 5; i++) h = (h ^ addr[i]) * 0xc2b2ae35u, h ^= h >> 13;
+  return h;
+}
+// returns the entry index of (shard,address,key), inserting an empty (value 0) entry when absent
+ZD u32 storage_find(const zkw_kparams& P, Lane& s, u32 shard, const u32 addr[5], const u256& key) {
+  const u32 mask = P.storage_slots - 1;
+  u32 i = storage_hash(shard, addr, key) & mask;
+  zkw_dev_storage_entry* tab = P.storage + (u64)s.inst * P.storage_slots;
+  for (u32 probe = 0; probe < P.storage_slots; probe++, i = (i + 1) & mask) {
+    zkw_dev_storage_entry* e = tab + i;
+    const u32 st = e->shard_state;
+    if (!(st & 0x100u)) {  // free: claim
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        e->key[k] = key.w[k];
+        e->value[k] = 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 5; k++) e->address[k] = addr[k];
+      e->shard_state = shard | 0x100u;
+      return i;
+    }
+    bool same = (st & 0xffu) == shard;
+#pragma unroll
+    for (int k = 0; k < 8; k++) same = same && e->key[k] == key.w[k];
+#pragma unroll
+    for (int k = 0; k < 5; k++) same = same && e->address[k] == addr[k];
+    if (same) return i;
+  }
+  lane_fail(s, ZKW_STATUS_LIMIT);
+  return 0;
+}
+// Storage::execute_partial_query (storage.rs:88-139) + access_storage's read convention (helpers.rs:145-148)
+ZD void access_storage(const zkw_kparams& P, Shared& sh, Lane& s, LogQ& q) {
+  const u32 slot = storage_find(P, s, q.shard_id, q.address, q.key);
+  if (!lane_ok(s)) return;
+  zkw_dev_storage_entry* e = P.storage + (u64)s.inst * P.storage_slots + slot;
+  u256 cur;
+#pragma unroll
+  for (int k = 0; k < 8; k++) cur.w[k] = e->value[k];
+  e->shard_state |= 0x200u;  // warm marker
+  q.read_value = cur;
+  if (q.rw) {
+    if (s.journal_len >= P.storage_journal) {
+      lane_fail(s, ZKW_STATUS_LIMIT);
+      return;
+    }
+    zkw_dev_journal_entry* j = P.journal + (u64)s.inst * P.storage_journal + s.journal_len;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      j->old_value[k] = cur.w[k];
+      e->value[k] = q.written_value.w[k];
+    }
+    j->slot = slot;
+    s.journal_len++;
+  } else {
+    q.written_value = q.read_value;
+  }
+  emit_log(P, sh, s, q, ZKW_LQ_LOG);
+}
+// Storage::finish_frame(panicked) (storage.rs:144-186): undo this frame's writes newest-first
+ZD void storage_finish_frame(const zkw_kparams& P, Lane& s, u32 mark, bool panicked) {
+  if (!panicked) return;
+  while (s.journal_len > mark) {
+    s.journal_len--;
+    const zkw_dev_journal_entry* j = P.journal + (u64)s.inst * P.storage_journal + s.journal_len;
+    zkw_dev_storage_entry* e = P.storage + (u64)s.inst * P.storage_slots + j->slot;
+#pragma unroll
+    for (int k = 0; k < 8; k++) e->value[k] = j->old_value[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers shared by opcodes
+// ---------------------------------------------------------------------------------------------
+ZD u32 clip16(const zkw_kparams& P, const u256& v) {  // AllowedPcOrImm::from_u64_clipped(value.low_u64())
+  if (P.consts.clip_mode == 0) return (v.w[1] != 0 || v.w[0] > 0xffffu) ? 0xffffu : v.w[0];
+  return v.w[0] & 0xffffu;
+}
+
+struct Operand {
+  bool has_loc;
+  u32 type, page, index;
+};
+
+// MemOpsProcessor::compute_addresses_and_select_operands (mem_ops.rs:14-125)
+ZD Operand compute_address(const zkw_kparams& P, Lane& s, u32& sp, const u256& reg_value, u32 imm, u32 mode, bool is_write) {
+  Operand o;
+  o.has_loc = false;
+  o.type = ZKW_MEM_STACK;
+  o.page = s.base_page + 1;  // stack_page_from_base
+  o.index = 0;
+  const u32 vaddr = (clip16(P, reg_value) + imm) & 0xffffu;  // :34-35
+  if (mode == ZKW_MODE_STACK_PP) {
+    if (is_write) {  // :55-70
+      o.index = sp;
+      sp = (sp + vaddr) & 0xffffu;
+    } else {  // :71-86
+      sp = (sp - vaddr) & 0xffffu;
+      o.index = sp;
+    }
+    o.has_loc = true;
+  } else if (mode == ZKW_MODE_STACK_OFF) {  // :88-98
+    o.index = (sp - vaddr) & 0xffffu;
+    o.has_loc = true;
+  } else if (mode == ZKW_MODE_CODE) {  // :100-110
+    o.type = ZKW_MEM_CODE;
+    o.page = s.code_page;
+    o.index = vaddr;
+    o.has_loc = true;
+  } else if (mode == ZKW_MODE_STACK_ABS) {  // :111-121
+    o.index = vaddr;
+    o.has_loc = true;
+  }
+  return o;
+}
+
+// perform_dst0_update (helpers.rs:266-283)
+ZD void dst0_update(const zkw_kparams& P, Shared& sh, Lane& s, const Operand& dst0, u32 dst0_idx, const u256& v, bool is_ptr) {
+  if (dst0.has_loc) {
+    stack_write(P, s, dst0.index, v, is_ptr);
+    emit_mem(P, sh, s, s.timestamp + 3, ZKW_MEM_STACK, dst0.page, dst0.index, v, is_ptr, true, 0);
+  } else {
+    reg_write(sh, s, dst0_idx, v, is_ptr);
+  }
+}
+
+ZD void set_flags3(Lane& s, bool lt, bool eq, bool gt) {
+  s.flags = (s.flags & FLAG_PENDING) | (lt ? FLAG_LT : 0u) | (eq ? FLAG_EQ : 0u) | (gt ? FLAG_GT : 0u);
+}
+
+struct FatPtr {  // zkevm_opcode_defs::FatPointer (Appendix B layout)
+  u32 offset, page, start, length;
+};
+ZD FatPtr fat_ptr_from(const u256& v) {
+  FatPtr p;
+  p.offset = v.w[0]; p.page = v.w[1]; p.start = v.w[2]; p.length = v.w[3];
+  return p;
+}
+ZD u256 fat_ptr_to_u256(const FatPtr& p) {
+  u256 v = u256_zero();
+  v.w[0] = p.offset; v.w[1] = p.page; v.w[2] = p.start; v.w[3] = p.length;
+  return v;
+}
+#define FPV_OFFSET_NOT_ZERO 1u
+#define FPV_DEREF_BEYOND 2u
+ZD u32 fat_ptr_validate(const FatPtr& p, bool fresh) {
+  u32 e = 0;
+  if (fresh && p.offset != 0) e |= FPV_OFFSET_NOT_ZERO;
+  if (p.start + p.length < p.start) e |= FPV_DEREF_BEYOND;
+  return e;
+}
+ZD u32 forward_type(u32 b) { return b == 1u ? 1u : (b == 2u ? 2u : 0u); }  // 0 UseHeap, 1 ForwardFatPointer, 2 UseAuxHeap
+
+// build a callstack entry image (32 dwords) from the lane's current frame: cold fields come from HBM
+ZD void entry_image_current(const zkw_kparams& P, const Lane& s, u32 img[32]) {
+  const uint4* e = entry_ptr(P, s, s.depth);
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint4 v = e[i];
+    img[4 * i] = v.x; img[4 * i + 1] = v.y; img[4 * i + 2] = v.z; img[4 * i + 3] = v.w;
+  }
+  img[E_SP_PC] = (s.sp & 0xffffu) | (s.pc << 16);
+  img[E_ERGS] = s.ergs;
+  img[E_HEAP_BOUND] = s.heap_bound;
+  img[E_AUX_BOUND] = s.aux_bound;
+}
+
+// VmState::start_frame (helpers.rs:225-246): Storage/EventSink::start_frame are a journal mark here
+// (the event sink is replayed on the host); emits WT.start_new_execution_context and pushes.
+ZD void start_frame(const zkw_kparams& P, Shared& sh, Lane& s, const u32 prev[32], u32 next[32], bool far) {
+  next[E_JOURNAL_MARK] = s.journal_len;
+  uint4* a = aux_alloc(P, sh, s, ZKW_AUX_FRAME_START, far ? 1u : 0u, 0, 0, 0);
+  if (a) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+      a[1 + i] = make_uint4(prev[4 * i], prev[4 * i + 1], prev[4 * i + 2], prev[4 * i + 3]);
+      a[8 + i] = make_uint4(next[4 * i], next[4 * i + 1], next[4 * i + 2], next[4 * i + 3]);
+    }
+    a[15] = make_uint4(0, 0, 0, 0);
+  }
+  if (s.depth + 1 > P.D) {
+    lane_fail(s, ZKW_STATUS_LIMIT);
+    return;
+  }
+  // callstack.push_entry: the old current (with its hot fields) stays at [depth], the new one goes to [depth+1]
+  uint4* cur = entry_ptr(P, s, s.depth);
+  uint4* nxt = entry_ptr(P, s, s.depth + 1);
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    cur[i] = make_uint4(prev[4 * i], prev[4 * i + 1], prev[4 * i + 2], prev[4 * i + 3]);
+    nxt[i] = make_uint4(next[4 * i], next[4 * i + 1], next[4 * i + 2], next[4 * i + 3]);
+  }
+  hwm_writeback(P, s);
+  s.depth++;
+  frame_load(P, s);
+}
+
+// =============================================================================================
+// opcodes
+// =============================================================================================
+
+struct Decoded {
+  u32 attr;
+  u32 cond, src0, src1, dst0, dst1, imm0, imm1;
+};
+struct Pre {  // PreState (cycle.rs:8-14)
+  u256 src0, src1;
+  bool src0_ptr, src1_ptr;
+  Operand dst0;
+  u32 new_pc;
+};
+
+// near_call.rs:6-68
+ZD void op_near_call(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+  s.flags &= FLAG_PENDING;  // reset_flags
+  const u32 abi_ergs = ps.src0.w[0];
+  const u32 remaining = s.ergs;
+  u32 passed, left;
+  if (abi_ergs == 0 || remaining < abi_ergs) {
+    passed = remaining;
+    left = 0;
+  } else {
+    passed = abi_ergs;
+    left = remaining - abi_ergs;
+  }
+  s.ergs = left;
+  s.pc = ps.new_pc;
+  u32 prev[32], next[32];
+  entry_image_current(P, s, prev);
+#pragma unroll
+  for (int i = 0; i < 32; i++) next[i] = prev[i];
+  next[E_SP_PC] = (s.sp & 0xffffu) | (d.imm0 << 16);
+  next[E_EH_FLAGS] = (d.imm1 & 0xffffu) | (prev[E_EH_FLAGS] & 0x00ff0000u) | (1u << 24);  // is_local_frame = true
+  next[E_ERGS] = passed;
+  start_frame(P, sh, s, prev, next, false);
+}
+
+// context.rs:6-111
+ZD void op_context(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+  s.pc = ps.new_pc;
+  const u32 v = ZKW_ATTR_VARIANT(d.attr);
+  u256 value = u256_zero();
+  if (v == ZKW_CTX_SET_CONTEXT_U128) {
+    bool changed = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      changed = changed || s.ctx_reg[i] != ps.src0.w[i];
+      s.ctx_reg[i] = ps.src0.w[i];
+    }
+    if (changed) s.cold_dirty = 1;
+    return;
+  }
+  if (v == ZKW_CTX_SET_ERGS_PER_PUBDATA) {
+    if (s.ergs_pp != ps.src0.w[0]) s.cold_dirty = 1;
+    s.ergs_pp = ps.src0.w[0];
+    return;
+  }
+  if (v == ZKW_CTX_INC_TX_NUMBER) {
+    s.tx_number = (s.tx_number + 1) & 0xffffu;
+    s.cold_dirty = 1;
+    return;
+  }
+  const u32* e = (const u32*)entry_ptr(P, s, s.depth);
+  if (v == ZKW_CTX_THIS || v == ZKW_CTX_CALLER || v == ZKW_CTX_CODE_ADDRESS) {
+    const u32 off = v == ZKW_CTX_THIS ? E_THIS : (v == ZKW_CTX_CALLER ? E_SENDER : E_CODE_ADDR);
+#pragma unroll
+    for (int i = 0; i < 5; i++) value.w[i] = e[off + i];
+  } else if (v == ZKW_CTX_META) {  // VmMetaParameters::to_u256 (Appendix B layout)
+    const u32 sh3 = e[E_SHARDS];
+    value.w[0] = s.ergs_pp;
+    value.w[2] = s.heap_bound;
+    value.w[3] = s.aux_bound;
+    value.w[7] = (sh3 & 0xffu) | (((sh3 >> 8) & 0xffu) << 8) | (((sh3 >> 16) & 0xffu) << 16);
+  } else if (v == ZKW_CTX_ERGS_LEFT) {
+    value.w[0] = s.ergs;
+  } else if (v == ZKW_CTX_SP) {
+    value.w[0] = s.sp;
+  } else {  // GetContextU128
+#pragma unroll
+    for (int i = 0; i < 4; i++) value.w[i] = e[E_CTX + i];
+  }
+  dst0_update(P, sh, s, ps.dst0, d.dst0, value, false);
+}
+
+// ptr.rs:6-194
+ZD void op_ptr(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+  s.pc = ps.new_pc;
+  const u32 v = ZKW_ATTR_VARIANT(d.attr);
+  if (!ps.src0_ptr || ps.src1_ptr) {  // :35-45
+    s.flags |= FLAG_PENDING;
+    return;
+  }
+  u256 result = ps.src0;
+  if (v == ZKW_PTR_ADD || v == ZKW_PTR_SUB) {
+    const bool too_far = (ps.src1.w[1] | ps.src1.w[2] | ps.src1.w[3] | ps.src1.w[4] | ps.src1.w[5] | ps.src1.w[6] | ps.src1.w[7]) != 0;  // >= 2^32 (:47)
+    const u32 off = ps.src1.w[0];
+    const u32 cur = ps.src0.w[0];
+    u32 n;
+    bool err;
+    if (v == ZKW_PTR_ADD) {
+      n = cur + off;
+      err = n < cur;
+    } else {
+      n = cur - off;
+      err = cur < off;
+    }
+    if (too_far || err) {
+      s.flags |= FLAG_PENDING;
+      return;
+    }
+    result.w[0] = n;  // :82 low 128 bits from the pointer, high 128 from src0
+  } else if (v == ZKW_PTR_PACK) {
+    if ((ps.src1.w[0] | ps.src1.w[1] | ps.src1.w[2] | ps.src1.w[3]) != 0) {  // :110-114
+      s.flags |= FLAG_PENDING;
+      return;
+    }
+#pragma unroll
+    for (int i = 4; i < 8; i++) result.w[i] = ps.src1.w[i];  // :126
+  } else {  // Shrink
+    const u32 off = ps.src1.w[0];
+    if (ps.src0.w[3] < off) {
+      s.flags |= FLAG_PENDING;
+      return;
+    }
+    result.w[3] = ps.src0.w[3] - off;
+  }
+  dst0_update(P, sh, s, ps.dst0, d.dst0, result, true);
+}
+
+// uma.rs:26-425
+ZD void op_uma(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+  const u32 v = ZKW_ATTR_VARIANT(d.attr);
+  s.pc = ps.new_pc;
+  const bool increment = ZKW_ATTR_FLAGS(d.attr) & 1u;
+  FatPtr fp = fat_ptr_from(ps.src0);
+  u32 exceptions = 0;
+  bool skip_legit = false;
+  const bool is_ptr_read = v == ZKW_UMA_FAT_PTR_READ;
+  const bool is_heap = v == ZKW_UMA_HEAP_READ || v == ZKW_UMA_HEAP_WRITE;
+  const bool is_write = v == ZKW_UMA_HEAP_WRITE || v == ZKW_UMA_AUX_WRITE;
+  if (is_ptr_read && !ps.src0_ptr) exceptions |= 1u;  // INPUT_IS_NOT_POINTER_WHEN_EXPECTED :73-78
+  u32 mem_type;
+  if (is_ptr_read) {
+    mem_type = ZKW_MEM_FAT_PTR;
+  } else if (is_heap) {
+    fp.page = s.base_page + 2;
+    mem_type = ZKW_MEM_HEAP;
+  } else {
+    fp.page = s.base_page + 3;
+    mem_type = ZKW_MEM_AUX_HEAP;
+  }
+  u32 src_offset;
+  if (is_ptr_read) {  // :110-120
+    if (!(fp.offset < fp.length)) skip_legit = true;
+    src_offset = fp.start + fp.offset;
+  } else {  // :121-135  src0 > MAX_OFFSET_TO_DEREF
+    const bool beyond = (ps.src0.w[1] | ps.src0.w[2] | ps.src0.w[3] | ps.src0.w[4] | ps.src0.w[5] | ps.src0.w[6] | ps.src0.w[7]) != 0 ||
+                        ps.src0.w[0] > P.consts.max_offset_to_deref_low;
+    if (beyond) {
+      exceptions |= 2u;  // DEREF_BEYOND_HEAP_RANGE
+      skip_legit = true;
+    }
+    src_offset = fp.offset;
+  }
+  const u32 incremented = fp.offset + 32u;
+  if (incremented < fp.offset) {  // :139-147
+    exceptions |= 4u;
+    if (!is_ptr_read && !(exceptions & 2u)) lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
+  }
+  u32 growth = 0;  // :152-194
+  if (!is_ptr_read) {
+    const u32 bound = is_heap ? s.heap_bound : s.aux_bound;
+    if (incremented >= bound) {
+      growth = incremented - bound;
+      if (is_heap) s.heap_bound = incremented; else s.aux_bound = incremented;
+    }
+  }
+  u32 cost = growth * P.consts.memory_growth_ergs_per_byte;  // :196-197
+  if (exceptions & 2u) cost = 0xffffffffu;                   // :202-207
+  if (s.ergs < cost) {
+    s.ergs = 0;
+    exceptions |= 8u;  // NOT_ENOUGH_ERGS_TO_GROW_MEMORY
+  } else {
+    s.ergs -= cost;
+  }
+  const bool set_panic = exceptions != 0;
+  const bool skip = skip_legit || set_panic;  // :223-228
+  const u32 word0 = src_offset >> 5, word1 = word0 + 1, unal = src_offset & 31u;
+  const bool unaligned = unal != 0;
+  const u32 ts_r = s.timestamp, ts_w = s.timestamp + 3;
+  u256 w0v = u256_zero(), w1v = u256_zero();
+  if (!skip) {  // :265-288
+    w0v = is_ptr_read ? fat_ptr_read(P, s, fp.page, word0) : heap_read_cur(P, s, !is_heap, word0);
+    emit_mem(P, sh, s, ts_r, mem_type, fp.page, word0, w0v, false, false, 0);
+    if (unaligned) {
+      w1v = is_ptr_read ? fat_ptr_read(P, s, fp.page, word1) : heap_read_cur(P, s, !is_heap, word1);
+      emit_mem(P, sh, s, ts_r, mem_type, fp.page, word1, w1v, false, false, 0);
+    }
+  }
+  if (!is_write) {  // :291-348
+    u256 result = u256_or(u256_shl(w0v, unal * 8), u256_shr(w1v, (32 - unal) * 8));
+    if (is_ptr_read) {
+      u32 beyond = incremented - fp.length;
+      if (incremented < fp.length || skip) beyond = 0;
+      beyond &= 31u;
+      result = u256_shl(u256_shr(result, beyond * 8), beyond * 8);
+    }
+    if (!set_panic) {
+      dst0_update(P, sh, s, ps.dst0, d.dst0, result, false);
+      if (increment) {
+        u256 upd = ps.src0;
+        upd.w[0] = incremented;  // (l[0] & TOP_32) + incremented :337-338
+        reg_write(sh, s, d.dst1, upd, ps.src0_ptr);
+      }
+    } else {
+      s.flags |= FLAG_PENDING;
+    }
+  } else {  // :349-423
+    const u32 lowest = 32 - unal;
+    u256 n0 = u256_shl(u256_shr(w0v, lowest * 8), lowest * 8);
+    n0 = u256_or(n0, u256_shr(ps.src1, unal * 8));
+    u256 n1 = u256_shr(u256_shl(w1v, unal * 8), unal * 8);
+    n1 = u256_or(n1, u256_shl(ps.src1, (32 - unal) * 8));
+    if (!skip) {
+      heap_write_cur(P, s, !is_heap, word0, n0);
+      emit_mem(P, sh, s, ts_w, mem_type, fp.page, word0, n0, false, true, 0);
+      if (unaligned) {
+        heap_write_cur(P, s, !is_heap, word1, n1);
+        emit_mem(P, sh, s, ts_w, mem_type, fp.page, word1, n1, false, true, 0);
+      }
+    }
+    if (!set_panic) {
+      if (increment) {
+        u256 upd = ps.src0;
+        upd.w[0] = incremented;
+        dst0_update(P, sh, s, ps.dst0, d.dst0, upd, false);
+      }
+    } else {
+      s.flags |= FLAG_PENDING;
+    }
+  }
+}
+
+// log.rs:11-330 (precompile calls: see zkw_precompiles below)
+ZD void call_precompile(const zkw_kparams& P, Shared& sh, Lane& s, const LogQ& q);
+
+ZD void op_log(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+  const u32 v = ZKW_ATTR_VARIANT(d.attr);
+  s.pc = ps.new_pc;
+  const bool is_first = ZKW_ATTR_FLAGS(d.attr) & 1u;
+  const u32* e = (const u32*)entry_ptr(P, s, s.depth);
+  const u32 shard = e[E_SHARDS] & 0xffu;
+  const u32 ergs_available = s.ergs;
+  const zkw_isa_consts& K = P.consts;
+  LogQ q;
+  q.timestamp = s.timestamp + 1;
+  q.tx_number = s.tx_number;
+  q.shard_id = shard;
+#pragma unroll
+  for (int i = 0; i < 5; i++) q.address[i] = e[E_THIS + i];
+  q.key = ps.src0;
+  q.read_value = u256_zero();
+  q.written_value = ps.src1;
+  q.rollback = false;
+  u32 ergs_on_pubdata = 0;
+  if (v == ZKW_LOG_STORAGE_WRITE) {  // :71-118
+    q.aux_byte = K.storage_aux_byte;
+    q.rw = true;
+    q.is_service = false;
+    emit_log(P, sh, s, q, ZKW_LQ_REFUND);  // refund_for_partial_query: InMemoryStorage refunds nothing (storage.rs:80-86)
+    const u32 net = shard == 0 ? K.initial_storage_write_pubdata_bytes : 0u;
+    ergs_on_pubdata = s.ergs_pp * net;
+  } else if (v == ZKW_LOG_TO_L1) {
+    ergs_on_pubdata = s.ergs_pp * K.l1_message_pubdata_bytes;
+  }
+  const u32 extra = v == ZKW_LOG_PRECOMPILE ? ps.src1.w[0] : 0u;
+  const u32 total = extra + ergs_on_pubdata;
+  const bool not_enough = ergs_available < total;
+  u32 spent;
+  if (not_enough) {  // :136-153
+    s.ergs = 0;
+    spent = ergs_available < ergs_on_pubdata ? ergs_available : ergs_on_pubdata;
+  } else {
+    s.ergs = ergs_available - total;
+    spent = ergs_on_pubdata;
+  }
+  if (spent) {
+    s.spent_pubdata += spent;
+    s.cold_dirty = 1;
+  }
+  q.is_service = is_first;
+  if (v == ZKW_LOG_STORAGE_READ) {  // :163-195
+    if (not_enough) {
+      lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
+      return;
+    }
+    q.aux_byte = K.storage_aux_byte;
+    q.rw = false;
+    q.written_value = u256_zero();
+    access_storage(P, sh, s, q);
+    dst0_update(P, sh, s, ps.dst0, d.dst0, q.read_value, false);
+  } else if (v == ZKW_LOG_STORAGE_WRITE) {  // :196-220
+    if (not_enough) return;
+    access_storage(P, sh, s, q);
+  } else if (v == ZKW_LOG_EVENT || v == ZKW_LOG_TO_L1) {  // :221-251; EventSink is replayed on the host
+    if (not_enough) {
+      if (v != ZKW_LOG_TO_L1) lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
+      return;
+    }
+    q.aux_byte = v == ZKW_LOG_EVENT ? K.event_aux_byte : K.l1_message_aux_byte;
+    q.rw = true;
+    emit_log(P, sh, s, q, ZKW_LQ_LOG);
+  } else {  // PrecompileCall :252-328
+    if (not_enough) {
+      dst0_update(P, sh, s, ps.dst0, d.dst0, u256_zero(), false);
+      return;
+    }
+    const u32 heap_page = s.base_page + 2;
+    if (q.key.w[4] == 0) q.key.w[4] = heap_page;  // memory_page_to_read  :273-283
+    if (q.key.w[5] == 0) q.key.w[5] = heap_page;  // memory_page_to_write :285-295
+    q.aux_byte = K.precompile_aux_byte;
+    q.rw = false;
+    q.written_value = u256_zero();
+    call_precompile(P, sh, s, q);
+    dst0_update(P, sh, s, ps.dst0, d.dst0, u256_from_u32(1), false);
+  }
+}
+
+// VersionedHashGeneric<ContractCodeSha256> (Appendix B): big-endian byte 0 = version, 1 = marker, 2-3 = words
+ZD void versioned_hash(const u256& h, bool& ok, u32& marker, u32& len_words, u256& stored) {
+  ok = (h.w[7] >> 24) == 1u;
+  marker = (h.w[7] >> 16) & 0xffu;
+  len_words = h.w[7] & 0xffffu;
+  stored = h;
+  stored.w[7] &= 0xff00ffffu;
+}
+
+// far_call.rs:35-613
+ZD void op_far_call(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+  const zkw_isa_consts& K = P.consts;
+  const u32 variant = ZKW_ATTR_VARIANT(d.attr);
+  s.flags &= FLAG_PENDING;  // :69
+  const bool is_static_call = ZKW_ATTR_FLAGS(d.attr) & 1u;
+  const bool is_call_shard = ZKW_ATTR_FLAGS(d.attr) & 2u;
+  const u32 handler = d.imm0;
+  u32 called[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) called[i] = ps.src1.w[i];
+  const bool dst_is_kernel = called[0] < 0x10000u && (called[1] | called[2] | called[3] | called[4]) == 0;
+  FatPtr abi = fat_ptr_from(ps.src0);
+  const u32 abi_ergs = ps.src0.w[6];
+  const u32 fwd = forward_type(ps.src0.w[7] & 0xffu);
+  const u32 abi_shard = (ps.src0.w[7] >> 8) & 0xffu;
+  bool constructor_call = ((ps.src0.w[7] >> 16) & 0xffu) != 0;
+  bool to_system = ((ps.src0.w[7] >> 24) & 0xffu) != 0;
+  constructor_call = constructor_call && s.is_kernel;  // :85
+  to_system = to_system && dst_is_kernel;               // :86
+  u32 prev[32];
+  entry_image_current(P, s, prev);
+  const u32 caller_shard = prev[E_SHARDS] & 0xffu;
+  const u32 remaining_ergs = s.ergs;
+  const u32 new_code_shard = is_call_shard ? abi_shard : caller_shard;
+  const u32 new_this_shard = variant == ZKW_FAR_DELEGATE ? caller_shard : new_code_shard;
+  const u32 new_base = s.mpc;  // :118
+  u256 code_hash;
+  bool map_to_trivial;
+  if (new_code_shard != 0 && !P.props.zkporter_is_available) {  // :123-129
+    code_hash = u256_zero();
+    map_to_trivial = true;
+  } else {
+    LogQ q;
+    q.timestamp = s.timestamp + 1;
+    q.tx_number = s.tx_number;
+    q.aux_byte = K.storage_aux_byte;
+    q.shard_id = new_code_shard;
+    q.address[0] = K.deployer_address_low;
+    q.address[1] = q.address[2] = q.address[3] = q.address[4] = 0;
+    q.key = u256_zero();
+#pragma unroll
+    for (int i = 0; i < 5; i++) q.key.w[i] = called[i];
+    q.read_value = u256_zero();
+    q.written_value = u256_zero();
+    q.rw = false;
+    q.rollback = false;
+    q.is_service = false;
+    access_storage(P, sh, s, q);  // :144-145
+    if (!lane_ok(s)) return;
+    const bool mask_aa = u256_is_zero(q.read_value) && !dst_is_kernel;
+    if (mask_aa) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        code_hash.w[2 * i] = (u32)P.props.default_aa_code_hash.l[i];
+        code_hash.w[2 * i + 1] = (u32)(P.props.default_aa_code_hash.l[i] >> 32);
+      }
+    } else {
+      code_hash = q.read_value;
+    }
+    map_to_trivial = false;
+  }
+  const u32 candidate_page = map_to_trivial ? 0u : new_base;  // :161-165
+  u32 exceptions = 0;
+  u32 code_len_words = 0;
+  bool ok;
+  u32 marker, vlen;
+  u256 stored;
+  versioned_hash(code_hash, ok, marker, vlen, stored);
+  if (ok) {
+    const bool at_rest = marker == 0, constructed = marker == 1;
+    if (!(at_rest || constructed)) {
+      exceptions |= 2u;  // INVALID_CODE_HASH_FORMAT
+      code_hash = u256_zero();
+    } else if ((!constructor_call && at_rest) || (constructor_call && constructed)) {
+      code_hash = stored;
+      code_len_words = vlen;
+    } else if (!dst_is_kernel) {  // :215-237 degrade to default AA
+      u256 aa;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        aa.w[2 * i] = (u32)P.props.default_aa_code_hash.l[i];
+        aa.w[2 * i + 1] = (u32)(P.props.default_aa_code_hash.l[i] >> 32);
+      }
+      bool aok;
+      u32 am, al;
+      u256 as;
+      versioned_hash(aa, aok, am, al, as);
+      if (!aok || am != 0) {
+        lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
+        return;
+      }
+      code_hash = aa;
+      code_len_words = al;
+    } else {
+      exceptions |= 32u;  // CALL_IN_NOW_CONSTRUCTED_SYSTEM_CONTRACT
+      code_hash = u256_zero();
+    }
+  } else {
+    exceptions |= 2u;
+    code_hash = u256_zero();
+  }
+  if (fwd == 1u && !ps.src0_ptr) exceptions |= 1u;  // :255-262
+  const u32 pve = fat_ptr_validate(abi, fwd != 1u);
+  if (pve) exceptions |= 16u;                             // MALFORMED_ABI_QUASI_POINTER
+  if (!(abi.offset <= abi.length)) exceptions |= 16u;     // validate_as_slice :280-282
+  if (fwd == 1u) {  // :285-314
+    abi.start = abi.start + abi.offset;
+    abi.length = abi.length - abi.offset;
+    abi.offset = 0;
+  } else if (fwd == 0u) {
+    abi.page = s.base_page + 2;
+  } else {
+    abi.page = s.base_page + 3;
+  }
+  if (exceptions) {  // :321-325
+    abi.offset = abi.page = abi.start = abi.length = 0;
+  }
+  u32 growth = 0;  // :330-369
+  if (fwd != 1u) {
+    u32 upper = abi.start + abi.length;
+    if (pve & FPV_DEREF_BEYOND) upper = 0xffffffffu;
+    const u32 bound = fwd == 0u ? s.heap_bound : s.aux_bound;
+    if (upper >= bound) {
+      growth = upper - bound;
+      if (fwd == 0u) s.heap_bound = upper; else s.aux_bound = upper;
+    }
+  }
+  const u32 growth_cost = growth * K.memory_growth_ergs_per_byte;
+  u32 after_growth;
+  if (remaining_ergs >= growth_cost) {
+    after_growth = remaining_ergs - growth_cost;
+  } else {
+    exceptions |= 8u;
+    after_growth = 0;
+  }
+  const u32 decommit_cost = K.ergs_per_code_word_decommittment * code_len_words;  // :423-424
+  u32 after_decommit;
+  if (after_growth >= decommit_cost) {
+    after_decommit = after_growth - decommit_cost;
+  } else {
+    exceptions |= 4u;
+    after_decommit = after_growth;
+  }
+  u32 mapped_code_page = 0, mapped_blob = 0;
+  if (exceptions) {  // :435-439
+    s.flags |= FLAG_PENDING;
+  } else {  // :441-455 decommit (helpers.rs:164-194 + SimpleDecommitter decommitter.rs:32-98)
+    u32 pre = 0xffffffffu;
+    for (u32 i = 0; i < P.n_preimages; i++) {
+      bool same = true;
+#pragma unroll
+      for (int k = 0; k < 8; k++) same = same && P.preimages[i].hash[k] == code_hash.w[k];
+      if (same) pre = i;
+    }
+    zkw_dev_history* hist = P.history + (u64)s.inst * P.F;
+    bool fresh = true;
+    u32 page = candidate_page;
+    for (u32 i = 0; i < s.n_history; i++) {
+      if (hist[i].preimage == pre && pre != 0xffffffffu) {
+        fresh = false;
+        page = hist[i].page;
+      }
+    }
+    if (pre == 0xffffffffu) {  // decommitter.rs:54-56: Err propagates out of cycle()
+      lane_fail(s, ZKW_STATUS_UNKNOWN_CODE_HASH);
+      return;
+    }
+    const u32 blob = P.preimages[pre].blob;
+    const u32 blob_len = P.blob_dir[blob].y & 0xffffu;  // `values.len() as u16`
+    if (fresh) {
+      if (s.n_history >= P.F) {
+        lane_fail(s, ZKW_STATUS_LIMIT);
+        return;
+      }
+      hist[s.n_history].preimage = pre;
+      hist[s.n_history].page = page;
+      s.n_history++;
+    } else {
+      after_decommit += decommit_cost;  // :450-453 refund
+    }
+    uint4* a = aux_alloc(P, sh, s, ZKW_AUX_DECOMMIT, fresh ? 1u : 0u, s.timestamp + 1, page, blob_len | (blob << 16));
+    if (a) {
+      a[1] = u256_lo4(code_hash);
+      a[2] = u256_hi4(code_hash);
+#pragma unroll
+      for (int i = 3; i < 16; i++) a[i] = make_uint4(0, 0, 0, 0);
+    }
+    mapped_code_page = page;
+    mapped_blob = blob;
+  }
+  // :468-487
+  const u32 max_passable = (after_decommit / 64u) * 63u;
+  const u32 leftover = after_decommit - max_passable;
+  u32 passed, remaining_here;
+  if (max_passable < abi_ergs) {
+    passed = max_passable;
+    remaining_here = leftover;
+  } else {
+    passed = abi_ergs;
+    remaining_here = leftover + (max_passable - abi_ergs);
+  }
+  s.ergs = remaining_here;  // :490-495
+  s.pc = ps.new_pc;
+  prev[E_SP_PC] = (s.sp & 0xffffu) | (s.pc << 16);
+  prev[E_ERGS] = s.ergs;
+  prev[E_HEAP_BOUND] = s.heap_bound;
+  prev[E_AUX_BOUND] = s.aux_bound;
+  const u32 new_static = (s.is_static | (is_static_call ? 1u : 0u)) ? 1u : 0u;
+  s.mpc += K.new_memory_pages_per_far_call;  // :503
+  s.cold_dirty = 1;
+  bool r15p;
+  const u256 r15 = reg_read(sh, s, 15, r15p);  // CALL_IMPLICIT_PARAMETER_REG_IDX :506-508
+  u32 next[32];
+#pragma unroll
+  for (int i = 0; i < 32; i++) next[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    u32 this_a, sender_a;
+    if (variant == ZKW_FAR_NORMAL) {
+      this_a = called[i];
+      sender_a = prev[E_THIS + i];
+    } else if (variant == ZKW_FAR_DELEGATE) {
+      this_a = prev[E_THIS + i];
+      sender_a = prev[E_SENDER + i];
+    } else {
+      this_a = called[i];
+      sender_a = r15.w[i];
+    }
+    next[E_THIS + i] = this_a;
+    next[E_SENDER + i] = sender_a;
+    next[E_CODE_ADDR + i] = called[i];
+  }
+  next[E_BASE_PAGE] = new_base;
+  next[E_CODE_PAGE] = mapped_code_page;
+  next[E_SP_PC] = K.initial_sp_on_far_call > 0xffffu ? 0xffffu : K.initial_sp_on_far_call;  // pc = 0
+  next[E_EH_FLAGS] = (handler & 0xffffu) | (new_static << 16);                               // is_local_frame = false
+  next[E_ERGS] = passed;
+  next[E_SHARDS] = new_this_shard | (caller_shard << 8) | (new_code_shard << 16);
+#pragma unroll
+  for (int i = 0; i < 4; i++) next[E_CTX + i] = variant == ZKW_FAR_DELEGATE ? prev[E_CTX + i] : s.ctx_reg[i];
+  next[E_HEAP_BOUND] = K.new_frame_memory_stipend;
+  next[E_AUX_BOUND] = K.new_frame_memory_stipend;
+  next[E_CODE_BLOB] = mapped_blob;
+  s.ctx_reg[0] = s.ctx_reg[1] = s.ctx_reg[2] = s.ctx_reg[3] = 0;  // :558
+  // memory.start_global_frame (memory.rs:573-657): a fresh arena slot, pages lazily zero
+  const u32 new_slot = s.next_slot;
+  if (new_slot >= P.F) {
+    lane_fail(s, ZKW_STATUS_LIMIT);
+    return;
+  }
+  s.next_slot++;
+  next[E_SLOT] = new_slot;
+  {
+    zkw_dev_frame_meta* fm = P.frames + (u64)s.inst * P.F + new_slot;
+    fm->base_page = new_base;
+    fm->stack_hwm = 0;
+    fm->heap_hwm = 0;
+    fm->aux_hwm = 0;
+  }
+  start_frame(P, sh, s, prev, next, true);  // :562
+  if (!lane_ok(s)) return;
+  // registers :573-610
+  reg_write(sh, s, 1, fat_ptr_to_u256(abi), true);
+  u256 r2 = u256_zero();
+  r2.w[0] = (constructor_call ? 1u : 0u) | (to_system ? 2u : 0u);
+  reg_write(sh, s, 2, r2, false);
+  if (!to_system) {
+    for (u32 r = 3; r <= 12; r++) reg_write(sh, s, r, u256_zero(), false);
+  } else {
+    s.ptr_bitmap &= ~(0x3ffu << 2);  // CALL_SYSTEM_ABI_REGISTERS = 2..12: drop the pointer markers only
+  }
+  reg_write(sh, s, 13, u256_zero(), false);
+  reg_write(sh, s, 14, u256_zero(), false);
+  reg_write(sh, s, 15, u256_zero(), false);
+}
+
+// ret.rs:9-265
+ZD void op_ret(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+  const zkw_isa_consts& K = P.consts;
+  u32 variant = ZKW_ATTR_VARIANT(d.attr);
+  s.flags &= FLAG_PENDING;  // :27
+  u256 src0 = ps.src0;
+  bool src0_ptr = ps.src0_ptr;
+  if (variant == ZKW_RET_PANIC) {
+    src0 = u256_zero();
+    src0_ptr = false;
+  }
+  FatPtr ptr = fat_ptr_from(src0);
+  const u32 fwd = forward_type(src0.w[7] & 0xffu);
+  bool to_label = ZKW_ATTR_FLAGS(d.attr) & 1u;
+  const u32 label_pc = d.imm0;
+  u32 pve = 0;
+  const bool local = s.is_local != 0;
+  if (!local) {  // :58-96
+    if (fwd == 1u) {
+      if (!src0_ptr) variant = ZKW_RET_PANIC;
+      if (ptr.page < s.base_page) variant = ZKW_RET_PANIC;
+    }
+    pve = fat_ptr_validate(ptr, fwd != 1u);
+    if (pve) variant = ZKW_RET_PANIC;
+    if (!(ptr.offset <= ptr.length)) variant = ZKW_RET_PANIC;
+    if (variant == ZKW_RET_PANIC) ptr.offset = ptr.page = ptr.start = ptr.length = 0;
+  }
+  u32 ergs_remaining = s.ergs;
+  if (!local) {  // :101-190
+    if (variant == ZKW_RET_OK || variant == ZKW_RET_REVERT) {
+      if (fwd == 1u) {
+        ptr.start = ptr.start + ptr.offset;
+        ptr.length = ptr.length - ptr.offset;
+        ptr.offset = 0;
+      } else if (fwd == 0u) {
+        ptr.page = s.base_page + 2;
+      } else {
+        ptr.page = s.base_page + 3;
+      }
+    }
+    u32 growth = 0;
+    if (fwd != 1u) {
+      u32 upper = ptr.start + ptr.length;
+      if (pve & FPV_DEREF_BEYOND) upper = 0xffffffffu;
+      const u32 bound = fwd == 0u ? s.heap_bound : s.aux_bound;
+      growth = upper < bound ? 0u : upper - bound;
+    }
+    const u32 cost = growth * K.memory_growth_ergs_per_byte;
+    if (ergs_remaining >= cost) {
+      ergs_remaining -= cost;
+    } else {
+      ergs_remaining = 0;
+      variant = ZKW_RET_PANIC;
+      ptr.offset = ptr.page = ptr.start = ptr.length = 0;
+    }
+  }
+  const bool panicked = variant == ZKW_RET_REVERT || variant == ZKW_RET_PANIC;  // :196
+  // finish_frame (helpers.rs:248-264)
+  const u32* fin = (const u32*)entry_ptr(P, s, s.depth);
+  const u32 fin_eh = fin[E_EH_FLAGS] & 0xffffu;
+  const u32 fin_mark = fin[E_JOURNAL_MARK];
+  const u32 fin_heap_bound = s.heap_bound, fin_aux_bound = s.aux_bound;
+  storage_finish_frame(P, s, fin_mark, panicked);
+  {
+    uint4* a = aux_alloc(P, sh, s, ZKW_AUX_FRAME_FINISH, panicked ? 1u : 0u, 0, 0, 0);
+    if (a) {
+#pragma unroll
+      for (int i = 1; i < 16; i++) a[i] = make_uint4(0, 0, 0, 0);
+    }
+  }
+  if (s.depth == 0) {  // pop on an empty callstack: unwrap() panic (execution_stack.rs:112)
+    lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
+    return;
+  }
+  hwm_writeback(P, s);
+  s.depth--;
+  frame_load(P, s);
+  to_label = to_label && local;  // :202
+  if (!local) {  // :204-236; memory.finish_global_frame (memory.rs:660-758) is pure bookkeeping here: arena slots are never recycled
+    reg_write(sh, s, 1, fat_ptr_to_u256(ptr), true);
+    for (u32 r = 2; r <= 15; r++) reg_write(sh, s, r, u256_zero(), false);
+    if (s.ctx_reg[0] | s.ctx_reg[1] | s.ctx_reg[2] | s.ctx_reg[3]) s.cold_dirty = 1;
+    s.ctx_reg[0] = s.ctx_reg[1] = s.ctx_reg[2] = s.ctx_reg[3] = 0;
+  }
+  s.ergs += ergs_remaining;  // :243
+  if (to_label) s.pc = label_pc;
+  else if (panicked) s.pc = fin_eh;
+  if (local) {  // :254-260
+    if (fin_heap_bound < s.heap_bound || fin_aux_bound < s.aux_bound) {
+      lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
+      return;
+    }
+    s.heap_bound = fin_heap_bound;
+    s.aux_bound = fin_aux_bound;
+  }
+  if (variant == ZKW_RET_PANIC) s.flags |= FLAG_LT;  // :262-264
+}
+
+// ---------------------------------------------------------------------------------------------
+// precompiles: see zkw_precompiles.hip.h (keccak256 / sha256 round functions over the lane's memory)
+// ---------------------------------------------------------------------------------------------
+#include "zkw_precompiles.hip.h"
+
+// helpers.rs:196-223 + DefaultPrecompilesProcessor dispatch on the low 16 address bits
+ZD void call_precompile(const zkw_kparams& P, Shared& sh, Lane& s, const LogQ& q) {
+  emit_log(P, sh, s, q, ZKW_LQ_LOG);
+  const u32 addr_low = q.address[0] & 0xffffu;
+  if (addr_low == P.consts.keccak_precompile_address) precompile_keccak256(P, sh, s, q);
+  else if (addr_low == P.consts.sha256_precompile_address) precompile_sha256(P, sh, s, q);
+  // anything else (incl. ecrecover, not built yet) behaves as an unknown precompile: no memory traffic
+}
+
+// =============================================================================================
+// the cycle kernel
+// =============================================================================================
+__global__ void __launch_bounds__(ZKW_WAVE) zkw_cycle_kernel(zkw_kparams P) {
+  extern __shared__ uint4 zkw_lds[];
+  const u32 tid = threadIdx.x;
+  const u32 wave = blockIdx.x;
+  Shared sh;
+  sh.L = P.L;
+  sh.isa = (uint2*)zkw_lds;                                     // 16 KB
+  sh.cursor = (u32*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2);          // 16 B
+  sh.regs = zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + 1;                // 30 * L * 16 B
+  sh.krow = (u32*)(sh.regs + ZKW_REG_CHUNKS * P.L);              // 34 * L * 4 B
+  // stage the packed ISA table in LDS (all 64 threads, 16 B each per step)
+  {
+    const uint4* src = (const uint4*)P.isa;
+    uint4* dst = (uint4*)sh.isa;
+    for (u32 i = tid; i < ZKW_ISA_TABLE_SIZE / 2; i += blockDim.x) dst[i] = src[i];
+  }
+  for (u32 i = tid; i < 4; i += blockDim.x) sh.cursor[i] = P.cursors[wave * 4 + i];
+  __syncthreads();
+
+  const u32 inst = wave * P.L + tid;
+  const bool exists = tid < P.L && inst < P.n_instances;
+  Lane s;
+  s.inst = inst;
+  s.wave = wave;
+  s.lane = tid;
+  if (exists) {
+    const zkw_dev_scalars sc = P.scalars[inst];
+#pragma unroll
+    for (int i = 0; i < 8; i++) s.pcw[i] = sc.prev_code_word[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) s.ctx_reg[i] = sc.ctx_u128_reg[i];
+    s.ptr_bitmap = sc.ptr_bitmap; s.flags = sc.flags; s.prev_code_page = sc.prev_code_page; s.timestamp = sc.timestamp;
+    s.cycle_counter = sc.cycle_counter; s.spent_pubdata = sc.spent_pubdata; s.mpc = sc.memory_page_counter; s.ergs_pp = sc.ergs_per_pubdata;
+    s.tx_number = sc.tx_number; s.prev_super_pc = sc.prev_super_pc; s.depth = sc.depth; s.status = sc.status; s.n_cycles = sc.n_cycles;
+    s.first_dyn = sc.first_dynamic_page; s.n_initial_slots = sc.n_initial_slots; s.next_slot = sc.next_slot; s.journal_len = sc.journal_len;
+    s.n_history = sc.n_history;
+    frame_load(P, s);
+    // register file -> LDS
+    const uint4* rg = P.regs + (u64)wave * ZKW_REG_CHUNKS * P.L;
+#pragma unroll 6
+    for (int c = 0; c < ZKW_REG_CHUNKS; c++) sh_reg(sh, c, tid) = rg[(u64)c * P.L + tid];
+  } else {
+    s.status = ZKW_STATUS_ENDED;  // parked lane
+    s.depth = 0;
+    s.n_cycles = 0;
+  }
+
+  u32 k = 0;
+  for (; k < P.run_cycles; k++) {
+    // directory: stream cursors at the start of wave-cycle (cycle_base + k)
+    for (u32 i = tid; i < 4; i += blockDim.x) P.dir[((u64)wave * (P.max_cycles + 1) + P.cycle_base + k) * 4 + i] = ((volatile u32*)sh.cursor)[i];
+    bool active = exists && s.status == ZKW_STATUS_RUNNING;
+    if (active && s.depth == 0) {  // execution_has_ended() (mod.rs:96-98): callers stop cycling here
+      s.status = ZKW_STATUS_ENDED;
+      active = false;
+    }
+    if (__ballot(active) == 0) break;
+    if (active) {
+      s.seq = 0; s.n_mem = 0; s.n_log = 0; s.n_aux = 0; s.cold_dirty = 0;
+      // ----------------------------------------------------------------------------------------
+      // read_and_decode (cycle.rs:19-236)
+      // ----------------------------------------------------------------------------------------
+      const bool pending = (s.flags & FLAG_PENDING) != 0;
+      const u32 super_pc = s.pc >> 2, sub_pc = s.pc & 3u;
+      u64 enc;
+      if (!pending) {
+        if (s.code_page != s.prev_code_page || s.prev_super_pc != super_pc) {  // :59-95
+          const u256 word = code_read(P, s, super_pc);
+          emit_mem(P, sh, s, s.timestamp, ZKW_MEM_CODE, s.code_page, super_pc, word, false, false, 0);
+#pragma unroll
+          for (int i = 0; i < 8; i++) s.pcw[i] = word.w[i];
+          s.prev_super_pc = super_pc;
+        }
+        // integer_representaiton_from_u256: opcode k of a word is u64 limb 3-k (:86-94)
+        const u32 lo = sub_pc == 0 ? s.pcw[6] : (sub_pc == 1 ? s.pcw[4] : (sub_pc == 2 ? s.pcw[2] : s.pcw[0]));
+        const u32 hi = sub_pc == 0 ? s.pcw[7] : (sub_pc == 1 ? s.pcw[5] : (sub_pc == 2 ? s.pcw[3] : s.pcw[1]));
+        enc = ((u64)hi << 32) | lo;
+      } else {  // :104-115
+        s.flags &= ~FLAG_PENDING;
+        s.prev_super_pc = super_pc;
+        enc = P.consts.exception_revert_encoding;
+      }
+      s.prev_code_page = s.code_page;  // :49
+      Decoded d;
+      const u32 raw_idx = (u32)enc & (ZKW_ISA_TABLE_SIZE - 1);
+      const uint2 isa_e = sh.isa[raw_idx];
+      d.attr = isa_e.x;
+      d.cond = ((u32)enc >> 13) & 7u;
+      d.src0 = ((u32)enc >> 16) & 15u;
+      d.src1 = ((u32)enc >> 20) & 15u;
+      d.dst0 = ((u32)enc >> 24) & 15u;
+      d.dst1 = ((u32)enc >> 28) & 15u;
+      d.imm0 = (u32)(enc >> 32) & 0xffffu;
+      d.imm1 = (u32)(enc >> 48);
+      bool err = (ZKW_ATTR_PROPS(d.attr) & ZKW_PROP_EXPLICIT_PANIC) != 0;  // :142-144
+      const u32 price = isa_e.y;                                            // :147-148
+      if (s.ergs < price) {                                                 // :153-161
+        s.ergs = 0;
+        err = true;
+      } else {
+        s.ergs -= price;
+      }
+      if ((ZKW_ATTR_PROPS(d.attr) & ZKW_PROP_KERNEL_ONLY) && !s.is_kernel) err = true;  // :174-176
+      if (!(ZKW_ATTR_PROPS(d.attr) & ZKW_PROP_STATIC_OK) && s.is_static) err = true;   // :178-180
+      if (s.depth == P.consts.vm_max_stack_depth) err = true;                           // :182-184
+      if (err) {  // mask_into_panic :187-190
+        d.attr = sh.isa[P.consts.panic_variant_idx].x;
+        d.cond = d.src0 = d.src1 = d.dst0 = d.dst1 = d.imm0 = d.imm1 = 0;
+      }
+      const bool f_lt = s.flags & FLAG_LT, f_eq = s.flags & FLAG_EQ, f_gt = s.flags & FLAG_GT;
+      bool resolved;
+      switch (d.cond) {  // :193-209
+        case 0: resolved = true; break;
+        case 1: resolved = f_gt; break;
+        case 2: resolved = f_lt; break;
+        case 3: resolved = f_eq; break;
+        case 4: resolved = f_gt || f_eq; break;
+        case 5: resolved = f_lt || f_eq; break;
+        case 6: resolved = !f_eq; break;
+        default: resolved = f_gt || f_lt; break;
+      }
+      if (!resolved && !err) {  // mask_into_nop :212-217
+        d.attr = sh.isa[P.consts.nop_variant_idx].x;
+        d.cond = d.src0 = d.src1 = d.dst0 = d.dst1 = d.imm0 = d.imm1 = 0;
+      }
+      const u32 opcode = ZKW_ATTR_OPCODE(d.attr);
+      const u32 props = ZKW_ATTR_PROPS(d.attr);
+      const bool set_flags = ZKW_ATTR_FLAGS(d.attr) & 1u;
+      // ----------------------------------------------------------------------------------------
+      // operands (cycle.rs:275-350)
+      // ----------------------------------------------------------------------------------------
+      Pre ps;
+      u32 sp = s.sp;
+      bool src0_reg_ptr;
+      const u256 src0_reg = reg_read(sh, s, d.src0, src0_reg_ptr);
+      Operand src0_loc = compute_address(P, s, sp, src0_reg, d.imm0, ZKW_ATTR_SRC0(d.attr), false);
+      bool dummy_ptr;
+      const u256 dst0_reg = reg_read(sh, s, d.dst0, dummy_ptr);
+      ps.dst0 = compute_address(P, s, sp, dst0_reg, d.imm1, ZKW_ATTR_DST0(d.attr), true);
+      s.sp = sp;                                            // :297
+      if (opcode == ZKW_OP_NOP) src0_loc.has_loc = false;  // :298-301
+      u256 src0_mem = u256_zero();
+      bool src0_mem_ptr = false;
+      if (src0_loc.has_loc) {  // :304-325
+        if (src0_loc.type == ZKW_MEM_CODE) src0_mem = code_read(P, s, src0_loc.index);
+        else src0_mem = stack_read(P, s, src0_loc.index, src0_mem_ptr);
+        emit_mem(P, sh, s, s.timestamp, src0_loc.type, src0_loc.page, src0_loc.index, src0_mem, src0_mem_ptr, false, 0);
+      }
+      const u32 src0_mode = ZKW_ATTR_SRC0(d.attr);
+      if (src0_mode == ZKW_MODE_REG) {
+        ps.src0 = src0_reg;
+        ps.src0_ptr = src0_reg_ptr;
+      } else if (src0_mode == ZKW_MODE_IMM) {
+        ps.src0 = u256_from_u32(d.imm0);
+        ps.src0_ptr = false;
+      } else {
+        ps.src0 = src0_mem;
+        ps.src0_ptr = src0_mem_ptr;
+      }
+      ps.src1 = reg_read(sh, s, d.src1, ps.src1_ptr);  // :339
+      if (props & ZKW_PROP_SWAP) {                     // :341-345
+        const u256 t = ps.src0;
+        ps.src0 = ps.src1;
+        ps.src1 = t;
+        const bool tp = ps.src0_ptr;
+        ps.src0_ptr = ps.src1_ptr;
+        ps.src1_ptr = tp;
+      }
+      ps.new_pc = (s.pc + 1) & 0xffffu;  // :347-350 (never a skip cycle here)
+      if (!s.is_kernel) {                // erase_fat_pointer_metadata :374-396
+        if (!(props & ZKW_PROP_SRC0_PTR_OK) && ps.src0_ptr) {
+          ps.src0.w[1] = 0;
+          ps.src0.w[2] = 0;
+          ps.src0_ptr = false;
+        }
+        if (!(props & ZKW_PROP_SRC1_PTR_OK) && ps.src1_ptr) {
+          ps.src1.w[1] = 0;
+          ps.src1.w[2] = 0;
+          ps.src1_ptr = false;
+        }
+      }
+      // ----------------------------------------------------------------------------------------
+      // apply (opcodes/parsing.rs:47-79)
+      // ----------------------------------------------------------------------------------------
+      if (lane_ok(s)) {
+        switch (opcode) {
+          case ZKW_OP_NOP: s.pc = ps.new_pc; break;  // noop.rs:16-19
+          case ZKW_OP_ADD:
+          case ZKW_OP_SUB: {  // add.rs:35-53, sub.rs:35-54
+            s.pc = ps.new_pc;
+            bool of;
+            const u256 r = opcode == ZKW_OP_ADD ? u256_add(ps.src0, ps.src1, of) : u256_sub(ps.src0, ps.src1, of);
+            const bool eq = u256_is_zero(r);
+            if (set_flags) set_flags3(s, of, eq, !eq && !of);
+            dst0_update(P, sh, s, ps.dst0, d.dst0, r, false);
+            break;
+          }
+          case ZKW_OP_MUL: {  // mul.rs:35-65
+            s.pc = ps.new_pc;
+            u256 lo, hi;
+            u256_mul(ps.src0, ps.src1, lo, hi);
+            if (set_flags) {
+              const bool of = !u256_is_zero(hi), eq = u256_is_zero(lo);
+              set_flags3(s, of, eq, !of && !eq);
+            }
+            dst0_update(P, sh, s, ps.dst0, d.dst0, lo, false);
+            reg_write(sh, s, d.dst1, hi, false);
+            break;
+          }
+          case ZKW_OP_DIV: {  // div.rs:35-75
+            s.pc = ps.new_pc;
+            if (u256_is_zero(ps.src1)) {
+              if (set_flags) set_flags3(s, true, false, false);
+              dst0_update(P, sh, s, ps.dst0, d.dst0, u256_zero(), false);
+              reg_write(sh, s, d.dst1, u256_zero(), false);
+            } else {
+              u256 q, r;
+              u256_divmod(ps.src0, ps.src1, q, r);
+              if (set_flags) set_flags3(s, false, u256_is_zero(q), u256_is_zero(r));
+              dst0_update(P, sh, s, ps.dst0, d.dst0, q, false);
+              reg_write(sh, s, d.dst1, r, false);
+            }
+            break;
+          }
+          case ZKW_OP_JUMP: s.pc = clip16(P, ps.src0); break;  // jump.rs:23-25
+          case ZKW_OP_CONTEXT: op_context(P, sh, s, d, ps); break;
+          case ZKW_OP_SHIFT: {  // shift.rs:44-78
+            s.pc = ps.new_pc;
+            const u32 n = ps.src1.w[0] & 0xffu;
+            const u32 v = ZKW_ATTR_VARIANT(d.attr);
+            const bool cyclic = v == ZKW_SHIFT_ROL || v == ZKW_SHIFT_ROR;
+            const bool right = v == ZKW_SHIFT_SHR || v == ZKW_SHIFT_ROR;
+            u256 r;
+            if (right) {
+              r = u256_shr(ps.src0, n);
+              if (cyclic) r = u256_or(r, u256_shl(ps.src0, 256u - n));
+            } else {
+              r = u256_shl(ps.src0, n);
+              if (cyclic) r = u256_or(r, u256_shr(ps.src0, 256u - n));
+            }
+            if (set_flags) set_flags3(s, false, u256_is_zero(r), false);
+            dst0_update(P, sh, s, ps.dst0, d.dst0, r, false);
+            break;
+          }
+          case ZKW_OP_BINOP: {  // binop.rs:42-61
+            s.pc = ps.new_pc;
+            const u32 v = ZKW_ATTR_VARIANT(d.attr);
+            const u256 r = v == ZKW_BINOP_XOR ? u256_xor(ps.src0, ps.src1) : (v == ZKW_BINOP_AND ? u256_and(ps.src0, ps.src1) : u256_or(ps.src0, ps.src1));
+            if (set_flags) set_flags3(s, false, u256_is_zero(r), false);
+            dst0_update(P, sh, s, ps.dst0, d.dst0, r, false);
+            break;
+          }
+          case ZKW_OP_PTR: op_ptr(P, sh, s, d, ps); break;
+          case ZKW_OP_LOG: op_log(P, sh, s, d, ps); break;
+          case ZKW_OP_NEAR_CALL: op_near_call(P, sh, s, d, ps); break;
+          case ZKW_OP_FAR_CALL: op_far_call(P, sh, s, d, ps); break;
+          case ZKW_OP_RET: op_ret(P, sh, s, d, ps); break;
+          case ZKW_OP_UMA: op_uma(P, sh, s, d, ps); break;
+          default: lane_fail(s, ZKW_STATUS_REFERENCE_PANIC); break;  // Opcode::Invalid => unreachable!() parsing.rs:77
+        }
+      }
+      // ----------------------------------------------------------------------------------------
+      // end of cycle (cycle.rs:408-413)
+      // ----------------------------------------------------------------------------------------
+      if (lane_ok(s)) {
+        s.timestamp += P.consts.time_delta_per_cycle;
+        s.cycle_counter += 1;
+        if (s.cold_dirty) {
+          uint4* a = aux_alloc(P, sh, s, ZKW_AUX_COLD_STATE, 0, s.spent_pubdata, s.ergs_pp, s.tx_number);
+          if (a) {
+            a[1] = make_uint4(s.ctx_reg[0], s.ctx_reg[1], s.ctx_reg[2], s.ctx_reg[3]);
+            a[2] = make_uint4(s.mpc, 0, 0, 0);
+#pragma unroll
+            for (int i = 3; i < 16; i++) a[i] = make_uint4(0, 0, 0, 0);
+          }
+        }
+      }
+      if (lane_ok(s)) {
+        // CycleRecord: 30 register chunks straight from LDS + 2 tail chunks, coalesced across lanes
+        uint4* rec = P.rec + ((u64)wave * P.max_cycles + (P.cycle_base + k)) * ZKW_REC_CHUNKS * P.L;
+#pragma unroll 6
+        for (int c = 0; c < ZKW_REG_CHUNKS; c++) rec[(u64)c * P.L + tid] = sh_reg(sh, c, tid);
+        const u32 cnt = (s.n_mem > 255u ? 255u : s.n_mem) | ((s.n_log > 255u ? 255u : s.n_log) << 8) | ((s.n_aux > 255u ? 255u : s.n_aux) << 16);
+        rec[(u64)30 * P.L + tid] = make_uint4((s.ptr_bitmap & 0xffffu) | ((s.flags & 0xfu) << 16), (s.pc & 0xffffu) | (s.sp << 16), s.ergs, s.timestamp);
+        rec[(u64)31 * P.L + tid] = make_uint4(s.heap_bound, s.aux_bound, (s.depth & 0xffffu) | (s.prev_super_pc << 16), cnt);
+        s.n_cycles++;
+      }
+    }
+  }
+  // final directory entry
+  for (u32 i = tid; i < 4; i += blockDim.x) {
+    const u32 cur = ((volatile u32*)sh.cursor)[i];
+    P.dir[((u64)wave * (P.max_cycles + 1) + P.cycle_base + k) * 4 + i] = cur;
+    P.cursors[wave * 4 + i] = cur;
+  }
+  if (exists) {
+    if (s.status == ZKW_STATUS_RUNNING && s.depth == 0) s.status = ZKW_STATUS_ENDED;
+    // state write-back so that a later run continues / the host can read the final state
+    frame_writeback(P, s);
+    hwm_writeback(P, s);
+    zkw_dev_scalars sc;
+#pragma unroll
+    for (int i = 0; i < 8; i++) sc.prev_code_word[i] = s.pcw[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) sc.ctx_u128_reg[i] = s.ctx_reg[i];
+    sc.ptr_bitmap = s.ptr_bitmap; sc.flags = s.flags; sc.prev_code_page = s.prev_code_page; sc.timestamp = s.timestamp;
+    sc.cycle_counter = s.cycle_counter; sc.spent_pubdata = s.spent_pubdata; sc.memory_page_counter = s.mpc;
+    sc.absolute_execution_step = P.scalars[inst].absolute_execution_step; sc.ergs_per_pubdata = s.ergs_pp; sc.tx_number = s.tx_number;
+    sc.prev_super_pc = s.prev_super_pc; sc.depth = s.depth; sc.status = s.status; sc.n_cycles = s.n_cycles; sc.first_dynamic_page = s.first_dyn;
+    sc.n_initial_slots = s.n_initial_slots; sc.next_slot = s.next_slot; sc.journal_len = s.journal_len; sc.n_history = s.n_history;
+    sc.reserved[0] = 0;
+    P.scalars[inst] = sc;
+    uint4* rg = P.regs + (u64)wave * ZKW_REG_CHUNKS * P.L;
+#pragma unroll 6
+    for (int c = 0; c < ZKW_REG_CHUNKS; c++) rg[(u64)c * P.L + tid] = sh_reg(sh, c, tid);
+  }
+}
+
+// dynamic LDS per workgroup: ISA table + cursors + per-lane register file and Keccak row
+extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L) { return ZKW_ISA_TABLE_SIZE * 8 + 16 + L * (ZKW_REG_CHUNKS * 16 + 34 * 4); }
+
+// host-callable launcher (keeps <<<>>> out of the runtime)
+// queue commitments are built in a later milestone
+extern "C" hipError_t zkw_launch_commit_kernel(const zkw_kparams*, uint64_t*, hipStream_t) { return hipErrorNotSupported; }
+
+extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_kparams* P, hipStream_t stream) {
+  hipLaunchKernelGGL(zkw_cycle_kernel, dim3(P->n_waves), dim3(P->wave_threads), zkw_cycle_kernel_lds_bytes(P->L), stream, *P);
+  return hipGetLastError();
+}

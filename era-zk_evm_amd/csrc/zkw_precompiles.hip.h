@@ -1,0 +1,175 @@
+// Precompile round functions on device: keccak256 and sha256 over the calling lane's memory.
+//
+// Reference call site: VmState::call_precompile (src/vm_state/helpers.rs:196-223) ->
+// DefaultPrecompilesProcessor::execute_precompile (zk_evm_abstractions @ v1.4.1, not on disk; the
+// restated semantics and their pinning are documented in oracle/vm.cpp and DESIGN.md §precompiles).
+// Observable behaviour reproduced here: which memory words are read (each input word once, in
+// order, MemoryType::FatPointer for keccak / Heap for sha256, at query.timestamp), the digest, and
+// the single result write (MemoryType::Heap, at query.timestamp + 1).  One message per lane; the
+// Keccak state (25 x u64) and the SHA-256 schedule stay in VGPRs with static indexing, the
+// 136-byte Keccak rate block is assembled byte-wise in a per-lane LDS row.
+#pragma once
+
+__device__ const u64 ZKW_KECCAK_RC[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL, 0x0000000080000001ULL,
+    0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+    0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL,
+    0x000000000000800aULL, 0x800000008000000aULL, 0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+
+__device__ const u32 ZKW_SHA256_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+ZD u64 zk_rotl64(u64 x, int n) { return (x << n) | (x >> (64 - n)); }
+
+// Keccak-f[1600], state in 25 statically indexed u64
+ZD void zk_keccak_f1600(u64 a[25]) {
+  for (int round = 0; round < 24; round++) {
+    u64 c[5];
+#pragma unroll
+    for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+#pragma unroll
+    for (int x = 0; x < 5; x++) {
+      const u64 dd = c[(x + 4) % 5] ^ zk_rotl64(c[(x + 1) % 5], 1);
+#pragma unroll
+      for (int y = 0; y < 25; y += 5) a[y + x] ^= dd;
+    }
+    // rho + pi (explicit chain, static indices)
+    u64 t = a[1], b;
+#define ZK_RP(j, r) b = a[j]; a[j] = zk_rotl64(t, r); t = b;
+    ZK_RP(10, 1) ZK_RP(7, 3) ZK_RP(11, 6) ZK_RP(17, 10) ZK_RP(18, 15) ZK_RP(3, 21) ZK_RP(5, 28) ZK_RP(16, 36) ZK_RP(8, 45) ZK_RP(21, 55) ZK_RP(24, 2)
+    ZK_RP(4, 14) ZK_RP(15, 27) ZK_RP(23, 41) ZK_RP(19, 56) ZK_RP(13, 8) ZK_RP(12, 25) ZK_RP(2, 43) ZK_RP(20, 62) ZK_RP(14, 18) ZK_RP(22, 39)
+    ZK_RP(9, 61) ZK_RP(6, 20) ZK_RP(1, 44)
+#undef ZK_RP
+#pragma unroll
+    for (int y = 0; y < 25; y += 5) {
+      u64 r0 = a[y], r1 = a[y + 1], r2 = a[y + 2], r3 = a[y + 3], r4 = a[y + 4];
+      a[y] = r0 ^ (~r1 & r2);
+      a[y + 1] = r1 ^ (~r2 & r3);
+      a[y + 2] = r2 ^ (~r3 & r4);
+      a[y + 3] = r3 ^ (~r4 & r0);
+      a[y + 4] = r4 ^ (~r0 & r1);
+    }
+    a[0] ^= ZKW_KECCAK_RC[round];
+  }
+}
+
+#define ZKW_KECCAK_RATE 136
+#define ZKW_KROW_WORDS 34 /* 136 / 4 */
+
+ZD void kbuf_set_byte(Shared& sh, u32 lane, u32 pos, u32 byte) {
+  u32* w = &sh.krow[(pos >> 2) * sh.L + lane];  // [dword][lane]: conflict-free across lanes
+  const u32 shf = (pos & 3u) * 8u;
+  *w = (*w & ~(0xffu << shf)) | (byte << shf);
+}
+
+ZD void keccak_absorb_block(Shared& sh, u32 lane, u64 st[25]) {
+#pragma unroll
+  for (int i = 0; i < 17; i++) {
+    const u64 w = (u64)sh.krow[(2 * i) * sh.L + lane] | ((u64)sh.krow[(2 * i + 1) * sh.L + lane] << 32);
+    st[i] ^= w;
+  }
+  zk_keccak_f1600(st);
+}
+
+// keccak256_rounds_function: input = `input_memory_length` bytes at byte offset `input_memory_offset`
+// of page `memory_page_to_read`; output = one big-endian word at word `output_memory_offset` of
+// `memory_page_to_write` (reference test src/testing/tests/precompiles/keccak256.rs:99-139).
+ZD void precompile_keccak256(const zkw_kparams& P, Shared& sh, Lane& s, const LogQ& q) {
+  const u32 in_off = q.key.w[0], in_len = q.key.w[1], out_off = q.key.w[2];
+  const u32 page_r = q.key.w[4], page_w = q.key.w[5];
+  u64 st[25];
+#pragma unroll
+  for (int i = 0; i < 25; i++) st[i] = 0;
+  u32 fill = 0;
+  u32 byte_off = in_off, left = in_len;
+  while (left > 0 && lane_ok(s)) {
+    const u32 widx = byte_off >> 5, unal = byte_off & 31u;
+    const u32 take = left < 32u - unal ? left : 32u - unal;
+    const u256 word = fat_ptr_read(P, s, page_r, widx);
+    emit_mem(P, sh, s, q.timestamp, ZKW_MEM_FAT_PTR, page_r, widx, word, false, false, 1);
+    for (u32 b = 0; b < take; b++) {
+      const u32 bi = unal + b;             // big-endian byte index inside the word
+      const u32 limb = 7u - (bi >> 2);     // limb holding that byte
+      const u32 shift = (3u - (bi & 3u)) * 8u;
+      // select the limb without dynamic register indexing
+      u32 lv = word.w[0];
+#pragma unroll
+      for (int i = 1; i < 8; i++) lv = limb == (u32)i ? word.w[i] : lv;
+      kbuf_set_byte(sh, s.lane, fill, (lv >> shift) & 0xffu);
+      fill++;
+      if (fill == ZKW_KECCAK_RATE) {
+        keccak_absorb_block(sh, s.lane, st);
+        fill = 0;
+      }
+    }
+    byte_off += take;
+    left -= take;
+  }
+  if (!lane_ok(s)) return;
+  // pad10*1 with the legacy 0x01 domain byte
+  kbuf_set_byte(sh, s.lane, fill, 0x01u);
+  for (u32 p = fill + 1; p < ZKW_KECCAK_RATE; p++) kbuf_set_byte(sh, s.lane, p, 0);
+  sh.krow[(ZKW_KROW_WORDS - 1) * sh.L + s.lane] |= 0x80000000u;
+  keccak_absorb_block(sh, s.lane, st);
+  u256 digest;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    digest.w[7 - 2 * i] = __builtin_bswap32((u32)st[i]);
+    digest.w[6 - 2 * i] = __builtin_bswap32((u32)(st[i] >> 32));
+  }
+  heap_write_cur(P, s, false, out_off, digest);
+  emit_mem(P, sh, s, q.timestamp + 1, ZKW_MEM_HEAP, page_w, out_off, digest, false, true, 2);
+}
+
+ZD u32 zk_rotr32(u32 x, int n) { return (x >> n) | (x << (32 - n)); }
+
+// sha256_rounds_function: `precompile_interpreted_data` rounds, two words per round from word offset
+// `input_memory_offset` (the caller supplies the padded message), digest at `output_memory_offset`.
+ZD void precompile_sha256(const zkw_kparams& P, Shared& sh, Lane& s, const LogQ& q) {
+  const u32 in_word = q.key.w[0], out_off = q.key.w[2];
+  const u32 page_r = q.key.w[4], page_w = q.key.w[5];
+  const u32 rounds = q.key.w[6];  // low half of the u64; > 2^32 rounds cannot be paid for
+  u32 h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+  u32 rd = in_word;
+  for (u32 round = 0; round < rounds && lane_ok(s); round++) {
+    u32 w[16];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const u256 word = heap_read_cur(P, s, false, rd);
+      emit_mem(P, sh, s, q.timestamp, ZKW_MEM_HEAP, page_r, rd, word, false, false, 1);
+      rd++;
+#pragma unroll
+      for (int i = 0; i < 8; i++) w[half * 8 + i] = word.w[7 - i];
+    }
+    u32 a = h[0], b = h[1], c = h[2], dd = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+      if (i >= 16) {
+        const u32 w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+        const u32 s0 = zk_rotr32(w15, 7) ^ zk_rotr32(w15, 18) ^ (w15 >> 3);
+        const u32 s1 = zk_rotr32(w2, 17) ^ zk_rotr32(w2, 19) ^ (w2 >> 10);
+        w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+      }
+      const u32 S1 = zk_rotr32(e, 6) ^ zk_rotr32(e, 11) ^ zk_rotr32(e, 25);
+      const u32 ch = (e & f) ^ (~e & g);
+      const u32 t1 = hh + S1 + ch + ZKW_SHA256_K[i] + w[i & 15];
+      const u32 S0 = zk_rotr32(a, 2) ^ zk_rotr32(a, 13) ^ zk_rotr32(a, 22);
+      const u32 mj = (a & b) ^ (a & c) ^ (b & c);
+      const u32 t2 = S0 + mj;
+      hh = g; g = f; f = e; e = dd + t1; dd = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += dd; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    if (round == rounds - 1) {
+      u256 digest;
+#pragma unroll
+      for (int i = 0; i < 8; i++) digest.w[7 - i] = h[i];
+      heap_write_cur(P, s, false, out_off, digest);
+      emit_mem(P, sh, s, q.timestamp + 1, ZKW_MEM_HEAP, page_w, out_off, digest, false, true, 2);
+    }
+  }
+}

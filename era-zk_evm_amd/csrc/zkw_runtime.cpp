@@ -1,0 +1,858 @@
+// Host runtime of libzkw.so: implements the C ABI of include/zkw.h on top of the HIP kernels.
+//
+//   staging (zkw_batch_set_*)  ->  zkw_batch_upload: pristine device images
+//   zkw_batch_reset            ->  device-side copy pristine -> working state (async)
+//   zkw_batch_run              ->  zkw_cycle_kernel, bracketed by HIP events on the run stream
+//   zkw_batch_sync             ->  waits, downloads the small per-instance scalars
+//   zkw_batch_get_instance_trace -> downloads the owning wave's streams on demand and
+//                                 de-interleaves them into the per-instance view
+// There is no CPU execution path: without a GPU zkw_ctx_create fails with ZKW_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "zkw_device.h"
+
+extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_kparams* P, hipStream_t stream);
+extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L);
+extern "C" hipError_t zkw_launch_commit_kernel(const zkw_kparams* P, uint64_t* out, hipStream_t stream);
+
+static_assert(sizeof(zkw_callstack_entry) == 112, "abi");
+static_assert(sizeof(zkw_vm_local_state) == 680, "abi");
+static_assert(sizeof(zkw_cycle_record) == 512, "abi");
+static_assert(sizeof(zkw_mem_query) == 48, "abi");
+static_assert(sizeof(zkw_log_query) == 128, "abi");
+static_assert(sizeof(zkw_aux_event) == 256, "abi");
+static_assert(sizeof(zkw_dev_entry) == 128, "dev");
+static_assert(sizeof(zkw_dev_scalars) == 128, "dev");
+static_assert(sizeof(zkw_dev_storage_entry) == 96, "dev");
+static_assert(sizeof(zkw_dev_journal_entry) == 48, "dev");
+static_assert(sizeof(zkw_dev_preimage) == 48, "dev");
+
+struct zkw_ctx {
+  int device = 0;
+  int n_cus = 256;
+  int wave_width = 64;
+  bool has_isa = false;
+  zkw_isa_table isa;
+  uint2* d_isa = nullptr;
+  std::string last_error;
+};
+
+static std::string g_create_error;
+
+#define HIP_TRY(ctx, expr)                                                                      \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);                   \
+      return ZKW_ERR_DEVICE;                                                                    \
+    }                                                                                           \
+  } while (0)
+
+struct StagedInstance {
+  zkw_vm_local_state state;
+  std::vector<zkw_callstack_entry> inner;
+  std::vector<std::pair<uint32_t, uint32_t>> code_pages;  // page -> blob
+  std::vector<zkw_u256> heap;
+  std::vector<zkw_storage_slot> storage;
+  bool has_state = false;
+};
+
+struct WaveTrace {  // de-interleaved streams of one wave
+  std::vector<std::vector<zkw_cycle_record>> records;
+  std::vector<std::vector<zkw_mem_query>> mem;
+  std::vector<std::vector<zkw_log_query>> log;
+  std::vector<std::vector<zkw_aux_event>> aux;
+  std::vector<std::vector<uint32_t>> mem_off, log_off, aux_off;
+};
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    n = count;
+    if (count == 0) count = 1;
+    return hipMalloc((void**)&p, count * sizeof(T));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+  }
+  size_t bytes() const { return n * sizeof(T); }
+};
+
+struct zkw_batch {
+  zkw_ctx* ctx;
+  uint32_t n;
+  zkw_limits lim;
+  uint32_t L, n_waves;
+  uint32_t cap_mem, cap_log, cap_aux;
+  // staging
+  std::vector<std::vector<zkw_u256>> blobs;
+  std::vector<std::pair<zkw_u256, uint32_t>> preimages;
+  std::vector<StagedInstance> staged;
+  zkw_block_properties props;
+  bool uploaded = false, ran = false, synced = false;
+  uint32_t cycles_run = 0;  // wave cycles since reset
+  uint32_t heap_image_words = 0;
+  // device: pristine
+  DevBuf<uint4> d_regs0;
+  DevBuf<zkw_dev_scalars> d_scalars0;
+  DevBuf<zkw_dev_entry> d_callstack0;
+  DevBuf<zkw_dev_frame_meta> d_frames0;
+  DevBuf<zkw_dev_storage_entry> d_storage0;
+  DevBuf<uint4> d_heap0;  // [n_waves][heap_image_words][L][2]
+  // device: working
+  DevBuf<uint4> d_regs;
+  DevBuf<zkw_dev_scalars> d_scalars;
+  DevBuf<zkw_dev_entry> d_callstack;
+  DevBuf<zkw_dev_frame_meta> d_frames;
+  DevBuf<zkw_dev_storage_entry> d_storage;
+  DevBuf<zkw_dev_journal_entry> d_journal;
+  DevBuf<zkw_dev_history> d_history;
+  DevBuf<uint4> d_stack_vals, d_heap, d_aux;
+  DevBuf<uint8_t> d_stack_ptrs;
+  DevBuf<uint4> d_blob_words;
+  DevBuf<uint2> d_blob_dir;
+  DevBuf<zkw_dev_preimage> d_preimages;
+  // device: outputs
+  DevBuf<uint4> d_rec, d_mem, d_log, d_auxs;
+  DevBuf<uint32_t> d_dir, d_cursors;
+  DevBuf<uint64_t> d_commit;
+  static const int EV_RING = 64;
+  std::vector<hipEvent_t> evs;  // EV_RING (start, stop) pairs, one per run since the last sync
+  uint32_t pending_runs = 0;
+  hipStream_t run_stream = nullptr;
+  // host results
+  std::vector<zkw_dev_scalars> h_scalars;
+  std::vector<uint32_t> h_cursors;
+  std::map<uint32_t, std::unique_ptr<WaveTrace>> wave_cache;
+  float kernel_ms = 0;
+  zkw_kparams kp;
+};
+
+static uint32_t pow2_ceil(uint32_t v) {
+  uint32_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+extern "C" {
+
+int zkw_ctx_create(int device, zkw_ctx** out) {
+  if (!out) return ZKW_ERR_INVALID;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    g_create_error = std::string("no HIP device available (") + (e == hipSuccess ? "device count 0" : hipGetErrorString(e)) +
+                     "): libzkw has no CPU fallback";
+    return ZKW_ERR_DEVICE;
+  }
+  if (device < 0 || device >= count) {
+    g_create_error = "device index out of range";
+    return ZKW_ERR_INVALID;
+  }
+  auto* c = new zkw_ctx();
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess) {
+    g_create_error = "hipSetDevice failed";
+    delete c;
+    return ZKW_ERR_DEVICE;
+  }
+  (void)hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device);
+  (void)hipDeviceGetAttribute(&c->wave_width, hipDeviceAttributeWarpSize, device);
+  if (c->n_cus <= 0) c->n_cus = 256;
+  if (c->wave_width <= 0 || c->wave_width > ZKW_WAVE) c->wave_width = ZKW_WAVE;
+  *out = c;
+  return ZKW_OK;
+}
+
+void zkw_ctx_destroy(zkw_ctx* c) {
+  if (!c) return;
+  if (c->d_isa) (void)hipFree(c->d_isa);
+  delete c;
+}
+
+const char* zkw_last_error(zkw_ctx* c) { return c ? c->last_error.c_str() : g_create_error.c_str(); }
+
+int zkw_ctx_set_isa(zkw_ctx* c, const zkw_isa_table* t) {
+  if (!c || !t) return ZKW_ERR_INVALID;
+  if (t->consts.panic_variant_idx >= ZKW_ISA_TABLE_SIZE || t->consts.nop_variant_idx >= ZKW_ISA_TABLE_SIZE) {
+    c->last_error = "ISA table: panic/nop variant index out of range";
+    return ZKW_ERR_INVALID;
+  }
+  c->isa = *t;
+  std::vector<uint2> packed(ZKW_ISA_TABLE_SIZE);
+  for (int i = 0; i < ZKW_ISA_TABLE_SIZE; i++) {
+    const zkw_isa_entry& e = t->entries[i];
+    if (e.opcode > 15 || e.src0_mode > 5 || e.dst0_mode > 3 || e.flags > 3 || e.props > 63 || e.variant > 15) {
+      c->last_error = "ISA table: entry " + std::to_string(i) + " out of range";
+      return ZKW_ERR_INVALID;
+    }
+    packed[i].x = ZKW_ATTR_PACK(e.opcode, e.variant, e.src0_mode, e.dst0_mode, e.flags, e.props);
+    packed[i].y = e.price;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->d_isa) HIP_TRY(c, hipMalloc((void**)&c->d_isa, sizeof(uint2) * ZKW_ISA_TABLE_SIZE));
+  HIP_TRY(c, hipMemcpy(c->d_isa, packed.data(), sizeof(uint2) * ZKW_ISA_TABLE_SIZE, hipMemcpyHostToDevice));
+  c->has_isa = true;
+  return ZKW_OK;
+}
+
+int zkw_batch_create(zkw_ctx* c, uint32_t n, const zkw_limits* limits, zkw_batch** out) {
+  if (!c || !limits || !out || n == 0) return ZKW_ERR_INVALID;
+  if (!c->has_isa) {
+    c->last_error = "zkw_ctx_set_isa must be called before zkw_batch_create";
+    return ZKW_ERR_INVALID;
+  }
+  zkw_limits lim = *limits;
+  if (lim.max_cycles == 0 || lim.max_far_frames == 0 || lim.max_callstack_depth == 0 || lim.stack_words == 0 || lim.heap_words == 0 || lim.aux_heap_words == 0) {
+    c->last_error = "zkw_limits: zero capacity";
+    return ZKW_ERR_INVALID;
+  }
+  lim.storage_slots = pow2_ceil(std::max(lim.storage_slots, 4u));
+  if (lim.storage_journal == 0) lim.storage_journal = 4;
+  if (lim.max_mem_queries == 0) lim.max_mem_queries = 6 * lim.max_cycles;
+  if (lim.max_log_queries == 0) lim.max_log_queries = lim.max_cycles / 2 + 16;
+  if (lim.max_aux_events == 0) lim.max_aux_events = lim.max_cycles / 4 + 16;
+  auto* b = new zkw_batch();
+  b->ctx = c;
+  b->n = n;
+  b->lim = lim;
+  uint32_t L = lim.lanes_per_wave;
+  if (const char* env = getenv("ZKW_LANES_PER_WAVE")) L = (uint32_t)atoi(env);
+  if (L == 0) {
+    // enough waves to put one or two on every SIMD of the chip before filling lanes
+    const uint32_t target_waves = (uint32_t)c->n_cus * 8;
+    L = pow2_ceil((n + target_waves - 1) / target_waves);
+  }
+  L = pow2_ceil(L);
+  if (L > (uint32_t)c->wave_width) L = (uint32_t)c->wave_width;
+  b->L = L;
+  b->n_waves = (n + L - 1) / L;
+  b->cap_mem = lim.max_mem_queries * L;
+  b->cap_log = lim.max_log_queries * L;
+  b->cap_aux = lim.max_aux_events * L;
+  b->staged.resize(n);
+  std::memset(&b->props, 0, sizeof b->props);
+  b->blobs.emplace_back();  // blob 0 = the all-zero page (UNMAPPED_PAGE)
+  *out = b;
+  return ZKW_OK;
+}
+
+void zkw_batch_destroy(zkw_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->ctx->device);
+  b->d_regs0.release(); b->d_scalars0.release(); b->d_callstack0.release(); b->d_frames0.release(); b->d_storage0.release(); b->d_heap0.release();
+  b->d_regs.release(); b->d_scalars.release(); b->d_callstack.release(); b->d_frames.release(); b->d_storage.release(); b->d_journal.release();
+  b->d_history.release(); b->d_stack_vals.release(); b->d_heap.release(); b->d_aux.release(); b->d_stack_ptrs.release(); b->d_blob_words.release();
+  b->d_blob_dir.release(); b->d_preimages.release(); b->d_rec.release(); b->d_mem.release(); b->d_log.release(); b->d_auxs.release();
+  b->d_dir.release(); b->d_cursors.release(); b->d_commit.release();
+  for (hipEvent_t e : b->evs) (void)hipEventDestroy(e);
+  delete b;
+}
+
+int zkw_batch_add_code_blob(zkw_batch* b, const zkw_u256* words, uint32_t n_words, uint32_t* blob_id) {
+  if (!b || !blob_id || (n_words && !words)) return ZKW_ERR_INVALID;
+  if (n_words > (1u << 16)) {  // MAX_CODE_PAGE_SIZE_IN_WORDS (memory.rs:276)
+    b->ctx->last_error = "code blob longer than 2^16 words";
+    return ZKW_ERR_INVALID;
+  }
+  b->blobs.emplace_back(words, words + n_words);
+  *blob_id = (uint32_t)b->blobs.size() - 1;
+  b->uploaded = false;
+  return ZKW_OK;
+}
+
+int zkw_batch_add_decommit_preimage(zkw_batch* b, const zkw_u256* hash, uint32_t blob_id) {
+  if (!b || !hash || blob_id >= b->blobs.size()) return ZKW_ERR_INVALID;
+  for (auto& p : b->preimages)
+    if (std::memcmp(&p.first, hash, 32) == 0) {
+      b->ctx->last_error = "duplicate code hash (decommitter.rs:25)";
+      return ZKW_ERR_INVALID;
+    }
+  b->preimages.emplace_back(*hash, blob_id);
+  b->uploaded = false;
+  return ZKW_OK;
+}
+
+int zkw_batch_set_code_page(zkw_batch* b, uint32_t first, uint32_t count, uint32_t page, uint32_t blob_id) {
+  if (!b || (uint64_t)first + count > b->n || blob_id >= b->blobs.size()) return ZKW_ERR_INVALID;
+  for (uint32_t i = first; i < first + count; i++) b->staged[i].code_pages.emplace_back(page, blob_id);
+  b->uploaded = false;
+  return ZKW_OK;
+}
+
+int zkw_batch_set_state(zkw_batch* b, uint32_t first, uint32_t count, const zkw_vm_local_state* states, const zkw_callstack_entry* inner,
+                        uint32_t inner_depth) {
+  if (!b || !states || (uint64_t)first + count > b->n || (inner_depth && !inner)) return ZKW_ERR_INVALID;
+  if (inner_depth > b->lim.max_callstack_depth) {
+    b->ctx->last_error = "initial callstack deeper than limits.max_callstack_depth";
+    return ZKW_ERR_LIMIT;
+  }
+  for (uint32_t i = 0; i < count; i++) {
+    StagedInstance& s = b->staged[first + i];
+    if (states[i].callstack_depth != inner_depth) {
+      b->ctx->last_error = "state.callstack_depth != inner_depth";
+      return ZKW_ERR_INVALID;
+    }
+    s.state = states[i];
+    s.inner.assign(inner + (size_t)i * inner_depth, inner + (size_t)(i + 1) * inner_depth);
+    s.has_state = true;
+  }
+  b->uploaded = false;
+  return ZKW_OK;
+}
+
+int zkw_batch_set_heap(zkw_batch* b, uint32_t instance, const zkw_u256* words, uint32_t n_words) {
+  if (!b || instance >= b->n || (n_words && !words)) return ZKW_ERR_INVALID;
+  if (n_words > b->lim.heap_words) {
+    b->ctx->last_error = "heap image longer than limits.heap_words";
+    return ZKW_ERR_LIMIT;
+  }
+  b->staged[instance].heap.assign(words, words + n_words);
+  b->uploaded = false;
+  return ZKW_OK;
+}
+
+int zkw_batch_set_storage(zkw_batch* b, uint32_t instance, const zkw_storage_slot* slots, uint32_t n_slots) {
+  if (!b || instance >= b->n || (n_slots && !slots)) return ZKW_ERR_INVALID;
+  if (n_slots * 2 > b->lim.storage_slots) {
+    b->ctx->last_error = "storage snapshot needs limits.storage_slots >= 2 * n_slots";
+    return ZKW_ERR_LIMIT;
+  }
+  b->staged[instance].storage.assign(slots, slots + n_slots);
+  b->uploaded = false;
+  return ZKW_OK;
+}
+
+int zkw_batch_set_block_properties(zkw_batch* b, const zkw_block_properties* p) {
+  if (!b || !p) return ZKW_ERR_INVALID;
+  b->props = *p;
+  return ZKW_OK;
+}
+
+// same hash / probe sequence as storage_find() in zkw_kernels.hip
+static uint32_t host_storage_hash(uint32_t shard, const uint32_t addr[5], const uint32_t key[8]) {
+  uint32_t h = 0x9e3779b9u * (shard + 1);
+  for (int i = 0; i < 8; i++) h = (h ^ key[i]) * 0x85ebca6bu, h ^= h >> 15;
+  for (int i = 0; i < 5; i++) h = (h ^ addr[i]) * 0xc2b2ae35u, h ^= h >> 13;
+  return h;
+}
+
+static void entry_to_dev(const zkw_callstack_entry& e, uint32_t blob, uint32_t slot, zkw_dev_entry* o) {
+  std::memset(o, 0, sizeof *o);
+  o->e = e;
+  o->e.reserved0 = 0;
+  o->e.reserved1 = 0;
+  o->code_blob = blob;
+  o->frame_slot = slot;
+  o->journal_mark = 0;
+}
+
+int zkw_batch_upload(zkw_batch* b) {
+  if (!b) return ZKW_ERR_INVALID;
+  zkw_ctx* c = b->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t n = b->n, L = b->L, W = b->n_waves;
+  const zkw_limits& lim = b->lim;
+  const uint32_t F = lim.max_far_frames, D = lim.max_callstack_depth;
+  for (uint32_t i = 0; i < n; i++)
+    if (!b->staged[i].has_state) {
+      c->last_error = "instance " + std::to_string(i) + " has no state (zkw_batch_set_state)";
+      return ZKW_ERR_INVALID;
+    }
+  // ---- blobs ----
+  std::vector<uint2> dir(b->blobs.size());
+  size_t total_words = 0;
+  for (size_t i = 0; i < b->blobs.size(); i++) {
+    dir[i].x = (uint32_t)total_words;
+    dir[i].y = (uint32_t)b->blobs[i].size();
+    total_words += b->blobs[i].size();
+  }
+  std::vector<zkw_u256> all(total_words ? total_words : 1);
+  for (size_t i = 0; i < b->blobs.size(); i++)
+    if (!b->blobs[i].empty()) std::memcpy(&all[dir[i].x], b->blobs[i].data(), b->blobs[i].size() * 32);
+  b->d_blob_words.release();
+  b->d_blob_dir.release();
+  b->d_preimages.release();
+  HIP_TRY(c, b->d_blob_words.alloc(all.size() * 2));
+  HIP_TRY(c, hipMemcpy(b->d_blob_words.p, all.data(), all.size() * 32, hipMemcpyHostToDevice));
+  HIP_TRY(c, b->d_blob_dir.alloc(dir.size()));
+  HIP_TRY(c, hipMemcpy(b->d_blob_dir.p, dir.data(), dir.size() * sizeof(uint2), hipMemcpyHostToDevice));
+  std::vector<zkw_dev_preimage> pre(b->preimages.size() ? b->preimages.size() : 1);
+  std::memset(pre.data(), 0, pre.size() * sizeof(zkw_dev_preimage));
+  for (size_t i = 0; i < b->preimages.size(); i++) {
+    std::memcpy(pre[i].hash, &b->preimages[i].first, 32);
+    pre[i].blob = b->preimages[i].second;
+  }
+  HIP_TRY(c, b->d_preimages.alloc(pre.size()));
+  HIP_TRY(c, hipMemcpy(b->d_preimages.p, pre.data(), pre.size() * sizeof(zkw_dev_preimage), hipMemcpyHostToDevice));
+
+  // ---- per-instance pristine images ----
+  std::vector<uint4> regs((size_t)W * ZKW_REG_CHUNKS * L, make_uint4(0, 0, 0, 0));
+  std::vector<zkw_dev_scalars> scal(n);
+  std::vector<zkw_dev_entry> stack((size_t)n * (D + 1));
+  std::vector<zkw_dev_frame_meta> frames((size_t)n * F);
+  std::vector<zkw_dev_storage_entry> storage((size_t)n * lim.storage_slots);
+  std::memset(scal.data(), 0, scal.size() * sizeof(zkw_dev_scalars));
+  std::memset(stack.data(), 0, stack.size() * sizeof(zkw_dev_entry));
+  std::memset(frames.data(), 0, frames.size() * sizeof(zkw_dev_frame_meta));
+  std::memset(storage.data(), 0, storage.size() * sizeof(zkw_dev_storage_entry));
+  uint32_t himg = 0;
+  for (uint32_t i = 0; i < n; i++) himg = std::max(himg, (uint32_t)b->staged[i].heap.size());
+  b->heap_image_words = himg;
+  std::vector<uint4> heap0((size_t)W * himg * L * 2, make_uint4(0, 0, 0, 0));
+  for (uint32_t i = 0; i < n; i++) {
+    const StagedInstance& s = b->staged[i];
+    const uint32_t w = i / L, l = i % L;
+    const zkw_vm_local_state& st = s.state;
+    for (int r = 0; r < ZKW_REGISTERS_COUNT; r++) {
+      const uint32_t* v = (const uint32_t*)st.registers[r].l;
+      regs[((size_t)w * ZKW_REG_CHUNKS + 2 * r) * L + l] = make_uint4(v[0], v[1], v[2], v[3]);
+      regs[((size_t)w * ZKW_REG_CHUNKS + 2 * r + 1) * L + l] = make_uint4(v[4], v[5], v[6], v[7]);
+    }
+    zkw_dev_scalars& sc = scal[i];
+    std::memcpy(sc.prev_code_word, st.previous_code_word.l, 32);
+    std::memcpy(sc.ctx_u128_reg, st.context_u128_register, 16);
+    sc.ptr_bitmap = st.register_ptr_bitmap & 0x7fffu;
+    sc.flags = (st.flags & 7u) | (st.pending_exception ? 8u : 0u);
+    sc.prev_code_page = st.previous_code_memory_page;
+    sc.timestamp = st.timestamp;
+    sc.cycle_counter = st.monotonic_cycle_counter;
+    sc.spent_pubdata = st.spent_pubdata_counter;
+    sc.memory_page_counter = st.memory_page_counter;
+    sc.absolute_execution_step = st.absolute_execution_step;
+    sc.ergs_per_pubdata = st.current_ergs_per_pubdata_byte;
+    sc.tx_number = st.tx_number_in_block;
+    sc.prev_super_pc = st.previous_super_pc;
+    sc.depth = st.callstack_depth;
+    sc.status = ZKW_STATUS_RUNNING;
+    sc.n_cycles = 0;
+    sc.first_dynamic_page = st.memory_page_counter;
+    // callstack: entries 0..depth-1 = inner, entry depth = current.  Far frames alive at reset get
+    // arena slots in order (push_bootloader_context's start_global_frame, helpers.rs:306-315).
+    uint32_t next_slot = 0;
+    auto blob_of = [&](uint32_t page) -> int64_t {
+      if (page == 0) return 0;
+      for (auto it = s.code_pages.rbegin(); it != s.code_pages.rend(); ++it)
+        if (it->first == page) return it->second;
+      return -1;
+    };
+    const uint32_t depth = st.callstack_depth;
+    for (uint32_t d = 0; d <= depth; d++) {
+      const zkw_callstack_entry& e = d < depth ? s.inner[d] : st.current;
+      uint32_t slot = 0;
+      if (d > 0) {
+        if (!e.is_local_frame) {
+          if (next_slot >= F) {
+            c->last_error = "initial far frames exceed limits.max_far_frames";
+            return ZKW_ERR_LIMIT;
+          }
+          frames[(size_t)i * F + next_slot].base_page = e.base_memory_page;
+          slot = next_slot++;
+        } else {
+          slot = next_slot ? next_slot - 1 : 0;
+        }
+      }
+      int64_t blob = blob_of(e.code_page);
+      if (blob < 0) {
+        c->last_error = "instance " + std::to_string(i) + ": code page " + std::to_string(e.code_page) + " has no blob (zkw_batch_set_code_page)";
+        return ZKW_ERR_INVALID;
+      }
+      entry_to_dev(e, (uint32_t)blob, slot, &stack[(size_t)i * (D + 1) + d]);
+    }
+    if (next_slot == 0) next_slot = 1;  // slot 0 is reserved even for an already-ended VM
+    sc.n_initial_slots = next_slot;
+    sc.next_slot = next_slot;
+    // heap image of the current frame
+    if (!s.heap.empty()) {
+      const uint32_t cur_slot = stack[(size_t)i * (D + 1) + depth].frame_slot;
+      if (cur_slot != 0) {
+        c->last_error = "zkw_batch_set_heap supports the first far frame only";
+        return ZKW_ERR_INVALID;
+      }
+      frames[(size_t)i * F + cur_slot].heap_hwm = (uint32_t)s.heap.size();
+      for (size_t k = 0; k < s.heap.size(); k++) {
+        const uint32_t* v = (const uint32_t*)s.heap[k].l;
+        heap0[(((size_t)w * himg + k) * L + l) * 2] = make_uint4(v[0], v[1], v[2], v[3]);
+        heap0[(((size_t)w * himg + k) * L + l) * 2 + 1] = make_uint4(v[4], v[5], v[6], v[7]);
+      }
+    }
+    // storage snapshot
+    zkw_dev_storage_entry* tab = &storage[(size_t)i * lim.storage_slots];
+    const uint32_t mask = lim.storage_slots - 1;
+    for (const zkw_storage_slot& sl : s.storage) {
+      uint32_t key[8], addr[5];
+      std::memcpy(key, sl.key.l, 32);
+      std::memcpy(addr, sl.address, 20);
+      uint32_t pos = host_storage_hash(sl.shard_id, addr, key) & mask;
+      for (;;) {
+        zkw_dev_storage_entry& e = tab[pos];
+        bool same = (e.shard_state & 0x100u) && (e.shard_state & 0xffu) == sl.shard_id && !std::memcmp(e.key, key, 32) && !std::memcmp(e.address, addr, 20);
+        if (!(e.shard_state & 0x100u) || same) {
+          std::memcpy(e.key, key, 32);
+          std::memcpy(e.address, addr, 20);
+          std::memcpy(e.value, sl.value.l, 32);
+          e.shard_state = sl.shard_id | 0x100u;
+          break;
+        }
+        pos = (pos + 1) & mask;
+      }
+    }
+  }
+  auto up = [&](auto& dbuf, const auto& host) -> hipError_t {
+    dbuf.release();
+    hipError_t e = dbuf.alloc(host.size());
+    if (e != hipSuccess) return e;
+    if (host.empty()) return hipSuccess;
+    return hipMemcpy(dbuf.p, host.data(), host.size() * sizeof(host[0]), hipMemcpyHostToDevice);
+  };
+  HIP_TRY(c, up(b->d_regs0, regs));
+  HIP_TRY(c, up(b->d_scalars0, scal));
+  HIP_TRY(c, up(b->d_callstack0, stack));
+  HIP_TRY(c, up(b->d_frames0, frames));
+  HIP_TRY(c, up(b->d_storage0, storage));
+  HIP_TRY(c, up(b->d_heap0, heap0));
+  // ---- working state + arenas + outputs ----
+  auto ensure = [&](auto& dbuf, size_t count) -> hipError_t {
+    if (dbuf.p && dbuf.n == count) return hipSuccess;
+    dbuf.release();
+    return dbuf.alloc(count);
+  };
+  HIP_TRY(c, ensure(b->d_regs, regs.size()));
+  HIP_TRY(c, ensure(b->d_scalars, scal.size()));
+  HIP_TRY(c, ensure(b->d_callstack, stack.size()));
+  HIP_TRY(c, ensure(b->d_frames, frames.size()));
+  HIP_TRY(c, ensure(b->d_storage, storage.size()));
+  HIP_TRY(c, ensure(b->d_journal, (size_t)n * lim.storage_journal));
+  HIP_TRY(c, ensure(b->d_history, (size_t)n * F));
+  HIP_TRY(c, ensure(b->d_stack_vals, (size_t)W * F * lim.stack_words * L * 2));
+  HIP_TRY(c, ensure(b->d_stack_ptrs, (size_t)W * F * lim.stack_words * L));
+  HIP_TRY(c, ensure(b->d_heap, (size_t)W * F * lim.heap_words * L * 2));
+  HIP_TRY(c, ensure(b->d_aux, (size_t)W * F * lim.aux_heap_words * L * 2));
+  HIP_TRY(c, ensure(b->d_rec, (size_t)W * lim.max_cycles * ZKW_REC_CHUNKS * L));
+  HIP_TRY(c, ensure(b->d_mem, (size_t)W * b->cap_mem * 3));
+  HIP_TRY(c, ensure(b->d_log, (size_t)W * b->cap_log * 8));
+  HIP_TRY(c, ensure(b->d_auxs, (size_t)W * b->cap_aux * 16));
+  HIP_TRY(c, ensure(b->d_dir, (size_t)W * (lim.max_cycles + 1) * 4));
+  HIP_TRY(c, ensure(b->d_cursors, (size_t)W * 4));
+  HIP_TRY(c, ensure(b->d_commit, (size_t)n * ZKW_QUEUE_COUNT * 4));
+  if (b->evs.empty()) {
+    b->evs.resize(2 * zkw_batch::EV_RING, nullptr);
+    for (auto& e : b->evs) HIP_TRY(c, hipEventCreate(&e));
+  }
+  // kernel parameter block
+  zkw_kparams& P = b->kp;
+  std::memset(&P, 0, sizeof P);
+  P.n_instances = n; P.L = L; P.n_waves = W; P.max_cycles = lim.max_cycles;
+  P.F = F; P.D = D; P.S = lim.stack_words; P.H = lim.heap_words; P.A = lim.aux_heap_words;
+  P.storage_slots = lim.storage_slots; P.storage_journal = lim.storage_journal;
+  P.cap_mem = b->cap_mem; P.cap_log = b->cap_log; P.cap_aux = b->cap_aux;
+  P.n_blobs = (uint32_t)b->blobs.size(); P.n_preimages = (uint32_t)b->preimages.size();
+  P.consts = c->isa.consts;
+  P.wave_threads = (uint32_t)c->wave_width;
+  P.isa = c->d_isa;
+  P.regs = b->d_regs.p; P.scalars = b->d_scalars.p; P.callstack = b->d_callstack.p; P.frames = b->d_frames.p;
+  P.stack_vals = b->d_stack_vals.p; P.stack_ptrs = b->d_stack_ptrs.p; P.heap = b->d_heap.p; P.aux_heap = b->d_aux.p;
+  P.storage = b->d_storage.p; P.journal = b->d_journal.p; P.history = b->d_history.p;
+  P.blob_words = b->d_blob_words.p; P.blob_dir = b->d_blob_dir.p; P.preimages = b->d_preimages.p;
+  P.rec = b->d_rec.p; P.mem_stream = b->d_mem.p; P.log_stream = b->d_log.p; P.aux_stream = b->d_auxs.p;
+  P.dir = b->d_dir.p; P.cursors = b->d_cursors.p;
+  b->uploaded = true;
+  b->ran = false;
+  return zkw_batch_reset(b, nullptr);
+}
+
+int zkw_batch_reset(zkw_batch* b, void* hip_stream) {
+  if (!b) return ZKW_ERR_INVALID;
+  zkw_ctx* c = b->ctx;
+  if (!b->uploaded) {
+    c->last_error = "zkw_batch_upload first";
+    return ZKW_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(b->d_regs.p, b->d_regs0.p, b->d_regs0.bytes(), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(b->d_scalars.p, b->d_scalars0.p, b->d_scalars0.bytes(), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(b->d_callstack.p, b->d_callstack0.p, b->d_callstack0.bytes(), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(b->d_frames.p, b->d_frames0.p, b->d_frames0.bytes(), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(b->d_storage.p, b->d_storage0.p, b->d_storage0.bytes(), hipMemcpyDeviceToDevice, st));
+  if (b->heap_image_words) {
+    const size_t row = (size_t)b->heap_image_words * b->L * 32;
+    const size_t pitch = (size_t)b->lim.max_far_frames * b->lim.heap_words * b->L * 32;
+    HIP_TRY(c, hipMemcpy2DAsync(b->d_heap.p, pitch, b->d_heap0.p, row, row, b->n_waves, hipMemcpyDeviceToDevice, st));
+  }
+  HIP_TRY(c, hipMemsetAsync(b->d_cursors.p, 0, b->d_cursors.bytes(), st));
+  b->cycles_run = 0;
+  b->ran = false;
+  b->synced = false;
+  b->wave_cache.clear();
+  return ZKW_OK;
+}
+
+int zkw_batch_run(zkw_batch* b, uint32_t max_cycles, void* hip_stream) {
+  if (!b) return ZKW_ERR_INVALID;
+  zkw_ctx* c = b->ctx;
+  if (!b->uploaded) {
+    c->last_error = "zkw_batch_upload first";
+    return ZKW_ERR_INVALID;
+  }
+  if (max_cycles == 0 || (uint64_t)b->cycles_run + max_cycles > b->lim.max_cycles) {
+    c->last_error = "run exceeds limits.max_cycles since the last reset";
+    return ZKW_ERR_LIMIT;
+  }
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIP_TRY(c, hipSetDevice(c->device));
+  zkw_kparams P = b->kp;
+  P.cycle_base = b->cycles_run;
+  P.run_cycles = max_cycles;
+  P.props = b->props;
+  const uint32_t slot = b->pending_runs % zkw_batch::EV_RING;
+  HIP_TRY(c, hipEventRecord(b->evs[2 * slot], st));
+  HIP_TRY(c, zkw_launch_cycle_kernel(&P, st));
+  HIP_TRY(c, hipEventRecord(b->evs[2 * slot + 1], st));
+  b->pending_runs++;
+  b->run_stream = st;
+  b->cycles_run += max_cycles;
+  b->ran = true;
+  b->synced = false;
+  b->wave_cache.clear();
+  return ZKW_OK;
+}
+
+int zkw_batch_sync(zkw_batch* b) {
+  if (!b) return ZKW_ERR_INVALID;
+  zkw_ctx* c = b->ctx;
+  if (!b->ran) {
+    c->last_error = "nothing was run";
+    return ZKW_ERR_NOT_RUN;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (b->pending_runs) {  // mean device time of the cycle kernel over the runs since the last sync
+    const uint32_t last = (b->pending_runs - 1) % zkw_batch::EV_RING;
+    HIP_TRY(c, hipEventSynchronize(b->evs[2 * last + 1]));
+    const uint32_t cnt = std::min<uint32_t>(b->pending_runs, zkw_batch::EV_RING);
+    float total = 0;
+    for (uint32_t i = 0; i < cnt; i++) {
+      float ms = 0;
+      HIP_TRY(c, hipEventElapsedTime(&ms, b->evs[2 * i], b->evs[2 * i + 1]));
+      total += ms;
+    }
+    b->kernel_ms = total / cnt;
+    b->pending_runs = 0;
+  }
+  HIP_TRY(c, hipStreamSynchronize(b->run_stream));
+  b->h_scalars.resize(b->n);
+  HIP_TRY(c, hipMemcpy(b->h_scalars.data(), b->d_scalars.p, b->d_scalars.bytes(), hipMemcpyDeviceToHost));
+  b->h_cursors.resize((size_t)b->n_waves * 4);
+  HIP_TRY(c, hipMemcpy(b->h_cursors.data(), b->d_cursors.p, b->d_cursors.bytes(), hipMemcpyDeviceToHost));
+  b->synced = true;
+  return ZKW_OK;
+}
+
+int zkw_batch_get_stats(zkw_batch* b, zkw_run_stats* out) {
+  if (!b || !out) return ZKW_ERR_INVALID;
+  if (!b->synced) {
+    int rc = zkw_batch_sync(b);
+    if (rc != ZKW_OK) return rc;
+  }
+  std::memset(out, 0, sizeof *out);
+  for (uint32_t i = 0; i < b->n; i++) {
+    const zkw_dev_scalars& s = b->h_scalars[i];
+    out->cycles += s.n_cycles;
+    if (s.status == ZKW_STATUS_ENDED) out->instances_ended++;
+    if (s.status >= ZKW_STATUS_UNKNOWN_CODE_HASH) out->instances_failed++;
+  }
+  for (uint32_t w = 0; w < b->n_waves; w++) {  // stream totals (include the discarded records of failed cycles)
+    out->mem_queries += std::min(b->h_cursors[(size_t)w * 4 + 0], b->cap_mem);
+    out->log_queries += std::min(b->h_cursors[(size_t)w * 4 + 1], b->cap_log);
+    out->aux_events += std::min(b->h_cursors[(size_t)w * 4 + 2], b->cap_aux);
+  }
+  out->kernel_ms = b->kernel_ms;
+  return ZKW_OK;
+}
+
+static int build_wave(zkw_batch* b, uint32_t w) {
+  zkw_ctx* c = b->ctx;
+  const uint32_t L = b->L, MC = b->lim.max_cycles;
+  auto wt = std::make_unique<WaveTrace>();
+  wt->records.resize(L); wt->mem.resize(L); wt->log.resize(L); wt->aux.resize(L);
+  wt->mem_off.resize(L); wt->log_off.resize(L); wt->aux_off.resize(L);
+  uint32_t max_cycles_lane = 0;
+  std::vector<uint32_t> ncyc(L, 0);
+  for (uint32_t l = 0; l < L; l++) {
+    const uint32_t i = w * L + l;
+    if (i < b->n) ncyc[l] = b->h_scalars[i].n_cycles;
+    max_cycles_lane = std::max(max_cycles_lane, ncyc[l]);
+  }
+  // directory + streams of this wave
+  std::vector<uint32_t> dir((size_t)(MC + 1) * 4);
+  HIP_TRY(c, hipMemcpy(dir.data(), b->d_dir.p + (size_t)w * (MC + 1) * 4, dir.size() * 4, hipMemcpyDeviceToHost));
+  const uint32_t n_mem = std::min(b->h_cursors[(size_t)w * 4 + 0], b->cap_mem);
+  const uint32_t n_log = std::min(b->h_cursors[(size_t)w * 4 + 1], b->cap_log);
+  const uint32_t n_aux = std::min(b->h_cursors[(size_t)w * 4 + 2], b->cap_aux);
+  std::vector<zkw_mem_query> mem(n_mem);
+  std::vector<zkw_log_query> log(n_log);
+  std::vector<zkw_aux_event> aux(n_aux);
+  if (n_mem) HIP_TRY(c, hipMemcpy(mem.data(), b->d_mem.p + (size_t)w * b->cap_mem * 3, (size_t)n_mem * 48, hipMemcpyDeviceToHost));
+  if (n_log) HIP_TRY(c, hipMemcpy(log.data(), b->d_log.p + (size_t)w * b->cap_log * 8, (size_t)n_log * 128, hipMemcpyDeviceToHost));
+  if (n_aux) HIP_TRY(c, hipMemcpy(aux.data(), b->d_auxs.p + (size_t)w * b->cap_aux * 16, (size_t)n_aux * 256, hipMemcpyDeviceToHost));
+  // records
+  std::vector<uint4> rec((size_t)max_cycles_lane * ZKW_REC_CHUNKS * L);
+  if (max_cycles_lane)
+    HIP_TRY(c, hipMemcpy(rec.data(), b->d_rec.p + (size_t)w * MC * ZKW_REC_CHUNKS * L, rec.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+  for (uint32_t l = 0; l < L; l++) {
+    wt->records[l].resize(ncyc[l]);
+    for (uint32_t k = 0; k < ncyc[l]; k++) {
+      uint4* dst = (uint4*)&wt->records[l][k];
+      for (uint32_t ch = 0; ch < ZKW_REC_CHUNKS; ch++) dst[ch] = rec[((size_t)k * ZKW_REC_CHUNKS + ch) * L + l];
+    }
+    wt->mem_off[l].assign(1, 0); wt->log_off[l].assign(1, 0); wt->aux_off[l].assign(1, 0);
+  }
+  // bucket the stream records by lane, cycle by cycle (stream order preserves each lane's order)
+  for (uint32_t k = 0; k < max_cycles_lane; k++) {
+    const uint32_t* d0 = &dir[(size_t)k * 4];
+    const uint32_t* d1 = &dir[(size_t)(k + 1) * 4];
+    for (uint32_t p = std::min(d0[0], n_mem); p < std::min(d1[0], n_mem); p++) {
+      const uint32_t l = mem[p].lane;
+      if (l < L && k < ncyc[l]) {
+        zkw_mem_query q = mem[p];
+        q.lane = 0;
+        wt->mem[l].push_back(q);
+      }
+    }
+    for (uint32_t p = std::min(d0[1], n_log); p < std::min(d1[1], n_log); p++) {
+      const uint32_t l = log[p].lane;
+      if (l < L && k < ncyc[l]) {
+        zkw_log_query q = log[p];
+        q.lane = 0;
+        wt->log[l].push_back(q);
+      }
+    }
+    for (uint32_t p = std::min(d0[2], n_aux); p < std::min(d1[2], n_aux); p++) {
+      const uint32_t l = aux[p].lane;
+      if (l < L && k < ncyc[l]) {
+        zkw_aux_event q = aux[p];
+        q.lane = 0;
+        wt->aux[l].push_back(q);
+      }
+    }
+    for (uint32_t l = 0; l < L; l++)
+      if (k < ncyc[l]) {
+        wt->mem_off[l].push_back((uint32_t)wt->mem[l].size());
+        wt->log_off[l].push_back((uint32_t)wt->log[l].size());
+        wt->aux_off[l].push_back((uint32_t)wt->aux[l].size());
+      }
+  }
+  if (b->wave_cache.size() >= 64) b->wave_cache.clear();
+  b->wave_cache[w] = std::move(wt);
+  return ZKW_OK;
+}
+
+int zkw_batch_get_instance_trace(zkw_batch* b, uint32_t instance, zkw_instance_trace* out) {
+  if (!b || !out || instance >= b->n) return ZKW_ERR_INVALID;
+  zkw_ctx* c = b->ctx;
+  if (!b->synced) {
+    int rc = zkw_batch_sync(b);
+    if (rc != ZKW_OK) return rc;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t w = instance / b->L, l = instance % b->L;
+  if (!b->wave_cache.count(w)) {
+    int rc = build_wave(b, w);
+    if (rc != ZKW_OK) return rc;
+  }
+  WaveTrace& wt = *b->wave_cache[w];
+  const zkw_dev_scalars& sc = b->h_scalars[instance];
+  std::memset(out, 0, sizeof *out);
+  out->status = sc.status;
+  out->n_cycles = sc.n_cycles;
+  out->n_mem = (uint32_t)wt.mem[l].size();
+  out->n_log = (uint32_t)wt.log[l].size();
+  out->n_aux = (uint32_t)wt.aux[l].size();
+  out->records = wt.records[l].data();
+  out->mem = wt.mem[l].data();
+  out->log = wt.log[l].data();
+  out->aux = wt.aux[l].data();
+  out->mem_off = wt.mem_off[l].data();
+  out->log_off = wt.log_off[l].data();
+  out->aux_off = wt.aux_off[l].data();
+  // final VmLocalState: scalars + register file + current callstack entry
+  zkw_vm_local_state& fs = out->final_state;
+  std::memcpy(fs.previous_code_word.l, sc.prev_code_word, 32);
+  std::vector<uint4> regs(ZKW_REG_CHUNKS);
+  for (uint32_t ch = 0; ch < ZKW_REG_CHUNKS; ch++)
+    HIP_TRY(c, hipMemcpy(&regs[ch], b->d_regs.p + ((size_t)w * ZKW_REG_CHUNKS + ch) * b->L + l, sizeof(uint4), hipMemcpyDeviceToHost));
+  std::memcpy(fs.registers, regs.data(), 480);
+  fs.register_ptr_bitmap = (uint16_t)sc.ptr_bitmap;
+  fs.flags = sc.flags & 7u;
+  fs.pending_exception = (sc.flags >> 3) & 1u;
+  fs.previous_code_memory_page = sc.prev_code_page;
+  fs.timestamp = sc.timestamp;
+  fs.monotonic_cycle_counter = sc.cycle_counter;
+  fs.spent_pubdata_counter = sc.spent_pubdata;
+  fs.memory_page_counter = sc.memory_page_counter;
+  fs.absolute_execution_step = sc.absolute_execution_step;
+  fs.current_ergs_per_pubdata_byte = sc.ergs_per_pubdata;
+  fs.tx_number_in_block = (uint16_t)sc.tx_number;
+  fs.previous_super_pc = (uint16_t)sc.prev_super_pc;
+  fs.callstack_depth = sc.depth;
+  std::memcpy(fs.context_u128_register, sc.ctx_u128_reg, 16);
+  zkw_dev_entry cur;
+  HIP_TRY(c, hipMemcpy(&cur, b->d_callstack.p + (size_t)instance * (b->lim.max_callstack_depth + 1) + sc.depth, sizeof cur, hipMemcpyDeviceToHost));
+  fs.current = cur.e;
+  return ZKW_OK;
+}
+
+int zkw_batch_get_commitments(zkw_batch* b, uint64_t* out) {
+  if (!b || !out) return ZKW_ERR_INVALID;
+  zkw_ctx* c = b->ctx;
+  if (!b->ran) return ZKW_ERR_NOT_RUN;
+  HIP_TRY(c, hipSetDevice(c->device));
+  zkw_kparams P = b->kp;
+  P.cycle_base = 0;
+  P.run_cycles = b->cycles_run;
+  HIP_TRY(c, zkw_launch_commit_kernel(&P, b->d_commit.p, b->run_stream));
+  HIP_TRY(c, hipStreamSynchronize(b->run_stream));
+  HIP_TRY(c, hipMemcpy(out, b->d_commit.p, b->d_commit.bytes(), hipMemcpyDeviceToHost));
+  return ZKW_OK;
+}
+
+int zkw_batch_commitments_device_ptr(zkw_batch* b, void** dptr, uint64_t* n_bytes) {
+  if (!b || !dptr || !n_bytes) return ZKW_ERR_INVALID;
+  *dptr = b->d_commit.p;
+  *n_bytes = b->d_commit.bytes();
+  return ZKW_OK;
+}
+
+// sizes of the ABI structs, for binding self-checks (tests/test_capi_layout.py)
+uint32_t zkw_abi_sizeof(uint32_t which) {
+  switch (which) {
+    case 0: return sizeof(zkw_isa_table);
+    case 1: return sizeof(zkw_callstack_entry);
+    case 2: return sizeof(zkw_vm_local_state);
+    case 3: return sizeof(zkw_block_properties);
+    case 4: return sizeof(zkw_storage_slot);
+    case 5: return sizeof(zkw_limits);
+    case 6: return sizeof(zkw_cycle_record);
+    case 7: return sizeof(zkw_mem_query);
+    case 8: return sizeof(zkw_log_query);
+    case 9: return sizeof(zkw_aux_event);
+    case 10: return sizeof(zkw_instance_trace);
+    case 11: return sizeof(zkw_run_stats);
+    case 12: return sizeof(zkw_isa_consts);
+    default: return 0;
+  }
+}
+
+}  // extern "C"

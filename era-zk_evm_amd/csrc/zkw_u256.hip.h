@@ -1,0 +1,277 @@
+// 256-bit integer arithmetic for gfx950 lanes (one VM instance per lane).
+//
+// Values are 8 x u32 little-endian limbs held in VGPRs; every loop below has compile-time
+// bounds and static indices so nothing is demoted to scratch.  Semantics are those of
+// ethereum_types::U256 as used by the reference ALU (reference src/opcodes/execution/
+// add.rs:35, sub.rs:35, mul.rs:35-39, div.rs:50, shift.rs:44-62, uma.rs:299-361).
+//
+// Division is a fixed-trip-count Knuth algorithm D: the divisor is normalised to a full
+// 256 bits (so every lane of a wave runs the same 9 digit steps — no divergence on operand
+// length), each quotient digit comes from a 2-by-1 division with a precomputed reciprocal
+// (Möller & Granlund, "Improved division by invariant integers", Alg. 4) followed by the
+// classical two-limb correction and a conditional add-back.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+struct u256 {
+  u32 w[8];
+};
+
+#define ZD __device__ __forceinline__
+
+ZD u256 u256_zero() {
+  u256 r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.w[i] = 0;
+  return r;
+}
+ZD u256 u256_from_u32(u32 v) {
+  u256 r = u256_zero();
+  r.w[0] = v;
+  return r;
+}
+ZD bool u256_is_zero(const u256& a) { return (a.w[0] | a.w[1] | a.w[2] | a.w[3] | a.w[4] | a.w[5] | a.w[6] | a.w[7]) == 0; }
+ZD bool u256_eq(const u256& a, const u256& b) {
+  u32 d = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) d |= a.w[i] ^ b.w[i];
+  return d == 0;
+}
+ZD u256 u256_from_uint4(uint4 lo, uint4 hi) {
+  u256 r;
+  r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w;
+  r.w[4] = hi.x; r.w[5] = hi.y; r.w[6] = hi.z; r.w[7] = hi.w;
+  return r;
+}
+ZD uint4 u256_lo4(const u256& a) { return make_uint4(a.w[0], a.w[1], a.w[2], a.w[3]); }
+ZD uint4 u256_hi4(const u256& a) { return make_uint4(a.w[4], a.w[5], a.w[6], a.w[7]); }
+
+// overflowing_add (add.rs:35)
+ZD u256 u256_add(const u256& a, const u256& b, bool& of) {
+  u256 r;
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (u64)a.w[i] + b.w[i];
+    r.w[i] = (u32)c;
+    c >>= 32;
+  }
+  of = c != 0;
+  return r;
+}
+// overflowing_sub (sub.rs:35)
+ZD u256 u256_sub(const u256& a, const u256& b, bool& of) {
+  u256 r;
+  u64 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u64 d = (u64)a.w[i] - b.w[i] - borrow;
+    r.w[i] = (u32)d;
+    borrow = (d >> 32) & 1;
+  }
+  of = borrow != 0;
+  return r;
+}
+// full_mul (mul.rs:35-39): 64 x v_mad_u64_u32
+ZD void u256_mul(const u256& a, const u256& b, u256& lo, u256& hi) {
+  u32 out[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) out[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u32 carry = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      u64 t = (u64)a.w[i] * b.w[j] + out[i + j] + carry;
+      out[i + j] = (u32)t;
+      carry = (u32)(t >> 32);
+    }
+    out[i + 8] = carry;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    lo.w[i] = out[i];
+    hi.w[i] = out[i + 8];
+  }
+}
+
+// U256 << n with the `uint` crate's "n >= 256 => 0" (shift.rs:51,58; uma.rs:303,361)
+ZD u256 u256_shl(const u256& a, u32 n) {
+  u32 bs = n & 31, ws = (n >> 5) & 7;
+  u256 t;
+  t.w[0] = a.w[0] << bs;
+#pragma unroll
+  for (int i = 1; i < 8; i++) t.w[i] = (u32)(((((u64)a.w[i] << 32) | a.w[i - 1]) << bs) >> 32);
+  if (ws & 1) {
+#pragma unroll
+    for (int i = 7; i >= 1; i--) t.w[i] = t.w[i - 1];
+    t.w[0] = 0;
+  }
+  if (ws & 2) {
+#pragma unroll
+    for (int i = 7; i >= 2; i--) t.w[i] = t.w[i - 2];
+    t.w[0] = t.w[1] = 0;
+  }
+  if (ws & 4) {
+#pragma unroll
+    for (int i = 7; i >= 4; i--) t.w[i] = t.w[i - 4];
+    t.w[0] = t.w[1] = t.w[2] = t.w[3] = 0;
+  }
+  if (n >= 256) t = u256_zero();
+  return t;
+}
+ZD u256 u256_shr(const u256& a, u32 n) {
+  u32 bs = n & 31, ws = (n >> 5) & 7;
+  u256 t;
+#pragma unroll
+  for (int i = 0; i < 7; i++) t.w[i] = (u32)((((u64)a.w[i + 1] << 32) | a.w[i]) >> bs);
+  t.w[7] = a.w[7] >> bs;
+  if (ws & 1) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) t.w[i] = t.w[i + 1];
+    t.w[7] = 0;
+  }
+  if (ws & 2) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) t.w[i] = t.w[i + 2];
+    t.w[6] = t.w[7] = 0;
+  }
+  if (ws & 4) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) t.w[i] = t.w[i + 4];
+    t.w[4] = t.w[5] = t.w[6] = t.w[7] = 0;
+  }
+  if (n >= 256) t = u256_zero();
+  return t;
+}
+ZD u256 u256_or(const u256& a, const u256& b) {
+  u256 r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.w[i] = a.w[i] | b.w[i];
+  return r;
+}
+ZD u256 u256_and(const u256& a, const u256& b) {
+  u256 r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.w[i] = a.w[i] & b.w[i];
+  return r;
+}
+ZD u256 u256_xor(const u256& a, const u256& b) {
+  u256 r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.w[i] = a.w[i] ^ b.w[i];
+  return r;
+}
+
+// count leading zero bits of a non-zero u256
+ZD u32 u256_clz(const u256& a) {
+  u32 n = 0;
+  bool done = false;
+#pragma unroll
+  for (int i = 7; i >= 0; i--) {
+    u32 z = a.w[i] ? (u32)__builtin_clz(a.w[i]) : 32u;
+    n += done ? 0u : z;
+    done = done || (a.w[i] != 0);
+  }
+  return n;
+}
+
+// floor((2^64 - 1) / d) - 2^32 for a normalised d (top bit set): the 2-by-1 reciprocal
+ZD u32 zk_invert_limb(u32 d) { return (u32)(0xffffffffffffffffULL / d - 0x100000000ULL); }
+
+// (u1:u0) / d with u1 < d, d normalised, v = zk_invert_limb(d) — Möller–Granlund Alg. 4
+ZD u32 zk_div_2by1(u32 u1, u32 u0, u32 d, u32 v, u32& rem) {
+  u64 q = (u64)v * u1 + (((u64)u1 << 32) | u0);
+  u32 q1 = (u32)(q >> 32) + 1;
+  u32 q0 = (u32)q;
+  u32 r = u0 - q1 * d;
+  if (r > q0) {
+    q1 -= 1;
+    r += d;
+  }
+  if (r >= d) {
+    q1 += 1;
+    r -= d;
+  }
+  rem = r;
+  return q1;
+}
+
+// div_mod (div.rs:50); b != 0
+ZD void u256_divmod(const u256& a, const u256& b, u256& q, u256& r) {
+  const u32 s = u256_clz(b);  // 0..255
+  const u256 v = u256_shl(b, s);
+  // u = a << s as 16 limbs + overflow limb (always 0 since a < 2^256 and s < 256 => u < 2^512)
+  const u256 ulo = u256_shl(a, s);
+  const u256 uhi = s ? u256_shr(a, 256 - s) : u256_zero();
+  const u32 dinv = zk_invert_limb(v.w[7]);
+  // window rem[0..8]: rem[8] is the top limb; starts as (0 : uhi), then slides down over ulo
+  u32 rem[9];
+#pragma unroll
+  for (int i = 0; i < 8; i++) rem[i] = uhi.w[i];
+  rem[8] = 0;
+  // uhi < 2^s <= v, so the Knuth invariant (window / v < B) holds from the start and the
+  // quotient has exactly 8 digits: steps j = 7..0, each sliding one limb of ulo into the window.
+#pragma unroll
+  for (int j = 7; j >= 0; j--) {
+#pragma unroll
+    for (int i = 8; i >= 1; i--) rem[i] = rem[i - 1];
+    rem[0] = ulo.w[j];
+    // estimate qhat from (rem[8]:rem[7]) / v[7]
+    u32 qhat, rhat;
+    bool rhat_big = false;  // rhat >= B: no further correction possible/needed
+    if (rem[8] >= v.w[7]) {
+      qhat = 0xffffffffu;
+      u64 rh = (u64)rem[7] + v.w[7];  // rhat = rem[8]*B + rem[7] - qhat*v7 with rem[8] == v7
+      rhat = (u32)rh;
+      rhat_big = (rh >> 32) != 0;
+    } else {
+      qhat = zk_div_2by1(rem[8], rem[7], v.w[7], dinv, rhat);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      u64 lhs = (u64)qhat * v.w[6];
+      u64 rhs = ((u64)rhat << 32) | rem[6];
+      if (!rhat_big && lhs > rhs) {
+        qhat -= 1;
+        u64 rh = (u64)rhat + v.w[7];
+        rhat = (u32)rh;
+        rhat_big = (rh >> 32) != 0;
+      }
+    }
+    // multiply and subtract: rem -= qhat * v
+    u32 carry = 0;
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      u64 p = (u64)qhat * v.w[i] + carry;
+      carry = (u32)(p >> 32);
+      u64 t = (u64)rem[i] - (u32)p - borrow;
+      rem[i] = (u32)t;
+      borrow = (u32)(t >> 32) & 1;
+    }
+    u64 t = (u64)rem[8] - carry - borrow;
+    rem[8] = (u32)t;
+    if ((t >> 32) & 1) {  // went negative: add back once
+      qhat -= 1;
+      u64 c = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        c += (u64)rem[i] + v.w[i];
+        rem[i] = (u32)c;
+        c >>= 32;
+      }
+      rem[8] += (u32)c;
+    }
+    q.w[j] = qhat;
+  }
+  // remainder = rem >> s
+  u256 rn;
+#pragma unroll
+  for (int i = 0; i < 8; i++) rn.w[i] = rem[i];
+  r = u256_shr(rn, s);
+}

@@ -440,6 +440,9 @@ int zkw_batch_get_commitments(zkw_batch* batch, uint64_t* out);
 /* device pointer (n_instances * ZKW_QUEUE_COUNT * 4 u64) for the RCCL all-gather */
 int zkw_batch_commitments_device_ptr(zkw_batch* batch, void** dptr, uint64_t* n_bytes);
 
+/* sizeof() of the ABI structs as compiled into the library (binding self-check) */
+uint32_t zkw_abi_sizeof(uint32_t which);
+
 #ifdef __cplusplus
 }
 #endif
