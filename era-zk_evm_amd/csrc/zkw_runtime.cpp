@@ -231,9 +231,11 @@ int zkw_batch_create(zkw_ctx* c, uint32_t n, const zkw_limits* limits, zkw_batch
   uint32_t L = lim.lanes_per_wave;
   if (const char* env = getenv("ZKW_LANES_PER_WAVE")) L = (uint32_t)atoi(env);
   if (L == 0) {
-    // enough waves to put one or two on every SIMD of the chip before filling lanes
-    const uint32_t target_waves = (uint32_t)c->n_cus * 8;
-    L = pow2_ceil((n + target_waves - 1) / target_waves);
+    // Measured on MI355X (profiles/r01_lane_sweep.md): the kernel is bound by the per-wave latency of one
+    // VM cycle, which does not depend on the number of active lanes, so fill waves first and only thin
+    // them out when that would leave fewer than one wave per 4 CUs.
+    const uint32_t min_waves = std::max(1u, (uint32_t)c->n_cus / 4);
+    L = pow2_ceil((n + min_waves - 1) / min_waves);
   }
   L = pow2_ceil(L);
   if (L > (uint32_t)c->wave_width) L = (uint32_t)c->wave_width;
