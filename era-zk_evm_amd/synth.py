@@ -441,3 +441,329 @@ def config2(isa, n_instances=4096, n_cycles=256, seed=0x5EED0002):
 
 def make(cfg, isa, **kw):
     return {0: config0, 1: config1, 2: config2}[cfg](isa, **kw)
+
+
+# ----------------------------------------------------------------------------------------
+# cfg 3 — precompile-dominant trace (keccak256 / sha256 over heap data)
+# ----------------------------------------------------------------------------------------
+SHA256_ADDRESS = 0x02
+KECCAK_ADDRESS = 0x8010
+KECCAK_COST_PER_ROUND = 40
+SHA256_COST_PER_ROUND = 7
+
+
+def precompile_abi(in_off, in_len, out_off, out_len, page_r, page_w, extra=0):
+    return K.u256_from_int(in_off | (in_len << 32) | (out_off << 64) | (out_len << 96) | (page_r << 128) | (page_w << 160) | (extra << 192))
+
+
+def sha256_padded_len(n):
+    return ((n + 9 + 63) // 64) * 64
+
+
+def config3(isa, n_instances=4096, n_cycles=64, seed=0x5EED0003, keccak_k=(1, 8, 64, 512), sha_rounds=(1, 8, 64, 157)):
+    """The bootloader frame runs as the sha256 system contract (address 0x02) and hashes four
+    regions of its own heap (precompile reads are MemoryType::Heap of the current frame), then
+    far-calls the keccak system contract (0x8010) passing its whole heap as calldata; the callee
+    issues four keccak256 calls that read the caller's heap page through MemoryType::FatPointer
+    (2 byte-aligned + 2 with a 31-byte unaligned start) and writes the digests to its own heap."""
+    wl = Workload("cfg3_precompiles", n_instances, n_cycles)
+    # heap layout (bytes): sha regions back to back from 0, then keccak regions (each preceded by 32 spare bytes)
+    sha_off, off = [], 0
+    for r in sha_rounds:
+        sha_off.append(off)
+        off += 64 * r
+    kec_off = []
+    for j, k in enumerate(keccak_k):
+        off = (off + 31) // 32 * 32
+        kec_off.append(off + (31 if j % 2 else 0))
+        off += 136 * k + 32
+    heap_words = (off + 31) // 32 + 8
+    out_base_boot = heap_words - 6  # sha digests land in the last words of the bootloader heap
+    boot_page_heap = BOOTLOADER_BASE_PAGE + 2
+    consts = []
+    for j, r in enumerate(sha_rounds):
+        consts.append(precompile_abi(sha_off[j] // 32, 0, out_base_boot + j, 0, 0, 0, extra=r))
+    consts.append(far_call_abi(0, heap_words * 32, 0x7FFFFFFF))  # [4] far-call ABI: whole heap as calldata
+    consts.append(K.u256_from_int(KECCAK_ADDRESS))                # [5]
+    ops = []
+    for j, r in enumerate(sha_rounds):
+        ops.append(isa.enc(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=CONST_BASE + j, src1=0, dst0=3))
+        ops.append(isa.enc(K.OP_ADD, src0_mode=K.MODE_IMM, imm0=SHA256_COST_PER_ROUND * r, src1=0, dst0=4))
+        ops.append(isa.enc(K.OP_LOG, variant=K.LOG_PRECOMPILE, src0=3, src1=4, dst0=5 + j))
+    ops.append(isa.enc(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=CONST_BASE + 4, src1=0, dst0=13))
+    ops.append(isa.enc(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=CONST_BASE + 5, src1=0, dst0=14))
+    ops.append(isa.enc(K.OP_FAR_CALL, variant=K.FAR_NORMAL, src0=13, src1=14, imm0=len(ops) + 1))
+    n_boot_tail = 4
+    for _ in range(n_boot_tail):
+        ops.append(isa.enc(K.OP_UMA, variant=K.UMA_FAT_PTR_READ, flags=1, src0=1, dst0=3, dst1=1))  # read back the digests
+    boot = np.zeros((CONST_BASE + len(consts), 4), dtype="<u8")
+    code = K.pack_code(ops)
+    boot[: len(code)] = code
+    for i, c in enumerate(consts):
+        boot[CONST_BASE + i] = c
+    wl.blobs.append(boot)
+    wl.code_pages.append((0, n_instances, BOOTLOADER_CODE_PAGE, 0))
+    # keccak system contract
+    cops = []
+    cconsts = []
+    for j, k in enumerate(keccak_k):
+        cconsts.append(precompile_abi(kec_off[j], 136 * k, j, 0, boot_page_heap, 0))
+    cconsts.append(ret_abi(0, 32 * len(keccak_k)))
+    local = 64
+    for j, k in enumerate(keccak_k):
+        cops.append(isa.enc(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=local + j, src1=0, dst0=3))
+        cost = KECCAK_COST_PER_ROUND * (k + 1)
+        cops.append(isa.enc(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=local + 8 + j, src1=0, dst0=4))
+        cconsts_cost = K.u256_from_int(cost)
+        cops.append(isa.enc(K.OP_LOG, variant=K.LOG_PRECOMPILE, src0=3, src1=4, dst0=5 + j))
+    cops.append(isa.enc(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=local + 4, src1=0, dst0=13))
+    cops.append(isa.enc(K.OP_RET, variant=K.RET_OK, src0=13))
+    callee = np.zeros((96, 4), dtype="<u8")
+    code = K.pack_code(cops)
+    callee[: len(code)] = code
+    for i, c in enumerate(cconsts):
+        callee[local + i] = c
+    for j, k in enumerate(keccak_k):
+        callee[local + 8 + j] = K.u256_from_int(KECCAK_COST_PER_ROUND * (k + 1))
+    wl.blobs.append(callee)
+    h = versioned_code_hash(callee)
+    wl.preimages.append((h, 1))
+    slots = np.zeros(1, dtype=K.STORAGE_SLOT)
+    slots[0]["key"] = K.u256_from_int(KECCAK_ADDRESS)
+    slots[0]["value"] = h
+    slots[0]["address"] = K.address_bytes(0x8002)
+    wl.storage = [slots] * n_instances
+    executed = len(ops) + len(cops)
+    assert executed <= n_cycles, (executed, n_cycles)
+    wl.n_cycles = executed
+    wl.limits["max_cycles"] = executed
+    regs = np.zeros((n_instances, 15, 4), dtype="<u8")
+    wl.states, wl.inner = initial_states(n_instances, regs, heap_bound=heap_words * 32 + 64)
+    wl.states["current"]["this_address"] = K.address_bytes(SHA256_ADDRESS)
+    wl.states["current"]["code_address"] = K.address_bytes(SHA256_ADDRESS)
+    # per-instance random heap; sha regions hold properly padded messages so that the digests are real SHA-256 values
+    heaps = Xoshiro(seed ^ 0x4EA9, n_instances).words(heap_words)
+    raw = heaps.astype(">u8")[:, :, ::-1].copy()  # big-endian byte image [n, words, 4] -> bytes
+    by = raw.view("u1").reshape(n_instances, heap_words * 32)
+    wl.sha_messages = []
+    for j, r in enumerate(sha_rounds):
+        msg_len = 64 * r - 9 - (j * 5) % 40  # fits r blocks exactly
+        start = sha_off[j]
+        by[:, start + msg_len] = 0x80
+        by[:, start + msg_len + 1: start + 64 * r - 8] = 0
+        by[:, start + 64 * r - 8: start + 64 * r] = np.frombuffer((8 * msg_len).to_bytes(8, "big"), dtype="u1")
+        wl.sha_messages.append((start, msg_len, out_base_boot + j))
+    wl.keccak_messages = [(kec_off[j], 136 * k, j) for j, k in enumerate(keccak_k)]
+    wl.heap_bytes = by
+    heaps = by.reshape(n_instances, heap_words, 4, 8).view(">u8").reshape(n_instances, heap_words, 4)[:, :, ::-1].astype("<u8")
+    wl.heaps = np.ascontiguousarray(heaps)
+    n_pre_reads = sum(2 * r for r in sha_rounds) + sum((136 * k + 31 + 31) // 32 + 1 for k in keccak_k)
+    wl.limits.update(max_far_frames=2, heap_words=heap_words + 8, stack_words=8, aux_heap_words=8, storage_slots=8, storage_journal=4,
+                     max_mem_queries=n_pre_reads + 8 * executed + 64, max_log_queries=16, max_aux_events=16)
+    return wl
+
+
+# ----------------------------------------------------------------------------------------
+# cfg 4 — full synthetic L2 block: cfg-2 mix + storage r/w + events + L2->L1 + reverting near calls
+# ----------------------------------------------------------------------------------------
+N_STORAGE_KEYS = 256
+
+
+class BlockTapeBuilder(TapeBuilder):
+    def key_reg(self):
+        # r11 := small storage key (pre-populated slots are keys 0..255)
+        self.emit(self.isa.enc(K.OP_ADD, src0_mode=K.MODE_IMM, imm0=self.rng.below(N_STORAGE_KEYS + 32), src1=0, dst0=11))
+
+    def dst(self):
+        self.k += 1
+        return 3 + (self.k % 8)  # r3..r10; r11 = storage key, r12 = heap cursor
+
+    def src(self):
+        return 1 + self.rng.below(10)
+
+    def storage_read(self):
+        self.key_reg()
+        self.emit(self.isa.enc(K.OP_LOG, variant=K.LOG_STORAGE_READ, src0=11, src1=0, dst0=self.dst()))
+
+    def storage_write(self):
+        self.key_reg()
+        self.emit(self.isa.enc(K.OP_LOG, variant=K.LOG_STORAGE_WRITE, src0=11, src1=self.src()))
+
+    def event(self):
+        self.emit(self.isa.enc(K.OP_LOG, variant=K.LOG_EVENT, flags=self.rng.below(2), src0=self.src(), src1=self.src()))
+
+    def to_l1(self):
+        self.emit(self.isa.enc(K.OP_LOG, variant=K.LOG_TO_L1, flags=self.rng.below(2), src0=self.src(), src1=self.src()))
+
+    def context_op(self):
+        r = self.rng
+        v = r.below(10)
+        if v <= K.CTX_GET_CONTEXT_U128:
+            self.emit(self.isa.enc(K.OP_CONTEXT, variant=v, dst0=self.dst()))
+        elif v == K.CTX_INC_TX_NUMBER:
+            self.emit(self.isa.enc(K.OP_CONTEXT, variant=v))
+        else:
+            self.emit(self.isa.enc(K.OP_CONTEXT, variant=v, src0=self.src()))
+            if v == K.CTX_SET_ERGS_PER_PUBDATA:  # keep pubdata prices small: immediately override with an immediate-derived value
+                self.emit(self.isa.enc(K.OP_ADD, src0_mode=K.MODE_IMM, imm0=1 + r.below(20), src1=0, dst0=10))
+                self.emit(self.isa.enc(K.OP_CONTEXT, variant=v, src0=10))
+
+    def ptr_op(self):
+        # r1 holds a fat pointer after any far-call return; results go to r2 (keeps the pointer tag)
+        r = self.rng
+        v = r.below(4)
+        if v in (K.PTR_ADD, K.PTR_SHRINK):
+            self.emit(self.isa.enc(K.OP_ADD, src0_mode=K.MODE_IMM, imm0=r.below(48), src1=0, dst0=10))
+            self.emit(self.isa.enc(K.OP_PTR, variant=v, flags=0, src0=1, src1=10, dst0=2))
+        elif v == K.PTR_SUB:  # advance first so that the subtraction cannot underflow (that would be a VM panic)
+            self.emit(self.isa.enc(K.OP_ADD, src0_mode=K.MODE_IMM, imm0=48, src1=0, dst0=10))
+            self.emit(self.isa.enc(K.OP_PTR, variant=K.PTR_ADD, flags=0, src0=1, src1=10, dst0=2))
+            self.emit(self.isa.enc(K.OP_ADD, src0_mode=K.MODE_IMM, imm0=r.below(48), src1=0, dst0=10))
+            if r.below(2):  # swapped form: the pointer travels in src1 and the swap flag puts it back into src0
+                self.emit(self.isa.enc(K.OP_PTR, variant=K.PTR_SUB, flags=1, src0=10, src1=2, dst0=2))
+            else:
+                self.emit(self.isa.enc(K.OP_PTR, variant=K.PTR_SUB, flags=0, src0=2, src1=10, dst0=2))
+        else:
+            self.emit(self.isa.enc(K.OP_SHIFT, variant=K.SHIFT_SHL, src0_mode=K.MODE_REG, flags=0, src0=self.src(), src1=0, dst0=10))
+            self.emit(self.isa.enc(K.OP_ADD, src0_mode=K.MODE_IMM, imm0=128, src1=0, dst0=9))
+            self.emit(self.isa.enc(K.OP_SHIFT, variant=K.SHIFT_SHL, flags=0, src0=10, src1=9, dst0=10))  # low 128 bits cleared
+            self.emit(self.isa.enc(K.OP_PTR, variant=K.PTR_PACK, flags=0, src0=1, src1=10, dst0=2))
+
+    def block_segment(self, n):
+        """cfg-2 mix + 8% storage read, 4% storage write, 3% event, 1% L2->L1 (+ context / ptr ops)."""
+        target = self.executed + n
+        self.set_cursor()
+        while self.executed < target - 4:
+            x = self.rng.below(100)
+            if x < 8:
+                self.storage_read()
+            elif x < 12:
+                self.storage_write()
+            elif x < 15:
+                self.event()
+            elif x < 16:
+                self.to_l1()
+            elif x < 19:
+                self.context_op()
+            elif x < 22:
+                self.ptr_op()
+            elif x < 52:
+                if self.rng.chance(1, 6):
+                    self.set_cursor()
+                else:
+                    self.alu()
+            elif x < 68:
+                self.heap_ld()
+            elif x < 84:
+                self.heap_st()
+            elif x < 92:
+                self.stack_op()
+            else:
+                self.jump()
+        while self.executed < target:
+            self.emit(self.isa.enc(K.OP_NOP))
+
+
+def config4(isa, n_instances=4096, n_cycles=1024, seed=0x5EED0004):
+    wl = Workload("cfg4_l2_block", n_instances, n_cycles)
+    rng = ScalarRng(seed)
+    tb = BlockTapeBuilder(isa, rng)
+    consts_rnd = Xoshiro(seed ^ 0x77, 1).words(4)[0]
+    consts = [far_call_abi(64, 256, 100000), K.u256_from_int(ADDR_A), far_call_abi(512, 96, 50000), K.u256_from_int(ADDR_B),
+              consts_rnd[0], consts_rnd[1], consts_rnd[2], consts_rnd[3]]
+    # subroutines (near-call targets) are placed after the main program; their bodies write storage and
+    # emit events so that a reverting return exercises the rollback journals
+    SUB_BODY = 12
+    n_near = max(1, n_cycles // 64)
+    far_overhead = 2 * (1 + CALLEE_CYCLES + RELOAD_CYCLES)
+    near_overhead = n_near * (2 + SUB_BODY + 1)
+    main_budget = n_cycles - far_overhead - near_overhead
+    assert main_budget > 64
+    seg = main_budget // (n_near + 2)
+    pending_subs = []  # (index of the near_call op in tb.ops, reverting?)
+    far_at = {n_near // 3: (2, 3), (2 * n_near) // 3: (0, 1)}
+    used = 0
+    for j in range(n_near):
+        tb.block_segment(seg)
+        used += seg
+        if j in far_at:
+            tb.far_call()
+            tb.executed += CALLEE_CYCLES
+            tb.reload(*far_at[j])
+        # near call: r10 := ergs to pass, then near_call r10, @sub, @handler
+        tb.emit(isa.enc(K.OP_ADD, src0_mode=K.MODE_IMM, imm0=20000 + rng.below(20000), src1=0, dst0=10))
+        pending_subs.append((len(tb.ops), rng.chance(1, 10) or j == 1))
+        tb.emit(0)  # patched below
+        tb.executed += SUB_BODY + 1
+    tb.block_segment(n_cycles - tb.executed)
+    assert tb.executed == n_cycles, (tb.executed, n_cycles)
+    # jump-over guard, then the subroutines
+    for idx, reverting in pending_subs:
+        sub_pc = len(tb.ops)
+        handler = idx + 1  # exception handler = fall through
+        tb.ops[idx] = isa.enc(K.OP_NEAR_CALL, src0=10, imm0=sub_pc, imm1=handler)
+        sub = BlockTapeBuilder(isa, rng)
+        sub.ops = tb.ops
+        for q in range(SUB_BODY // 4):
+            sub.storage_write()   # 2 ops
+            sub.event()           # 1 op
+            sub.alu()             # 1 op
+        tb.ops.append(isa.enc(K.OP_RET, variant=K.RET_REVERT if reverting else K.RET_OK, flags=0, src0=0))
+    boot_words = np.zeros((CONST_BASE + len(consts), 4), dtype="<u8")
+    code = K.pack_code(tb.ops)
+    assert len(code) < CONST_BASE, len(code)
+    boot_words[: len(code)] = code
+    for i, c in enumerate(consts):
+        boot_words[CONST_BASE + i] = c
+    wl.blobs.append(boot_words)
+    wl.code_pages.append((0, n_instances, BOOTLOADER_CODE_PAGE, 0))
+    for which, retv in ((0, K.RET_OK), (1, K.RET_REVERT)):
+        ops = callee_program(isa, rng, retv)
+        words = np.zeros((CALLEE_CODE_WORDS, 4), dtype="<u8")
+        fill = Xoshiro(seed ^ (0x1000 + which), 1).words(CALLEE_CODE_WORDS - 64)[0]
+        words[32: 32 + len(fill)] = fill
+        words[CALLEE_CODE_WORDS - 8:] = 0
+        local = CALLEE_CODE_WORDS - 8
+        ops[11] = isa.enc(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=local, src1=0, dst0=13)
+        code = K.pack_code(ops)
+        words[: len(code)] = code
+        words[local] = ret_abi(0, 64)
+        wl.blobs.append(words)
+        wl.preimages.append((versioned_code_hash(words), 1 + which))
+    # storage: deployer entries + 256 pre-populated slots of the bootloader's own account
+    n_slots = 2 + N_STORAGE_KEYS
+    vals = Xoshiro(seed ^ 0x5107, n_instances).words(N_STORAGE_KEYS)
+    wl.storage = []
+    base = np.zeros(n_slots, dtype=K.STORAGE_SLOT)
+    for which, addr in enumerate((ADDR_A, ADDR_B)):
+        base[which]["key"] = K.u256_from_int(addr)
+        base[which]["value"] = wl.preimages[which][0]
+        base[which]["address"] = K.address_bytes(0x8002)
+    for kx in range(N_STORAGE_KEYS):
+        base[2 + kx]["key"] = K.u256_from_int(kx)
+        base[2 + kx]["address"] = K.address_bytes(KERNEL_ADDRESS)
+    for i in range(n_instances):
+        s = base.copy()
+        s["value"][2:] = vals[i]
+        wl.storage.append(s)
+    regs = Xoshiro(seed ^ 0xABCDEF, n_instances).words(15)
+    regs[:, 5::4, 3] = 0
+    regs[:, 6::4, 2:] = 0
+    regs[:, 10] = 0
+    regs[:, 11] = 0
+    regs[:, 12] = consts[0]
+    regs[:, 13] = consts[1]
+    regs[:, 14] = 0
+    wl.states, wl.inner = initial_states(n_instances, regs)
+    wl.states["current_ergs_per_pubdata_byte"] = 7
+    wl.states["register_ptr_bitmap"] = 1  # r1 starts as a (synthetic) fat pointer so that ptr.* ops before the first far call are legal
+    wl.states["registers"][:, 0] = K.u256_from_int((0) | (0 << 32) | (0 << 64) | (4096 << 96))  # offset 0, page 0 (Empty), start 0, length 4096
+    wl.heaps = Xoshiro(seed ^ 0x4EA9, n_instances).words(HEAP_BYTES // 32)
+    n_writes = n_cycles  # generous
+    wl.limits.update(max_far_frames=3, max_callstack_depth=6, heap_words=384, stack_words=256, aux_heap_words=8, storage_slots=1024,
+                     storage_journal=n_writes, max_log_queries=n_cycles, max_aux_events=n_cycles // 2 + 64)
+    return wl
+
+
+def make(cfg, isa, **kw):  # noqa: F811
+    return {0: config0, 1: config1, 2: config2, 3: config3, 4: config4}[cfg](isa, **kw)

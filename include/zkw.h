@@ -404,7 +404,8 @@ void zkw_batch_destroy(zkw_batch* batch);
 int zkw_batch_add_code_blob(zkw_batch* batch, const zkw_u256* words, uint32_t n_words, uint32_t* blob_id);
 /* known_hashes[hash] = blob (decommitter.rs:23-28) */
 int zkw_batch_add_decommit_preimage(zkw_batch* batch, const zkw_u256* hash, uint32_t blob_id);
-/* code_pages[page] = blob for instances [first, first+count) (memory.rs:271-284) */
+/* code_pages[page] = blob for instances [first, first+count) (memory.rs:271-284); a later call for the
+ * same (instance, page) replaces the earlier one */
 int zkw_batch_set_code_page(zkw_batch* batch, uint32_t first, uint32_t count, uint32_t page, uint32_t blob_id);
 /* VmLocalState + callstack.inner (inner_depth entries per instance, oldest first) for
  * instances [first, first+count).  Mirrors VmState::empty_state + push_bootloader_context

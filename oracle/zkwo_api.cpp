@@ -173,7 +173,11 @@ static void build_vm(zkwo_batch* b, uint32_t i) {
     vm->event_sink.start_frame(0);
     if (!f->is_local_frame) vm->memory.start_global_frame(0, f->base_memory_page, FatPointer::empty(), 0);
   }
-  for (auto& pb : s.code_pages) vm->memory.populate_code(pb.first, *b->blobs[pb.second]);
+  {  // zkw_batch_set_code_page: a later call for the same page replaces the earlier one
+    std::unordered_map<uint32_t, uint32_t> last;
+    for (auto& pb : s.code_pages) last[pb.first] = pb.second;
+    for (auto& pb : last) vm->memory.populate_code(pb.first, *b->blobs[pb.second]);
+  }
   if (!s.heap.empty()) vm->memory.populate_heap(s.heap);
   for (const zkw_storage_slot& sl : s.storage) {
     Address a;
@@ -193,7 +197,12 @@ int zkwo_batch_reset(zkwo_batch* b, void*) {
   b->vms.resize(b->n);
   b->results.clear();
   b->results.resize(b->n);
-  for (uint32_t i = 0; i < b->n; i++) build_vm(b, i);
+  try {
+    for (uint32_t i = 0; i < b->n; i++) build_vm(b, i);
+  } catch (const std::exception& e) {
+    b->ctx->last_error = std::string("reset: ") + e.what();
+    return ZKW_ERR_INVALID;
+  }
   b->ran = false;
   return ZKW_OK;
 }

@@ -83,3 +83,68 @@ def test_split_run_equals_single_run(product, isa):
     for a, c in zip(whole, parts):
         ok, why = K.traces_equal(a, c)
         assert ok, why
+
+
+@pytest.mark.parametrize("lanes", [0, 64])
+def test_cfg3_precompiles(oracle, product, isa, lanes):
+    _compare(oracle, product, synth.make(3, isa, n_instances=96, keccak_k=(1, 2, 8, 3), sha_rounds=(1, 2, 8, 5)), lanes)
+
+
+def test_cfg3_baseline_sizes_sampled(oracle, product, isa):
+    # BASELINE sizes: keccak 136*{1,8,64,512} bytes, sha256 {1,8,64,157} rounds; 128 instances on the GPU,
+    # a sample of them against the oracle, and every digest against hashlib / an independent Keccak
+    import hashlib
+    from test_oracle_precompiles import _keccak256_py
+    wl = synth.make(3, isa, n_instances=128)
+    bp = _run(product, wl)
+    bo = _run(oracle, wl)
+    for i in (0, 63, 64, 127):
+        ok, why = K.traces_equal(bo.trace(i), bp.trace(i))
+        assert ok, "instance %d: %s" % (i, why)
+    for i in range(0, 128, 9):
+        t = bp.trace(i)
+        writes = [q for q in t["mem"] if (q["meta"] >> K.MQ_KIND_SHIFT) == 2]
+        data = wl.heap_bytes[i].tobytes()
+        for (start, length, _), q in zip(wl.sha_messages, writes[:4]):
+            assert K.u256_to_int(q["value"]).to_bytes(32, "big") == hashlib.sha256(data[start:start + length]).digest()
+        for (start, length, _), q in zip(wl.keccak_messages[:3], writes[4:7]):
+            assert K.u256_to_int(q["value"]).to_bytes(32, "big") == _keccak256_py(data[start:start + length])
+
+
+@pytest.mark.parametrize("lanes", [0, 16, 64])
+def test_cfg4_l2_block(oracle, product, isa, lanes):
+    _compare(oracle, product, synth.make(4, isa, n_instances=192, n_cycles=1024), lanes)
+
+
+def test_cfg4_full_size_sampled(oracle, product, isa):
+    wl = synth.make(4, isa, n_instances=4096, n_cycles=1024)
+    _compare(oracle, product, wl, 0, sample=range(5, 4096, 211))
+
+
+def test_divergent_tapes_in_one_wave(oracle, product, isa):
+    """Instances of one wave running DIFFERENT programs (lanes diverge on every opcode): half the lanes run
+    the cfg-4 tape, the others a cfg-1-style arithmetic tape through a second code page."""
+    wl = synth.make(4, isa, n_instances=64, n_cycles=512)
+    other = synth.arith_tape(isa, 512, synth.ScalarRng(99))
+    wl.blobs.append(K.pack_code(other))
+    alt = len(wl.blobs) - 1
+    for i in range(1, 64, 2):
+        wl.code_pages.append((i, 1, synth.BOOTLOADER_CODE_PAGE, alt))
+    _compare(oracle, product, wl, 64)
+
+
+def test_status_codes(oracle, product, isa):
+    wl = synth.make(2, isa, n_instances=64)
+    wl.preimages = wl.preimages[1:]
+    bo, bp = _run(oracle, wl), _run(product, wl, 64)
+    for i in (0, 31, 63):
+        to, tp = bo.trace(i), bp.trace(i)
+        assert tp["status"] == K.STATUS_UNKNOWN_CODE_HASH
+        ok, why = K.traces_equal(to, tp)
+        assert ok, why
+    wl = synth.make(0, isa, n_cycles=64)
+    wl.blobs[0] = K.pack_code([isa.enc(K.OP_ADD, src0=1, src1=2, dst0=3)] * 5 + [isa.enc(K.OP_RET, variant=K.RET_OK, src0=0)])
+    to, tp = _run(oracle, wl).trace(0), _run(product, wl).trace(0)
+    assert tp["status"] == K.STATUS_ENDED and tp["n_cycles"] == 6
+    ok, why = K.traces_equal(to, tp)
+    assert ok, why
