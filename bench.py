@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per wave (0 = library default)")
     ap.add_argument("--cfg", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--commit-mask", type=int, default=4, help="queue commitments computed inside every step: bit0 memory, bit1 log, bit2 decommit (BASELINE configs[2]: decommit queue)")
     args = ap.parse_args()
 
     import torch
@@ -55,17 +56,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    import ctypes as C
+
+    def step():
         batch.reset(sptr)
         batch.run(wl.n_cycles, sptr)
+        if args.commit_mask:
+            prod.call("batch_commit", batch.h, C.c_uint32(args.commit_mask), C.c_void_p(sptr))
+
+    for _ in range(args.warmup):
+        step()
         batch.sync()
     # timed region: K steps; resets are queued between steps on the same stream (they restore the inputs
     # for the next step and are charged to the wall clock, not to the kernel's own HIP-event time)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        batch.reset(sptr)
-        batch.run(wl.n_cycles, sptr)
+        step()
     batch.sync()  # one host sync for all K steps; per-run HIP event pairs give the kernel's own mean time
     barrier()
     elapsed = time.perf_counter() - t0
@@ -95,7 +102,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u256 (8 x u32 limbs)", "data": "synthetic",
             "config": {"workload": "cfg%d: %d instances x %d cycles per GPU (%s)" % (args.cfg, args.instances, args.cycles, wl.name),
-                       "instances_per_gpu": args.instances, "cycles_per_instance": args.cycles, "lanes_per_wave": int(batch.limits["lanes_per_wave"][0])},
+                       "instances_per_gpu": args.instances, "cycles_per_instance": args.cycles, "lanes_per_wave": int(batch.limits["lanes_per_wave"][0]), "commit_mask": args.commit_mask},
             "kernel_ms": k_ms,
             "kernel_cycles_per_s": cycles_per_step / (k_ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,

@@ -1,0 +1,283 @@
+// Queue commitments: memory / log / decommit queue digests per VM instance.
+//
+// The reference crate has NO sponge or queue commitment (only a comment, far_call.rs:29-32, and a
+// dead stub, vm_state/aux_data.rs:1-6): downstream circuits own that.  This file implements the
+// build's OWN spec ("ZKW-GL-sponge v1") so that the north star's
+// "algebraic sponge absorb over the emitted queues" and the multi-GPU final reduction have something
+// concrete and testable; oracle/commit.hpp restates the same spec on the CPU.  PARITY UNPINNED w.r.t.
+// any real zkEVM circuit format.
+//
+//   field   Goldilocks p = 2^64 - 2^32 + 1, canonical representatives
+//   P       Poseidon2-shaped permutation, t = 12, x^7, 4 + 22 + 4 rounds, external layer
+//           circ(2 M4, M4, M4), internal layer J + diag(2^i), constants from splitmix64("zkwGLv1")
+//   leaf    sponge (rate 8 / capacity 4) over the record's u32 limbs, domain = (type, length)
+//   chain   tail' = P(leaf || tail || i+1 || queue id || 0 || 0)[0..4]
+//
+// Parallel structure on the GPU: leaves are hashed one record per lane over the dense wave streams
+// (embarrassingly parallel, coalesced), a bucket pass turns the lane tags of each wave stream into
+// per-instance index lists, and the sequential chains then run one instance per lane in lockstep.
+#include <hip/hip_runtime.h>
+
+#include "zkw_device.h"
+#include "zkw_commit.h"
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+#define ZD __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------------
+// Goldilocks
+// ---------------------------------------------------------------------------------------------
+#define GL_P 0xffffffff00000001ULL
+#define GL_EPS 0xffffffffULL
+
+ZD u64 gl_add(u64 a, u64 b) {
+  u64 r = a + b;
+  if (r < a) r += GL_EPS;  // wrapped past 2^64: 2^64 = EPS (mod p); cannot wrap again since a, b < p
+  if (r >= GL_P) r -= GL_P;
+  return r;
+}
+ZD void mul64(u64 a, u64 b, u64& lo, u64& hi) {
+  const u64 a0 = (u32)a, a1 = a >> 32, b0 = (u32)b, b1 = b >> 32;
+  const u64 p00 = a0 * b0, p01 = a0 * b1, p10 = a1 * b0, p11 = a1 * b1;
+  const u64 mid = (p00 >> 32) + (u32)p01 + (u32)p10;
+  lo = (mid << 32) | (u32)p00;
+  hi = p11 + (p01 >> 32) + (p10 >> 32) + (mid >> 32);
+}
+ZD u64 gl_reduce128(u64 lo, u64 hi) {
+  const u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+  u64 t0 = lo - hi_hi;
+  if (lo < hi_hi) t0 -= GL_EPS;  // borrow: subtract 2^64 = EPS (mod p) once more
+  const u64 t1 = hi_lo * GL_EPS;
+  u64 r = t0 + t1;
+  if (r < t1) r += GL_EPS;
+  if (r >= GL_P) r -= GL_P;
+  return r;
+}
+ZD u64 gl_mul(u64 a, u64 b) {
+  u64 lo, hi;
+  mul64(a, b, lo, hi);
+  return gl_reduce128(lo, hi);
+}
+ZD u64 gl_pow7(u64 x) {
+  const u64 x2 = gl_mul(x, x), x3 = gl_mul(x2, x), x4 = gl_mul(x2, x2);
+  return gl_mul(x4, x3);
+}
+
+// M4 of the Poseidon2 paper: [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]]
+ZD void gl_m4(u64& a, u64& b, u64& c, u64& d) {
+  const u64 t0 = gl_add(a, b), t1 = gl_add(c, d);
+  const u64 t2 = gl_add(gl_add(b, b), t1), t3 = gl_add(gl_add(d, d), t0);
+  const u64 t4 = gl_add(gl_add(gl_add(t1, t1), gl_add(t1, t1)), t3);
+  const u64 t5 = gl_add(gl_add(gl_add(t0, t0), gl_add(t0, t0)), t2);
+  const u64 t6 = gl_add(t3, t5), t7 = gl_add(t2, t4);
+  a = t6; b = t5; c = t7; d = t4;
+}
+ZD void gl_external(u64 s[12]) {
+#pragma unroll
+  for (int i = 0; i < 12; i += 4) gl_m4(s[i], s[i + 1], s[i + 2], s[i + 3]);
+  u64 sum[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) sum[j] = gl_add(gl_add(s[j], s[4 + j]), s[8 + j]);
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], sum[i & 3]);
+}
+ZD void gl_internal(u64 s[12]) {
+  u64 sum = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) sum = gl_add(sum, s[i]);
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl_add(sum, gl_mul(s[i], 1ULL << i));
+}
+
+ZD void gl_permute(const u64* rc, u64 s[12]) {
+  gl_external(s);
+  int k = 0;
+  for (int r = 0; r < 4; r++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_pow7(gl_add(s[i], rc[k + i]));
+    k += 12;
+    gl_external(s);
+  }
+  for (int r = 0; r < 22; r++) {
+    s[0] = gl_pow7(gl_add(s[0], rc[k]));
+    k += 1;
+    gl_internal(s);
+  }
+  for (int r = 0; r < 4; r++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_pow7(gl_add(s[i], rc[k + i]));
+    k += 12;
+    gl_external(s);
+  }
+}
+
+// sponge over n <= 32 field elements held in a statically indexed array
+template <int N>
+ZD void gl_leaf(const u64* rc, u32 type, const u64 f[N], u64 out[4]) {
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = 0;
+  s[8] = ((u64)type << 32) | (u64)N;
+#pragma unroll
+  for (int b = 0; b < (N + 7) / 8; b++) {
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (b * 8 + j < N) s[j] = gl_add(s[j], f[b * 8 + j]);
+    gl_permute(rc, s);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[i] = s[i];
+}
+
+ZD void gl_chain_step(const u64* rc, const u64 leaf[4], u64 tail[4], u64 index_plus_1, u32 queue_id) {
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    s[i] = leaf[i];
+    s[4 + i] = tail[i];
+  }
+  s[8] = index_plus_1;
+  s[9] = queue_id;
+  s[10] = 0;
+  s[11] = 0;
+  gl_permute(rc, s);
+#pragma unroll
+  for (int i = 0; i < 4; i++) tail[i] = s[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+
+// one stream record per thread -> leaf[wave][pos] (4 x u64)
+__global__ void zkw_leaf_kernel(zkw_commit_params C) {
+  const u32 wave = blockIdx.y;
+  u32 n = C.n_override;
+  if (!n) n = C.cursors[wave * 4 + C.queue] < C.cap ? C.cursors[wave * 4 + C.queue] : C.cap;
+  for (u32 pos = blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += gridDim.x * blockDim.x) {
+    u64 out[4];
+    if (C.queue == ZKW_QUEUE_MEMORY) {
+      const uint4* e = C.stream + ((u64)wave * C.cap + pos) * 3;
+      const uint4 h = e[0], lo = e[1], hi = e[2];
+      u64 f[12] = {h.x, h.y, h.z, (h.w >> 16) & 0xffu, lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      gl_leaf<12>(C.rc, ZKW_LEAF_MEM, f, out);
+    } else if (C.queue == ZKW_QUEUE_LOG) {
+      const uint4* e = C.stream + ((u64)wave * C.cap + pos) * 8;
+      u64 f[32];
+      const uint4 a6 = e[6], a7 = e[7];
+      f[0] = a7.y;                                              // timestamp
+      f[1] = a7.z & 0xffffu;                                    // tx number
+      f[2] = ((a7.z >> 16) & 0xffu) | (((a7.z >> 24) & 0xffu) << 8) | ((a7.w & 0xffu) << 16) | (((a7.w >> 8) & 0xffu) << 24);  // aux|shard|bools|kind
+      f[3] = a6.x; f[4] = a6.y; f[5] = a6.z; f[6] = a6.w; f[7] = a7.x;  // address
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        const uint4 v = e[q];
+        f[8 + 4 * q] = v.x; f[9 + 4 * q] = v.y; f[10 + 4 * q] = v.z; f[11 + 4 * q] = v.w;
+      }
+      gl_leaf<32>(C.rc, ZKW_LEAF_LOG, f, out);
+    } else if (C.queue == ZKW_QUEUE_DECOMMIT) {
+      const uint4* e = C.stream + ((u64)wave * C.cap + pos) * 16;
+      const uint4 h = e[0];
+      const u32 type = h.x & 0xffu;
+      if (type == ZKW_AUX_DECOMMIT) {
+        const uint4 lo = e[1], hi = e[2];
+        const u32 blob = h.w >> 16;
+        const u64* bd = C.blob_digests + (u64)blob * 4;
+        u64 f[16] = {h.y, h.z, h.w & 0xffffu, (h.x >> 24) & 0xffu, lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, bd[0], bd[1], bd[2], bd[3]};
+        gl_leaf<16>(C.rc, ZKW_LEAF_DECOMMIT, f, out);
+      } else {
+        out[0] = out[1] = out[2] = out[3] = 0;
+      }
+    } else {  // code words of the blobs: stream = blob words (2 x uint4 per word), wave = 0
+      const uint4 lo = C.stream[(u64)pos * 2], hi = C.stream[(u64)pos * 2 + 1];
+      u64 f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      gl_leaf<8>(C.rc, ZKW_LEAF_CODE_WORD, f, out);
+    }
+    u64* dst = C.leaves + ((u64)wave * C.cap + pos) * 4;
+    dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2]; dst[3] = out[3];
+  }
+}
+
+// per wave: lane l walks the wave's stream cycle by cycle (directory) and lists the positions of its
+// own records (of completed cycles only) -> idx[inst][j], count[inst]
+__global__ void zkw_bucket_kernel(zkw_commit_params C) {
+  const u32 wave = blockIdx.x;
+  const u32 lane = threadIdx.x;
+  const u32 inst = wave * C.L + lane;
+  if (lane >= C.L || inst >= C.n_instances) return;
+  const u32 ncyc = C.scalars[inst].n_cycles;
+  const u32 rec_bytes = C.queue == ZKW_QUEUE_MEMORY ? 48u : (C.queue == ZKW_QUEUE_LOG ? 128u : 256u);
+  const uint8_t* base = (const uint8_t*)C.stream + (u64)wave * C.cap * rec_bytes;
+  const u32 n = C.cursors[wave * 4 + C.queue] < C.cap ? C.cursors[wave * 4 + C.queue] : C.cap;
+  u32* out = C.idx + (u64)inst * C.per_instance_cap;
+  u32 cnt = 0;
+  const uint32_t* dir = C.dir + (u64)wave * (C.max_cycles + 1) * 4;
+  const u32 p_end_all = dir[(u64)ncyc * 4 + C.queue] < n ? dir[(u64)ncyc * 4 + C.queue] : n;  // records of cycles < ncyc
+  for (u32 p = 0; p < p_end_all; p++) {
+    u32 tag, type = 0;
+    if (C.queue == ZKW_QUEUE_MEMORY) {
+      tag = base[(u64)p * 48 + 12];
+    } else if (C.queue == ZKW_QUEUE_LOG) {
+      tag = base[(u64)p * 128 + 126];
+    } else {
+      tag = base[(u64)p * 256 + 1];
+      type = base[(u64)p * 256];
+    }
+    if (tag == lane && (C.queue != ZKW_QUEUE_DECOMMIT || type == ZKW_AUX_DECOMMIT)) {
+      if (cnt < C.per_instance_cap) out[cnt] = p;
+      cnt++;
+    }
+  }
+  C.counts[inst] = cnt < C.per_instance_cap ? cnt : C.per_instance_cap;
+}
+
+// one instance per lane: sequential chain over its leaves
+__global__ void zkw_chain_kernel(zkw_commit_params C) {
+  const u32 wave = blockIdx.x;
+  const u32 lane = threadIdx.x;
+  const u32 inst = wave * C.L + lane;
+  if (lane >= C.L || inst >= C.n_instances) return;
+  const u32 cnt = C.counts[inst];
+  const u32* idx = C.idx + (u64)inst * C.per_instance_cap;
+  u64 tail[4] = {0, 0, 0, 0};
+  for (u32 j = 0; j < cnt; j++) {
+    const u64* lf = C.leaves + ((u64)wave * C.cap + idx[j]) * 4;
+    const u64 leaf[4] = {lf[0], lf[1], lf[2], lf[3]};
+    gl_chain_step(C.rc, leaf, tail, (u64)j + 1, C.queue);
+  }
+  u64* dst = C.out + ((u64)inst * ZKW_QUEUE_COUNT + C.queue) * 4;
+  dst[0] = tail[0]; dst[1] = tail[1]; dst[2] = tail[2]; dst[3] = tail[3];
+}
+
+// blob digests: one blob per thread, chain over its word leaves (run once per upload)
+__global__ void zkw_blob_chain_kernel(zkw_commit_params C) {
+  for (u32 b = blockIdx.x * blockDim.x + threadIdx.x; b < C.n_blobs; b += gridDim.x * blockDim.x) {
+    const uint2 d = C.blob_dir[b];
+    u64 tail[4] = {0, 0, 0, 0};
+    for (u32 j = 0; j < d.y; j++) {
+      const u64* lf = C.leaves + ((u64)d.x + j) * 4;
+      const u64 leaf[4] = {lf[0], lf[1], lf[2], lf[3]};
+      gl_chain_step(C.rc, leaf, tail, (u64)j + 1, ZKW_QUEUE_ID_BLOB);
+    }
+    u64* dst = C.out + (u64)b * 4;
+    dst[0] = tail[0]; dst[1] = tail[1]; dst[2] = tail[2]; dst[3] = tail[3];
+  }
+}
+
+extern "C" hipError_t zkw_launch_commit(const zkw_commit_params* C, int stage, hipStream_t stream) {
+  const u32 wt = C->wave_threads;
+  if (stage == ZKW_COMMIT_STAGE_LEAF) {
+    const u32 threads = wt > 1 ? 256 : 1;
+    const u32 per_wave_blocks = (C->cap + threads - 1) / threads;
+    hipLaunchKernelGGL(zkw_leaf_kernel, dim3(per_wave_blocks < 64 ? (per_wave_blocks ? per_wave_blocks : 1) : 64, C->n_waves), dim3(threads), 0, stream, *C);
+  } else if (stage == ZKW_COMMIT_STAGE_BUCKET) {
+    hipLaunchKernelGGL(zkw_bucket_kernel, dim3(C->n_waves), dim3(wt), 0, stream, *C);
+  } else if (stage == ZKW_COMMIT_STAGE_CHAIN) {
+    hipLaunchKernelGGL(zkw_chain_kernel, dim3(C->n_waves), dim3(wt), 0, stream, *C);
+  } else {
+    const u32 threads = wt > 1 ? 64 : 1;
+    hipLaunchKernelGGL(zkw_blob_chain_kernel, dim3((C->n_blobs + threads - 1) / threads), dim3(threads), 0, stream, *C);
+  }
+  return hipGetLastError();
+}

@@ -1613,9 +1613,6 @@ __global__ void __launch_bounds__(ZKW_WAVE) zkw_cycle_kernel(zkw_kparams P) {
 extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L) { return ZKW_ISA_TABLE_SIZE * 8 + 16 + L * (ZKW_REG_CHUNKS * 16 + 34 * 4); }
 
 // host-callable launcher (keeps <<<>>> out of the runtime)
-// queue commitments are built in a later milestone
-extern "C" hipError_t zkw_launch_commit_kernel(const zkw_kparams*, uint64_t*, hipStream_t) { return hipErrorNotSupported; }
-
 extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_kparams* P, hipStream_t stream) {
   hipLaunchKernelGGL(zkw_cycle_kernel, dim3(P->n_waves), dim3(P->wave_threads), zkw_cycle_kernel_lds_bytes(P->L), stream, *P);
   return hipGetLastError();

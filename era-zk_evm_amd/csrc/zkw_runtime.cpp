@@ -18,11 +18,12 @@
 #include <string>
 #include <vector>
 
+#include "zkw_commit.h"
 #include "zkw_device.h"
 
 extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_kparams* P, hipStream_t stream);
 extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L);
-extern "C" hipError_t zkw_launch_commit_kernel(const zkw_kparams* P, uint64_t* out, hipStream_t stream);
+extern "C" hipError_t zkw_launch_commit(const zkw_commit_params* C, int stage, hipStream_t stream);
 
 static_assert(sizeof(zkw_callstack_entry) == 112, "abi");
 static_assert(sizeof(zkw_vm_local_state) == 680, "abi");
@@ -127,7 +128,8 @@ struct zkw_batch {
   // device: outputs
   DevBuf<uint4> d_rec, d_mem, d_log, d_auxs;
   DevBuf<uint32_t> d_dir, d_cursors;
-  DevBuf<uint64_t> d_commit;
+  DevBuf<uint64_t> d_commit, d_rc, d_blob_digests, d_leaves;
+  DevBuf<uint32_t> d_idx, d_counts;
   static const int EV_RING = 64;
   std::vector<hipEvent_t> evs;  // EV_RING (start, stop) pairs, one per run since the last sync
   uint32_t pending_runs = 0;
@@ -258,7 +260,8 @@ void zkw_batch_destroy(zkw_batch* b) {
   b->d_regs.release(); b->d_scalars.release(); b->d_callstack.release(); b->d_frames.release(); b->d_storage.release(); b->d_journal.release();
   b->d_history.release(); b->d_stack_vals.release(); b->d_heap.release(); b->d_aux.release(); b->d_stack_ptrs.release(); b->d_blob_words.release();
   b->d_blob_dir.release(); b->d_preimages.release(); b->d_rec.release(); b->d_mem.release(); b->d_log.release(); b->d_auxs.release();
-  b->d_dir.release(); b->d_cursors.release(); b->d_commit.release();
+  b->d_dir.release(); b->d_cursors.release(); b->d_commit.release(); b->d_rc.release(); b->d_blob_digests.release(); b->d_leaves.release();
+  b->d_idx.release(); b->d_counts.release();
   for (hipEvent_t e : b->evs) (void)hipEventDestroy(e);
   delete b;
 }
@@ -399,6 +402,28 @@ int zkw_batch_upload(zkw_batch* b) {
   }
   HIP_TRY(c, b->d_preimages.alloc(pre.size()));
   HIP_TRY(c, hipMemcpy(b->d_preimages.p, pre.data(), pre.size() * sizeof(zkw_dev_preimage), hipMemcpyHostToDevice));
+
+  // ---- blob digests for the decommit-queue commitment, once per upload ----
+  {
+    uint64_t rc[ZKW_GL_RC_COUNT];
+    zkw_gl_round_constants(rc);
+    b->d_rc.release();
+    HIP_TRY(c, b->d_rc.alloc(ZKW_GL_RC_COUNT));
+    HIP_TRY(c, hipMemcpy(b->d_rc.p, rc, sizeof rc, hipMemcpyHostToDevice));
+    b->d_blob_digests.release();
+    HIP_TRY(c, b->d_blob_digests.alloc(b->blobs.size() * 4));
+    DevBuf<uint64_t> word_leaves;
+    HIP_TRY(c, word_leaves.alloc(all.size() * 4));
+    zkw_commit_params C;
+    std::memset(&C, 0, sizeof C);
+    C.n_waves = 1; C.wave_threads = (uint32_t)c->wave_width; C.queue = ZKW_QUEUE_CODE_WORDS; C.cap = (uint32_t)total_words;
+    C.n_override = (uint32_t)total_words; C.n_blobs = (uint32_t)b->blobs.size(); C.rc = b->d_rc.p; C.stream = b->d_blob_words.p;
+    C.blob_dir = b->d_blob_dir.p; C.leaves = word_leaves.p; C.out = b->d_blob_digests.p;
+    if (total_words) HIP_TRY(c, zkw_launch_commit(&C, ZKW_COMMIT_STAGE_LEAF, nullptr));
+    HIP_TRY(c, zkw_launch_commit(&C, ZKW_COMMIT_STAGE_BLOB_CHAIN, nullptr));
+    HIP_TRY(c, hipStreamSynchronize(nullptr));
+    word_leaves.release();
+  }
 
   // ---- per-instance pristine images ----
   std::vector<uint4> regs((size_t)W * ZKW_REG_CHUNKS * L, make_uint4(0, 0, 0, 0));
@@ -816,15 +841,41 @@ int zkw_batch_get_instance_trace(zkw_batch* b, uint32_t instance, zkw_instance_t
   return ZKW_OK;
 }
 
+int zkw_batch_commit(zkw_batch* b, uint32_t queue_mask, void* hip_stream) {
+  if (!b) return ZKW_ERR_INVALID;
+  zkw_ctx* c = b->ctx;
+  if (!b->ran) return ZKW_ERR_NOT_RUN;
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t caps[3] = {b->cap_mem, b->cap_log, b->cap_aux};
+  const uint32_t per_inst[3] = {b->lim.max_mem_queries, b->lim.max_log_queries, b->lim.max_aux_events};
+  const uint32_t max_cap = std::max(caps[0], std::max(caps[1], caps[2]));
+  const uint32_t max_per = std::max(per_inst[0], std::max(per_inst[1], per_inst[2]));
+  if (!b->d_leaves.p) HIP_TRY(c, b->d_leaves.alloc((size_t)b->n_waves * max_cap * 4));
+  if (!b->d_idx.p) HIP_TRY(c, b->d_idx.alloc((size_t)b->n * max_per));
+  if (!b->d_counts.p) HIP_TRY(c, b->d_counts.alloc(b->n));
+  const uint4* streams[3] = {b->d_mem.p, b->d_log.p, b->d_auxs.p};
+  for (uint32_t q = 0; q < ZKW_QUEUE_COUNT; q++) {
+    if (!((queue_mask >> q) & 1u)) continue;
+    zkw_commit_params C;
+    std::memset(&C, 0, sizeof C);
+    C.n_instances = b->n; C.L = b->L; C.n_waves = b->n_waves; C.max_cycles = b->lim.max_cycles; C.wave_threads = (uint32_t)c->wave_width;
+    C.queue = q; C.cap = caps[q]; C.per_instance_cap = per_inst[q]; C.n_blobs = (uint32_t)b->blobs.size();
+    C.rc = b->d_rc.p; C.stream = streams[q]; C.cursors = b->d_cursors.p; C.dir = b->d_dir.p; C.scalars = b->d_scalars.p;
+    C.blob_digests = b->d_blob_digests.p; C.blob_dir = b->d_blob_dir.p; C.leaves = b->d_leaves.p; C.idx = b->d_idx.p; C.counts = b->d_counts.p;
+    C.out = b->d_commit.p;
+    HIP_TRY(c, zkw_launch_commit(&C, ZKW_COMMIT_STAGE_LEAF, st));
+    HIP_TRY(c, zkw_launch_commit(&C, ZKW_COMMIT_STAGE_BUCKET, st));
+    HIP_TRY(c, zkw_launch_commit(&C, ZKW_COMMIT_STAGE_CHAIN, st));
+  }
+  return ZKW_OK;
+}
+
 int zkw_batch_get_commitments(zkw_batch* b, uint64_t* out) {
   if (!b || !out) return ZKW_ERR_INVALID;
   zkw_ctx* c = b->ctx;
-  if (!b->ran) return ZKW_ERR_NOT_RUN;
-  HIP_TRY(c, hipSetDevice(c->device));
-  zkw_kparams P = b->kp;
-  P.cycle_base = 0;
-  P.run_cycles = b->cycles_run;
-  HIP_TRY(c, zkw_launch_commit_kernel(&P, b->d_commit.p, b->run_stream));
+  int rc = zkw_batch_commit(b, 7u, b->run_stream);
+  if (rc != ZKW_OK) return rc;
   HIP_TRY(c, hipStreamSynchronize(b->run_stream));
   HIP_TRY(c, hipMemcpy(out, b->d_commit.p, b->d_commit.bytes(), hipMemcpyDeviceToHost));
   return ZKW_OK;

@@ -435,6 +435,9 @@ int zkw_batch_get_instance_trace(zkw_batch* batch, uint32_t instance, zkw_instan
 #define ZKW_QUEUE_LOG 1
 #define ZKW_QUEUE_DECOMMIT 2
 #define ZKW_QUEUE_COUNT 3
+/* enqueues the commitment kernels for the queues in `queue_mask` (bit q = ZKW_QUEUE_q) on `stream`, after
+ * the run(s) since the last reset; results stay in device memory (zkw_batch_commitments_device_ptr) */
+int zkw_batch_commit(zkw_batch* batch, uint32_t queue_mask, void* hip_stream);
 /* digests[instance][queue] : 4 x u64 Goldilocks elements each, computed on device from the
  * streams of the last run; `out` holds n_instances * ZKW_QUEUE_COUNT * 4 u64 */
 int zkw_batch_get_commitments(zkw_batch* batch, uint64_t* out);

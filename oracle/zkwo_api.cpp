@@ -7,6 +7,7 @@
 #include <chrono>
 #include <thread>
 
+#include "commit.hpp"
 #include "vm.hpp"
 
 using namespace zko;
@@ -298,6 +299,20 @@ int zkwo_batch_get_instance_trace(zkwo_batch* b, uint32_t instance, zkw_instance
   return ZKW_OK;
 }
 const char* zkwo_batch_instance_message(zkwo_batch* b, uint32_t instance) { return instance < b->results.size() ? b->results[instance].message.c_str() : ""; }
+
+int zkwo_batch_get_commitments(zkwo_batch* b, uint64_t* out) {
+  if (!b->ran) return ZKW_ERR_NOT_RUN;
+  gl::Perm perm;
+  std::vector<gl::Digest> blob_digests;
+  for (auto& bl : b->blobs) blob_digests.push_back(gl::blob_digest(perm, (const zkw_u256*)bl->data(), bl->size()));
+  for (uint32_t i = 0; i < b->n; i++) {
+    const Recorder& r = b->results[i].rec;
+    gl::Digest d[3] = {gl::mem_queue(perm, r.mem.data(), r.mem.size()), gl::log_queue(perm, r.log.data(), r.log.size()),
+                       gl::decommit_queue(perm, r.aux.data(), r.aux.size(), blob_digests)};
+    for (int q = 0; q < 3; q++) std::memcpy(out + ((size_t)i * 3 + q) * 4, d[q].v, 32);
+  }
+  return ZKW_OK;
+}
 
 // ---- unit-test hooks --------------------------------------------------------------------
 // op: 0 add (out[0]=result, out[1].l[0]=of) 1 sub 2 mul (out[0]=low,out[1]=high) 3 div (q,r) 4 shl 5 shr (b.l[0]=n)

@@ -73,11 +73,12 @@ template <typename K, typename... Args>
 static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, Args... args) {
   gridDim = grid;
   blockDim = block;
-  for (unsigned b = 0; b < grid.x; b++) {
-    blockIdx = dim3(b);
-    for (unsigned t = 0; t < block.x; t++) {  // block.x == 1 (warpSize 1)
-      threadIdx = dim3(t);
-      kernel(args...);
+  for (unsigned by = 0; by < grid.y; by++)
+    for (unsigned b = 0; b < grid.x; b++) {
+      blockIdx = dim3(b, by);
+      for (unsigned t = 0; t < block.x; t++) {  // block.x == 1 (warpSize 1)
+        threadIdx = dim3(t);
+        kernel(args...);
+      }
     }
-  }
 }

@@ -148,3 +148,11 @@ def test_status_codes(oracle, product, isa):
     assert tp["status"] == K.STATUS_ENDED and tp["n_cycles"] == 6
     ok, why = K.traces_equal(to, tp)
     assert ok, why
+
+
+@pytest.mark.parametrize("cfg,kw", [(2, dict(n_instances=200)), (4, dict(n_instances=96, n_cycles=512)),
+                                    (3, dict(n_instances=64, keccak_k=(1, 2, 3, 1), sha_rounds=(1, 2, 3, 5)))])
+def test_queue_commitments(oracle, product, isa, cfg, kw):
+    wl = synth.make(cfg, isa, **kw)
+    bo, bp = _run(oracle, wl), _run(product, wl)
+    assert np.array_equal(bo.commitments(), bp.commitments())
