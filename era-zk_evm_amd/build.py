@@ -59,7 +59,7 @@ def build_oracle(force=False, native=False):
     """TEST INFRASTRUCTURE ONLY. `native=True` builds the -march=native flavour bench.py times."""
     out = ORACLE_LIB if not native else ORACLE_LIB.replace(".so", "_native.so")
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("vm.cpp", "zkwo_api.cpp")]
-    deps = srcs + [os.path.join(ORACLE_DIR, f) for f in ("vm.hpp", "u256.hpp", "hashes.hpp", "commit.hpp")] + [os.path.join(ROOT, "include", "zkw.h")]
+    deps = srcs + [os.path.join(ORACLE_DIR, f) for f in ("vm.hpp", "u256.hpp", "hashes.hpp", "commit.hpp", "callback_log.hpp")] + [os.path.join(ROOT, "include", "zkw.h")]
     if force or _stale(out, deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         flags = ["-O3", "-std=c++17", "-fPIC", "-shared", "-pthread"] + (["-march=native"] if native else [])

@@ -199,37 +199,66 @@ __global__ void zkw_leaf_kernel(zkw_commit_params C) {
   }
 }
 
-// per wave: lane l walks the wave's stream cycle by cycle (directory) and lists the positions of its
-// own records (of completed cycles only) -> idx[inst][j], count[inst]
+// per wave: stable partition of the wave's stream by lane tag -> idx[inst][j], count[inst].
+// One tile of blockDim.x records per step: six ballots give every thread the mask of the threads
+// holding a record of the same lane, its rank inside that group is a popcount, and the group's
+// leader bumps the per-lane running count in LDS.  Records of cycles the instance did not complete
+// (failed cycles) are dropped through the stream directory: record p of lane l counts iff
+// p < dir[n_cycles[l]].
 __global__ void zkw_bucket_kernel(zkw_commit_params C) {
+  __shared__ u32 s_count[ZKW_WAVE];
+  __shared__ u32 s_limit[ZKW_WAVE];
   const u32 wave = blockIdx.x;
-  const u32 lane = threadIdx.x;
-  const u32 inst = wave * C.L + lane;
-  if (lane >= C.L || inst >= C.n_instances) return;
-  const u32 ncyc = C.scalars[inst].n_cycles;
+  const u32 tid = threadIdx.x;
   const u32 rec_bytes = C.queue == ZKW_QUEUE_MEMORY ? 48u : (C.queue == ZKW_QUEUE_LOG ? 128u : 256u);
   const uint8_t* base = (const uint8_t*)C.stream + (u64)wave * C.cap * rec_bytes;
   const u32 n = C.cursors[wave * 4 + C.queue] < C.cap ? C.cursors[wave * 4 + C.queue] : C.cap;
-  u32* out = C.idx + (u64)inst * C.per_instance_cap;
-  u32 cnt = 0;
   const uint32_t* dir = C.dir + (u64)wave * (C.max_cycles + 1) * 4;
-  const u32 p_end_all = dir[(u64)ncyc * 4 + C.queue] < n ? dir[(u64)ncyc * 4 + C.queue] : n;  // records of cycles < ncyc
-  for (u32 p = 0; p < p_end_all; p++) {
-    u32 tag, type = 0;
-    if (C.queue == ZKW_QUEUE_MEMORY) {
-      tag = base[(u64)p * 48 + 12];
-    } else if (C.queue == ZKW_QUEUE_LOG) {
-      tag = base[(u64)p * 128 + 126];
-    } else {
-      tag = base[(u64)p * 256 + 1];
-      type = base[(u64)p * 256];
-    }
-    if (tag == lane && (C.queue != ZKW_QUEUE_DECOMMIT || type == ZKW_AUX_DECOMMIT)) {
-      if (cnt < C.per_instance_cap) out[cnt] = p;
-      cnt++;
-    }
+  for (u32 l = tid; l < ZKW_WAVE; l += blockDim.x) {
+    const u32 inst = wave * C.L + l;
+    u32 lim = 0;
+    if (l < C.L && inst < C.n_instances) lim = dir[(u64)C.scalars[inst].n_cycles * 4 + C.queue];
+    s_limit[l] = lim < n ? lim : n;
+    s_count[l] = 0;
   }
-  C.counts[inst] = cnt < C.per_instance_cap ? cnt : C.per_instance_cap;
+  __syncthreads();
+  for (u32 tile = 0; tile < n; tile += blockDim.x) {
+    const u32 p = tile + tid;
+    u32 tag = 0;
+    bool keep = false;
+    if (p < n) {
+      u32 type = ZKW_AUX_DECOMMIT;
+      if (C.queue == ZKW_QUEUE_MEMORY) {
+        tag = base[(u64)p * 48 + 12];
+      } else if (C.queue == ZKW_QUEUE_LOG) {
+        tag = base[(u64)p * 128 + 126];
+      } else {
+        tag = base[(u64)p * 256 + 1];
+        type = base[(u64)p * 256];
+      }
+      keep = tag < ZKW_WAVE && p < s_limit[tag & (ZKW_WAVE - 1)] && type == ZKW_AUX_DECOMMIT;
+    }
+    tag &= ZKW_WAVE - 1;
+    u64 same = __ballot(keep);
+#pragma unroll
+    for (int bit = 0; bit < 6; bit++) {
+      const bool b = (tag >> bit) & 1u;
+      const u64 m = __ballot(keep && b);
+      same &= b ? m : ~m;
+    }
+    if (keep) {
+      const u32 rank = (u32)__popcll(same & ((1ull << (tid & 63u)) - 1ull));
+      const u32 before = s_count[tag];
+      const u32 inst = wave * C.L + tag;
+      if (before + rank < C.per_instance_cap) C.idx[(u64)inst * C.per_instance_cap + before + rank] = p;
+      if (rank == 0) s_count[tag] = before + (u32)__popcll(same);
+    }
+    __syncthreads();
+  }
+  for (u32 l = tid; l < C.L; l += blockDim.x) {
+    const u32 inst = wave * C.L + l;
+    if (inst < C.n_instances) C.counts[inst] = s_count[l] < C.per_instance_cap ? s_count[l] : C.per_instance_cap;
+  }
 }
 
 // one instance per lane: sequential chain over its leaves

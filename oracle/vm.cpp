@@ -477,7 +477,7 @@ void Vm::near_call(const Decoded& op, const PreState& ps) {
 // helpers.rs:196-223 + DefaultPrecompilesProcessor::execute_precompile (absent crate; dispatch on
 // the low 16 bits of the address, Appendix B)
 void Vm::call_precompile(uint32_t cc, const LogQuery& query) {
-  witness_tracer.add_log(query, ZKW_LQ_LOG);
+  witness_tracer.add_log(query, ZKW_LQ_LOG, cc);
   uint32_t address_low = (uint32_t)query.address.b[0] | ((uint32_t)query.address.b[1] << 8);
   std::vector<MemoryQuery> reads, writes;
   if (address_low == isa->consts.keccak_precompile_address)
@@ -486,6 +486,12 @@ void Vm::call_precompile(uint32_t cc, const LogQuery& query) {
     sha256_rounds_function(cc, query, memory, reads, writes);
   else
     return;  // incl. ecrecover: not implemented in this build => behaves like an unknown precompile
+  if (witness_tracer.cb) {  // add_precompile_call_result(cc, query, mem_in, mem_out, round_witness) helpers.rs:214-221
+    std::vector<cblog::MemQ> in, out;
+    for (const MemoryQuery& q : reads) in.push_back(Recorder::cb_mem(q));
+    for (const MemoryQuery& q : writes) out.push_back(Recorder::cb_mem(q));
+    witness_tracer.cb->precompile(cc, Recorder::cb_log(query), in, out);
+  }
   for (const MemoryQuery& q : reads) witness_tracer.add_memory_query(q, 1);
   for (const MemoryQuery& q : writes) witness_tracer.add_memory_query(q, 2);
 }

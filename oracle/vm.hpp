@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../include/zkw.h"
+#include "callback_log.hpp"
 #include "hashes.hpp"
 #include "u256.hpp"
 
@@ -214,6 +215,7 @@ struct Recorder {
   std::vector<zkw_aux_event> aux;
   std::vector<uint32_t> mem_off, log_off, aux_off;  // [n_cycles + 1]
   uint32_t seq = 0;
+  cblog::Log* cb = nullptr;  // optional: canonical log of the outward calls (tests/test_host_replay.py)
   // cold fields as of the previous end_execution_cycle
   uint32_t cold_spent = 0, cold_ergs_pp = 0, cold_tx = 0, cold_mpc = 0;
   uint64_t cold_ctx[2] = {0, 0};
@@ -233,9 +235,39 @@ struct Recorder {
     return s;
   }
   // witness_trace/mod.rs:13 start_new_execution_cycle
-  void start_new_execution_cycle(const VmLocalState&) { seq = 0; }
+  void log_state(uint32_t id, const VmLocalState& s) {
+    zkw_vm_local_state c;
+    state_to_c(s, &c);
+    std::vector<zkw_callstack_entry> inner(s.callstack.inner.size());
+    for (size_t d = 0; d < inner.size(); d++) entry_to_c(s.callstack.inner[d], &inner[d]);
+    cb->state(id, c, inner.data());
+  }
+  static cblog::MemQ cb_mem(const MemoryQuery& q) {
+    cblog::MemQ m;
+    m.timestamp = q.timestamp; m.page = q.location.page; m.index = q.location.index; m.type = q.location.memory_type; m.is_ptr = q.value_is_pointer;
+    m.rw = q.rw_flag;
+    std::memcpy(m.value, q.value.l, 32);
+    return m;
+  }
+  static cblog::LogQ cb_log(const LogQuery& q) {
+    cblog::LogQ l;
+    l.timestamp = q.timestamp; l.tx = q.tx_number_in_block; l.aux = q.aux_byte; l.shard = q.shard_id; l.rw = q.rw_flag; l.rollback = q.rollback;
+    l.is_service = q.is_service;
+    std::memcpy(l.address, q.address.b, 20);
+    std::memcpy(l.key, q.key.l, 32); std::memcpy(l.read, q.read_value.l, 32); std::memcpy(l.written, q.written_value.l, 32);
+    return l;
+  }
+  size_t cb_mark = 0;
+  void start_new_execution_cycle(const VmLocalState& s) {
+    seq = 0;
+    if (cb) {
+      cb_mark = cb->entries.size();
+      log_state(cblog::START_CYCLE, s);
+    }
+  }
   // witness_trace/mod.rs:19 add_memory_query; kind 1/2 = payload of add_precompile_call_result (:43-50)
-  void add_memory_query(const MemoryQuery& q, int kind = 0) {
+  void add_memory_query(const MemoryQuery& q, int kind = 0, uint32_t cc = 0) {
+    if (cb && kind == 0) cb->mem(cc, cb_mem(q));
     zkw_mem_query o;
     std::memset(&o, 0, sizeof o);
     o.timestamp = q.timestamp; o.page = q.location.page; o.index = q.location.index;
@@ -246,7 +278,8 @@ struct Recorder {
     mem.push_back(o);
   }
   // witness_trace/mod.rs:22-31 record_refund_for_query (kind REFUND) / :33 add_log_query
-  void add_log(const LogQuery& q, int kind) {
+  void add_log(const LogQuery& q, int kind, uint32_t cc = 0) {
+    if (cb) cb->log(kind == ZKW_LQ_REFUND ? cblog::RECORD_REFUND : cblog::ADD_LOG_QUERY, cc, cb_log(q));
     zkw_log_query o;
     std::memset(&o, 0, sizeof o);
     std::memcpy(o.key.l, q.key.l, 32); std::memcpy(o.read_value.l, q.read_value.l, 32); std::memcpy(o.written_value.l, q.written_value.l, 32);
@@ -258,7 +291,13 @@ struct Recorder {
     log.push_back(o);
   }
   // witness_trace/mod.rs:61-68 start_new_execution_context
-  void frame_start(const CallStackEntry& prev, const CallStackEntry& next, bool far) {
+  void frame_start(const CallStackEntry& prev, const CallStackEntry& next, bool far, uint32_t cc = 0) {
+    if (cb) {
+      zkw_callstack_entry a, b;
+      entry_to_c(prev, &a);
+      entry_to_c(next, &b);
+      cb->frame_start(cc, a, b);
+    }
     zkw_aux_event e;
     std::memset(&e, 0, sizeof e);
     e.type = ZKW_AUX_FRAME_START; e.seq = next_seq(); e.flag = far ? 1 : 0;
@@ -267,14 +306,20 @@ struct Recorder {
     aux.push_back(e);
   }
   // witness_trace/mod.rs:70-71 finish_execution_context
-  void frame_finish(bool panicked) {
+  void frame_finish(bool panicked, uint32_t cc = 0) {
+    if (cb) cb->simple(cblog::FINISH_CONTEXT, cc, panicked);
     zkw_aux_event e;
     std::memset(&e, 0, sizeof e);
     e.type = ZKW_AUX_FRAME_FINISH; e.seq = next_seq(); e.flag = panicked ? 1 : 0;
     aux.push_back(e);
   }
   // witness_trace/mod.rs:35-41 add_decommittment (recorded whether or not B, helpers.rs:185-191)
-  void decommit(const DecommittmentQuery& q, uint32_t blob_id) {
+  void decommit(const DecommittmentQuery& q, uint32_t blob_id, uint32_t cc = 0, const std::vector<U256>* words = nullptr) {
+    if (cb) {  // SimpleDecommitter<true>: Some(values) when fresh, Some(vec![]) otherwise (decommitter.rs:43-47,81-96)
+      const bool payload = q.is_fresh && words;
+      cb->decommit(cc, q.hash.l, q.timestamp, q.memory_page, q.decommitted_length, q.is_fresh, payload ? (const uint64_t*)words->data() : nullptr,
+                   payload ? words->size() : 0);
+    }
     zkw_aux_event e;
     std::memset(&e, 0, sizeof e);
     e.type = ZKW_AUX_DECOMMIT; e.seq = next_seq(); e.flag = q.is_fresh ? 1 : 0;
@@ -284,6 +329,7 @@ struct Recorder {
   }
   // witness_trace/mod.rs:16 end_execution_cycle
   void end_execution_cycle(const VmLocalState& s) {
+    if (cb) log_state(cblog::END_CYCLE, s);
     if (s.spent_pubdata_counter != cold_spent || s.current_ergs_per_pubdata_byte != cold_ergs_pp || s.tx_number_in_block != cold_tx ||
         s.memory_page_counter != cold_mpc || s.context_u128_register[0] != cold_ctx[0] || s.context_u128_register[1] != cold_ctx[1]) {
       zkw_aux_event e;
@@ -316,6 +362,7 @@ struct Recorder {
   }
   // a cycle that ended in RefPanic/RefErr leaves no trace
   void rollback_cycle() {
+    if (cb) cb->entries.resize(cb_mark);
     mem.resize(mem_off.back()); log.resize(log_off.back()); aux.resize(aux_off.back());
   }
 };
@@ -744,65 +791,70 @@ struct Vm {
   MemoryQuery read_code(uint32_t cc, uint32_t ts, MemoryLocation loc) {
     MemoryQuery pq{ts, loc, U256::zero(), false, false};
     MemoryQuery q = memory.read_code_query(cc, pq);
-    witness_tracer.add_memory_query(q);
+    witness_tracer.add_memory_query(q, 0, cc);
     return q;
   }
   // helpers.rs:53-76
   MemoryQuery read_memory(uint32_t cc, uint32_t ts, MemoryLocation loc) {
     MemoryQuery pq{ts, loc, U256::zero(), false, false};
     MemoryQuery q = memory.execute_partial_query(cc, pq);
-    witness_tracer.add_memory_query(q);
+    witness_tracer.add_memory_query(q, 0, cc);
     return q;
   }
   // helpers.rs:87-117
   MemoryQuery write_memory(uint32_t cc, uint32_t ts, MemoryLocation loc, const PrimitiveValue& v) {
     MemoryQuery pq{ts, loc, v.value, v.is_pointer, true};
     MemoryQuery q = memory.execute_partial_query(cc, pq);
-    witness_tracer.add_memory_query(q);
+    witness_tracer.add_memory_query(q, 0, cc);
     return q;
   }
   // helpers.rs:119-136
   uint32_t refund_for_partial_query(uint32_t cc, const LogQuery& pq) {
     REF_ASSERT(pq.rw_flag == true, "refund for read");
     uint32_t refund = storage.estimate_refunds_for_write(cc, pq);
-    witness_tracer.add_log(pq, ZKW_LQ_REFUND);
+    witness_tracer.add_log(pq, ZKW_LQ_REFUND, cc);
     return refund;
   }
   // helpers.rs:138-155
   LogQuery access_storage(uint32_t cc, LogQuery query) {
     query = storage.execute_partial_query(cc, query);
     if (!query.rw_flag) query.written_value = query.read_value;
-    witness_tracer.add_log(query, ZKW_LQ_LOG);
+    witness_tracer.add_log(query, ZKW_LQ_LOG, cc);
     return query;
   }
   // helpers.rs:157-162
   void emit_event(uint32_t cc, const LogQuery& query) {
     event_sink.add_partial_query(cc, query, isa->consts.event_aux_byte, isa->consts.l1_message_aux_byte);
-    witness_tracer.add_log(query, ZKW_LQ_LOG);
+    if (witness_tracer.cb) witness_tracer.cb->log(cblog::EV_ADD_PARTIAL_QUERY, cc, Recorder::cb_log(query));
+    witness_tracer.add_log(query, ZKW_LQ_LOG, cc);
   }
   // helpers.rs:164-194
   DecommittmentQuery decommit(uint32_t cc, const U256& hash, uint32_t candidate_page, uint32_t ts) {
     DecommittmentQuery pq{hash, ts, candidate_page, 0, false};
     uint32_t blob_id = 0;
     DecommittmentQuery q = decommittment_processor.decommit_into_memory(cc, pq, memory, &blob_id);
-    witness_tracer.decommit(q, blob_id);
+    const std::vector<U256>* words = nullptr;
+    if (q.is_fresh) words = decommittment_processor.known_hashes->find(q.hash)->second.words.get();
+    witness_tracer.decommit(q, blob_id, cc, words);
     return q;
   }
   void call_precompile(uint32_t cc, const LogQuery& query);  // helpers.rs:196-223
   // helpers.rs:225-246
-  void start_frame(uint32_t, const CallStackEntry& context_entry) {
+  void start_frame(uint32_t cc, const CallStackEntry& context_entry) {
     uint32_t ts = local_state.timestamp;
     storage.start_frame(ts);
     event_sink.start_frame(ts);
-    witness_tracer.frame_start(local_state.callstack.current, context_entry, !context_entry.is_local_frame);
+    if (witness_tracer.cb) witness_tracer.cb->simple(cblog::EV_START_FRAME, ts, 0);
+    witness_tracer.frame_start(local_state.callstack.current, context_entry, !context_entry.is_local_frame, cc);
     local_state.callstack.push_entry(context_entry);
   }
   // helpers.rs:248-264
-  CallStackEntry finish_frame(uint32_t, bool panicked) {
+  CallStackEntry finish_frame(uint32_t cc, bool panicked) {
     uint32_t ts = local_state.timestamp;
     storage.finish_frame(ts, panicked);
     event_sink.finish_frame(panicked, ts);
-    witness_tracer.frame_finish(panicked);
+    if (witness_tracer.cb) witness_tracer.cb->simple(cblog::EV_FINISH_FRAME, panicked, ts);
+    witness_tracer.frame_finish(panicked, cc);
     return local_state.callstack.pop_entry();
   }
   // helpers.rs:266-283

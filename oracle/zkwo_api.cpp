@@ -31,6 +31,7 @@ struct InstanceResult {
   Recorder rec;
   zkw_vm_local_state final_state;
   std::string message;
+  cblog::Log cb;
 };
 
 struct zkwo_batch {
@@ -44,6 +45,7 @@ struct zkwo_batch {
   std::vector<std::unique_ptr<Vm>> vms;
   std::vector<InstanceResult> results;
   unsigned threads = 1;
+  bool callback_log = false;
   double last_ms = 0;
   bool ran = false;
 };
@@ -190,6 +192,7 @@ static void build_vm(zkwo_batch* b, uint32_t i) {
   }
   b->results[i] = InstanceResult();
   b->results[i].rec.init(L);
+  b->results[i].rec.cb = b->callback_log ? &b->results[i].cb : nullptr;
   b->vms[i] = std::move(vm);
 }
 
@@ -296,6 +299,16 @@ int zkwo_batch_get_instance_trace(zkwo_batch* b, uint32_t instance, zkw_instance
   out->log_off = r.rec.log_off.data();
   out->aux_off = r.rec.aux_off.data();
   out->final_state = r.final_state;
+  return ZKW_OK;
+}
+int zkwo_batch_enable_callback_log(zkwo_batch* b, int on) {
+  b->callback_log = on != 0;
+  return ZKW_OK;
+}
+int zkwo_batch_get_callback_log(zkwo_batch* b, uint32_t instance, const uint64_t** entries, uint32_t* n) {
+  if (instance >= b->results.size()) return ZKW_ERR_INVALID;
+  *entries = b->results[instance].cb.entries.data();
+  *n = (uint32_t)b->results[instance].cb.entries.size();
   return ZKW_OK;
 }
 const char* zkwo_batch_instance_message(zkwo_batch* b, uint32_t instance) { return instance < b->results.size() ? b->results[instance].message.c_str() : ""; }

@@ -1,0 +1,106 @@
+// TEST INFRASTRUCTURE: drives the C++ host mirror (era-zk_evm_amd/host/zk_evm.hpp) over one
+// instance trace with a tracer + event sink that write the canonical callback log of
+// oracle/callback_log.hpp, so that tests can compare "GPU trace replayed through the mirror" with
+// "what the oracle's restated cycle() called directly".
+#include <vector>
+
+#include "../../era-zk_evm_amd/host/zk_evm.hpp"
+#include "../../oracle/callback_log.hpp"
+
+using namespace zk_evm;
+
+static void state_to_c(const VmLocalState& s, zkw_vm_local_state* o) {
+  std::memset(o, 0, sizeof *o);
+  std::memcpy(o->previous_code_word.l, s.previous_code_word.l, 32);
+  uint16_t bm = 0;
+  for (int i = 0; i < ZKW_REGISTERS_COUNT; i++) {
+    std::memcpy(o->registers[i].l, s.registers[i].value.l, 32);
+    if (s.registers[i].is_pointer) bm |= (uint16_t)(1u << i);
+  }
+  o->register_ptr_bitmap = bm;
+  o->flags = (uint8_t)((s.flags.overflow_or_less_than_flag ? 1 : 0) | (s.flags.equality_flag ? 2 : 0) | (s.flags.greater_than_flag ? 4 : 0));
+  o->pending_exception = s.pending_exception;
+  o->previous_code_memory_page = s.previous_code_memory_page;
+  o->timestamp = s.timestamp; o->monotonic_cycle_counter = s.monotonic_cycle_counter; o->spent_pubdata_counter = s.spent_pubdata_counter;
+  o->memory_page_counter = s.memory_page_counter; o->absolute_execution_step = s.absolute_execution_step;
+  o->current_ergs_per_pubdata_byte = s.current_ergs_per_pubdata_byte; o->tx_number_in_block = s.tx_number_in_block;
+  o->previous_super_pc = s.previous_super_pc; o->callstack_depth = (uint32_t)s.callstack.depth();
+  o->context_u128_register[0] = s.context_u128_register[0]; o->context_u128_register[1] = s.context_u128_register[1];
+  o->current = s.callstack.current;
+}
+static cblog::MemQ cb_mem(const MemoryQuery& q) {
+  cblog::MemQ m;
+  m.timestamp = q.timestamp; m.page = q.location.page; m.index = q.location.index; m.type = q.location.memory_type; m.is_ptr = q.value_is_pointer;
+  m.rw = q.rw_flag;
+  std::memcpy(m.value, q.value.l, 32);
+  return m;
+}
+static cblog::LogQ cb_log(const LogQuery& q) {
+  cblog::LogQ l;
+  l.timestamp = q.timestamp; l.tx = q.tx_number_in_block; l.aux = q.aux_byte; l.shard = q.shard_id; l.rw = q.rw_flag; l.rollback = q.rollback;
+  l.is_service = q.is_service;
+  std::memcpy(l.address, q.address.b, 20);
+  std::memcpy(l.key, q.key.l, 32); std::memcpy(l.read, q.read_value.l, 32); std::memcpy(l.written, q.written_value.l, 32);
+  return l;
+}
+
+struct LoggingTracer : VmWitnessTracer {
+  cblog::Log* log;
+  void st(uint32_t id, const VmLocalState& s) {
+    zkw_vm_local_state c;
+    state_to_c(s, &c);
+    log->state(id, c, s.callstack.inner.data());
+  }
+  void start_new_execution_cycle(const VmLocalState& s) override { st(cblog::START_CYCLE, s); }
+  void end_execution_cycle(const VmLocalState& s) override { st(cblog::END_CYCLE, s); }
+  void add_memory_query(uint32_t cc, const MemoryQuery& q) override { log->mem(cc, cb_mem(q)); }
+  void record_refund_for_query(uint32_t cc, const LogQuery& q, uint32_t) override { log->log(cblog::RECORD_REFUND, cc, cb_log(q)); }
+  void add_log_query(uint32_t cc, const LogQuery& q) override { log->log(cblog::ADD_LOG_QUERY, cc, cb_log(q)); }
+  void add_decommittment(uint32_t cc, const DecommittmentQuery& q, const std::vector<U256>& w) override {
+    log->decommit(cc, q.hash.l, q.timestamp, q.memory_page, q.decommitted_length, q.is_fresh, (const uint64_t*)w.data(), w.size());
+  }
+  void add_precompile_call_result(uint32_t cc, const LogQuery& call, const std::vector<MemoryQuery>& in, const std::vector<MemoryQuery>& out) override {
+    std::vector<cblog::MemQ> a, b;
+    for (auto& q : in) a.push_back(cb_mem(q));
+    for (auto& q : out) b.push_back(cb_mem(q));
+    log->precompile(cc, cb_log(call), a, b);
+  }
+  void start_new_execution_context(uint32_t cc, const CallStackEntry& p, const CallStackEntry& n) override { log->frame_start(cc, p, n); }
+  void finish_execution_context(uint32_t cc, bool panicked) override { log->simple(cblog::FINISH_CONTEXT, cc, panicked); }
+};
+struct LoggingSink : EventSink {
+  cblog::Log* log;
+  void add_partial_query(uint32_t cc, const LogQuery& q) override { log->log(cblog::EV_ADD_PARTIAL_QUERY, cc, cb_log(q)); }
+  void start_frame(uint32_t ts) override { log->simple(cblog::EV_START_FRAME, ts, 0); }
+  void finish_frame(bool panicked, uint32_t ts) override { log->simple(cblog::EV_FINISH_FRAME, panicked, ts); }
+};
+
+extern "C" int zkw_host_replay_callback_log(const zkw_vm_local_state* initial, const zkw_callstack_entry* inner, const zkw_instance_trace* trace,
+                                            const zkw_u256* blob_words, const uint32_t* blob_first, const uint32_t* blob_len, uint32_t n_blobs,
+                                            uint64_t* out, uint32_t cap, uint32_t* n_out, int* last_rc) {
+  try {
+    cblog::Log log;
+    LoggingTracer wt;
+    wt.log = &log;
+    LoggingSink ev;
+    ev.log = &log;
+    BatchedVmState vm(*initial, inner, *trace, &wt, &ev);
+    vm.code_of_blob = [&](uint32_t blob) {
+      std::vector<U256> w;
+      if (blob < n_blobs) {
+        w.resize(blob_len[blob]);
+        std::memcpy(w.data(), blob_words + blob_first[blob], (size_t)blob_len[blob] * 32);
+      }
+      return w;
+    };
+    int rc = 0;
+    while (!vm.execution_has_ended() && (rc = vm.cycle()) == 0) {
+    }
+    *last_rc = rc;
+    *n_out = (uint32_t)log.entries.size();
+    for (uint32_t i = 0; i < log.entries.size() && i < cap; i++) out[i] = log.entries[i];
+    return 0;
+  } catch (const std::exception&) {
+    return -1;
+  }
+}

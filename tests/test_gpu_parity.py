@@ -156,3 +156,16 @@ def test_queue_commitments(oracle, product, isa, cfg, kw):
     wl = synth.make(cfg, isa, **kw)
     bo, bp = _run(oracle, wl), _run(product, wl)
     assert np.array_equal(bo.commitments(), bp.commitments())
+
+
+def test_host_replay_on_gpu(oracle, product, isa):
+    """End to end: GPU run -> C ABI trace -> C++ host mirror (VmWitnessTracer/EventSink replay) == the calls the
+    oracle's restated cycle() makes directly."""
+    from test_host_replay import build_replay_lib, oracle_callback_log, replay_log
+    lib = build_replay_lib()
+    wl = synth.make(4, isa, n_instances=70, n_cycles=1024)
+    _, logs = oracle_callback_log(oracle, wl)
+    bp = _run(product, wl, 64)
+    for i in (0, 1, 63, 64, 69):
+        got, rc = replay_log(lib, bp, wl, i)
+        assert len(got) == len(logs[i]) and (got == logs[i]).all()
