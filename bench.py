@@ -57,12 +57,21 @@ def main():
         torch.cuda.synchronize()
 
     import ctypes as C
+    from era_zk_evm_amd import shard
+
+    # final exchange: all-gather of the per-instance queue digests over RCCL, once per step
+    digests = torch.zeros((args.instances, 3, 4), dtype=torch.int64, device="cuda")
+    gathered = torch.zeros((world * args.instances, 3, 4), dtype=torch.int64, device="cuda") if world > 1 else None
 
     def step():
         batch.reset(sptr)
         batch.run(wl.n_cycles, sptr)
         if args.commit_mask:
             prod.call("batch_commit", batch.h, C.c_uint32(args.commit_mask), C.c_void_p(sptr))
+            if world > 1:
+                prod.call("batch_copy_commitments", batch.h, C.c_void_p(digests.data_ptr()), C.c_void_p(sptr))
+                with torch.cuda.stream(stream):
+                    dist.all_gather_into_tensor(gathered, digests)
 
     for _ in range(args.warmup):
         step()

@@ -6,6 +6,6 @@ synthetic workloads of SURVEY.md §8d (`synth`) and drives the compiler (`build`
 There is no CPU execution path here: `capi.load_product()` raises if libzkw.so is missing and
 every run fails with ZKW_ERR_DEVICE when no GPU is present.
 """
-from . import build, capi, synth  # noqa: F401
+from . import build, capi, synth  # noqa: F401  (shard imports torch: import it explicitly)
 
 __all__ = ["build", "capi", "synth"]

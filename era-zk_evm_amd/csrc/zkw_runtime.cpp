@@ -881,6 +881,14 @@ int zkw_batch_get_commitments(zkw_batch* b, uint64_t* out) {
   return ZKW_OK;
 }
 
+int zkw_batch_copy_commitments(zkw_batch* b, void* dst_device, void* hip_stream) {
+  if (!b || !dst_device) return ZKW_ERR_INVALID;
+  zkw_ctx* c = b->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(dst_device, b->d_commit.p, b->d_commit.bytes(), hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
+  return ZKW_OK;
+}
+
 int zkw_batch_commitments_device_ptr(zkw_batch* b, void** dptr, uint64_t* n_bytes) {
   if (!b || !dptr || !n_bytes) return ZKW_ERR_INVALID;
   *dptr = b->d_commit.p;

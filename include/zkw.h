@@ -441,6 +441,9 @@ int zkw_batch_commit(zkw_batch* batch, uint32_t queue_mask, void* hip_stream);
 /* digests[instance][queue] : 4 x u64 Goldilocks elements each, computed on device from the
  * streams of the last run; `out` holds n_instances * ZKW_QUEUE_COUNT * 4 u64 */
 int zkw_batch_get_commitments(zkw_batch* batch, uint64_t* out);
+/* async device-to-device copy of the digests (n_instances * ZKW_QUEUE_COUNT * 4 u64) into a caller buffer,
+ * e.g. the send buffer of the RCCL all-gather */
+int zkw_batch_copy_commitments(zkw_batch* batch, void* dst_device, void* hip_stream);
 /* device pointer (n_instances * ZKW_QUEUE_COUNT * 4 u64) for the RCCL all-gather */
 int zkw_batch_commitments_device_ptr(zkw_batch* batch, void** dptr, uint64_t* n_bytes);
 
