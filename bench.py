@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per wave (0 = library default)")
     ap.add_argument("--cfg", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nop-only", action="store_true")
     ap.add_argument("--commit-mask", type=int, default=4, help="queue commitments computed inside every step: bit0 memory, bit1 log, bit2 decommit (BASELINE configs[2]: decommit queue)")
     args = ap.parse_args()
 
@@ -44,7 +45,12 @@ def main():
     isa = K.Isa()
     prod = K.load_product().open(isa, device=local_rank)
     # shard: every rank owns `instances` independent VM instances (different seeds), no data-path collective
-    wl = synth.make(args.cfg, isa, n_instances=args.instances, n_cycles=args.cycles, seed=0x5EED0000 + args.cfg + 0x100 * rank)
+    if args.cfg == 0:  # NOP/ADD plumbing tape replicated over many instances (loop-overhead floor)
+        wl = synth.make(1, isa, n_instances=args.instances, n_cycles=args.cycles, seed=0x5EED0000 + 0x100 * rank)
+        ops = [isa.enc(K.OP_NOP) if args.nop_only or k % 2 == 0 else isa.enc(K.OP_ADD, flags=(k // 2) % 2, src0=1, src1=2, dst0=3) for k in range(args.cycles)]
+        wl.blobs[0] = K.pack_code(ops)
+    else:
+        wl = synth.make(args.cfg, isa, n_instances=args.instances, n_cycles=args.cycles, seed=0x5EED0000 + args.cfg + 0x100 * rank)
     wl.limits["lanes_per_wave"] = args.lanes
     batch = prod.create_batch(wl)
     stream = torch.cuda.Stream(device=local_rank)

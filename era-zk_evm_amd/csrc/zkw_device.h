@@ -106,8 +106,10 @@ typedef struct zkw_kparams {
   uint32_t cap_mem, cap_log, cap_aux; /* stream capacity per wave (records) */
   uint32_t n_blobs, n_preimages;
   uint32_t wave_threads; /* threads per workgroup = hardware wave width (64 on gfx950) */
+  uint32_t debug_flags;  /* profiling ablations only (ZKW_DEBUG_FLAGS): 1 = no CycleRecord stores, 2 = no stream stores */
   zkw_isa_consts consts;
   zkw_block_properties props;
+  const struct zkw_kparams* self; /* device copy of this block (out-of-line opcode handlers read it from memory) */
   const uint2* isa;            /* [2048] packed */
   /* state */
   uint4* regs;                 /* [n_waves][30][L]                      */

@@ -111,6 +111,7 @@ ZD void emit_mem(const zkw_kparams& P, Shared& sh, Lane& s, u32 ts, u32 type, u3
     lane_fail(s, ZKW_STATUS_LIMIT);
     return;
   }
+  if (P.debug_flags & 2u) return;
   const u32 meta = (type & ZKW_MQ_TYPE_MASK) | (is_ptr ? ZKW_MQ_IS_PTR : 0u) | (rw ? ZKW_MQ_RW : 0u) | (kind << ZKW_MQ_KIND_SHIFT);
   uint4* dst = P.mem_stream + ((u64)s.wave * P.cap_mem + pos) * 3;
   dst[0] = make_uint4(ts, page, index, s.lane | (seq << 8) | (meta << 16));
@@ -1288,6 +1289,193 @@ ZD void call_precompile(const zkw_kparams& P, Shared& sh, Lane& s, const LogQ& q
   // anything else (incl. ecrecover, not built yet) behaves as an unknown precompile: no memory traffic
 }
 
+// ---------------------------------------------------------------------------------------------
+// Rare opcode families (context, ptr, log incl. precompiles, near_call, far_call, ret) go through one
+// wrapper that works on a copy of the lane state.  Measured on MI355X (profiles/r01_kernel_variants.md): a
+// real out-of-line call (noinline) shrinks the kernel from 100 KB to 44 KB but the caller-saved traffic
+// around the call costs more than it saves (1.03 vs 0.98 ms per 1M cycles), so the wrapper is inlined.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void zkw_rare_op(const zkw_kparams* Pg, Shared sh, Lane* lane, const Decoded* dp, const Pre* pp) {
+  const zkw_kparams& P = *Pg;
+  Lane s = *lane;
+  const Decoded d = *dp;
+  const Pre ps = *pp;
+  switch (ZKW_ATTR_OPCODE(d.attr)) {
+    case ZKW_OP_CONTEXT: op_context(P, sh, s, d, ps); break;
+    case ZKW_OP_PTR: op_ptr(P, sh, s, d, ps); break;
+    case ZKW_OP_LOG: op_log(P, sh, s, d, ps); break;
+    case ZKW_OP_NEAR_CALL: op_near_call(P, sh, s, d, ps); break;
+    case ZKW_OP_FAR_CALL: op_far_call(P, sh, s, d, ps); break;
+    case ZKW_OP_RET: op_ret(P, sh, s, d, ps); break;
+    default: lane_fail(s, ZKW_STATUS_REFERENCE_PANIC); break;
+  }
+  *lane = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// read_and_decode exceptions (cycle.rs:142-184) and condition resolution (:193-209), branch-free
+// ---------------------------------------------------------------------------------------------
+ZD bool decode_exception(const zkw_kparams& P, const Lane& s, u32 attr, u32 price) {
+  const u32 props = ZKW_ATTR_PROPS(attr);
+  return ((props & ZKW_PROP_EXPLICIT_PANIC) != 0) | (s.ergs < price) | (((props & ZKW_PROP_KERNEL_ONLY) != 0) & (s.is_kernel == 0)) |
+         (((props & ZKW_PROP_STATIC_OK) == 0) & (s.is_static != 0)) | (s.depth == P.consts.vm_max_stack_depth);
+}
+// one bit per (condition, lt|eq<<1|gt<<2): Always, Gt, Lt, Eq, Ge, Le, Ne, GtOrLt
+ZD bool condition_resolved(u32 cond, u32 flags) {
+  const u64 lut = 0xffull | (0xf0ull << 8) | (0xaaull << 16) | (0xccull << 24) | (0xfcull << 32) | (0xeeull << 40) | (0x33ull << 48) | (0xfaull << 56);
+  return (lut >> (cond * 8 + (flags & 7u))) & 1ull;
+}
+
+// ---------------------------------------------------------------------------------------------
+// operands .. opcode body of one cycle (cycle.rs:275-406) for one group of lanes that hold the SAME
+// decoded instruction.  `d` is wave-uniform (its fields live in scalar registers), so every branch that
+// depends on the opcode, the addressing modes or the register indices is a scalar branch; only the data
+// path (256-bit values, sp, ergs, memory addresses) is per lane.
+// ---------------------------------------------------------------------------------------------
+ZD void exec_decoded(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d) {
+  const u32 opcode = ZKW_ATTR_OPCODE(d.attr);
+  const u32 props = ZKW_ATTR_PROPS(d.attr);
+  const bool set_flags = ZKW_ATTR_FLAGS(d.attr) & 1u;
+  // ----------------------------------------------------------------------------------------
+  // operands (cycle.rs:275-350)
+  // ----------------------------------------------------------------------------------------
+  Pre ps;
+  u32 sp = s.sp;
+  // all register-file reads of the cycle are issued back to back (one LDS round trip instead of three)
+  bool src0_reg_ptr, dummy_ptr;
+  const u256 src0_reg = reg_read(sh, s, d.src0, src0_reg_ptr);
+  ps.src1 = reg_read(sh, s, d.src1, ps.src1_ptr);  // :339
+  const u256 dst0_reg = ZKW_ATTR_DST0(d.attr) == ZKW_MODE_REG ? u256_zero() : reg_read(sh, s, d.dst0, dummy_ptr);  // only addressing modes use it
+  Operand src0_loc = compute_address(P, s, sp, src0_reg, d.imm0, ZKW_ATTR_SRC0(d.attr), false);
+  ps.dst0 = compute_address(P, s, sp, dst0_reg, d.imm1, ZKW_ATTR_DST0(d.attr), true);
+  s.sp = sp;                                            // :297
+  if (opcode == ZKW_OP_NOP) src0_loc.has_loc = false;  // :298-301
+  u256 src0_mem = u256_zero();
+  bool src0_mem_ptr = false;
+  if (src0_loc.has_loc) {  // :304-325
+    if (src0_loc.type == ZKW_MEM_CODE) src0_mem = code_read(P, s, src0_loc.index);
+    else src0_mem = stack_read(P, s, src0_loc.index, src0_mem_ptr);
+    emit_mem(P, sh, s, s.timestamp, src0_loc.type, src0_loc.page, src0_loc.index, src0_mem, src0_mem_ptr, false, 0);
+  }
+  const u32 src0_mode = ZKW_ATTR_SRC0(d.attr);
+  if (src0_mode == ZKW_MODE_REG) {
+    ps.src0 = src0_reg;
+    ps.src0_ptr = src0_reg_ptr;
+  } else if (src0_mode == ZKW_MODE_IMM) {
+    ps.src0 = u256_from_u32(d.imm0);
+    ps.src0_ptr = false;
+  } else {
+    ps.src0 = src0_mem;
+    ps.src0_ptr = src0_mem_ptr;
+  }
+  if (props & ZKW_PROP_SWAP) {                     // :341-345
+    const u256 t = ps.src0;
+    ps.src0 = ps.src1;
+    ps.src1 = t;
+    const bool tp = ps.src0_ptr;
+    ps.src0_ptr = ps.src1_ptr;
+    ps.src1_ptr = tp;
+  }
+  ps.new_pc = (s.pc + 1) & 0xffffu;  // :347-350 (never a skip cycle here)
+  if (!s.is_kernel) {                // erase_fat_pointer_metadata :374-396
+    if (!(props & ZKW_PROP_SRC0_PTR_OK) && ps.src0_ptr) {
+      ps.src0.w[1] = 0;
+      ps.src0.w[2] = 0;
+      ps.src0_ptr = false;
+    }
+    if (!(props & ZKW_PROP_SRC1_PTR_OK) && ps.src1_ptr) {
+      ps.src1.w[1] = 0;
+      ps.src1.w[2] = 0;
+      ps.src1_ptr = false;
+    }
+  }
+  // ----------------------------------------------------------------------------------------
+  // apply (opcodes/parsing.rs:47-79)
+  // ----------------------------------------------------------------------------------------
+  if (lane_ok(s)) {
+    switch (opcode) {
+      case ZKW_OP_NOP: s.pc = ps.new_pc; break;  // noop.rs:16-19
+      case ZKW_OP_ADD:
+      case ZKW_OP_SUB: {  // add.rs:35-53, sub.rs:35-54
+        s.pc = ps.new_pc;
+        bool of;
+        const u256 r = opcode == ZKW_OP_ADD ? u256_add(ps.src0, ps.src1, of) : u256_sub(ps.src0, ps.src1, of);
+        const bool eq = u256_is_zero(r);
+        if (set_flags) set_flags3(s, of, eq, !eq && !of);
+        dst0_update(P, sh, s, ps.dst0, d.dst0, r, false);
+        break;
+      }
+      case ZKW_OP_MUL: {  // mul.rs:35-65
+        s.pc = ps.new_pc;
+        u256 lo, hi;
+        u256_mul(ps.src0, ps.src1, lo, hi);
+        if (set_flags) {
+          const bool of = !u256_is_zero(hi), eq = u256_is_zero(lo);
+          set_flags3(s, of, eq, !of && !eq);
+        }
+        dst0_update(P, sh, s, ps.dst0, d.dst0, lo, false);
+        reg_write(sh, s, d.dst1, hi, false);
+        break;
+      }
+      case ZKW_OP_DIV: {  // div.rs:35-75
+        s.pc = ps.new_pc;
+        if (u256_is_zero(ps.src1)) {
+          if (set_flags) set_flags3(s, true, false, false);
+          dst0_update(P, sh, s, ps.dst0, d.dst0, u256_zero(), false);
+          reg_write(sh, s, d.dst1, u256_zero(), false);
+        } else {
+          u256 q, r;
+          u256_divmod(ps.src0, ps.src1, q, r);
+          if (set_flags) set_flags3(s, false, u256_is_zero(q), u256_is_zero(r));
+          dst0_update(P, sh, s, ps.dst0, d.dst0, q, false);
+          reg_write(sh, s, d.dst1, r, false);
+        }
+        break;
+      }
+      case ZKW_OP_JUMP: s.pc = clip16(P, ps.src0); break;  // jump.rs:23-25
+      case ZKW_OP_SHIFT: {  // shift.rs:44-78
+        s.pc = ps.new_pc;
+        const u32 n = ps.src1.w[0] & 0xffu;
+        const u32 v = ZKW_ATTR_VARIANT(d.attr);
+        const bool cyclic = v == ZKW_SHIFT_ROL || v == ZKW_SHIFT_ROR;
+        const bool right = v == ZKW_SHIFT_SHR || v == ZKW_SHIFT_ROR;
+        u256 r;
+        if (right) {
+          r = u256_shr(ps.src0, n);
+          if (cyclic) r = u256_or(r, u256_shl(ps.src0, 256u - n));
+        } else {
+          r = u256_shl(ps.src0, n);
+          if (cyclic) r = u256_or(r, u256_shr(ps.src0, 256u - n));
+        }
+        if (set_flags) set_flags3(s, false, u256_is_zero(r), false);
+        dst0_update(P, sh, s, ps.dst0, d.dst0, r, false);
+        break;
+      }
+      case ZKW_OP_BINOP: {  // binop.rs:42-61
+        s.pc = ps.new_pc;
+        const u32 v = ZKW_ATTR_VARIANT(d.attr);
+        const u256 r = v == ZKW_BINOP_XOR ? u256_xor(ps.src0, ps.src1) : (v == ZKW_BINOP_AND ? u256_and(ps.src0, ps.src1) : u256_or(ps.src0, ps.src1));
+        if (set_flags) set_flags3(s, false, u256_is_zero(r), false);
+        dst0_update(P, sh, s, ps.dst0, d.dst0, r, false);
+        break;
+      }
+      case ZKW_OP_CONTEXT:
+      case ZKW_OP_PTR:
+      case ZKW_OP_LOG:
+      case ZKW_OP_NEAR_CALL:
+      case ZKW_OP_FAR_CALL:
+      case ZKW_OP_RET: {
+        Lane tmp = s;
+        zkw_rare_op(P.self, sh, &tmp, &d, &ps);
+        s = tmp;
+        break;
+      }
+      case ZKW_OP_UMA: op_uma(P, sh, s, d, ps); break;
+      default: lane_fail(s, ZKW_STATUS_REFERENCE_PANIC); break;  // Opcode::Invalid => unreachable!() parsing.rs:77
+    }
+  }
+}
+
 // =============================================================================================
 // the cycle kernel
 // =============================================================================================
@@ -1374,182 +1562,52 @@ __global__ void __launch_bounds__(ZKW_WAVE) zkw_cycle_kernel(zkw_kparams P) {
         enc = P.consts.exception_revert_encoding;
       }
       s.prev_code_page = s.code_page;  // :49
-      Decoded d;
-      const u32 raw_idx = (u32)enc & (ZKW_ISA_TABLE_SIZE - 1);
-      const uint2 isa_e = sh.isa[raw_idx];
-      d.attr = isa_e.x;
-      d.cond = ((u32)enc >> 13) & 7u;
-      d.src0 = ((u32)enc >> 16) & 15u;
-      d.src1 = ((u32)enc >> 20) & 15u;
-      d.dst0 = ((u32)enc >> 24) & 15u;
-      d.dst1 = ((u32)enc >> 28) & 15u;
-      d.imm0 = (u32)(enc >> 32) & 0xffffu;
-      d.imm1 = (u32)(enc >> 48);
-      bool err = (ZKW_ATTR_PROPS(d.attr) & ZKW_PROP_EXPLICIT_PANIC) != 0;  // :142-144
-      const u32 price = isa_e.y;                                            // :147-148
-      if (s.ergs < price) {                                                 // :153-161
-        s.ergs = 0;
-        err = true;
-      } else {
-        s.ergs -= price;
-      }
-      if ((ZKW_ATTR_PROPS(d.attr) & ZKW_PROP_KERNEL_ONLY) && !s.is_kernel) err = true;  // :174-176
-      if (!(ZKW_ATTR_PROPS(d.attr) & ZKW_PROP_STATIC_OK) && s.is_static) err = true;   // :178-180
-      if (s.depth == P.consts.vm_max_stack_depth) err = true;                           // :182-184
-      if (err) {  // mask_into_panic :187-190
-        d.attr = sh.isa[P.consts.panic_variant_idx].x;
-        d.cond = d.src0 = d.src1 = d.dst0 = d.dst1 = d.imm0 = d.imm1 = 0;
-      }
-      const bool f_lt = s.flags & FLAG_LT, f_eq = s.flags & FLAG_EQ, f_gt = s.flags & FLAG_GT;
-      bool resolved;
-      switch (d.cond) {  // :193-209
-        case 0: resolved = true; break;
-        case 1: resolved = f_gt; break;
-        case 2: resolved = f_lt; break;
-        case 3: resolved = f_eq; break;
-        case 4: resolved = f_gt || f_eq; break;
-        case 5: resolved = f_lt || f_eq; break;
-        case 6: resolved = !f_eq; break;
-        default: resolved = f_gt || f_lt; break;
-      }
-      if (!resolved && !err) {  // mask_into_nop :212-217
-        d.attr = sh.isa[P.consts.nop_variant_idx].x;
-        d.cond = d.src0 = d.src1 = d.dst0 = d.dst1 = d.imm0 = d.imm1 = 0;
-      }
-      const u32 opcode = ZKW_ATTR_OPCODE(d.attr);
-      const u32 props = ZKW_ATTR_PROPS(d.attr);
-      const bool set_flags = ZKW_ATTR_FLAGS(d.attr) & 1u;
       // ----------------------------------------------------------------------------------------
-      // operands (cycle.rs:275-350)
+      // decode + execute, grouped by instruction word: take the first lane that has
+      // not been served, broadcast its opcode word (readlane -> SGPRs), ballot the lanes holding the
+      // same word, decode ONCE on the scalar unit and run the body with exec = that group.  A shared
+      // tape needs one iteration per cycle; lanes running different programs need one per distinct word.
+      // Lanes whose decode raises an exception (masked into panic, cycle.rs:187-190) or whose condition
+      // fails (masked into nop, :212-217) are served by extra passes with the panic / nop variant.
       // ----------------------------------------------------------------------------------------
-      Pre ps;
-      u32 sp = s.sp;
-      bool src0_reg_ptr;
-      const u256 src0_reg = reg_read(sh, s, d.src0, src0_reg_ptr);
-      Operand src0_loc = compute_address(P, s, sp, src0_reg, d.imm0, ZKW_ATTR_SRC0(d.attr), false);
-      bool dummy_ptr;
-      const u256 dst0_reg = reg_read(sh, s, d.dst0, dummy_ptr);
-      ps.dst0 = compute_address(P, s, sp, dst0_reg, d.imm1, ZKW_ATTR_DST0(d.attr), true);
-      s.sp = sp;                                            // :297
-      if (opcode == ZKW_OP_NOP) src0_loc.has_loc = false;  // :298-301
-      u256 src0_mem = u256_zero();
-      bool src0_mem_ptr = false;
-      if (src0_loc.has_loc) {  // :304-325
-        if (src0_loc.type == ZKW_MEM_CODE) src0_mem = code_read(P, s, src0_loc.index);
-        else src0_mem = stack_read(P, s, src0_loc.index, src0_mem_ptr);
-        emit_mem(P, sh, s, s.timestamp, src0_loc.type, src0_loc.page, src0_loc.index, src0_mem, src0_mem_ptr, false, 0);
-      }
-      const u32 src0_mode = ZKW_ATTR_SRC0(d.attr);
-      if (src0_mode == ZKW_MODE_REG) {
-        ps.src0 = src0_reg;
-        ps.src0_ptr = src0_reg_ptr;
-      } else if (src0_mode == ZKW_MODE_IMM) {
-        ps.src0 = u256_from_u32(d.imm0);
-        ps.src0_ptr = false;
-      } else {
-        ps.src0 = src0_mem;
-        ps.src0_ptr = src0_mem_ptr;
-      }
-      ps.src1 = reg_read(sh, s, d.src1, ps.src1_ptr);  // :339
-      if (props & ZKW_PROP_SWAP) {                     // :341-345
-        const u256 t = ps.src0;
-        ps.src0 = ps.src1;
-        ps.src1 = t;
-        const bool tp = ps.src0_ptr;
-        ps.src0_ptr = ps.src1_ptr;
-        ps.src1_ptr = tp;
-      }
-      ps.new_pc = (s.pc + 1) & 0xffffu;  // :347-350 (never a skip cycle here)
-      if (!s.is_kernel) {                // erase_fat_pointer_metadata :374-396
-        if (!(props & ZKW_PROP_SRC0_PTR_OK) && ps.src0_ptr) {
-          ps.src0.w[1] = 0;
-          ps.src0.w[2] = 0;
-          ps.src0_ptr = false;
+      u32 enc_lo = (u32)enc, enc_hi = (u32)(enc >> 32);
+      bool charged = false;  // price taken and exceptions / condition resolved for this lane (once per cycle)
+      u64 todo = __ballot(1);
+      while (todo) {
+        const u32 leader = (u32)__ffsll((long long)todo) - 1u;
+        const u32 u_lo = (u32)__builtin_amdgcn_readlane((int)enc_lo, (int)leader);
+        const u32 u_hi = (u32)__builtin_amdgcn_readlane((int)enc_hi, (int)leader);
+        const bool u_charged = __builtin_amdgcn_readlane((int)charged, (int)leader) != 0;
+        // only lanes that are still waiting: a lane that already ran a genuine `nop` must not join the group of lanes
+        // that were masked into the nop encoding later in the same cycle
+        bool mine = ((todo >> (threadIdx.x & (ZKW_WAVE - 1))) & 1ull) != 0 && enc_lo == u_lo && enc_hi == u_hi && charged == u_charged;
+        if (P.debug_flags & 4u) mine = (threadIdx.x & (ZKW_WAVE - 1)) == leader;  // test hook: one lane per group
+        const uint2 e_raw = sh.isa[u_lo & (ZKW_ISA_TABLE_SIZE - 1)];
+        const u32 u_attr = (u32)__builtin_amdgcn_readfirstlane((int)e_raw.x);
+        const u32 u_price = (u32)__builtin_amdgcn_readfirstlane((int)e_raw.y);
+        if (!u_charged) {  // uniform: first visit of this opcode word
+          if (mine) {
+            const bool err = decode_exception(P, s, u_attr, u_price);  // :142-184
+            if (s.ergs < u_price) s.ergs = 0; else s.ergs -= u_price;  // :153-161
+            const bool nop = !err && !condition_resolved((u_lo >> 13) & 7u, s.flags);
+            charged = true;
+            if (err | nop) {
+              // mask_into_panic (:187-190) / mask_into_nop (:212-217): the lane re-enters the loop as a member of
+              // the group of the panic / nop encoding (all operand fields zero, condition Always)
+              const u64 masked = err ? P.consts.exception_revert_encoding : P.consts.nop_encoding;
+              enc_lo = (u32)masked;
+              enc_hi = (u32)(masked >> 32);
+              mine = false;
+            }
+          }
         }
-        if (!(props & ZKW_PROP_SRC1_PTR_OK) && ps.src1_ptr) {
-          ps.src1.w[1] = 0;
-          ps.src1.w[2] = 0;
-          ps.src1_ptr = false;
-        }
-      }
-      // ----------------------------------------------------------------------------------------
-      // apply (opcodes/parsing.rs:47-79)
-      // ----------------------------------------------------------------------------------------
-      if (lane_ok(s)) {
-        switch (opcode) {
-          case ZKW_OP_NOP: s.pc = ps.new_pc; break;  // noop.rs:16-19
-          case ZKW_OP_ADD:
-          case ZKW_OP_SUB: {  // add.rs:35-53, sub.rs:35-54
-            s.pc = ps.new_pc;
-            bool of;
-            const u256 r = opcode == ZKW_OP_ADD ? u256_add(ps.src0, ps.src1, of) : u256_sub(ps.src0, ps.src1, of);
-            const bool eq = u256_is_zero(r);
-            if (set_flags) set_flags3(s, of, eq, !eq && !of);
-            dst0_update(P, sh, s, ps.dst0, d.dst0, r, false);
-            break;
-          }
-          case ZKW_OP_MUL: {  // mul.rs:35-65
-            s.pc = ps.new_pc;
-            u256 lo, hi;
-            u256_mul(ps.src0, ps.src1, lo, hi);
-            if (set_flags) {
-              const bool of = !u256_is_zero(hi), eq = u256_is_zero(lo);
-              set_flags3(s, of, eq, !of && !eq);
-            }
-            dst0_update(P, sh, s, ps.dst0, d.dst0, lo, false);
-            reg_write(sh, s, d.dst1, hi, false);
-            break;
-          }
-          case ZKW_OP_DIV: {  // div.rs:35-75
-            s.pc = ps.new_pc;
-            if (u256_is_zero(ps.src1)) {
-              if (set_flags) set_flags3(s, true, false, false);
-              dst0_update(P, sh, s, ps.dst0, d.dst0, u256_zero(), false);
-              reg_write(sh, s, d.dst1, u256_zero(), false);
-            } else {
-              u256 q, r;
-              u256_divmod(ps.src0, ps.src1, q, r);
-              if (set_flags) set_flags3(s, false, u256_is_zero(q), u256_is_zero(r));
-              dst0_update(P, sh, s, ps.dst0, d.dst0, q, false);
-              reg_write(sh, s, d.dst1, r, false);
-            }
-            break;
-          }
-          case ZKW_OP_JUMP: s.pc = clip16(P, ps.src0); break;  // jump.rs:23-25
-          case ZKW_OP_CONTEXT: op_context(P, sh, s, d, ps); break;
-          case ZKW_OP_SHIFT: {  // shift.rs:44-78
-            s.pc = ps.new_pc;
-            const u32 n = ps.src1.w[0] & 0xffu;
-            const u32 v = ZKW_ATTR_VARIANT(d.attr);
-            const bool cyclic = v == ZKW_SHIFT_ROL || v == ZKW_SHIFT_ROR;
-            const bool right = v == ZKW_SHIFT_SHR || v == ZKW_SHIFT_ROR;
-            u256 r;
-            if (right) {
-              r = u256_shr(ps.src0, n);
-              if (cyclic) r = u256_or(r, u256_shl(ps.src0, 256u - n));
-            } else {
-              r = u256_shl(ps.src0, n);
-              if (cyclic) r = u256_or(r, u256_shr(ps.src0, 256u - n));
-            }
-            if (set_flags) set_flags3(s, false, u256_is_zero(r), false);
-            dst0_update(P, sh, s, ps.dst0, d.dst0, r, false);
-            break;
-          }
-          case ZKW_OP_BINOP: {  // binop.rs:42-61
-            s.pc = ps.new_pc;
-            const u32 v = ZKW_ATTR_VARIANT(d.attr);
-            const u256 r = v == ZKW_BINOP_XOR ? u256_xor(ps.src0, ps.src1) : (v == ZKW_BINOP_AND ? u256_and(ps.src0, ps.src1) : u256_or(ps.src0, ps.src1));
-            if (set_flags) set_flags3(s, false, u256_is_zero(r), false);
-            dst0_update(P, sh, s, ps.dst0, d.dst0, r, false);
-            break;
-          }
-          case ZKW_OP_PTR: op_ptr(P, sh, s, d, ps); break;
-          case ZKW_OP_LOG: op_log(P, sh, s, d, ps); break;
-          case ZKW_OP_NEAR_CALL: op_near_call(P, sh, s, d, ps); break;
-          case ZKW_OP_FAR_CALL: op_far_call(P, sh, s, d, ps); break;
-          case ZKW_OP_RET: op_ret(P, sh, s, d, ps); break;
-          case ZKW_OP_UMA: op_uma(P, sh, s, d, ps); break;
-          default: lane_fail(s, ZKW_STATUS_REFERENCE_PANIC); break;  // Opcode::Invalid => unreachable!() parsing.rs:77
+        todo &= ~__ballot(mine);
+        if (mine) {
+          Decoded d;
+          d.attr = u_attr;
+          d.cond = (u_lo >> 13) & 7u; d.src0 = (u_lo >> 16) & 15u; d.src1 = (u_lo >> 20) & 15u; d.dst0 = (u_lo >> 24) & 15u; d.dst1 = u_lo >> 28;
+          d.imm0 = u_hi & 0xffffu; d.imm1 = u_hi >> 16;
+          exec_decoded(P, sh, s, d);
         }
       }
       // ----------------------------------------------------------------------------------------
@@ -1568,11 +1626,19 @@ __global__ void __launch_bounds__(ZKW_WAVE) zkw_cycle_kernel(zkw_kparams P) {
           }
         }
       }
-      if (lane_ok(s)) {
+      if (lane_ok(s) && (P.debug_flags & 1u)) s.n_cycles++;
+      if (lane_ok(s) && !(P.debug_flags & 1u)) {
         // CycleRecord: 30 register chunks straight from LDS + 2 tail chunks, coalesced across lanes
         uint4* rec = P.rec + ((u64)wave * P.max_cycles + (P.cycle_base + k)) * ZKW_REC_CHUNKS * P.L;
-#pragma unroll 6
-        for (int c = 0; c < ZKW_REG_CHUNKS; c++) rec[(u64)c * P.L + tid] = sh_reg(sh, c, tid);
+#pragma unroll
+        for (int g = 0; g < ZKW_REG_CHUNKS; g += 5) {  // 5 LDS reads in flight per wait, then 5 coalesced stores
+          const uint4 t0 = sh_reg(sh, g, tid), t1 = sh_reg(sh, g + 1, tid), t2 = sh_reg(sh, g + 2, tid), t3 = sh_reg(sh, g + 3, tid), t4 = sh_reg(sh, g + 4, tid);
+          rec[(u64)g * P.L + tid] = t0;
+          rec[(u64)(g + 1) * P.L + tid] = t1;
+          rec[(u64)(g + 2) * P.L + tid] = t2;
+          rec[(u64)(g + 3) * P.L + tid] = t3;
+          rec[(u64)(g + 4) * P.L + tid] = t4;
+        }
         const u32 cnt = (s.n_mem > 255u ? 255u : s.n_mem) | ((s.n_log > 255u ? 255u : s.n_log) << 8) | ((s.n_aux > 255u ? 255u : s.n_aux) << 16);
         rec[(u64)30 * P.L + tid] = make_uint4((s.ptr_bitmap & 0xffffu) | ((s.flags & 0xfu) << 16), (s.pc & 0xffffu) | (s.sp << 16), s.ergs, s.timestamp);
         rec[(u64)31 * P.L + tid] = make_uint4(s.heap_bound, s.aux_bound, (s.depth & 0xffffu) | (s.prev_super_pc << 16), cnt);

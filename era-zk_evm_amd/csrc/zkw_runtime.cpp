@@ -130,6 +130,7 @@ struct zkw_batch {
   DevBuf<uint32_t> d_dir, d_cursors;
   DevBuf<uint64_t> d_commit, d_rc, d_blob_digests, d_leaves;
   DevBuf<uint32_t> d_idx, d_counts;
+  DevBuf<zkw_kparams> d_kparams;  // device copy of the parameter block of the latest run
   static const int EV_RING = 64;
   std::vector<hipEvent_t> evs;  // EV_RING (start, stop) pairs, one per run since the last sync
   uint32_t pending_runs = 0;
@@ -190,6 +191,11 @@ int zkw_ctx_set_isa(zkw_ctx* c, const zkw_isa_table* t) {
   if (!c || !t) return ZKW_ERR_INVALID;
   if (t->consts.panic_variant_idx >= ZKW_ISA_TABLE_SIZE || t->consts.nop_variant_idx >= ZKW_ISA_TABLE_SIZE) {
     c->last_error = "ISA table: panic/nop variant index out of range";
+    return ZKW_ERR_INVALID;
+  }
+  if ((t->consts.exception_revert_encoding & (ZKW_ISA_TABLE_SIZE - 1)) != t->consts.panic_variant_idx || (t->consts.exception_revert_encoding >> 11) != 0 ||
+      (t->consts.nop_encoding & (ZKW_ISA_TABLE_SIZE - 1)) != t->consts.nop_variant_idx || (t->consts.nop_encoding >> 11) != 0) {
+    c->last_error = "ISA table: nop/exception_revert encodings must be the bare nop/panic variant (Always, r0 operands, zero immediates)";
     return ZKW_ERR_INVALID;
   }
   c->isa = *t;
@@ -261,7 +267,7 @@ void zkw_batch_destroy(zkw_batch* b) {
   b->d_history.release(); b->d_stack_vals.release(); b->d_heap.release(); b->d_aux.release(); b->d_stack_ptrs.release(); b->d_blob_words.release();
   b->d_blob_dir.release(); b->d_preimages.release(); b->d_rec.release(); b->d_mem.release(); b->d_log.release(); b->d_auxs.release();
   b->d_dir.release(); b->d_cursors.release(); b->d_commit.release(); b->d_rc.release(); b->d_blob_digests.release(); b->d_leaves.release();
-  b->d_idx.release(); b->d_counts.release();
+  b->d_idx.release(); b->d_counts.release(); b->d_kparams.release();
   for (hipEvent_t e : b->evs) (void)hipEventDestroy(e);
   delete b;
 }
@@ -644,6 +650,10 @@ int zkw_batch_run(zkw_batch* b, uint32_t max_cycles, void* hip_stream) {
   P.cycle_base = b->cycles_run;
   P.run_cycles = max_cycles;
   P.props = b->props;
+  if (const char* dbg = getenv("ZKW_DEBUG_FLAGS")) P.debug_flags = (uint32_t)atoi(dbg);  // profiling ablations only
+  if (!b->d_kparams.p) HIP_TRY(c, b->d_kparams.alloc(1));
+  P.self = b->d_kparams.p;
+  HIP_TRY(c, hipMemcpyAsync(b->d_kparams.p, &P, sizeof P, hipMemcpyHostToDevice, st));
   const uint32_t slot = b->pending_runs % zkw_batch::EV_RING;
   HIP_TRY(c, hipEventRecord(b->evs[2 * slot], st));
   HIP_TRY(c, zkw_launch_cycle_kernel(&P, st));

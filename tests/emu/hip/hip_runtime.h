@@ -82,3 +82,9 @@ static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, h
       }
     }
 }
+
+// wave-uniform broadcast of the first active lane: identity for a one-lane wave
+static inline int zkw_emu_readfirstlane(int x) { return x; }
+#define __builtin_amdgcn_readfirstlane(x) zkw_emu_readfirstlane(x)
+static inline int zkw_emu_readlane(int x, int) { return x; }
+#define __builtin_amdgcn_readlane(x, l) zkw_emu_readlane(x, l)

@@ -169,3 +169,10 @@ def test_host_replay_on_gpu(oracle, product, isa):
     for i in (0, 1, 63, 64, 69):
         got, rc = replay_log(lib, bp, wl, i)
         assert len(got) == len(logs[i]) and (got == logs[i]).all()
+
+
+@pytest.mark.parametrize("cfg,kw", [(1, dict()), (2, dict(n_instances=320)), (4, dict(n_instances=128, n_cycles=512))])
+def test_generic_per_lane_path_forced(oracle, product, isa, cfg, kw, monkeypatch):
+    """ZKW_DEBUG_FLAGS=4 disables the wave-uniform fast path: the fully per-lane decode must give the same bits."""
+    monkeypatch.setenv("ZKW_DEBUG_FLAGS", "4")
+    _compare(oracle, product, synth.make(cfg, isa, **kw), 64)
