@@ -1368,13 +1368,17 @@ ZD void exec_decoded(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d
     ps.src0 = src0_mem;
     ps.src0_ptr = src0_mem_ptr;
   }
-  if (props & ZKW_PROP_SWAP) {                     // :341-345
-    const u256 t = ps.src0;
-    ps.src0 = ps.src1;
-    ps.src1 = t;
-    const bool tp = ps.src0_ptr;
-    ps.src0_ptr = ps.src1_ptr;
-    ps.src1_ptr = tp;
+  {  // swap_operands (:341-345) — limb-wise selects (a struct swap keeps both operands in scratch memory)
+    const bool sw = (props & ZKW_PROP_SWAP) != 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const u32 a = ps.src0.w[i], b = ps.src1.w[i];
+      ps.src0.w[i] = sw ? b : a;
+      ps.src1.w[i] = sw ? a : b;
+    }
+    const bool ap = ps.src0_ptr, bp = ps.src1_ptr;
+    ps.src0_ptr = sw ? bp : ap;
+    ps.src1_ptr = sw ? ap : bp;
   }
   ps.new_pc = (s.pc + 1) & 0xffffu;  // :347-350 (never a skip cycle here)
   if (!s.is_kernel) {                // erase_fat_pointer_metadata :374-396

@@ -100,12 +100,17 @@ ZD void u256_mul(const u256& a, const u256& b, u256& lo, u256& hi) {
 }
 
 // U256 << n with the `uint` crate's "n >= 256 => 0" (shift.rs:51,58; uma.rs:303,361)
+// funnel shift: low 32 bits of ((hi:lo) >> (n & 31)) — one v_alignbit_b32.  (Spelling the funnel as
+// ((u64)hi << 32 | lo) lets the optimiser fuse the two limb loads into an unaligned i64 load while the
+// operand still sits in a struct, which then pins the whole operand in scratch memory.)
+ZD u32 zk_funnel_r(u32 hi, u32 lo, u32 n) { return __builtin_amdgcn_alignbit(hi, lo, n); }
+
 ZD u256 u256_shl(const u256& a, u32 n) {
-  u32 bs = n & 31, ws = (n >> 5) & 7;
+  const u32 bs = n & 31, ws = (n >> 5) & 7;
   u256 t;
   t.w[0] = a.w[0] << bs;
 #pragma unroll
-  for (int i = 1; i < 8; i++) t.w[i] = (u32)(((((u64)a.w[i] << 32) | a.w[i - 1]) << bs) >> 32);
+  for (int i = 1; i < 8; i++) t.w[i] = bs ? zk_funnel_r(a.w[i], a.w[i - 1], 32u - bs) : a.w[i];
   if (ws & 1) {
 #pragma unroll
     for (int i = 7; i >= 1; i--) t.w[i] = t.w[i - 1];
@@ -125,10 +130,10 @@ ZD u256 u256_shl(const u256& a, u32 n) {
   return t;
 }
 ZD u256 u256_shr(const u256& a, u32 n) {
-  u32 bs = n & 31, ws = (n >> 5) & 7;
+  const u32 bs = n & 31, ws = (n >> 5) & 7;
   u256 t;
 #pragma unroll
-  for (int i = 0; i < 7; i++) t.w[i] = (u32)((((u64)a.w[i + 1] << 32) | a.w[i]) >> bs);
+  for (int i = 0; i < 7; i++) t.w[i] = zk_funnel_r(a.w[i + 1], a.w[i], bs);
   t.w[7] = a.w[7] >> bs;
   if (ws & 1) {
 #pragma unroll

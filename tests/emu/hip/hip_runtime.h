@@ -88,3 +88,5 @@ static inline int zkw_emu_readfirstlane(int x) { return x; }
 #define __builtin_amdgcn_readfirstlane(x) zkw_emu_readfirstlane(x)
 static inline int zkw_emu_readlane(int x, int) { return x; }
 #define __builtin_amdgcn_readlane(x, l) zkw_emu_readlane(x, l)
+static inline uint32_t zkw_emu_alignbit(uint32_t hi, uint32_t lo, uint32_t n) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (n & 31u)); }
+#define __builtin_amdgcn_alignbit(hi, lo, n) zkw_emu_alignbit(hi, lo, n)
