@@ -109,7 +109,6 @@ typedef struct zkw_kparams {
   uint32_t debug_flags;  /* profiling ablations only (ZKW_DEBUG_FLAGS): 1 = no CycleRecord stores, 2 = no stream stores */
   zkw_isa_consts consts;
   zkw_block_properties props;
-  const struct zkw_kparams* self; /* device copy of this block (out-of-line opcode handlers read it from memory) */
   const uint2* isa;            /* [2048] packed */
   /* state */
   uint4* regs;                 /* [n_waves][30][L]                      */
@@ -135,3 +134,16 @@ typedef struct zkw_kparams {
   uint32_t* dir;               /* [n_waves][max_cycles + 1][4] (mem, log, aux cursors at cycle start) */
   uint32_t* cursors;           /* [n_waves][4] persistent stream cursors */
 } zkw_kparams;
+
+/* zkw_reset_kernel: working state := pristine images, one launch */
+typedef struct zkw_reset_params {
+  uint4* dst[5];
+  const uint4* src[5];
+  uint32_t n16[5];          /* 16-byte units per buffer */
+  uint4* heap_dst;           /* working heap arena */
+  const uint4* heap_src;     /* [n_waves][heap_image_words][L][2] */
+  uint32_t heap_row16;       /* 16-byte units per wave row of the image */
+  uint32_t heap_pitch16;     /* 16-byte units between wave rows in the arena */
+  uint32_t n_waves;
+  uint32_t* cursors;         /* [n_waves][4] */
+} zkw_reset_params;

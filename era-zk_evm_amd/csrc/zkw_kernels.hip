@@ -1470,7 +1470,7 @@ ZD void exec_decoded(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d
       case ZKW_OP_FAR_CALL:
       case ZKW_OP_RET: {
         Lane tmp = s;
-        zkw_rare_op(P.self, sh, &tmp, &d, &ps);
+        zkw_rare_op(&P, sh, &tmp, &d, &ps);
         s = tmp;
         break;
       }
@@ -1677,6 +1677,28 @@ __global__ void __launch_bounds__(ZKW_WAVE) zkw_cycle_kernel(zkw_kparams P) {
 #pragma unroll 6
     for (int c = 0; c < ZKW_REG_CHUNKS; c++) rg[(u64)c * P.L + tid] = sh_reg(sh, c, tid);
   }
+}
+
+// working state := pristine images (register file, scalars, callstack, frame meta, storage table, heap
+// image) and stream cursors := 0 — one launch instead of seven copies per reset
+__global__ void zkw_reset_kernel(zkw_reset_params R) {
+  const u32 stride = gridDim.x * blockDim.x;
+  const u32 t0 = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll 1
+  for (int b = 0; b < 5; b++) {
+    const uint4* src = R.src[b];
+    uint4* dst = R.dst[b];
+    for (u32 i = t0; i < R.n16[b]; i += stride) dst[i] = src[i];
+  }
+  for (u32 w = 0; w < R.n_waves; w++)
+    for (u32 i = t0; i < R.heap_row16; i += stride) R.heap_dst[(u64)w * R.heap_pitch16 + i] = R.heap_src[(u64)w * R.heap_row16 + i];
+  for (u32 i = t0; i < R.n_waves * 4; i += stride) R.cursors[i] = 0;
+}
+
+extern "C" hipError_t zkw_launch_reset_kernel(const zkw_reset_params* R, uint32_t wave_threads, hipStream_t stream) {
+  const u32 threads = wave_threads > 1 ? 256 : 1;
+  hipLaunchKernelGGL(zkw_reset_kernel, dim3(wave_threads > 1 ? 512 : 1), dim3(threads), 0, stream, *R);
+  return hipGetLastError();
 }
 
 // dynamic LDS per workgroup: ISA table + cursors + per-lane register file and Keccak row

@@ -23,6 +23,7 @@
 
 extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_kparams* P, hipStream_t stream);
 extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L);
+extern "C" hipError_t zkw_launch_reset_kernel(const zkw_reset_params* R, uint32_t wave_threads, hipStream_t stream);
 extern "C" hipError_t zkw_launch_commit(const zkw_commit_params* C, int stage, hipStream_t stream);
 
 static_assert(sizeof(zkw_callstack_entry) == 112, "abi");
@@ -615,17 +616,19 @@ int zkw_batch_reset(zkw_batch* b, void* hip_stream) {
   }
   hipStream_t st = (hipStream_t)hip_stream;
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipMemcpyAsync(b->d_regs.p, b->d_regs0.p, b->d_regs0.bytes(), hipMemcpyDeviceToDevice, st));
-  HIP_TRY(c, hipMemcpyAsync(b->d_scalars.p, b->d_scalars0.p, b->d_scalars0.bytes(), hipMemcpyDeviceToDevice, st));
-  HIP_TRY(c, hipMemcpyAsync(b->d_callstack.p, b->d_callstack0.p, b->d_callstack0.bytes(), hipMemcpyDeviceToDevice, st));
-  HIP_TRY(c, hipMemcpyAsync(b->d_frames.p, b->d_frames0.p, b->d_frames0.bytes(), hipMemcpyDeviceToDevice, st));
-  HIP_TRY(c, hipMemcpyAsync(b->d_storage.p, b->d_storage0.p, b->d_storage0.bytes(), hipMemcpyDeviceToDevice, st));
-  if (b->heap_image_words) {
-    const size_t row = (size_t)b->heap_image_words * b->L * 32;
-    const size_t pitch = (size_t)b->lim.max_far_frames * b->lim.heap_words * b->L * 32;
-    HIP_TRY(c, hipMemcpy2DAsync(b->d_heap.p, pitch, b->d_heap0.p, row, row, b->n_waves, hipMemcpyDeviceToDevice, st));
-  }
-  HIP_TRY(c, hipMemsetAsync(b->d_cursors.p, 0, b->d_cursors.bytes(), st));
+  zkw_reset_params R;
+  std::memset(&R, 0, sizeof R);
+  R.dst[0] = b->d_regs.p; R.src[0] = b->d_regs0.p; R.n16[0] = (uint32_t)(b->d_regs0.bytes() / 16);
+  R.dst[1] = (uint4*)b->d_scalars.p; R.src[1] = (const uint4*)b->d_scalars0.p; R.n16[1] = (uint32_t)(b->d_scalars0.bytes() / 16);
+  R.dst[2] = (uint4*)b->d_callstack.p; R.src[2] = (const uint4*)b->d_callstack0.p; R.n16[2] = (uint32_t)(b->d_callstack0.bytes() / 16);
+  R.dst[3] = (uint4*)b->d_frames.p; R.src[3] = (const uint4*)b->d_frames0.p; R.n16[3] = (uint32_t)(b->d_frames0.bytes() / 16);
+  R.dst[4] = (uint4*)b->d_storage.p; R.src[4] = (const uint4*)b->d_storage0.p; R.n16[4] = (uint32_t)(b->d_storage0.bytes() / 16);
+  R.heap_dst = b->d_heap.p; R.heap_src = b->d_heap0.p;
+  R.heap_row16 = b->heap_image_words * b->L * 2;
+  R.heap_pitch16 = b->lim.max_far_frames * b->lim.heap_words * b->L * 2;
+  R.n_waves = b->n_waves;
+  R.cursors = b->d_cursors.p;
+  HIP_TRY(c, zkw_launch_reset_kernel(&R, (uint32_t)c->wave_width, st));
   b->cycles_run = 0;
   b->ran = false;
   b->synced = false;
@@ -651,9 +654,6 @@ int zkw_batch_run(zkw_batch* b, uint32_t max_cycles, void* hip_stream) {
   P.run_cycles = max_cycles;
   P.props = b->props;
   if (const char* dbg = getenv("ZKW_DEBUG_FLAGS")) P.debug_flags = (uint32_t)atoi(dbg);  // profiling ablations only
-  if (!b->d_kparams.p) HIP_TRY(c, b->d_kparams.alloc(1));
-  P.self = b->d_kparams.p;
-  HIP_TRY(c, hipMemcpyAsync(b->d_kparams.p, &P, sizeof P, hipMemcpyHostToDevice, st));
   const uint32_t slot = b->pending_runs % zkw_batch::EV_RING;
   HIP_TRY(c, hipEventRecord(b->evs[2 * slot], st));
   HIP_TRY(c, zkw_launch_cycle_kernel(&P, st));
