@@ -11,6 +11,8 @@
 #include "../../include/zkw.h"
 
 #define ZKW_WAVE 64            /* CDNA wavefront width */
+#define ZKW_WAVES_PER_GROUP 4   /* waves per workgroup of the cycle kernel: one per SIMD, sharing the LDS ISA table */
+#define ZKW_KROW_WORDS 34      /* Keccak rate block (136 B) in dwords */
 #define ZKW_REC_CHUNKS 32      /* 512-byte CycleRecord = 32 x 16 B */
 #define ZKW_REG_CHUNKS 30      /* 15 registers x 2 halves */
 
@@ -105,13 +107,16 @@ typedef struct zkw_kparams {
   uint32_t storage_slots, storage_journal;
   uint32_t cap_mem, cap_log, cap_aux; /* stream capacity per wave (records) */
   uint32_t n_blobs, n_preimages;
-  uint32_t wave_threads; /* threads per workgroup = hardware wave width (64 on gfx950) */
+  uint32_t wave_threads; /* hardware wave width (64 on gfx950; 1 in the CPU emulation build of tests/emu) */
+  uint32_t waves_per_group; /* waves per workgroup (ZKW_WAVES_PER_GROUP; 1 in the emulation build) */
+  uint32_t reserved0;
   uint32_t debug_flags;  /* profiling ablations only (ZKW_DEBUG_FLAGS): 1 = no CycleRecord stores, 2 = no stream stores */
   zkw_isa_consts consts;
   zkw_block_properties props;
   const uint2* isa;            /* [2048] packed */
   /* state */
   uint4* regs;                 /* [n_waves][30][L]                      */
+  uint32_t* krow;              /* [n_waves][34][L] Keccak block assembly rows */
   zkw_dev_scalars* scalars;    /* [n_instances]                          */
   zkw_dev_entry* callstack;    /* [n_instances][D + 1]                   */
   zkw_dev_frame_meta* frames;  /* [n_instances][F]                       */

@@ -86,12 +86,19 @@ ZD u32 stream_alloc(u32* cursor) {
   return base + rank;
 }
 
-// LDS view of one workgroup (= one wave).  Dynamic size: 16 KB ISA + (30*16 + 34*4) B per lane.
+// orders this wave's own LDS stores before later cross-lane LDS reads/atomics (no workgroup barrier involved)
+ZD void zkw_wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// LDS view of one wave.  A workgroup holds ZKW_WAVES_PER_GROUP waves that share the 16 KB ISA table; each wave
+// owns 16 B of cursors + 30*16 B per lane of register file.  The Keccak row (rare, precompile only) is in HBM.
 struct Shared {
-  uint2* isa;     // [2048] packed ISA table
+  uint2* isa;     // [2048] packed ISA table (shared by the waves of the workgroup)
   u32* cursor;    // [4] stream cursors of this wave
   uint4* regs;    // [30][L] register file, 16-byte chunks, lane-minor
-  u32* krow;      // [34][L] Keccak rate block assembly rows
+  u32* krow;      // [34][L] Keccak rate block assembly rows (global memory)
   u32 L;
 };
 ZD uint4& sh_reg(Shared& sh, u32 chunk, u32 lane) { return sh.regs[chunk * sh.L + lane]; }
@@ -1483,24 +1490,29 @@ ZD void exec_decoded(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d
 // =============================================================================================
 // the cycle kernel
 // =============================================================================================
-__global__ void __launch_bounds__(ZKW_WAVE) zkw_cycle_kernel(zkw_kparams P) {
+__global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kernel(zkw_kparams P) {
   extern __shared__ uint4 zkw_lds[];
-  const u32 tid = threadIdx.x;
-  const u32 wave = blockIdx.x;
+  // one wave = one independent group of L VM instances; ZKW_WAVES_PER_GROUP waves per workgroup (one per SIMD)
+  // share the ISA table so that four of them fit the 160 KB of a CU
+  const u32 tid = threadIdx.x % P.wave_threads;
+  const u32 wib = threadIdx.x / P.wave_threads;
+  const u32 wave = blockIdx.x * P.waves_per_group + wib;
   Shared sh;
   sh.L = P.L;
-  sh.isa = (uint2*)zkw_lds;                                     // 16 KB
-  sh.cursor = (u32*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2);          // 16 B
-  sh.regs = zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + 1;                // 30 * L * 16 B
-  sh.krow = (u32*)(sh.regs + ZKW_REG_CHUNKS * P.L);              // 34 * L * 4 B
-  // stage the packed ISA table in LDS (all 64 threads, 16 B each per step)
+  sh.isa = (uint2*)zkw_lds;                                                        // 16 KB
+  sh.cursor = (u32*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + wib * (1 + ZKW_REG_CHUNKS * P.L));  // 16 B
+  sh.regs = (uint4*)sh.cursor + 1;                                                  // 30 * L * 16 B
+  sh.krow = P.krow + (u64)wave * ZKW_KROW_WORDS * P.L;
+  // stage the packed ISA table in LDS (all threads of the workgroup, 16 B each per step)
   {
     const uint4* src = (const uint4*)P.isa;
     uint4* dst = (uint4*)sh.isa;
-    for (u32 i = tid; i < ZKW_ISA_TABLE_SIZE / 2; i += blockDim.x) dst[i] = src[i];
+    for (u32 i = threadIdx.x; i < ZKW_ISA_TABLE_SIZE / 2; i += blockDim.x) dst[i] = src[i];
   }
-  for (u32 i = tid; i < 4; i += blockDim.x) sh.cursor[i] = P.cursors[wave * 4 + i];
   __syncthreads();
+  if (wave >= P.n_waves) return;  // tail workgroup: no further workgroup-level barrier below
+  for (u32 i = tid; i < 4; i += P.wave_threads) sh.cursor[i] = P.cursors[wave * 4 + i];
+  zkw_wave_lds_fence();
 
   const u32 inst = wave * P.L + tid;
   const bool exists = tid < P.L && inst < P.n_instances;
@@ -1533,7 +1545,7 @@ __global__ void __launch_bounds__(ZKW_WAVE) zkw_cycle_kernel(zkw_kparams P) {
   u32 k = 0;
   for (; k < P.run_cycles; k++) {
     // directory: stream cursors at the start of wave-cycle (cycle_base + k)
-    for (u32 i = tid; i < 4; i += blockDim.x) P.dir[((u64)wave * (P.max_cycles + 1) + P.cycle_base + k) * 4 + i] = ((volatile u32*)sh.cursor)[i];
+    for (u32 i = tid; i < 4; i += P.wave_threads) P.dir[((u64)wave * (P.max_cycles + 1) + P.cycle_base + k) * 4 + i] = ((volatile u32*)sh.cursor)[i];
     bool active = exists && s.status == ZKW_STATUS_RUNNING;
     if (active && s.depth == 0) {  // execution_has_ended() (mod.rs:96-98): callers stop cycling here
       s.status = ZKW_STATUS_ENDED;
@@ -1651,7 +1663,7 @@ __global__ void __launch_bounds__(ZKW_WAVE) zkw_cycle_kernel(zkw_kparams P) {
     }
   }
   // final directory entry
-  for (u32 i = tid; i < 4; i += blockDim.x) {
+  for (u32 i = tid; i < 4; i += P.wave_threads) {
     const u32 cur = ((volatile u32*)sh.cursor)[i];
     P.dir[((u64)wave * (P.max_cycles + 1) + P.cycle_base + k) * 4 + i] = cur;
     P.cursors[wave * 4 + i] = cur;
@@ -1701,11 +1713,19 @@ extern "C" hipError_t zkw_launch_reset_kernel(const zkw_reset_params* R, uint32_
   return hipGetLastError();
 }
 
-// dynamic LDS per workgroup: ISA table + cursors + per-lane register file and Keccak row
-extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L) { return ZKW_ISA_TABLE_SIZE * 8 + 16 + L * (ZKW_REG_CHUNKS * 16 + 34 * 4); }
+// dynamic LDS per workgroup: ISA table + per wave (cursors + per-lane register file)
+extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_group) { return ZKW_ISA_TABLE_SIZE * 8 + waves_per_group * (16 + L * ZKW_REG_CHUNKS * 16); }
 
 // host-callable launcher (keeps <<<>>> out of the runtime)
 extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_kparams* P, hipStream_t stream) {
-  hipLaunchKernelGGL(zkw_cycle_kernel, dim3(P->n_waves), dim3(P->wave_threads), zkw_cycle_kernel_lds_bytes(P->L), stream, *P);
+  const u32 g = P->waves_per_group;
+  static uint32_t lds_opt_in = 0;  // dynamic LDS above the 64 KB default needs an explicit opt-in, once per size
+  const uint32_t lds = zkw_cycle_kernel_lds_bytes(P->L, g);
+  if (lds > lds_opt_in) {
+    const hipError_t e = hipFuncSetAttribute((const void*)zkw_cycle_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    lds_opt_in = lds;
+  }
+  hipLaunchKernelGGL(zkw_cycle_kernel, dim3((P->n_waves + g - 1) / g), dim3(P->wave_threads * g), zkw_cycle_kernel_lds_bytes(P->L, g), stream, *P);
   return hipGetLastError();
 }

@@ -59,7 +59,6 @@ ZD void zk_keccak_f1600(u64 a[25]) {
 }
 
 #define ZKW_KECCAK_RATE 136
-#define ZKW_KROW_WORDS 34 /* 136 / 4 */
 
 ZD void kbuf_set_byte(Shared& sh, u32 lane, u32 pos, u32 byte) {
   u32* w = &sh.krow[(pos >> 2) * sh.L + lane];  // [dword][lane]: conflict-free across lanes

@@ -22,7 +22,7 @@
 #include "zkw_device.h"
 
 extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_kparams* P, hipStream_t stream);
-extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L);
+extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_group);
 extern "C" hipError_t zkw_launch_reset_kernel(const zkw_reset_params* R, uint32_t wave_threads, hipStream_t stream);
 extern "C" hipError_t zkw_launch_commit(const zkw_commit_params* C, int stage, hipStream_t stream);
 
@@ -128,10 +128,15 @@ struct zkw_batch {
   DevBuf<zkw_dev_preimage> d_preimages;
   // device: outputs
   DevBuf<uint4> d_rec, d_mem, d_log, d_auxs;
-  DevBuf<uint32_t> d_dir, d_cursors;
+  DevBuf<uint32_t> d_dir, d_cursors, d_krow;
   DevBuf<uint64_t> d_commit, d_rc, d_blob_digests, d_leaves;
   DevBuf<uint32_t> d_idx, d_counts;
-  DevBuf<zkw_kparams> d_kparams;  // device copy of the parameter block of the latest run
+  // hipGraph of one whole step (reset -> cycle kernel -> commitment kernels), replayed by zkw_batch_step
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  uint32_t graph_cycles = 0, graph_mask = 0;
+  hipStream_t graph_stream = nullptr;
+  bool graph_failed = false;
   static const int EV_RING = 64;
   std::vector<hipEvent_t> evs;  // EV_RING (start, stop) pairs, one per run since the last sync
   uint32_t pending_runs = 0;
@@ -267,8 +272,10 @@ void zkw_batch_destroy(zkw_batch* b) {
   b->d_regs.release(); b->d_scalars.release(); b->d_callstack.release(); b->d_frames.release(); b->d_storage.release(); b->d_journal.release();
   b->d_history.release(); b->d_stack_vals.release(); b->d_heap.release(); b->d_aux.release(); b->d_stack_ptrs.release(); b->d_blob_words.release();
   b->d_blob_dir.release(); b->d_preimages.release(); b->d_rec.release(); b->d_mem.release(); b->d_log.release(); b->d_auxs.release();
-  b->d_dir.release(); b->d_cursors.release(); b->d_commit.release(); b->d_rc.release(); b->d_blob_digests.release(); b->d_leaves.release();
-  b->d_idx.release(); b->d_counts.release(); b->d_kparams.release();
+  b->d_dir.release(); b->d_cursors.release(); b->d_krow.release(); b->d_commit.release(); b->d_rc.release(); b->d_blob_digests.release(); b->d_leaves.release();
+  b->d_idx.release(); b->d_counts.release();
+  if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
+  if (b->graph) (void)hipGraphDestroy(b->graph);
   for (hipEvent_t e : b->evs) (void)hipEventDestroy(e);
   delete b;
 }
@@ -580,6 +587,7 @@ int zkw_batch_upload(zkw_batch* b) {
   HIP_TRY(c, ensure(b->d_auxs, (size_t)W * b->cap_aux * 16));
   HIP_TRY(c, ensure(b->d_dir, (size_t)W * (lim.max_cycles + 1) * 4));
   HIP_TRY(c, ensure(b->d_cursors, (size_t)W * 4));
+  HIP_TRY(c, ensure(b->d_krow, (size_t)W * ZKW_KROW_WORDS * L));
   HIP_TRY(c, ensure(b->d_commit, (size_t)n * ZKW_QUEUE_COUNT * 4));
   if (b->evs.empty()) {
     b->evs.resize(2 * zkw_batch::EV_RING, nullptr);
@@ -595,7 +603,9 @@ int zkw_batch_upload(zkw_batch* b) {
   P.n_blobs = (uint32_t)b->blobs.size(); P.n_preimages = (uint32_t)b->preimages.size();
   P.consts = c->isa.consts;
   P.wave_threads = (uint32_t)c->wave_width;
+  P.waves_per_group = c->wave_width > 1 ? ZKW_WAVES_PER_GROUP : 1;
   P.isa = c->d_isa;
+  P.krow = b->d_krow.p;
   P.regs = b->d_regs.p; P.scalars = b->d_scalars.p; P.callstack = b->d_callstack.p; P.frames = b->d_frames.p;
   P.stack_vals = b->d_stack_vals.p; P.stack_ptrs = b->d_stack_ptrs.p; P.heap = b->d_heap.p; P.aux_heap = b->d_aux.p;
   P.storage = b->d_storage.p; P.journal = b->d_journal.p; P.history = b->d_history.p;
@@ -888,6 +898,61 @@ int zkw_batch_get_commitments(zkw_batch* b, uint64_t* out) {
   if (rc != ZKW_OK) return rc;
   HIP_TRY(c, hipStreamSynchronize(b->run_stream));
   HIP_TRY(c, hipMemcpy(out, b->d_commit.p, b->d_commit.bytes(), hipMemcpyDeviceToHost));
+  return ZKW_OK;
+}
+
+int zkw_batch_step(zkw_batch* b, uint32_t max_cycles, uint32_t queue_mask, void* hip_stream) {
+  if (!b) return ZKW_ERR_INVALID;
+  zkw_ctx* c = b->ctx;
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (b->graph_exec && b->graph_cycles == max_cycles && b->graph_mask == queue_mask && b->graph_stream == st) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipGraphLaunch(b->graph_exec, st));
+    b->cycles_run = max_cycles;
+    b->ran = true;
+    b->synced = false;
+    b->wave_cache.clear();
+    b->run_stream = st;
+    b->pending_runs = 1;  // the captured run uses event pair 0
+    return ZKW_OK;
+  }
+  // eager pass first: validates arguments and performs every lazy allocation outside of stream capture
+  int rc = zkw_batch_reset(b, hip_stream);
+  if (rc == ZKW_OK) rc = zkw_batch_run(b, max_cycles, hip_stream);
+  if (rc == ZKW_OK && queue_mask) rc = zkw_batch_commit(b, queue_mask, hip_stream);
+  if (!b->graph_failed && std::getenv("ZKW_NO_GRAPH")) b->graph_failed = true;  // diagnostics: eager steps only
+  if (rc != ZKW_OK || b->graph_failed || !st) return rc;  // no capture on the legacy default stream
+  // capture the same sequence for the following steps
+  if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
+  if (b->graph) { (void)hipGraphDestroy(b->graph); b->graph = nullptr; }
+  HIP_TRY(c, hipStreamSynchronize(st));
+  const uint32_t saved_pending = b->pending_runs;
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) {
+    b->graph_failed = true;
+    return ZKW_OK;
+  }
+  b->pending_runs = 0;
+  int crc = zkw_batch_reset(b, hip_stream);
+  if (crc == ZKW_OK) crc = zkw_batch_run(b, max_cycles, hip_stream);
+  if (crc == ZKW_OK && queue_mask) crc = zkw_batch_commit(b, queue_mask, hip_stream);
+  hipGraph_t g = nullptr;
+  const hipError_t e_end = hipStreamEndCapture(st, &g);
+  b->pending_runs = saved_pending;
+  if (crc != ZKW_OK || e_end != hipSuccess || !g) {
+    if (g) (void)hipGraphDestroy(g);
+    b->graph_failed = true;
+    return ZKW_OK;
+  }
+  if (hipGraphInstantiate(&b->graph_exec, g, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    b->graph_exec = nullptr;
+    b->graph_failed = true;
+    return ZKW_OK;
+  }
+  b->graph = g;
+  b->graph_cycles = max_cycles;
+  b->graph_mask = queue_mask;
+  b->graph_stream = st;
   return ZKW_OK;
 }
 

@@ -425,6 +425,10 @@ int zkw_batch_reset(zkw_batch* batch, void* hip_stream);
 /* every instance cycles until ended or `max_cycles` more cycles (<= limits.max_cycles);
  * async on `stream` (hipStream_t; NULL = default stream) */
 int zkw_batch_run(zkw_batch* batch, uint32_t max_cycles, void* hip_stream);
+/* one whole step = zkw_batch_reset + zkw_batch_run(max_cycles) + zkw_batch_commit(queue_mask), enqueued on `stream`.
+ * The first call runs eagerly and captures the sequence into a hipGraph; later calls with the same arguments replay
+ * it with a single launch (the launch-bound regime of small batches). */
+int zkw_batch_step(zkw_batch* batch, uint32_t max_cycles, uint32_t queue_mask, void* hip_stream);
 /* waits for the run, downloads the streams and builds the per-instance views */
 int zkw_batch_sync(zkw_batch* batch);
 int zkw_batch_get_stats(zkw_batch* batch, zkw_run_stats* out);

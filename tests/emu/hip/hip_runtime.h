@@ -90,3 +90,19 @@ static inline int zkw_emu_readlane(int x, int) { return x; }
 #define __builtin_amdgcn_readlane(x, l) zkw_emu_readlane(x, l)
 static inline uint32_t zkw_emu_alignbit(uint32_t hi, uint32_t lo, uint32_t n) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (n & 31u)); }
 #define __builtin_amdgcn_alignbit(hi, lo, n) zkw_emu_alignbit(hi, lo, n)
+
+// stream capture / graphs: not emulated — zkw_batch_step falls back to its eager sequence
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
+static inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorNotSupported; }
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return hipErrorNotSupported; }
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return hipErrorNotSupported; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
+static inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_wave_barrier() ((void)0)
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }

@@ -176,3 +176,23 @@ def test_generic_per_lane_path_forced(oracle, product, isa, cfg, kw, monkeypatch
     """ZKW_DEBUG_FLAGS=4 disables the wave-uniform fast path: the fully per-lane decode must give the same bits."""
     monkeypatch.setenv("ZKW_DEBUG_FLAGS", "4")
     _compare(oracle, product, synth.make(cfg, isa, **kw), 64)
+
+
+def test_graph_replayed_step(oracle, product, isa):
+    """zkw_batch_step: the first call runs eagerly and captures a hipGraph, later calls replay it — same bits."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    stream = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(stream)) == 0
+    wl = synth.make(2, isa, n_instances=256)
+    bo = _run(oracle, wl)
+    bp = product.create_batch(wl)
+    for _ in range(4):
+        product.call("batch_step", bp.h, C.c_uint32(wl.n_cycles), C.c_uint32(7), stream)
+    bp.sync()
+    for i in range(0, 256, 17):
+        ok, why = K.traces_equal(bo.trace(i), bp.trace(i))
+        assert ok, why
+    cp = bp.commitments()
+    assert np.array_equal(bo.commitments(), cp)
+    assert float(bp.stats()["kernel_ms"]) > 0
