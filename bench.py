@@ -23,12 +23,13 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--instances", type=int, default=4096, help="VM instances per GPU (weak scaling)")
     ap.add_argument("--cycles", type=int, default=256)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per wave (0 = library default)")
-    ap.add_argument("--streams", type=int, default=8, help="independent batch slots / HIP streams the K steps are pipelined over")
+    ap.add_argument("--fuse", type=int, default=16, help="batches (steps) per fused launch (zkw_batches_step), <= 32")
+    ap.add_argument("--streams", type=int, default=2, help="fused groups in flight on separate HIP streams")
     ap.add_argument("--cfg", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nop-only", action="store_true")
@@ -57,14 +58,16 @@ def main():
     else:
         wl = synth.make(args.cfg, isa, n_instances=args.instances, n_cycles=args.cycles, seed=0x5EED0000 + args.cfg + 0x100 * rank)
     wl.limits["lanes_per_wave"] = args.lanes
-    # Software pipelining: a 4096-instance batch is 64 waves (a quarter of the chip's CUs) and every instance is a
-    # sequential 256-cycle chain, so one batch cannot fill the GPU.  The K steps are therefore issued round-robin
-    # over S batch slots, each with its own resident state / output buffers and its own HIP stream; every step is
-    # still one complete pass (reset -> cycle kernel -> decommit-queue commitment [-> RCCL all-gather]) over one
-    # full batch.  `kernel_ms` stays the duration of ONE launch (HIP events on its stream).
-    n_slots = max(1, min(args.streams, args.steps))
-    batches = [prod.create_batch(wl) for _ in range(n_slots)]
-    streams = [torch.cuda.Stream(device=local_rank) for _ in range(n_slots)]
+    # A 4096-instance batch is 64 waves and every instance is a sequential chain of cycles, so ONE batch cannot fill
+    # 256 CUs (the cycle kernel is latency-bound per wave) and the hardware overlaps only ~4 kernels of different
+    # streams.  The K steps (one step = one 1M-cycle batch, every cycle of it executed and witnessed) are therefore
+    # issued `--fuse` batches per launch through zkw_batches_step (one reset launch, one cycle-kernel launch, one set
+    # of commitment launches; grid.y = batch) and `--streams` such groups are in flight on separate HIP streams.
+    fuse = max(1, min(args.fuse, 32, args.steps))
+    n_groups = max(1, min(args.streams, (args.steps + fuse - 1) // fuse))
+    groups = [[prod.create_batch(wl) for _ in range(fuse)] for _ in range(n_groups)]
+    streams = [torch.cuda.Stream(device=local_rank) for _ in range(n_groups)]
+    batches = [b for g in groups for b in g]
     batch = batches[0]
 
     def barrier():
@@ -76,35 +79,46 @@ def main():
     import ctypes as C
     from era_zk_evm_amd import shard  # noqa: F401  (final_reduce is exercised by tests; the bench keeps the raw collective)
 
-    # final exchange: all-gather of the per-instance queue digests over RCCL, once per step
-    digests = [torch.zeros((args.instances, 3, 4), dtype=torch.int64, device="cuda") for _ in range(n_slots)]
-    gathered = [torch.zeros((world * args.instances, 3, 4), dtype=torch.int64, device="cuda") if world > 1 else None for _ in range(n_slots)]
+    # final exchange: all-gather of the per-instance queue digests over RCCL, once per fused group
+    digests = [torch.zeros((fuse, args.instances, 3, 4), dtype=torch.int64, device="cuda") for _ in range(n_groups)]
+    gathered = [torch.zeros((world * fuse, args.instances, 3, 4), dtype=torch.int64, device="cuda") if world > 1 else None for _ in range(n_groups)]
+    digest_bytes = args.instances * 3 * 4 * 8
 
-    def step(i):
-        k = i % n_slots
-        b, stream = batches[k], streams[k]
+    def launch(g, n):
+        """n <= fuse steps (batches) in one fused launch sequence on group g's stream"""
+        stream = streams[g]
         sptr = stream.cuda_stream
-        # reset -> cycle kernel -> commitment kernels: one hipGraph replay per step (captured on the slot's first step)
-        prod.call("batch_step", b.h, C.c_uint32(wl.n_cycles), C.c_uint32(args.commit_mask), C.c_void_p(sptr))
+        prod.step_many(groups[g][:n], wl.n_cycles, args.commit_mask, sptr)
         if args.commit_mask and world > 1:
-            prod.call("batch_copy_commitments", b.h, C.c_void_p(digests[k].data_ptr()), C.c_void_p(sptr))
+            for j, b in enumerate(groups[g][:n]):
+                prod.call("batch_copy_commitments", b.h, C.c_void_p(digests[g].data_ptr() + j * digest_bytes), C.c_void_p(sptr))
             with torch.cuda.stream(stream):
-                dist.all_gather_into_tensor(gathered[k], digests[k])
+                dist.all_gather_into_tensor(gathered[g], digests[g])
 
-    for i in range(max(args.warmup, 2 * n_slots)):  # every slot: one eager + capture step, one replayed step
-        step(i)
+    def run_steps(k):
+        g = 0
+        while k > 0:
+            n = min(fuse, k)
+            launch(g % n_groups, n)
+            g += 1
+            k -= n
+        return g
+
+    run_steps(max(args.warmup, fuse * n_groups))  # untimed: every group at least once
     for b in batches:
         b.sync()
     # timed region: exactly K steps
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    n_launches = run_steps(args.steps)
     t_enq = time.perf_counter() - t0  # host time spent enqueueing (launch-bound check)
-    for b in batches:
-        b.sync()  # per slot: one host sync; per-run HIP event pairs give the kernel's own mean duration
+    for st_ in streams:
+        st_.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    leaders = [g[0] for g in groups]
+    for b in leaders:
+        b.sync()  # HIP event pairs around the cycle-kernel launches give the kernel's own mean duration
     st = batch.stats()
     cycles_per_step = int(st["cycles"])
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -123,9 +137,11 @@ def main():
         n_log = float(st["log_queries"]) / max(1, cycles_per_step)
         heap_words = 0.9 if args.cfg == 2 else 0.0
         b_cycle = 8 + 512 + 48 * n_mem + 128 * n_log + 32 * heap_words
-        k_ms = sum(float(b.stats()["kernel_ms"]) for b in batches) / len(batches)  # mean duration of one launch (HIP events on its stream)
-        achieved = b_cycle * cycles_per_step / (k_ms * 1e-3) / 1e9
-        traffic = measured_traffic(args)
+        # mean duration of one cycle-kernel launch (HIP events on its stream) and the cycles that launch processed
+        k_ms = sum(float(b.stats()["kernel_ms"]) for b in leaders) / len(leaders)
+        batches_per_launch = min(fuse, args.steps)
+        achieved = b_cycle * cycles_per_step * batches_per_launch / (k_ms * 1e-3) / 1e9
+        traffic = measured_traffic(args, batches_per_launch)
         out = {
             "metric": "witnessed VM cycles/sec (1M-cycle synthetic batch)",
             "value": value, "unit": "cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -133,11 +149,11 @@ def main():
             "dtype": "u256 (8 x u32 limbs)", "data": "synthetic",
             "config": {"workload": "cfg%d: %d instances x %d cycles per GPU (%s)" % (args.cfg, args.instances, args.cycles, wl.name),
                        "instances_per_gpu": args.instances, "cycles_per_instance": args.cycles, "lanes_per_wave": int(batch.limits["lanes_per_wave"][0]), "commit_mask": args.commit_mask,
-                       "pipelined_batch_slots": n_slots},
+                       "batches_per_fused_launch": batches_per_launch, "fused_groups_in_flight": n_groups, "cycle_kernel_launches": n_launches},
             "kernel_ms": k_ms, "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
-            "kernel_cycles_per_s": cycles_per_step / (k_ms * 1e-3),
+            "kernel_cycles_per_s": cycles_per_step * batches_per_launch / (k_ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "bytes_per_cycle": b_cycle, "launches_in_flight": n_slots,
+                         "bytes_per_cycle": b_cycle, "cycles_per_launch": cycles_per_step * batches_per_launch,
                          "chip_achieved": b_cycle * value / 1e9, "chip_frac": b_cycle * value / 1e9 / 8000.0},
         }
         if not args.no_cpu_baseline:
@@ -147,14 +163,19 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(args):
+def measured_traffic(args, batches_per_launch):
     """HBM bytes per launch of the cycle kernel from the rocprofv3 PMC passes committed under profiles/
-    (FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM). Only valid for the
+    (FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM): measured per
+    launch with `fused_batches` batches in it, scaled to this run's batches per launch.  Only valid for the
     default workload the profile was taken on; null otherwise."""
     path = os.path.join(ROOT, "profiles", "r01_traffic.json")
     if args.cfg != 2 or args.instances != 4096 or args.cycles != 256 or not os.path.exists(path):
         return None
-    return json.load(open(path)).get("hbm_bytes_per_launch")
+    j = json.load(open(path))
+    per_launch = j.get("hbm_bytes_per_launch")
+    if per_launch is None:
+        return None
+    return per_launch * batches_per_launch / float(j.get("fused_batches", 1))
 
 
 def cpu_baseline(isa, args):

@@ -230,6 +230,11 @@ class Backend:
     def create_batch(self, workload):
         return Batch(self, workload)
 
+    def step_many(self, batches, max_cycles, queue_mask=0, stream=None):
+        """zkw_batches_step: reset + run + commit of several batches with fused launches (one batch per grid row)."""
+        arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])
+        self.call("batches_step", arr, C.c_uint32(len(batches)), C.c_uint32(max_cycles), C.c_uint32(queue_mask), C.c_void_p(stream))
+
 
 def load_product():
     """libzkw.so — the HIP library. Raises if it has not been built; never falls back."""

@@ -151,7 +151,9 @@ ZD void gl_chain_step(const u64* rc, const u64 leaf[4], u64 tail[4], u64 index_p
 // ---------------------------------------------------------------------------------------------
 
 // one stream record per thread -> leaf[wave][pos] (4 x u64)
-__global__ void zkw_leaf_kernel(zkw_commit_params C) {
+__global__ void zkw_leaf_kernel(zkw_fused_table T) {
+  const zkw_commit_params ZKW_CONST_AS& C = *(const zkw_commit_params ZKW_CONST_AS*)T.p[blockIdx.z];
+  if (blockIdx.y >= C.n_waves) return;
   const u32 wave = blockIdx.y;
   u32 n = C.n_override;
   if (!n) n = C.cursors[wave * 4 + C.queue] < C.cap ? C.cursors[wave * 4 + C.queue] : C.cap;
@@ -205,11 +207,13 @@ __global__ void zkw_leaf_kernel(zkw_commit_params C) {
 // leader bumps the per-lane running count in LDS.  Records of cycles the instance did not complete
 // (failed cycles) are dropped through the stream directory: record p of lane l counts iff
 // p < dir[n_cycles[l]].
-__global__ void zkw_bucket_kernel(zkw_commit_params C) {
+__global__ void zkw_bucket_kernel(zkw_fused_table T) {
+  const zkw_commit_params ZKW_CONST_AS& C = *(const zkw_commit_params ZKW_CONST_AS*)T.p[blockIdx.y];
   __shared__ u32 s_count[ZKW_WAVE];
   __shared__ u32 s_limit[ZKW_WAVE];
   const u32 wave = blockIdx.x;
   const u32 tid = threadIdx.x;
+  if (wave >= C.n_waves) return;  // uniform per workgroup
   const u32 rec_bytes = C.queue == ZKW_QUEUE_MEMORY ? 48u : (C.queue == ZKW_QUEUE_LOG ? 128u : 256u);
   const uint8_t* base = (const uint8_t*)C.stream + (u64)wave * C.cap * rec_bytes;
   const u32 n = C.cursors[wave * 4 + C.queue] < C.cap ? C.cursors[wave * 4 + C.queue] : C.cap;
@@ -262,11 +266,12 @@ __global__ void zkw_bucket_kernel(zkw_commit_params C) {
 }
 
 // one instance per lane: sequential chain over its leaves
-__global__ void zkw_chain_kernel(zkw_commit_params C) {
+__global__ void zkw_chain_kernel(zkw_fused_table T) {
+  const zkw_commit_params ZKW_CONST_AS& C = *(const zkw_commit_params ZKW_CONST_AS*)T.p[blockIdx.y];
   const u32 wave = blockIdx.x;
   const u32 lane = threadIdx.x;
   const u32 inst = wave * C.L + lane;
-  if (lane >= C.L || inst >= C.n_instances) return;
+  if (wave >= C.n_waves || lane >= C.L || inst >= C.n_instances) return;
   const u32 cnt = C.counts[inst];
   const u32* idx = C.idx + (u64)inst * C.per_instance_cap;
   u64 tail[4] = {0, 0, 0, 0};
@@ -280,7 +285,8 @@ __global__ void zkw_chain_kernel(zkw_commit_params C) {
 }
 
 // blob digests: one blob per thread, chain over its word leaves (run once per upload)
-__global__ void zkw_blob_chain_kernel(zkw_commit_params C) {
+__global__ void zkw_blob_chain_kernel(zkw_fused_table T) {
+  const zkw_commit_params ZKW_CONST_AS& C = *(const zkw_commit_params ZKW_CONST_AS*)T.p[0];
   for (u32 b = blockIdx.x * blockDim.x + threadIdx.x; b < C.n_blobs; b += gridDim.x * blockDim.x) {
     const uint2 d = C.blob_dir[b];
     u64 tail[4] = {0, 0, 0, 0};
@@ -294,19 +300,19 @@ __global__ void zkw_blob_chain_kernel(zkw_commit_params C) {
   }
 }
 
-extern "C" hipError_t zkw_launch_commit(const zkw_commit_params* C, int stage, hipStream_t stream) {
-  const u32 wt = C->wave_threads;
+extern "C" hipError_t zkw_launch_commit(const zkw_fused_table* T, int stage, hipStream_t stream) {
+  const u32 wt = T->wave_threads;
   if (stage == ZKW_COMMIT_STAGE_LEAF) {
     const u32 threads = wt > 1 ? 256 : 1;
-    const u32 per_wave_blocks = (C->cap + threads - 1) / threads;
-    hipLaunchKernelGGL(zkw_leaf_kernel, dim3(per_wave_blocks < 64 ? (per_wave_blocks ? per_wave_blocks : 1) : 64, C->n_waves), dim3(threads), 0, stream, *C);
+    const u32 per_wave_blocks = (T->max_cap + threads - 1) / threads;
+    hipLaunchKernelGGL(zkw_leaf_kernel, dim3(per_wave_blocks < 64 ? (per_wave_blocks ? per_wave_blocks : 1) : 64, T->max_waves, T->n), dim3(threads), 0, stream, *T);
   } else if (stage == ZKW_COMMIT_STAGE_BUCKET) {
-    hipLaunchKernelGGL(zkw_bucket_kernel, dim3(C->n_waves), dim3(wt), 0, stream, *C);
+    hipLaunchKernelGGL(zkw_bucket_kernel, dim3(T->max_waves, T->n), dim3(wt), 0, stream, *T);
   } else if (stage == ZKW_COMMIT_STAGE_CHAIN) {
-    hipLaunchKernelGGL(zkw_chain_kernel, dim3(C->n_waves), dim3(wt), 0, stream, *C);
+    hipLaunchKernelGGL(zkw_chain_kernel, dim3(T->max_waves, T->n), dim3(wt), 0, stream, *T);
   } else {
     const u32 threads = wt > 1 ? 64 : 1;
-    hipLaunchKernelGGL(zkw_blob_chain_kernel, dim3((C->n_blobs + threads - 1) / threads), dim3(threads), 0, stream, *C);
+    hipLaunchKernelGGL(zkw_blob_chain_kernel, dim3((T->n_blobs + threads - 1) / threads), dim3(threads), 0, stream, *T);
   }
   return hipGetLastError();
 }

@@ -95,14 +95,23 @@ typedef struct zkw_dev_history {
   uint32_t page;
 } zkw_dev_history;
 
+/* The parameter block of a batch lives in device memory (written once at upload) and is read through the
+ * constant address space, so that its fields are scalar (s_load) loads exactly like kernel arguments while one
+ * launch can cover several batches (grid.y = batch).  The CPU emulation build of tests/emu has no address spaces. */
+#ifdef __HIP_DEVICE_COMPILE__
+#define ZKW_CONST_AS __attribute__((address_space(4)))
+#else
+#define ZKW_CONST_AS
+#endif
+#define ZKW_MAX_FUSED 32 /* batches per fused launch */
+
 /* kernel parameter block */
 typedef struct zkw_kparams {
   uint32_t n_instances;
   uint32_t L;          /* lanes per wave */
   uint32_t n_waves;
   uint32_t max_cycles; /* limits.max_cycles (record capacity per instance) */
-  uint32_t cycle_base; /* wave-cycle index of the first cycle of this run */
-  uint32_t run_cycles;
+  uint32_t reserved1[2];
   uint32_t F, D, S, H, A; /* max_far_frames, max_callstack_depth, stack/heap/aux words */
   uint32_t storage_slots, storage_journal;
   uint32_t cap_mem, cap_log, cap_aux; /* stream capacity per wave (records) */
@@ -110,7 +119,7 @@ typedef struct zkw_kparams {
   uint32_t wave_threads; /* hardware wave width (64 on gfx950; 1 in the CPU emulation build of tests/emu) */
   uint32_t waves_per_group; /* waves per workgroup (ZKW_WAVES_PER_GROUP; 1 in the emulation build) */
   uint32_t reserved0;
-  uint32_t debug_flags;  /* profiling ablations only (ZKW_DEBUG_FLAGS): 1 = no CycleRecord stores, 2 = no stream stores */
+  uint32_t reserved2;
   zkw_isa_consts consts;
   zkw_block_properties props;
   const uint2* isa;            /* [2048] packed */
@@ -137,8 +146,30 @@ typedef struct zkw_kparams {
   uint4* log_stream;           /* [n_waves][cap_log][8]                  */
   uint4* aux_stream;           /* [n_waves][cap_aux][16]                 */
   uint32_t* dir;               /* [n_waves][max_cycles + 1][4] (mem, log, aux cursors at cycle start) */
-  uint32_t* cursors;           /* [n_waves][4] persistent stream cursors */
+  uint32_t* cursors;           /* [n_waves][4] persistent stream cursors (mem, log, aux) + [3] = wave-cycles run since the reset */
 } zkw_kparams;
+#define ZKW_KP const zkw_kparams ZKW_CONST_AS&
+
+/* by-value arguments of one (possibly fused) launch of the cycle kernel: grid.y = batch */
+typedef struct zkw_launch_args {
+  const zkw_kparams* kp[ZKW_MAX_FUSED]; /* device copies of the parameter blocks */
+  uint32_t n_batches;
+  uint32_t run_cycles;
+  uint32_t debug_flags; /* profiling ablations / test hooks only (ZKW_DEBUG_FLAGS): 1 = no CycleRecord stores, 2 = no stream stores, 4 = one lane per group */
+  uint32_t max_waves, max_L, wave_threads, waves_per_group; /* launch geometry (host side of the launcher) */
+} zkw_launch_args;
+
+/* by-value argument of the reset / commitment kernels: device copies of per-batch parameter structs, one batch
+ * per grid.y (leaf kernel: grid.z) */
+typedef struct zkw_fused_table {
+  const void* p[ZKW_MAX_FUSED];
+  uint32_t n;
+  uint32_t max_waves;    /* launch geometry (host side of the launchers): max over the batches */
+  uint32_t max_cap;      /* leaf kernel: upper bound of records per wave */
+  uint32_t wave_threads;
+  uint32_t n_blobs;      /* blob-chain stage only */
+  uint32_t reserved[3];
+} zkw_fused_table;
 
 /* zkw_reset_kernel: working state := pristine images, one launch */
 typedef struct zkw_reset_params {

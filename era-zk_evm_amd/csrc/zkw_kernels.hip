@@ -100,6 +100,7 @@ struct Shared {
   uint4* regs;    // [30][L] register file, 16-byte chunks, lane-minor
   u32* krow;      // [34][L] Keccak rate block assembly rows (global memory)
   u32 L;
+  u32 debug_flags;
 };
 ZD uint4& sh_reg(Shared& sh, u32 chunk, u32 lane) { return sh.regs[chunk * sh.L + lane]; }
 
@@ -110,7 +111,7 @@ ZD u32 next_seq(Lane& s) {
 }
 
 // WT.add_memory_query (witness_trace/mod.rs:19) / payload of add_precompile_call_result (:43-50)
-ZD void emit_mem(const zkw_kparams& P, Shared& sh, Lane& s, u32 ts, u32 type, u32 page, u32 index, const u256& value, bool is_ptr, bool rw, u32 kind) {
+ZD void emit_mem(ZKW_KP P, Shared& sh, Lane& s, u32 ts, u32 type, u32 page, u32 index, const u256& value, bool is_ptr, bool rw, u32 kind) {
   const u32 pos = stream_alloc(sh.cursor + 0);
   const u32 seq = next_seq(s);
   s.n_mem++;
@@ -118,7 +119,7 @@ ZD void emit_mem(const zkw_kparams& P, Shared& sh, Lane& s, u32 ts, u32 type, u3
     lane_fail(s, ZKW_STATUS_LIMIT);
     return;
   }
-  if (P.debug_flags & 2u) return;
+  if (sh.debug_flags & 2u) return;
   const u32 meta = (type & ZKW_MQ_TYPE_MASK) | (is_ptr ? ZKW_MQ_IS_PTR : 0u) | (rw ? ZKW_MQ_RW : 0u) | (kind << ZKW_MQ_KIND_SHIFT);
   uint4* dst = P.mem_stream + ((u64)s.wave * P.cap_mem + pos) * 3;
   dst[0] = make_uint4(ts, page, index, s.lane | (seq << 8) | (meta << 16));
@@ -134,7 +135,7 @@ struct LogQ {  // LogQuery (log.rs:85-97)
 };
 
 // WT.add_log_query / WT.record_refund_for_query (witness_trace/mod.rs:22-33)
-ZD void emit_log(const zkw_kparams& P, Shared& sh, Lane& s, const LogQ& q, u32 kind) {
+ZD void emit_log(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q, u32 kind) {
   const u32 pos = stream_alloc(sh.cursor + 1);
   const u32 seq = next_seq(s);
   s.n_log++;
@@ -156,7 +157,7 @@ ZD void emit_log(const zkw_kparams& P, Shared& sh, Lane& s, const LogQ& q, u32 k
 }
 
 // aux events: header + up to 60 payload dwords
-ZD uint4* aux_alloc(const zkw_kparams& P, Shared& sh, Lane& s, u32 type, u32 flag, u32 a, u32 b, u32 c) {
+ZD uint4* aux_alloc(ZKW_KP P, Shared& sh, Lane& s, u32 type, u32 flag, u32 a, u32 b, u32 c) {
   const u32 pos = stream_alloc(sh.cursor + 2);
   const u32 seq = next_seq(s);
   s.n_aux++;
@@ -192,12 +193,12 @@ ZD void reg_write(Shared& sh, Lane& s, u32 idx, const u256& v, bool is_ptr) {
 // ---------------------------------------------------------------------------------------------
 // memory arenas — the device-side SimpleMemory (reference_impls/memory.rs:403-528)
 // ---------------------------------------------------------------------------------------------
-ZD u64 page_word_index(const zkw_kparams& P, const Lane& s, u32 slot, u32 words_per_page, u32 idx) {
+ZD u64 page_word_index(ZKW_KP P, const Lane& s, u32 slot, u32 words_per_page, u32 idx) {
   return (((u64)s.wave * P.F + slot) * words_per_page + idx) * P.L + s.lane;
 }
 
 // MemoryType::Stack read of the current frame (memory.rs:427-436)
-ZD u256 stack_read(const zkw_kparams& P, Lane& s, u32 idx, bool& is_ptr) {
+ZD u256 stack_read(ZKW_KP P, Lane& s, u32 idx, bool& is_ptr) {
   is_ptr = false;
   if (idx >= P.S) {
     lane_fail(s, ZKW_STATUS_LIMIT);
@@ -209,7 +210,7 @@ ZD u256 stack_read(const zkw_kparams& P, Lane& s, u32 idx, bool& is_ptr) {
   return u256_from_uint4(P.stack_vals[2 * w], P.stack_vals[2 * w + 1]);
 }
 // MemoryType::Stack write (memory.rs:413-425)
-ZD void stack_write(const zkw_kparams& P, Lane& s, u32 idx, const u256& v, bool is_ptr) {
+ZD void stack_write(ZKW_KP P, Lane& s, u32 idx, const u256& v, bool is_ptr) {
   if (idx >= P.S) {
     lane_fail(s, ZKW_STATUS_LIMIT);
     return;
@@ -228,7 +229,7 @@ ZD void stack_write(const zkw_kparams& P, Lane& s, u32 idx, const u256& v, bool 
 }
 
 // heap / aux heap of an arbitrary arena slot; `hwm` is that page's high-water mark
-ZD u256 heap_read_at(const zkw_kparams& P, Lane& s, bool is_aux, u32 slot, u32 hwm, u32 idx) {
+ZD u256 heap_read_at(ZKW_KP P, Lane& s, bool is_aux, u32 slot, u32 hwm, u32 idx) {
   const u32 words = is_aux ? P.A : P.H;
   if (idx >= hwm) {
     if (idx >= words) lane_fail(s, ZKW_STATUS_LIMIT);  // the reference would grow the page (memory.rs:464,468)
@@ -240,10 +241,10 @@ ZD u256 heap_read_at(const zkw_kparams& P, Lane& s, bool is_aux, u32 slot, u32 h
 }
 // MemoryType::Heap / AuxHeap of the current frame (memory.rs:439-473; the page number of the query
 // is only debug_assert'ed there, i.e. ignored in release builds)
-ZD u256 heap_read_cur(const zkw_kparams& P, Lane& s, bool is_aux, u32 idx) {
+ZD u256 heap_read_cur(ZKW_KP P, Lane& s, bool is_aux, u32 idx) {
   return heap_read_at(P, s, is_aux, s.slot, is_aux ? s.aux_hwm : s.heap_hwm, idx);
 }
-ZD void heap_write_cur(const zkw_kparams& P, Lane& s, bool is_aux, u32 idx, const u256& v) {
+ZD void heap_write_cur(ZKW_KP P, Lane& s, bool is_aux, u32 idx, const u256& v) {
   const u32 words = is_aux ? P.A : P.H;
   if (idx >= words) {
     lane_fail(s, ZKW_STATUS_LIMIT);
@@ -266,7 +267,7 @@ ZD void heap_write_cur(const zkw_kparams& P, Lane& s, bool is_aux, u32 idx, cons
 // MemoryType::FatPointer read (memory.rs:475-521): resolve the page to an arena slot.
 // Page 0 is Indirection::Empty; pages that never were a heap/aux page of a frame of this
 // instance are "unreachable memory" (the reference's expect() at :478-481).
-ZD u256 fat_ptr_read(const zkw_kparams& P, Lane& s, u32 page, u32 idx) {
+ZD u256 fat_ptr_read(ZKW_KP P, Lane& s, u32 page, u32 idx) {
   if (page == 0) return u256_zero();
   u32 slot, kind;
   bool found = false;
@@ -308,7 +309,7 @@ ZD u256 fat_ptr_read(const zkw_kparams& P, Lane& s, u32 page, u32 idx) {
 }
 
 // read_code_query (memory.rs:556-569) against the blob backing the current code page
-ZD u256 code_read(const zkw_kparams& P, const Lane& s, u32 idx) {
+ZD u256 code_read(ZKW_KP P, const Lane& s, u32 idx) {
   if (idx >= s.code_len) return u256_zero();
   const u64 w = (u64)s.code_off + idx;
   return u256_from_uint4(P.blob_words[2 * w], P.blob_words[2 * w + 1]);
@@ -317,25 +318,25 @@ ZD u256 code_read(const zkw_kparams& P, const Lane& s, u32 idx) {
 // ---------------------------------------------------------------------------------------------
 // callstack entries in HBM ([inst][depth] x 8 uint4)
 // ---------------------------------------------------------------------------------------------
-ZD uint4* entry_ptr(const zkw_kparams& P, const Lane& s, u32 depth) { return (uint4*)(P.callstack + ((u64)s.inst * (P.D + 1) + depth)); }
-ZD u32 entry_dword(const zkw_kparams& P, const Lane& s, u32 depth, u32 d) { return ((const u32*)entry_ptr(P, s, depth))[d]; }
+ZD uint4* entry_ptr(ZKW_KP P, const Lane& s, u32 depth) { return (uint4*)(P.callstack + ((u64)s.inst * (P.D + 1) + depth)); }
+ZD u32 entry_dword(ZKW_KP P, const Lane& s, u32 depth, u32 d) { return ((const u32*)entry_ptr(P, s, depth))[d]; }
 
 // write the hot fields of callstack.current back into its HBM entry
-ZD void frame_writeback(const zkw_kparams& P, const Lane& s) {
+ZD void frame_writeback(ZKW_KP P, const Lane& s) {
   u32* e = (u32*)entry_ptr(P, s, s.depth);
   e[E_SP_PC] = (s.sp & 0xffffu) | (s.pc << 16);
   e[E_ERGS] = s.ergs;
   e[E_HEAP_BOUND] = s.heap_bound;
   e[E_AUX_BOUND] = s.aux_bound;
 }
-ZD void hwm_writeback(const zkw_kparams& P, const Lane& s) {
+ZD void hwm_writeback(ZKW_KP P, const Lane& s) {
   zkw_dev_frame_meta* fm = P.frames + (u64)s.inst * P.F + s.slot;
   fm->stack_hwm = s.stack_hwm;
   fm->heap_hwm = s.heap_hwm;
   fm->aux_hwm = s.aux_hwm;
 }
 // load the hot fields of entry `s.depth` into the lane
-ZD void frame_load(const zkw_kparams& P, Lane& s) {
+ZD void frame_load(ZKW_KP P, Lane& s) {
   const u32* e = (const u32*)entry_ptr(P, s, s.depth);
   s.base_page = e[E_BASE_PAGE];
   s.code_page = e[E_CODE_PAGE];
@@ -373,7 +374,7 @@ ZD u32 storage_hash(u32 shard, const u32 addr[5], const u256& key) {
   return h;
 }
 // returns the entry index of (shard,address,key), inserting an empty (value 0) entry when absent
-ZD u32 storage_find(const zkw_kparams& P, Lane& s, u32 shard, const u32 addr[5], const u256& key) {
+ZD u32 storage_find(ZKW_KP P, Lane& s, u32 shard, const u32 addr[5], const u256& key) {
   const u32 mask = P.storage_slots - 1;
   u32 i = storage_hash(shard, addr, key) & mask;
   zkw_dev_storage_entry* tab = P.storage + (u64)s.inst * P.storage_slots;
@@ -402,7 +403,7 @@ ZD u32 storage_find(const zkw_kparams& P, Lane& s, u32 shard, const u32 addr[5],
   return 0;
 }
 // Storage::execute_partial_query (storage.rs:88-139) + access_storage's read convention (helpers.rs:145-148)
-ZD void access_storage(const zkw_kparams& P, Shared& sh, Lane& s, LogQ& q) {
+ZD void access_storage(ZKW_KP P, Shared& sh, Lane& s, LogQ& q) {
   const u32 slot = storage_find(P, s, q.shard_id, q.address, q.key);
   if (!lane_ok(s)) return;
   zkw_dev_storage_entry* e = P.storage + (u64)s.inst * P.storage_slots + slot;
@@ -430,7 +431,7 @@ ZD void access_storage(const zkw_kparams& P, Shared& sh, Lane& s, LogQ& q) {
   emit_log(P, sh, s, q, ZKW_LQ_LOG);
 }
 // Storage::finish_frame(panicked) (storage.rs:144-186): undo this frame's writes newest-first
-ZD void storage_finish_frame(const zkw_kparams& P, Lane& s, u32 mark, bool panicked) {
+ZD void storage_finish_frame(ZKW_KP P, Lane& s, u32 mark, bool panicked) {
   if (!panicked) return;
   while (s.journal_len > mark) {
     s.journal_len--;
@@ -444,7 +445,7 @@ ZD void storage_finish_frame(const zkw_kparams& P, Lane& s, u32 mark, bool panic
 // ---------------------------------------------------------------------------------------------
 // helpers shared by opcodes
 // ---------------------------------------------------------------------------------------------
-ZD u32 clip16(const zkw_kparams& P, const u256& v) {  // AllowedPcOrImm::from_u64_clipped(value.low_u64())
+ZD u32 clip16(ZKW_KP P, const u256& v) {  // AllowedPcOrImm::from_u64_clipped(value.low_u64())
   if (P.consts.clip_mode == 0) return (v.w[1] != 0 || v.w[0] > 0xffffu) ? 0xffffu : v.w[0];
   return v.w[0] & 0xffffu;
 }
@@ -455,7 +456,7 @@ struct Operand {
 };
 
 // MemOpsProcessor::compute_addresses_and_select_operands (mem_ops.rs:14-125)
-ZD Operand compute_address(const zkw_kparams& P, Lane& s, u32& sp, const u256& reg_value, u32 imm, u32 mode, bool is_write) {
+ZD Operand compute_address(ZKW_KP P, Lane& s, u32& sp, const u256& reg_value, u32 imm, u32 mode, bool is_write) {
   Operand o;
   o.has_loc = false;
   o.type = ZKW_MEM_STACK;
@@ -487,7 +488,7 @@ ZD Operand compute_address(const zkw_kparams& P, Lane& s, u32& sp, const u256& r
 }
 
 // perform_dst0_update (helpers.rs:266-283)
-ZD void dst0_update(const zkw_kparams& P, Shared& sh, Lane& s, const Operand& dst0, u32 dst0_idx, const u256& v, bool is_ptr) {
+ZD void dst0_update(ZKW_KP P, Shared& sh, Lane& s, const Operand& dst0, u32 dst0_idx, const u256& v, bool is_ptr) {
   if (dst0.has_loc) {
     stack_write(P, s, dst0.index, v, is_ptr);
     emit_mem(P, sh, s, s.timestamp + 3, ZKW_MEM_STACK, dst0.page, dst0.index, v, is_ptr, true, 0);
@@ -524,7 +525,7 @@ ZD u32 fat_ptr_validate(const FatPtr& p, bool fresh) {
 ZD u32 forward_type(u32 b) { return b == 1u ? 1u : (b == 2u ? 2u : 0u); }  // 0 UseHeap, 1 ForwardFatPointer, 2 UseAuxHeap
 
 // build a callstack entry image (32 dwords) from the lane's current frame: cold fields come from HBM
-ZD void entry_image_current(const zkw_kparams& P, const Lane& s, u32 img[32]) {
+ZD void entry_image_current(ZKW_KP P, const Lane& s, u32 img[32]) {
   const uint4* e = entry_ptr(P, s, s.depth);
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -539,7 +540,7 @@ ZD void entry_image_current(const zkw_kparams& P, const Lane& s, u32 img[32]) {
 
 // VmState::start_frame (helpers.rs:225-246): Storage/EventSink::start_frame are a journal mark here
 // (the event sink is replayed on the host); emits WT.start_new_execution_context and pushes.
-ZD void start_frame(const zkw_kparams& P, Shared& sh, Lane& s, const u32 prev[32], u32 next[32], bool far) {
+ZD void start_frame(ZKW_KP P, Shared& sh, Lane& s, const u32 prev[32], u32 next[32], bool far) {
   next[E_JOURNAL_MARK] = s.journal_len;
   uint4* a = aux_alloc(P, sh, s, ZKW_AUX_FRAME_START, far ? 1u : 0u, 0, 0, 0);
   if (a) {
@@ -583,7 +584,7 @@ struct Pre {  // PreState (cycle.rs:8-14)
 };
 
 // near_call.rs:6-68
-ZD void op_near_call(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+ZD void op_near_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
   s.flags &= FLAG_PENDING;  // reset_flags
   const u32 abi_ergs = ps.src0.w[0];
   const u32 remaining = s.ergs;
@@ -608,7 +609,7 @@ ZD void op_near_call(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d
 }
 
 // context.rs:6-111
-ZD void op_context(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+ZD void op_context(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
   s.pc = ps.new_pc;
   const u32 v = ZKW_ATTR_VARIANT(d.attr);
   u256 value = u256_zero();
@@ -655,7 +656,7 @@ ZD void op_context(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d, 
 }
 
 // ptr.rs:6-194
-ZD void op_ptr(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+ZD void op_ptr(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
   s.pc = ps.new_pc;
   const u32 v = ZKW_ATTR_VARIANT(d.attr);
   if (!ps.src0_ptr || ps.src1_ptr) {  // :35-45
@@ -700,7 +701,7 @@ ZD void op_ptr(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d, cons
 }
 
 // uma.rs:26-425
-ZD void op_uma(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+ZD void op_uma(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
   const u32 v = ZKW_ATTR_VARIANT(d.attr);
   s.pc = ps.new_pc;
   const bool increment = ZKW_ATTR_FLAGS(d.attr) & 1u;
@@ -814,16 +815,16 @@ ZD void op_uma(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d, cons
 }
 
 // log.rs:11-330 (precompile calls: see zkw_precompiles below)
-ZD void call_precompile(const zkw_kparams& P, Shared& sh, Lane& s, const LogQ& q);
+ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q);
 
-ZD void op_log(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+ZD void op_log(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
   const u32 v = ZKW_ATTR_VARIANT(d.attr);
   s.pc = ps.new_pc;
   const bool is_first = ZKW_ATTR_FLAGS(d.attr) & 1u;
   const u32* e = (const u32*)entry_ptr(P, s, s.depth);
   const u32 shard = e[E_SHARDS] & 0xffu;
   const u32 ergs_available = s.ergs;
-  const zkw_isa_consts& K = P.consts;
+  const zkw_isa_consts ZKW_CONST_AS& K = P.consts;
   LogQ q;
   q.timestamp = s.timestamp + 1;
   q.tx_number = s.tx_number;
@@ -908,8 +909,8 @@ ZD void versioned_hash(const u256& h, bool& ok, u32& marker, u32& len_words, u25
 }
 
 // far_call.rs:35-613
-ZD void op_far_call(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
-  const zkw_isa_consts& K = P.consts;
+ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+  const zkw_isa_consts ZKW_CONST_AS& K = P.consts;
   const u32 variant = ZKW_ATTR_VARIANT(d.attr);
   s.flags &= FLAG_PENDING;  // :69
   const bool is_static_call = ZKW_ATTR_FLAGS(d.attr) & 1u;
@@ -1185,8 +1186,8 @@ ZD void op_far_call(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d,
 }
 
 // ret.rs:9-265
-ZD void op_ret(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
-  const zkw_isa_consts& K = P.consts;
+ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+  const zkw_isa_consts ZKW_CONST_AS& K = P.consts;
   u32 variant = ZKW_ATTR_VARIANT(d.attr);
   s.flags &= FLAG_PENDING;  // :27
   u256 src0 = ps.src0;
@@ -1288,7 +1289,7 @@ ZD void op_ret(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d, cons
 #include "zkw_precompiles.hip.h"
 
 // helpers.rs:196-223 + DefaultPrecompilesProcessor dispatch on the low 16 address bits
-ZD void call_precompile(const zkw_kparams& P, Shared& sh, Lane& s, const LogQ& q) {
+ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   emit_log(P, sh, s, q, ZKW_LQ_LOG);
   const u32 addr_low = q.address[0] & 0xffffu;
   if (addr_low == P.consts.keccak_precompile_address) precompile_keccak256(P, sh, s, q);
@@ -1302,8 +1303,7 @@ ZD void call_precompile(const zkw_kparams& P, Shared& sh, Lane& s, const LogQ& q
 // real out-of-line call (noinline) shrinks the kernel from 100 KB to 44 KB but the caller-saved traffic
 // around the call costs more than it saves (1.03 vs 0.98 ms per 1M cycles), so the wrapper is inlined.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void zkw_rare_op(const zkw_kparams* Pg, Shared sh, Lane* lane, const Decoded* dp, const Pre* pp) {
-  const zkw_kparams& P = *Pg;
+__device__ __forceinline__ void zkw_rare_op(ZKW_KP P, Shared sh, Lane* lane, const Decoded* dp, const Pre* pp) {
   Lane s = *lane;
   const Decoded d = *dp;
   const Pre ps = *pp;
@@ -1322,7 +1322,7 @@ __device__ __forceinline__ void zkw_rare_op(const zkw_kparams* Pg, Shared sh, La
 // ---------------------------------------------------------------------------------------------
 // read_and_decode exceptions (cycle.rs:142-184) and condition resolution (:193-209), branch-free
 // ---------------------------------------------------------------------------------------------
-ZD bool decode_exception(const zkw_kparams& P, const Lane& s, u32 attr, u32 price) {
+ZD bool decode_exception(ZKW_KP P, const Lane& s, u32 attr, u32 price) {
   const u32 props = ZKW_ATTR_PROPS(attr);
   return ((props & ZKW_PROP_EXPLICIT_PANIC) != 0) | (s.ergs < price) | (((props & ZKW_PROP_KERNEL_ONLY) != 0) & (s.is_kernel == 0)) |
          (((props & ZKW_PROP_STATIC_OK) == 0) & (s.is_static != 0)) | (s.depth == P.consts.vm_max_stack_depth);
@@ -1339,7 +1339,7 @@ ZD bool condition_resolved(u32 cond, u32 flags) {
 // depends on the opcode, the addressing modes or the register indices is a scalar branch; only the data
 // path (256-bit values, sp, ergs, memory addresses) is per lane.
 // ---------------------------------------------------------------------------------------------
-ZD void exec_decoded(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d) {
+ZD void exec_decoded(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d) {
   const u32 opcode = ZKW_ATTR_OPCODE(d.attr);
   const u32 props = ZKW_ATTR_PROPS(d.attr);
   const bool set_flags = ZKW_ATTR_FLAGS(d.attr) & 1u;
@@ -1477,7 +1477,7 @@ ZD void exec_decoded(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d
       case ZKW_OP_FAR_CALL:
       case ZKW_OP_RET: {
         Lane tmp = s;
-        zkw_rare_op(&P, sh, &tmp, &d, &ps);
+        zkw_rare_op(P, sh, &tmp, &d, &ps);
         s = tmp;
         break;
       }
@@ -1490,8 +1490,9 @@ ZD void exec_decoded(const zkw_kparams& P, Shared& sh, Lane& s, const Decoded& d
 // =============================================================================================
 // the cycle kernel
 // =============================================================================================
-__global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kernel(zkw_kparams P) {
+__global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kernel(zkw_launch_args A) {
   extern __shared__ uint4 zkw_lds[];
+  ZKW_KP P = *(const zkw_kparams ZKW_CONST_AS*)A.kp[blockIdx.y];
   // one wave = one independent group of L VM instances; ZKW_WAVES_PER_GROUP waves per workgroup (one per SIMD)
   // share the ISA table so that four of them fit the 160 KB of a CU
   const u32 tid = threadIdx.x % P.wave_threads;
@@ -1499,6 +1500,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   const u32 wave = blockIdx.x * P.waves_per_group + wib;
   Shared sh;
   sh.L = P.L;
+  sh.debug_flags = A.debug_flags;
   sh.isa = (uint2*)zkw_lds;                                                        // 16 KB
   sh.cursor = (u32*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + wib * (1 + ZKW_REG_CHUNKS * P.L));  // 16 B
   sh.regs = (uint4*)sh.cursor + 1;                                                  // 30 * L * 16 B
@@ -1513,6 +1515,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   if (wave >= P.n_waves) return;  // tail workgroup: no further workgroup-level barrier below
   for (u32 i = tid; i < 4; i += P.wave_threads) sh.cursor[i] = P.cursors[wave * 4 + i];
   zkw_wave_lds_fence();
+  const u32 cycle_base = P.cursors[wave * 4 + 3];  // wave-cycles run since the reset (records / directory index)
 
   const u32 inst = wave * P.L + tid;
   const bool exists = tid < P.L && inst < P.n_instances;
@@ -1543,9 +1546,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   }
 
   u32 k = 0;
-  for (; k < P.run_cycles; k++) {
+  for (; k < A.run_cycles; k++) {
     // directory: stream cursors at the start of wave-cycle (cycle_base + k)
-    for (u32 i = tid; i < 4; i += P.wave_threads) P.dir[((u64)wave * (P.max_cycles + 1) + P.cycle_base + k) * 4 + i] = ((volatile u32*)sh.cursor)[i];
+    for (u32 i = tid; i < 4; i += P.wave_threads) P.dir[((u64)wave * (P.max_cycles + 1) + cycle_base + k) * 4 + i] = ((volatile u32*)sh.cursor)[i];
     bool active = exists && s.status == ZKW_STATUS_RUNNING;
     if (active && s.depth == 0) {  // execution_has_ended() (mod.rs:96-98): callers stop cycling here
       s.status = ZKW_STATUS_ENDED;
@@ -1597,7 +1600,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
         // only lanes that are still waiting: a lane that already ran a genuine `nop` must not join the group of lanes
         // that were masked into the nop encoding later in the same cycle
         bool mine = ((todo >> (threadIdx.x & (ZKW_WAVE - 1))) & 1ull) != 0 && enc_lo == u_lo && enc_hi == u_hi && charged == u_charged;
-        if (P.debug_flags & 4u) mine = (threadIdx.x & (ZKW_WAVE - 1)) == leader;  // test hook: one lane per group
+        if (A.debug_flags & 4u) mine = (threadIdx.x & (ZKW_WAVE - 1)) == leader;  // test hook: one lane per group
         const uint2 e_raw = sh.isa[u_lo & (ZKW_ISA_TABLE_SIZE - 1)];
         const u32 u_attr = (u32)__builtin_amdgcn_readfirstlane((int)e_raw.x);
         const u32 u_price = (u32)__builtin_amdgcn_readfirstlane((int)e_raw.y);
@@ -1642,10 +1645,10 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
           }
         }
       }
-      if (lane_ok(s) && (P.debug_flags & 1u)) s.n_cycles++;
-      if (lane_ok(s) && !(P.debug_flags & 1u)) {
+      if (lane_ok(s) && (A.debug_flags & 1u)) s.n_cycles++;
+      if (lane_ok(s) && !(A.debug_flags & 1u)) {
         // CycleRecord: 30 register chunks straight from LDS + 2 tail chunks, coalesced across lanes
-        uint4* rec = P.rec + ((u64)wave * P.max_cycles + (P.cycle_base + k)) * ZKW_REC_CHUNKS * P.L;
+        uint4* rec = P.rec + ((u64)wave * P.max_cycles + (cycle_base + k)) * ZKW_REC_CHUNKS * P.L;
 #pragma unroll
         for (int g = 0; g < ZKW_REG_CHUNKS; g += 5) {  // 5 LDS reads in flight per wait, then 5 coalesced stores
           const uint4 t0 = sh_reg(sh, g, tid), t1 = sh_reg(sh, g + 1, tid), t2 = sh_reg(sh, g + 2, tid), t3 = sh_reg(sh, g + 3, tid), t4 = sh_reg(sh, g + 4, tid);
@@ -1665,8 +1668,8 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   // final directory entry
   for (u32 i = tid; i < 4; i += P.wave_threads) {
     const u32 cur = ((volatile u32*)sh.cursor)[i];
-    P.dir[((u64)wave * (P.max_cycles + 1) + P.cycle_base + k) * 4 + i] = cur;
-    P.cursors[wave * 4 + i] = cur;
+    P.dir[((u64)wave * (P.max_cycles + 1) + cycle_base + k) * 4 + i] = cur;
+    P.cursors[wave * 4 + i] = i == 3 ? cycle_base + k : cur;
   }
   if (exists) {
     if (s.status == ZKW_STATUS_RUNNING && s.depth == 0) s.status = ZKW_STATUS_ENDED;
@@ -1693,7 +1696,8 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
 
 // working state := pristine images (register file, scalars, callstack, frame meta, storage table, heap
 // image) and stream cursors := 0 — one launch instead of seven copies per reset
-__global__ void zkw_reset_kernel(zkw_reset_params R) {
+__global__ void zkw_reset_kernel(zkw_fused_table T) {
+  const zkw_reset_params ZKW_CONST_AS& R = *(const zkw_reset_params ZKW_CONST_AS*)T.p[blockIdx.y];
   const u32 stride = gridDim.x * blockDim.x;
   const u32 t0 = blockIdx.x * blockDim.x + threadIdx.x;
 #pragma unroll 1
@@ -1707,9 +1711,12 @@ __global__ void zkw_reset_kernel(zkw_reset_params R) {
   for (u32 i = t0; i < R.n_waves * 4; i += stride) R.cursors[i] = 0;
 }
 
-extern "C" hipError_t zkw_launch_reset_kernel(const zkw_reset_params* R, uint32_t wave_threads, hipStream_t stream) {
-  const u32 threads = wave_threads > 1 ? 256 : 1;
-  hipLaunchKernelGGL(zkw_reset_kernel, dim3(wave_threads > 1 ? 512 : 1), dim3(threads), 0, stream, *R);
+extern "C" hipError_t zkw_launch_reset_kernel(const zkw_fused_table* T, hipStream_t stream) {
+  const u32 threads = T->wave_threads > 1 ? 256 : 1;
+  // ~2 workgroups per CU in total, however many batches share the launch
+  u32 blocks = T->wave_threads > 1 ? (512 + T->n - 1) / T->n : 1;
+  if (blocks < 32 && T->wave_threads > 1) blocks = 32;
+  hipLaunchKernelGGL(zkw_reset_kernel, dim3(blocks, T->n), dim3(threads), 0, stream, *T);
   return hipGetLastError();
 }
 
@@ -1717,15 +1724,15 @@ extern "C" hipError_t zkw_launch_reset_kernel(const zkw_reset_params* R, uint32_
 extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_group) { return ZKW_ISA_TABLE_SIZE * 8 + waves_per_group * (16 + L * ZKW_REG_CHUNKS * 16); }
 
 // host-callable launcher (keeps <<<>>> out of the runtime)
-extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_kparams* P, hipStream_t stream) {
-  const u32 g = P->waves_per_group;
+extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_launch_args* A, hipStream_t stream) {
+  const u32 g = A->waves_per_group;
   static uint32_t lds_opt_in = 0;  // dynamic LDS above the 64 KB default needs an explicit opt-in, once per size
-  const uint32_t lds = zkw_cycle_kernel_lds_bytes(P->L, g);
+  const uint32_t lds = zkw_cycle_kernel_lds_bytes(A->max_L, g);
   if (lds > lds_opt_in) {
     const hipError_t e = hipFuncSetAttribute((const void*)zkw_cycle_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     lds_opt_in = lds;
   }
-  hipLaunchKernelGGL(zkw_cycle_kernel, dim3((P->n_waves + g - 1) / g), dim3(P->wave_threads * g), zkw_cycle_kernel_lds_bytes(P->L, g), stream, *P);
+  hipLaunchKernelGGL(zkw_cycle_kernel, dim3((A->max_waves + g - 1) / g, A->n_batches), dim3(A->wave_threads * g), lds, stream, *A);
   return hipGetLastError();
 }

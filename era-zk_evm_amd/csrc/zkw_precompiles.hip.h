@@ -78,7 +78,7 @@ ZD void keccak_absorb_block(Shared& sh, u32 lane, u64 st[25]) {
 // keccak256_rounds_function: input = `input_memory_length` bytes at byte offset `input_memory_offset`
 // of page `memory_page_to_read`; output = one big-endian word at word `output_memory_offset` of
 // `memory_page_to_write` (reference test src/testing/tests/precompiles/keccak256.rs:99-139).
-ZD void precompile_keccak256(const zkw_kparams& P, Shared& sh, Lane& s, const LogQ& q) {
+ZD void precompile_keccak256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   const u32 in_off = q.key.w[0], in_len = q.key.w[1], out_off = q.key.w[2];
   const u32 page_r = q.key.w[4], page_w = q.key.w[5];
   u64 st[25];
@@ -129,7 +129,7 @@ ZD u32 zk_rotr32(u32 x, int n) { return (x >> n) | (x << (32 - n)); }
 
 // sha256_rounds_function: `precompile_interpreted_data` rounds, two words per round from word offset
 // `input_memory_offset` (the caller supplies the padded message), digest at `output_memory_offset`.
-ZD void precompile_sha256(const zkw_kparams& P, Shared& sh, Lane& s, const LogQ& q) {
+ZD void precompile_sha256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   const u32 in_word = q.key.w[0], out_off = q.key.w[2];
   const u32 page_r = q.key.w[4], page_w = q.key.w[5];
   const u32 rounds = q.key.w[6];  // low half of the u64; > 2^32 rounds cannot be paid for

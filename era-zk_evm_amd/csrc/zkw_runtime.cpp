@@ -21,10 +21,10 @@
 #include "zkw_commit.h"
 #include "zkw_device.h"
 
-extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_kparams* P, hipStream_t stream);
+extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_launch_args* A, hipStream_t stream);
 extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_group);
-extern "C" hipError_t zkw_launch_reset_kernel(const zkw_reset_params* R, uint32_t wave_threads, hipStream_t stream);
-extern "C" hipError_t zkw_launch_commit(const zkw_commit_params* C, int stage, hipStream_t stream);
+extern "C" hipError_t zkw_launch_reset_kernel(const zkw_fused_table* T, hipStream_t stream);
+extern "C" hipError_t zkw_launch_commit(const zkw_fused_table* T, int stage, hipStream_t stream);
 
 static_assert(sizeof(zkw_callstack_entry) == 112, "abi");
 static_assert(sizeof(zkw_vm_local_state) == 680, "abi");
@@ -146,7 +146,10 @@ struct zkw_batch {
   std::vector<uint32_t> h_cursors;
   std::map<uint32_t, std::unique_ptr<WaveTrace>> wave_cache;
   float kernel_ms = 0;
-  zkw_kparams kp;
+  zkw_kparams kp;            // host copy of the parameter block
+  DevBuf<zkw_kparams> d_kp;  // device copy the kernels read (constant address space)
+  DevBuf<zkw_reset_params> d_reset_params;    // [1]
+  DevBuf<zkw_commit_params> d_commit_params;  // [ZKW_QUEUE_COUNT] + [1] for the blob digests of the upload
 };
 
 static uint32_t pow2_ceil(uint32_t v) {
@@ -272,7 +275,7 @@ void zkw_batch_destroy(zkw_batch* b) {
   b->d_regs.release(); b->d_scalars.release(); b->d_callstack.release(); b->d_frames.release(); b->d_storage.release(); b->d_journal.release();
   b->d_history.release(); b->d_stack_vals.release(); b->d_heap.release(); b->d_aux.release(); b->d_stack_ptrs.release(); b->d_blob_words.release();
   b->d_blob_dir.release(); b->d_preimages.release(); b->d_rec.release(); b->d_mem.release(); b->d_log.release(); b->d_auxs.release();
-  b->d_dir.release(); b->d_cursors.release(); b->d_krow.release(); b->d_commit.release(); b->d_rc.release(); b->d_blob_digests.release(); b->d_leaves.release();
+  b->d_dir.release(); b->d_cursors.release(); b->d_krow.release(); b->d_kp.release(); b->d_reset_params.release(); b->d_commit_params.release(); b->d_commit.release(); b->d_rc.release(); b->d_blob_digests.release(); b->d_leaves.release();
   b->d_idx.release(); b->d_counts.release();
   if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
   if (b->graph) (void)hipGraphDestroy(b->graph);
@@ -357,6 +360,12 @@ int zkw_batch_set_storage(zkw_batch* b, uint32_t instance, const zkw_storage_slo
 int zkw_batch_set_block_properties(zkw_batch* b, const zkw_block_properties* p) {
   if (!b || !p) return ZKW_ERR_INVALID;
   b->props = *p;
+  if (b->uploaded) {  // keep the device parameter block current (takes effect for runs enqueued after this call)
+    zkw_ctx* c = b->ctx;
+    b->kp.props = *p;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpy(&b->d_kp.p->props, p, sizeof *p, hipMemcpyHostToDevice));
+  }
   return ZKW_OK;
 }
 
@@ -433,8 +442,13 @@ int zkw_batch_upload(zkw_batch* b) {
     C.n_waves = 1; C.wave_threads = (uint32_t)c->wave_width; C.queue = ZKW_QUEUE_CODE_WORDS; C.cap = (uint32_t)total_words;
     C.n_override = (uint32_t)total_words; C.n_blobs = (uint32_t)b->blobs.size(); C.rc = b->d_rc.p; C.stream = b->d_blob_words.p;
     C.blob_dir = b->d_blob_dir.p; C.leaves = word_leaves.p; C.out = b->d_blob_digests.p;
-    if (total_words) HIP_TRY(c, zkw_launch_commit(&C, ZKW_COMMIT_STAGE_LEAF, nullptr));
-    HIP_TRY(c, zkw_launch_commit(&C, ZKW_COMMIT_STAGE_BLOB_CHAIN, nullptr));
+    if (!b->d_commit_params.p) HIP_TRY(c, b->d_commit_params.alloc(ZKW_QUEUE_COUNT + 1));
+    HIP_TRY(c, hipMemcpy(b->d_commit_params.p + ZKW_QUEUE_COUNT, &C, sizeof C, hipMemcpyHostToDevice));
+    zkw_fused_table T;
+    std::memset(&T, 0, sizeof T);
+    T.p[0] = b->d_commit_params.p + ZKW_QUEUE_COUNT; T.n = 1; T.max_waves = 1; T.max_cap = C.cap; T.wave_threads = C.wave_threads; T.n_blobs = C.n_blobs;
+    if (total_words) HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_LEAF, nullptr));
+    HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_BLOB_CHAIN, nullptr));
     HIP_TRY(c, hipStreamSynchronize(nullptr));
     word_leaves.release();
   }
@@ -612,69 +626,175 @@ int zkw_batch_upload(zkw_batch* b) {
   P.blob_words = b->d_blob_words.p; P.blob_dir = b->d_blob_dir.p; P.preimages = b->d_preimages.p;
   P.rec = b->d_rec.p; P.mem_stream = b->d_mem.p; P.log_stream = b->d_log.p; P.aux_stream = b->d_auxs.p;
   P.dir = b->d_dir.p; P.cursors = b->d_cursors.p;
+  P.props = b->props;
+  HIP_TRY(c, ensure(b->d_kp, 1));
+  HIP_TRY(c, hipMemcpy(b->d_kp.p, &P, sizeof P, hipMemcpyHostToDevice));
+  {  // parameter blocks of the reset and commitment kernels (device copies, constant per upload)
+    zkw_reset_params R;
+    std::memset(&R, 0, sizeof R);
+    R.dst[0] = b->d_regs.p; R.src[0] = b->d_regs0.p; R.n16[0] = (uint32_t)(b->d_regs0.bytes() / 16);
+    R.dst[1] = (uint4*)b->d_scalars.p; R.src[1] = (const uint4*)b->d_scalars0.p; R.n16[1] = (uint32_t)(b->d_scalars0.bytes() / 16);
+    R.dst[2] = (uint4*)b->d_callstack.p; R.src[2] = (const uint4*)b->d_callstack0.p; R.n16[2] = (uint32_t)(b->d_callstack0.bytes() / 16);
+    R.dst[3] = (uint4*)b->d_frames.p; R.src[3] = (const uint4*)b->d_frames0.p; R.n16[3] = (uint32_t)(b->d_frames0.bytes() / 16);
+    R.dst[4] = (uint4*)b->d_storage.p; R.src[4] = (const uint4*)b->d_storage0.p; R.n16[4] = (uint32_t)(b->d_storage0.bytes() / 16);
+    R.heap_dst = b->d_heap.p; R.heap_src = b->d_heap0.p;
+    R.heap_row16 = b->heap_image_words * b->L * 2;
+    R.heap_pitch16 = b->lim.max_far_frames * b->lim.heap_words * b->L * 2;
+    R.n_waves = b->n_waves;
+    R.cursors = b->d_cursors.p;
+    HIP_TRY(c, ensure(b->d_reset_params, 1));
+    HIP_TRY(c, hipMemcpy(b->d_reset_params.p, &R, sizeof R, hipMemcpyHostToDevice));
+    const uint32_t caps[3] = {b->cap_mem, b->cap_log, b->cap_aux};
+    const uint32_t per_inst[3] = {b->lim.max_mem_queries, b->lim.max_log_queries, b->lim.max_aux_events};
+    const uint32_t max_cap = std::max(caps[0], std::max(caps[1], caps[2]));
+    const uint32_t max_per = std::max(per_inst[0], std::max(per_inst[1], per_inst[2]));
+    HIP_TRY(c, ensure(b->d_leaves, (size_t)b->n_waves * max_cap * 4));
+    HIP_TRY(c, ensure(b->d_idx, (size_t)b->n * max_per));
+    HIP_TRY(c, ensure(b->d_counts, b->n));
+    const uint4* streams[3] = {b->d_mem.p, b->d_log.p, b->d_auxs.p};
+    zkw_commit_params CP[ZKW_QUEUE_COUNT];
+    std::memset(CP, 0, sizeof CP);
+    for (uint32_t q = 0; q < ZKW_QUEUE_COUNT; q++) {
+      zkw_commit_params& C = CP[q];
+      C.n_instances = b->n; C.L = b->L; C.n_waves = b->n_waves; C.max_cycles = b->lim.max_cycles; C.wave_threads = (uint32_t)c->wave_width;
+      C.queue = q; C.cap = caps[q]; C.per_instance_cap = per_inst[q]; C.n_blobs = (uint32_t)b->blobs.size();
+      C.rc = b->d_rc.p; C.stream = streams[q]; C.cursors = b->d_cursors.p; C.dir = b->d_dir.p; C.scalars = b->d_scalars.p;
+      C.blob_digests = b->d_blob_digests.p; C.blob_dir = b->d_blob_dir.p; C.leaves = b->d_leaves.p; C.idx = b->d_idx.p; C.counts = b->d_counts.p;
+      C.out = b->d_commit.p;
+    }
+    HIP_TRY(c, ensure(b->d_commit_params, ZKW_QUEUE_COUNT + 1));
+    HIP_TRY(c, hipMemcpy(b->d_commit_params.p, CP, sizeof CP, hipMemcpyHostToDevice));
+  }
   b->uploaded = true;
   b->ran = false;
   return zkw_batch_reset(b, nullptr);
 }
 
-int zkw_batch_reset(zkw_batch* b, void* hip_stream) {
-  if (!b) return ZKW_ERR_INVALID;
-  zkw_ctx* c = b->ctx;
-  if (!b->uploaded) {
-    c->last_error = "zkw_batch_upload first";
-    return ZKW_ERR_INVALID;
+// ---- enqueue helpers: every launch covers a list of batches of one context (grid.y / grid.z = batch) ----
+static int check_group(zkw_batch* const* bs, uint32_t n) {
+  if (!bs || n == 0 || !bs[0]) return ZKW_ERR_INVALID;
+  zkw_ctx* c = bs[0]->ctx;
+  if (n > ZKW_MAX_FUSED) {
+    c->last_error = "more than ZKW_MAX_FUSED batches in one fused step";
+    return ZKW_ERR_LIMIT;
   }
-  hipStream_t st = (hipStream_t)hip_stream;
-  HIP_TRY(c, hipSetDevice(c->device));
-  zkw_reset_params R;
-  std::memset(&R, 0, sizeof R);
-  R.dst[0] = b->d_regs.p; R.src[0] = b->d_regs0.p; R.n16[0] = (uint32_t)(b->d_regs0.bytes() / 16);
-  R.dst[1] = (uint4*)b->d_scalars.p; R.src[1] = (const uint4*)b->d_scalars0.p; R.n16[1] = (uint32_t)(b->d_scalars0.bytes() / 16);
-  R.dst[2] = (uint4*)b->d_callstack.p; R.src[2] = (const uint4*)b->d_callstack0.p; R.n16[2] = (uint32_t)(b->d_callstack0.bytes() / 16);
-  R.dst[3] = (uint4*)b->d_frames.p; R.src[3] = (const uint4*)b->d_frames0.p; R.n16[3] = (uint32_t)(b->d_frames0.bytes() / 16);
-  R.dst[4] = (uint4*)b->d_storage.p; R.src[4] = (const uint4*)b->d_storage0.p; R.n16[4] = (uint32_t)(b->d_storage0.bytes() / 16);
-  R.heap_dst = b->d_heap.p; R.heap_src = b->d_heap0.p;
-  R.heap_row16 = b->heap_image_words * b->L * 2;
-  R.heap_pitch16 = b->lim.max_far_frames * b->lim.heap_words * b->L * 2;
-  R.n_waves = b->n_waves;
-  R.cursors = b->d_cursors.p;
-  HIP_TRY(c, zkw_launch_reset_kernel(&R, (uint32_t)c->wave_width, st));
-  b->cycles_run = 0;
-  b->ran = false;
-  b->synced = false;
-  b->wave_cache.clear();
+  for (uint32_t i = 0; i < n; i++) {
+    if (!bs[i] || bs[i]->ctx != c) {
+      c->last_error = "fused batches must belong to one context";
+      return ZKW_ERR_INVALID;
+    }
+    if (!bs[i]->uploaded) {
+      c->last_error = "zkw_batch_upload first";
+      return ZKW_ERR_INVALID;
+    }
+    for (uint32_t j = 0; j < i; j++)
+      if (bs[j] == bs[i]) {
+        c->last_error = "a batch appears twice in one fused step";
+        return ZKW_ERR_INVALID;
+      }
+  }
   return ZKW_OK;
 }
 
-int zkw_batch_run(zkw_batch* b, uint32_t max_cycles, void* hip_stream) {
-  if (!b) return ZKW_ERR_INVALID;
-  zkw_ctx* c = b->ctx;
-  if (!b->uploaded) {
-    c->last_error = "zkw_batch_upload first";
-    return ZKW_ERR_INVALID;
-  }
-  if (max_cycles == 0 || (uint64_t)b->cycles_run + max_cycles > b->lim.max_cycles) {
-    c->last_error = "run exceeds limits.max_cycles since the last reset";
-    return ZKW_ERR_LIMIT;
-  }
-  hipStream_t st = (hipStream_t)hip_stream;
+static int enqueue_reset(zkw_batch* const* bs, uint32_t n, hipStream_t st) {
+  zkw_ctx* c = bs[0]->ctx;
   HIP_TRY(c, hipSetDevice(c->device));
-  zkw_kparams P = b->kp;
-  P.cycle_base = b->cycles_run;
-  P.run_cycles = max_cycles;
-  P.props = b->props;
-  if (const char* dbg = getenv("ZKW_DEBUG_FLAGS")) P.debug_flags = (uint32_t)atoi(dbg);  // profiling ablations only
-  const uint32_t slot = b->pending_runs % zkw_batch::EV_RING;
-  HIP_TRY(c, hipEventRecord(b->evs[2 * slot], st));
-  HIP_TRY(c, zkw_launch_cycle_kernel(&P, st));
-  HIP_TRY(c, hipEventRecord(b->evs[2 * slot + 1], st));
-  b->pending_runs++;
-  b->run_stream = st;
-  b->cycles_run += max_cycles;
-  b->ran = true;
-  b->synced = false;
-  b->wave_cache.clear();
+  zkw_fused_table T;
+  std::memset(&T, 0, sizeof T);
+  T.n = n;
+  T.wave_threads = (uint32_t)c->wave_width;
+  for (uint32_t i = 0; i < n; i++) T.p[i] = bs[i]->d_reset_params.p;
+  HIP_TRY(c, zkw_launch_reset_kernel(&T, st));
+  for (uint32_t i = 0; i < n; i++) {
+    zkw_batch* b = bs[i];
+    b->cycles_run = 0;
+    b->ran = false;
+    b->synced = false;
+    b->wave_cache.clear();
+  }
   return ZKW_OK;
+}
+
+static int enqueue_run(zkw_batch* const* bs, uint32_t n, uint32_t max_cycles, hipStream_t st) {
+  zkw_ctx* c = bs[0]->ctx;
+  for (uint32_t i = 0; i < n; i++)
+    if (max_cycles == 0 || (uint64_t)bs[i]->cycles_run + max_cycles > bs[i]->lim.max_cycles) {
+      c->last_error = "run exceeds limits.max_cycles since the last reset";
+      return ZKW_ERR_LIMIT;
+    }
+  HIP_TRY(c, hipSetDevice(c->device));
+  zkw_launch_args A;
+  std::memset(&A, 0, sizeof A);
+  A.n_batches = n;
+  A.run_cycles = max_cycles;
+  A.wave_threads = bs[0]->kp.wave_threads;
+  A.waves_per_group = bs[0]->kp.waves_per_group;
+  for (uint32_t i = 0; i < n; i++) {
+    A.kp[i] = bs[i]->d_kp.p;
+    A.max_waves = std::max(A.max_waves, bs[i]->n_waves);
+    A.max_L = std::max(A.max_L, bs[i]->L);
+  }
+  if (const char* dbg = getenv("ZKW_DEBUG_FLAGS")) A.debug_flags = (uint32_t)atoi(dbg);  // profiling ablations / test hooks only
+  // HIP events around the launch: on the first batch of the group (its kernel_ms is the launch's duration)
+  zkw_batch* lead = bs[0];
+  const uint32_t slot = lead->pending_runs % zkw_batch::EV_RING;
+  HIP_TRY(c, hipEventRecord(lead->evs[2 * slot], st));
+  HIP_TRY(c, zkw_launch_cycle_kernel(&A, st));
+  HIP_TRY(c, hipEventRecord(lead->evs[2 * slot + 1], st));
+  lead->pending_runs++;
+  for (uint32_t i = 0; i < n; i++) {
+    zkw_batch* b = bs[i];
+    b->run_stream = st;
+    b->cycles_run += max_cycles;
+    b->ran = true;
+    b->synced = false;
+    b->wave_cache.clear();
+  }
+  return ZKW_OK;
+}
+
+static int enqueue_commit(zkw_batch* const* bs, uint32_t n, uint32_t queue_mask, hipStream_t st) {
+  zkw_ctx* c = bs[0]->ctx;
+  for (uint32_t i = 0; i < n; i++)
+    if (!bs[i]->ran) return ZKW_ERR_NOT_RUN;
+  HIP_TRY(c, hipSetDevice(c->device));
+  for (uint32_t q = 0; q < ZKW_QUEUE_COUNT; q++) {
+    if (!((queue_mask >> q) & 1u)) continue;
+    zkw_fused_table T;
+    std::memset(&T, 0, sizeof T);
+    T.n = n;
+    T.wave_threads = (uint32_t)c->wave_width;
+    for (uint32_t i = 0; i < n; i++) {
+      const uint32_t caps[3] = {bs[i]->cap_mem, bs[i]->cap_log, bs[i]->cap_aux};
+      T.p[i] = bs[i]->d_commit_params.p + q;
+      T.max_waves = std::max(T.max_waves, bs[i]->n_waves);
+      T.max_cap = std::max(T.max_cap, caps[q]);
+    }
+    HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_LEAF, st));
+    HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_BUCKET, st));
+    HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_CHAIN, st));
+  }
+  return ZKW_OK;
+}
+
+int zkw_batch_reset(zkw_batch* b, void* hip_stream) {
+  int rc = check_group(&b, 1);
+  return rc != ZKW_OK ? rc : enqueue_reset(&b, 1, (hipStream_t)hip_stream);
+}
+
+int zkw_batch_run(zkw_batch* b, uint32_t max_cycles, void* hip_stream) {
+  int rc = check_group(&b, 1);
+  return rc != ZKW_OK ? rc : enqueue_run(&b, 1, max_cycles, (hipStream_t)hip_stream);
+}
+
+int zkw_batches_step(zkw_batch* const* batches, uint32_t n_batches, uint32_t max_cycles, uint32_t queue_mask, void* hip_stream) {
+  int rc = check_group(batches, n_batches);
+  if (rc != ZKW_OK) return rc;
+  hipStream_t st = (hipStream_t)hip_stream;
+  rc = enqueue_reset(batches, n_batches, st);
+  if (rc == ZKW_OK) rc = enqueue_run(batches, n_batches, max_cycles, st);
+  if (rc == ZKW_OK && queue_mask) rc = enqueue_commit(batches, n_batches, queue_mask, st);
+  return rc;
 }
 
 int zkw_batch_sync(zkw_batch* b) {
@@ -863,32 +983,8 @@ int zkw_batch_get_instance_trace(zkw_batch* b, uint32_t instance, zkw_instance_t
 
 int zkw_batch_commit(zkw_batch* b, uint32_t queue_mask, void* hip_stream) {
   if (!b) return ZKW_ERR_INVALID;
-  zkw_ctx* c = b->ctx;
-  if (!b->ran) return ZKW_ERR_NOT_RUN;
-  hipStream_t st = (hipStream_t)hip_stream;
-  HIP_TRY(c, hipSetDevice(c->device));
-  const uint32_t caps[3] = {b->cap_mem, b->cap_log, b->cap_aux};
-  const uint32_t per_inst[3] = {b->lim.max_mem_queries, b->lim.max_log_queries, b->lim.max_aux_events};
-  const uint32_t max_cap = std::max(caps[0], std::max(caps[1], caps[2]));
-  const uint32_t max_per = std::max(per_inst[0], std::max(per_inst[1], per_inst[2]));
-  if (!b->d_leaves.p) HIP_TRY(c, b->d_leaves.alloc((size_t)b->n_waves * max_cap * 4));
-  if (!b->d_idx.p) HIP_TRY(c, b->d_idx.alloc((size_t)b->n * max_per));
-  if (!b->d_counts.p) HIP_TRY(c, b->d_counts.alloc(b->n));
-  const uint4* streams[3] = {b->d_mem.p, b->d_log.p, b->d_auxs.p};
-  for (uint32_t q = 0; q < ZKW_QUEUE_COUNT; q++) {
-    if (!((queue_mask >> q) & 1u)) continue;
-    zkw_commit_params C;
-    std::memset(&C, 0, sizeof C);
-    C.n_instances = b->n; C.L = b->L; C.n_waves = b->n_waves; C.max_cycles = b->lim.max_cycles; C.wave_threads = (uint32_t)c->wave_width;
-    C.queue = q; C.cap = caps[q]; C.per_instance_cap = per_inst[q]; C.n_blobs = (uint32_t)b->blobs.size();
-    C.rc = b->d_rc.p; C.stream = streams[q]; C.cursors = b->d_cursors.p; C.dir = b->d_dir.p; C.scalars = b->d_scalars.p;
-    C.blob_digests = b->d_blob_digests.p; C.blob_dir = b->d_blob_dir.p; C.leaves = b->d_leaves.p; C.idx = b->d_idx.p; C.counts = b->d_counts.p;
-    C.out = b->d_commit.p;
-    HIP_TRY(c, zkw_launch_commit(&C, ZKW_COMMIT_STAGE_LEAF, st));
-    HIP_TRY(c, zkw_launch_commit(&C, ZKW_COMMIT_STAGE_BUCKET, st));
-    HIP_TRY(c, zkw_launch_commit(&C, ZKW_COMMIT_STAGE_CHAIN, st));
-  }
-  return ZKW_OK;
+  if (!b->uploaded) return ZKW_ERR_INVALID;
+  return enqueue_commit(&b, 1, queue_mask, (hipStream_t)hip_stream);
 }
 
 int zkw_batch_get_commitments(zkw_batch* b, uint64_t* out) {

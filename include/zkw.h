@@ -429,6 +429,12 @@ int zkw_batch_run(zkw_batch* batch, uint32_t max_cycles, void* hip_stream);
  * The first call runs eagerly and captures the sequence into a hipGraph; later calls with the same arguments replay
  * it with a single launch (the launch-bound regime of small batches). */
 int zkw_batch_step(zkw_batch* batch, uint32_t max_cycles, uint32_t queue_mask, void* hip_stream);
+/* The same step for up to 32 (ZKW_MAX_FUSED) uploaded batches of one context with FUSED launches: one reset launch,
+ * one cycle-kernel launch and one set of commitment launches cover all of them (one batch per grid row).  A cycle
+ * kernel launch of a small batch cannot fill the GPU (one wave per 64 instances, latency-bound), and the hardware
+ * runs only a few kernels of different streams concurrently, so independent small batches are stepped together.
+ * Every batch is afterwards synced / read exactly as after zkw_batch_run; kernel_ms is reported on batches[0]. */
+int zkw_batches_step(zkw_batch* const* batches, uint32_t n_batches, uint32_t max_cycles, uint32_t queue_mask, void* hip_stream);
 /* waits for the run, downloads the streams and builds the per-instance views */
 int zkw_batch_sync(zkw_batch* batch);
 int zkw_batch_get_stats(zkw_batch* batch, zkw_run_stats* out);

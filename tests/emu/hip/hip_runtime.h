@@ -73,9 +73,10 @@ template <typename K, typename... Args>
 static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, Args... args) {
   gridDim = grid;
   blockDim = block;
+  for (unsigned bz = 0; bz < grid.z; bz++)
   for (unsigned by = 0; by < grid.y; by++)
     for (unsigned b = 0; b < grid.x; b++) {
-      blockIdx = dim3(b, by);
+      blockIdx = dim3(b, by, bz);
       for (unsigned t = 0; t < block.x; t++) {  // block.x == 1 (warpSize 1)
         threadIdx = dim3(t);
         kernel(args...);

@@ -196,3 +196,25 @@ def test_graph_replayed_step(oracle, product, isa):
     cp = bp.commitments()
     assert np.array_equal(bo.commitments(), cp)
     assert float(bp.stats()["kernel_ms"]) > 0
+
+
+def test_fused_step_of_several_batches(oracle, product, isa):
+    """zkw_batches_step on the GPU: four batches of different shape and geometry in shared launches, bit-exact each."""
+    wls = [synth.make(2, isa, n_instances=300), synth.make(4, isa, n_instances=64), synth.make(1, isa, n_instances=1000), synth.make(3, isa, n_instances=70)]
+    cyc = max(w.n_cycles for w in wls)
+    for w in wls:
+        w.limits["max_cycles"] = cyc
+    bos = []
+    for w in wls:
+        bo = oracle.create_batch(w)
+        bo.reset(); bo.run(cyc); bo.sync()
+        bos.append(bo)
+    bps = [product.create_batch(w) for w in wls]
+    for _ in range(3):
+        product.step_many(bps, cyc, 7)
+    for w, bo, bp in zip(wls, bos, bps):
+        bp.sync()
+        for i in range(0, w.n_instances, 7):
+            ok, why = K.traces_equal(bo.trace(i), bp.trace(i))
+            assert ok, (w.name, i, why)
+        assert np.array_equal(bo.commitments(), bp.commitments()), w.name
