@@ -59,6 +59,18 @@ ZD u64 gl_mul(u64 a, u64 b) {
   mul64(a, b, lo, hi);
   return gl_reduce128(lo, hi);
 }
+// x * 2^K for a static 0 <= K < 32: the 128-bit product is (x >> (64-K)) : (x << K), and hi < 2^K reduces as
+// hi * 2^64 = hi * (2^32 - 1) (mod p) — no multiplier involved
+template <int K>
+ZD u64 gl_mul_pow2(u64 x) {
+  if (K == 0) return x;
+  const u64 lo = x << K, hi = x >> (64 - K);
+  const u64 t1 = (hi << 32) - hi;
+  u64 r = lo + t1;
+  if (r < t1) r += GL_EPS;
+  if (r >= GL_P) r -= GL_P;
+  return r;
+}
 ZD u64 gl_pow7(u64 x) {
   const u64 x2 = gl_mul(x, x), x3 = gl_mul(x2, x), x4 = gl_mul(x2, x2);
   return gl_mul(x4, x3);
@@ -86,8 +98,10 @@ ZD void gl_internal(u64 s[12]) {
   u64 sum = 0;
 #pragma unroll
   for (int i = 0; i < 12; i++) sum = gl_add(sum, s[i]);
-#pragma unroll
-  for (int i = 0; i < 12; i++) s[i] = gl_add(sum, gl_mul(s[i], 1ULL << i));
+  s[0] = gl_add(sum, gl_mul_pow2<0>(s[0]));   s[1] = gl_add(sum, gl_mul_pow2<1>(s[1]));   s[2] = gl_add(sum, gl_mul_pow2<2>(s[2]));
+  s[3] = gl_add(sum, gl_mul_pow2<3>(s[3]));   s[4] = gl_add(sum, gl_mul_pow2<4>(s[4]));   s[5] = gl_add(sum, gl_mul_pow2<5>(s[5]));
+  s[6] = gl_add(sum, gl_mul_pow2<6>(s[6]));   s[7] = gl_add(sum, gl_mul_pow2<7>(s[7]));   s[8] = gl_add(sum, gl_mul_pow2<8>(s[8]));
+  s[9] = gl_add(sum, gl_mul_pow2<9>(s[9]));   s[10] = gl_add(sum, gl_mul_pow2<10>(s[10])); s[11] = gl_add(sum, gl_mul_pow2<11>(s[11]));
 }
 
 ZD void gl_permute(const u64* rc, u64 s[12]) {
@@ -146,6 +160,12 @@ ZD void gl_chain_step(const u64* rc, const u64 leaf[4], u64 tail[4], u64 index_p
   for (int i = 0; i < 4; i++) tail[i] = s[i];
 }
 
+// orders one wavefront's LDS stores before its later cross-lane LDS reads
+ZD void zkw_commit_wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
@@ -157,6 +177,50 @@ __global__ void zkw_leaf_kernel(zkw_fused_table T) {
   const u32 wave = blockIdx.y;
   u32 n = C.n_override;
   if (!n) n = C.cursors[wave * 4 + C.queue] < C.cap ? C.cursors[wave * 4 + C.queue] : C.cap;
+  if (C.queue == ZKW_QUEUE_DECOMMIT) {
+    // Only the DECOMMIT events of the aux stream carry a leaf (about one record in six): every wavefront scans its
+    // share of the stream, compacts the positions of the DECOMMIT records into an LDS list with ballot + popcount,
+    // and hashes them 64 at a time, so the permutation runs on full wavefronts.
+    __shared__ u32 s_list[4][2 * ZKW_WAVE];
+    const u32 wt = C.wave_threads;
+    const u32 wf = threadIdx.x / wt, ln = threadIdx.x % wt, nwf = blockDim.x / wt;
+    u32 pending = 0;
+    for (u32 base = (blockIdx.x * nwf + wf) * wt; base < n || pending; base += gridDim.x * nwf * wt) {
+      const u32 pos = base + ln;
+      bool is = false;
+      if (base < n) {
+        if (pos < n) is = (C.stream[((u64)wave * C.cap + pos) * 16].x & 0xffu) == ZKW_AUX_DECOMMIT;
+        const u64 mask = __ballot(is);
+        const u32 rank = (u32)__popcll(mask & ((1ull << ln) - 1ull));
+        if (is) s_list[wf][pending + rank] = pos;
+        pending += (u32)__popcll(mask);
+        zkw_commit_wave_fence();
+      }
+      if (pending >= wt || (base + gridDim.x * nwf * wt >= n && pending)) {  // a full wavefront of work, or the tail
+        const u32 take = pending < wt ? pending : wt;
+        u32 carry = 0;
+        if (ln + take < pending) carry = s_list[wf][ln + take];
+        if (ln < take) {
+          const u32 p = s_list[wf][ln];
+          const uint4* e = C.stream + ((u64)wave * C.cap + p) * 16;
+          const uint4 h = e[0], lo = e[1], hi = e[2];
+          const u32 blob = h.w >> 16;
+          const u64* bd = C.blob_digests + (u64)blob * 4;
+          u64 f[16] = {h.y, h.z, h.w & 0xffffu, (h.x >> 24) & 0xffu, lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, bd[0], bd[1], bd[2], bd[3]};
+          u64 out[4];
+          gl_leaf<16>(C.rc, ZKW_LEAF_DECOMMIT, f, out);
+          u64* dst = C.leaves + ((u64)wave * C.cap + p) * 4;
+          dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2]; dst[3] = out[3];
+        }
+        zkw_commit_wave_fence();
+        if (ln + take < pending) s_list[wf][ln] = carry;
+        pending -= take;
+        zkw_commit_wave_fence();
+      }
+      if (base >= n && !pending) break;
+    }
+    return;
+  }
   for (u32 pos = blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += gridDim.x * blockDim.x) {
     u64 out[4];
     if (C.queue == ZKW_QUEUE_MEMORY) {
@@ -178,19 +242,6 @@ __global__ void zkw_leaf_kernel(zkw_fused_table T) {
         f[8 + 4 * q] = v.x; f[9 + 4 * q] = v.y; f[10 + 4 * q] = v.z; f[11 + 4 * q] = v.w;
       }
       gl_leaf<32>(C.rc, ZKW_LEAF_LOG, f, out);
-    } else if (C.queue == ZKW_QUEUE_DECOMMIT) {
-      const uint4* e = C.stream + ((u64)wave * C.cap + pos) * 16;
-      const uint4 h = e[0];
-      const u32 type = h.x & 0xffu;
-      if (type == ZKW_AUX_DECOMMIT) {
-        const uint4 lo = e[1], hi = e[2];
-        const u32 blob = h.w >> 16;
-        const u64* bd = C.blob_digests + (u64)blob * 4;
-        u64 f[16] = {h.y, h.z, h.w & 0xffffu, (h.x >> 24) & 0xffu, lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, bd[0], bd[1], bd[2], bd[3]};
-        gl_leaf<16>(C.rc, ZKW_LEAF_DECOMMIT, f, out);
-      } else {
-        out[0] = out[1] = out[2] = out[3] = 0;
-      }
     } else {  // code words of the blobs: stream = blob words (2 x uint4 per word), wave = 0
       const uint4 lo = C.stream[(u64)pos * 2], hi = C.stream[(u64)pos * 2 + 1];
       u64 f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};

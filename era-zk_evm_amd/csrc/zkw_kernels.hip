@@ -1700,22 +1700,42 @@ __global__ void zkw_reset_kernel(zkw_fused_table T) {
   const zkw_reset_params ZKW_CONST_AS& R = *(const zkw_reset_params ZKW_CONST_AS*)T.p[blockIdx.y];
   const u32 stride = gridDim.x * blockDim.x;
   const u32 t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  // four independent 16-byte loads in flight per thread before the stores (a latency-bound copy otherwise)
 #pragma unroll 1
   for (int b = 0; b < 5; b++) {
     const uint4* src = R.src[b];
     uint4* dst = R.dst[b];
-    for (u32 i = t0; i < R.n16[b]; i += stride) dst[i] = src[i];
+    const u32 n = R.n16[b];
+    u32 i = t0;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+      const uint4 a = src[i], c = src[i + stride], d = src[i + 2 * stride], e = src[i + 3 * stride];
+      dst[i] = a; dst[i + stride] = c; dst[i + 2 * stride] = d; dst[i + 3 * stride] = e;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
   }
-  for (u32 w = 0; w < R.n_waves; w++)
-    for (u32 i = t0; i < R.heap_row16; i += stride) R.heap_dst[(u64)w * R.heap_pitch16 + i] = R.heap_src[(u64)w * R.heap_row16 + i];
+  // heap image: [n_waves][heap_row16] (dense) -> rows of the working arena, one flat index space
+  const u32 row = R.heap_row16;
+  const u32 total = R.n_waves * row;
+  if (row) {
+    u32 i = t0;
+    for (; i + 3 * stride < total; i += 4 * stride) {
+      const u32 i1 = i + stride, i2 = i + 2 * stride, i3 = i + 3 * stride;
+      const uint4 a = R.heap_src[i], c = R.heap_src[i1], d = R.heap_src[i2], e = R.heap_src[i3];
+      R.heap_dst[(u64)(i / row) * R.heap_pitch16 + i % row] = a;
+      R.heap_dst[(u64)(i1 / row) * R.heap_pitch16 + i1 % row] = c;
+      R.heap_dst[(u64)(i2 / row) * R.heap_pitch16 + i2 % row] = d;
+      R.heap_dst[(u64)(i3 / row) * R.heap_pitch16 + i3 % row] = e;
+    }
+    for (; i < total; i += stride) R.heap_dst[(u64)(i / row) * R.heap_pitch16 + i % row] = R.heap_src[i];
+  }
   for (u32 i = t0; i < R.n_waves * 4; i += stride) R.cursors[i] = 0;
 }
 
 extern "C" hipError_t zkw_launch_reset_kernel(const zkw_fused_table* T, hipStream_t stream) {
   const u32 threads = T->wave_threads > 1 ? 256 : 1;
-  // ~2 workgroups per CU in total, however many batches share the launch
-  u32 blocks = T->wave_threads > 1 ? (512 + T->n - 1) / T->n : 1;
-  if (blocks < 32 && T->wave_threads > 1) blocks = 32;
+  // ~8 workgroups per CU in total, however many batches share the launch
+  u32 blocks = T->wave_threads > 1 ? (2048 + T->n - 1) / T->n : 1;
+  if (blocks < 64 && T->wave_threads > 1) blocks = 64;
   hipLaunchKernelGGL(zkw_reset_kernel, dim3(blocks, T->n), dim3(threads), 0, stream, *T);
   return hipGetLastError();
 }

@@ -741,6 +741,7 @@ static int enqueue_run(zkw_batch* const* bs, uint32_t n, uint32_t max_cycles, hi
   HIP_TRY(c, hipEventRecord(lead->evs[2 * slot], st));
   HIP_TRY(c, zkw_launch_cycle_kernel(&A, st));
   HIP_TRY(c, hipEventRecord(lead->evs[2 * slot + 1], st));
+  if (getenv("ZKW_DEBUG_SYNC")) HIP_TRY(c, hipStreamSynchronize(st));  // diagnostics only
   lead->pending_runs++;
   for (uint32_t i = 0; i < n; i++) {
     zkw_batch* b = bs[i];
