@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — witnessed VM cycles/sec on the 1M-cycle synthetic batch (BASELINE.json configs[2]).
 
-One "step" = one pass of the hot path (zkw_batch_run: every instance replays its opcode tape and
-emits its witness trace) over one batch whose inputs are already resident in HBM.  Each step runs on
-its own freshly reset batch state (reset = device-side restore of the pristine images, outside the
-step).  Prints ONE JSON line (contract in the task description) with `roofline` and `cpu_baseline`.
+One "step" = one pass of the hot path over one batch whose inputs are already resident in HBM: device-side restore
+of the batch's pristine state, the cycle kernel (every instance replays its opcode tape and emits its witness
+trace) and the queue-commitment kernels selected by --commit-mask.  Steps are issued `--fuse` batches per fused
+launch (zkw_batches_step).  Prints ONE JSON line (contract in the task description) with `roofline` and
+`cpu_baseline`.
 """
 import os
 # The pipelined batch slots live on separate HIP streams; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware
