@@ -96,6 +96,16 @@ RUN_STATS = _dt([("cycles", "<u8", 0), ("mem_queries", "<u8", 8), ("log_queries"
                  ("instances_failed", "<u8", 40), ("kernel_ms", "<f8", 48), ("reserved0", "<f8", 56)], 64)
 
 
+EVENT_MESSAGE = _dt([("shard_id", "u1", 0), ("is_first", "u1", 1), ("tx_number_in_block", "<u2", 2), ("address", ("u1", 20), 4), ("key", U256, 24),
+                     ("value", U256, 56)], 88)
+
+
+class NetStateC(C.Structure):
+    _fields_ = [("n_storage_history", C.c_uint32), ("n_event_history", C.c_uint32), ("n_events", C.c_uint32), ("n_l1_messages", C.c_uint32),
+                ("n_final_storage", C.c_uint32), ("reserved0", C.c_uint32), ("storage_history", C.c_void_p), ("event_history", C.c_void_p),
+                ("events", C.c_void_p), ("l1_messages", C.c_void_p), ("final_storage", C.c_void_p)]
+
+
 class InstanceTraceC(C.Structure):
     _fields_ = [("status", C.c_uint32), ("n_cycles", C.c_uint32), ("n_mem", C.c_uint32), ("n_log", C.c_uint32), ("n_aux", C.c_uint32),
                 ("reserved0", C.c_uint32), ("records", C.c_void_p), ("mem", C.c_void_p), ("log", C.c_void_p), ("aux", C.c_void_p),
@@ -324,6 +334,19 @@ class Batch:
             "final_state": np.frombuffer(bytes(t.final_state), dtype=VM_LOCAL_STATE, count=1).copy()[0],
         }
 
+    def net_state(self, i):
+        """get_final_net_states (testing/mod.rs:42-71) of instance i: storage / event histories, net events and L1
+        messages, final storage."""
+        t = NetStateC()
+        self.be.call("batch_get_net_state", self.h, C.c_uint32(i), C.byref(t))
+        return {
+            "storage_history": _from_ptr(t.storage_history, t.n_storage_history, LOG_QUERY),
+            "event_history": _from_ptr(t.event_history, t.n_event_history, LOG_QUERY),
+            "events": _from_ptr(t.events, t.n_events, EVENT_MESSAGE),
+            "l1_messages": _from_ptr(t.l1_messages, t.n_l1_messages, EVENT_MESSAGE),
+            "final_storage": _from_ptr(t.final_storage, t.n_final_storage, STORAGE_SLOT),
+        }
+
     def commitments(self):
         out = np.zeros((self.wl.n_instances, QUEUE_COUNT, 4), dtype="<u8")
         self.be.call("batch_get_commitments", self.h, _ptr(out))
@@ -336,6 +359,17 @@ class Batch:
 
 
 TRACE_ARRAYS = ("records", "mem", "log", "aux", "mem_off", "log_off", "aux_off")
+
+
+def net_states_equal(a, b):
+    for k in ("storage_history", "event_history", "events", "l1_messages", "final_storage"):
+        if a[k].shape != b[k].shape:
+            return False, "%s: shape %r != %r" % (k, a[k].shape, b[k].shape)
+        if a[k].tobytes() != b[k].tobytes():
+            for j in range(len(a[k])):
+                if a[k][j].tobytes() != b[k][j].tobytes():
+                    return False, "%s[%d]: %r vs %r" % (k, j, a[k][j], b[k][j])
+    return True, ""
 
 
 def traces_equal(a, b):

@@ -15,6 +15,7 @@
 #define ZKW_COMMIT_STAGE_BUCKET 1
 #define ZKW_COMMIT_STAGE_CHAIN 2
 #define ZKW_COMMIT_STAGE_BLOB_CHAIN 3
+#define ZKW_COMMIT_STAGE_NETSTATE 4
 
 typedef struct zkw_commit_params {
   uint32_t n_instances, L, n_waves, max_cycles, wave_threads;
@@ -23,6 +24,8 @@ typedef struct zkw_commit_params {
   uint32_t per_instance_cap; /* idx capacity per instance */
   uint32_t n_blobs;
   uint32_t n_override;       /* != 0: number of records instead of cursors[] (code-word leaves) */
+  uint32_t aux_type_mask;    /* bucket pass over the aux stream: bit t keeps events of type t (0 = DECOMMIT only) */
+  uint32_t reserved0;
   const uint64_t* rc;        /* [ZKW_GL_RC_COUNT] round constants */
   const uint4* stream;
   const uint32_t* cursors;   /* [n_waves][4] */
@@ -35,6 +38,31 @@ typedef struct zkw_commit_params {
   uint32_t* counts;          /* [n_instances] */
   uint64_t* out;             /* chain: [n_instances][ZKW_QUEUE_COUNT][4]; blob chain: [n_blobs][4] */
 } zkw_commit_params;
+
+/* zkw_netstate_kernel: one instance per lane walks its cycles and nets its log queries against its frame events
+ * (the device form of testing/storage.rs:144-186 + reference_impls/event_sink.rs:160-176) */
+typedef struct zkw_netstate_params {
+  uint32_t n_instances, L, n_waves, max_cycles, wave_threads;
+  uint32_t cap_log, cap_aux;      /* stream capacity per wave (records) */
+  uint32_t per_log, per_aux;      /* index-list capacity per instance */
+  uint32_t hist_cap;              /* history capacity per instance (2 * per_log) */
+  uint32_t mark_cap;              /* frame-mark capacity per instance */
+  uint32_t storage_aux_byte, event_aux_byte, l1_aux_byte;
+  uint32_t reserved0;
+  const uint4* rec;               /* CycleRecords: the per-cycle event counts of the tail */
+  const uint4* log_stream;
+  const uint4* aux_stream;
+  const zkw_dev_scalars* scalars;   /* status, n_cycles */
+  const zkw_dev_scalars* scalars0;  /* pristine: the callstack depth the instance started with */
+  const uint32_t* log_idx;  const uint32_t* log_cnt;   /* bucket pass over the log stream */
+  const uint32_t* aux_idx;  const uint32_t* aux_cnt;   /* bucket pass over the aux stream, every type */
+  uint32_t* st_hist;   /* [n_instances][hist_cap]  stream position | rollback << 31 */
+  uint32_t* ev_hist;   /* [n_instances][hist_cap] */
+  uint32_t* rb_st;     /* [n_instances][per_log]   pending storage rollbacks (stack) */
+  uint32_t* rb_ev;     /* [n_instances][per_log]   pending event rollbacks = the surviving events at the end */
+  uint32_t* marks;     /* [n_instances][mark_cap][2] */
+  uint32_t* out_counts; /* [n_instances][4]: storage history, event history, surviving events, flags (1 = overflow) */
+} zkw_netstate_params;
 
 /* round constants: splitmix64 stream seeded with "zkwGLv1", values >= p rejected */
 static inline void zkw_gl_round_constants(uint64_t* rc) {

@@ -266,6 +266,7 @@ __global__ void zkw_bucket_kernel(zkw_fused_table T) {
   const u32 tid = threadIdx.x;
   if (wave >= C.n_waves) return;  // uniform per workgroup
   const u32 rec_bytes = C.queue == ZKW_QUEUE_MEMORY ? 48u : (C.queue == ZKW_QUEUE_LOG ? 128u : 256u);
+  const u32 type_mask = C.aux_type_mask ? C.aux_type_mask : (1u << ZKW_AUX_DECOMMIT);
   const uint8_t* base = (const uint8_t*)C.stream + (u64)wave * C.cap * rec_bytes;
   const u32 n = C.cursors[wave * 4 + C.queue] < C.cap ? C.cursors[wave * 4 + C.queue] : C.cap;
   const uint32_t* dir = C.dir + (u64)wave * (C.max_cycles + 1) * 4;
@@ -291,7 +292,7 @@ __global__ void zkw_bucket_kernel(zkw_fused_table T) {
         tag = base[(u64)p * 256 + 1];
         type = base[(u64)p * 256];
       }
-      keep = tag < ZKW_WAVE && p < s_limit[tag & (ZKW_WAVE - 1)] && type == ZKW_AUX_DECOMMIT;
+      keep = tag < ZKW_WAVE && p < s_limit[tag & (ZKW_WAVE - 1)] && ((type_mask >> (type & 31u)) & 1u);
     }
     tag &= ZKW_WAVE - 1;
     u64 same = __ballot(keep);
@@ -351,6 +352,95 @@ __global__ void zkw_blob_chain_kernel(zkw_fused_table T) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// final net states: one instance per lane.  The walk is the frame discipline of the reference sinks:
+//   query            -> history;  writes also push a pending rollback          (storage.rs:100-118, event_sink.rs:140-151)
+//   start_frame      -> remember the rollback-stack heights                    (storage.rs:140-143, event_sink.rs:152-155)
+//   finish_frame ok  -> the frame's pending rollbacks now belong to its parent (storage.rs:181-185, event_sink.rs:170-174)
+//   finish_frame bad -> they are appended to the history in reverse order      (storage.rs:176-180, event_sink.rs:166-169)
+// What is left on the event rollback stack at the end is exactly what InMemoryEventSink::flatten keeps
+// (event_sink.rs:84-96: insert on forward, remove on rollback, sort by timestamp = emission order).
+// ---------------------------------------------------------------------------------------------
+__global__ void zkw_netstate_kernel(zkw_fused_table T) {
+  const zkw_netstate_params ZKW_CONST_AS& N = *(const zkw_netstate_params ZKW_CONST_AS*)T.p[blockIdx.y];
+  const u32 wave = blockIdx.x;
+  const u32 lane = threadIdx.x;
+  const u32 inst = wave * N.L + lane;
+  if (wave >= N.n_waves || lane >= N.L || inst >= N.n_instances) return;
+  u32* outc = N.out_counts + (u64)inst * 4;
+  const u32 status = N.scalars[inst].status;
+  if (status >= ZKW_STATUS_UNKNOWN_CODE_HASH) {
+    outc[0] = 0; outc[1] = 0; outc[2] = 0; outc[3] = 2u;  // failed instance: no net state
+    return;
+  }
+  const u32 n_cyc = N.scalars[inst].n_cycles;
+  const u32* lidx = N.log_idx + (u64)inst * N.per_log;
+  const u32* aidx = N.aux_idx + (u64)inst * N.per_aux;
+  const u32 n_l = N.log_cnt[inst], n_a = N.aux_cnt[inst];
+  u32* st_hist = N.st_hist + (u64)inst * N.hist_cap;
+  u32* ev_hist = N.ev_hist + (u64)inst * N.hist_cap;
+  u32* rb_st = N.rb_st + (u64)inst * N.per_log;
+  u32* rb_ev = N.rb_ev + (u64)inst * N.per_log;
+  u32* marks = N.marks + (u64)inst * N.mark_cap * 2;
+  u32 n_sh = 0, n_eh = 0, n_rs = 0, n_re = 0, n_mk = 0, li = 0, ai = 0, flags = 0;
+  if (n_l >= N.per_log || n_a >= N.per_aux) flags |= 1u;  // an index list was clipped: the walk would be incomplete
+  // frames that were already open when the batch took over (push_bootloader_context / initial callstack depth)
+  const u32 depth0 = N.scalars0[inst].depth;
+  for (u32 d = 0; d < depth0 && n_mk < N.mark_cap; d++) {
+    marks[2 * n_mk] = 0; marks[2 * n_mk + 1] = 0;
+    n_mk++;
+  }
+  const uint4* lbase = N.log_stream + (u64)wave * N.cap_log * 8;
+  const uint4* abase = N.aux_stream + (u64)wave * N.cap_aux * 16;
+  for (u32 c = 0; c < n_cyc && !flags; c++) {
+    const u32 cnt = N.rec[(((u64)wave * N.max_cycles + c) * ZKW_REC_CHUNKS + 31) * N.L + lane].w;
+    u32 nl = (cnt >> 8) & 0xffu, na = (cnt >> 16) & 0xffu;
+    while ((nl || na) && !flags) {
+      // next record of this cycle by in-cycle sequence number (SURVEY Appendix A order)
+      u32 lseq = 0xffffffffu, aseq = 0xffffffffu, lp = 0, ap = 0;
+      uint4 l7 = make_uint4(0, 0, 0, 0), a0 = make_uint4(0, 0, 0, 0);
+      if (nl && li < n_l) { lp = lidx[li]; l7 = lbase[(u64)lp * 8 + 7]; lseq = l7.w >> 24; }
+      if (na && ai < n_a) { ap = aidx[ai]; a0 = abase[(u64)ap * 16]; aseq = (a0.x >> 16) & 0xffu; }
+      if (lseq == 0xffffffffu && aseq == 0xffffffffu) { flags |= 1u; break; }
+      if (lseq <= aseq) {
+        li++; nl--;
+        const u32 kind = (l7.w >> 8) & 0xffu;
+        if (kind != ZKW_LQ_LOG) continue;  // refund records are witness only
+        const u32 aux_byte = (l7.z >> 16) & 0xffu;
+        const bool rw = (l7.w & ZKW_LQ_RW) != 0;
+        if (aux_byte == N.storage_aux_byte) {
+          if (n_sh >= N.hist_cap) { flags |= 1u; break; }
+          st_hist[n_sh++] = lp;
+          if (rw) rb_st[n_rs++] = lp;  // n_rs <= number of log records <= per_log
+        } else if (aux_byte == N.event_aux_byte || aux_byte == N.l1_aux_byte) {
+          if (n_eh >= N.hist_cap) { flags |= 1u; break; }
+          ev_hist[n_eh++] = lp;
+          rb_ev[n_re++] = lp;
+        }
+      } else {
+        ai++; na--;
+        const u32 type = a0.x & 0xffu;
+        if (type == ZKW_AUX_FRAME_START) {
+          if (n_mk >= N.mark_cap) { flags |= 1u; break; }
+          marks[2 * n_mk] = n_rs; marks[2 * n_mk + 1] = n_re;
+          n_mk++;
+        } else if (type == ZKW_AUX_FRAME_FINISH) {
+          if (n_mk == 0) { flags |= 1u; break; }
+          n_mk--;
+          const bool panicked = ((a0.x >> 24) & 0xffu) != 0;
+          if (panicked) {
+            const u32 ms = marks[2 * n_mk], me = marks[2 * n_mk + 1];
+            if (n_sh + (n_rs - ms) > N.hist_cap || n_eh + (n_re - me) > N.hist_cap) { flags |= 1u; break; }
+            while (n_rs > ms) st_hist[n_sh++] = rb_st[--n_rs] | 0x80000000u;
+            while (n_re > me) ev_hist[n_eh++] = rb_ev[--n_re] | 0x80000000u;
+          }
+        }
+      }
+    }
+  }
+  outc[0] = n_sh; outc[1] = n_eh; outc[2] = n_re; outc[3] = flags;
+}
+
 extern "C" hipError_t zkw_launch_commit(const zkw_fused_table* T, int stage, hipStream_t stream) {
   const u32 wt = T->wave_threads;
   if (stage == ZKW_COMMIT_STAGE_LEAF) {
@@ -361,6 +451,8 @@ extern "C" hipError_t zkw_launch_commit(const zkw_fused_table* T, int stage, hip
     hipLaunchKernelGGL(zkw_bucket_kernel, dim3(T->max_waves, T->n), dim3(wt), 0, stream, *T);
   } else if (stage == ZKW_COMMIT_STAGE_CHAIN) {
     hipLaunchKernelGGL(zkw_chain_kernel, dim3(T->max_waves, T->n), dim3(wt), 0, stream, *T);
+  } else if (stage == ZKW_COMMIT_STAGE_NETSTATE) {
+    hipLaunchKernelGGL(zkw_netstate_kernel, dim3(T->max_waves, T->n), dim3(wt), 0, stream, *T);
   } else {
     const u32 threads = wt > 1 ? 64 : 1;
     hipLaunchKernelGGL(zkw_blob_chain_kernel, dim3((T->n_blobs + threads - 1) / threads), dim3(threads), 0, stream, *T);

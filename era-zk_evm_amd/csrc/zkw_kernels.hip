@@ -425,6 +425,7 @@ ZD void access_storage(ZKW_KP P, Shared& sh, Lane& s, LogQ& q) {
     }
     j->slot = slot;
     s.journal_len++;
+    e->shard_state |= 0x400u;  // the key now exists in the reference's `inner` map and stays there across rollbacks
   } else {
     q.written_value = q.read_value;
   }

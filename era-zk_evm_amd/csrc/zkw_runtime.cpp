@@ -148,6 +148,16 @@ struct zkw_batch {
   float kernel_ms = 0;
   zkw_kparams kp;            // host copy of the parameter block
   DevBuf<zkw_kparams> d_kp;  // device copy the kernels read (constant address space)
+  // final net states (zkw_batch_net_states)
+  DevBuf<uint32_t> d_ns_log_idx, d_ns_log_cnt, d_ns_aux_idx, d_ns_aux_cnt, d_ns_st_hist, d_ns_ev_hist, d_ns_rb_st, d_ns_rb_ev, d_ns_marks, d_ns_counts;
+  DevBuf<zkw_commit_params> d_ns_bucket_params;  // [2]: log stream, aux stream (every type)
+  DevBuf<zkw_netstate_params> d_ns_params;       // [1]
+  bool ns_done = false;
+  uint32_t ns_cached_wave = 0xffffffffu;
+  std::vector<zkw_log_query> ns_wave_log;
+  std::vector<zkw_log_query> ns_st_hist, ns_ev_hist;
+  std::vector<zkw_event_message> ns_events, ns_l1;
+  std::vector<zkw_storage_slot> ns_final;
   DevBuf<zkw_reset_params> d_reset_params;    // [1]
   DevBuf<zkw_commit_params> d_commit_params;  // [ZKW_QUEUE_COUNT] + [1] for the blob digests of the upload
 };
@@ -275,7 +285,10 @@ void zkw_batch_destroy(zkw_batch* b) {
   b->d_regs.release(); b->d_scalars.release(); b->d_callstack.release(); b->d_frames.release(); b->d_storage.release(); b->d_journal.release();
   b->d_history.release(); b->d_stack_vals.release(); b->d_heap.release(); b->d_aux.release(); b->d_stack_ptrs.release(); b->d_blob_words.release();
   b->d_blob_dir.release(); b->d_preimages.release(); b->d_rec.release(); b->d_mem.release(); b->d_log.release(); b->d_auxs.release();
-  b->d_dir.release(); b->d_cursors.release(); b->d_krow.release(); b->d_kp.release(); b->d_reset_params.release(); b->d_commit_params.release(); b->d_commit.release(); b->d_rc.release(); b->d_blob_digests.release(); b->d_leaves.release();
+  b->d_dir.release(); b->d_cursors.release(); b->d_krow.release(); b->d_kp.release(); b->d_reset_params.release(); b->d_commit_params.release();
+  b->d_ns_log_idx.release(); b->d_ns_log_cnt.release(); b->d_ns_aux_idx.release(); b->d_ns_aux_cnt.release(); b->d_ns_st_hist.release();
+  b->d_ns_ev_hist.release(); b->d_ns_rb_st.release(); b->d_ns_rb_ev.release(); b->d_ns_marks.release(); b->d_ns_counts.release();
+  b->d_ns_bucket_params.release(); b->d_ns_params.release(); b->d_commit.release(); b->d_rc.release(); b->d_blob_digests.release(); b->d_leaves.release();
   b->d_idx.release(); b->d_counts.release();
   if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
   if (b->graph) (void)hipGraphDestroy(b->graph);
@@ -558,7 +571,7 @@ int zkw_batch_upload(zkw_batch* b) {
           std::memcpy(e.key, key, 32);
           std::memcpy(e.address, addr, 20);
           std::memcpy(e.value, sl.value.l, 32);
-          e.shard_state = sl.shard_id | 0x100u;
+          e.shard_state = sl.shard_id | 0x100u | 0x400u;  // occupied + present in the reference's `inner` map
           break;
         }
         pos = (pos + 1) & mask;
@@ -710,6 +723,8 @@ static int enqueue_reset(zkw_batch* const* bs, uint32_t n, hipStream_t st) {
     b->cycles_run = 0;
     b->ran = false;
     b->synced = false;
+    b->ns_done = false;
+    b->ns_cached_wave = 0xffffffffu;
     b->wave_cache.clear();
   }
   return ZKW_OK;
@@ -749,6 +764,8 @@ static int enqueue_run(zkw_batch* const* bs, uint32_t n, uint32_t max_cycles, hi
     b->cycles_run += max_cycles;
     b->ran = true;
     b->synced = false;
+    b->ns_done = false;
+    b->ns_cached_wave = 0xffffffffu;
     b->wave_cache.clear();
   }
   return ZKW_OK;
@@ -988,6 +1005,151 @@ int zkw_batch_commit(zkw_batch* b, uint32_t queue_mask, void* hip_stream) {
   return enqueue_commit(&b, 1, queue_mask, (hipStream_t)hip_stream);
 }
 
+int zkw_batch_net_states(zkw_batch* b, void* hip_stream) {
+  if (!b) return ZKW_ERR_INVALID;
+  zkw_ctx* c = b->ctx;
+  if (!b->uploaded) return ZKW_ERR_INVALID;
+  if (!b->ran) return ZKW_ERR_NOT_RUN;
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t per_log = b->lim.max_log_queries, per_aux = b->lim.max_aux_events, mark_cap = b->lim.max_callstack_depth + 2;
+  if (!b->d_ns_params.p) {  // first use: buffers + parameter blocks (constant until the next upload)
+    HIP_TRY(c, b->d_ns_log_idx.alloc((size_t)b->n * per_log));
+    HIP_TRY(c, b->d_ns_log_cnt.alloc(b->n));
+    HIP_TRY(c, b->d_ns_aux_idx.alloc((size_t)b->n * per_aux));
+    HIP_TRY(c, b->d_ns_aux_cnt.alloc(b->n));
+    HIP_TRY(c, b->d_ns_st_hist.alloc((size_t)b->n * 2 * per_log));
+    HIP_TRY(c, b->d_ns_ev_hist.alloc((size_t)b->n * 2 * per_log));
+    HIP_TRY(c, b->d_ns_rb_st.alloc((size_t)b->n * per_log));
+    HIP_TRY(c, b->d_ns_rb_ev.alloc((size_t)b->n * per_log));
+    HIP_TRY(c, b->d_ns_marks.alloc((size_t)b->n * mark_cap * 2));
+    HIP_TRY(c, b->d_ns_counts.alloc((size_t)b->n * 4));
+    zkw_commit_params CP[2];
+    std::memset(CP, 0, sizeof CP);
+    for (int k = 0; k < 2; k++) {
+      zkw_commit_params& C = CP[k];
+      C.n_instances = b->n; C.L = b->L; C.n_waves = b->n_waves; C.max_cycles = b->lim.max_cycles; C.wave_threads = (uint32_t)c->wave_width;
+      C.cursors = b->d_cursors.p; C.dir = b->d_dir.p; C.scalars = b->d_scalars.p;
+    }
+    CP[0].queue = ZKW_QUEUE_LOG; CP[0].cap = b->cap_log; CP[0].per_instance_cap = per_log; CP[0].stream = b->d_log.p;
+    CP[0].idx = b->d_ns_log_idx.p; CP[0].counts = b->d_ns_log_cnt.p;
+    CP[1].queue = ZKW_QUEUE_DECOMMIT; CP[1].cap = b->cap_aux; CP[1].per_instance_cap = per_aux; CP[1].stream = b->d_auxs.p;
+    CP[1].idx = b->d_ns_aux_idx.p; CP[1].counts = b->d_ns_aux_cnt.p; CP[1].aux_type_mask = 0xffffffffu;
+    HIP_TRY(c, b->d_ns_bucket_params.alloc(2));
+    HIP_TRY(c, hipMemcpy(b->d_ns_bucket_params.p, CP, sizeof CP, hipMemcpyHostToDevice));
+    zkw_netstate_params N;
+    std::memset(&N, 0, sizeof N);
+    N.n_instances = b->n; N.L = b->L; N.n_waves = b->n_waves; N.max_cycles = b->lim.max_cycles; N.wave_threads = (uint32_t)c->wave_width;
+    N.cap_log = b->cap_log; N.cap_aux = b->cap_aux; N.per_log = per_log; N.per_aux = per_aux; N.hist_cap = 2 * per_log; N.mark_cap = mark_cap;
+    N.storage_aux_byte = c->isa.consts.storage_aux_byte; N.event_aux_byte = c->isa.consts.event_aux_byte; N.l1_aux_byte = c->isa.consts.l1_message_aux_byte;
+    N.rec = b->d_rec.p; N.log_stream = b->d_log.p; N.aux_stream = b->d_auxs.p; N.scalars = b->d_scalars.p; N.scalars0 = b->d_scalars0.p;
+    N.log_idx = b->d_ns_log_idx.p; N.log_cnt = b->d_ns_log_cnt.p; N.aux_idx = b->d_ns_aux_idx.p; N.aux_cnt = b->d_ns_aux_cnt.p;
+    N.st_hist = b->d_ns_st_hist.p; N.ev_hist = b->d_ns_ev_hist.p; N.rb_st = b->d_ns_rb_st.p; N.rb_ev = b->d_ns_rb_ev.p; N.marks = b->d_ns_marks.p;
+    N.out_counts = b->d_ns_counts.p;
+    HIP_TRY(c, b->d_ns_params.alloc(1));
+    HIP_TRY(c, hipMemcpy(b->d_ns_params.p, &N, sizeof N, hipMemcpyHostToDevice));
+  }
+  zkw_fused_table T;
+  std::memset(&T, 0, sizeof T);
+  T.n = 1; T.max_waves = b->n_waves; T.wave_threads = (uint32_t)c->wave_width;
+  T.p[0] = b->d_ns_bucket_params.p;
+  HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_BUCKET, st));
+  T.p[0] = b->d_ns_bucket_params.p + 1;
+  HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_BUCKET, st));
+  T.p[0] = b->d_ns_params.p;
+  HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_NETSTATE, st));
+  b->run_stream = st;
+  b->ns_done = true;
+  b->ns_cached_wave = 0xffffffffu;
+  return ZKW_OK;
+}
+
+int zkw_batch_get_net_state(zkw_batch* b, uint32_t instance, zkw_net_state* out) {
+  if (!b || !out || instance >= b->n) return ZKW_ERR_INVALID;
+  zkw_ctx* c = b->ctx;
+  if (!b->ns_done) {
+    int rc = zkw_batch_net_states(b, b->run_stream);
+    if (rc != ZKW_OK) return rc;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(b->run_stream));
+  std::memset(out, 0, sizeof *out);
+  uint32_t cnt[4];
+  HIP_TRY(c, hipMemcpy(cnt, b->d_ns_counts.p + (size_t)instance * 4, sizeof cnt, hipMemcpyDeviceToHost));
+  if (cnt[3] & 2u) {
+    c->last_error = "instance failed: no net state";
+    return ZKW_ERR_INVALID;
+  }
+  if (cnt[3] & 1u) {
+    c->last_error = "net state: per-instance index capacity exceeded (limits.max_log_queries / max_aux_events / max_callstack_depth)";
+    return ZKW_ERR_LIMIT;
+  }
+  const uint32_t w = instance / b->L, per_log = b->lim.max_log_queries;
+  if (b->ns_cached_wave != w) {  // the wave's log stream, once per wave
+    uint32_t cur[4];
+    HIP_TRY(c, hipMemcpy(cur, b->d_cursors.p + (size_t)w * 4, sizeof cur, hipMemcpyDeviceToHost));
+    const uint32_t n_log = std::min(cur[1], b->cap_log);
+    b->ns_wave_log.resize(n_log);
+    if (n_log) HIP_TRY(c, hipMemcpy(b->ns_wave_log.data(), b->d_log.p + (size_t)w * b->cap_log * 8, (size_t)n_log * sizeof(zkw_log_query), hipMemcpyDeviceToHost));
+    b->ns_cached_wave = w;
+  }
+  std::vector<uint32_t> sh(cnt[0]), eh(cnt[1]), ne(cnt[2]);
+  if (cnt[0]) HIP_TRY(c, hipMemcpy(sh.data(), b->d_ns_st_hist.p + (size_t)instance * 2 * per_log, (size_t)cnt[0] * 4, hipMemcpyDeviceToHost));
+  if (cnt[1]) HIP_TRY(c, hipMemcpy(eh.data(), b->d_ns_ev_hist.p + (size_t)instance * 2 * per_log, (size_t)cnt[1] * 4, hipMemcpyDeviceToHost));
+  if (cnt[2]) HIP_TRY(c, hipMemcpy(ne.data(), b->d_ns_rb_ev.p + (size_t)instance * per_log, (size_t)cnt[2] * 4, hipMemcpyDeviceToHost));
+  auto materialise = [&](const std::vector<uint32_t>& idx, std::vector<zkw_log_query>& dst) {
+    dst.resize(idx.size());
+    for (size_t k = 0; k < idx.size(); k++) {
+      zkw_log_query q = b->ns_wave_log[idx[k] & 0x7fffffffu];
+      q.lane = 0; q.seq = 0; q.kind = 0;
+      // the storage keeps a read as it arrived (written_value = 0: log.rs:175, far_call.rs:139); "written := read" is a
+      // convention of access_storage for the witness tracer only (helpers.rs:143-146)
+      if (!(q.bools & ZKW_LQ_RW)) std::memset(&q.written_value, 0, sizeof q.written_value);
+      if (idx[k] & 0x80000000u) q.bools |= ZKW_LQ_ROLLBACK;
+      dst[k] = q;
+    }
+  };
+  materialise(sh, b->ns_st_hist);
+  materialise(eh, b->ns_ev_hist);
+  b->ns_events.clear();
+  b->ns_l1.clear();
+  for (uint32_t p : ne) {
+    const zkw_log_query& q = b->ns_wave_log[p];
+    zkw_event_message m;
+    std::memset(&m, 0, sizeof m);
+    m.shard_id = q.shard_id; m.is_first = (q.bools & ZKW_LQ_IS_SERVICE) ? 1 : 0; m.tx_number_in_block = q.tx_number_in_block;
+    std::memcpy(m.address, q.address, 20);
+    m.key = q.key; m.value = q.written_value;
+    (q.aux_byte == c->isa.consts.event_aux_byte ? b->ns_events : b->ns_l1).push_back(m);
+  }
+  // final storage: the instance's table, entries that exist in the reference's `inner` map
+  std::vector<zkw_dev_storage_entry> tab(b->lim.storage_slots);
+  HIP_TRY(c, hipMemcpy(tab.data(), b->d_storage.p + (size_t)instance * b->lim.storage_slots, tab.size() * sizeof(zkw_dev_storage_entry), hipMemcpyDeviceToHost));
+  b->ns_final.clear();
+  for (const zkw_dev_storage_entry& e : tab) {
+    if ((e.shard_state & 0x500u) != 0x500u) continue;
+    zkw_storage_slot sl;
+    std::memset(&sl, 0, sizeof sl);
+    std::memcpy(sl.key.l, e.key, 32); std::memcpy(sl.value.l, e.value, 32);
+    std::memcpy(sl.address, e.address, 20);  // same byte image as zkw_storage_slot / zkw_log_query
+    sl.shard_id = (uint8_t)(e.shard_state & 0xffu);
+    b->ns_final.push_back(sl);
+  }
+  std::sort(b->ns_final.begin(), b->ns_final.end(), [](const zkw_storage_slot& x, const zkw_storage_slot& y) {
+    if (x.shard_id != y.shard_id) return x.shard_id < y.shard_id;
+    int ca = std::memcmp(x.address, y.address, 20);
+    if (ca) return ca < 0;
+    for (int k = 3; k >= 0; k--)
+      if (x.key.l[k] != y.key.l[k]) return x.key.l[k] < y.key.l[k];
+    return false;
+  });
+  out->n_storage_history = (uint32_t)b->ns_st_hist.size(); out->n_event_history = (uint32_t)b->ns_ev_hist.size();
+  out->n_events = (uint32_t)b->ns_events.size(); out->n_l1_messages = (uint32_t)b->ns_l1.size(); out->n_final_storage = (uint32_t)b->ns_final.size();
+  out->storage_history = b->ns_st_hist.data(); out->event_history = b->ns_ev_hist.data(); out->events = b->ns_events.data();
+  out->l1_messages = b->ns_l1.data(); out->final_storage = b->ns_final.data();
+  return ZKW_OK;
+}
+
 int zkw_batch_get_commitments(zkw_batch* b, uint64_t* out) {
   if (!b || !out) return ZKW_ERR_INVALID;
   zkw_ctx* c = b->ctx;
@@ -1011,6 +1173,8 @@ int zkw_batch_step(zkw_batch* b, uint32_t max_cycles, uint32_t queue_mask, void*
     b->wave_cache.clear();
     b->run_stream = st;
     b->pending_runs = 1;  // the captured run uses event pair 0
+    b->ns_done = false;
+    b->ns_cached_wave = 0xffffffffu;
     return ZKW_OK;
   }
   // eager pass first: validates arguments and performs every lazy allocation outside of stream capture
@@ -1084,6 +1248,8 @@ uint32_t zkw_abi_sizeof(uint32_t which) {
     case 10: return sizeof(zkw_instance_trace);
     case 11: return sizeof(zkw_run_stats);
     case 12: return sizeof(zkw_isa_consts);
+    case 13: return sizeof(zkw_event_message);
+    case 14: return sizeof(zkw_net_state);
     default: return 0;
   }
 }

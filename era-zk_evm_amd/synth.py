@@ -765,5 +765,63 @@ def config4(isa, n_instances=4096, n_cycles=1024, seed=0x5EED0004):
     return wl
 
 
+# ----------------------------------------------------------------------------------------
+# nested near-call frames with storage writes / events / L1 messages and every ok / revert / panic
+# combination — the frame discipline get_final_net_states depends on (testing/storage.rs:144-186,
+# reference_impls/event_sink.rs:160-176)
+# ----------------------------------------------------------------------------------------
+def nested_frames(isa, outer=K.RET_OK, inner=K.RET_OK, main_panics=False, n_instances=3, n_cycles=40, seed=0x5EED00F2):
+    wl = Workload("nested_frames_%d_%d_%d" % (outer, inner, int(main_panics)), n_instances, n_cycles)
+    A, B = 16, 32
+    e = isa.enc
+    ops = [e(K.OP_NOP)] * 48
+    def key(k):
+        return e(K.OP_ADD, src0_mode=K.MODE_IMM, imm0=k, src1=0, dst0=11)
+    ops[0] = e(K.OP_ADD, src0_mode=K.MODE_IMM, imm0=0, src1=0, dst0=10)  # near_call with 0 ergs = pass everything
+    ops[1] = e(K.OP_NEAR_CALL, src0=10, imm0=A, imm1=2)
+    ops[2] = e(K.OP_LOG, variant=K.LOG_EVENT, flags=1, src0=1, src1=2)
+    ops[3] = key(5)
+    ops[4] = e(K.OP_LOG, variant=K.LOG_STORAGE_WRITE, src0=11, src1=3)
+    ops[5] = e(K.OP_LOG, variant=K.LOG_STORAGE_READ, src0=11, src1=0, dst0=4)
+    ops[6] = e(K.OP_LOG, variant=K.LOG_TO_L1, flags=0, src0=4, src1=5)
+    ops[7] = key(1)
+    ops[8] = e(K.OP_LOG, variant=K.LOG_STORAGE_READ, src0=11, src1=0, dst0=6)
+    ops[9] = e(K.OP_RET, variant=K.RET_PANIC) if main_panics else e(K.OP_JUMP, src0_mode=K.MODE_IMM, imm0=9)  # park
+    # A: write key 1, event, call B, event, write key 1 again, write absent key 2, return
+    ops[A + 0] = key(1)
+    ops[A + 1] = e(K.OP_LOG, variant=K.LOG_STORAGE_WRITE, src0=11, src1=5)
+    ops[A + 2] = e(K.OP_LOG, variant=K.LOG_EVENT, flags=0, src0=2, src1=3)
+    ops[A + 3] = e(K.OP_ADD, src0_mode=K.MODE_IMM, imm0=0, src1=0, dst0=10)
+    ops[A + 4] = e(K.OP_NEAR_CALL, src0=10, imm0=B, imm1=A + 5)
+    ops[A + 5] = e(K.OP_LOG, variant=K.LOG_EVENT, flags=0, src0=3, src1=4)
+    ops[A + 6] = e(K.OP_LOG, variant=K.LOG_STORAGE_WRITE, src0=11, src1=6)
+    ops[A + 7] = key(2)
+    ops[A + 8] = e(K.OP_LOG, variant=K.LOG_STORAGE_WRITE, src0=11, src1=7)
+    ops[A + 9] = e(K.OP_RET, variant=outer, flags=0, src0=0)
+    # B: overwrite key 1, event, L1 message, return
+    ops[B + 0] = key(1)
+    ops[B + 1] = e(K.OP_LOG, variant=K.LOG_STORAGE_WRITE, src0=11, src1=8)
+    ops[B + 2] = e(K.OP_LOG, variant=K.LOG_EVENT, flags=1, src0=5, src1=6)
+    ops[B + 3] = e(K.OP_LOG, variant=K.LOG_TO_L1, flags=1, src0=6, src1=7)
+    ops[B + 4] = e(K.OP_RET, variant=inner, flags=0, src0=0)
+    wl.blobs.append(K.pack_code(ops))
+    wl.code_pages.append((0, n_instances, BOOTLOADER_CODE_PAGE, 0))
+    vals = Xoshiro(seed ^ 0x5107, n_instances).words(2)
+    wl.storage = []
+    for i in range(n_instances):
+        sl = np.zeros(2, dtype=K.STORAGE_SLOT)
+        for j, k in enumerate((1, 5)):
+            sl[j]["key"] = K.u256_from_int(k)
+            sl[j]["value"] = vals[i][j]
+            sl[j]["address"] = K.address_bytes(KERNEL_ADDRESS)
+        wl.storage.append(sl)
+    regs = Xoshiro(seed ^ 0xABCDEF, n_instances).words(15)
+    wl.states, wl.inner = initial_states(n_instances, regs)
+    wl.states["current_ergs_per_pubdata_byte"] = 3
+    wl.limits.update(max_far_frames=2, max_callstack_depth=6, heap_words=8, stack_words=8, aux_heap_words=8, storage_slots=16, storage_journal=16,
+                     max_log_queries=64, max_aux_events=32)
+    return wl
+
+
 def make(cfg, isa, **kw):  # noqa: F811
     return {0: config0, 1: config1, 2: config2, 3: config3, 4: config4}[cfg](isa, **kw)

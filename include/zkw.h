@@ -457,6 +457,41 @@ int zkw_batch_copy_commitments(zkw_batch* batch, void* dst_device, void* hip_str
 /* device pointer (n_instances * ZKW_QUEUE_COUNT * 4 u64) for the RCCL all-gather */
 int zkw_batch_commitments_device_ptr(zkw_batch* batch, void** dptr, uint64_t* n_bytes);
 
+/* ---- final net states: what the reference's get_final_net_states (testing/mod.rs:42-71) returns ----
+ * The device nets the log stream of every instance against its frame events exactly like
+ * InMemoryStorage::finish_frame / flatten_and_net_history (testing/storage.rs:34-76,144-186) and
+ * InMemoryEventSink::finish_frame / flatten (reference_impls/event_sink.rs:66-131,160-176) do on the host: the access
+ * history is the chronological list of queries with, at the finish of every panicked frame, that frame's pending
+ * rollback entries appended in reverse order (rollback flag set); net events / L1 messages are the event queries that
+ * were never rolled back, in timestamp order.  Instances that are still running are netted as if their open frames
+ * were kept.  Failed instances (status >= ZKW_STATUS_UNKNOWN_CODE_HASH) have no net state. */
+typedef struct zkw_event_message { /* EventMessage, reference_impls/event_sink.rs:7-14 */
+  uint8_t shard_id;
+  uint8_t is_first;            /* = LogQuery.is_service */
+  uint16_t tx_number_in_block;
+  uint8_t address[20];
+  zkw_u256 key;
+  zkw_u256 value;              /* = LogQuery.written_value */
+} zkw_event_message;           /* 88 B */
+
+typedef struct zkw_net_state {
+  uint32_t n_storage_history, n_event_history, n_events, n_l1_messages, n_final_storage, reserved0;
+  const zkw_log_query* storage_history; /* full_storage_access_history; lane / seq / kind are zero, ZKW_LQ_ROLLBACK marks rollback entries, reads carry written_value = 0 (what the Storage saw: log.rs:175, far_call.rs:139) */
+  const zkw_log_query* event_history;   /* events_log_history, same conventions */
+  const zkw_event_message* events;      /* aux_byte == event_aux_byte */
+  const zkw_event_message* l1_messages; /* every other surviving event-sink query (event_sink.rs:124-128) */
+  const zkw_storage_slot* final_storage; /* final_storage_state: populated or written slots, sorted by (shard, address, key) */
+} zkw_net_state;
+
+/* enqueues the netting pass over the finished run on `stream` (bucket passes over the log / aux streams + one
+ * sequential walk per instance, one instance per lane) */
+int zkw_batch_net_states(zkw_batch* batch, void* hip_stream);
+/* downloads and materialises the net state of one instance (library-owned arrays, valid until the next call for this
+ * batch); runs zkw_batch_net_states first if it has not been run since the last run.  ZKW_ERR_LIMIT if the instance
+ * overflowed its per-instance index capacity (limits.max_log_queries / max_aux_events), ZKW_ERR_INVALID for a failed
+ * instance. */
+int zkw_batch_get_net_state(zkw_batch* batch, uint32_t instance, zkw_net_state* out);
+
 /* sizeof() of the ABI structs as compiled into the library (binding self-check) */
 uint32_t zkw_abi_sizeof(uint32_t which);
 

@@ -19,6 +19,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <map>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -659,6 +660,24 @@ struct InMemoryStorage {
   }
 };
 
+// InMemoryStorage::flatten_and_net_history (testing/storage.rs:34-76), first component: the keeper frame's `forward`.
+// The reference asserts frames_stack.len() == 1; for an instance that is still running the open frames are
+// concatenated bottom-up, which is what the keeper's `forward` would become if every open frame were kept
+// (storage.rs:181-185) — identical to the reference whenever it does not panic.
+inline std::vector<LogQuery> flatten_history(const std::vector<ApplicationData>& frames_stack) {
+  std::vector<LogQuery> history;
+  for (const ApplicationData& f : frames_stack) history.insert(history.end(), f.forward.begin(), f.forward.end());
+  return history;
+}
+
+struct EventMessage {  // event_sink.rs:7-14
+  uint8_t shard_id;
+  bool is_first;
+  uint16_t tx_number_in_block;
+  Address address;
+  U256 key, value;
+};
+
 struct InMemoryEventSink {  // event_sink.rs:51-56, 134-176
   std::vector<ApplicationData> frames_stack;
   InMemoryEventSink() { frames_stack.emplace_back(); }
@@ -671,6 +690,28 @@ struct InMemoryEventSink {  // event_sink.rs:51-56, 134-176
     f.forward.push_back(query);
     query.rollback = true;
     f.rollbacks.push_back(query);
+  }
+  // flatten (event_sink.rs:66-131): net the forward history by timestamp, then split by aux byte
+  void flatten(uint8_t event_aux, std::vector<LogQuery>* history, std::vector<EventMessage>* events, std::vector<EventMessage>* l1_messages) const {
+    *history = flatten_history(frames_stack);
+    std::map<uint32_t, LogQuery> tmp;  // :81 HashMap<u32, LogQuery>; the keys are sorted afterwards (:99-100)
+    for (const LogQuery& el : *history) {
+      auto it = tmp.find(el.timestamp);
+      if (it != tmp.end()) {
+        REF_ASSERT(el.rollback, "event_sink.rs:88");
+        tmp.erase(it);
+      } else {
+        REF_ASSERT(!el.rollback, "event_sink.rs:91");
+        tmp.emplace(el.timestamp, el);
+      }
+    }
+    events->clear();
+    l1_messages->clear();
+    for (const auto& kv : tmp) {
+      const LogQuery& el = kv.second;
+      EventMessage m{el.shard_id, el.is_service, el.tx_number_in_block, el.address, el.key, el.written_value};
+      (el.aux_byte == event_aux ? *events : *l1_messages).push_back(m);  // :124-128
+    }
   }
   void start_frame(uint32_t) { frames_stack.emplace_back(); }
   void finish_frame(bool panicked, uint32_t) {

@@ -3,6 +3,7 @@
 // `zkwo_` prefix so that tests drive the oracle and the HIP library through the same
 // harness.  Instances run sequentially per thread ("one VmState per thread");
 // zkwo_batch_set_threads picks the worker count for the cpu_baseline leg of bench.py.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <thread>
@@ -28,6 +29,9 @@ struct StagedInstance {
 
 struct InstanceResult {
   uint32_t status = ZKW_STATUS_RUNNING;
+  std::vector<zkw_log_query> ns_st_hist, ns_ev_hist;
+  std::vector<zkw_event_message> ns_events, ns_l1;
+  std::vector<zkw_storage_slot> ns_final;
   Recorder rec;
   zkw_vm_local_state final_state;
   std::string message;
@@ -301,6 +305,74 @@ int zkwo_batch_get_instance_trace(zkwo_batch* b, uint32_t instance, zkw_instance
   out->final_state = r.final_state;
   return ZKW_OK;
 }
+// ---- final net states: get_final_net_states (testing/mod.rs:42-71) restated on the oracle's own sinks ----
+static zkw_log_query net_log_to_c(const LogQuery& q) {
+  zkw_log_query o;
+  std::memset(&o, 0, sizeof o);
+  std::memcpy(o.key.l, q.key.l, 32); std::memcpy(o.read_value.l, q.read_value.l, 32); std::memcpy(o.written_value.l, q.written_value.l, 32);
+  std::memcpy(o.address, q.address.b, 20);
+  o.timestamp = q.timestamp; o.tx_number_in_block = q.tx_number_in_block; o.aux_byte = q.aux_byte; o.shard_id = q.shard_id;
+  o.bools = (uint8_t)((q.rw_flag ? ZKW_LQ_RW : 0) | (q.rollback ? ZKW_LQ_ROLLBACK : 0) | (q.is_service ? ZKW_LQ_IS_SERVICE : 0));
+  return o;
+}
+static zkw_event_message net_event_to_c(const EventMessage& e) {
+  zkw_event_message m;
+  std::memset(&m, 0, sizeof m);
+  m.shard_id = e.shard_id; m.is_first = e.is_first ? 1 : 0; m.tx_number_in_block = e.tx_number_in_block;
+  std::memcpy(m.address, e.address.b, 20);
+  std::memcpy(m.key.l, e.key.l, 32); std::memcpy(m.value.l, e.value.l, 32);
+  return m;
+}
+int zkwo_batch_net_states(zkwo_batch* b, void*) { return b->ran ? ZKW_OK : ZKW_ERR_NOT_RUN; }
+int zkwo_batch_get_net_state(zkwo_batch* b, uint32_t instance, zkw_net_state* out) {
+  if (!b->ran) return ZKW_ERR_NOT_RUN;
+  if (instance >= b->n) return ZKW_ERR_INVALID;
+  InstanceResult& r = b->results[instance];
+  if (r.status >= ZKW_STATUS_UNKNOWN_CODE_HASH) {
+    b->ctx->last_error = "instance failed: no net state";
+    return ZKW_ERR_INVALID;
+  }
+  Vm& vm = *b->vms[instance];
+  std::memset(out, 0, sizeof *out);
+  try {
+    r.ns_st_hist.clear();
+    for (const LogQuery& q : flatten_history(vm.storage.frames_stack)) r.ns_st_hist.push_back(net_log_to_c(q));
+    std::vector<LogQuery> eh;
+    std::vector<EventMessage> ev, l1;
+    vm.event_sink.flatten(vm.isa->consts.event_aux_byte, &eh, &ev, &l1);
+    r.ns_ev_hist.clear(); r.ns_events.clear(); r.ns_l1.clear();
+    for (const LogQuery& q : eh) r.ns_ev_hist.push_back(net_log_to_c(q));
+    for (const EventMessage& e : ev) r.ns_events.push_back(net_event_to_c(e));
+    for (const EventMessage& e : l1) r.ns_l1.push_back(net_event_to_c(e));
+  } catch (const RefPanic& e) {
+    b->ctx->last_error = std::string("net state: ") + e.what();
+    return ZKW_ERR_INVALID;
+  }
+  // final_storage_state = storage.inner.clone() (testing/mod.rs:58), in the canonical order of zkw.h
+  r.ns_final.clear();
+  for (const auto& kv : vm.storage.inner) {
+    zkw_storage_slot sl;
+    std::memset(&sl, 0, sizeof sl);
+    std::memcpy(sl.key.l, kv.first.key.l, 32); std::memcpy(sl.value.l, kv.second.l, 32);
+    std::memcpy(sl.address, kv.first.address.b, 20);
+    sl.shard_id = kv.first.shard_id;
+    r.ns_final.push_back(sl);
+  }
+  std::sort(r.ns_final.begin(), r.ns_final.end(), [](const zkw_storage_slot& x, const zkw_storage_slot& y) {
+    if (x.shard_id != y.shard_id) return x.shard_id < y.shard_id;
+    int ca = std::memcmp(x.address, y.address, 20);
+    if (ca) return ca < 0;
+    for (int k = 3; k >= 0; k--)
+      if (x.key.l[k] != y.key.l[k]) return x.key.l[k] < y.key.l[k];
+    return false;
+  });
+  out->n_storage_history = (uint32_t)r.ns_st_hist.size(); out->n_event_history = (uint32_t)r.ns_ev_hist.size();
+  out->n_events = (uint32_t)r.ns_events.size(); out->n_l1_messages = (uint32_t)r.ns_l1.size(); out->n_final_storage = (uint32_t)r.ns_final.size();
+  out->storage_history = r.ns_st_hist.data(); out->event_history = r.ns_ev_hist.data(); out->events = r.ns_events.data();
+  out->l1_messages = r.ns_l1.data(); out->final_storage = r.ns_final.data();
+  return ZKW_OK;
+}
+
 int zkwo_batch_enable_callback_log(zkwo_batch* b, int on) {
   b->callback_log = on != 0;
   return ZKW_OK;

@@ -27,7 +27,7 @@ def lib():
 def test_header_declares_the_documented_entry_points():
     names = _declared_functions()
     for must in ("zkw_ctx_create", "zkw_ctx_set_isa", "zkw_batch_create", "zkw_batch_set_state", "zkw_batch_upload", "zkw_batch_reset", "zkw_batch_run",
-                 "zkw_batch_step", "zkw_batches_step", "zkw_batch_sync", "zkw_batch_get_instance_trace", "zkw_batch_commit", "zkw_batch_get_commitments",
+                 "zkw_batch_step", "zkw_batches_step", "zkw_batch_sync", "zkw_batch_get_instance_trace", "zkw_batch_commit", "zkw_batch_get_commitments", "zkw_batch_net_states", "zkw_batch_get_net_state",
                  "zkw_isa_default", "zkw_abi_sizeof"):
         assert must in names
 
@@ -50,7 +50,8 @@ def test_struct_sizes_match_the_bindings(lib):
     lib.zkw_abi_sizeof.argtypes = [C.c_uint32]
     expect = {0: K.ISA_TABLE.itemsize, 1: K.CALLSTACK_ENTRY.itemsize, 2: K.VM_LOCAL_STATE.itemsize, 3: K.BLOCK_PROPERTIES.itemsize,
               4: K.STORAGE_SLOT.itemsize, 5: K.LIMITS.itemsize, 6: K.CYCLE_RECORD.itemsize, 7: K.MEM_QUERY.itemsize, 8: K.LOG_QUERY.itemsize,
-              9: K.AUX_EVENT.itemsize, 10: C.sizeof(K.InstanceTraceC), 11: K.RUN_STATS.itemsize, 12: K.ISA_CONSTS.itemsize}
+              9: K.AUX_EVENT.itemsize, 10: C.sizeof(K.InstanceTraceC), 11: K.RUN_STATS.itemsize, 12: K.ISA_CONSTS.itemsize,
+              13: K.EVENT_MESSAGE.itemsize, 14: C.sizeof(K.NetStateC)}
     for which, size in expect.items():
         assert lib.zkw_abi_sizeof(which) == size, which
     assert lib.zkw_abi_sizeof(99) == 0

@@ -218,3 +218,34 @@ def test_fused_step_of_several_batches(oracle, product, isa):
             ok, why = K.traces_equal(bo.trace(i), bp.trace(i))
             assert ok, (w.name, i, why)
         assert np.array_equal(bo.commitments(), bp.commitments()), w.name
+
+
+@pytest.mark.parametrize("outer,inner,main_panics", [(K.RET_OK, K.RET_OK, False), (K.RET_PANIC, K.RET_OK, False), (K.RET_OK, K.RET_REVERT, False),
+                                                     (K.RET_REVERT, K.RET_PANIC, False), (K.RET_OK, K.RET_OK, True)])
+def test_net_states_nested_frames(oracle, product, isa, outer, inner, main_panics):
+    """get_final_net_states on the device for nested near-call frames, 130 instances = 3 waves."""
+    wl = synth.nested_frames(isa, outer=outer, inner=inner, main_panics=main_panics, n_instances=130)
+    bo, bp = _run(oracle, wl), _run(product, wl)
+    for i in range(0, 130, 3):
+        ok, why = K.net_states_equal(bo.net_state(i), bp.net_state(i))
+        assert ok, (i, why)
+
+
+def test_net_states_l2_block(oracle, product, isa):
+    wl = synth.make(4, isa, n_instances=256)
+    bo, bp = _run(oracle, wl), _run(product, wl)
+    for i in range(0, 256, 5):
+        a, b = bo.net_state(i), bp.net_state(i)
+        ok, why = K.net_states_equal(a, b)
+        assert ok, (i, why)
+    assert len(a["storage_history"]) > 50 and len(a["events"]) > 10
+
+
+def test_net_states_partial_run(oracle, product, isa):
+    wl = synth.nested_frames(isa, outer=K.RET_PANIC, inner=K.RET_OK, n_instances=70)
+    for cycles in (5, 22, 27):
+        bo = oracle.create_batch(wl); bo.reset(); bo.run(cycles); bo.sync()
+        bp = product.create_batch(wl); bp.reset(); bp.run(cycles); bp.sync()
+        for i in (0, 63, 64, 69):
+            ok, why = K.net_states_equal(bo.net_state(i), bp.net_state(i))
+            assert ok, (cycles, i, why)
