@@ -30,7 +30,8 @@ def main():
     ap.add_argument("--cycles", type=int, default=256)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per wave (0 = library default)")
     ap.add_argument("--fuse", type=int, default=32, help="batches (steps) per fused launch (zkw_batches_step), <= 32")
-    ap.add_argument("--streams", type=int, default=1, help="fused groups in flight on separate HIP streams")
+    ap.add_argument("--streams", type=int, default=2, help="fused groups in flight (1 = everything on one stream; >= 2 = cycle kernels on the main stream, commitments + restores on side streams)")
+    ap.add_argument("--side", choices=["commit", "commit+reset"], default="commit", help="what the side streams carry when --streams >= 2")
     ap.add_argument("--cfg", type=int, default=2)
     ap.add_argument("--min-warmup-s", type=float, default=0.6, help="untimed warm-up is extended to at least this long (clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -86,16 +87,48 @@ def main():
     gathered = [torch.zeros((world * fuse, args.instances, 3, 4), dtype=torch.int64, device="cuda") if world > 1 else None for _ in range(n_groups)]
     digest_bytes = args.instances * 3 * 4 * 8
 
+    # Pipelining over streams (--streams >= 2): the main stream carries the restore + cycle kernel of every group, back
+    # to back; every group has a side stream that carries its commitment kernels (integer-ALU bound) and the digest
+    # exchange (--side commit+reset: also the restore for the group's next use), ordered by events.  The commitments
+    # therefore run in the shadow of the HBM-bound cycle kernel of another group, while the cycle kernels themselves
+    # stay serialised (their durations are inflated only by that side work, not by a second cycle kernel).
+    # Measured (profiles/r01_kernel_variants.md): 1 stream 6.2 G cycles/s, kernel at 0.76 of peak; commit on the side
+    # stream 6.8 G, kernel 0.66; commit + restore on the side stream 6.6 G, kernel 0.53.
+    main_stream = streams[0]
+    side_streams = [torch.cuda.Stream(device=local_rank) for _ in range(n_groups)]
+    ev_run = [torch.cuda.Event() for _ in range(n_groups)]
+    ev_ready = [torch.cuda.Event() for _ in range(n_groups)]
+    overlap = n_groups > 1
+    side_reset = args.side == "commit+reset"
+    group_used = [False] * n_groups  # the upload leaves every batch reset
+
     def launch(g, n):
-        """n <= fuse steps (batches) in one fused launch sequence on group g's stream"""
-        stream = streams[g]
-        sptr = stream.cuda_stream
-        prod.step_many(groups[g][:n], wl.n_cycles, args.commit_mask, sptr)
+        """n <= fuse steps (batches) in one fused launch sequence of group g"""
+        if not overlap:
+            stream = streams[g]
+            sptr = stream.cuda_stream
+            prod.step_many(groups[g][:n], wl.n_cycles, args.commit_mask, sptr)
+        else:
+            if group_used[g]:
+                main_stream.wait_event(ev_ready[g])  # the old streams consumed by the commitment (and the inputs restored)
+            group_used[g] = True
+            if not side_reset:
+                prod.reset_many(groups[g][:n], main_stream.cuda_stream)
+            prod.run_many(groups[g][:n], wl.n_cycles, main_stream.cuda_stream)
+            ev_run[g].record(main_stream)
+            stream = side_streams[g]
+            sptr = stream.cuda_stream
+            stream.wait_event(ev_run[g])
+            prod.commit_many(groups[g][:n], args.commit_mask, sptr)
         if args.commit_mask and world > 1:
             for j, b in enumerate(groups[g][:n]):
                 prod.call("batch_copy_commitments", b.h, C.c_void_p(digests[g].data_ptr() + j * digest_bytes), C.c_void_p(sptr))
             with torch.cuda.stream(stream):
                 dist.all_gather_into_tensor(gathered[g], digests[g])
+        if overlap:
+            if side_reset:
+                prod.reset_many(groups[g], sptr)  # the whole group, so that a later partial launch finds it restored
+            ev_ready[g].record(stream)
 
     def run_steps(k):
         g = 0
@@ -106,28 +139,45 @@ def main():
             k -= n
         return g
 
+    def drain_timing():
+        out = []
+        for g in groups:
+            ms, nl = C.c_double(0), C.c_uint32(0)
+            prod.call("batch_kernel_time", g[0].h, C.byref(ms), C.byref(nl))
+            if nl.value:
+                out.append(ms.value)
+        return out
+
     run_steps(max(args.warmup, fuse * n_groups))  # untimed: every group at least once
-    for b in batches:
-        b.sync()
+    for st_ in streams + side_streams:
+        st_.synchronize()
     # the GPU's clocks need a few hundred ms of load to settle (measured: the first launches of a fresh process run
     # ~20% slower): keep warming up, untimed, until 0.6 s of device work has been issued
     t_w = time.perf_counter()
     while time.perf_counter() - t_w < args.min_warmup_s:
         run_steps(fuse * n_groups)
-        for st_ in streams:
+        for st_ in streams + side_streams:
             st_.synchronize()
+    drain_timing()  # the event pairs of the warm-up launches do not count
     # timed region: exactly K steps
     barrier()
     t0 = time.perf_counter()
     n_launches = run_steps(args.steps)
     t_enq = time.perf_counter() - t0  # host time spent enqueueing (launch-bound check)
-    for st_ in streams:
+    for st_ in streams + side_streams:
         st_.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     leaders = [g[0] for g in groups]
-    for b in leaders:
-        b.sync()  # HIP event pairs around the cycle-kernel launches give the kernel's own mean duration
+    # HIP event pairs around the cycle-kernel launches of the timed region give the kernel's own mean duration
+    k_ms_list = drain_timing()
+    # untimed epilogue: the same fused launch with nothing else in flight (duration of the kernel on its own)
+    for _ in range(3):
+        prod.reset_many(groups[0], main_stream.cuda_stream)
+        prod.run_many(groups[0], wl.n_cycles, main_stream.cuda_stream)
+        main_stream.synchronize()
+    k_ms_alone = drain_timing()[0]
+    batch.sync()
     st = batch.stats()
     cycles_per_step = int(st["cycles"])
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -147,7 +197,7 @@ def main():
         heap_words = 0.9 if args.cfg == 2 else 0.0
         b_cycle = 8 + 512 + 48 * n_mem + 128 * n_log + 32 * heap_words
         # mean duration of one cycle-kernel launch (HIP events on its stream) and the cycles that launch processed
-        k_ms = sum(float(b.stats()["kernel_ms"]) for b in leaders) / len(leaders)
+        k_ms = sum(k_ms_list) / len(k_ms_list)
         batches_per_launch = min(fuse, args.steps)
         achieved = b_cycle * cycles_per_step * batches_per_launch / (k_ms * 1e-3) / 1e9
         traffic = measured_traffic(args, batches_per_launch)
@@ -158,11 +208,11 @@ def main():
             "dtype": "u256 (8 x u32 limbs)", "data": "synthetic",
             "config": {"workload": "cfg%d: %d instances x %d cycles per GPU (%s)" % (args.cfg, args.instances, args.cycles, wl.name),
                        "instances_per_gpu": args.instances, "cycles_per_instance": args.cycles, "lanes_per_wave": int(batch.limits["lanes_per_wave"][0]), "commit_mask": args.commit_mask,
-                       "batches_per_fused_launch": batches_per_launch, "fused_groups_in_flight": n_groups, "cycle_kernel_launches": n_launches},
-            "kernel_ms": k_ms, "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
+                       "batches_per_fused_launch": batches_per_launch, "fused_groups_in_flight": n_groups, "side_stream_work": (args.side if overlap else None), "cycle_kernel_launches": n_launches},
+            "kernel_ms": k_ms, "kernel_ms_alone": k_ms_alone, "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
             "kernel_cycles_per_s": cycles_per_step * batches_per_launch / (k_ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "bytes_per_cycle": b_cycle, "cycles_per_launch": cycles_per_step * batches_per_launch,
+                         "frac_alone": b_cycle * cycles_per_step * len(groups[0]) / (k_ms_alone * 1e-3) / 1e9 / 8000.0, "bytes_per_cycle": b_cycle, "cycles_per_launch": cycles_per_step * batches_per_launch,
                          "chip_achieved": b_cycle * value / 1e9, "chip_frac": b_cycle * value / 1e9 / 8000.0},
         }
         if not args.no_cpu_baseline:

@@ -240,6 +240,19 @@ class Backend:
     def create_batch(self, workload):
         return Batch(self, workload)
 
+    def reset_many(self, batches, stream=None):
+        arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])
+        self.call("batches_reset", arr, C.c_uint32(len(batches)), C.c_void_p(stream))
+
+    def run_many(self, batches, max_cycles, stream=None):
+        arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])
+        self.call("batches_run", arr, C.c_uint32(len(batches)), C.c_uint32(max_cycles), C.c_void_p(stream))
+
+    def commit_many(self, batches, queue_mask, stream=None):
+        """zkw_batches_commit: the fused commitment launches alone (caller orders the streams)."""
+        arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])
+        self.call("batches_commit", arr, C.c_uint32(len(batches)), C.c_uint32(queue_mask), C.c_void_p(stream))
+
     def step_many(self, batches, max_cycles, queue_mask=0, stream=None):
         """zkw_batches_step: reset + run + commit of several batches with fused launches (one batch per grid row)."""
         arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])

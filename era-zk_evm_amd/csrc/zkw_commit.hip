@@ -171,13 +171,17 @@ ZD void zkw_commit_wave_fence() {
 // ---------------------------------------------------------------------------------------------
 
 // one stream record per thread -> leaf[wave][pos] (4 x u64)
-__global__ void zkw_leaf_kernel(zkw_fused_table T) {
+// One instantiation per queue (Q = ZKW_QUEUE_* or ZKW_QUEUE_CODE_WORDS): the decommit instantiation needs <= 80
+// VGPRs so that its waves fit beside a resident cycle-kernel wave (256 VGPR + 174 AGPR of the 512 per SIMD lane) and
+// the hashing can run in the shadow of the HBM-bound cycle kernel of the next group.
+template <int Q>
+__global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) zkw_leaf_kernel(zkw_fused_table T) {
   const zkw_commit_params ZKW_CONST_AS& C = *(const zkw_commit_params ZKW_CONST_AS*)T.p[blockIdx.z];
   if (blockIdx.y >= C.n_waves) return;
   const u32 wave = blockIdx.y;
   u32 n = C.n_override;
   if (!n) n = C.cursors[wave * 4 + C.queue] < C.cap ? C.cursors[wave * 4 + C.queue] : C.cap;
-  if (C.queue == ZKW_QUEUE_DECOMMIT) {
+  if (Q == ZKW_QUEUE_DECOMMIT) {
     // Only the DECOMMIT events of the aux stream carry a leaf (about one record in six): every wavefront scans its
     // share of the stream, compacts the positions of the DECOMMIT records into an LDS list with ballot + popcount,
     // and hashes them 64 at a time, so the permutation runs on full wavefronts.
@@ -223,12 +227,12 @@ __global__ void zkw_leaf_kernel(zkw_fused_table T) {
   }
   for (u32 pos = blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += gridDim.x * blockDim.x) {
     u64 out[4];
-    if (C.queue == ZKW_QUEUE_MEMORY) {
+    if (Q == ZKW_QUEUE_MEMORY) {
       const uint4* e = C.stream + ((u64)wave * C.cap + pos) * 3;
       const uint4 h = e[0], lo = e[1], hi = e[2];
       u64 f[12] = {h.x, h.y, h.z, (h.w >> 16) & 0xffu, lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
       gl_leaf<12>(C.rc, ZKW_LEAF_MEM, f, out);
-    } else if (C.queue == ZKW_QUEUE_LOG) {
+    } else if (Q == ZKW_QUEUE_LOG) {
       const uint4* e = C.stream + ((u64)wave * C.cap + pos) * 8;
       u64 f[32];
       const uint4 a6 = e[6], a7 = e[7];
@@ -318,7 +322,7 @@ __global__ void zkw_bucket_kernel(zkw_fused_table T) {
 }
 
 // one instance per lane: sequential chain over its leaves
-__global__ void zkw_chain_kernel(zkw_fused_table T) {
+__global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) zkw_chain_kernel(zkw_fused_table T) {
   const zkw_commit_params ZKW_CONST_AS& C = *(const zkw_commit_params ZKW_CONST_AS*)T.p[blockIdx.y];
   const u32 wave = blockIdx.x;
   const u32 lane = threadIdx.x;
@@ -446,7 +450,13 @@ extern "C" hipError_t zkw_launch_commit(const zkw_fused_table* T, int stage, hip
   if (stage == ZKW_COMMIT_STAGE_LEAF) {
     const u32 threads = wt > 1 ? 256 : 1;
     const u32 per_wave_blocks = (T->max_cap + threads - 1) / threads;
-    hipLaunchKernelGGL(zkw_leaf_kernel, dim3(per_wave_blocks < 64 ? (per_wave_blocks ? per_wave_blocks : 1) : 64, T->max_waves, T->n), dim3(threads), 0, stream, *T);
+    const dim3 grid(per_wave_blocks < 64 ? (per_wave_blocks ? per_wave_blocks : 1) : 64, T->max_waves, T->n);
+    switch (T->reserved[0]) {  // the queue of every block in the table
+      case ZKW_QUEUE_MEMORY: hipLaunchKernelGGL(zkw_leaf_kernel<ZKW_QUEUE_MEMORY>, grid, dim3(threads), 0, stream, *T); break;
+      case ZKW_QUEUE_LOG: hipLaunchKernelGGL(zkw_leaf_kernel<ZKW_QUEUE_LOG>, grid, dim3(threads), 0, stream, *T); break;
+      case ZKW_QUEUE_DECOMMIT: hipLaunchKernelGGL(zkw_leaf_kernel<ZKW_QUEUE_DECOMMIT>, grid, dim3(threads), 0, stream, *T); break;
+      default: hipLaunchKernelGGL(zkw_leaf_kernel<ZKW_QUEUE_CODE_WORDS>, grid, dim3(threads), 0, stream, *T); break;
+    }
   } else if (stage == ZKW_COMMIT_STAGE_BUCKET) {
     hipLaunchKernelGGL(zkw_bucket_kernel, dim3(T->max_waves, T->n), dim3(wt), 0, stream, *T);
   } else if (stage == ZKW_COMMIT_STAGE_CHAIN) {

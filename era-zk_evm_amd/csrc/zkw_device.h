@@ -168,7 +168,7 @@ typedef struct zkw_fused_table {
   uint32_t max_cap;      /* leaf kernel: upper bound of records per wave */
   uint32_t wave_threads;
   uint32_t n_blobs;      /* blob-chain stage only */
-  uint32_t reserved[3];
+  uint32_t reserved[3];  /* [0]: leaf stage: the queue (ZKW_QUEUE_* / ZKW_QUEUE_CODE_WORDS) of the blocks in the table */
 } zkw_fused_table;
 
 /* zkw_reset_kernel: working state := pristine images, one launch */

@@ -146,6 +146,7 @@ struct zkw_batch {
   std::vector<uint32_t> h_cursors;
   std::map<uint32_t, std::unique_ptr<WaveTrace>> wave_cache;
   float kernel_ms = 0;
+  uint32_t timed_runs = 0;
   zkw_kparams kp;            // host copy of the parameter block
   DevBuf<zkw_kparams> d_kp;  // device copy the kernels read (constant address space)
   // final net states (zkw_batch_net_states)
@@ -459,6 +460,7 @@ int zkw_batch_upload(zkw_batch* b) {
     HIP_TRY(c, hipMemcpy(b->d_commit_params.p + ZKW_QUEUE_COUNT, &C, sizeof C, hipMemcpyHostToDevice));
     zkw_fused_table T;
     std::memset(&T, 0, sizeof T);
+    T.reserved[0] = ZKW_QUEUE_CODE_WORDS;
     T.p[0] = b->d_commit_params.p + ZKW_QUEUE_COUNT; T.n = 1; T.max_waves = 1; T.max_cap = C.cap; T.wave_threads = C.wave_threads; T.n_blobs = C.n_blobs;
     if (total_words) HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_LEAF, nullptr));
     HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_BLOB_CHAIN, nullptr));
@@ -781,6 +783,7 @@ static int enqueue_commit(zkw_batch* const* bs, uint32_t n, uint32_t queue_mask,
     zkw_fused_table T;
     std::memset(&T, 0, sizeof T);
     T.n = n;
+    T.reserved[0] = q;
     T.wave_threads = (uint32_t)c->wave_width;
     for (uint32_t i = 0; i < n; i++) {
       const uint32_t caps[3] = {bs[i]->cap_mem, bs[i]->cap_log, bs[i]->cap_aux};
@@ -805,6 +808,22 @@ int zkw_batch_run(zkw_batch* b, uint32_t max_cycles, void* hip_stream) {
   return rc != ZKW_OK ? rc : enqueue_run(&b, 1, max_cycles, (hipStream_t)hip_stream);
 }
 
+int zkw_batches_reset(zkw_batch* const* batches, uint32_t n_batches, void* hip_stream) {
+  int rc = check_group(batches, n_batches);
+  return rc != ZKW_OK ? rc : enqueue_reset(batches, n_batches, (hipStream_t)hip_stream);
+}
+
+int zkw_batches_run(zkw_batch* const* batches, uint32_t n_batches, uint32_t max_cycles, void* hip_stream) {
+  int rc = check_group(batches, n_batches);
+  return rc != ZKW_OK ? rc : enqueue_run(batches, n_batches, max_cycles, (hipStream_t)hip_stream);
+}
+
+int zkw_batches_commit(zkw_batch* const* batches, uint32_t n_batches, uint32_t queue_mask, void* hip_stream) {
+  int rc = check_group(batches, n_batches);
+  if (rc != ZKW_OK) return rc;
+  return queue_mask ? enqueue_commit(batches, n_batches, queue_mask, (hipStream_t)hip_stream) : ZKW_OK;
+}
+
 int zkw_batches_step(zkw_batch* const* batches, uint32_t n_batches, uint32_t max_cycles, uint32_t queue_mask, void* hip_stream) {
   int rc = check_group(batches, n_batches);
   if (rc != ZKW_OK) return rc;
@@ -815,6 +834,36 @@ int zkw_batches_step(zkw_batch* const* batches, uint32_t n_batches, uint32_t max
   return rc;
 }
 
+// mean device time of the cycle-kernel launches recorded on this batch since the last drain (HIP event pairs)
+static int drain_timing(zkw_batch* b) {
+  zkw_ctx* c = b->ctx;
+  if (!b->pending_runs) return ZKW_OK;
+  const uint32_t last = (b->pending_runs - 1) % zkw_batch::EV_RING;
+  HIP_TRY(c, hipEventSynchronize(b->evs[2 * last + 1]));
+  const uint32_t cnt = std::min<uint32_t>(b->pending_runs, zkw_batch::EV_RING);
+  float total = 0;
+  for (uint32_t i = 0; i < cnt; i++) {
+    float ms = 0;
+    HIP_TRY(c, hipEventElapsedTime(&ms, b->evs[2 * i], b->evs[2 * i + 1]));
+    total += ms;
+  }
+  b->kernel_ms = total / cnt;
+  b->timed_runs = cnt;
+  b->pending_runs = 0;
+  return ZKW_OK;
+}
+
+int zkw_batch_kernel_time(zkw_batch* b, double* mean_ms, uint32_t* n_launches) {
+  if (!b || !mean_ms) return ZKW_ERR_INVALID;
+  if (!b->uploaded) return ZKW_ERR_INVALID;
+  HIP_TRY(b->ctx, hipSetDevice(b->ctx->device));
+  int rc = drain_timing(b);
+  if (rc != ZKW_OK) return rc;
+  *mean_ms = b->kernel_ms;
+  if (n_launches) *n_launches = b->timed_runs;
+  return ZKW_OK;
+}
+
 int zkw_batch_sync(zkw_batch* b) {
   if (!b) return ZKW_ERR_INVALID;
   zkw_ctx* c = b->ctx;
@@ -823,18 +872,9 @@ int zkw_batch_sync(zkw_batch* b) {
     return ZKW_ERR_NOT_RUN;
   }
   HIP_TRY(c, hipSetDevice(c->device));
-  if (b->pending_runs) {  // mean device time of the cycle kernel over the runs since the last sync
-    const uint32_t last = (b->pending_runs - 1) % zkw_batch::EV_RING;
-    HIP_TRY(c, hipEventSynchronize(b->evs[2 * last + 1]));
-    const uint32_t cnt = std::min<uint32_t>(b->pending_runs, zkw_batch::EV_RING);
-    float total = 0;
-    for (uint32_t i = 0; i < cnt; i++) {
-      float ms = 0;
-      HIP_TRY(c, hipEventElapsedTime(&ms, b->evs[2 * i], b->evs[2 * i + 1]));
-      total += ms;
-    }
-    b->kernel_ms = total / cnt;
-    b->pending_runs = 0;
+  {
+    int trc = drain_timing(b);
+    if (trc != ZKW_OK) return trc;
   }
   HIP_TRY(c, hipStreamSynchronize(b->run_stream));
   b->h_scalars.resize(b->n);

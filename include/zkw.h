@@ -435,6 +435,15 @@ int zkw_batch_step(zkw_batch* batch, uint32_t max_cycles, uint32_t queue_mask, v
  * runs only a few kernels of different streams concurrently, so independent small batches are stepped together.
  * Every batch is afterwards synced / read exactly as after zkw_batch_run; kernel_ms is reported on batches[0]. */
 int zkw_batches_step(zkw_batch* const* batches, uint32_t n_batches, uint32_t max_cycles, uint32_t queue_mask, void* hip_stream);
+/* The three stages of zkw_batches_step as separate fused launches, for callers that pipeline groups of batches over
+ * several streams (the caller orders the streams with hipStreamWaitEvent): e.g. commitments (integer-ALU bound) and
+ * the restore of the next inputs on a side stream, in the shadow of the HBM-bound cycle kernel of another group. */
+int zkw_batches_reset(zkw_batch* const* batches, uint32_t n_batches, void* hip_stream);
+int zkw_batches_run(zkw_batch* const* batches, uint32_t n_batches, uint32_t max_cycles, void* hip_stream);
+int zkw_batches_commit(zkw_batch* const* batches, uint32_t n_batches, uint32_t queue_mask, void* hip_stream);
+/* mean device time (ms) of the cycle-kernel launches recorded on this batch since the last call / sync — HIP event
+ * pairs on the launch stream; for fused launches the pairs live on batches[0].  Waits for the last recorded launch only. */
+int zkw_batch_kernel_time(zkw_batch* batch, double* mean_ms, uint32_t* n_launches);
 /* waits for the run, downloads the streams and builds the per-instance views */
 int zkw_batch_sync(zkw_batch* batch);
 int zkw_batch_get_stats(zkw_batch* batch, zkw_run_stats* out);
