@@ -62,7 +62,7 @@ ISA_CONSTS = _dt([("nop_encoding", "<u8", 0), ("exception_revert_encoding", "<u8
                   ("initial_storage_write_pubdata_bytes", "<u4", 56), ("l1_message_pubdata_bytes", "<u4", 60), ("max_offset_to_deref_low", "<u4", 64),
                   ("deployer_address_low", "<u4", 68), ("keccak_precompile_address", "<u4", 72), ("sha256_precompile_address", "<u4", 76),
                   ("ecrecover_precompile_address", "<u4", 80), ("storage_aux_byte", "u1", 84), ("event_aux_byte", "u1", 85),
-                  ("l1_message_aux_byte", "u1", 86), ("precompile_aux_byte", "u1", 87), ("reserved", ("<u4", 8), 88)], 120)
+                  ("l1_message_aux_byte", "u1", 86), ("precompile_aux_byte", "u1", 87), ("ecrecover_input_layout", "<u4", 88), ("reserved", ("<u4", 7), 92)], 120)
 ISA_TABLE = _dt([("entries", (ISA_ENTRY, ISA_TABLE_SIZE), 0), ("consts", ISA_CONSTS, 12 * ISA_TABLE_SIZE)], 12 * ISA_TABLE_SIZE + 120)
 
 CALLSTACK_ENTRY = _dt([("this_address", ("u1", 20), 0), ("msg_sender", ("u1", 20), 20), ("code_address", ("u1", 20), 40), ("base_memory_page", "<u4", 60),

@@ -1295,6 +1295,7 @@ ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   const u32 addr_low = q.address[0] & 0xffffu;
   if (addr_low == P.consts.keccak_precompile_address) precompile_keccak256(P, sh, s, q);
   else if (addr_low == P.consts.sha256_precompile_address) precompile_sha256(P, sh, s, q);
+  else if (addr_low == P.consts.ecrecover_precompile_address) precompile_ecrecover(P, sh, s, q);
   // anything else (incl. ecrecover, not built yet) behaves as an unknown precompile: no memory traffic
 }
 

@@ -172,3 +172,38 @@ ZD void precompile_sha256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
     }
   }
 }
+
+#include "zkw_secp256k1.hip.h"
+
+// ecrecover_function: four words from word offset `input_memory_offset` of `memory_page_to_read` (order per
+// consts.ecrecover_input_layout), two words at `output_memory_offset`: the ok marker (1 / 0) and the address as the
+// low 20 bytes of a big-endian word (reference test src/testing/tests/precompiles/ecrecover.rs:51-95).
+ZD void precompile_ecrecover(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
+  const u32 in_word = q.key.w[0], out_off = q.key.w[2];
+  const u32 page_r = q.key.w[4], page_w = q.key.w[5];
+  u256 w0, w1, w2, w3;
+  w0 = heap_read_cur(P, s, false, in_word);
+  emit_mem(P, sh, s, q.timestamp, ZKW_MEM_HEAP, page_r, in_word, w0, false, false, 1);
+  w1 = heap_read_cur(P, s, false, in_word + 1);
+  emit_mem(P, sh, s, q.timestamp, ZKW_MEM_HEAP, page_r, in_word + 1, w1, false, false, 1);
+  w2 = heap_read_cur(P, s, false, in_word + 2);
+  emit_mem(P, sh, s, q.timestamp, ZKW_MEM_HEAP, page_r, in_word + 2, w2, false, false, 1);
+  w3 = heap_read_cur(P, s, false, in_word + 3);
+  emit_mem(P, sh, s, q.timestamp, ZKW_MEM_HEAP, page_r, in_word + 3, w3, false, false, 1);
+  if (!lane_ok(s)) return;
+  const bool evm_order = P.consts.ecrecover_input_layout != 0;
+  const u256 vw = evm_order ? w1 : w3;
+  const u256 r = evm_order ? w2 : w1;
+  const u256 sg = evm_order ? w3 : w2;
+  // the recovery id is a single byte that must be 0 or 1 (an assert in the precompile => the reference panics)
+  if ((vw.w[0] > 1u) | ((vw.w[1] | vw.w[2] | vw.w[3] | vw.w[4] | vw.w[5] | vw.w[6] | vw.w[7]) != 0u)) {
+    lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
+    return;
+  }
+  const ec_result res = zkw_ecrecover(w0, r, sg, vw.w[0]);
+  const u256 marker = u256_from_u32(res.ok);
+  heap_write_cur(P, s, false, out_off, marker);
+  emit_mem(P, sh, s, q.timestamp + 1, ZKW_MEM_HEAP, page_w, out_off, marker, false, true, 2);
+  heap_write_cur(P, s, false, out_off + 1, res.address_word);
+  emit_mem(P, sh, s, q.timestamp + 1, ZKW_MEM_HEAP, page_w, out_off + 1, res.address_word, false, true, 2);
+}

@@ -766,6 +766,53 @@ def config4(isa, n_instances=4096, n_cycles=1024, seed=0x5EED0004):
 
 
 # ----------------------------------------------------------------------------------------
+# ecrecover precompile calls from a frame whose address is the ecrecover system contract (0x01)
+# ----------------------------------------------------------------------------------------
+ECRECOVER_ADDRESS = 0x01
+
+
+def ecrecover_workload(isa, sig_words, tail_cycles=6):
+    """sig_words: [n_instances][n_sigs][4] python ints, already in the memory order of isa.consts.ecrecover_input_layout.
+    Signature j sits at heap words 4j..4j+3; the precompile writes (ok marker, address word) at words out_base + 2j,
+    which the tail of the tape loads back into registers."""
+    n_instances, n_sigs = len(sig_words), len(sig_words[0])
+    out_base = 4 * n_sigs
+    heap_words = out_base + 2 * n_sigs + 2
+    ops, consts = [], []
+    for j in range(n_sigs):
+        consts.append(precompile_abi(4 * j, 4, out_base + 2 * j, 2, 0, 0))
+        ops.append(isa.enc(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=CONST_BASE + j, src1=0, dst0=3))
+        ops.append(isa.enc(K.OP_ADD, src0_mode=K.MODE_IMM, imm0=1112, src1=0, dst0=4))
+        ops.append(isa.enc(K.OP_LOG, variant=K.LOG_PRECOMPILE, src0=3, src1=4, dst0=5))
+    for j in range(min(n_sigs, tail_cycles // 2)):  # read the results back through the heap
+        ops.append(isa.enc(K.OP_ADD, src0_mode=K.MODE_IMM, imm0=32 * (out_base + 2 * j + 1), src1=0, dst0=12))
+        ops.append(isa.enc(K.OP_UMA, variant=K.UMA_HEAP_READ, flags=0, src0=12, dst0=6 + j))
+    n_cycles = len(ops) + 2
+    wl = Workload("ecrecover_%d" % n_sigs, n_instances, n_cycles)
+    boot = np.zeros((CONST_BASE + len(consts), 4), dtype="<u8")
+    code = K.pack_code(ops + [isa.enc(K.OP_NOP)] * 8)
+    boot[: len(code)] = code
+    for i, c in enumerate(consts):
+        boot[CONST_BASE + i] = c
+    wl.blobs.append(boot)
+    wl.code_pages.append((0, n_instances, BOOTLOADER_CODE_PAGE, 0))
+    regs = np.zeros((n_instances, 15, 4), dtype="<u8")
+    wl.states, wl.inner = initial_states(n_instances, regs, heap_bound=heap_words * 32 + 64)
+    wl.states["current"]["this_address"] = K.address_bytes(ECRECOVER_ADDRESS)
+    wl.states["current"]["code_address"] = K.address_bytes(ECRECOVER_ADDRESS)
+    heaps = np.zeros((n_instances, heap_words, 4), dtype="<u8")
+    for i in range(n_instances):
+        for j in range(n_sigs):
+            for k in range(4):
+                heaps[i, 4 * j + k] = K.u256_from_int(sig_words[i][j][k])
+    wl.heaps = heaps
+    wl.out_base = out_base
+    wl.limits.update(max_far_frames=2, heap_words=heap_words + 8, stack_words=8, aux_heap_words=8, storage_slots=8, storage_journal=4,
+                     max_mem_queries=8 * n_sigs + 16, max_log_queries=16, max_aux_events=16)
+    return wl
+
+
+# ----------------------------------------------------------------------------------------
 # nested near-call frames with storage writes / events / L1 messages and every ok / revert / panic
 # combination — the frame discipline get_final_net_states depends on (testing/storage.rs:144-186,
 # reference_impls/event_sink.rs:160-176)

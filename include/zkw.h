@@ -143,7 +143,9 @@ typedef struct zkw_isa_consts {
   uint32_t sha256_precompile_address; /* 0x02   */
   uint32_t ecrecover_precompile_address; /* 0x01 */
   uint8_t storage_aux_byte, event_aux_byte, l1_message_aux_byte, precompile_aux_byte; /* log.rs:6-8 */
-  uint32_t reserved[8];
+  uint32_t ecrecover_input_layout;    /* words at input_memory_offset: 0 = (hash, r, s, v) as the reference's own test fills
+                                         memory (testing/tests/precompiles/ecrecover.rs:3-49); 1 = (hash, v, r, s) */
+  uint32_t reserved[7];
 } zkw_isa_consts;
 
 typedef struct zkw_isa_table {

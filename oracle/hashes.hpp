@@ -82,4 +82,30 @@ inline void sha256_compress(uint32_t state[8], const uint8_t block[64]) {
   state[0] += a; state[1] += b; state[2] += c; state[3] += d; state[4] += e; state[5] += f; state[6] += g; state[7] += h;
 }
 
+// keccak256 of a byte string (legacy 0x01 padding), on top of the pinned permutation
+inline void keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
+  uint64_t st[25] = {0};
+  uint8_t block[136];
+  size_t off = 0;
+  for (;;) {
+    size_t take = len - off < 136 ? len - off : 136;
+    std::memset(block, 0, sizeof block);
+    std::memcpy(block, data + off, take);
+    off += take;
+    bool last = take < 136;
+    if (last) {
+      block[take] ^= 0x01;
+      block[135] ^= 0x80;
+    }
+    for (int i = 0; i < 17; i++) {
+      uint64_t w = 0;
+      for (int b = 0; b < 8; b++) w |= (uint64_t)block[8 * i + b] << (8 * b);
+      st[i] ^= w;
+    }
+    keccak_f1600(st);
+    if (last) break;
+  }
+  for (int i = 0; i < 32; i++) out[i] = (uint8_t)(st[i / 8] >> (8 * (i % 8)));
+}
+
 }  // namespace zko

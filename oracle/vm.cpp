@@ -1,6 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see vm.hpp header).
 // Restatement of reference src/vm_state/cycle.rs, mem_ops.rs and src/opcodes/execution/*.rs.
 #include "vm.hpp"
+#include "secp256k1.hpp"
 
 namespace zko {
 
@@ -484,8 +485,10 @@ void Vm::call_precompile(uint32_t cc, const LogQuery& query) {
     keccak256_rounds_function(cc, query, memory, reads, writes);
   else if (address_low == isa->consts.sha256_precompile_address)
     sha256_rounds_function(cc, query, memory, reads, writes);
+  else if (address_low == isa->consts.ecrecover_precompile_address)
+    ecrecover_function(cc, query, memory, isa->consts.ecrecover_input_layout, reads, writes);
   else
-    return;  // incl. ecrecover: not implemented in this build => behaves like an unknown precompile
+    return;  // unknown precompile address: the default processor does nothing
   if (witness_tracer.cb) {  // add_precompile_call_result(cc, query, mem_in, mem_out, round_witness) helpers.rs:214-221
     std::vector<cblog::MemQ> in, out;
     for (const MemoryQuery& q : reads) in.push_back(Recorder::cb_mem(q));
@@ -1080,6 +1083,35 @@ void keccak256_rounds_function(uint32_t cc, const LogQuery& params, SimpleMemory
       writes.push_back(w);
     }
   }
+}
+
+// ecrecover precompile (absent crate zk_evm_abstractions; layout per the reference's test
+// src/testing/tests/precompiles/ecrecover.rs:3-95): 4 reads @timestamp, 2 writes @timestamp + 1
+void ecrecover_function(uint32_t cc, const LogQuery& params, SimpleMemory& memory, uint32_t layout, std::vector<MemoryQuery>& reads,
+                        std::vector<MemoryQuery>& writes) {
+  PrecompileCallABI abi = PrecompileCallABI::from_u256(params.key);
+  uint32_t timestamp_to_read = params.timestamp, timestamp_to_write = timestamp_to_read + 1;
+  U256 w[4];
+  for (uint32_t k = 0; k < 4; k++) {
+    MemoryQuery q{timestamp_to_read, MemoryLocation{ZKW_MEM_HEAP, abi.memory_page_to_read, abi.input_memory_offset + k}, U256::zero(), false, false};
+    q = memory.execute_partial_query(cc, q);
+    reads.push_back(q);
+    w[k] = q.value;
+  }
+  const U256& vw = layout ? w[1] : w[3];
+  const U256& r = layout ? w[2] : w[1];
+  const U256& s = layout ? w[3] : w[2];
+  REF_ASSERT(vw.l[0] <= 1 && vw.l[1] == 0 && vw.l[2] == 0 && vw.l[3] == 0, "ecrecover: v must be 0 or 1");
+  uint8_t address[20];
+  bool ok = secp::ecrecover(w[0], r, s, vw.l[0] == 1, address);
+  uint8_t word[32] = {0};
+  if (ok) std::memcpy(word + 12, address, 20);
+  MemoryQuery m{timestamp_to_write, MemoryLocation{ZKW_MEM_HEAP, abi.memory_page_to_write, abi.output_memory_offset}, U256::from_u64(ok ? 1 : 0), false, true};
+  m = memory.execute_partial_query(cc, m);
+  writes.push_back(m);
+  MemoryQuery a{timestamp_to_write, MemoryLocation{ZKW_MEM_HEAP, abi.memory_page_to_write, abi.output_memory_offset + 1}, from_big_endian(word), false, true};
+  a = memory.execute_partial_query(cc, a);
+  writes.push_back(a);
 }
 
 void sha256_rounds_function(uint32_t cc, const LogQuery& params, SimpleMemory& memory, std::vector<MemoryQuery>& reads, std::vector<MemoryQuery>& writes) {

@@ -928,5 +928,7 @@ struct Vm {
 // precompiles (zk_evm_abstractions::precompiles, absent crate — see hashes.hpp header)
 void keccak256_rounds_function(uint32_t cc, const LogQuery& params, SimpleMemory& memory, std::vector<MemoryQuery>& reads, std::vector<MemoryQuery>& writes);
 void sha256_rounds_function(uint32_t cc, const LogQuery& params, SimpleMemory& memory, std::vector<MemoryQuery>& reads, std::vector<MemoryQuery>& writes);
+void ecrecover_function(uint32_t cc, const LogQuery& params, SimpleMemory& memory, uint32_t layout, std::vector<MemoryQuery>& reads,
+                        std::vector<MemoryQuery>& writes);
 
 }  // namespace zko

@@ -107,3 +107,5 @@ static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess
 #define __builtin_amdgcn_wave_barrier() ((void)0)
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+
+#define __noinline__ __attribute__((noinline))

@@ -249,3 +249,20 @@ def test_net_states_partial_run(oracle, product, isa):
         for i in (0, 63, 64, 69):
             ok, why = K.net_states_equal(bo.net_state(i), bp.net_state(i))
             assert ok, (cycles, i, why)
+
+
+def test_ecrecover_precompile(oracle, product, isa):
+    """ecrecover through the VM on the GPU: 70 instances x 3 signatures (valid, out-of-range, off-curve), bit-exact vs
+    the oracle and correct vs the independent Python implementation."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_ecrecover import make_signatures, check_against_python
+    words, expect = make_signatures(70, 3, seed=0xEC7)
+    wl = synth.ecrecover_workload(isa, words)
+    bo, bp = _run(oracle, wl), _run(product, wl)
+    for i in range(0, 70, 3):
+        tp = bp.trace(i)
+        ok, why = K.traces_equal(bo.trace(i), tp)
+        assert ok, (i, why)
+        check_against_python(wl, tp, expect[i])

@@ -135,3 +135,70 @@ def test_sha256_stale_reference_inputs(oracle, data):
     digest, n_reads, n_writes = run_precompile(oracle.lib, 1, words, key, n)
     assert digest == hashlib.sha256(data).digest()
     assert n_reads == 2 * rounds and n_writes == 1
+
+
+# ---------------------------------------------------------------------------------------------
+# ecrecover: the two literal vectors of the reference's (stale) test src/testing/tests/precompiles/ecrecover.rs:127-143
+# (raw input = hash || v || r || s, memory filled as hash, r, s, v :3-49; output = ok marker, address word :80-93)
+# and random signatures against the independent arbitrary-precision implementation tests/secp256k1_ref.py
+# ---------------------------------------------------------------------------------------------
+ECRECOVER_VECTORS = [
+    ("38d18acb67d25c8bb9942764b62f18e17054f66a817bd4295423adf9ed98873e000000000000000000000000000000000000000000000000000000000000001b"
+     "38d18acb67d25c8bb9942764b62f18e17054f66a817bd4295423adf9ed98873e789d1dd423d25f0772d2748d60f7e4b81bb14d086eba8e8e8efb6dcff8a4ae02",
+     "ceaccac640adf55b2028469bd36ba501f28b699d"),
+    ("38d18acb67d25c8bb9942764b62f18e17054f66a817bd4295423adf9ed98873e000000000000000000000000000000000000000000000000000000000000001b"
+     "38d18acb67d25c8bb9942764b62f18e17054f66a817bd4295423adf9ed98873e7fffffffffffffffffffffffffffffff5d576e7357a4501ddfe92f46681b20a0",
+     bytes([88, 198, 174, 93, 17, 93, 119, 163, 216, 169, 239, 54, 214, 164, 45, 35, 105, 43, 170, 127]).hex()),
+]
+
+
+def ecrecover_words(h, r, s, v, layout):
+    order = (h, r, s, v) if layout == 0 else (h, v, r, s)
+    return np.array([K.u256_from_int(x) for x in order], dtype="<u8").reshape(-1, 4)
+
+
+def run_ecrecover(lib, h, r, s, v, layout):
+    words = ecrecover_words(h, r, s, v, layout)
+    key = abi_key(0, 4, 4, 2, 4, 4)
+    marker, n_reads, n_writes = run_precompile(lib, 2 + layout, words, key, 4)
+    addr, _, _ = run_precompile(lib, 2 + layout, words, key, 5)
+    assert (n_reads, n_writes) == (4, 2)
+    return int.from_bytes(marker, "big"), addr
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("raw,address", ECRECOVER_VECTORS)
+def test_ecrecover_reference_vectors(oracle, raw, address, layout):
+    b = bytes.fromhex(raw)
+    h, v, r, s = (int.from_bytes(b[i:i + 32], "big") for i in (0, 32, 64, 96))
+    v = {27: 0, 28: 1, 0: 0, 1: 1}[v]  # ecrecover.rs:107-117
+    marker, addr = run_ecrecover(oracle.lib, h, r, s, v, layout)
+    assert marker == 1                                   # ecrecover.rs:83-86
+    assert addr[:12] == bytes(12) and addr[12:].hex() == address  # :87
+
+
+def test_ecrecover_random_signatures_vs_python(oracle):
+    import random
+    import secp256k1_ref as S
+    rng = random.Random(0xEC)
+    n_ok = n_bad = 0
+    for k in range(12):
+        h = rng.getrandbits(256)
+        r = rng.getrandbits(256) % S.N
+        s = rng.getrandbits(256) % S.N
+        v = rng.getrandbits(1)
+        marker, addr = run_ecrecover(oracle.lib, h, r, s, v, 0)
+        expect = S.ecrecover_address(h, r, s, v)
+        if expect is None:  # x = r not on the curve (about half of all random r)
+            assert marker == 0 and addr == bytes(32)
+            n_bad += 1
+        else:
+            assert marker == 1 and addr[12:] == expect and addr[:12] == bytes(12)
+            n_ok += 1
+    assert n_ok >= 2 and n_bad >= 2
+
+
+@pytest.mark.parametrize("r,s", [(0, 5), (5, 0), (2**256 - 1, 5), (5, 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141)])
+def test_ecrecover_rejects_out_of_range_scalars(oracle, r, s):
+    marker, addr = run_ecrecover(oracle.lib, 12345, r, s, 0, 0)
+    assert marker == 0 and addr == bytes(32)
