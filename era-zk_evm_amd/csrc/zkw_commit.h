@@ -16,6 +16,7 @@
 #define ZKW_COMMIT_STAGE_CHAIN 2
 #define ZKW_COMMIT_STAGE_BLOB_CHAIN 3
 #define ZKW_COMMIT_STAGE_NETSTATE 4
+#define ZKW_COMMIT_STAGE_MIDSTATE 5
 
 typedef struct zkw_commit_params {
   uint32_t n_instances, L, n_waves, max_cycles, wave_threads;
@@ -33,6 +34,10 @@ typedef struct zkw_commit_params {
   const zkw_dev_scalars* scalars;
   const uint64_t* blob_digests; /* [n_blobs][4] */
   const uint2* blob_dir;
+  const zkw_dev_preimage* preimages; /* [n_preimages] (midstate stage) */
+  uint64_t* midstates;       /* [n_preimages][12] sponge state after absorbing the code hash (decommit leaves) */
+  uint32_t n_preimages;
+  uint32_t reserved1;
   uint64_t* leaves;          /* [n_waves][cap][4] */
   uint32_t* idx;             /* [n_instances][per_instance_cap] */
   uint32_t* counts;          /* [n_instances] */

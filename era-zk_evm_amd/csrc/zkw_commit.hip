@@ -207,14 +207,20 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) zkw_leaf_kernel(zkw_f
         if (ln < take) {
           const u32 p = s_list[wf][ln];
           const uint4* e = C.stream + ((u64)wave * C.cap + p) * 16;
-          const uint4 h = e[0], lo = e[1], hi = e[2];
-          const u32 blob = h.w >> 16;
+          const uint4 h = e[0];
+          const u32 pre = e[3].x, blob = h.w >> 16;
+          // the first sponge block (the 8 limbs of the code hash) is cached per preimage at upload: one permutation here
+          const u64* ms = C.midstates + (u64)pre * 12;
           const u64* bd = C.blob_digests + (u64)blob * 4;
-          u64 f[16] = {h.y, h.z, h.w & 0xffffu, (h.x >> 24) & 0xffu, lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, bd[0], bd[1], bd[2], bd[3]};
-          u64 out[4];
-          gl_leaf<16>(C.rc, ZKW_LEAF_DECOMMIT, f, out);
+          u64 st[12];
+#pragma unroll
+          for (int i = 0; i < 12; i++) st[i] = ms[i];
+          const u64 f[8] = {h.y, h.z, h.w & 0xffffu, (h.x >> 24) & 0xffu, bd[0], bd[1], bd[2], bd[3]};
+#pragma unroll
+          for (int i = 0; i < 8; i++) st[i] = gl_add(st[i], f[i]);
+          gl_permute(C.rc, st);
           u64* dst = C.leaves + ((u64)wave * C.cap + p) * 4;
-          dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2]; dst[3] = out[3];
+          dst[0] = st[0]; dst[1] = st[1]; dst[2] = st[2]; dst[3] = st[3];
         }
         zkw_commit_wave_fence();
         if (ln + take < pending) s_list[wf][ln] = carry;
@@ -356,6 +362,23 @@ __global__ void zkw_blob_chain_kernel(zkw_fused_table T) {
   }
 }
 
+// sponge state after the first block of a decommit leaf: domain (ZKW_LEAF_DECOMMIT, 16 elements) + the 8 limbs of the
+// code hash, one permutation — once per (hash -> blob) pair and upload instead of once per decommit
+__global__ void zkw_midstate_kernel(zkw_fused_table T) {
+  const zkw_commit_params ZKW_CONST_AS& C = *(const zkw_commit_params ZKW_CONST_AS*)T.p[0];
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < C.n_preimages; i += gridDim.x * blockDim.x) {
+    u64 st[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) st[k] = 0;
+    st[8] = ((u64)ZKW_LEAF_DECOMMIT << 32) | 16u;
+#pragma unroll
+    for (int k = 0; k < 8; k++) st[k] = C.preimages[i].hash[k];
+    gl_permute(C.rc, st);
+#pragma unroll
+    for (int k = 0; k < 12; k++) C.midstates[(u64)i * 12 + k] = st[k];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // final net states: one instance per lane.  The walk is the frame discipline of the reference sinks:
 //   query            -> history;  writes also push a pending rollback          (storage.rs:100-118, event_sink.rs:140-151)
@@ -461,6 +484,9 @@ extern "C" hipError_t zkw_launch_commit(const zkw_fused_table* T, int stage, hip
     hipLaunchKernelGGL(zkw_bucket_kernel, dim3(T->max_waves, T->n), dim3(wt), 0, stream, *T);
   } else if (stage == ZKW_COMMIT_STAGE_CHAIN) {
     hipLaunchKernelGGL(zkw_chain_kernel, dim3(T->max_waves, T->n), dim3(wt), 0, stream, *T);
+  } else if (stage == ZKW_COMMIT_STAGE_MIDSTATE) {
+    const u32 threads = wt > 1 ? 64 : 1;
+    hipLaunchKernelGGL(zkw_midstate_kernel, dim3((T->n_blobs + threads - 1) / threads), dim3(threads), 0, stream, *T);  // n_blobs = number of preimages here
   } else if (stage == ZKW_COMMIT_STAGE_NETSTATE) {
     hipLaunchKernelGGL(zkw_netstate_kernel, dim3(T->max_waves, T->n), dim3(wt), 0, stream, *T);
   } else {

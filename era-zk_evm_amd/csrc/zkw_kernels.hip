@@ -1094,8 +1094,9 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
     if (a) {
       a[1] = u256_lo4(code_hash);
       a[2] = u256_hi4(code_hash);
+      a[3] = make_uint4(pre, 0, 0, 0);  // preimage index: selects the cached sponge midstate of this code hash (zkw_commit.hip)
 #pragma unroll
-      for (int i = 3; i < 16; i++) a[i] = make_uint4(0, 0, 0, 0);
+      for (int i = 4; i < 16; i++) a[i] = make_uint4(0, 0, 0, 0);
     }
     mapped_code_page = page;
     mapped_blob = blob;

@@ -336,6 +336,10 @@ typedef struct zkw_aux_event {
     } frame;                         /* FRAME_START  */
     zkw_u256 hash;                   /* DECOMMIT     */
     struct {
+      zkw_u256 hash;
+      uint32_t preimage_index;       /* index of the (hash -> blob) pair in the order of zkw_batch_add_decommit_preimage */
+    } decommit;                      /* DECOMMIT, with the bookkeeping field the commitment kernels use */
+    struct {
       uint64_t context_u128_register[2];
       uint32_t memory_page_counter;
     } cold;                          /* COLD_STATE   */

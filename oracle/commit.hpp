@@ -138,9 +138,9 @@ inline Digest decommit_queue(const Perm& perm, const zkw_aux_event* e, size_t n,
   uint64_t j = 0;
   for (size_t k = 0; k < n; k++) {
     if (e[k].type != ZKW_AUX_DECOMMIT) continue;
-    std::vector<uint64_t> f = {e[k].a, e[k].b, e[k].c & 0xffffu, e[k].flag};
-    auto v = limbs(e[k].u.hash);
-    f.insert(f.end(), v.begin(), v.end());
+    // first sponge block = the 8 limbs of the code hash (cacheable per hash), second = the query fields + blob digest
+    std::vector<uint64_t> f = limbs(e[k].u.hash);
+    for (uint64_t x : {(uint64_t)e[k].a, (uint64_t)e[k].b, (uint64_t)(e[k].c & 0xffffu), (uint64_t)e[k].flag}) f.push_back(x);
     const Digest& bd = blob_digests[e[k].c >> 16];
     for (int i = 0; i < 4; i++) f.push_back(bd.v[i]);
     chain_step(perm, leaf(perm, 3, f), tail, ++j, ZKW_QUEUE_DECOMMIT);

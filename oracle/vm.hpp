@@ -315,7 +315,7 @@ struct Recorder {
     aux.push_back(e);
   }
   // witness_trace/mod.rs:35-41 add_decommittment (recorded whether or not B, helpers.rs:185-191)
-  void decommit(const DecommittmentQuery& q, uint32_t blob_id, uint32_t cc = 0, const std::vector<U256>* words = nullptr) {
+  void decommit(const DecommittmentQuery& q, uint32_t blob_id, uint32_t preimage_index, uint32_t cc = 0, const std::vector<U256>* words = nullptr) {
     if (cb) {  // SimpleDecommitter<true>: Some(values) when fresh, Some(vec![]) otherwise (decommitter.rs:43-47,81-96)
       const bool payload = q.is_fresh && words;
       cb->decommit(cc, q.hash.l, q.timestamp, q.memory_page, q.decommitted_length, q.is_fresh, payload ? (const uint64_t*)words->data() : nullptr,
@@ -326,6 +326,7 @@ struct Recorder {
     e.type = ZKW_AUX_DECOMMIT; e.seq = next_seq(); e.flag = q.is_fresh ? 1 : 0;
     e.a = q.timestamp; e.b = q.memory_page; e.c = (uint32_t)q.decommitted_length | (blob_id << 16);
     std::memcpy(e.u.hash.l, q.hash.l, 32);
+    e.u.decommit.preimage_index = preimage_index;
     aux.push_back(e);
   }
   // witness_trace/mod.rs:16 end_execution_cycle
@@ -742,6 +743,7 @@ struct U256Hash {
 };
 struct KnownCode {
   uint32_t blob_id;
+  uint32_t preimage_index;  // insertion order of populate (bookkeeping of the build's commitment spec, not reference state)
   CodeBlob words;
 };
 struct SimpleDecommitter {
@@ -750,16 +752,18 @@ struct SimpleDecommitter {
     uint32_t page;
     uint16_t len;
     uint32_t blob_id;
+    uint32_t preimage_index;
   };
   std::unordered_map<U256, Hist, U256Hash> history;  // :12
   // :32-98; returns the blob id of the code for the recorder
-  DecommittmentQuery decommit_into_memory(uint32_t cc, DecommittmentQuery q, SimpleMemory& memory, uint32_t* blob_id) {
+  DecommittmentQuery decommit_into_memory(uint32_t cc, DecommittmentQuery q, SimpleMemory& memory, uint32_t* blob_id, uint32_t* preimage_index) {
     auto h = history.find(q.hash);
     if (h != history.end()) {
       q.is_fresh = false;
       q.memory_page = h->second.page;
       q.decommitted_length = h->second.len;
       *blob_id = h->second.blob_id;
+      *preimage_index = h->second.preimage_index;
       return q;
     }
     if (!known_hashes) throw RefErr("Code hash must be known");
@@ -768,7 +772,7 @@ struct SimpleDecommitter {
     const std::vector<U256>& values = *k->second.words;
     q.decommitted_length = (uint16_t)values.size();
     q.is_fresh = true;
-    history[q.hash] = Hist{q.memory_page, q.decommitted_length, k->second.blob_id};
+    history[q.hash] = Hist{q.memory_page, q.decommitted_length, k->second.blob_id, k->second.preimage_index};
     MemoryQuery tmp{q.timestamp, MemoryLocation{ZKW_MEM_CODE, q.memory_page, 0}, U256::zero(), false, true};
     for (size_t i = 0; i < values.size(); i++) {
       tmp.location.index = (uint32_t)i;
@@ -776,6 +780,7 @@ struct SimpleDecommitter {
       memory.specialized_code_query(cc, tmp);
     }
     *blob_id = k->second.blob_id;
+    *preimage_index = k->second.preimage_index;
     return q;
   }
 };
@@ -872,11 +877,11 @@ struct Vm {
   // helpers.rs:164-194
   DecommittmentQuery decommit(uint32_t cc, const U256& hash, uint32_t candidate_page, uint32_t ts) {
     DecommittmentQuery pq{hash, ts, candidate_page, 0, false};
-    uint32_t blob_id = 0;
-    DecommittmentQuery q = decommittment_processor.decommit_into_memory(cc, pq, memory, &blob_id);
+    uint32_t blob_id = 0, preimage_index = 0;
+    DecommittmentQuery q = decommittment_processor.decommit_into_memory(cc, pq, memory, &blob_id, &preimage_index);
     const std::vector<U256>* words = nullptr;
     if (q.is_fresh) words = decommittment_processor.known_hashes->find(q.hash)->second.words.get();
-    witness_tracer.decommit(q, blob_id, cc, words);
+    witness_tracer.decommit(q, blob_id, preimage_index, cc, words);
     return q;
   }
   void call_precompile(uint32_t cc, const LogQuery& query);  // helpers.rs:196-223

@@ -103,7 +103,8 @@ int zkwo_batch_add_decommit_preimage(zkwo_batch* b, const zkw_u256* hash, uint32
   U256 h;
   std::memcpy(h.l, hash->l, 32);
   if (b->known_hashes.count(h)) return ZKW_ERR_INVALID;  // decommitter.rs:25 assert
-  b->known_hashes[h] = KnownCode{blob_id, b->blobs[blob_id]};
+  const uint32_t index = (uint32_t)b->known_hashes.size();
+  b->known_hashes[h] = KnownCode{blob_id, index, b->blobs[blob_id]};
   return ZKW_OK;
 }
 int zkwo_batch_set_code_page(zkwo_batch* b, uint32_t first, uint32_t count, uint32_t page, uint32_t blob_id) {
