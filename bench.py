@@ -195,7 +195,11 @@ def main():
         n_mem = float(st["mem_queries"]) / max(1, cycles_per_step)
         n_log = float(st["log_queries"]) / max(1, cycles_per_step)
         heap_words = 0.9 if args.cfg == 2 else 0.0
-        b_cycle = 8 + 512 + 48 * n_mem + 128 * n_log + 32 * heap_words
+        n_delta = float(st["reg_deltas"]) / max(1, cycles_per_step)
+        # bytes the kernel has to move per VM cycle: code word + record tail + register deltas + queries + heap words
+        # (the 512-B snapshot of SURVEY §8d is stored losslessly as 32-B tail + 32 B per written register)
+        b_cycle = 8 + 32 + 32 * n_delta + 48 * n_mem + 128 * n_log + 32 * heap_words
+        b_cycle_snapshot = 8 + 512 + 48 * n_mem + 128 * n_log + 32 * heap_words
         # mean duration of one cycle-kernel launch (HIP events on its stream) and the cycles that launch processed
         k_ms = sum(k_ms_list) / len(k_ms_list)
         batches_per_launch = min(fuse, args.steps)
@@ -212,7 +216,7 @@ def main():
             "kernel_ms": k_ms, "kernel_ms_alone": k_ms_alone, "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
             "kernel_cycles_per_s": cycles_per_step * batches_per_launch / (k_ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "frac_alone": b_cycle * cycles_per_step * len(groups[0]) / (k_ms_alone * 1e-3) / 1e9 / 8000.0, "bytes_per_cycle": b_cycle, "cycles_per_launch": cycles_per_step * batches_per_launch,
+                         "frac_alone": b_cycle * cycles_per_step * len(groups[0]) / (k_ms_alone * 1e-3) / 1e9 / 8000.0, "bytes_per_cycle": b_cycle, "snapshot_equivalent_bytes_per_cycle": b_cycle_snapshot, "snapshot_equivalent_GBps": b_cycle_snapshot * cycles_per_step * batches_per_launch / (k_ms * 1e-3) / 1e9, "cycles_per_launch": cycles_per_step * batches_per_launch,
                          "chip_achieved": b_cycle * value / 1e9, "chip_frac": b_cycle * value / 1e9 / 8000.0},
         }
         if not args.no_cpu_baseline:

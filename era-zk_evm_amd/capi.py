@@ -80,7 +80,7 @@ BLOCK_PROPERTIES = _dt([("default_aa_code_hash", U256, 0), ("zkporter_is_availab
 STORAGE_SLOT = _dt([("key", U256, 0), ("value", U256, 32), ("address", ("u1", 20), 64), ("shard_id", "u1", 84), ("reserved0", ("u1", 3), 85)], 88)
 LIMITS = _dt([("max_cycles", "<u4", 0), ("max_far_frames", "<u4", 4), ("max_callstack_depth", "<u4", 8), ("stack_words", "<u4", 12), ("heap_words", "<u4", 16),
               ("aux_heap_words", "<u4", 20), ("storage_slots", "<u4", 24), ("storage_journal", "<u4", 28), ("max_mem_queries", "<u4", 32),
-              ("max_log_queries", "<u4", 36), ("max_aux_events", "<u4", 40), ("lanes_per_wave", "<u4", 44), ("reserved", ("<u4", 4), 48)], 64)
+              ("max_log_queries", "<u4", 36), ("max_aux_events", "<u4", 40), ("lanes_per_wave", "<u4", 44), ("max_reg_deltas", "<u4", 48), ("reserved", ("<u4", 3), 52)], 64)
 CYCLE_TAIL = _dt([("register_ptr_bitmap", "<u2", 0), ("flags", "u1", 2), ("reserved0", "u1", 3), ("pc", "<u2", 4), ("sp", "<u2", 6), ("ergs_remaining", "<u4", 8),
                   ("timestamp", "<u4", 12), ("heap_bound", "<u4", 16), ("aux_heap_bound", "<u4", 20), ("callstack_depth", "<u2", 24),
                   ("previous_super_pc", "<u2", 26), ("event_counts", "<u4", 28)], 32)
@@ -93,7 +93,7 @@ LOG_QUERY = _dt([("key", U256, 0), ("read_value", U256, 32), ("written_value", U
 AUX_EVENT = _dt([("type", "u1", 0), ("lane", "u1", 1), ("seq", "u1", 2), ("flag", "u1", 3), ("a", "<u4", 4), ("b", "<u4", 8), ("c", "<u4", 12),
                  ("raw", ("u1", 240), 16)], 256)
 RUN_STATS = _dt([("cycles", "<u8", 0), ("mem_queries", "<u8", 8), ("log_queries", "<u8", 16), ("aux_events", "<u8", 24), ("instances_ended", "<u8", 32),
-                 ("instances_failed", "<u8", 40), ("kernel_ms", "<f8", 48), ("reserved0", "<f8", 56)], 64)
+                 ("instances_failed", "<u8", 40), ("kernel_ms", "<f8", 48), ("reg_deltas", "<u8", 56)], 64)
 
 
 EVENT_MESSAGE = _dt([("shard_id", "u1", 0), ("is_first", "u1", 1), ("tx_number_in_block", "<u2", 2), ("address", ("u1", 20), 4), ("key", U256, 24),

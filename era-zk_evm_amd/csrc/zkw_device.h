@@ -115,6 +115,8 @@ typedef struct zkw_kparams {
   uint32_t F, D, S, H, A; /* max_far_frames, max_callstack_depth, stack/heap/aux words */
   uint32_t storage_slots, storage_journal;
   uint32_t cap_mem, cap_log, cap_aux; /* stream capacity per wave (records) */
+  uint32_t cap_delta;  /* register-delta capacity per wave (32-B values) */
+  uint32_t reserved3;
   uint32_t n_blobs, n_preimages;
   uint32_t wave_threads; /* hardware wave width (64 on gfx950; 1 in the CPU emulation build of tests/emu) */
   uint32_t waves_per_group; /* waves per workgroup (ZKW_WAVES_PER_GROUP; 1 in the emulation build) */
@@ -141,12 +143,14 @@ typedef struct zkw_kparams {
   const uint2* blob_dir;       /* [n_blobs] (first word, n_words)        */
   const zkw_dev_preimage* preimages; /* [n_preimages]                    */
   /* outputs */
-  uint4* rec;                  /* [n_waves][max_cycles][32][L]           */
+  uint4* tails;                /* [n_waves][max_cycles][2][L]: the 32-B record tail of every executed cycle (+ dirty-register mask) */
+  uint4* deltas;               /* [n_waves][cap_delta][2]: 32-B values of the registers a cycle wrote, dense per wave               */
+  uint32_t* wave_cycles;       /* [n_waves] wave-cycles run since the reset */
   uint4* mem_stream;           /* [n_waves][cap_mem][3]                  */
   uint4* log_stream;           /* [n_waves][cap_log][8]                  */
   uint4* aux_stream;           /* [n_waves][cap_aux][16]                 */
   uint32_t* dir;               /* [n_waves][max_cycles + 1][4] (mem, log, aux cursors at cycle start) */
-  uint32_t* cursors;           /* [n_waves][4] persistent stream cursors (mem, log, aux) + [3] = wave-cycles run since the reset */
+  uint32_t* cursors;           /* [n_waves][4] persistent stream cursors: mem, log, aux, register deltas */
 } zkw_kparams;
 #define ZKW_KP const zkw_kparams ZKW_CONST_AS&
 
@@ -182,4 +186,5 @@ typedef struct zkw_reset_params {
   uint32_t heap_pitch16;     /* 16-byte units between wave rows in the arena */
   uint32_t n_waves;
   uint32_t* cursors;         /* [n_waves][4] */
+  uint32_t* wave_cycles;     /* [n_waves] */
 } zkw_reset_params;

@@ -41,6 +41,7 @@ struct Lane {
   u32 stack_hwm, heap_hwm, aux_hwm;
   // per-cycle
   u32 seq, n_mem, n_log, n_aux, cold_dirty;
+  u32 reg_dirty;  // registers written in this cycle (bit r = register r + 1)
 };
 
 #define FLAG_LT 1u
@@ -187,6 +188,7 @@ ZD void reg_write(Shared& sh, Lane& s, u32 idx, const u256& v, bool is_ptr) {
   const u32 r = idx - 1;
   sh_reg(sh, 2 * r, s.lane) = u256_lo4(v);
   sh_reg(sh, 2 * r + 1, s.lane) = u256_hi4(v);
+  s.reg_dirty |= 1u << r;
   s.ptr_bitmap = (s.ptr_bitmap & ~(1u << r)) | ((is_ptr ? 1u : 0u) << r);
 }
 
@@ -1296,7 +1298,9 @@ ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   const u32 addr_low = q.address[0] & 0xffffu;
   if (addr_low == P.consts.keccak_precompile_address) precompile_keccak256(P, sh, s, q);
   else if (addr_low == P.consts.sha256_precompile_address) precompile_sha256(P, sh, s, q);
+#ifndef ZKW_EXPERIMENT_NO_ECRECOVER
   else if (addr_low == P.consts.ecrecover_precompile_address) precompile_ecrecover(P, sh, s, q);
+#endif
   // anything else (incl. ecrecover, not built yet) behaves as an unknown precompile: no memory traffic
 }
 
@@ -1518,7 +1522,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   if (wave >= P.n_waves) return;  // tail workgroup: no further workgroup-level barrier below
   for (u32 i = tid; i < 4; i += P.wave_threads) sh.cursor[i] = P.cursors[wave * 4 + i];
   zkw_wave_lds_fence();
-  const u32 cycle_base = P.cursors[wave * 4 + 3];  // wave-cycles run since the reset (records / directory index)
+  const u32 cycle_base = P.wave_cycles[wave];  // wave-cycles run since the reset (records / directory index)
 
   const u32 inst = wave * P.L + tid;
   const bool exists = tid < P.L && inst < P.n_instances;
@@ -1559,7 +1563,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
     }
     if (__ballot(active) == 0) break;
     if (active) {
-      s.seq = 0; s.n_mem = 0; s.n_log = 0; s.n_aux = 0; s.cold_dirty = 0;
+      s.seq = 0; s.n_mem = 0; s.n_log = 0; s.n_aux = 0; s.cold_dirty = 0; s.reg_dirty = 0;
       // ----------------------------------------------------------------------------------------
       // read_and_decode (cycle.rs:19-236)
       // ----------------------------------------------------------------------------------------
@@ -1649,22 +1653,49 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
         }
       }
       if (lane_ok(s) && (A.debug_flags & 1u)) s.n_cycles++;
-      if (lane_ok(s) && !(A.debug_flags & 1u)) {
-        // CycleRecord: 30 register chunks straight from LDS + 2 tail chunks, coalesced across lanes
-        uint4* rec = P.rec + ((u64)wave * P.max_cycles + (cycle_base + k)) * ZKW_REC_CHUNKS * P.L;
-#pragma unroll
-        for (int g = 0; g < ZKW_REG_CHUNKS; g += 5) {  // 5 LDS reads in flight per wait, then 5 coalesced stores
-          const uint4 t0 = sh_reg(sh, g, tid), t1 = sh_reg(sh, g + 1, tid), t2 = sh_reg(sh, g + 2, tid), t3 = sh_reg(sh, g + 3, tid), t4 = sh_reg(sh, g + 4, tid);
-          rec[(u64)g * P.L + tid] = t0;
-          rec[(u64)(g + 1) * P.L + tid] = t1;
-          rec[(u64)(g + 2) * P.L + tid] = t2;
-          rec[(u64)(g + 3) * P.L + tid] = t3;
-          rec[(u64)(g + 4) * P.L + tid] = t4;
+      if (!(A.debug_flags & 1u)) {
+        // CycleRecord, delta form: the 512-byte snapshot the tracer observes (15 registers + 32-byte tail) is emitted as
+        // the tail (dense [cycle][lane], coalesced) plus the 32-byte values of the registers THIS cycle wrote, compacted
+        // per wave.  Delta j of a lane sits at base + (number of lanes with more than j' deltas, summed over j' < j) +
+        // (rank of the lane among the lanes with more than j deltas): no tags and no atomics — the host (and any
+        // consumer) recomputes the positions from the dirty masks in the tails and rebuilds the snapshots from the
+        // initial register file.  A cycle writes one register on average, so this is ~70 B instead of 512 B.
+        const bool ok = lane_ok(s);
+        const u32 n_dirty = ok ? (u32)__popcll((u64)s.reg_dirty) : 0u;
+        u32 total = 0;
+        for (u32 j = 0; j < ZKW_REGISTERS_COUNT; j++) {
+          const u32 cj = (u32)__popcll(__ballot(n_dirty > j));
+          if (cj == 0) break;
+          total += cj;
         }
-        const u32 cnt = (s.n_mem > 255u ? 255u : s.n_mem) | ((s.n_log > 255u ? 255u : s.n_log) << 8) | ((s.n_aux > 255u ? 255u : s.n_aux) << 16);
-        rec[(u64)30 * P.L + tid] = make_uint4((s.ptr_bitmap & 0xffffu) | ((s.flags & 0xfu) << 16), (s.pc & 0xffffu) | (s.sp << 16), s.ergs, s.timestamp);
-        rec[(u64)31 * P.L + tid] = make_uint4(s.heap_bound, s.aux_bound, (s.depth & 0xffffu) | (s.prev_super_pc << 16), cnt);
-        s.n_cycles++;
+        const u32 base = ((volatile u32*)sh.cursor)[3];
+        const bool fits = base + total <= P.cap_delta;  // wave-uniform: either every lane's deltas fit or none are written
+        if (ok && !fits) lane_fail(s, ZKW_STATUS_LIMIT);
+        if (ok && fits) {
+          uint4* dl = P.deltas + (u64)wave * P.cap_delta * 2;
+          u32 m = s.reg_dirty, before = 0;
+          for (u32 j = 0; j < n_dirty; j++) {
+            const u64 part = __ballot(true);  // the lanes with more than j deltas (this loop runs n_dirty times per lane)
+            const u32 r = (u32)__ffsll((long long)m) - 1u;
+            m &= m - 1u;
+            const u32 pos = base + before + (u32)__popcll(part & ((1ull << tid) - 1ull));
+            before += (u32)__popcll(part);
+            dl[(u64)pos * 2] = sh_reg(sh, 2 * r, tid);
+            dl[(u64)pos * 2 + 1] = sh_reg(sh, 2 * r + 1, tid);
+          }
+          uint4* tl = P.tails + ((u64)wave * P.max_cycles + (cycle_base + k)) * 2 * P.L;
+          const u32 cnt = (s.n_mem > 255u ? 255u : s.n_mem) | ((s.n_log > 255u ? 255u : s.n_log) << 8) | ((s.n_aux > 255u ? 255u : s.n_aux) << 16);
+          // dirty mask: bits 0-7 in the tail's reserved byte, bits 8-14 in the top byte of the event counts
+          tl[tid] = make_uint4((s.ptr_bitmap & 0xffffu) | ((s.flags & 0xfu) << 16) | ((s.reg_dirty & 0xffu) << 24), (s.pc & 0xffffu) | (s.sp << 16), s.ergs,
+                               s.timestamp);
+          tl[P.L + tid] = make_uint4(s.heap_bound, s.aux_bound, (s.depth & 0xffffu) | (s.prev_super_pc << 16), cnt | ((s.reg_dirty >> 8) << 24));
+          s.n_cycles++;
+        }
+        if (fits && total) {
+          zkw_wave_lds_fence();
+          if (__ballot(true) != 0 && tid == (u32)__ffsll((long long)__ballot(true)) - 1u) sh.cursor[3] = base + total;
+          zkw_wave_lds_fence();
+        }
       }
     }
   }
@@ -1672,8 +1703,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   for (u32 i = tid; i < 4; i += P.wave_threads) {
     const u32 cur = ((volatile u32*)sh.cursor)[i];
     P.dir[((u64)wave * (P.max_cycles + 1) + cycle_base + k) * 4 + i] = cur;
-    P.cursors[wave * 4 + i] = i == 3 ? cycle_base + k : cur;
+    P.cursors[wave * 4 + i] = cur;
   }
+  if (tid == 0) P.wave_cycles[wave] = cycle_base + k;
   if (exists) {
     if (s.status == ZKW_STATUS_RUNNING && s.depth == 0) s.status = ZKW_STATUS_ENDED;
     // state write-back so that a later run continues / the host can read the final state
@@ -1732,6 +1764,7 @@ __global__ void zkw_reset_kernel(zkw_fused_table T) {
     for (; i < total; i += stride) R.heap_dst[(u64)(i / row) * R.heap_pitch16 + i % row] = R.heap_src[i];
   }
   for (u32 i = t0; i < R.n_waves * 4; i += stride) R.cursors[i] = 0;
+  for (u32 i = t0; i < R.n_waves; i += stride) R.wave_cycles[i] = 0;
 }
 
 extern "C" hipError_t zkw_launch_reset_kernel(const zkw_fused_table* T, hipStream_t stream) {

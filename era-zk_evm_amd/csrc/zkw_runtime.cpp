@@ -101,7 +101,7 @@ struct zkw_batch {
   uint32_t n;
   zkw_limits lim;
   uint32_t L, n_waves;
-  uint32_t cap_mem, cap_log, cap_aux;
+  uint32_t cap_mem, cap_log, cap_aux, cap_delta;
   // staging
   std::vector<std::vector<zkw_u256>> blobs;
   std::vector<std::pair<zkw_u256, uint32_t>> preimages;
@@ -131,7 +131,8 @@ struct zkw_batch {
   DevBuf<uint2> d_blob_dir;
   DevBuf<zkw_dev_preimage> d_preimages;
   // device: outputs
-  DevBuf<uint4> d_rec, d_mem, d_log, d_auxs;
+  DevBuf<uint4> d_tails, d_deltas, d_mem, d_log, d_auxs;
+  DevBuf<uint32_t> d_wave_cycles;
   DevBuf<uint32_t> d_dir, d_cursors, d_krow;
   DevBuf<uint64_t> d_commit, d_rc, d_blob_digests, d_leaves, d_midstates;
   DevBuf<uint32_t> d_idx, d_counts;
@@ -256,6 +257,7 @@ int zkw_batch_create(zkw_ctx* c, uint32_t n, const zkw_limits* limits, zkw_batch
   if (lim.max_mem_queries == 0) lim.max_mem_queries = 6 * lim.max_cycles;
   if (lim.max_log_queries == 0) lim.max_log_queries = lim.max_cycles / 2 + 16;
   if (lim.max_aux_events == 0) lim.max_aux_events = lim.max_cycles / 4 + 16;
+  if (lim.max_reg_deltas == 0) lim.max_reg_deltas = 2 * lim.max_cycles + 32;
   auto* b = new zkw_batch();
   b->ctx = c;
   b->n = n;
@@ -276,6 +278,7 @@ int zkw_batch_create(zkw_ctx* c, uint32_t n, const zkw_limits* limits, zkw_batch
   b->cap_mem = lim.max_mem_queries * L;
   b->cap_log = lim.max_log_queries * L;
   b->cap_aux = lim.max_aux_events * L;
+  b->cap_delta = lim.max_reg_deltas * L;
   b->staged.resize(n);
   std::memset(&b->props, 0, sizeof b->props);
   b->blobs.emplace_back();  // blob 0 = the all-zero page (UNMAPPED_PAGE)
@@ -289,7 +292,7 @@ void zkw_batch_destroy(zkw_batch* b) {
   b->d_regs0.release(); b->d_scalars0.release(); b->d_callstack0.release(); b->d_frames0.release(); b->d_storage0.release(); b->d_heap0.release();
   b->d_regs.release(); b->d_scalars.release(); b->d_callstack.release(); b->d_frames.release(); b->d_storage.release(); b->d_journal.release();
   b->d_history.release(); b->d_stack_vals.release(); b->d_heap.release(); b->d_aux.release(); b->d_stack_ptrs.release(); b->d_blob_words.release();
-  b->d_blob_dir.release(); b->d_preimages.release(); b->d_rec.release(); b->d_mem.release(); b->d_log.release(); b->d_auxs.release();
+  b->d_blob_dir.release(); b->d_preimages.release(); b->d_tails.release(); b->d_deltas.release(); b->d_wave_cycles.release(); b->d_mem.release(); b->d_log.release(); b->d_auxs.release();
   b->d_dir.release(); b->d_cursors.release(); b->d_krow.release(); b->d_kp.release(); b->d_reset_params.release(); b->d_commit_params.release();
   b->d_ns_log_idx.release(); b->d_ns_log_cnt.release(); b->d_ns_aux_idx.release(); b->d_ns_aux_cnt.release(); b->d_ns_st_hist.release();
   b->d_ns_ev_hist.release(); b->d_ns_rb_st.release(); b->d_ns_rb_ev.release(); b->d_ns_marks.release(); b->d_ns_counts.release();
@@ -650,7 +653,9 @@ int zkw_batch_upload(zkw_batch* b) {
   HIP_TRY(c, ensure(b->d_stack_ptrs, (size_t)W * F * lim.stack_words * L));
   HIP_TRY(c, ensure(b->d_heap, (size_t)W * F * lim.heap_words * L * 2));
   HIP_TRY(c, ensure(b->d_aux, (size_t)W * F * lim.aux_heap_words * L * 2));
-  HIP_TRY(c, ensure(b->d_rec, (size_t)W * lim.max_cycles * ZKW_REC_CHUNKS * L));
+  HIP_TRY(c, ensure(b->d_tails, (size_t)W * lim.max_cycles * 2 * L));
+  HIP_TRY(c, ensure(b->d_deltas, (size_t)W * b->cap_delta * 2));
+  HIP_TRY(c, ensure(b->d_wave_cycles, (size_t)W));
   HIP_TRY(c, ensure(b->d_mem, (size_t)W * b->cap_mem * 3));
   HIP_TRY(c, ensure(b->d_log, (size_t)W * b->cap_log * 8));
   HIP_TRY(c, ensure(b->d_auxs, (size_t)W * b->cap_aux * 16));
@@ -673,13 +678,17 @@ int zkw_batch_upload(zkw_batch* b) {
   P.consts = c->isa.consts;
   P.wave_threads = (uint32_t)c->wave_width;
   P.waves_per_group = c->wave_width > 1 ? ZKW_WAVES_PER_GROUP : 1;
+  if (const char* env = getenv("ZKW_WAVES_PER_GROUP")) {  // experiments: 1, 2 or 4
+    const int g = atoi(env);
+    if (c->wave_width > 1 && (g == 1 || g == 2 || g == 4)) P.waves_per_group = (uint32_t)g;
+  }
   P.isa = c->d_isa;
   P.krow = b->d_krow.p;
   P.regs = b->d_regs.p; P.scalars = b->d_scalars.p; P.callstack = b->d_callstack.p; P.frames = b->d_frames.p;
   P.stack_vals = b->d_stack_vals.p; P.stack_ptrs = b->d_stack_ptrs.p; P.heap = b->d_heap.p; P.aux_heap = b->d_aux.p;
   P.storage = b->d_storage.p; P.journal = b->d_journal.p; P.history = b->d_history.p;
   P.blob_words = b->d_blob_words.p; P.blob_dir = b->d_blob_dir.p; P.preimages = b->d_preimages.p;
-  P.rec = b->d_rec.p; P.mem_stream = b->d_mem.p; P.log_stream = b->d_log.p; P.aux_stream = b->d_auxs.p;
+  P.tails = b->d_tails.p; P.deltas = b->d_deltas.p; P.wave_cycles = b->d_wave_cycles.p; P.cap_delta = b->cap_delta; P.mem_stream = b->d_mem.p; P.log_stream = b->d_log.p; P.aux_stream = b->d_auxs.p;
   P.dir = b->d_dir.p; P.cursors = b->d_cursors.p;
   P.props = b->props;
   HIP_TRY(c, ensure(b->d_kp, 1));
@@ -697,6 +706,7 @@ int zkw_batch_upload(zkw_batch* b) {
     R.heap_pitch16 = b->lim.max_far_frames * b->lim.heap_words * b->L * 2;
     R.n_waves = b->n_waves;
     R.cursors = b->d_cursors.p;
+    R.wave_cycles = b->d_wave_cycles.p;
     HIP_TRY(c, ensure(b->d_reset_params, 1));
     HIP_TRY(c, hipMemcpy(b->d_reset_params.p, &R, sizeof R, hipMemcpyHostToDevice));
     const uint32_t caps[3] = {b->cap_mem, b->cap_log, b->cap_aux};
@@ -942,6 +952,7 @@ int zkw_batch_get_stats(zkw_batch* b, zkw_run_stats* out) {
     out->mem_queries += std::min(b->h_cursors[(size_t)w * 4 + 0], b->cap_mem);
     out->log_queries += std::min(b->h_cursors[(size_t)w * 4 + 1], b->cap_log);
     out->aux_events += std::min(b->h_cursors[(size_t)w * 4 + 2], b->cap_aux);
+    out->reg_deltas += std::min(b->h_cursors[(size_t)w * 4 + 3], b->cap_delta);
   }
   out->kernel_ms = b->kernel_ms;
   return ZKW_OK;
@@ -972,16 +983,64 @@ static int build_wave(zkw_batch* b, uint32_t w) {
   if (n_mem) HIP_TRY(c, hipMemcpy(mem.data(), b->d_mem.p + (size_t)w * b->cap_mem * 3, (size_t)n_mem * 48, hipMemcpyDeviceToHost));
   if (n_log) HIP_TRY(c, hipMemcpy(log.data(), b->d_log.p + (size_t)w * b->cap_log * 8, (size_t)n_log * 128, hipMemcpyDeviceToHost));
   if (n_aux) HIP_TRY(c, hipMemcpy(aux.data(), b->d_auxs.p + (size_t)w * b->cap_aux * 16, (size_t)n_aux * 256, hipMemcpyDeviceToHost));
-  // records
-  std::vector<uint4> rec((size_t)max_cycles_lane * ZKW_REC_CHUNKS * L);
+  // records: tails [cycle][2][L] + register deltas of the wave; the 512-byte snapshots are rebuilt from the initial
+  // register file by replaying every lane's deltas (positions from the dirty masks, see zkw_cycle_kernel)
+  std::vector<uint4> tails((size_t)max_cycles_lane * 2 * L);
   if (max_cycles_lane)
-    HIP_TRY(c, hipMemcpy(rec.data(), b->d_rec.p + (size_t)w * MC * ZKW_REC_CHUNKS * L, rec.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(tails.data(), b->d_tails.p + (size_t)w * MC * 2 * L, tails.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+  const uint32_t n_delta = std::min(b->h_cursors[(size_t)w * 4 + 3], b->cap_delta);
+  std::vector<uint4> deltas((size_t)n_delta * 2);
+  if (n_delta) HIP_TRY(c, hipMemcpy(deltas.data(), b->d_deltas.p + (size_t)w * b->cap_delta * 2, deltas.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+  std::vector<uint4> regs0((size_t)ZKW_REG_CHUNKS * L);
+  HIP_TRY(c, hipMemcpy(regs0.data(), b->d_regs0.p + (size_t)w * ZKW_REG_CHUNKS * L, regs0.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+  std::vector<std::array<uint4, ZKW_REG_CHUNKS>> cur(L);
   for (uint32_t l = 0; l < L; l++) {
     wt->records[l].resize(ncyc[l]);
-    for (uint32_t k = 0; k < ncyc[l]; k++) {
-      uint4* dst = (uint4*)&wt->records[l][k];
-      for (uint32_t ch = 0; ch < ZKW_REC_CHUNKS; ch++) dst[ch] = rec[((size_t)k * ZKW_REC_CHUNKS + ch) * L + l];
+    for (uint32_t ch = 0; ch < ZKW_REG_CHUNKS; ch++) cur[l][ch] = regs0[(size_t)ch * L + l];
+  }
+  {
+    std::vector<uint32_t> mask(L), cnt(L);
+    for (uint32_t k = 0; k < max_cycles_lane; k++) {
+      const uint32_t base = dir[(size_t)k * 4 + 3];
+      uint32_t max_cnt = 0;
+      for (uint32_t l = 0; l < L; l++) {
+        mask[l] = 0; cnt[l] = 0;
+        if (k >= ncyc[l]) continue;
+        const uint4 t0 = tails[((size_t)k * 2) * L + l], t1 = tails[((size_t)k * 2 + 1) * L + l];
+        mask[l] = (t0.x >> 24) | ((t1.w >> 24) << 8);
+        cnt[l] = (uint32_t)__builtin_popcount(mask[l]);
+        max_cnt = std::max(max_cnt, cnt[l]);
+      }
+      uint32_t before = 0;
+      for (uint32_t j = 0; j < max_cnt; j++) {  // round j: the lanes with more than j deltas, in lane order
+        uint32_t rank = 0;
+        for (uint32_t l = 0; l < L; l++) {
+          if (cnt[l] <= j) continue;
+          uint32_t m = mask[l];
+          for (uint32_t skip = 0; skip < j; skip++) m &= m - 1;
+          const uint32_t r = (uint32_t)__builtin_ctz(m);
+          const uint32_t pos = base + before + rank;
+          if (pos < n_delta) {
+            cur[l][2 * r] = deltas[(size_t)pos * 2];
+            cur[l][2 * r + 1] = deltas[(size_t)pos * 2 + 1];
+          }
+          rank++;
+        }
+        before += rank;
+      }
+      for (uint32_t l = 0; l < L; l++) {
+        if (k >= ncyc[l]) continue;
+        uint4* dst = (uint4*)&wt->records[l][k];
+        for (uint32_t ch = 0; ch < ZKW_REG_CHUNKS; ch++) dst[ch] = cur[l][ch];
+        uint4 t0 = tails[((size_t)k * 2) * L + l], t1 = tails[((size_t)k * 2 + 1) * L + l];
+        t0.x &= 0x00ffffffu;  // the dirty mask is device bookkeeping: reserved byte and top byte of the counts are zero in the ABI
+        t1.w &= 0x00ffffffu;
+        dst[30] = t0;
+        dst[31] = t1;
+      }
     }
+  }
+  for (uint32_t l = 0; l < L; l++) {
     wt->mem_off[l].assign(1, 0); wt->log_off[l].assign(1, 0); wt->aux_off[l].assign(1, 0);
   }
   // bucket the stream records by lane, cycle by cycle (stream order preserves each lane's order)
@@ -1122,7 +1181,7 @@ int zkw_batch_net_states(zkw_batch* b, void* hip_stream) {
     N.n_instances = b->n; N.L = b->L; N.n_waves = b->n_waves; N.max_cycles = b->lim.max_cycles; N.wave_threads = (uint32_t)c->wave_width;
     N.cap_log = b->cap_log; N.cap_aux = b->cap_aux; N.per_log = per_log; N.per_aux = per_aux; N.hist_cap = 2 * per_log; N.mark_cap = mark_cap;
     N.storage_aux_byte = c->isa.consts.storage_aux_byte; N.event_aux_byte = c->isa.consts.event_aux_byte; N.l1_aux_byte = c->isa.consts.l1_message_aux_byte;
-    N.rec = b->d_rec.p; N.log_stream = b->d_log.p; N.aux_stream = b->d_auxs.p; N.scalars = b->d_scalars.p; N.scalars0 = b->d_scalars0.p;
+    N.tails = b->d_tails.p; N.log_stream = b->d_log.p; N.aux_stream = b->d_auxs.p; N.scalars = b->d_scalars.p; N.scalars0 = b->d_scalars0.p;
     N.log_idx = b->d_ns_log_idx.p; N.log_cnt = b->d_ns_log_cnt.p; N.aux_idx = b->d_ns_aux_idx.p; N.aux_cnt = b->d_ns_aux_cnt.p;
     N.st_hist = b->d_ns_st_hist.p; N.ev_hist = b->d_ns_ev_hist.p; N.rb_st = b->d_ns_rb_st.p; N.rb_ev = b->d_ns_rb_ev.p; N.marks = b->d_ns_marks.p;
     N.out_counts = b->d_ns_counts.p;

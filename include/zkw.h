@@ -231,7 +231,8 @@ typedef struct zkw_limits {
   uint32_t max_log_queries;       /* LogQuery records per instance and per run; 0 = 2*max_cycles    */
   uint32_t max_aux_events;        /* aux events per instance and per run; 0 = derived               */
   uint32_t lanes_per_wave;        /* 0 = let the library choose (1..64, power of two)               */
-  uint32_t reserved[4];
+  uint32_t max_reg_deltas;        /* register writes recorded per instance and per run; 0 = 2*max_cycles + 32 */
+  uint32_t reserved[3];
 } zkw_limits;
 
 /* ------------------------------------------------------------------------------------ */
@@ -373,7 +374,7 @@ typedef struct zkw_run_stats {
   uint64_t instances_ended;
   uint64_t instances_failed; /* status >= ZKW_STATUS_UNKNOWN_CODE_HASH */
   double kernel_ms;     /* device time of the last run's cycle kernel (HIP events on the run stream) */
-  double reserved0;
+  uint64_t reg_deltas;  /* register values written to the delta stream (CycleRecords are stored as tail + deltas) */
 } zkw_run_stats;
 
 /* ------------------------------------------------------------------------------------ */
