@@ -146,6 +146,9 @@ typedef struct zkw_kparams {
   uint4* tails;                /* [n_waves][max_cycles][2][L]: the 32-B record tail of every executed cycle (+ dirty-register mask) */
   uint4* deltas;               /* [n_waves][cap_delta][2]: 32-B values of the registers a cycle wrote, dense per wave               */
   uint32_t* wave_cycles;       /* [n_waves] wave-cycles run since the reset */
+  uint32_t* heap_dirty;        /* [n_waves][ceil(heap_image_words / 32)][L]: words of the heap image overwritten since the reset */
+  uint32_t heap_image_words;   /* words of the uploaded heap image (frame slot 0) */
+  uint32_t reserved4;
   uint4* mem_stream;           /* [n_waves][cap_mem][3]                  */
   uint4* log_stream;           /* [n_waves][cap_log][8]                  */
   uint4* aux_stream;           /* [n_waves][cap_aux][16]                 */
@@ -172,7 +175,8 @@ typedef struct zkw_fused_table {
   uint32_t max_cap;      /* leaf kernel: upper bound of records per wave */
   uint32_t wave_threads;
   uint32_t n_blobs;      /* blob-chain stage only */
-  uint32_t reserved[3];  /* [0]: leaf stage: the queue (ZKW_QUEUE_* / ZKW_QUEUE_CODE_WORDS) of the blocks in the table */
+  uint32_t reserved[3];  /* [0]: leaf stage: the queue (ZKW_QUEUE_* / ZKW_QUEUE_CODE_WORDS) of the blocks in the table;
+                            [1]: reset kernel: 1 = copy the whole heap image (first reset after an upload) */
 } zkw_fused_table;
 
 /* zkw_reset_kernel: working state := pristine images, one launch */
@@ -187,4 +191,7 @@ typedef struct zkw_reset_params {
   uint32_t n_waves;
   uint32_t* cursors;         /* [n_waves][4] */
   uint32_t* wave_cycles;     /* [n_waves] */
+  uint32_t* heap_dirty;      /* [n_waves][ceil(image_words / 32)][L] */
+  uint32_t image_words;      /* words of the heap image */
+  uint32_t L;
 } zkw_reset_params;

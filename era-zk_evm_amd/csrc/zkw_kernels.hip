@@ -262,6 +262,11 @@ ZD void heap_write_cur(ZKW_KP P, Lane& s, bool is_aux, u32 idx, const u256& v) {
   const u64 w = page_word_index(P, s, s.slot, words, idx);
   base[2 * w] = u256_lo4(v);
   base[2 * w + 1] = u256_hi4(v);
+  if (!is_aux && s.slot == 0 && idx < P.heap_image_words) {
+    // a word of the uploaded heap image is overwritten: remember it, the next reset restores only those words
+    u32* d = P.heap_dirty + ((u64)s.wave * ((P.heap_image_words + 31u) >> 5) + (idx >> 5)) * P.L + s.lane;
+    *d |= 1u << (idx & 31u);
+  }
   if (idx >= hwm) hwm = idx + 1;
   if (is_aux) s.aux_hwm = hwm; else s.heap_hwm = hwm;
 }
@@ -1748,10 +1753,10 @@ __global__ void zkw_reset_kernel(zkw_fused_table T) {
     }
     for (; i < n; i += stride) dst[i] = src[i];
   }
-  // heap image: [n_waves][heap_row16] (dense) -> rows of the working arena, one flat index space
+  // heap image: [n_waves][heap_row16] (dense) -> rows of the working arena
   const u32 row = R.heap_row16;
-  const u32 total = R.n_waves * row;
-  if (row) {
+  if (row && T.reserved[1]) {  // first reset after an upload: the whole image, one flat index space
+    const u32 total = R.n_waves * row;
     u32 i = t0;
     for (; i + 3 * stride < total; i += 4 * stride) {
       const u32 i1 = i + stride, i2 = i + 2 * stride, i3 = i + 3 * stride;
@@ -1762,6 +1767,27 @@ __global__ void zkw_reset_kernel(zkw_fused_table T) {
       R.heap_dst[(u64)(i3 / row) * R.heap_pitch16 + i3 % row] = e;
     }
     for (; i < total; i += stride) R.heap_dst[(u64)(i / row) * R.heap_pitch16 + i % row] = R.heap_src[i];
+    const u32 nd = R.n_waves * ((R.image_words + 31u) >> 5) * R.L;
+    for (u32 j = t0; j < nd; j += stride) R.heap_dirty[j] = 0;
+  } else if (row) {
+    // later resets: only the words the run overwrote (the cycle kernel sets one bit per overwritten image word).  One
+    // thread owns one 32-word mask of one lane: it restores those words and clears the mask, so no second pass is needed.
+    const u32 groups = (R.image_words + 31u) >> 5;
+    const u32 nd = R.n_waves * groups * R.L;
+    for (u32 j = t0; j < nd; j += stride) {
+      u32 m = R.heap_dirty[j];
+      if (!m) continue;
+      R.heap_dirty[j] = 0;
+      const u32 lane = j % R.L, g = (j / R.L) % groups, w = j / (R.L * groups);
+      while (m) {
+        const u32 word = g * 32u + (u32)__ffsll((long long)m) - 1u;
+        m &= m - 1u;
+        const u32 off = (word * R.L + lane) * 2u;  // [word][lane][2] inside the wave's row
+        const uint4 a = R.heap_src[(u64)w * row + off], c = R.heap_src[(u64)w * row + off + 1];
+        R.heap_dst[(u64)w * R.heap_pitch16 + off] = a;
+        R.heap_dst[(u64)w * R.heap_pitch16 + off + 1] = c;
+      }
+    }
   }
   for (u32 i = t0; i < R.n_waves * 4; i += stride) R.cursors[i] = 0;
   for (u32 i = t0; i < R.n_waves; i += stride) R.wave_cycles[i] = 0;

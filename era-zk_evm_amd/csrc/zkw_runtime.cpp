@@ -132,7 +132,8 @@ struct zkw_batch {
   DevBuf<zkw_dev_preimage> d_preimages;
   // device: outputs
   DevBuf<uint4> d_tails, d_deltas, d_mem, d_log, d_auxs;
-  DevBuf<uint32_t> d_wave_cycles;
+  DevBuf<uint32_t> d_wave_cycles, d_heap_dirty;
+  bool full_reset_pending = true;  // the first reset after an upload copies the whole heap image
   DevBuf<uint32_t> d_dir, d_cursors, d_krow;
   DevBuf<uint64_t> d_commit, d_rc, d_blob_digests, d_leaves, d_midstates;
   DevBuf<uint32_t> d_idx, d_counts;
@@ -292,7 +293,7 @@ void zkw_batch_destroy(zkw_batch* b) {
   b->d_regs0.release(); b->d_scalars0.release(); b->d_callstack0.release(); b->d_frames0.release(); b->d_storage0.release(); b->d_heap0.release();
   b->d_regs.release(); b->d_scalars.release(); b->d_callstack.release(); b->d_frames.release(); b->d_storage.release(); b->d_journal.release();
   b->d_history.release(); b->d_stack_vals.release(); b->d_heap.release(); b->d_aux.release(); b->d_stack_ptrs.release(); b->d_blob_words.release();
-  b->d_blob_dir.release(); b->d_preimages.release(); b->d_tails.release(); b->d_deltas.release(); b->d_wave_cycles.release(); b->d_mem.release(); b->d_log.release(); b->d_auxs.release();
+  b->d_blob_dir.release(); b->d_preimages.release(); b->d_tails.release(); b->d_deltas.release(); b->d_wave_cycles.release(); b->d_heap_dirty.release(); b->d_mem.release(); b->d_log.release(); b->d_auxs.release();
   b->d_dir.release(); b->d_cursors.release(); b->d_krow.release(); b->d_kp.release(); b->d_reset_params.release(); b->d_commit_params.release();
   b->d_ns_log_idx.release(); b->d_ns_log_cnt.release(); b->d_ns_aux_idx.release(); b->d_ns_aux_cnt.release(); b->d_ns_st_hist.release();
   b->d_ns_ev_hist.release(); b->d_ns_rb_st.release(); b->d_ns_rb_ev.release(); b->d_ns_marks.release(); b->d_ns_counts.release();
@@ -656,6 +657,8 @@ int zkw_batch_upload(zkw_batch* b) {
   HIP_TRY(c, ensure(b->d_tails, (size_t)W * lim.max_cycles * 2 * L));
   HIP_TRY(c, ensure(b->d_deltas, (size_t)W * b->cap_delta * 2));
   HIP_TRY(c, ensure(b->d_wave_cycles, (size_t)W));
+  HIP_TRY(c, ensure(b->d_heap_dirty, std::max<size_t>(1, (size_t)W * ((b->heap_image_words + 31) / 32) * L)));
+  b->full_reset_pending = true;
   HIP_TRY(c, ensure(b->d_mem, (size_t)W * b->cap_mem * 3));
   HIP_TRY(c, ensure(b->d_log, (size_t)W * b->cap_log * 8));
   HIP_TRY(c, ensure(b->d_auxs, (size_t)W * b->cap_aux * 16));
@@ -688,7 +691,7 @@ int zkw_batch_upload(zkw_batch* b) {
   P.stack_vals = b->d_stack_vals.p; P.stack_ptrs = b->d_stack_ptrs.p; P.heap = b->d_heap.p; P.aux_heap = b->d_aux.p;
   P.storage = b->d_storage.p; P.journal = b->d_journal.p; P.history = b->d_history.p;
   P.blob_words = b->d_blob_words.p; P.blob_dir = b->d_blob_dir.p; P.preimages = b->d_preimages.p;
-  P.tails = b->d_tails.p; P.deltas = b->d_deltas.p; P.wave_cycles = b->d_wave_cycles.p; P.cap_delta = b->cap_delta; P.mem_stream = b->d_mem.p; P.log_stream = b->d_log.p; P.aux_stream = b->d_auxs.p;
+  P.tails = b->d_tails.p; P.deltas = b->d_deltas.p; P.wave_cycles = b->d_wave_cycles.p; P.cap_delta = b->cap_delta; P.heap_dirty = b->d_heap_dirty.p; P.heap_image_words = b->heap_image_words; P.mem_stream = b->d_mem.p; P.log_stream = b->d_log.p; P.aux_stream = b->d_auxs.p;
   P.dir = b->d_dir.p; P.cursors = b->d_cursors.p;
   P.props = b->props;
   HIP_TRY(c, ensure(b->d_kp, 1));
@@ -707,6 +710,7 @@ int zkw_batch_upload(zkw_batch* b) {
     R.n_waves = b->n_waves;
     R.cursors = b->d_cursors.p;
     R.wave_cycles = b->d_wave_cycles.p;
+    R.heap_dirty = b->d_heap_dirty.p; R.image_words = b->heap_image_words; R.L = b->L;
     HIP_TRY(c, ensure(b->d_reset_params, 1));
     HIP_TRY(c, hipMemcpy(b->d_reset_params.p, &R, sizeof R, hipMemcpyHostToDevice));
     const uint32_t caps[3] = {b->cap_mem, b->cap_log, b->cap_aux};
@@ -768,7 +772,11 @@ static int enqueue_reset(zkw_batch* const* bs, uint32_t n, hipStream_t st) {
   std::memset(&T, 0, sizeof T);
   T.n = n;
   T.wave_threads = (uint32_t)c->wave_width;
-  for (uint32_t i = 0; i < n; i++) T.p[i] = bs[i]->d_reset_params.p;
+  for (uint32_t i = 0; i < n; i++) {
+    T.p[i] = bs[i]->d_reset_params.p;
+    if (bs[i]->full_reset_pending) T.reserved[1] = 1;  // any freshly uploaded batch in the group: whole heap images for all
+    bs[i]->full_reset_pending = false;
+  }
   HIP_TRY(c, zkw_launch_reset_kernel(&T, st));
   for (uint32_t i = 0; i < n; i++) {
     zkw_batch* b = bs[i];
