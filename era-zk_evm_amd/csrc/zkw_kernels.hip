@@ -29,7 +29,6 @@ struct Lane {
   // identity
   u32 inst, wave, lane;
   // VmLocalState scalars (mod.rs:54-73)
-  u32 pcw[8];  // previous_code_word
   u32 ctx_reg[4];
   u32 ptr_bitmap, flags, prev_code_page, timestamp, cycle_counter, spent_pubdata, mpc, ergs_pp, tx_number, prev_super_pc, depth;
   // run bookkeeping
@@ -100,6 +99,7 @@ struct Shared {
   u32* cursor;    // [4] stream cursors of this wave
   uint4* regs;    // [30][L] register file, 16-byte chunks, lane-minor
   u32* krow;      // [34][L] Keccak rate block assembly rows (global memory)
+  uint2* pcw;     // [4][L] previous_code_word as 4 opcode slots (u64 limb k), lane-minor — read once per cycle, LDS
   u32 L;
   u32 debug_flags;
 };
@@ -1516,6 +1516,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   sh.isa = (uint2*)zkw_lds;                                                        // 16 KB
   sh.cursor = (u32*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + wib * (1 + ZKW_REG_CHUNKS * P.L));  // 16 B
   sh.regs = (uint4*)sh.cursor + 1;                                                  // 30 * L * 16 B
+  sh.pcw = (uint2*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + P.waves_per_group * (1 + ZKW_REG_CHUNKS * P.L)) + wib * 4 * P.L;  // 4 * L * 8 B
   sh.krow = P.krow + (u64)wave * ZKW_KROW_WORDS * P.L;
   // stage the packed ISA table in LDS (all threads of the workgroup, 16 B each per step)
   {
@@ -1538,7 +1539,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   if (exists) {
     const zkw_dev_scalars sc = P.scalars[inst];
 #pragma unroll
-    for (int i = 0; i < 8; i++) s.pcw[i] = sc.prev_code_word[i];
+    for (int i = 0; i < 4; i++) sh.pcw[i * P.L + tid] = make_uint2(sc.prev_code_word[2 * i], sc.prev_code_word[2 * i + 1]);
 #pragma unroll
     for (int i = 0; i < 4; i++) s.ctx_reg[i] = sc.ctx_u128_reg[i];
     s.ptr_bitmap = sc.ptr_bitmap; s.flags = sc.flags; s.prev_code_page = sc.prev_code_page; s.timestamp = sc.timestamp;
@@ -1580,13 +1581,12 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
           const u256 word = code_read(P, s, super_pc);
           emit_mem(P, sh, s, s.timestamp, ZKW_MEM_CODE, s.code_page, super_pc, word, false, false, 0);
 #pragma unroll
-          for (int i = 0; i < 8; i++) s.pcw[i] = word.w[i];
+          for (int i = 0; i < 4; i++) sh.pcw[i * P.L + tid] = make_uint2(word.w[2 * i], word.w[2 * i + 1]);
           s.prev_super_pc = super_pc;
         }
         // integer_representaiton_from_u256: opcode k of a word is u64 limb 3-k (:86-94)
-        const u32 lo = sub_pc == 0 ? s.pcw[6] : (sub_pc == 1 ? s.pcw[4] : (sub_pc == 2 ? s.pcw[2] : s.pcw[0]));
-        const u32 hi = sub_pc == 0 ? s.pcw[7] : (sub_pc == 1 ? s.pcw[5] : (sub_pc == 2 ? s.pcw[3] : s.pcw[1]));
-        enc = ((u64)hi << 32) | lo;
+        const uint2 slot = sh.pcw[(3u - sub_pc) * P.L + tid];
+        enc = ((u64)slot.y << 32) | slot.x;
       } else {  // :104-115
         s.flags &= ~FLAG_PENDING;
         s.prev_super_pc = super_pc;
@@ -1718,7 +1718,11 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
     hwm_writeback(P, s);
     zkw_dev_scalars sc;
 #pragma unroll
-    for (int i = 0; i < 8; i++) sc.prev_code_word[i] = s.pcw[i];
+    for (int i = 0; i < 4; i++) {
+      const uint2 v = sh.pcw[i * P.L + tid];
+      sc.prev_code_word[2 * i] = v.x;
+      sc.prev_code_word[2 * i + 1] = v.y;
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) sc.ctx_u128_reg[i] = s.ctx_reg[i];
     sc.ptr_bitmap = s.ptr_bitmap; sc.flags = s.flags; sc.prev_code_page = s.prev_code_page; sc.timestamp = s.timestamp;
@@ -1803,7 +1807,9 @@ extern "C" hipError_t zkw_launch_reset_kernel(const zkw_fused_table* T, hipStrea
 }
 
 // dynamic LDS per workgroup: ISA table + per wave (cursors + per-lane register file)
-extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_group) { return ZKW_ISA_TABLE_SIZE * 8 + waves_per_group * (16 + L * ZKW_REG_CHUNKS * 16); }
+extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_group) {
+  return ZKW_ISA_TABLE_SIZE * 8 + waves_per_group * (16 + L * ZKW_REG_CHUNKS * 16 + L * 32);  // + previous_code_word: 32 B per lane
+}
 
 // host-callable launcher (keeps <<<>>> out of the runtime)
 extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_launch_args* A, hipStream_t stream) {
