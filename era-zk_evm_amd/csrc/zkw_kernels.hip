@@ -1482,17 +1482,12 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d) {
         dst0_update(P, sh, s, ps.dst0, d.dst0, r, false);
         break;
       }
-      case ZKW_OP_CONTEXT:
-      case ZKW_OP_PTR:
-      case ZKW_OP_LOG:
-      case ZKW_OP_NEAR_CALL:
-      case ZKW_OP_FAR_CALL:
-      case ZKW_OP_RET: {
-        Lane tmp = s;
-        zkw_rare_op(P, sh, &tmp, &d, &ps);
-        s = tmp;
-        break;
-      }
+      case ZKW_OP_CONTEXT: op_context(P, sh, s, d, ps); break;
+      case ZKW_OP_PTR: op_ptr(P, sh, s, d, ps); break;
+      case ZKW_OP_LOG: op_log(P, sh, s, d, ps); break;
+      case ZKW_OP_NEAR_CALL: op_near_call(P, sh, s, d, ps); break;
+      case ZKW_OP_FAR_CALL: op_far_call(P, sh, s, d, ps); break;
+      case ZKW_OP_RET: op_ret(P, sh, s, d, ps); break;
       case ZKW_OP_UMA: op_uma(P, sh, s, d, ps); break;
       default: lane_fail(s, ZKW_STATUS_REFERENCE_PANIC); break;  // Opcode::Invalid => unreachable!() parsing.rs:77
     }
@@ -1638,7 +1633,8 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
           d.attr = u_attr;
           d.cond = (u_lo >> 13) & 7u; d.src0 = (u_lo >> 16) & 15u; d.src1 = (u_lo >> 20) & 15u; d.dst0 = (u_lo >> 24) & 15u; d.dst1 = u_lo >> 28;
           d.imm0 = u_hi & 0xffffu; d.imm1 = u_hi >> 16;
-          exec_decoded(P, sh, s, d);
+          if (A.debug_flags & 8u) s.pc = (s.pc + 1u) & 0xffffu;  // profiling ablation: no operand / opcode work
+          else exec_decoded(P, sh, s, d);
         }
       }
       // ----------------------------------------------------------------------------------------
