@@ -1297,16 +1297,31 @@ ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
 // ---------------------------------------------------------------------------------------------
 #include "zkw_precompiles.hip.h"
 
+// The precompile bodies (Keccak-f state of 50 VGPRs, SHA-256 schedule, secp256k1) are compiled as ONE out-of-line
+// function that takes and returns the lane state by value.  Inlined, their register demand made the allocator park the
+// hot per-cycle state in AGPRs for the whole kernel (256 VGPR + 256 AGPR, ~1000 v_accvgpr_read in the code, a reload
+// per use); out of line, the cycle loop itself fits 254 VGPRs with no AGPR traffic and only the lanes that execute a
+// precompile call pay for the call (profiles/r01_kernel_variants.md).
+__device__ __noinline__ Lane zkw_precompile_entry(const zkw_kparams ZKW_CONST_AS* Pp, Shared sh, Lane s, LogQ q, u32 which) {
+  ZKW_KP P = *Pp;
+  if (which == 0) precompile_keccak256(P, sh, s, q);
+  else if (which == 1) precompile_sha256(P, sh, s, q);
+#ifndef ZKW_EXPERIMENT_NO_ECRECOVER
+  else precompile_ecrecover(P, sh, s, q);
+#endif
+  return s;
+}
+
 // helpers.rs:196-223 + DefaultPrecompilesProcessor dispatch on the low 16 address bits
 ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   emit_log(P, sh, s, q, ZKW_LQ_LOG);
   const u32 addr_low = q.address[0] & 0xffffu;
-  if (addr_low == P.consts.keccak_precompile_address) precompile_keccak256(P, sh, s, q);
-  else if (addr_low == P.consts.sha256_precompile_address) precompile_sha256(P, sh, s, q);
-#ifndef ZKW_EXPERIMENT_NO_ECRECOVER
-  else if (addr_low == P.consts.ecrecover_precompile_address) precompile_ecrecover(P, sh, s, q);
-#endif
-  // anything else (incl. ecrecover, not built yet) behaves as an unknown precompile: no memory traffic
+  u32 which = 3;
+  if (addr_low == P.consts.keccak_precompile_address) which = 0;
+  else if (addr_low == P.consts.sha256_precompile_address) which = 1;
+  else if (addr_low == P.consts.ecrecover_precompile_address) which = 2;
+  // anything else behaves as an unknown precompile: no memory traffic
+  if (which < 3) s = zkw_precompile_entry(&P, sh, s, q, which);
 }
 
 // ---------------------------------------------------------------------------------------------
