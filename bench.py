@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--fuse", type=int, default=32, help="batches (steps) per fused launch (zkw_batches_step), <= 32")
     ap.add_argument("--streams", type=int, default=2, help="fused groups in flight (1 = everything on one stream; >= 2 = cycle kernels on the main stream, commitments + restores on side streams)")
     ap.add_argument("--side", choices=["commit", "commit+reset"], default="commit", help="what the side streams carry when --streams >= 2")
+    ap.add_argument("--main-priority", type=int, default=0, help="1 = create the main stream with high priority")
     ap.add_argument("--cfg", type=int, default=2)
     ap.add_argument("--min-warmup-s", type=float, default=0.6, help="untimed warm-up is extended to at least this long (clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -69,7 +70,8 @@ def main():
     fuse = max(1, min(args.fuse, 32, args.steps))
     n_groups = max(1, min(args.streams, (args.steps + fuse - 1) // fuse))
     groups = [[prod.create_batch(wl) for _ in range(fuse)] for _ in range(n_groups)]
-    streams = [torch.cuda.Stream(device=local_rank) for _ in range(n_groups)]
+    # the main stream (cycle kernels) gets the higher queue priority, the side streams fill in behind it
+    streams = [torch.cuda.Stream(device=local_rank, priority=(-1 if args.main_priority else 0)) for _ in range(n_groups)]
     batches = [b for g in groups for b in g]
     batch = batches[0]
 

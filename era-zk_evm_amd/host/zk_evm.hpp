@@ -17,6 +17,7 @@
 #include <cstring>
 #include <functional>
 #include <stdexcept>
+#include <map>
 #include <vector>
 
 #include "../../include/zkw.h"
@@ -103,6 +104,62 @@ struct EventSink {
   virtual void add_partial_query(uint32_t, const LogQuery&) {}
   virtual void start_frame(uint32_t /*timestamp*/) {}
   virtual void finish_frame(bool /*panicked*/, uint32_t /*timestamp*/) {}
+};
+
+// reference_impls/event_sink.rs:7-14
+struct EventMessage {
+  uint8_t shard_id;
+  bool is_first;
+  uint16_t tx_number_in_block;
+  Address address;
+  U256 key, value;
+};
+
+// The reference's own EventSink implementation (reference_impls/event_sink.rs:51-176), for callers that used
+// `InMemoryEventSink` under the reference: driven by BatchedVmState's replay it ends in the same state, so `flatten()`
+// (:66-131) returns the same (history, events, l1 messages) — the device computes the same thing for every instance
+// at once (zkw_batch_get_net_state); tests/test_host_replay.py checks the two against each other.
+struct InMemoryEventSink : EventSink {
+  struct ApplicationData {  // :29-33
+    std::vector<LogQuery> forward, rollbacks;
+  };
+  std::vector<ApplicationData> frames_stack;
+  uint8_t event_aux_byte = 1;
+  InMemoryEventSink() { frames_stack.emplace_back(); }  // :61: a single keeper frame
+  void add_partial_query(uint32_t, const LogQuery& query) override {  // :140-151
+    ApplicationData& f = frames_stack.back();
+    f.forward.push_back(query);
+    LogQuery rb = query;
+    rb.rollback = true;
+    f.rollbacks.push_back(rb);
+  }
+  void start_frame(uint32_t) override { frames_stack.emplace_back(); }  // :152-155
+  void finish_frame(bool panicked, uint32_t) override {                  // :156-176
+    ApplicationData cur = std::move(frames_stack.back());
+    frames_stack.pop_back();
+    ApplicationData& parent = frames_stack.back();
+    parent.forward.insert(parent.forward.end(), cur.forward.begin(), cur.forward.end());
+    if (panicked) parent.forward.insert(parent.forward.end(), cur.rollbacks.rbegin(), cur.rollbacks.rend());
+    else parent.rollbacks.insert(parent.rollbacks.end(), cur.rollbacks.begin(), cur.rollbacks.end());
+  }
+  // :66-131; open frames (an instance that is still running) are netted as if they were kept
+  void flatten(std::vector<LogQuery>* history, std::vector<EventMessage>* events, std::vector<EventMessage>* l1_messages) const {
+    history->clear();
+    for (const ApplicationData& f : frames_stack) history->insert(history->end(), f.forward.begin(), f.forward.end());
+    std::map<uint32_t, LogQuery> tmp;
+    for (const LogQuery& el : *history) {
+      auto it = tmp.find(el.timestamp);
+      if (it != tmp.end()) tmp.erase(it);  // :88 (a rollback of the entry with this timestamp)
+      else tmp.emplace(el.timestamp, el);
+    }
+    events->clear();
+    l1_messages->clear();
+    for (const auto& kv : tmp) {
+      const LogQuery& el = kv.second;
+      EventMessage m{el.shard_id, el.is_service, el.tx_number_in_block, el.address, el.key, el.written_value};
+      (el.aux_byte == event_aux_byte ? *events : *l1_messages).push_back(m);
+    }
+  }
 };
 
 inline U256 to_u256(const zkw_u256& v) {

@@ -104,3 +104,46 @@ extern "C" int zkw_host_replay_callback_log(const zkw_vm_local_state* initial, c
     return -1;
   }
 }
+
+// Replays a finished run into the host mirror of the reference's InMemoryEventSink and returns its flatten() result in
+// the zkw_net_state conventions (history as zkw_log_query with lane / seq / kind = 0).
+extern "C" int zkw_host_replay_event_sink(const zkw_vm_local_state* initial, const zkw_callstack_entry* inner, const zkw_instance_trace* trace,
+                                          uint32_t initial_depth, uint8_t event_aux_byte, zkw_log_query* history, uint32_t cap_history, uint32_t* n_history,
+                                          zkw_event_message* events, uint32_t cap_events, uint32_t* n_events, zkw_event_message* l1, uint32_t cap_l1,
+                                          uint32_t* n_l1) {
+  try {
+    VmWitnessTracer wt;
+    InMemoryEventSink ev;
+    ev.event_aux_byte = event_aux_byte;
+    for (uint32_t d = 0; d < initial_depth; d++) ev.start_frame(0);  // push_bootloader_context (helpers.rs:289-316)
+    BatchedVmState vm(*initial, inner, *trace, &wt, &ev);
+    int rc = 0;
+    while (!vm.execution_has_ended() && (rc = vm.cycle()) == 0) {
+    }
+    std::vector<LogQuery> h;
+    std::vector<EventMessage> e, m;
+    ev.flatten(&h, &e, &m);
+    *n_history = (uint32_t)h.size(); *n_events = (uint32_t)e.size(); *n_l1 = (uint32_t)m.size();
+    for (uint32_t i = 0; i < h.size() && i < cap_history; i++) {
+      zkw_log_query o;
+      std::memset(&o, 0, sizeof o);
+      const LogQuery& q = h[i];
+      std::memcpy(o.key.l, q.key.l, 32); std::memcpy(o.read_value.l, q.read_value.l, 32); std::memcpy(o.written_value.l, q.written_value.l, 32);
+      std::memcpy(o.address, q.address.b, 20);
+      o.timestamp = q.timestamp; o.tx_number_in_block = q.tx_number_in_block; o.aux_byte = q.aux_byte; o.shard_id = q.shard_id;
+      o.bools = (uint8_t)((q.rw_flag ? ZKW_LQ_RW : 0) | (q.rollback ? ZKW_LQ_ROLLBACK : 0) | (q.is_service ? ZKW_LQ_IS_SERVICE : 0));
+      history[i] = o;
+    }
+    auto put = [](const EventMessage& x, zkw_event_message* o) {
+      std::memset(o, 0, sizeof *o);
+      o->shard_id = x.shard_id; o->is_first = x.is_first ? 1 : 0; o->tx_number_in_block = x.tx_number_in_block;
+      std::memcpy(o->address, x.address.b, 20);
+      std::memcpy(o->key.l, x.key.l, 32); std::memcpy(o->value.l, x.value.l, 32);
+    };
+    for (uint32_t i = 0; i < e.size() && i < cap_events; i++) put(e[i], &events[i]);
+    for (uint32_t i = 0; i < m.size() && i < cap_l1; i++) put(m[i], &l1[i]);
+    return rc == -1 || rc == 0 ? 0 : rc;  // -1 = the recorded cycles are exhausted (a run that was stopped while still running)
+  } catch (const std::exception&) {
+    return -1;
+  }
+}

@@ -113,3 +113,33 @@ def test_replay_surfaces_reference_errors(oracle, replay_lib, isa):
     got, rc = replay_log(replay_lib, b, wl, 0)
     assert rc == K.STATUS_UNKNOWN_CODE_HASH  # BatchedVmState::cycle() reports the reference's Err at the failing cycle
     assert len(got) == len(logs[0]) and (got == logs[0]).all()
+
+
+@pytest.mark.parametrize("make", [lambda isa: synth.make(4, isa, n_instances=3), lambda isa: synth.nested_frames(isa, outer=K.RET_PANIC, inner=K.RET_OK),
+                                  lambda isa: synth.nested_frames(isa, outer=K.RET_OK, inner=K.RET_REVERT)])
+def test_host_event_sink_mirror_flattens_to_the_device_net_state(oracle, emu, replay_lib, isa, make):
+    """BatchedVmState's replay into the host mirror of InMemoryEventSink ends where the reference's sink would:
+    flatten() == the events part of zkw_batch_get_net_state (computed on the device / by the oracle)."""
+    wl = make(isa)
+    be = emu.create_batch(wl)
+    be.reset(); be.run(wl.n_cycles); be.sync()
+    bo = oracle.create_batch(wl)
+    bo.reset(); bo.run(wl.n_cycles); bo.sync()
+    for i in range(wl.n_instances):
+        t = K.InstanceTraceC()
+        be.be.call("batch_get_instance_trace", be.h, C.c_uint32(i), C.byref(t))
+        cap = 2 * t.n_log + 8
+        hist = np.zeros(cap, dtype=K.LOG_QUERY)
+        ev = np.zeros(cap, dtype=K.EVENT_MESSAGE)
+        l1 = np.zeros(cap, dtype=K.EVENT_MESSAGE)
+        nh, ne, nl = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        st = np.ascontiguousarray(wl.states[i:i + 1])
+        inner = np.ascontiguousarray(wl.inner[i])
+        rc = replay_lib.zkw_host_replay_event_sink(K._ptr(st), K._ptr(inner), C.byref(t), C.c_uint32(int(wl.states[i]["callstack_depth"])),
+                                                   C.c_uint8(int(isa.table["consts"]["event_aux_byte"][0])), K._ptr(hist), C.c_uint32(cap), C.byref(nh),
+                                                   K._ptr(ev), C.c_uint32(cap), C.byref(ne), K._ptr(l1), C.c_uint32(cap), C.byref(nl))
+        assert rc == 0
+        for ns in (be.net_state(i), bo.net_state(i)):
+            assert ns["event_history"].tobytes() == hist[: nh.value].tobytes()
+            assert ns["events"].tobytes() == ev[: ne.value].tobytes()
+            assert ns["l1_messages"].tobytes() == l1[: nl.value].tobytes()
