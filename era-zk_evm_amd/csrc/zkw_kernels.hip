@@ -1306,9 +1306,7 @@ __device__ __noinline__ Lane zkw_precompile_entry(const zkw_kparams ZKW_CONST_AS
   ZKW_KP P = *Pp;
   if (which == 0) precompile_keccak256(P, sh, s, q);
   else if (which == 1) precompile_sha256(P, sh, s, q);
-#ifndef ZKW_EXPERIMENT_NO_ECRECOVER
   else precompile_ecrecover(P, sh, s, q);
-#endif
   return s;
 }
 
@@ -1322,28 +1320,6 @@ ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   else if (addr_low == P.consts.ecrecover_precompile_address) which = 2;
   // anything else behaves as an unknown precompile: no memory traffic
   if (which < 3) s = zkw_precompile_entry(&P, sh, s, q, which);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Rare opcode families (context, ptr, log incl. precompiles, near_call, far_call, ret) go through one
-// wrapper that works on a copy of the lane state.  Measured on MI355X (profiles/r01_kernel_variants.md): a
-// real out-of-line call (noinline) shrinks the kernel from 100 KB to 44 KB but the caller-saved traffic
-// around the call costs more than it saves (1.03 vs 0.98 ms per 1M cycles), so the wrapper is inlined.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void zkw_rare_op(ZKW_KP P, Shared sh, Lane* lane, const Decoded* dp, const Pre* pp) {
-  Lane s = *lane;
-  const Decoded d = *dp;
-  const Pre ps = *pp;
-  switch (ZKW_ATTR_OPCODE(d.attr)) {
-    case ZKW_OP_CONTEXT: op_context(P, sh, s, d, ps); break;
-    case ZKW_OP_PTR: op_ptr(P, sh, s, d, ps); break;
-    case ZKW_OP_LOG: op_log(P, sh, s, d, ps); break;
-    case ZKW_OP_NEAR_CALL: op_near_call(P, sh, s, d, ps); break;
-    case ZKW_OP_FAR_CALL: op_far_call(P, sh, s, d, ps); break;
-    case ZKW_OP_RET: op_ret(P, sh, s, d, ps); break;
-    default: lane_fail(s, ZKW_STATUS_REFERENCE_PANIC); break;
-  }
-  *lane = s;
 }
 
 // ---------------------------------------------------------------------------------------------

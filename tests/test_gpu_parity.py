@@ -266,3 +266,19 @@ def test_ecrecover_precompile(oracle, product, isa):
         ok, why = K.traces_equal(bo.trace(i), tp)
         assert ok, (i, why)
         check_against_python(wl, tp, expect[i])
+
+
+def test_register_delta_capacity_is_a_limit_status(oracle, product, isa):
+    """Delta-form CycleRecords: a wave that runs out of delta capacity fails all its lanes with ZKW_STATUS_LIMIT at the
+    same cycle; the records before that cycle are intact (130 instances = 3 waves)."""
+    wl = synth.make(1, isa, n_instances=130)
+    wl.limits["max_reg_deltas"] = 10
+    bp = _run(product, wl)
+    bo = _run(oracle, synth.make(1, isa, n_instances=130))
+    for i in (0, 1, 63, 64, 127, 128, 129):
+        tp, to = bp.trace(i), bo.trace(i)
+        assert tp["status"] == K.STATUS_LIMIT
+        n = tp["n_cycles"]
+        assert 0 < n < to["n_cycles"]
+        assert tp["records"].tobytes() == to["records"][:n].tobytes()
+    assert len({bp.trace(i)["n_cycles"] for i in range(0, 64)}) == 1  # wave-uniform
