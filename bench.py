@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--fuse", type=int, default=32, help="batches (steps) per fused launch (zkw_batches_step), <= 32")
     ap.add_argument("--streams", type=int, default=2, help="fused groups in flight (1 = everything on one stream; >= 2 = cycle kernels on the main stream, commitments + restores on side streams)")
     ap.add_argument("--side", choices=["commit", "commit+reset"], default="commit", help="what the side streams carry when --streams >= 2")
+    ap.add_argument("--force-collective", action="store_true", help="run the digest all-gather even with one rank (exercises the multi-GPU code path on a single GPU)")
     ap.add_argument("--main-priority", type=int, default=0, help="1 = create the main stream with high priority")
     ap.add_argument("--cfg", type=int, default=2)
     ap.add_argument("--min-warmup-s", type=float, default=0.6, help="untimed warm-up is extended to at least this long (clock ramp)")
@@ -47,8 +48,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if world == 1:
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
 
@@ -77,7 +83,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -85,8 +91,13 @@ def main():
     from era_zk_evm_amd import shard  # noqa: F401  (final_reduce is exercised by tests; the bench keeps the raw collective)
 
     # final exchange: all-gather of the per-instance queue digests over RCCL, once per fused group
+    # only the committed queues travel: [fuse, instances, n_committed, 4] u64 per group
+    committed = [q for q in range(3) if (args.commit_mask >> q) & 1]
     digests = [torch.zeros((fuse, args.instances, 3, 4), dtype=torch.int64, device="cuda") for _ in range(n_groups)]
-    gathered = [torch.zeros((world * fuse, args.instances, 3, 4), dtype=torch.int64, device="cuda") if world > 1 else None for _ in range(n_groups)]
+    packed = [torch.zeros((fuse, args.instances, max(1, len(committed)), 4), dtype=torch.int64, device="cuda") for _ in range(n_groups)]
+    gathered = [torch.zeros((world * fuse, args.instances, max(1, len(committed)), 4), dtype=torch.int64, device="cuda") if collective else None
+                for _ in range(n_groups)]
+    q_index = torch.tensor(committed if committed else [0], dtype=torch.long, device="cuda")
     digest_bytes = args.instances * 3 * 4 * 8
 
     # Pipelining over streams (--streams >= 2): the main stream carries the restore + cycle kernel of every group, back
@@ -122,11 +133,12 @@ def main():
             sptr = stream.cuda_stream
             stream.wait_event(ev_run[g])
             prod.commit_many(groups[g][:n], args.commit_mask, sptr)
-        if args.commit_mask and world > 1:
+        if args.commit_mask and collective:
             for j, b in enumerate(groups[g][:n]):
                 prod.call("batch_copy_commitments", b.h, C.c_void_p(digests[g].data_ptr() + j * digest_bytes), C.c_void_p(sptr))
             with torch.cuda.stream(stream):
-                dist.all_gather_into_tensor(gathered[g], digests[g])
+                torch.index_select(digests[g], 2, q_index, out=packed[g])  # drop the queues that were not committed
+                dist.all_gather_into_tensor(gathered[g], packed[g])
         if overlap:
             if side_reset:
                 prod.reset_many(groups[g], sptr)  # the whole group, so that a later partial launch finds it restored
@@ -184,12 +196,13 @@ def main():
     cycles_per_step = int(st["cycles"])
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     c = torch.tensor([float(cycles_per_step)], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if collective:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
     total_cycles_per_step = float(c.item())
 
+    out = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = total_cycles_per_step * args.steps / elapsed
@@ -221,11 +234,13 @@ def main():
                          "frac_alone": b_cycle * cycles_per_step * len(groups[0]) / (k_ms_alone * 1e-3) / 1e9 / 8000.0, "bytes_per_cycle": b_cycle, "snapshot_equivalent_bytes_per_cycle": b_cycle_snapshot, "snapshot_equivalent_GBps": b_cycle_snapshot * cycles_per_step * batches_per_launch / (k_ms * 1e-3) / 1e9, "cycles_per_launch": cycles_per_step * batches_per_launch,
                          "chip_achieved": b_cycle * value / 1e9, "chip_frac": b_cycle * value / 1e9 / 8000.0},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(isa, args)
-        print(json.dumps(out))
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
+    if rank == 0:  # the JSON line is the last thing on stdout (RCCL prints its own banner lines during init / teardown)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 def measured_traffic(args, batches_per_launch):
