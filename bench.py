@@ -240,6 +240,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:  # the JSON line is the last thing on stdout (RCCL prints its own banner lines during init / teardown)
         sys.stdout.flush()
+        C.CDLL(None).fflush(None)  # RCCL's banner sits in the C stdio buffer when stdout is a pipe
         print(json.dumps(out), flush=True)
 
 
