@@ -86,6 +86,18 @@ ZD u32 stream_alloc(u32* cursor) {
   return base + rank;
 }
 
+// streaming store of a 16-byte unit of a witness stream: written once, read by a later kernel / the host
+#ifdef __HIP_DEVICE_COMPILE__
+typedef unsigned int zkw_v4u __attribute__((ext_vector_type(4)));
+ZD void zkw_stream_store(uint4* p, const uint4 v) {
+  zkw_v4u t;
+  t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  __builtin_nontemporal_store(t, (zkw_v4u*)p);
+}
+#else
+ZD void zkw_stream_store(uint4* p, const uint4 v) { *p = v; }
+#endif
+
 // orders this wave's own LDS stores before later cross-lane LDS reads/atomics (no workgroup barrier involved)
 ZD void zkw_wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -123,9 +135,9 @@ ZD void emit_mem(ZKW_KP P, Shared& sh, Lane& s, u32 ts, u32 type, u32 page, u32 
   if (sh.debug_flags & 2u) return;
   const u32 meta = (type & ZKW_MQ_TYPE_MASK) | (is_ptr ? ZKW_MQ_IS_PTR : 0u) | (rw ? ZKW_MQ_RW : 0u) | (kind << ZKW_MQ_KIND_SHIFT);
   uint4* dst = P.mem_stream + ((u64)s.wave * P.cap_mem + pos) * 3;
-  dst[0] = make_uint4(ts, page, index, s.lane | (seq << 8) | (meta << 16));
-  dst[1] = u256_lo4(value);
-  dst[2] = u256_hi4(value);
+  zkw_stream_store(dst, make_uint4(ts, page, index, s.lane | (seq << 8) | (meta << 16)));
+  zkw_stream_store(dst + 1, u256_lo4(value));
+  zkw_stream_store(dst + 2, u256_hi4(value));
 }
 
 struct LogQ {  // LogQuery (log.rs:85-97)
@@ -145,16 +157,16 @@ ZD void emit_log(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q, u32 kind) {
     return;
   }
   uint4* dst = P.log_stream + ((u64)s.wave * P.cap_log + pos) * 8;
-  dst[0] = u256_lo4(q.key);
-  dst[1] = u256_hi4(q.key);
-  dst[2] = u256_lo4(q.read_value);
-  dst[3] = u256_hi4(q.read_value);
-  dst[4] = u256_lo4(q.written_value);
-  dst[5] = u256_hi4(q.written_value);
-  dst[6] = make_uint4(q.address[0], q.address[1], q.address[2], q.address[3]);
+  zkw_stream_store(dst + 0, u256_lo4(q.key));
+  zkw_stream_store(dst + 1, u256_hi4(q.key));
+  zkw_stream_store(dst + 2, u256_lo4(q.read_value));
+  zkw_stream_store(dst + 3, u256_hi4(q.read_value));
+  zkw_stream_store(dst + 4, u256_lo4(q.written_value));
+  zkw_stream_store(dst + 5, u256_hi4(q.written_value));
+  zkw_stream_store(dst + 6, make_uint4(q.address[0], q.address[1], q.address[2], q.address[3]));
   const u32 bools = (q.rw ? ZKW_LQ_RW : 0u) | (q.rollback ? ZKW_LQ_ROLLBACK : 0u) | (q.is_service ? ZKW_LQ_IS_SERVICE : 0u);
-  dst[7] = make_uint4(q.address[4], q.timestamp, (q.tx_number & 0xffffu) | (q.aux_byte << 16) | (q.shard_id << 24),
-                      bools | (kind << 8) | (s.lane << 16) | (seq << 24));
+  zkw_stream_store(dst + 7, make_uint4(q.address[4], q.timestamp, (q.tx_number & 0xffffu) | (q.aux_byte << 16) | (q.shard_id << 24),
+                      bools | (kind << 8) | (s.lane << 16) | (seq << 24)));
 }
 
 // aux events: header + up to 60 payload dwords
@@ -1672,15 +1684,15 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
             m &= m - 1u;
             const u32 pos = base + before + (u32)__popcll(part & ((1ull << tid) - 1ull));
             before += (u32)__popcll(part);
-            dl[(u64)pos * 2] = sh_reg(sh, 2 * r, tid);
-            dl[(u64)pos * 2 + 1] = sh_reg(sh, 2 * r + 1, tid);
+            zkw_stream_store(dl + (u64)pos * 2, sh_reg(sh, 2 * r, tid));
+            zkw_stream_store(dl + (u64)pos * 2 + 1, sh_reg(sh, 2 * r + 1, tid));
           }
           uint4* tl = P.tails + ((u64)wave * P.max_cycles + (cycle_base + k)) * 2 * P.L;
           const u32 cnt = (s.n_mem > 255u ? 255u : s.n_mem) | ((s.n_log > 255u ? 255u : s.n_log) << 8) | ((s.n_aux > 255u ? 255u : s.n_aux) << 16);
           // dirty mask: bits 0-7 in the tail's reserved byte, bits 8-14 in the top byte of the event counts
-          tl[tid] = make_uint4((s.ptr_bitmap & 0xffffu) | ((s.flags & 0xfu) << 16) | ((s.reg_dirty & 0xffu) << 24), (s.pc & 0xffffu) | (s.sp << 16), s.ergs,
-                               s.timestamp);
-          tl[P.L + tid] = make_uint4(s.heap_bound, s.aux_bound, (s.depth & 0xffffu) | (s.prev_super_pc << 16), cnt | ((s.reg_dirty >> 8) << 24));
+          zkw_stream_store(tl + tid, make_uint4((s.ptr_bitmap & 0xffffu) | ((s.flags & 0xfu) << 16) | ((s.reg_dirty & 0xffu) << 24),
+                                                (s.pc & 0xffffu) | (s.sp << 16), s.ergs, s.timestamp));
+          zkw_stream_store(tl + P.L + tid, make_uint4(s.heap_bound, s.aux_bound, (s.depth & 0xffffu) | (s.prev_super_pc << 16), cnt | ((s.reg_dirty >> 8) << 24)));
           s.n_cycles++;
         }
         if (fits && total) {
