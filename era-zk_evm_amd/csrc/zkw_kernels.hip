@@ -72,17 +72,17 @@ ZD bool lane_ok(const Lane& s) { return s.status == ZKW_STATUS_RUNNING; }
 
 // ---------------------------------------------------------------------------------------------
 // wave-level stream compaction: every lane that reaches this point (possibly under divergence)
-// gets a unique, dense slot of the wave's stream: ballot -> rank by popcount of lower lanes ->
-// one LDS atomic by the leader -> broadcast.
+// gets a unique, dense slot of the wave's stream: ballot -> rank by popcount of lower lanes.  The cursor lives in
+// LDS and belongs to this wave alone, and a wave's LDS operations complete in program order, so the base is a plain
+// broadcast read by every participating lane followed by one plain write of the leader — no atomic, no shuffle.
 // ---------------------------------------------------------------------------------------------
 ZD u32 stream_alloc(u32* cursor) {
   const u64 mask = __ballot(1);
   const u32 lane = threadIdx.x & (ZKW_WAVE - 1);
   const u32 leader = (u32)__ffsll((long long)mask) - 1u;
   const u32 rank = (u32)__popcll(mask & ((1ull << lane) - 1ull));
-  u32 base = 0;
-  if (lane == leader) base = atomicAdd(cursor, (u32)__popcll(mask));
-  base = (u32)__shfl((int)base, (int)leader);
+  const u32 base = *(volatile u32*)cursor;
+  if (lane == leader) *(volatile u32*)cursor = base + (u32)__popcll(mask);
   return base + rank;
 }
 
@@ -277,7 +277,7 @@ ZD void heap_write_cur(ZKW_KP P, Lane& s, bool is_aux, u32 idx, const u256& v) {
   if (!is_aux && s.slot == 0 && idx < P.heap_image_words) {
     // a word of the uploaded heap image is overwritten: remember it, the next reset restores only those words
     u32* d = P.heap_dirty + ((u64)s.wave * ((P.heap_image_words + 31u) >> 5) + (idx >> 5)) * P.L + s.lane;
-    *d |= 1u << (idx & 31u);
+    atomicOr(d, 1u << (idx & 31u));  // result unused: a fire-and-forget atomic instead of a load + store round trip
   }
   if (idx >= hwm) hwm = idx + 1;
   if (is_aux) s.aux_hwm = hwm; else s.heap_hwm = hwm;

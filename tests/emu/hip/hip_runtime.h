@@ -36,6 +36,7 @@ static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline int __shfl(int v, int) { return v; }
 static inline void __syncthreads() {}
 static inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+static inline uint32_t atomicOr(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNotSupported = 801 };
