@@ -59,6 +59,26 @@ ZD u64 gl_mul(u64 a, u64 b) {
   mul64(a, b, lo, hi);
   return gl_reduce128(lo, hi);
 }
+// a^2: the two cross products are equal (3 wide multiplies instead of 4)
+ZD void sqr64(u64 a, u64& lo, u64& hi) {
+  const u64 a0 = (u32)a, a1 = a >> 32;
+  const u64 p00 = a0 * a0, p01 = a0 * a1, p11 = a1 * a1;
+  const u64 mid = (p00 >> 32) + 2 * (u64)(u32)p01;
+  lo = (mid << 32) | (u32)p00;
+  hi = p11 + 2 * (p01 >> 32) + (mid >> 32);
+}
+// reduction without the final conditional subtraction: the result is < 2^64 and congruent, possibly >= p.  Such a value
+// is a valid INPUT of mul64 / sqr64 / gl_reduce128 (they accept any u64), so the canonical form is only restored at the
+// end of a multiplication chain.
+ZD u64 gl_reduce128_lazy(u64 lo, u64 hi) {
+  const u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+  u64 t0 = lo - hi_hi;
+  if (lo < hi_hi) t0 -= GL_EPS;
+  const u64 t1 = hi_lo * GL_EPS;
+  u64 r = t0 + t1;
+  if (r < t1) r += GL_EPS;
+  return r;
+}
 // x * 2^K for a static 0 <= K < 32: the 128-bit product is (x >> (64-K)) : (x << K), and hi < 2^K reduces as
 // hi * 2^64 = hi * (2^32 - 1) (mod p) — no multiplier involved
 template <int K>
@@ -72,8 +92,15 @@ ZD u64 gl_mul_pow2(u64 x) {
   return r;
 }
 ZD u64 gl_pow7(u64 x) {
-  const u64 x2 = gl_mul(x, x), x3 = gl_mul(x2, x), x4 = gl_mul(x2, x2);
-  return gl_mul(x4, x3);
+  u64 lo, hi;
+  sqr64(x, lo, hi);
+  const u64 x2 = gl_reduce128_lazy(lo, hi);
+  mul64(x2, x, lo, hi);
+  const u64 x3 = gl_reduce128_lazy(lo, hi);
+  sqr64(x2, lo, hi);
+  const u64 x4 = gl_reduce128_lazy(lo, hi);
+  mul64(x4, x3, lo, hi);
+  return gl_reduce128(lo, hi);  // canonical
 }
 
 // M4 of the Poseidon2 paper: [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]]
