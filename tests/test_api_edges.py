@@ -1,0 +1,91 @@
+"""Edge cases of the C-ABI (product sources in the emulation build): argument errors are error codes, capacity
+overruns are per-instance ZKW_STATUS_LIMIT — never a crash, never silent truncation."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from era_zk_evm_amd import capi as K, synth
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+
+
+@pytest.fixture(scope="module")
+def emu(isa):
+    import build_emu
+    be = K.Backend(build_emu.build(), "zkw_").open(isa)
+    yield be
+    be.close()
+
+
+def test_zero_instances_is_rejected(emu):
+    lim = np.zeros(1, dtype=K.LIMITS)
+    lim["max_cycles"] = 8
+    h = C.c_void_p()
+    rc = emu.fn("batch_create")(emu.ctx, C.c_uint32(0), K._ptr(lim), C.byref(h))
+    assert rc == K.ERR_INVALID and not h.value
+
+
+def test_calls_in_the_wrong_order_are_error_codes(emu, isa):
+    wl = synth.make(1, isa, n_instances=2)
+    b = emu.create_batch(wl)  # uploaded and reset, not run
+    t = K.InstanceTraceC()
+    assert emu.fn("batch_get_instance_trace")(b.h, C.c_uint32(0), C.byref(t)) == K.ERR_NOT_RUN
+    st = np.zeros(1, dtype=K.RUN_STATS)
+    assert emu.fn("batch_get_stats")(b.h, K._ptr(st)) == K.ERR_NOT_RUN
+    assert emu.fn("batch_commit")(b.h, C.c_uint32(7), C.c_void_p(None)) == K.ERR_NOT_RUN
+    assert emu.fn("batch_run")(b.h, C.c_uint32(0), C.c_void_p(None)) == K.ERR_LIMIT                       # zero cycles
+    assert emu.fn("batch_run")(b.h, C.c_uint32(wl.limits["max_cycles"] + 1), C.c_void_p(None)) == K.ERR_LIMIT
+    b.run(wl.n_cycles)
+    b.sync()
+    assert emu.fn("batch_get_instance_trace")(b.h, C.c_uint32(2), C.byref(t)) == K.ERR_INVALID           # instance out of range
+    assert emu.fn("batch_run")(b.h, C.c_uint32(1), C.c_void_p(None)) == K.ERR_LIMIT                       # record capacity used up
+    assert emu.fn("batch_get_instance_trace")(C.c_void_p(None), C.c_uint32(0), C.byref(t)) == K.ERR_INVALID
+
+
+def test_single_instance_and_ragged_waves(oracle, emu, isa):
+    for n in (1, 3):
+        wl = synth.make(2, isa, n_instances=n)
+        bo = oracle.create_batch(wl); bo.reset(); bo.run(wl.n_cycles); bo.sync()
+        be = emu.create_batch(wl); be.reset(); be.run(wl.n_cycles); be.sync()
+        for i in range(n):
+            ok, why = K.traces_equal(bo.trace(i), be.trace(i))
+            assert ok, (n, i, why)
+
+
+@pytest.mark.parametrize("field,value", [("max_mem_queries", 8), ("max_log_queries", 2), ("max_aux_events", 2), ("storage_journal", 1),
+                                         ("stack_words", 2), ("max_far_frames", 1), ("max_callstack_depth", 1)])
+def test_capacity_overruns_are_limit_statuses(oracle, emu, isa, field, value):
+    """every zkw_limits field: too small a value ends the affected instances with ZKW_STATUS_LIMIT; the cycles they did
+    complete are still bit-exact"""
+    wl = synth.make(4, isa, n_instances=3)
+    ref = synth.make(4, isa, n_instances=3)
+    wl.limits[field] = value
+    be = emu.create_batch(wl); be.reset(); be.run(wl.n_cycles); be.sync()
+    bo = oracle.create_batch(ref); bo.reset(); bo.run(ref.n_cycles); bo.sync()
+    hit = 0
+    for i in range(3):
+        te, to = be.trace(i), bo.trace(i)
+        assert te["status"] in (K.STATUS_LIMIT, to["status"])
+        if te["status"] == K.STATUS_LIMIT:
+            hit += 1
+            n = te["n_cycles"]
+            assert n < to["n_cycles"]
+            assert te["records"].tobytes() == to["records"][:n].tobytes()
+    assert hit > 0, "the workload never reached this limit: pick a smaller value"
+
+
+def test_storage_table_too_small_for_the_snapshot_is_an_argument_error(emu, isa):
+    wl = synth.make(4, isa, n_instances=2)
+    wl.limits["storage_slots"] = 256  # the snapshot alone holds 258 slots
+    with pytest.raises(K.ZkwError):
+        emu.create_batch(wl)
+
+
+def test_heap_image_longer_than_the_page_is_an_argument_error(emu, isa):
+    wl = synth.make(4, isa, n_instances=2)
+    wl.limits["heap_words"] = 200  # the image holds 256 words
+    with pytest.raises(K.ZkwError):
+        emu.create_batch(wl)

@@ -282,3 +282,23 @@ def test_register_delta_capacity_is_a_limit_status(oracle, product, isa):
         assert 0 < n < to["n_cycles"]
         assert tp["records"].tobytes() == to["records"][:n].tobytes()
     assert len({bp.trace(i)["n_cycles"] for i in range(0, 64)}) == 1  # wave-uniform
+
+
+@pytest.mark.parametrize("field,value", [("max_mem_queries", 8), ("max_log_queries", 2), ("max_far_frames", 1), ("max_callstack_depth", 1), ("stack_words", 2)])
+def test_capacity_overruns_are_limit_statuses(oracle, product, isa, field, value):
+    """too small a zkw_limits value ends the affected instances with ZKW_STATUS_LIMIT (130 instances = 3 waves); the
+    cycles they completed are bit-exact"""
+    wl = synth.make(4, isa, n_instances=130)
+    wl.limits[field] = value
+    bp = _run(product, wl)
+    bo = _run(oracle, synth.make(4, isa, n_instances=130))
+    hit = 0
+    for i in (0, 1, 63, 64, 100, 129):
+        tp, to = bp.trace(i), bo.trace(i)
+        assert tp["status"] in (K.STATUS_LIMIT, to["status"])
+        if tp["status"] == K.STATUS_LIMIT:
+            hit += 1
+            n = tp["n_cycles"]
+            assert n < to["n_cycles"]
+            assert tp["records"].tobytes() == to["records"][:n].tobytes()
+    assert hit > 0
