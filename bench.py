@@ -193,6 +193,9 @@ def main():
     k_ms_alone = drain_timing()[0]
     batch.sync()
     st = batch.stats()
+    # untimed: what pulling one step's whole trace over PCIe would cost
+    dl_bytes, dl_ms = C.c_uint64(0), C.c_double(0)
+    prod.call("batch_download_all", batch.h, C.byref(dl_bytes), C.byref(dl_ms))
     cycles_per_step = int(st["cycles"])
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     c = torch.tensor([float(cycles_per_step)], dtype=torch.float64, device="cuda")
@@ -228,7 +231,9 @@ def main():
             "config": {"workload": "cfg%d: %d instances x %d cycles per GPU (%s)" % (args.cfg, args.instances, args.cycles, wl.name),
                        "instances_per_gpu": args.instances, "cycles_per_instance": args.cycles, "lanes_per_wave": int(batch.limits["lanes_per_wave"][0]), "commit_mask": args.commit_mask,
                        "batches_per_fused_launch": batches_per_launch, "fused_groups_in_flight": n_groups, "side_stream_work": (args.side if overlap else None), "cycle_kernel_launches": n_launches},
-            "kernel_ms": k_ms, "kernel_ms_alone": k_ms_alone, "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
+            "kernel_ms": k_ms, "kernel_ms_alone": k_ms_alone,
+            "pcie_download_of_one_step": {"bytes": dl_bytes.value, "ms": dl_ms.value, "GBps": dl_bytes.value / max(dl_ms.value, 1e-9) / 1e6,
+                                          "cycles_per_s_if_every_step_were_downloaded": cycles_per_step / (1e-3 * (dl_ms.value + ms_per_step))}, "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
             "kernel_cycles_per_s": cycles_per_step * batches_per_launch / (k_ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "frac_alone": b_cycle * cycles_per_step * len(groups[0]) / (k_ms_alone * 1e-3) / 1e9 / 8000.0, "bytes_per_cycle": b_cycle, "snapshot_equivalent_bytes_per_cycle": b_cycle_snapshot, "snapshot_equivalent_GBps": b_cycle_snapshot * cycles_per_step * batches_per_launch / (k_ms * 1e-3) / 1e9, "cycles_per_launch": cycles_per_step * batches_per_launch,

@@ -943,6 +943,56 @@ int zkw_batch_sync(zkw_batch* b) {
   return ZKW_OK;
 }
 
+// Bulk download of everything a run produced (tails, register deltas, query streams, directory) into pinned host
+// staging buffers: what a consumer on the host side of PCIe would have to pull.  Only the used extents travel.
+int zkw_batch_download_all(zkw_batch* b, uint64_t* n_bytes, double* ms) {
+  if (!b || !n_bytes) return ZKW_ERR_INVALID;
+  zkw_ctx* c = b->ctx;
+  if (!b->synced) {
+    int rc = zkw_batch_sync(b);
+    if (rc != ZKW_OK) return rc;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t W = b->n_waves, L = b->L, MC = b->lim.max_cycles;
+  uint32_t max_cyc = 0;
+  for (uint32_t i = 0; i < b->n; i++) max_cyc = std::max(max_cyc, b->h_scalars[i].n_cycles);
+  struct Piece { const void* src; size_t pitch, bytes; };
+  std::vector<Piece> pieces;
+  size_t total = 0;
+  for (uint32_t w = 0; w < W; w++) {
+    const uint32_t* cur = &b->h_cursors[(size_t)w * 4];
+    pieces.push_back({b->d_tails.p + (size_t)w * MC * 2 * L, 0, (size_t)max_cyc * 2 * L * 16});
+    pieces.push_back({b->d_deltas.p + (size_t)w * b->cap_delta * 2, 0, (size_t)std::min(cur[3], b->cap_delta) * 32});
+    pieces.push_back({b->d_mem.p + (size_t)w * b->cap_mem * 3, 0, (size_t)std::min(cur[0], b->cap_mem) * 48});
+    pieces.push_back({b->d_log.p + (size_t)w * b->cap_log * 8, 0, (size_t)std::min(cur[1], b->cap_log) * 128});
+    pieces.push_back({b->d_auxs.p + (size_t)w * b->cap_aux * 16, 0, (size_t)std::min(cur[2], b->cap_aux) * 256});
+    pieces.push_back({b->d_dir.p + (size_t)w * (MC + 1) * 4, 0, (size_t)(max_cyc + 1) * 16});
+  }
+  for (const Piece& p : pieces) total += p.bytes;
+  void* host = nullptr;
+  HIP_TRY(c, hipHostMalloc(&host, std::max<size_t>(total, 16), hipHostMallocDefault));
+  hipEvent_t e0, e1;
+  HIP_TRY(c, hipEventCreate(&e0));
+  HIP_TRY(c, hipEventCreate(&e1));
+  hipStream_t st = b->run_stream;
+  HIP_TRY(c, hipEventRecord(e0, st));
+  size_t off = 0;
+  for (const Piece& p : pieces) {
+    if (p.bytes) HIP_TRY(c, hipMemcpyAsync((char*)host + off, p.src, p.bytes, hipMemcpyDeviceToHost, st));
+    off += p.bytes;
+  }
+  HIP_TRY(c, hipEventRecord(e1, st));
+  HIP_TRY(c, hipEventSynchronize(e1));
+  float t = 0;
+  HIP_TRY(c, hipEventElapsedTime(&t, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipHostFree(host);
+  *n_bytes = total;
+  if (ms) *ms = t;
+  return ZKW_OK;
+}
+
 int zkw_batch_get_stats(zkw_batch* b, zkw_run_stats* out) {
   if (!b || !out) return ZKW_ERR_INVALID;
   if (!b->synced) {

@@ -508,6 +508,11 @@ int zkw_batch_net_states(zkw_batch* batch, void* hip_stream);
  * instance. */
 int zkw_batch_get_net_state(zkw_batch* batch, uint32_t instance, zkw_net_state* out);
 
+/* Pulls everything the last run produced (record tails, register deltas, the three query streams, the directory; used
+ * extents only) over PCIe into pinned staging memory and reports the volume and the transfer time: the cost a host-side
+ * consumer of the whole trace would pay (PCIe-inclusive rate).  The data is discarded. */
+int zkw_batch_download_all(zkw_batch* batch, uint64_t* n_bytes, double* ms);
+
 /* sizeof() of the ABI structs as compiled into the library (binding self-check) */
 uint32_t zkw_abi_sizeof(uint32_t which);
 

@@ -110,3 +110,7 @@ enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 
 #define __noinline__ __attribute__((noinline))
+
+enum { hipHostMallocDefault = 0 };
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); return *p ? hipSuccess : hipErrorInvalidValue; }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }

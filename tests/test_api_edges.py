@@ -89,3 +89,15 @@ def test_heap_image_longer_than_the_page_is_an_argument_error(emu, isa):
     wl.limits["heap_words"] = 200  # the image holds 256 words
     with pytest.raises(K.ZkwError):
         emu.create_batch(wl)
+
+
+def test_download_all_reports_the_trace_volume(emu, isa):
+    wl = synth.make(2, isa, n_instances=4)
+    b = emu.create_batch(wl)
+    b.reset(); b.run(wl.n_cycles); b.sync()
+    nb, ms = C.c_uint64(0), C.c_double(0)
+    emu.call("batch_download_all", b.h, C.byref(nb), C.byref(ms))
+    st = b.stats()
+    # tails 32 B per cycle + 32 B per register delta + the query records (+ the directory)
+    expect = 32 * int(st["cycles"]) + 32 * int(st["reg_deltas"]) + 48 * int(st["mem_queries"]) + 128 * int(st["log_queries"]) + 256 * int(st["aux_events"])
+    assert expect <= nb.value <= expect + 4 * (wl.n_cycles + 1) * 16
