@@ -112,6 +112,7 @@ struct Shared {
   uint4* regs;    // [30][L] register file, 16-byte chunks, lane-minor
   u32* krow;      // [34][L] Keccak rate block assembly rows (global memory)
   uint2* pcw;     // [4][L] previous_code_word as 4 opcode slots (u64 limb k), lane-minor — read once per cycle, LDS
+  uint4 *mem_base, *log_base, *aux_base;  // this wave's rows of the query streams (computed once per launch)
   u32 L;
   u32 debug_flags;
 };
@@ -134,7 +135,7 @@ ZD void emit_mem(ZKW_KP P, Shared& sh, Lane& s, u32 ts, u32 type, u32 page, u32 
   }
   if (sh.debug_flags & 2u) return;
   const u32 meta = (type & ZKW_MQ_TYPE_MASK) | (is_ptr ? ZKW_MQ_IS_PTR : 0u) | (rw ? ZKW_MQ_RW : 0u) | (kind << ZKW_MQ_KIND_SHIFT);
-  uint4* dst = P.mem_stream + ((u64)s.wave * P.cap_mem + pos) * 3;
+  uint4* dst = sh.mem_base + (u64)pos * 3;
   zkw_stream_store(dst, make_uint4(ts, page, index, s.lane | (seq << 8) | (meta << 16)));
   zkw_stream_store(dst + 1, u256_lo4(value));
   zkw_stream_store(dst + 2, u256_hi4(value));
@@ -156,7 +157,7 @@ ZD void emit_log(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q, u32 kind) {
     lane_fail(s, ZKW_STATUS_LIMIT);
     return;
   }
-  uint4* dst = P.log_stream + ((u64)s.wave * P.cap_log + pos) * 8;
+  uint4* dst = sh.log_base + (u64)pos * 8;
   zkw_stream_store(dst + 0, u256_lo4(q.key));
   zkw_stream_store(dst + 1, u256_hi4(q.key));
   zkw_stream_store(dst + 2, u256_lo4(q.read_value));
@@ -178,7 +179,7 @@ ZD uint4* aux_alloc(ZKW_KP P, Shared& sh, Lane& s, u32 type, u32 flag, u32 a, u3
     lane_fail(s, ZKW_STATUS_LIMIT);
     return nullptr;
   }
-  uint4* dst = P.aux_stream + ((u64)s.wave * P.cap_aux + pos) * 16;
+  uint4* dst = sh.aux_base + (u64)pos * 16;
   dst[0] = make_uint4(type | (s.lane << 8) | (seq << 16) | (flag << 24), a, b, c);
   return dst;
 }
@@ -1516,6 +1517,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   sh.regs = (uint4*)sh.cursor + 1;                                                  // 30 * L * 16 B
   sh.pcw = (uint2*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + P.waves_per_group * (1 + ZKW_REG_CHUNKS * P.L)) + wib * 4 * P.L;  // 4 * L * 8 B
   sh.krow = P.krow + (u64)wave * ZKW_KROW_WORDS * P.L;
+  sh.mem_base = P.mem_stream + (u64)wave * P.cap_mem * 3;
+  sh.log_base = P.log_stream + (u64)wave * P.cap_log * 8;
+  sh.aux_base = P.aux_stream + (u64)wave * P.cap_aux * 16;
   // stage the packed ISA table in LDS (all threads of the workgroup, 16 B each per step)
   {
     const uint4* src = (const uint4*)P.isa;
@@ -1556,10 +1560,15 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
     s.n_cycles = 0;
   }
 
+  // running output pointers of this wave (advanced once per cycle instead of re-derived from the parameter block)
+  u32* dir_ptr = P.dir + ((u64)wave * (P.max_cycles + 1) + cycle_base) * 4;
+  uint4* tail_ptr = P.tails + ((u64)wave * P.max_cycles + cycle_base) * 2 * P.L + tid;
+  uint4* const delta_base = P.deltas + (u64)wave * P.cap_delta * 2;
+  const u32 tail_step = 2 * P.L;
   u32 k = 0;
-  for (; k < A.run_cycles; k++) {
+  for (; k < A.run_cycles; k++, dir_ptr += 4, tail_ptr += tail_step) {
     // directory: stream cursors at the start of wave-cycle (cycle_base + k)
-    for (u32 i = tid; i < 4; i += P.wave_threads) P.dir[((u64)wave * (P.max_cycles + 1) + cycle_base + k) * 4 + i] = ((volatile u32*)sh.cursor)[i];
+    for (u32 i = tid; i < 4; i += P.wave_threads) dir_ptr[i] = ((volatile u32*)sh.cursor)[i];
     bool active = exists && s.status == ZKW_STATUS_RUNNING;
     if (active && s.depth == 0) {  // execution_has_ended() (mod.rs:96-98): callers stop cycling here
       s.status = ZKW_STATUS_ENDED;
@@ -1676,7 +1685,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
         const bool fits = base + total <= P.cap_delta;  // wave-uniform: either every lane's deltas fit or none are written
         if (ok && !fits) lane_fail(s, ZKW_STATUS_LIMIT);
         if (ok && fits) {
-          uint4* dl = P.deltas + (u64)wave * P.cap_delta * 2;
+          uint4* dl = delta_base;
           u32 m = s.reg_dirty, before = 0;
           for (u32 j = 0; j < n_dirty; j++) {
             const u64 part = __ballot(true);  // the lanes with more than j deltas (this loop runs n_dirty times per lane)
@@ -1687,12 +1696,11 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
             zkw_stream_store(dl + (u64)pos * 2, sh_reg(sh, 2 * r, tid));
             zkw_stream_store(dl + (u64)pos * 2 + 1, sh_reg(sh, 2 * r + 1, tid));
           }
-          uint4* tl = P.tails + ((u64)wave * P.max_cycles + (cycle_base + k)) * 2 * P.L;
           const u32 cnt = (s.n_mem > 255u ? 255u : s.n_mem) | ((s.n_log > 255u ? 255u : s.n_log) << 8) | ((s.n_aux > 255u ? 255u : s.n_aux) << 16);
           // dirty mask: bits 0-7 in the tail's reserved byte, bits 8-14 in the top byte of the event counts
-          zkw_stream_store(tl + tid, make_uint4((s.ptr_bitmap & 0xffffu) | ((s.flags & 0xfu) << 16) | ((s.reg_dirty & 0xffu) << 24),
+          zkw_stream_store(tail_ptr, make_uint4((s.ptr_bitmap & 0xffffu) | ((s.flags & 0xfu) << 16) | ((s.reg_dirty & 0xffu) << 24),
                                                 (s.pc & 0xffffu) | (s.sp << 16), s.ergs, s.timestamp));
-          zkw_stream_store(tl + P.L + tid, make_uint4(s.heap_bound, s.aux_bound, (s.depth & 0xffffu) | (s.prev_super_pc << 16), cnt | ((s.reg_dirty >> 8) << 24)));
+          zkw_stream_store(tail_ptr + P.L, make_uint4(s.heap_bound, s.aux_bound, (s.depth & 0xffffu) | (s.prev_super_pc << 16), cnt | ((s.reg_dirty >> 8) << 24)));
           s.n_cycles++;
         }
         if (fits && total) {
@@ -1706,7 +1714,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   // final directory entry
   for (u32 i = tid; i < 4; i += P.wave_threads) {
     const u32 cur = ((volatile u32*)sh.cursor)[i];
-    P.dir[((u64)wave * (P.max_cycles + 1) + cycle_base + k) * 4 + i] = cur;
+    dir_ptr[i] = cur;
     P.cursors[wave * 4 + i] = cur;
   }
   if (tid == 0) P.wave_cycles[wave] = cycle_base + k;
