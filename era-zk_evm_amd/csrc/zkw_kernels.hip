@@ -70,6 +70,15 @@ ZD void lane_fail(Lane& s, u32 status) {
 }
 ZD bool lane_ok(const Lane& s) { return s.status == ZKW_STATUS_RUNNING; }
 
+// Volatile view of an LDS word.  The address space is spelled out: a volatile access through a generic pointer is
+// not rewritten by the compiler's address-space inference and becomes a FLAT load/store (sc0 sc1) followed by
+// s_waitcnt vmcnt(0), i.e. every cursor access waited for ALL outstanding global loads and stores of the wave.
+#ifdef __HIP_DEVICE_COMPILE__
+#define ZKW_LDS_WORD(p) ((volatile u32 __attribute__((address_space(3)))*)(p))
+#else
+#define ZKW_LDS_WORD(p) ((volatile u32*)(p))
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // wave-level stream compaction: every lane that reaches this point (possibly under divergence)
 // gets a unique, dense slot of the wave's stream: ballot -> rank by popcount of lower lanes.  The cursor lives in
@@ -81,8 +90,8 @@ ZD u32 stream_alloc(u32* cursor) {
   const u32 lane = threadIdx.x & (ZKW_WAVE - 1);
   const u32 leader = (u32)__ffsll((long long)mask) - 1u;
   const u32 rank = (u32)__popcll(mask & ((1ull << lane) - 1ull));
-  const u32 base = *(volatile u32*)cursor;
-  if (lane == leader) *(volatile u32*)cursor = base + (u32)__popcll(mask);
+  const u32 base = *ZKW_LDS_WORD(cursor);
+  if (lane == leader) *ZKW_LDS_WORD(cursor) = base + (u32)__popcll(mask);
   return base + rank;
 }
 
@@ -1568,7 +1577,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   u32 k = 0;
   for (; k < A.run_cycles; k++, dir_ptr += 4, tail_ptr += tail_step) {
     // directory: stream cursors at the start of wave-cycle (cycle_base + k)
-    for (u32 i = tid; i < 4; i += P.wave_threads) dir_ptr[i] = ((volatile u32*)sh.cursor)[i];
+    for (u32 i = tid; i < 4; i += P.wave_threads) dir_ptr[i] = ZKW_LDS_WORD(sh.cursor)[i];
     bool active = exists && s.status == ZKW_STATUS_RUNNING;
     if (active && s.depth == 0) {  // execution_has_ended() (mod.rs:96-98): callers stop cycling here
       s.status = ZKW_STATUS_ENDED;
@@ -1681,7 +1690,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
           if (cj == 0) break;
           total += cj;
         }
-        const u32 base = ((volatile u32*)sh.cursor)[3];
+        const u32 base = ZKW_LDS_WORD(sh.cursor)[3];
         const bool fits = base + total <= P.cap_delta;  // wave-uniform: either every lane's deltas fit or none are written
         if (ok && !fits) lane_fail(s, ZKW_STATUS_LIMIT);
         if (ok && fits) {
@@ -1705,7 +1714,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
         }
         if (fits && total) {
           zkw_wave_lds_fence();
-          if (__ballot(true) != 0 && tid == (u32)__ffsll((long long)__ballot(true)) - 1u) sh.cursor[3] = base + total;
+          if (__ballot(true) != 0 && tid == (u32)__ffsll((long long)__ballot(true)) - 1u) ZKW_LDS_WORD(sh.cursor)[3] = base + total;
           zkw_wave_lds_fence();
         }
       }
@@ -1713,7 +1722,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   }
   // final directory entry
   for (u32 i = tid; i < 4; i += P.wave_threads) {
-    const u32 cur = ((volatile u32*)sh.cursor)[i];
+    const u32 cur = ZKW_LDS_WORD(sh.cursor)[i];
     dir_ptr[i] = cur;
     P.cursors[wave * 4 + i] = cur;
   }
