@@ -1574,17 +1574,24 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   uint4* tail_ptr = P.tails + ((u64)wave * P.max_cycles + cycle_base) * 2 * P.L + tid;
   uint4* const delta_base = P.deltas + (u64)wave * P.cap_delta * 2;
   const u32 tail_step = 2 * P.L;
+  // The cycle loop is entered once by the lanes that are running and left per lane (divergent exit) when the lane ends,
+  // fails or has used its cycles: the lane state is then modified unconditionally inside the loop body instead of inside
+  // an `if (active)` region of every iteration (whose merge points cost ~75 register copies per VM cycle).
   u32 k = 0;
-  for (; k < A.run_cycles; k++, dir_ptr += 4, tail_ptr += tail_step) {
-    // directory: stream cursors at the start of wave-cycle (cycle_base + k)
-    for (u32 i = tid; i < 4; i += P.wave_threads) dir_ptr[i] = ZKW_LDS_WORD(sh.cursor)[i];
-    bool active = exists && s.status == ZKW_STATUS_RUNNING;
-    if (active && s.depth == 0) {  // execution_has_ended() (mod.rs:96-98): callers stop cycling here
-      s.status = ZKW_STATUS_ENDED;
-      active = false;
-    }
-    if (__ballot(active) == 0) break;
-    if (active) {
+  if (exists && s.status == ZKW_STATUS_RUNNING) {
+    for (;;) {
+      if (k >= A.run_cycles) break;
+      if (s.depth == 0) {  // execution_has_ended() (mod.rs:96-98): callers stop cycling here
+        s.status = ZKW_STATUS_ENDED;
+        break;
+      }
+      {  // directory: stream cursors at the start of wave-cycle (cycle_base + k), written by the first remaining lane
+        const u64 in_loop = __ballot(1);
+        if (tid == (u32)__ffsll((long long)in_loop) - 1u) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) dir_ptr[i] = ZKW_LDS_WORD(sh.cursor)[i];
+        }
+      }
       s.seq = 0; s.n_mem = 0; s.n_log = 0; s.n_aux = 0; s.cold_dirty = 0; s.reg_dirty = 0;
       // ----------------------------------------------------------------------------------------
       // read_and_decode (cycle.rs:19-236)
@@ -1718,8 +1725,19 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
           zkw_wave_lds_fence();
         }
       }
+      k++;
+      dir_ptr += 4;
+      tail_ptr += tail_step;
+      if (!lane_ok(s)) break;
     }
   }
+  // wave-cycles executed = the maximum over the lanes (lanes leave the loop at different iterations)
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const u32 o = (u32)__shfl_xor((int)k, off);
+    k = o > k ? o : k;
+  }
+  dir_ptr = P.dir + ((u64)wave * (P.max_cycles + 1) + cycle_base + k) * 4;
   // final directory entry
   for (u32 i = tid; i < 4; i += P.wave_threads) {
     const u32 cur = ZKW_LDS_WORD(sh.cursor)[i];

@@ -114,3 +114,5 @@ static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int)
 enum { hipHostMallocDefault = 0 };
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); return *p ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+
+static inline int __shfl_xor(int v, int) { return v; }
