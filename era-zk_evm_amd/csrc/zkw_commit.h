@@ -10,13 +10,16 @@
 #define ZKW_LEAF_DECOMMIT 3
 #define ZKW_LEAF_CODE_WORD 4
 #define ZKW_QUEUE_CODE_WORDS 3 /* pseudo queue: leaves of the code blobs */
-#define ZKW_QUEUE_ID_BLOB 0xB10Bu
+#define ZKW_QUEUE_ID_BLOB 0xB10Bu      /* chains inside a 64-word chunk of a code blob */
+#define ZKW_QUEUE_ID_BLOB_TOP 0xB10Cu  /* chain over the chunk tails of a blob */
+#define ZKW_BLOB_CHUNK_WORDS 64
 #define ZKW_COMMIT_STAGE_LEAF 0
 #define ZKW_COMMIT_STAGE_BUCKET 1
 #define ZKW_COMMIT_STAGE_CHAIN 2
 #define ZKW_COMMIT_STAGE_BLOB_CHAIN 3
 #define ZKW_COMMIT_STAGE_NETSTATE 4
 #define ZKW_COMMIT_STAGE_MIDSTATE 5
+#define ZKW_COMMIT_STAGE_BLOB_CHUNKS 6
 
 typedef struct zkw_commit_params {
   uint32_t n_instances, L, n_waves, max_cycles, wave_threads;
@@ -35,6 +38,7 @@ typedef struct zkw_commit_params {
   const uint64_t* blob_digests; /* [n_blobs][4] */
   const uint2* blob_dir;
   const zkw_dev_preimage* preimages; /* [n_preimages] (midstate stage) */
+  uint64_t* chunk_tails;     /* blob digests, first level: tail of every 64-word chunk (slot = first_word / 64 + blob + chunk) */
   uint64_t* midstates;       /* [n_preimages][12] sponge state after absorbing the code hash (decommit leaves) */
   uint32_t n_preimages;
   uint32_t reserved1;

@@ -373,16 +373,38 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) zkw_chain_kernel(zkw_
   dst[0] = tail[0]; dst[1] = tail[1]; dst[2] = tail[2]; dst[3] = tail[3];
 }
 
-// blob digests: one blob per thread, chain over its word leaves (run once per upload)
+// blob digests, two levels (run once per upload and new bytecode): a sequential chain over 64-word chunks in parallel
+// (one chunk per thread), then one chain per blob over its chunk tails — a 2000-word blob is 64 + 32 sequential
+// permutations instead of 2000.
+__global__ void zkw_blob_chunk_kernel(zkw_fused_table T) {
+  const zkw_commit_params ZKW_CONST_AS& C = *(const zkw_commit_params ZKW_CONST_AS*)T.p[0];
+  const u32 b = blockIdx.y;
+  if (b >= C.n_blobs) return;
+  const uint2 d = C.blob_dir[b];
+  const u32 n_chunks = (d.y + ZKW_BLOB_CHUNK_WORDS - 1) / ZKW_BLOB_CHUNK_WORDS;
+  for (u32 c = blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += gridDim.x * blockDim.x) {
+    const u32 first = c * ZKW_BLOB_CHUNK_WORDS;
+    const u32 cnt = d.y - first < ZKW_BLOB_CHUNK_WORDS ? d.y - first : ZKW_BLOB_CHUNK_WORDS;
+    u64 tail[4] = {0, 0, 0, 0};
+    for (u32 j = 0; j < cnt; j++) {
+      const u64* lf = C.leaves + ((u64)d.x + first + j) * 4;
+      const u64 leaf[4] = {lf[0], lf[1], lf[2], lf[3]};
+      gl_chain_step(C.rc, leaf, tail, (u64)j + 1, ZKW_QUEUE_ID_BLOB);
+    }
+    u64* dst = C.chunk_tails + ((u64)(d.x / ZKW_BLOB_CHUNK_WORDS) + b + c) * 4;
+    dst[0] = tail[0]; dst[1] = tail[1]; dst[2] = tail[2]; dst[3] = tail[3];
+  }
+}
 __global__ void zkw_blob_chain_kernel(zkw_fused_table T) {
   const zkw_commit_params ZKW_CONST_AS& C = *(const zkw_commit_params ZKW_CONST_AS*)T.p[0];
   for (u32 b = blockIdx.x * blockDim.x + threadIdx.x; b < C.n_blobs; b += gridDim.x * blockDim.x) {
     const uint2 d = C.blob_dir[b];
+    const u32 n_chunks = (d.y + ZKW_BLOB_CHUNK_WORDS - 1) / ZKW_BLOB_CHUNK_WORDS;
     u64 tail[4] = {0, 0, 0, 0};
-    for (u32 j = 0; j < d.y; j++) {
-      const u64* lf = C.leaves + ((u64)d.x + j) * 4;
+    for (u32 c = 0; c < n_chunks; c++) {
+      const u64* lf = C.chunk_tails + ((u64)(d.x / ZKW_BLOB_CHUNK_WORDS) + b + c) * 4;
       const u64 leaf[4] = {lf[0], lf[1], lf[2], lf[3]};
-      gl_chain_step(C.rc, leaf, tail, (u64)j + 1, ZKW_QUEUE_ID_BLOB);
+      gl_chain_step(C.rc, leaf, tail, (u64)c + 1, ZKW_QUEUE_ID_BLOB_TOP);
     }
     u64* dst = C.out + (u64)b * 4;
     dst[0] = tail[0]; dst[1] = tail[1]; dst[2] = tail[2]; dst[3] = tail[3];
@@ -511,6 +533,10 @@ extern "C" hipError_t zkw_launch_commit(const zkw_fused_table* T, int stage, hip
     hipLaunchKernelGGL(zkw_bucket_kernel, dim3(T->max_waves, T->n), dim3(wt), 0, stream, *T);
   } else if (stage == ZKW_COMMIT_STAGE_CHAIN) {
     hipLaunchKernelGGL(zkw_chain_kernel, dim3(T->max_waves, T->n), dim3(wt), 0, stream, *T);
+  } else if (stage == ZKW_COMMIT_STAGE_BLOB_CHUNKS) {
+    const u32 threads = wt > 1 ? 64 : 1;
+    const u32 max_chunks = (T->max_cap + ZKW_BLOB_CHUNK_WORDS - 1) / ZKW_BLOB_CHUNK_WORDS;  // max_cap = words of the longest blob (upper bound: all words)
+    hipLaunchKernelGGL(zkw_blob_chunk_kernel, dim3((max_chunks + threads - 1) / threads ? (max_chunks + threads - 1) / threads : 1, T->n_blobs), dim3(threads), 0, stream, *T);
   } else if (stage == ZKW_COMMIT_STAGE_MIDSTATE) {
     const u32 threads = wt > 1 ? 64 : 1;
     hipLaunchKernelGGL(zkw_midstate_kernel, dim3((T->n_blobs + threads - 1) / threads), dim3(threads), 0, stream, *T);  // n_blobs = number of preimages here

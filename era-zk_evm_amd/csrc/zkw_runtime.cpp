@@ -489,8 +489,15 @@ int zkw_batch_upload(zkw_batch* b) {
     if (all_cached) {
       if (!digests.empty()) HIP_TRY(c, hipMemcpy(b->d_blob_digests.p, digests.data(), digests.size() * 8, hipMemcpyHostToDevice));
     } else {
+      DevBuf<uint64_t> chunk_tails;
+      HIP_TRY(c, chunk_tails.alloc((total_words / ZKW_BLOB_CHUNK_WORDS + b->blobs.size() + 2) * 4));
+      C.chunk_tails = chunk_tails.p;
+      HIP_TRY(c, hipMemcpy(b->d_commit_params.p + ZKW_QUEUE_COUNT, &C, sizeof C, hipMemcpyHostToDevice));
       if (total_words) HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_LEAF, nullptr));
+      if (total_words) HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_BLOB_CHUNKS, nullptr));
       HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_BLOB_CHAIN, nullptr));
+      HIP_TRY(c, hipStreamSynchronize(nullptr));
+      chunk_tails.release();
       HIP_TRY(c, hipStreamSynchronize(nullptr));
       if (!digests.empty()) HIP_TRY(c, hipMemcpy(digests.data(), b->d_blob_digests.p, digests.size() * 8, hipMemcpyDeviceToHost));
       for (size_t i = 0; i < b->blobs.size(); i++) {

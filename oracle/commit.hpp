@@ -99,10 +99,18 @@ inline std::vector<uint64_t> limbs(const zkw_u256& v) {
   return r;
 }
 
+// two levels: chains inside 64-word chunks (queue id 0xB10B, index restarts at 1 in every chunk), then one chain over
+// the chunk tails (queue id 0xB10C)
 inline Digest blob_digest(const Perm& perm, const zkw_u256* words, size_t n) {
-  Digest tail{{0, 0, 0, 0}};
-  for (size_t j = 0; j < n; j++) chain_step(perm, leaf(perm, 4, limbs(words[j])), tail, j + 1, 0xB10B);
-  return tail;
+  Digest top{{0, 0, 0, 0}};
+  uint64_t c = 0;
+  for (size_t first = 0; first < n; first += 64) {
+    Digest tail{{0, 0, 0, 0}};
+    const size_t cnt = n - first < 64 ? n - first : 64;
+    for (size_t j = 0; j < cnt; j++) chain_step(perm, leaf(perm, 4, limbs(words[first + j])), tail, j + 1, 0xB10B);
+    chain_step(perm, tail, top, ++c, 0xB10C);
+  }
+  return top;
 }
 
 inline Digest mem_queue(const Perm& perm, const zkw_mem_query* q, size_t n) {
