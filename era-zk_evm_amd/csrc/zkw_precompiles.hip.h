@@ -60,12 +60,6 @@ ZD void zk_keccak_f1600(u64 a[25]) {
 
 #define ZKW_KECCAK_RATE 136
 
-ZD void kbuf_set_byte(Shared& sh, u32 lane, u32 pos, u32 byte) {
-  u32* w = &sh.krow[(pos >> 2) * sh.L + lane];  // [dword][lane]: conflict-free across lanes
-  const u32 shf = (pos & 3u) * 8u;
-  *w = (*w & ~(0xffu << shf)) | (byte << shf);
-}
-
 ZD void keccak_absorb_block(Shared& sh, u32 lane, u64 st[25]) {
 #pragma unroll
   for (int i = 0; i < 17; i++) {
@@ -75,44 +69,80 @@ ZD void keccak_absorb_block(Shared& sh, u32 lane, u64 st[25]) {
   zk_keccak_f1600(st);
 }
 
+// big-endian dword k (0 = most significant) of a memory word, k dynamic: select chain instead of register indexing
+ZD u32 word_be_dword(const u256& w, u32 k) {
+  u32 v = w.w[7];
+#pragma unroll
+  for (int i = 1; i < 8; i++) v = k == (u32)i ? w.w[7 - i] : v;
+  return v;
+}
+
 // keccak256_rounds_function: input = `input_memory_length` bytes at byte offset `input_memory_offset`
 // of page `memory_page_to_read`; output = one big-endian word at word `output_memory_offset` of
 // `memory_page_to_write` (reference test src/testing/tests/precompiles/keccak256.rs:99-139).
+// The message is consumed four bytes at a time: stream dword d is a funnel of two consecutive big-endian memory dwords
+// (the byte misalignment of the input is constant over the message); the rate block is staged as 34 dwords per lane in
+// the wave's row buffer ([dword][lane], one coalesced store per dword) and absorbed with static indices.  Every memory
+// word that holds message bytes is read exactly once, in order, as in the reference.
 ZD void precompile_keccak256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   const u32 in_off = q.key.w[0], in_len = q.key.w[1], out_off = q.key.w[2];
   const u32 page_r = q.key.w[4], page_w = q.key.w[5];
   u64 st[25];
 #pragma unroll
   for (int i = 0; i < 25; i++) st[i] = 0;
-  u32 fill = 0;
-  u32 byte_off = in_off, left = in_len;
-  while (left > 0 && lane_ok(s)) {
-    const u32 widx = byte_off >> 5, unal = byte_off & 31u;
-    const u32 take = left < 32u - unal ? left : 32u - unal;
-    const u256 word = fat_ptr_read(P, s, page_r, widx);
-    emit_mem(P, sh, s, q.timestamp, ZKW_MEM_FAT_PTR, page_r, widx, word, false, false, 1);
-    for (u32 b = 0; b < take; b++) {
-      const u32 bi = unal + b;             // big-endian byte index inside the word
-      const u32 limb = 7u - (bi >> 2);     // limb holding that byte
-      const u32 shift = (3u - (bi & 3u)) * 8u;
-      // select the limb without dynamic register indexing
-      u32 lv = word.w[0];
-#pragma unroll
-      for (int i = 1; i < 8; i++) lv = limb == (u32)i ? word.w[i] : lv;
-      kbuf_set_byte(sh, s.lane, fill, (lv >> shift) & 0xffu);
-      fill++;
-      if (fill == ZKW_KECCAK_RATE) {
-        keccak_absorb_block(sh, s.lane, st);
-        fill = 0;
+  const u32 sh8 = (in_off & 3u) * 8u;
+  u256 w_cur = u256_zero(), w_next = u256_zero();
+  u32 cur_idx = 0xffffffffu, next_idx = 0xffffffffu;  // word indices held in w_cur / w_next
+  const u32 n_dwords = (in_len + 3u) >> 2;
+  u32 slot = 0;  // dword position inside the rate block
+  for (u32 d = 0; d < n_dwords && lane_ok(s); d++) {
+    const u32 need = in_len - 4u * d < 4u ? in_len - 4u * d : 4u;  // message bytes in this stream dword
+    const u32 m0 = (in_off >> 2) + d;                               // memory dword holding its first byte
+    const bool two = (in_off & 3u) + need > 4u;                     // the dword straddles two memory dwords
+    // fetch (in order, once) the words that hold m0 and, if used, m0 + 1
+    const u32 wi0 = m0 >> 3, wi1 = (m0 + 1u) >> 3;
+    if (wi0 != cur_idx) {
+      if (wi0 == next_idx) {
+        w_cur = w_next;
+        cur_idx = next_idx;
+      } else {
+        w_cur = fat_ptr_read(P, s, page_r, wi0);
+        emit_mem(P, sh, s, q.timestamp, ZKW_MEM_FAT_PTR, page_r, wi0, w_cur, false, false, 1);
+        cur_idx = wi0;
       }
     }
-    byte_off += take;
-    left -= take;
+    u32 b = 0;
+    if (two) {
+      if (wi1 != cur_idx) {
+        if (wi1 != next_idx) {
+          w_next = fat_ptr_read(P, s, page_r, wi1);
+          emit_mem(P, sh, s, q.timestamp, ZKW_MEM_FAT_PTR, page_r, wi1, w_next, false, false, 1);
+          next_idx = wi1;
+        }
+        b = word_be_dword(w_next, (m0 + 1u) & 7u);
+      } else {
+        b = word_be_dword(w_cur, (m0 + 1u) & 7u);
+      }
+    }
+    const u32 a = word_be_dword(w_cur, m0 & 7u);
+    u32 v = sh8 ? ((a << sh8) | (b >> (32u - sh8))) : a;  // big-endian stream dword
+    if (need < 4u) v &= 0xffffffffu << (8u * (4u - need));
+    u32 le = __builtin_bswap32(v);
+    if (need < 4u) le |= 0x01u << (8u * need);  // the pad byte follows the last message byte inside this dword
+    sh.krow[slot * sh.L + s.lane] = le;
+    slot++;
+    if (slot == ZKW_KROW_WORDS && !(need < 4u)) {  // a full block of message bytes
+      keccak_absorb_block(sh, s.lane, st);
+      slot = 0;
+    }
   }
   if (!lane_ok(s)) return;
-  // pad10*1 with the legacy 0x01 domain byte
-  kbuf_set_byte(sh, s.lane, fill, 0x01u);
-  for (u32 p = fill + 1; p < ZKW_KECCAK_RATE; p++) kbuf_set_byte(sh, s.lane, p, 0);
+  // pad10*1 with the legacy 0x01 domain byte: 0x01 right after the message, 0x80 on the last byte of the block
+  if ((in_len & 3u) == 0u) {
+    sh.krow[slot * sh.L + s.lane] = 0x01u;
+    slot++;
+  }
+  for (u32 p = slot; p < ZKW_KROW_WORDS; p++) sh.krow[p * sh.L + s.lane] = 0;
   sh.krow[(ZKW_KROW_WORDS - 1) * sh.L + s.lane] |= 0x80000000u;
   keccak_absorb_block(sh, s.lane, st);
   u256 digest;

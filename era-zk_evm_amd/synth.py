@@ -460,7 +460,13 @@ def sha256_padded_len(n):
     return ((n + 9 + 63) // 64) * 64
 
 
-def config3(isa, n_instances=4096, n_cycles=64, seed=0x5EED0003, keccak_k=(1, 8, 64, 512), sha_rounds=(1, 8, 64, 157)):
+def config3(isa, n_instances=4096, n_cycles=64, seed=0x5EED0003, keccak_k=(1, 8, 64, 512), sha_rounds=(1, 8, 64, 157), keccak_bytes=None,
+            keccak_unalign=None):
+    """keccak_bytes / keccak_unalign: optional explicit message lengths (bytes) and byte misalignments (default: 136 * k
+    bytes, misalignment 0 / 31 alternating)"""
+    klen = list(keccak_bytes) if keccak_bytes is not None else [136 * k for k in keccak_k]
+    keccak_k = [b // 136 for b in klen]  # rounds - 1, for the ergs cost
+    kun = list(keccak_unalign) if keccak_unalign is not None else [(31 if j % 2 else 0) for j in range(len(klen))]
     """The bootloader frame runs as the sha256 system contract (address 0x02) and hashes four
     regions of its own heap (precompile reads are MemoryType::Heap of the current frame), then
     far-calls the keccak system contract (0x8010) passing its whole heap as calldata; the callee
@@ -475,8 +481,8 @@ def config3(isa, n_instances=4096, n_cycles=64, seed=0x5EED0003, keccak_k=(1, 8,
     kec_off = []
     for j, k in enumerate(keccak_k):
         off = (off + 31) // 32 * 32
-        kec_off.append(off + (31 if j % 2 else 0))
-        off += 136 * k + 32
+        kec_off.append(off + kun[j])
+        off += klen[j] + 32
     heap_words = (off + 31) // 32 + 8
     out_base_boot = heap_words - 6  # sha digests land in the last words of the bootloader heap
     boot_page_heap = BOOTLOADER_BASE_PAGE + 2
@@ -507,7 +513,7 @@ def config3(isa, n_instances=4096, n_cycles=64, seed=0x5EED0003, keccak_k=(1, 8,
     cops = []
     cconsts = []
     for j, k in enumerate(keccak_k):
-        cconsts.append(precompile_abi(kec_off[j], 136 * k, j, 0, boot_page_heap, 0))
+        cconsts.append(precompile_abi(kec_off[j], klen[j], j, 0, boot_page_heap, 0))
     cconsts.append(ret_abi(0, 32 * len(keccak_k)))
     local = 64
     for j, k in enumerate(keccak_k):
@@ -553,11 +559,11 @@ def config3(isa, n_instances=4096, n_cycles=64, seed=0x5EED0003, keccak_k=(1, 8,
         by[:, start + msg_len + 1: start + 64 * r - 8] = 0
         by[:, start + 64 * r - 8: start + 64 * r] = np.frombuffer((8 * msg_len).to_bytes(8, "big"), dtype="u1")
         wl.sha_messages.append((start, msg_len, out_base_boot + j))
-    wl.keccak_messages = [(kec_off[j], 136 * k, j) for j, k in enumerate(keccak_k)]
+    wl.keccak_messages = [(kec_off[j], klen[j], j) for j, k in enumerate(keccak_k)]
     wl.heap_bytes = by
     heaps = by.reshape(n_instances, heap_words, 4, 8).view(">u8").reshape(n_instances, heap_words, 4)[:, :, ::-1].astype("<u8")
     wl.heaps = np.ascontiguousarray(heaps)
-    n_pre_reads = sum(2 * r for r in sha_rounds) + sum((136 * k + 31 + 31) // 32 + 1 for k in keccak_k)
+    n_pre_reads = sum(2 * r for r in sha_rounds) + sum((b + 31 + 31) // 32 + 1 for b in klen)
     wl.limits.update(max_far_frames=2, heap_words=heap_words + 8, stack_words=8, aux_heap_words=8, storage_slots=8, storage_journal=4,
                      max_mem_queries=n_pre_reads + 8 * executed + 64, max_log_queries=16, max_aux_events=16)
     return wl

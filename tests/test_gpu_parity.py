@@ -302,3 +302,12 @@ def test_capacity_overruns_are_limit_statuses(oracle, product, isa, field, value
             assert n < to["n_cycles"]
             assert tp["records"].tobytes() == to["records"][:n].tobytes()
     assert hit > 0
+
+
+@pytest.mark.parametrize("lens,unal", [((0, 1, 3, 50), (0, 1, 2, 3)), ((135, 136, 137, 200), (31, 5, 30, 7)), ((272, 7, 131, 408), (1, 2, 3, 4))])
+def test_keccak_precompile_odd_lengths_and_alignments(oracle, product, isa, lens, unal):
+    wl = synth.make(3, isa, n_instances=70, keccak_bytes=lens, keccak_unalign=unal, sha_rounds=(1, 1, 1, 1))
+    bo, bp = _run(oracle, wl), _run(product, wl)
+    for i in range(0, 70, 3):
+        ok, why = K.traces_equal(bo.trace(i), bp.trace(i))
+        assert ok, (i, why)
