@@ -246,7 +246,9 @@ typedef struct zkw_limits {
  * Everything else of VmLocalState is either constant inside a frame (restored from the
  * FRAME_START/FRAME_FINISH aux events), derivable (monotonic_cycle_counter = initial + k + 1,
  * previous_code_word = value of the cycle's code read, previous_code_memory_page = code page
- * current at cycle start) or rare (COLD_STATE aux event). */
+ * current at cycle start) or rare (COLD_STATE aux event).
+ * On the device a record is stored losslessly as its 32-byte tail plus the values of the registers the cycle wrote
+ * (about 70 bytes per cycle instead of 512); zkw_batch_get_instance_trace materialises the full records. */
 typedef struct zkw_cycle_tail {
   uint16_t register_ptr_bitmap;
   uint8_t flags;  /* bits 0..2 = lt,eq,gt; bit 3 = pending_exception */
