@@ -111,3 +111,16 @@ def test_net_state_capacity_overflow_is_reported(emu, isa):
     b.reset(); b.run(wl.n_cycles); b.sync()
     with pytest.raises(K.ZkwError):
         b.net_state(0)
+
+
+def test_golden_net_state_digests(oracle, emu, isa):
+    """Regression pins (tests/golden/net_state_digests.json, generated by tests/golden/make_golden.py from the oracle):
+    the oracle still produces them, and so does the product."""
+    import json
+    from golden.make_golden import net_state_cases, net_state_digest
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "net_state_digests.json")))
+    cases = net_state_cases(isa)
+    assert sorted(cases) == sorted(golden)
+    for name, wl in cases.items():
+        assert net_state_digest(oracle, wl) == golden[name], name
+        assert net_state_digest(emu, wl) == golden[name], name
