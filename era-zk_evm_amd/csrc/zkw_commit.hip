@@ -79,18 +79,6 @@ ZD u64 gl_reduce128_lazy(u64 lo, u64 hi) {
   if (r < t1) r += GL_EPS;
   return r;
 }
-// x * 2^K for a static 0 <= K < 32: the 128-bit product is (x >> (64-K)) : (x << K), and hi < 2^K reduces as
-// hi * 2^64 = hi * (2^32 - 1) (mod p) — no multiplier involved
-template <int K>
-ZD u64 gl_mul_pow2(u64 x) {
-  if (K == 0) return x;
-  const u64 lo = x << K, hi = x >> (64 - K);
-  const u64 t1 = (hi << 32) - hi;
-  u64 r = lo + t1;
-  if (r < t1) r += GL_EPS;
-  if (r >= GL_P) r -= GL_P;
-  return r;
-}
 ZD u64 gl_pow7(u64 x) {
   u64 lo, hi;
   sqr64(x, lo, hi);
@@ -103,32 +91,35 @@ ZD u64 gl_pow7(u64 x) {
   return gl_reduce128(lo, hi);  // canonical
 }
 
-// M4 of the Poseidon2 paper: [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]]
-ZD void gl_m4(u64& a, u64& b, u64& c, u64& d) {
-  const u64 t0 = gl_add(a, b), t1 = gl_add(c, d);
-  const u64 t2 = gl_add(gl_add(b, b), t1), t3 = gl_add(gl_add(d, d), t0);
-  const u64 t4 = gl_add(gl_add(gl_add(t1, t1), gl_add(t1, t1)), t3);
-  const u64 t5 = gl_add(gl_add(gl_add(t0, t0), gl_add(t0, t0)), t2);
-  const u64 t6 = gl_add(t3, t5), t7 = gl_add(t2, t4);
-  a = t6; b = t5; c = t7; d = t4;
+// The linear layers are evaluated over the integers in 128-bit accumulators and reduced once per output element:
+// every coefficient pattern below sums to at most 64 * 2^64 (external) / 2^76 (internal), far inside 128 bits, and
+// gl_reduce128 accepts any 128-bit value.  (The element-wise form cost ~40 modular additions per layer.)
+typedef unsigned __int128 u128;
+ZD u64 gl_reduce_wide(u128 x) { return gl_reduce128((u64)x, (u64)(x >> 64)); }
+
+// M4 of the Poseidon2 paper: [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] — unreduced (row sums <= 16)
+ZD void gl_m4_wide(u64 a, u64 b, u64 c, u64 d, u128& o0, u128& o1, u128& o2, u128& o3) {
+  const u128 t0 = (u128)a + b, t1 = (u128)c + d;
+  const u128 t2 = ((u128)b << 1) + t1, t3 = ((u128)d << 1) + t0;
+  const u128 t4 = (t1 << 2) + t3, t5 = (t0 << 2) + t2;
+  o0 = t3 + t5; o1 = t5; o2 = t2 + t4; o3 = t4;
 }
 ZD void gl_external(u64 s[12]) {
+  u128 o[12];
 #pragma unroll
-  for (int i = 0; i < 12; i += 4) gl_m4(s[i], s[i + 1], s[i + 2], s[i + 3]);
-  u64 sum[4];
+  for (int i = 0; i < 12; i += 4) gl_m4_wide(s[i], s[i + 1], s[i + 2], s[i + 3], o[i], o[i + 1], o[i + 2], o[i + 3]);
+  u128 sum[4];
 #pragma unroll
-  for (int j = 0; j < 4; j++) sum[j] = gl_add(gl_add(s[j], s[4 + j]), s[8 + j]);
+  for (int j = 0; j < 4; j++) sum[j] = o[j] + o[4 + j] + o[8 + j];
 #pragma unroll
-  for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], sum[i & 3]);
+  for (int i = 0; i < 12; i++) s[i] = gl_reduce_wide(o[i] + sum[i & 3]);
 }
 ZD void gl_internal(u64 s[12]) {
-  u64 sum = 0;
+  u128 sum = 0;
 #pragma unroll
-  for (int i = 0; i < 12; i++) sum = gl_add(sum, s[i]);
-  s[0] = gl_add(sum, gl_mul_pow2<0>(s[0]));   s[1] = gl_add(sum, gl_mul_pow2<1>(s[1]));   s[2] = gl_add(sum, gl_mul_pow2<2>(s[2]));
-  s[3] = gl_add(sum, gl_mul_pow2<3>(s[3]));   s[4] = gl_add(sum, gl_mul_pow2<4>(s[4]));   s[5] = gl_add(sum, gl_mul_pow2<5>(s[5]));
-  s[6] = gl_add(sum, gl_mul_pow2<6>(s[6]));   s[7] = gl_add(sum, gl_mul_pow2<7>(s[7]));   s[8] = gl_add(sum, gl_mul_pow2<8>(s[8]));
-  s[9] = gl_add(sum, gl_mul_pow2<9>(s[9]));   s[10] = gl_add(sum, gl_mul_pow2<10>(s[10])); s[11] = gl_add(sum, gl_mul_pow2<11>(s[11]));
+  for (int i = 0; i < 12; i++) sum += s[i];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl_reduce_wide(sum + ((u128)s[i] << i));
 }
 
 ZD void gl_permute(const u64* rc, u64 s[12]) {
