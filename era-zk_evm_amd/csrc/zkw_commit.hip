@@ -88,14 +88,22 @@ ZD u64 gl_pow7(u64 x) {
   sqr64(x2, lo, hi);
   const u64 x4 = gl_reduce128_lazy(lo, hi);
   mul64(x4, x3, lo, hi);
-  return gl_reduce128(lo, hi);  // canonical
+  return gl_reduce128_lazy(lo, hi);
 }
 
 // The linear layers are evaluated over the integers in 128-bit accumulators and reduced once per output element:
 // every coefficient pattern below sums to at most 64 * 2^64 (external) / 2^76 (internal), far inside 128 bits, and
 // gl_reduce128 accepts any 128-bit value.  (The element-wise form cost ~40 modular additions per layer.)
 typedef unsigned __int128 u128;
-ZD u64 gl_reduce_wide(u128 x) { return gl_reduce128((u64)x, (u64)(x >> 64)); }
+// Inside the permutation every value is kept only congruent (< 2^64, possibly >= p): products, 128-bit sums and the
+// round-constant addition below accept that, and gl_permute canonicalises the state once at the end.
+ZD u64 gl_reduce_wide(u128 x) { return gl_reduce128_lazy((u64)x, (u64)(x >> 64)); }
+// s + rc for any s < 2^64 and a canonical constant: s + rc < 2^65 - 2^32, so one wrap correction suffices
+ZD u64 gl_add_rc(u64 s, u64 rc) {
+  u64 x = s + rc;
+  if (x < s) x += GL_EPS;
+  return x;
+}
 
 // M4 of the Poseidon2 paper: [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] — unreduced (row sums <= 16)
 ZD void gl_m4_wide(u64 a, u64 b, u64 c, u64 d, u128& o0, u128& o1, u128& o2, u128& o3) {
@@ -127,21 +135,24 @@ ZD void gl_permute(const u64* rc, u64 s[12]) {
   int k = 0;
   for (int r = 0; r < 4; r++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_pow7(gl_add(s[i], rc[k + i]));
+    for (int i = 0; i < 12; i++) s[i] = gl_pow7(gl_add_rc(s[i], rc[k + i]));
     k += 12;
     gl_external(s);
   }
   for (int r = 0; r < 22; r++) {
-    s[0] = gl_pow7(gl_add(s[0], rc[k]));
+    s[0] = gl_pow7(gl_add_rc(s[0], rc[k]));
     k += 1;
     gl_internal(s);
   }
   for (int r = 0; r < 4; r++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_pow7(gl_add(s[i], rc[k + i]));
+    for (int i = 0; i < 12; i++) s[i] = gl_pow7(gl_add_rc(s[i], rc[k + i]));
     k += 12;
     gl_external(s);
   }
+#pragma unroll
+  for (int i = 0; i < 12; i++)
+    if (s[i] >= GL_P) s[i] -= GL_P;  // canonical representatives out
 }
 
 // sponge over n <= 32 field elements held in a statically indexed array
