@@ -366,10 +366,31 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) zkw_chain_kernel(zkw_
   const u32 cnt = C.counts[inst];
   const u32* idx = C.idx + (u64)inst * C.per_instance_cap;
   u64 tail[4] = {0, 0, 0, 0};
-  for (u32 j = 0; j < cnt; j++) {
-    const u64* lf = C.leaves + ((u64)wave * C.cap + idx[j]) * 4;
-    const u64 leaf[4] = {lf[0], lf[1], lf[2], lf[3]};
-    gl_chain_step(C.rc, leaf, tail, (u64)j + 1, C.queue);
+  if (C.queue == ZKW_QUEUE_DECOMMIT) {
+    // few records per instance (one per decommit): the leaf is computed here from the cached sponge midstate of the
+    // code hash (one permutation) instead of in a separate pass over the whole aux stream
+    for (u32 j = 0; j < cnt; j++) {
+      const uint4* e = C.stream + ((u64)wave * C.cap + idx[j]) * 16;
+      const uint4 h = e[0];
+      const u32 pre = e[3].x, blob = h.w >> 16;
+      const u64* ms = C.midstates + (u64)pre * 12;
+      const u64* bd = C.blob_digests + (u64)blob * 4;
+      u64 st[12];
+#pragma unroll
+      for (int i = 0; i < 12; i++) st[i] = ms[i];
+      const u64 f[8] = {h.y, h.z, h.w & 0xffffu, (h.x >> 24) & 0xffu, bd[0], bd[1], bd[2], bd[3]};
+#pragma unroll
+      for (int i = 0; i < 8; i++) st[i] = gl_add(st[i], f[i]);
+      gl_permute(C.rc, st);
+      const u64 leaf[4] = {st[0], st[1], st[2], st[3]};
+      gl_chain_step(C.rc, leaf, tail, (u64)j + 1, C.queue);
+    }
+  } else {
+    for (u32 j = 0; j < cnt; j++) {
+      const u64* lf = C.leaves + ((u64)wave * C.cap + idx[j]) * 4;
+      const u64 leaf[4] = {lf[0], lf[1], lf[2], lf[3]};
+      gl_chain_step(C.rc, leaf, tail, (u64)j + 1, C.queue);
+    }
   }
   u64* dst = C.out + ((u64)inst * ZKW_QUEUE_COUNT + C.queue) * 4;
   dst[0] = tail[0]; dst[1] = tail[1]; dst[2] = tail[2]; dst[3] = tail[3];

@@ -856,7 +856,8 @@ static int enqueue_commit(zkw_batch* const* bs, uint32_t n, uint32_t queue_mask,
       T.max_waves = std::max(T.max_waves, bs[i]->n_waves);
       T.max_cap = std::max(T.max_cap, caps[q]);
     }
-    HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_LEAF, st));
+    // the decommit queue has a handful of records per instance: its leaves are computed inside the chain kernel
+    if (q != ZKW_QUEUE_DECOMMIT) HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_LEAF, st));
     HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_BUCKET, st));
     HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_CHAIN, st));
   }
