@@ -184,6 +184,8 @@ typedef struct zkw_reset_params {
   uint4* dst[5];
   const uint4* src[5];
   uint32_t n16[5];          /* 16-byte units per buffer */
+  uint32_t cs_row16;         /* callstack ([2]): 16-byte units to restore per instance (entries 0..initial depth) ... */
+  uint32_t cs_pitch16;       /* ... out of this many per instance; n16[2] = n_instances * cs_row16 */
   uint4* heap_dst;           /* working heap arena */
   const uint4* heap_src;     /* [n_waves][heap_image_words][L][2] */
   uint32_t heap_row16;       /* 16-byte units per wave row of the image */

@@ -1790,6 +1790,16 @@ __global__ void zkw_reset_kernel(zkw_fused_table T) {
       dst[i] = a; dst[i + stride] = c; dst[i + 2 * stride] = d; dst[i + 3 * stride] = e;
     }
     for (; i < n; i += stride) dst[i] = src[i];
+    if (b == 1) {  // callstack next: only the entries a run can read before writing them (0 .. initial depth) are restored
+      const u32 rows = R.n16[2], r16 = R.cs_row16, p16 = R.cs_pitch16;
+      const uint4* cs = R.src[2];
+      uint4* cd = R.dst[2];
+      for (u32 j = t0; j < rows; j += stride) {
+        const u32 at = (j / r16) * p16 + j % r16;
+        cd[at] = cs[at];
+      }
+      b = 2;  // skip the flat copy of buffer 2
+    }
   }
   // heap image: [n_waves][heap_row16] (dense) -> rows of the working arena
   const u32 row = R.heap_row16;

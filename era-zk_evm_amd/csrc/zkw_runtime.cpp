@@ -110,6 +110,7 @@ struct zkw_batch {
   bool uploaded = false, ran = false, synced = false;
   uint32_t cycles_run = 0;  // wave cycles since reset
   uint32_t heap_image_words = 0;
+  uint32_t max_initial_depth = 0;  // deepest initial callstack among the instances
   // device: pristine
   DevBuf<uint4> d_regs0;
   DevBuf<zkw_dev_scalars> d_scalars0;
@@ -532,6 +533,7 @@ int zkw_batch_upload(zkw_batch* b) {
   uint32_t himg = 0;
   for (uint32_t i = 0; i < n; i++) himg = std::max(himg, (uint32_t)b->staged[i].heap.size());
   b->heap_image_words = himg;
+  b->max_initial_depth = 0;
   std::vector<uint4> heap0((size_t)W * himg * L * 2, make_uint4(0, 0, 0, 0));
   for (uint32_t i = 0; i < n; i++) {
     const StagedInstance& s = b->staged[i];
@@ -570,6 +572,7 @@ int zkw_batch_upload(zkw_batch* b) {
       return -1;
     };
     const uint32_t depth = st.callstack_depth;
+    b->max_initial_depth = std::max(b->max_initial_depth, depth);
     for (uint32_t d = 0; d <= depth; d++) {
       const zkw_callstack_entry& e = d < depth ? s.inner[d] : st.current;
       uint32_t slot = 0;
@@ -708,7 +711,9 @@ int zkw_batch_upload(zkw_batch* b) {
     std::memset(&R, 0, sizeof R);
     R.dst[0] = b->d_regs.p; R.src[0] = b->d_regs0.p; R.n16[0] = (uint32_t)(b->d_regs0.bytes() / 16);
     R.dst[1] = (uint4*)b->d_scalars.p; R.src[1] = (const uint4*)b->d_scalars0.p; R.n16[1] = (uint32_t)(b->d_scalars0.bytes() / 16);
-    R.dst[2] = (uint4*)b->d_callstack.p; R.src[2] = (const uint4*)b->d_callstack0.p; R.n16[2] = (uint32_t)(b->d_callstack0.bytes() / 16);
+    R.dst[2] = (uint4*)b->d_callstack.p; R.src[2] = (const uint4*)b->d_callstack0.p; R.cs_pitch16 = (b->lim.max_callstack_depth + 1) * (uint32_t)(sizeof(zkw_dev_entry) / 16);
+    R.cs_row16 = std::min(R.cs_pitch16, (b->max_initial_depth + 1) * (uint32_t)(sizeof(zkw_dev_entry) / 16));
+    R.n16[2] = b->n * R.cs_row16;
     R.dst[3] = (uint4*)b->d_frames.p; R.src[3] = (const uint4*)b->d_frames0.p; R.n16[3] = (uint32_t)(b->d_frames0.bytes() / 16);
     R.dst[4] = (uint4*)b->d_storage.p; R.src[4] = (const uint4*)b->d_storage0.p; R.n16[4] = (uint32_t)(b->d_storage0.bytes() / 16);
     R.heap_dst = b->d_heap.p; R.heap_src = b->d_heap0.p;
