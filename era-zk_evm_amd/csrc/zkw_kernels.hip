@@ -1578,6 +1578,11 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   // fails or has used its cycles: the lane state is then modified unconditionally inside the loop body instead of inside
   // an `if (active)` region of every iteration (whose merge points cost ~75 register copies per VM cycle).
   u32 k = 0;
+  uint2 next_slot = make_uint2(0, 0), next_e = make_uint2(0, 0);
+  if (exists) {
+    next_slot = sh.pcw[(3u - (s.pc & 3u)) * P.L + tid];
+    next_e = sh.isa[next_slot.x & (ZKW_ISA_TABLE_SIZE - 1)];
+  }
   if (exists && s.status == ZKW_STATUS_RUNNING) {
     for (;;) {
       if (k >= A.run_cycles) break;
@@ -1599,6 +1604,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
       const bool pending = (s.flags & FLAG_PENDING) != 0;
       const u32 super_pc = s.pc >> 2, sub_pc = s.pc & 3u;
       u64 enc;
+      uint2 my_e;  // this lane's packed ISA entry (prefetched at the end of the previous cycle when no fetch is due)
       if (!pending) {
         if (s.code_page != s.prev_code_page || s.prev_super_pc != super_pc) {  // :59-95
           const u256 word = code_read(P, s, super_pc);
@@ -1606,14 +1612,20 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
 #pragma unroll
           for (int i = 0; i < 4; i++) sh.pcw[i * P.L + tid] = make_uint2(word.w[2 * i], word.w[2 * i + 1]);
           s.prev_super_pc = super_pc;
+          // integer_representaiton_from_u256: opcode k of a word is u64 limb 3-k (:86-94) — straight from the registers
+          const u32 lo = sub_pc == 0 ? word.w[6] : (sub_pc == 1 ? word.w[4] : (sub_pc == 2 ? word.w[2] : word.w[0]));
+          const u32 hi = sub_pc == 0 ? word.w[7] : (sub_pc == 1 ? word.w[5] : (sub_pc == 2 ? word.w[3] : word.w[1]));
+          enc = ((u64)hi << 32) | lo;
+          my_e = sh.isa[lo & (ZKW_ISA_TABLE_SIZE - 1)];
+        } else {
+          enc = ((u64)next_slot.y << 32) | next_slot.x;
+          my_e = next_e;
         }
-        // integer_representaiton_from_u256: opcode k of a word is u64 limb 3-k (:86-94)
-        const uint2 slot = sh.pcw[(3u - sub_pc) * P.L + tid];
-        enc = ((u64)slot.y << 32) | slot.x;
       } else {  // :104-115
         s.flags &= ~FLAG_PENDING;
         s.prev_super_pc = super_pc;
         enc = P.consts.exception_revert_encoding;
+        my_e = sh.isa[(u32)enc & (ZKW_ISA_TABLE_SIZE - 1)];
       }
       s.prev_code_page = s.code_page;  // :49
       // ----------------------------------------------------------------------------------------
@@ -1636,9 +1648,8 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
         // that were masked into the nop encoding later in the same cycle
         bool mine = ((todo >> (threadIdx.x & (ZKW_WAVE - 1))) & 1ull) != 0 && enc_lo == u_lo && enc_hi == u_hi && charged == u_charged;
         if (A.debug_flags & 4u) mine = (threadIdx.x & (ZKW_WAVE - 1)) == leader;  // test hook: one lane per group
-        const uint2 e_raw = sh.isa[u_lo & (ZKW_ISA_TABLE_SIZE - 1)];
-        const u32 u_attr = (u32)__builtin_amdgcn_readfirstlane((int)e_raw.x);
-        const u32 u_price = (u32)__builtin_amdgcn_readfirstlane((int)e_raw.y);
+        const u32 u_attr = (u32)__builtin_amdgcn_readlane((int)my_e.x, (int)leader);  // the leader's entry: no LDS access in the loop
+        const u32 u_price = (u32)__builtin_amdgcn_readlane((int)my_e.y, (int)leader);
         if (!u_charged) {  // uniform: first visit of this opcode word
           if (mine) {
             const bool err = decode_exception(P, s, u_attr, u_price);  // :142-184
@@ -1651,6 +1662,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
               const u64 masked = err ? P.consts.exception_revert_encoding : P.consts.nop_encoding;
               enc_lo = (u32)masked;
               enc_hi = (u32)(masked >> 32);
+              my_e = sh.isa[enc_lo & (ZKW_ISA_TABLE_SIZE - 1)];
               mine = false;
             }
           }
@@ -1665,6 +1677,10 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
           else exec_decoded(P, sh, s, d);
         }
       }
+      // prefetch for the next cycle (used only if that cycle does not fetch a new code word): its opcode slot of the
+      // current word and the ISA entry of that opcode — two chained LDS reads that complete behind the record stores
+      next_slot = sh.pcw[(3u - (s.pc & 3u)) * P.L + tid];
+      next_e = sh.isa[next_slot.x & (ZKW_ISA_TABLE_SIZE - 1)];
       // ----------------------------------------------------------------------------------------
       // end of cycle (cycle.rs:408-413)
       // ----------------------------------------------------------------------------------------
