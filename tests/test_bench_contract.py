@@ -1,0 +1,52 @@
+"""The bench line contract (task description, section 4): checked on the committed bench line of the round's final
+profile (profiles/r01m_bench.json) and on bench.py's argument parser — no GPU needed."""
+import ast
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def latest_bench_line():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))
+    assert files, "no committed bench line under profiles/"
+    return json.load(open(files[-1])), files[-1]
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    j, path = latest_bench_line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in j, (path, k)
+    assert j["metric"].startswith("witnessed VM cycles/sec") and j["unit"] == "cycles/s"
+    assert j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None and j["data"] == "synthetic"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = j["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["unit"] == j["unit"]
+    # whole-job throughput = cycles of K steps / time
+    cycles = j["config"]["instances_per_gpu"] * j["config"]["cycles_per_instance"] * j["n_gpus"]
+    assert abs(j["value"] - cycles / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+
+
+def test_bench_accepts_the_driver_flags():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    ast.parse(src)
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert 'add_argument("%s"' % flag in src
+    # rank / world come from the environment of torch.distributed.run
+    for env in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR"):
+        assert env in src
+
+
+def test_traffic_file_matches_the_profile_summary():
+    t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+    assert abs(t["hbm_bytes_per_launch"] - (t["fetch_bytes_corrected_x2"] + t["write_bytes"])) < 1
+    assert abs(t["fetch_bytes_corrected_x2"] - 2 * 1024 * t["FETCH_SIZE_KB"]) < 1
