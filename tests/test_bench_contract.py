@@ -1,5 +1,5 @@
 """The bench line contract (task description, section 4): checked on the committed bench line of the round's final
-profile (profiles/r01m_bench.json) and on bench.py's argument parser — no GPU needed."""
+profile (the newest profiles/r*_bench.json) and on bench.py's argument parser — no GPU needed."""
 import ast
 import glob
 import json
@@ -50,3 +50,19 @@ def test_traffic_file_matches_the_profile_summary():
     t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
     assert abs(t["hbm_bytes_per_launch"] - (t["fetch_bytes_corrected_x2"] + t["write_bytes"])) < 1
     assert abs(t["fetch_bytes_corrected_x2"] - 2 * 1024 * t["FETCH_SIZE_KB"]) < 1
+
+
+def test_rocprof_kernel_duration_agrees_with_the_bench_line():
+    """The committed rocprofv3 --kernel-trace --stats summary of the default command and the HIP-event duration the
+    bench line carries describe the same launches of zkw_cycle_kernel: they must agree (within 5 %)."""
+    import csv
+    j, path = latest_bench_line()
+    stats = path.replace("_bench.json", "_kernel_stats.csv")
+    assert os.path.exists(stats), stats
+    rows = [r for r in csv.DictReader(open(stats)) if r["Name"].startswith("zkw_cycle_kernel")]
+    assert rows, "zkw_cycle_kernel missing from the rocprof summary"
+    avg_ms = float(rows[0]["AverageNs"]) * 1e-6
+    assert abs(avg_ms - j["kernel_ms"]) / avg_ms < 0.05, (avg_ms, j["kernel_ms"])
+    # and the roofline figure is algorithmic bytes per launch over that duration
+    r = j["roofline"]
+    assert abs(r["achieved"] - r["bytes_per_cycle"] * r["cycles_per_launch"] / (j["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
