@@ -124,7 +124,18 @@ struct Shared {
   uint4 *mem_base, *log_base, *aux_base;  // this wave's rows of the query streams (computed once per launch)
   u32 L;
   u32 debug_flags;
+  // launch-invariant geometry and arena bases, loaded once and pinned in scalar registers (ZKW_PIN_SGPR): left to
+  // itself the compiler re-loads them from the parameter block at every use (s_load + s_waitcnt lgkmcnt(0), which
+  // also drains the outstanding LDS reads) because an invariant load is cheaper to rematerialise than to keep
+  u32 F, S, H, A, cap_mem;
+  uint4 *stack_vals, *heap, *aux_heap;
+  uint8_t* stack_ptrs;
 };
+#ifdef __HIP_DEVICE_COMPILE__
+#define ZKW_PIN_SGPR(x) asm volatile("" : "+s"(x))
+#else
+#define ZKW_PIN_SGPR(x) ((void)0)
+#endif
 ZD uint4& sh_reg(Shared& sh, u32 chunk, u32 lane) { return sh.regs[chunk * sh.L + lane]; }
 
 ZD u32 next_seq(Lane& s) {
@@ -138,7 +149,7 @@ ZD void emit_mem(ZKW_KP P, Shared& sh, Lane& s, u32 ts, u32 type, u32 page, u32 
   const u32 pos = stream_alloc(sh.cursor + 0);
   const u32 seq = next_seq(s);
   s.n_mem++;
-  if (pos >= P.cap_mem) {
+  if (pos >= sh.cap_mem) {
     lane_fail(s, ZKW_STATUS_LIMIT);
     return;
   }
@@ -217,76 +228,71 @@ ZD void reg_write(Shared& sh, Lane& s, u32 idx, const u256& v, bool is_ptr) {
 // ---------------------------------------------------------------------------------------------
 // memory arenas — the device-side SimpleMemory (reference_impls/memory.rs:403-528)
 // ---------------------------------------------------------------------------------------------
-ZD u64 page_word_index(ZKW_KP P, const Lane& s, u32 slot, u32 words_per_page, u32 idx) {
-  return (((u64)s.wave * P.F + slot) * words_per_page + idx) * P.L + s.lane;
+ZD u64 page_word_index(const Shared& sh, const Lane& s, u32 slot, u32 words_per_page, u32 idx) {
+  return (((u64)s.wave * sh.F + slot) * words_per_page + idx) * sh.L + s.lane;
 }
 
 // MemoryType::Stack read of the current frame (memory.rs:427-436)
-ZD u256 stack_read(ZKW_KP P, Lane& s, u32 idx, bool& is_ptr) {
+ZD u256 stack_read(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, bool& is_ptr) {
   is_ptr = false;
-  if (idx >= P.S) {
-    lane_fail(s, ZKW_STATUS_LIMIT);
-    return u256_zero();
-  }
+  // a word that was never written reads as zero in the reference (the stack page is a zero-filled Vec); only WRITES
+  // need capacity, and stack_hwm <= S
   if (idx >= s.stack_hwm) return u256_zero();
-  const u64 w = page_word_index(P, s, s.slot, P.S, idx);
-  is_ptr = P.stack_ptrs[w] != 0;
-  return u256_from_uint4(P.stack_vals[2 * w], P.stack_vals[2 * w + 1]);
+  const u64 w = page_word_index(sh, s, s.slot, sh.S, idx);
+  is_ptr = sh.stack_ptrs[w] != 0;
+  return u256_from_uint4(sh.stack_vals[2 * w], sh.stack_vals[2 * w + 1]);
 }
 // MemoryType::Stack write (memory.rs:413-425)
-ZD void stack_write(ZKW_KP P, Lane& s, u32 idx, const u256& v, bool is_ptr) {
-  if (idx >= P.S) {
+ZD void stack_write(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, const u256& v, bool is_ptr) {
+  if (idx >= sh.S) {
     lane_fail(s, ZKW_STATUS_LIMIT);
     return;
   }
   for (u32 g = s.stack_hwm; g < idx; g++) {  // lazily zero the gap
-    const u64 w = page_word_index(P, s, s.slot, P.S, g);
-    P.stack_vals[2 * w] = make_uint4(0, 0, 0, 0);
-    P.stack_vals[2 * w + 1] = make_uint4(0, 0, 0, 0);
-    P.stack_ptrs[w] = 0;
+    const u64 w = page_word_index(sh, s, s.slot, sh.S, g);
+    sh.stack_vals[2 * w] = make_uint4(0, 0, 0, 0);
+    sh.stack_vals[2 * w + 1] = make_uint4(0, 0, 0, 0);
+    sh.stack_ptrs[w] = 0;
   }
-  const u64 w = page_word_index(P, s, s.slot, P.S, idx);
-  P.stack_vals[2 * w] = u256_lo4(v);
-  P.stack_vals[2 * w + 1] = u256_hi4(v);
-  P.stack_ptrs[w] = is_ptr ? 1 : 0;
+  const u64 w = page_word_index(sh, s, s.slot, sh.S, idx);
+  sh.stack_vals[2 * w] = u256_lo4(v);
+  sh.stack_vals[2 * w + 1] = u256_hi4(v);
+  sh.stack_ptrs[w] = is_ptr ? 1 : 0;
   if (idx >= s.stack_hwm) s.stack_hwm = idx + 1;
 }
 
 // heap / aux heap of an arbitrary arena slot; `hwm` is that page's high-water mark
-ZD u256 heap_read_at(ZKW_KP P, Lane& s, bool is_aux, u32 slot, u32 hwm, u32 idx) {
-  const u32 words = is_aux ? P.A : P.H;
-  if (idx >= hwm) {
-    if (idx >= words) lane_fail(s, ZKW_STATUS_LIMIT);  // the reference would grow the page (memory.rs:464,468)
-    return u256_zero();
-  }
-  const uint4* base = is_aux ? P.aux_heap : P.heap;
-  const u64 w = page_word_index(P, s, slot, words, idx);
+ZD u256 heap_read_at(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 slot, u32 hwm, u32 idx) {
+  const u32 words = is_aux ? sh.A : sh.H;
+  if (idx >= hwm) return u256_zero();  // the reference grows its Vec on a read (memory.rs:464,468): not observable; hwm <= words
+  const uint4* base = is_aux ? sh.aux_heap : sh.heap;
+  const u64 w = page_word_index(sh, s, slot, words, idx);
   return u256_from_uint4(base[2 * w], base[2 * w + 1]);
 }
 // MemoryType::Heap / AuxHeap of the current frame (memory.rs:439-473; the page number of the query
 // is only debug_assert'ed there, i.e. ignored in release builds)
-ZD u256 heap_read_cur(ZKW_KP P, Lane& s, bool is_aux, u32 idx) {
-  return heap_read_at(P, s, is_aux, s.slot, is_aux ? s.aux_hwm : s.heap_hwm, idx);
+ZD u256 heap_read_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx) {
+  return heap_read_at(P, sh, s, is_aux, s.slot, is_aux ? s.aux_hwm : s.heap_hwm, idx);
 }
-ZD void heap_write_cur(ZKW_KP P, Lane& s, bool is_aux, u32 idx, const u256& v) {
-  const u32 words = is_aux ? P.A : P.H;
+ZD void heap_write_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx, const u256& v) {
+  const u32 words = is_aux ? sh.A : sh.H;
   if (idx >= words) {
     lane_fail(s, ZKW_STATUS_LIMIT);
     return;
   }
-  uint4* base = is_aux ? P.aux_heap : P.heap;
+  uint4* base = is_aux ? sh.aux_heap : sh.heap;
   u32 hwm = is_aux ? s.aux_hwm : s.heap_hwm;
   for (u32 g = hwm; g < idx; g++) {
-    const u64 w = page_word_index(P, s, s.slot, words, g);
+    const u64 w = page_word_index(sh, s, s.slot, words, g);
     base[2 * w] = make_uint4(0, 0, 0, 0);
     base[2 * w + 1] = make_uint4(0, 0, 0, 0);
   }
-  const u64 w = page_word_index(P, s, s.slot, words, idx);
+  const u64 w = page_word_index(sh, s, s.slot, words, idx);
   base[2 * w] = u256_lo4(v);
   base[2 * w + 1] = u256_hi4(v);
   if (!is_aux && s.slot == 0 && idx < P.heap_image_words) {
     // a word of the uploaded heap image is overwritten: remember it, the next reset restores only those words
-    u32* d = P.heap_dirty + ((u64)s.wave * ((P.heap_image_words + 31u) >> 5) + (idx >> 5)) * P.L + s.lane;
+    u32* d = P.heap_dirty + ((u64)s.wave * ((P.heap_image_words + 31u) >> 5) + (idx >> 5)) * sh.L + s.lane;
     atomicOr(d, 1u << (idx & 31u));  // result unused: a fire-and-forget atomic instead of a load + store round trip
   }
   if (idx >= hwm) hwm = idx + 1;
@@ -296,7 +302,7 @@ ZD void heap_write_cur(ZKW_KP P, Lane& s, bool is_aux, u32 idx, const u256& v) {
 // MemoryType::FatPointer read (memory.rs:475-521): resolve the page to an arena slot.
 // Page 0 is Indirection::Empty; pages that never were a heap/aux page of a frame of this
 // instance are "unreachable memory" (the reference's expect() at :478-481).
-ZD u256 fat_ptr_read(ZKW_KP P, Lane& s, u32 page, u32 idx) {
+ZD u256 fat_ptr_read(ZKW_KP P, const Shared& sh, Lane& s, u32 page, u32 idx) {
   if (page == 0) return u256_zero();
   u32 slot, kind;
   bool found = false;
@@ -330,10 +336,10 @@ ZD u256 fat_ptr_read(ZKW_KP P, Lane& s, u32 page, u32 idx) {
     const zkw_dev_frame_meta fm = P.frames[(u64)s.inst * P.F + slot];
     hwm = is_aux ? fm.aux_hwm : fm.heap_hwm;
   }
-  const u32 words = is_aux ? P.A : P.H;
+  const u32 words = is_aux ? sh.A : sh.H;
   if (idx >= hwm || idx >= words) return u256_zero();  // `.get(index).unwrap_or(zero)` (:490-495)
-  const uint4* base = is_aux ? P.aux_heap : P.heap;
-  const u64 w = page_word_index(P, s, slot, words, idx);
+  const uint4* base = is_aux ? sh.aux_heap : sh.heap;
+  const u64 w = page_word_index(sh, s, slot, words, idx);
   return u256_from_uint4(base[2 * w], base[2 * w + 1]);
 }
 
@@ -520,7 +526,7 @@ ZD Operand compute_address(ZKW_KP P, Lane& s, u32& sp, const u256& reg_value, u3
 // perform_dst0_update (helpers.rs:266-283)
 ZD void dst0_update(ZKW_KP P, Shared& sh, Lane& s, const Operand& dst0, u32 dst0_idx, const u256& v, bool is_ptr) {
   if (dst0.has_loc) {
-    stack_write(P, s, dst0.index, v, is_ptr);
+    stack_write(P, sh, s, dst0.index, v, is_ptr);
     emit_mem(P, sh, s, s.timestamp + 3, ZKW_MEM_STACK, dst0.page, dst0.index, v, is_ptr, true, 0);
   } else {
     reg_write(sh, s, dst0_idx, v, is_ptr);
@@ -793,10 +799,10 @@ ZD void op_uma(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
   const u32 ts_r = s.timestamp, ts_w = s.timestamp + 3;
   u256 w0v = u256_zero(), w1v = u256_zero();
   if (!skip) {  // :265-288
-    w0v = is_ptr_read ? fat_ptr_read(P, s, fp.page, word0) : heap_read_cur(P, s, !is_heap, word0);
+    w0v = is_ptr_read ? fat_ptr_read(P, sh, s, fp.page, word0) : heap_read_cur(P, sh, s, !is_heap, word0);
     emit_mem(P, sh, s, ts_r, mem_type, fp.page, word0, w0v, false, false, 0);
     if (unaligned) {
-      w1v = is_ptr_read ? fat_ptr_read(P, s, fp.page, word1) : heap_read_cur(P, s, !is_heap, word1);
+      w1v = is_ptr_read ? fat_ptr_read(P, sh, s, fp.page, word1) : heap_read_cur(P, sh, s, !is_heap, word1);
       emit_mem(P, sh, s, ts_r, mem_type, fp.page, word1, w1v, false, false, 0);
     }
   }
@@ -825,10 +831,10 @@ ZD void op_uma(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
     u256 n1 = u256_shr(u256_shl(w1v, unal * 8), unal * 8);
     n1 = u256_or(n1, u256_shl(ps.src1, (32 - unal) * 8));
     if (!skip) {
-      heap_write_cur(P, s, !is_heap, word0, n0);
+      heap_write_cur(P, sh, s, !is_heap, word0, n0);
       emit_mem(P, sh, s, ts_w, mem_type, fp.page, word0, n0, false, true, 0);
       if (unaligned) {
-        heap_write_cur(P, s, !is_heap, word1, n1);
+        heap_write_cur(P, sh, s, !is_heap, word1, n1);
         emit_mem(P, sh, s, ts_w, mem_type, fp.page, word1, n1, false, true, 0);
       }
     }
@@ -1347,10 +1353,10 @@ ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
 // ---------------------------------------------------------------------------------------------
 // read_and_decode exceptions (cycle.rs:142-184) and condition resolution (:193-209), branch-free
 // ---------------------------------------------------------------------------------------------
-ZD bool decode_exception(ZKW_KP P, const Lane& s, u32 attr, u32 price) {
+ZD bool decode_exception(u32 max_depth, const Lane& s, u32 attr, u32 price) {
   const u32 props = ZKW_ATTR_PROPS(attr);
   return ((props & ZKW_PROP_EXPLICIT_PANIC) != 0) | (s.ergs < price) | (((props & ZKW_PROP_KERNEL_ONLY) != 0) & (s.is_kernel == 0)) |
-         (((props & ZKW_PROP_STATIC_OK) == 0) & (s.is_static != 0)) | (s.depth == P.consts.vm_max_stack_depth);
+         (((props & ZKW_PROP_STATIC_OK) == 0) & (s.is_static != 0)) | (s.depth == max_depth);
 }
 // one bit per (condition, lt|eq<<1|gt<<2): Always, Gt, Lt, Eq, Ge, Le, Ne, GtOrLt
 ZD bool condition_resolved(u32 cond, u32 flags) {
@@ -1386,7 +1392,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d) {
   bool src0_mem_ptr = false;
   if (src0_loc.has_loc) {  // :304-325
     if (src0_loc.type == ZKW_MEM_CODE) src0_mem = code_read(P, s, src0_loc.index);
-    else src0_mem = stack_read(P, s, src0_loc.index, src0_mem_ptr);
+    else src0_mem = stack_read(P, sh, s, src0_loc.index, src0_mem_ptr);
     emit_mem(P, sh, s, s.timestamp, src0_loc.type, src0_loc.page, src0_loc.index, src0_mem, src0_mem_ptr, false, 0);
   }
   const u32 src0_mode = ZKW_ATTR_SRC0(d.attr);
@@ -1521,6 +1527,12 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   Shared sh;
   sh.L = P.L;
   sh.debug_flags = A.debug_flags;
+  sh.F = P.F; sh.S = P.S; sh.H = P.H; sh.A = P.A; sh.cap_mem = P.cap_mem;
+  sh.stack_vals = P.stack_vals; sh.stack_ptrs = P.stack_ptrs; sh.heap = P.heap; sh.aux_heap = P.aux_heap;
+  ZKW_PIN_SGPR(sh.L); ZKW_PIN_SGPR(sh.F); ZKW_PIN_SGPR(sh.S); ZKW_PIN_SGPR(sh.H); ZKW_PIN_SGPR(sh.A); ZKW_PIN_SGPR(sh.cap_mem);
+  ZKW_PIN_SGPR(sh.stack_vals); ZKW_PIN_SGPR(sh.stack_ptrs); ZKW_PIN_SGPR(sh.heap); ZKW_PIN_SGPR(sh.aux_heap);
+  u32 run_cycles = A.run_cycles, time_delta = P.consts.time_delta_per_cycle, cap_delta = P.cap_delta, max_depth = P.consts.vm_max_stack_depth;
+  ZKW_PIN_SGPR(run_cycles); ZKW_PIN_SGPR(time_delta); ZKW_PIN_SGPR(cap_delta); ZKW_PIN_SGPR(max_depth);
   sh.isa = (uint2*)zkw_lds;                                                        // 16 KB
   sh.cursor = (u32*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + wib * (1 + ZKW_REG_CHUNKS * P.L));  // 16 B
   sh.regs = (uint4*)sh.cursor + 1;                                                  // 30 * L * 16 B
@@ -1571,21 +1583,21 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
 
   // running output pointers of this wave (advanced once per cycle instead of re-derived from the parameter block)
   u32* dir_ptr = P.dir + ((u64)wave * (P.max_cycles + 1) + cycle_base) * 4;
-  uint4* tail_ptr = P.tails + ((u64)wave * P.max_cycles + cycle_base) * 2 * P.L + tid;
+  uint4* tail_ptr = P.tails + ((u64)wave * P.max_cycles + cycle_base) * 2 * sh.L + tid;
   uint4* const delta_base = P.deltas + (u64)wave * P.cap_delta * 2;
-  const u32 tail_step = 2 * P.L;
+  const u32 tail_step = 2 * sh.L;
   // The cycle loop is entered once by the lanes that are running and left per lane (divergent exit) when the lane ends,
   // fails or has used its cycles: the lane state is then modified unconditionally inside the loop body instead of inside
   // an `if (active)` region of every iteration (whose merge points cost ~75 register copies per VM cycle).
   u32 k = 0;
   uint2 next_slot = make_uint2(0, 0), next_e = make_uint2(0, 0);
   if (exists) {
-    next_slot = sh.pcw[(3u - (s.pc & 3u)) * P.L + tid];
+    next_slot = sh.pcw[(3u - (s.pc & 3u)) * sh.L + tid];
     next_e = sh.isa[next_slot.x & (ZKW_ISA_TABLE_SIZE - 1)];
   }
   if (exists && s.status == ZKW_STATUS_RUNNING) {
     for (;;) {
-      if (k >= A.run_cycles) break;
+      if (k >= run_cycles) break;
       if (s.depth == 0) {  // execution_has_ended() (mod.rs:96-98): callers stop cycling here
         s.status = ZKW_STATUS_ENDED;
         break;
@@ -1610,7 +1622,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
           const u256 word = code_read(P, s, super_pc);
           emit_mem(P, sh, s, s.timestamp, ZKW_MEM_CODE, s.code_page, super_pc, word, false, false, 0);
 #pragma unroll
-          for (int i = 0; i < 4; i++) sh.pcw[i * P.L + tid] = make_uint2(word.w[2 * i], word.w[2 * i + 1]);
+          for (int i = 0; i < 4; i++) sh.pcw[i * sh.L + tid] = make_uint2(word.w[2 * i], word.w[2 * i + 1]);
           s.prev_super_pc = super_pc;
           // integer_representaiton_from_u256: opcode k of a word is u64 limb 3-k (:86-94) — straight from the registers
           const u32 lo = sub_pc == 0 ? word.w[6] : (sub_pc == 1 ? word.w[4] : (sub_pc == 2 ? word.w[2] : word.w[0]));
@@ -1652,7 +1664,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
         const u32 u_price = (u32)__builtin_amdgcn_readlane((int)my_e.y, (int)leader);
         if (!u_charged) {  // uniform: first visit of this opcode word
           if (mine) {
-            const bool err = decode_exception(P, s, u_attr, u_price);  // :142-184
+            const bool err = decode_exception(max_depth, s, u_attr, u_price);  // :142-184
             if (s.ergs < u_price) s.ergs = 0; else s.ergs -= u_price;  // :153-161
             const bool nop = !err && !condition_resolved((u_lo >> 13) & 7u, s.flags);
             charged = true;
@@ -1679,13 +1691,13 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
       }
       // prefetch for the next cycle (used only if that cycle does not fetch a new code word): its opcode slot of the
       // current word and the ISA entry of that opcode — two chained LDS reads that complete behind the record stores
-      next_slot = sh.pcw[(3u - (s.pc & 3u)) * P.L + tid];
+      next_slot = sh.pcw[(3u - (s.pc & 3u)) * sh.L + tid];
       next_e = sh.isa[next_slot.x & (ZKW_ISA_TABLE_SIZE - 1)];
       // ----------------------------------------------------------------------------------------
       // end of cycle (cycle.rs:408-413)
       // ----------------------------------------------------------------------------------------
       if (lane_ok(s)) {
-        s.timestamp += P.consts.time_delta_per_cycle;
+        s.timestamp += time_delta;
         s.cycle_counter += 1;
         if (s.cold_dirty) {
           uint4* a = aux_alloc(P, sh, s, ZKW_AUX_COLD_STATE, 0, s.spent_pubdata, s.ergs_pp, s.tx_number);
@@ -1714,7 +1726,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
           total += cj;
         }
         const u32 base = ZKW_LDS_WORD(sh.cursor)[3];
-        const bool fits = base + total <= P.cap_delta;  // wave-uniform: either every lane's deltas fit or none are written
+        const bool fits = base + total <= cap_delta;  // wave-uniform: either every lane's deltas fit or none are written
         if (ok && !fits) lane_fail(s, ZKW_STATUS_LIMIT);
         if (ok && fits) {
           uint4* dl = delta_base;
@@ -1732,7 +1744,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
           // dirty mask: bits 0-7 in the tail's reserved byte, bits 8-14 in the top byte of the event counts
           zkw_stream_store(tail_ptr, make_uint4((s.ptr_bitmap & 0xffffu) | ((s.flags & 0xfu) << 16) | ((s.reg_dirty & 0xffu) << 24),
                                                 (s.pc & 0xffffu) | (s.sp << 16), s.ergs, s.timestamp));
-          zkw_stream_store(tail_ptr + P.L, make_uint4(s.heap_bound, s.aux_bound, (s.depth & 0xffffu) | (s.prev_super_pc << 16), cnt | ((s.reg_dirty >> 8) << 24)));
+          zkw_stream_store(tail_ptr + sh.L, make_uint4(s.heap_bound, s.aux_bound, (s.depth & 0xffffu) | (s.prev_super_pc << 16), cnt | ((s.reg_dirty >> 8) << 24)));
           s.n_cycles++;
         }
         if (fits && total) {

@@ -106,7 +106,7 @@ ZD void precompile_keccak256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
         w_cur = w_next;
         cur_idx = next_idx;
       } else {
-        w_cur = fat_ptr_read(P, s, page_r, wi0);
+        w_cur = fat_ptr_read(P, sh, s, page_r, wi0);
         emit_mem(P, sh, s, q.timestamp, ZKW_MEM_FAT_PTR, page_r, wi0, w_cur, false, false, 1);
         cur_idx = wi0;
       }
@@ -115,7 +115,7 @@ ZD void precompile_keccak256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
     if (two) {
       if (wi1 != cur_idx) {
         if (wi1 != next_idx) {
-          w_next = fat_ptr_read(P, s, page_r, wi1);
+          w_next = fat_ptr_read(P, sh, s, page_r, wi1);
           emit_mem(P, sh, s, q.timestamp, ZKW_MEM_FAT_PTR, page_r, wi1, w_next, false, false, 1);
           next_idx = wi1;
         }
@@ -151,7 +151,7 @@ ZD void precompile_keccak256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
     digest.w[7 - 2 * i] = __builtin_bswap32((u32)st[i]);
     digest.w[6 - 2 * i] = __builtin_bswap32((u32)(st[i] >> 32));
   }
-  heap_write_cur(P, s, false, out_off, digest);
+  heap_write_cur(P, sh, s, false, out_off, digest);
   emit_mem(P, sh, s, q.timestamp + 1, ZKW_MEM_HEAP, page_w, out_off, digest, false, true, 2);
 }
 
@@ -169,7 +169,7 @@ ZD void precompile_sha256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
     u32 w[16];
 #pragma unroll
     for (int half = 0; half < 2; half++) {
-      const u256 word = heap_read_cur(P, s, false, rd);
+      const u256 word = heap_read_cur(P, sh, s, false, rd);
       emit_mem(P, sh, s, q.timestamp, ZKW_MEM_HEAP, page_r, rd, word, false, false, 1);
       rd++;
 #pragma unroll
@@ -197,7 +197,7 @@ ZD void precompile_sha256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
       u256 digest;
 #pragma unroll
       for (int i = 0; i < 8; i++) digest.w[7 - i] = h[i];
-      heap_write_cur(P, s, false, out_off, digest);
+      heap_write_cur(P, sh, s, false, out_off, digest);
       emit_mem(P, sh, s, q.timestamp + 1, ZKW_MEM_HEAP, page_w, out_off, digest, false, true, 2);
     }
   }
@@ -212,13 +212,13 @@ ZD void precompile_ecrecover(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   const u32 in_word = q.key.w[0], out_off = q.key.w[2];
   const u32 page_r = q.key.w[4], page_w = q.key.w[5];
   u256 w0, w1, w2, w3;
-  w0 = heap_read_cur(P, s, false, in_word);
+  w0 = heap_read_cur(P, sh, s, false, in_word);
   emit_mem(P, sh, s, q.timestamp, ZKW_MEM_HEAP, page_r, in_word, w0, false, false, 1);
-  w1 = heap_read_cur(P, s, false, in_word + 1);
+  w1 = heap_read_cur(P, sh, s, false, in_word + 1);
   emit_mem(P, sh, s, q.timestamp, ZKW_MEM_HEAP, page_r, in_word + 1, w1, false, false, 1);
-  w2 = heap_read_cur(P, s, false, in_word + 2);
+  w2 = heap_read_cur(P, sh, s, false, in_word + 2);
   emit_mem(P, sh, s, q.timestamp, ZKW_MEM_HEAP, page_r, in_word + 2, w2, false, false, 1);
-  w3 = heap_read_cur(P, s, false, in_word + 3);
+  w3 = heap_read_cur(P, sh, s, false, in_word + 3);
   emit_mem(P, sh, s, q.timestamp, ZKW_MEM_HEAP, page_r, in_word + 3, w3, false, false, 1);
   if (!lane_ok(s)) return;
   const bool evm_order = P.consts.ecrecover_input_layout != 0;
@@ -232,8 +232,8 @@ ZD void precompile_ecrecover(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   }
   const ec_result res = zkw_ecrecover(w0, r, sg, vw.w[0]);
   const u256 marker = u256_from_u32(res.ok);
-  heap_write_cur(P, s, false, out_off, marker);
+  heap_write_cur(P, sh, s, false, out_off, marker);
   emit_mem(P, sh, s, q.timestamp + 1, ZKW_MEM_HEAP, page_w, out_off, marker, false, true, 2);
-  heap_write_cur(P, s, false, out_off + 1, res.address_word);
+  heap_write_cur(P, sh, s, false, out_off + 1, res.address_word);
   emit_mem(P, sh, s, q.timestamp + 1, ZKW_MEM_HEAP, page_w, out_off + 1, res.address_word, false, true, 2);
 }

@@ -878,3 +878,113 @@ def nested_frames(isa, outer=K.RET_OK, inner=K.RET_OK, main_panics=False, n_inst
 
 def make(cfg, isa, **kw):  # noqa: F811
     return {0: config0, 1: config1, 2: config2, 3: config3, 4: config4}[cfg](isa, **kw)
+
+
+# ----------------------------------------------------------------------------------------
+# fuzz tapes: every instance runs its own tape of random VALID encodings (any opcode variant, any operand mode,
+# condition and register numbers, small / page-sized / arbitrary immediates).  Used by the parity tests to drive the
+# rarely used paths (pointer arithmetic, context getters / setters, events / L1 messages, near calls, returns of
+# every kind, stack addressing modes, failing far calls) through the kernel and the oracle on the same inputs.
+# Precompile calls are left to cfg 3 (a random ABI would ask for up to 2^32 rounds).
+# ----------------------------------------------------------------------------------------
+def _shaped_u256(rng):
+    bits = (0, 5, 8, 13, 16, 32, 64, 128, 256)[rng.below(9)]
+    if bits == 0:
+        return 0
+    v = 0
+    for _ in range(4):
+        v = (v << 64) | rng.u64()
+    return v & ((1 << bits) - 1)
+
+
+def fuzz_workload(isa, n_instances=64, n_ops=96, seed=0xF022):
+    wl = Workload("fuzz_%x" % seed, n_instances, n_ops)
+    rng = ScalarRng(seed)
+    e = isa.table["entries"][0]
+    classes = {}
+    for idx in range(len(e)):
+        op, var = int(e["opcode"][idx]), int(e["variant"][idx])
+        if op == K.OP_LOG and var == K.LOG_PRECOMPILE:
+            continue
+        classes.setdefault(op, []).append(idx)
+    weights = {K.OP_INVALID: 1, K.OP_RET: 2, K.OP_FAR_CALL: 3, K.OP_NEAR_CALL: 4, K.OP_JUMP: 4}
+    wheel = []
+    for op, lst in sorted(classes.items()):
+        wheel += [op] * weights.get(op, 8)
+    # the cfg-2 callees, reachable through DEPLOYER[ADDR_A / ADDR_B]
+    callee_rng = ScalarRng(seed ^ 0xCA11)
+    callee_words = []
+    for which, retv in ((0, K.RET_OK), (1, K.RET_REVERT)):
+        ops = callee_program(isa, callee_rng, retv)
+        local = CALLEE_CODE_WORDS - 8
+        ops[11] = isa.enc(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=local, src1=0, dst0=13)
+        words = np.zeros((CALLEE_CODE_WORDS, 4), dtype="<u8")
+        code = K.pack_code(ops)
+        words[: len(code)] = code
+        words[local] = ret_abi(0, 64)
+        callee_words.append(words)
+    n_words = (n_ops + 3) // 4 + 8
+    regs = np.zeros((n_instances, 15, 4), dtype="<u8")
+    seg = 16  # ops per segment: ergs, near_call (handler = next segment), jump to the next segment, 12 random ops, ret.ok
+    for i in range(n_instances):
+        tape = []
+        for pc in range(n_ops):
+            base = pc - pc % seg
+            nxt = min(n_ops - 1, base + seg)
+            if pc % seg == 0:    # ergs for the segment (a panic forfeits what its frame was given)
+                tape.append(isa.enc(K.OP_ADD, src0_mode=K.MODE_IMM, imm0=20000, src1=0, dst0=15))
+                continue
+            if pc % seg == 1:    # a panic inside the segment unwinds to the next one instead of ending the instance
+                tape.append(isa.enc(K.OP_NEAR_CALL, src0=15, imm0=min(n_ops - 1, pc + 2), imm1=nxt))
+                continue
+            if pc % seg == 2:
+                tape.append(isa.enc(K.OP_JUMP, src0_mode=K.MODE_IMM, imm0=nxt))
+                continue
+            if pc % seg == seg - 1:
+                tape.append(isa.enc(K.OP_RET, variant=K.RET_OK, src0=rng.below(16)))
+                continue
+            op = wheel[rng.below(len(wheel))]
+            lst = classes[op]
+            idx = lst[rng.below(len(lst))]
+            cond = K.COND_ALWAYS if rng.below(10) < 7 else rng.below(8)
+            r = [rng.below(16) for _ in range(4)]
+            imms = []
+            for _ in range(2):
+                x = rng.below(4)
+                imms.append(rng.below(64) if x < 2 else (32 * rng.below(64) if x == 2 else rng.below(1 << 16)))
+            if op in (K.OP_JUMP, K.OP_NEAR_CALL) and rng.below(4) != 0:  # mostly forward, inside the segment
+                imms[0] = min(base + seg - 1, pc + 1 + rng.below(6))
+                imms[1] = min(base + seg - 1, pc + 1 + rng.below(12))
+            if op == K.OP_FAR_CALL and rng.below(2) == 0:
+                r[0], r[1] = 13, 14
+                imms[0] = min(n_ops - 1, pc + 1)
+            tape.append((idx & 0x7FF) | (cond << 13) | (r[0] << 16) | (r[1] << 20) | (r[2] << 24) | (r[3] << 28) | (imms[0] << 32) | (imms[1] << 48))
+        words = np.zeros((n_words, 4), dtype="<u8")
+        code = K.pack_code(tape)
+        words[: len(code)] = code
+        for k in range(len(code), n_words):  # constants for MODE_CODE operands that land behind the tape
+            words[k] = K.u256_from_int(_shaped_u256(rng))
+        wl.blobs.append(words)
+        wl.code_pages.append((i, 1, BOOTLOADER_CODE_PAGE, i))
+        for k in range(15):
+            regs[i, k] = K.u256_from_int(_shaped_u256(rng))
+        regs[i, 12] = far_call_abi(32 * rng.below(8), 32 * rng.below(8), 20000 + rng.below(1 << 20))  # r13
+        regs[i, 13] = K.u256_from_int((ADDR_A, ADDR_B)[rng.below(2)])                                 # r14
+    for which, words in enumerate(callee_words):
+        wl.blobs.append(words)
+        wl.preimages.append((versioned_code_hash(words), n_instances + which))
+    slots = np.zeros(2, dtype=K.STORAGE_SLOT)
+    for which, addr in enumerate((ADDR_A, ADDR_B)):
+        slots[which]["key"] = K.u256_from_int(addr)
+        slots[which]["value"] = wl.preimages[which][0]
+        slots[which]["address"] = K.address_bytes(0x8002)
+        slots[which]["shard_id"] = 0
+    wl.storage = [slots] * n_instances
+    # capacities that random operands cannot overrun: the whole 2^16-word stack page, and heaps as large as the ergs
+    # can pay for (growth costs one erg per byte, uma.rs:196-207)
+    ergs = 1 << 20
+    wl.states, wl.inner = initial_states(n_instances, regs, ergs=ergs)
+    wl.heaps = Xoshiro(seed ^ 0x4EA9, n_instances).words(64)
+    wl.limits.update(max_far_frames=8, max_callstack_depth=32, heap_words=(ergs + 4096) // 32 + 2, stack_words=1 << 16, aux_heap_words=(ergs + 4096) // 32 + 2,
+                     storage_slots=64, storage_journal=64)
+    return wl

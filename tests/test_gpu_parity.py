@@ -311,3 +311,28 @@ def test_keccak_precompile_odd_lengths_and_alignments(oracle, product, isa, lens
     for i in range(0, 70, 3):
         ok, why = K.traces_equal(bo.trace(i), bp.trace(i))
         assert ok, (i, why)
+
+
+@pytest.mark.parametrize("seed,lanes", [(0xF001, 64), (0xF002, 64), (0xF003, 16), (0xF004, 0)])
+def test_fuzz_tapes(oracle, product, isa, seed, lanes):
+    """Every instance runs its own tape of random valid encodings (synth.fuzz_workload): all 64 lanes of a wave diverge
+    on every cycle, and the rarely used opcode variants / operand modes / failure paths are driven through the kernel
+    and the oracle on the same inputs.  Instances that overran a capacity of the batch (ZKW_STATUS_LIMIT, a notion
+    the reference does not have) are excluded; they must stay a small minority."""
+    wl = synth.fuzz_workload(isa, n_instances=384, n_ops=96, seed=seed)
+    bo = _run(oracle, wl)
+    bp = _run(product, wl, lanes)
+    limited = compared = executed = 0
+    for i in range(wl.n_instances):
+        tp = bp.trace(i)
+        if int(tp["status"]) == K.STATUS_LIMIT:
+            limited += 1
+            continue
+        ok, why = K.traces_equal(bo.trace(i), tp)
+        assert ok, "fuzz %x instance %d (lanes=%d): %s" % (seed, i, lanes, why)
+        compared += 1
+        executed += len(tp["records"])
+    assert limited * 8 < wl.n_instances, limited
+    assert executed > 40 * compared  # the tapes survive: ~60 of 96 cycles on average
+    bo.destroy()
+    bp.destroy()
