@@ -130,6 +130,7 @@ struct Shared {
   u32 F, S, H, A, cap_mem;
   uint4 *stack_vals, *heap, *aux_heap;
   uint8_t* stack_ptrs;
+  const uint4* blob_words;
 };
 #ifdef __HIP_DEVICE_COMPILE__
 #define ZKW_PIN_SGPR(x) asm volatile("" : "+s"(x))
@@ -344,10 +345,10 @@ ZD u256 fat_ptr_read(ZKW_KP P, const Shared& sh, Lane& s, u32 page, u32 idx) {
 }
 
 // read_code_query (memory.rs:556-569) against the blob backing the current code page
-ZD u256 code_read(ZKW_KP P, const Lane& s, u32 idx) {
+ZD u256 code_read(const Shared& sh, const Lane& s, u32 idx) {
   if (idx >= s.code_len) return u256_zero();
   const u64 w = (u64)s.code_off + idx;
-  return u256_from_uint4(P.blob_words[2 * w], P.blob_words[2 * w + 1]);
+  return u256_from_uint4(sh.blob_words[2 * w], sh.blob_words[2 * w + 1]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -415,7 +416,11 @@ ZD u32 storage_find(ZKW_KP P, Lane& s, u32 shard, const u32 addr[5], const u256&
   zkw_dev_storage_entry* tab = P.storage + (u64)s.inst * P.storage_slots;
   for (u32 probe = 0; probe < P.storage_slots; probe++, i = (i + 1) & mask) {
     zkw_dev_storage_entry* e = tab + i;
-    const u32 st = e->shard_state;
+    // key (2 x 16 B) and address + state (2 x 16 B) in four wide loads issued together: a short-circuit compare of
+    // 14 separately loaded dwords is 14 dependent memory round trips
+    const uint4* e4 = (const uint4*)e;
+    const uint4 k0 = e4[0], k1 = e4[1], a0 = e4[4], a1 = e4[5];
+    const u32 st = a1.y;
     if (!(st & 0x100u)) {  // free: claim
 #pragma unroll
       for (int k = 0; k < 8; k++) {
@@ -427,11 +432,10 @@ ZD u32 storage_find(ZKW_KP P, Lane& s, u32 shard, const u32 addr[5], const u256&
       e->shard_state = shard | 0x100u;
       return i;
     }
-    bool same = (st & 0xffu) == shard;
-#pragma unroll
-    for (int k = 0; k < 8; k++) same = same && e->key[k] == key.w[k];
-#pragma unroll
-    for (int k = 0; k < 5; k++) same = same && e->address[k] == addr[k];
+    const u32 diff = ((st & 0xffu) ^ shard) | (k0.x ^ key.w[0]) | (k0.y ^ key.w[1]) | (k0.z ^ key.w[2]) | (k0.w ^ key.w[3]) | (k1.x ^ key.w[4]) |
+                     (k1.y ^ key.w[5]) | (k1.z ^ key.w[6]) | (k1.w ^ key.w[7]) | (a0.x ^ addr[0]) | (a0.y ^ addr[1]) | (a0.z ^ addr[2]) | (a0.w ^ addr[3]) |
+                     (a1.x ^ addr[4]);
+    const bool same = diff == 0;
     if (same) return i;
   }
   lane_fail(s, ZKW_STATUS_LIMIT);
@@ -1094,10 +1098,11 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
   } else {  // :441-455 decommit (helpers.rs:164-194 + SimpleDecommitter decommitter.rs:32-98)
     u32 pre = 0xffffffffu;
     for (u32 i = 0; i < P.n_preimages; i++) {
-      bool same = true;
-#pragma unroll
-      for (int k = 0; k < 8; k++) same = same && P.preimages[i].hash[k] == code_hash.w[k];
-      if (same) pre = i;
+      const uint4* h4 = (const uint4*)P.preimages[i].hash;  // two wide loads, not eight dependent dword round trips
+      const uint4 h0 = h4[0], h1 = h4[1];
+      const u32 diff = (h0.x ^ code_hash.w[0]) | (h0.y ^ code_hash.w[1]) | (h0.z ^ code_hash.w[2]) | (h0.w ^ code_hash.w[3]) | (h1.x ^ code_hash.w[4]) |
+                       (h1.y ^ code_hash.w[5]) | (h1.z ^ code_hash.w[6]) | (h1.w ^ code_hash.w[7]);
+      if (diff == 0) pre = i;
     }
     zkw_dev_history* hist = P.history + (u64)s.inst * P.F;
     bool fresh = true;
@@ -1391,7 +1396,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d) {
   u256 src0_mem = u256_zero();
   bool src0_mem_ptr = false;
   if (src0_loc.has_loc) {  // :304-325
-    if (src0_loc.type == ZKW_MEM_CODE) src0_mem = code_read(P, s, src0_loc.index);
+    if (src0_loc.type == ZKW_MEM_CODE) src0_mem = code_read(sh, s, src0_loc.index);
     else src0_mem = stack_read(P, sh, s, src0_loc.index, src0_mem_ptr);
     emit_mem(P, sh, s, s.timestamp, src0_loc.type, src0_loc.page, src0_loc.index, src0_mem, src0_mem_ptr, false, 0);
   }
@@ -1528,9 +1533,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   sh.L = P.L;
   sh.debug_flags = A.debug_flags;
   sh.F = P.F; sh.S = P.S; sh.H = P.H; sh.A = P.A; sh.cap_mem = P.cap_mem;
-  sh.stack_vals = P.stack_vals; sh.stack_ptrs = P.stack_ptrs; sh.heap = P.heap; sh.aux_heap = P.aux_heap;
+  sh.stack_vals = P.stack_vals; sh.stack_ptrs = P.stack_ptrs; sh.heap = P.heap; sh.aux_heap = P.aux_heap; sh.blob_words = P.blob_words;
   ZKW_PIN_SGPR(sh.L); ZKW_PIN_SGPR(sh.F); ZKW_PIN_SGPR(sh.S); ZKW_PIN_SGPR(sh.H); ZKW_PIN_SGPR(sh.A); ZKW_PIN_SGPR(sh.cap_mem);
-  ZKW_PIN_SGPR(sh.stack_vals); ZKW_PIN_SGPR(sh.stack_ptrs); ZKW_PIN_SGPR(sh.heap); ZKW_PIN_SGPR(sh.aux_heap);
+  ZKW_PIN_SGPR(sh.stack_vals); ZKW_PIN_SGPR(sh.stack_ptrs); ZKW_PIN_SGPR(sh.heap); ZKW_PIN_SGPR(sh.aux_heap); ZKW_PIN_SGPR(sh.blob_words);
   u32 run_cycles = A.run_cycles, time_delta = P.consts.time_delta_per_cycle, cap_delta = P.cap_delta, max_depth = P.consts.vm_max_stack_depth;
   ZKW_PIN_SGPR(run_cycles); ZKW_PIN_SGPR(time_delta); ZKW_PIN_SGPR(cap_delta); ZKW_PIN_SGPR(max_depth);
   sh.isa = (uint2*)zkw_lds;                                                        // 16 KB
@@ -1619,7 +1624,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
       uint2 my_e;  // this lane's packed ISA entry (prefetched at the end of the previous cycle when no fetch is due)
       if (!pending) {
         if (s.code_page != s.prev_code_page || s.prev_super_pc != super_pc) {  // :59-95
-          const u256 word = code_read(P, s, super_pc);
+          const u256 word = code_read(sh, s, super_pc);
           emit_mem(P, sh, s, s.timestamp, ZKW_MEM_CODE, s.code_page, super_pc, word, false, false, 0);
 #pragma unroll
           for (int i = 0; i < 4; i++) sh.pcw[i * sh.L + tid] = make_uint2(word.w[2 * i], word.w[2 * i + 1]);
