@@ -1521,6 +1521,36 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d) {
 // =============================================================================================
 // the cycle kernel
 // =============================================================================================
+// Per-lane state write-back (a later run continues from it / the host reads the final state).  Called by a lane at the
+// moment it LEAVES the cycle loop, from inside the loop: nothing of the lane state is then live after the loop, so the
+// compiler does not have to keep a per-iteration copy of ~30 registers for the lanes that have already left
+// (a loop with divergent exits preserves every live-out value of the exited lanes on each iteration).
+ZD void lane_writeback(ZKW_KP P, Shared& sh, Lane& s) {
+  const u32 tid = s.lane;
+  if (s.status == ZKW_STATUS_RUNNING && s.depth == 0) s.status = ZKW_STATUS_ENDED;  // execution_has_ended() (mod.rs:96-98)
+  frame_writeback(P, s);
+  hwm_writeback(P, s);
+  zkw_dev_scalars sc;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint2 v = sh.pcw[i * sh.L + tid];
+    sc.prev_code_word[2 * i] = v.x;
+    sc.prev_code_word[2 * i + 1] = v.y;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) sc.ctx_u128_reg[i] = s.ctx_reg[i];
+  sc.ptr_bitmap = s.ptr_bitmap; sc.flags = s.flags; sc.prev_code_page = s.prev_code_page; sc.timestamp = s.timestamp;
+  sc.cycle_counter = s.cycle_counter; sc.spent_pubdata = s.spent_pubdata; sc.memory_page_counter = s.mpc;
+  sc.absolute_execution_step = P.scalars[s.inst].absolute_execution_step; sc.ergs_per_pubdata = s.ergs_pp; sc.tx_number = s.tx_number;
+  sc.prev_super_pc = s.prev_super_pc; sc.depth = s.depth; sc.status = s.status; sc.n_cycles = s.n_cycles; sc.first_dynamic_page = s.first_dyn;
+  sc.n_initial_slots = s.n_initial_slots; sc.next_slot = s.next_slot; sc.journal_len = s.journal_len; sc.n_history = s.n_history;
+  sc.reserved[0] = 0;
+  P.scalars[s.inst] = sc;
+  uint4* rg = P.regs + (u64)s.wave * ZKW_REG_CHUNKS * sh.L;
+#pragma unroll 6
+  for (int c = 0; c < ZKW_REG_CHUNKS; c++) rg[(u64)c * sh.L + tid] = sh_reg(sh, c, tid);
+}
+
 __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kernel(zkw_launch_args A) {
   extern __shared__ uint4 zkw_lds[];
   ZKW_KP P = *(const zkw_kparams ZKW_CONST_AS*)A.kp[blockIdx.y];
@@ -1600,13 +1630,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
     next_slot = sh.pcw[(3u - (s.pc & 3u)) * sh.L + tid];
     next_e = sh.isa[next_slot.x & (ZKW_ISA_TABLE_SIZE - 1)];
   }
-  if (exists && s.status == ZKW_STATUS_RUNNING) {
+  if (exists && !(s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0)) lane_writeback(P, sh, s);  // does not cycle
+  if (exists && s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0) {
     for (;;) {
-      if (k >= run_cycles) break;
-      if (s.depth == 0) {  // execution_has_ended() (mod.rs:96-98): callers stop cycling here
-        s.status = ZKW_STATUS_ENDED;
-        break;
-      }
       {  // directory: stream cursors at the start of wave-cycle (cycle_base + k), written by the first remaining lane
         const u64 in_loop = __ballot(1);
         if (tid == (u32)__ffsll((long long)in_loop) - 1u) {
@@ -1761,7 +1787,11 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
       k++;
       dir_ptr += 4;
       tail_ptr += tail_step;
-      if (!lane_ok(s)) break;
+      // leave: failed / out of cycles / execution_has_ended() (mod.rs:96-98: callers stop cycling at depth 0)
+      if (!lane_ok(s) || k >= run_cycles || s.depth == 0) {
+        lane_writeback(P, sh, s);
+        break;
+      }
     }
   }
   // wave-cycles executed = the maximum over the lanes (lanes leave the loop at different iterations)
@@ -1778,31 +1808,6 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
     P.cursors[wave * 4 + i] = cur;
   }
   if (tid == 0) P.wave_cycles[wave] = cycle_base + k;
-  if (exists) {
-    if (s.status == ZKW_STATUS_RUNNING && s.depth == 0) s.status = ZKW_STATUS_ENDED;
-    // state write-back so that a later run continues / the host can read the final state
-    frame_writeback(P, s);
-    hwm_writeback(P, s);
-    zkw_dev_scalars sc;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const uint2 v = sh.pcw[i * P.L + tid];
-      sc.prev_code_word[2 * i] = v.x;
-      sc.prev_code_word[2 * i + 1] = v.y;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) sc.ctx_u128_reg[i] = s.ctx_reg[i];
-    sc.ptr_bitmap = s.ptr_bitmap; sc.flags = s.flags; sc.prev_code_page = s.prev_code_page; sc.timestamp = s.timestamp;
-    sc.cycle_counter = s.cycle_counter; sc.spent_pubdata = s.spent_pubdata; sc.memory_page_counter = s.mpc;
-    sc.absolute_execution_step = P.scalars[inst].absolute_execution_step; sc.ergs_per_pubdata = s.ergs_pp; sc.tx_number = s.tx_number;
-    sc.prev_super_pc = s.prev_super_pc; sc.depth = s.depth; sc.status = s.status; sc.n_cycles = s.n_cycles; sc.first_dynamic_page = s.first_dyn;
-    sc.n_initial_slots = s.n_initial_slots; sc.next_slot = s.next_slot; sc.journal_len = s.journal_len; sc.n_history = s.n_history;
-    sc.reserved[0] = 0;
-    P.scalars[inst] = sc;
-    uint4* rg = P.regs + (u64)wave * ZKW_REG_CHUNKS * P.L;
-#pragma unroll 6
-    for (int c = 0; c < ZKW_REG_CHUNKS; c++) rg[(u64)c * P.L + tid] = sh_reg(sh, c, tid);
-  }
 }
 
 // working state := pristine images (register file, scalars, callstack, frame meta, storage table, heap
