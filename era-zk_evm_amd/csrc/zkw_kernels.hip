@@ -78,6 +78,16 @@ ZD bool lane_ok(const Lane& s) { return s.status == ZKW_STATUS_RUNNING; }
 #else
 #define ZKW_LDS_WORD(p) ((volatile u32*)(p))
 #endif
+// the four stream cursors of a wave in one volatile 16-byte LDS read
+#ifdef __HIP_DEVICE_COMPILE__
+ZD uint4 zkw_lds_read4(const u32* p) {
+  typedef unsigned int zkw_lds_v4 __attribute__((ext_vector_type(4)));
+  const zkw_lds_v4 v = *(volatile zkw_lds_v4 __attribute__((address_space(3)))*)(p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+#else
+ZD uint4 zkw_lds_read4(const u32* p) { return make_uint4(ZKW_LDS_WORD(p)[0], ZKW_LDS_WORD(p)[1], ZKW_LDS_WORD(p)[2], ZKW_LDS_WORD(p)[3]); }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // wave-level stream compaction: every lane that reaches this point (possibly under divergence)
@@ -741,7 +751,14 @@ ZD void op_ptr(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
 }
 
 // uma.rs:26-425
+#ifdef ZKW_PROFILE
+__shared__ unsigned long long zp_mark[12];  // [0] last stamp, [1..] accumulated clocks between the marks of op_uma (wave 0 of the workgroup)
+#define ZKW_MARK(i) { if (threadIdx.x < 64u && threadIdx.x == (u32)__ffsll((long long)__ballot(1)) - 1u) { const unsigned long long zp_n = __builtin_readcyclecounter(); if (i) zp_mark[i] += zp_n - zp_mark[0]; zp_mark[0] = zp_n; } }
+#else
+#define ZKW_MARK(i)
+#endif
 ZD void op_uma(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+  ZKW_MARK(0)
   const u32 v = ZKW_ATTR_VARIANT(d.attr);
   s.pc = ps.new_pc;
   const bool increment = ZKW_ATTR_FLAGS(d.attr) & 1u;
@@ -802,14 +819,16 @@ ZD void op_uma(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
   const bool unaligned = unal != 0;
   const u32 ts_r = s.timestamp, ts_w = s.timestamp + 3;
   u256 w0v = u256_zero(), w1v = u256_zero();
+  ZKW_MARK(1)  // exceptions, growth
   if (!skip) {  // :265-288
+    // both word loads are issued before the first query is emitted: the emission needs the loaded value, so reading
+    // and emitting word by word would serialise two memory round trips (the dominant cost of this opcode)
     w0v = is_ptr_read ? fat_ptr_read(P, sh, s, fp.page, word0) : heap_read_cur(P, sh, s, !is_heap, word0);
+    if (unaligned) w1v = is_ptr_read ? fat_ptr_read(P, sh, s, fp.page, word1) : heap_read_cur(P, sh, s, !is_heap, word1);
     emit_mem(P, sh, s, ts_r, mem_type, fp.page, word0, w0v, false, false, 0);
-    if (unaligned) {
-      w1v = is_ptr_read ? fat_ptr_read(P, sh, s, fp.page, word1) : heap_read_cur(P, sh, s, !is_heap, word1);
-      emit_mem(P, sh, s, ts_r, mem_type, fp.page, word1, w1v, false, false, 0);
-    }
+    if (unaligned) emit_mem(P, sh, s, ts_r, mem_type, fp.page, word1, w1v, false, false, 0);
   }
+  ZKW_MARK(2)  // word reads + read queries
   if (!is_write) {  // :291-348
     u256 result = u256_or(u256_shl(w0v, unal * 8), u256_shr(w1v, (32 - unal) * 8));
     if (is_ptr_read) {
@@ -818,6 +837,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
       beyond &= 31u;
       result = u256_shl(u256_shr(result, beyond * 8), beyond * 8);
     }
+    ZKW_MARK(3)  // read: shifts
     if (!set_panic) {
       dst0_update(P, sh, s, ps.dst0, d.dst0, result, false);
       if (increment) {
@@ -834,6 +854,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
     n0 = u256_or(n0, u256_shr(ps.src1, unal * 8));
     u256 n1 = u256_shr(u256_shl(w1v, unal * 8), unal * 8);
     n1 = u256_or(n1, u256_shl(ps.src1, (32 - unal) * 8));
+    ZKW_MARK(4)  // write: shifts
     if (!skip) {
       heap_write_cur(P, sh, s, !is_heap, word0, n0);
       emit_mem(P, sh, s, ts_w, mem_type, fp.page, word0, n0, false, true, 0);
@@ -842,6 +863,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
         emit_mem(P, sh, s, ts_w, mem_type, fp.page, word1, n1, false, true, 0);
       }
     }
+    ZKW_MARK(5)  // write: heap writes + write queries
     if (!set_panic) {
       if (increment) {
         u256 upd = ps.src0;
@@ -852,6 +874,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
       s.flags |= FLAG_PENDING;
     }
   }
+  ZKW_MARK(6)  // destination updates
 }
 
 // log.rs:11-330 (precompile calls: see zkw_precompiles below)
@@ -1625,6 +1648,16 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   // fails or has used its cycles: the lane state is then modified unconditionally inside the loop body instead of inside
   // an `if (active)` region of every iteration (whose merge points cost ~75 register copies per VM cycle).
   u32 k = 0;
+  u32 delta_cur = ZKW_LDS_WORD(sh.cursor)[3];
+#ifdef ZKW_PROFILE  // profiling build only (profiles/tools/phase_profile.sh): shader-clock time of the phases of a VM cycle
+  unsigned long long zp_t[6] = {0, 0, 0, 0, 0, 0}, zp_last = 0;
+  __shared__ unsigned long long zp_op[ZKW_WAVES_PER_GROUP][16][2];  // per opcode: clocks, group iterations
+  for (u32 i = tid; i < 32; i += P.wave_threads) (&zp_op[wib][0][0])[i] = 0;
+  if (threadIdx.x < 12) zp_mark[threadIdx.x] = 0;
+#define ZKW_PHASE(i) { const unsigned long long zp_now = __builtin_readcyclecounter(); zp_t[i] += zp_now - zp_last; zp_last = zp_now; }
+#else
+#define ZKW_PHASE(i)
+#endif
   uint2 next_slot = make_uint2(0, 0), next_e = make_uint2(0, 0);
   if (exists) {
     next_slot = sh.pcw[(3u - (s.pc & 3u)) * sh.L + tid];
@@ -1632,14 +1665,15 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   }
   if (exists && !(s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0)) lane_writeback(P, sh, s);  // does not cycle
   if (exists && s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0) {
+#ifdef ZKW_PROFILE
+    zp_last = __builtin_readcyclecounter();
+#endif
     for (;;) {
-      {  // directory: stream cursors at the start of wave-cycle (cycle_base + k), written by the first remaining lane
-        const u64 in_loop = __ballot(1);
-        if (tid == (u32)__ffsll((long long)in_loop) - 1u) {
-#pragma unroll
-          for (int i = 0; i < 4; i++) dir_ptr[i] = ZKW_LDS_WORD(sh.cursor)[i];
-        }
-      }
+      // directory: stream cursors at the start of wave-cycle (cycle_base + k).  Read here (one broadcast 16-B LDS read),
+      // stored by the first remaining lane after the fetch below, so that the LDS latency hides behind it.  The
+      // register-delta cursor is carried in a register: only the end of the cycle advances it.
+      uint4 dir_entry = zkw_lds_read4(sh.cursor);
+      dir_entry.w = delta_cur;
       s.seq = 0; s.n_mem = 0; s.n_log = 0; s.n_aux = 0; s.cold_dirty = 0; s.reg_dirty = 0;
       // ----------------------------------------------------------------------------------------
       // read_and_decode (cycle.rs:19-236)
@@ -1671,6 +1705,10 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
         my_e = sh.isa[(u32)enc & (ZKW_ISA_TABLE_SIZE - 1)];
       }
       s.prev_code_page = s.code_page;  // :49
+      {
+        const u64 in_loop = __ballot(1);
+        if (tid == (u32)__ffsll((long long)in_loop) - 1u) *(uint4*)dir_ptr = dir_entry;
+      }
       // ----------------------------------------------------------------------------------------
       // decode + execute, grouped by instruction word: take the first lane that has
       // not been served, broadcast its opcode word (readlane -> SGPRs), ballot the lanes holding the
@@ -1679,6 +1717,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
       // Lanes whose decode raises an exception (masked into panic, cycle.rs:187-190) or whose condition
       // fails (masked into nop, :212-217) are served by extra passes with the panic / nop variant.
       // ----------------------------------------------------------------------------------------
+      ZKW_PHASE(0)  // fetch + directory
       u32 enc_lo = (u32)enc, enc_hi = (u32)(enc >> 32);
       bool charged = false;  // price taken and exceptions / condition resolved for this lane (once per cycle)
       u64 todo = __ballot(1);
@@ -1711,6 +1750,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
           }
         }
         todo &= ~__ballot(mine);
+#ifdef ZKW_PROFILE
+        const unsigned long long zp_g0 = __builtin_readcyclecounter();
+#endif
         if (mine) {
           Decoded d;
           d.attr = u_attr;
@@ -1719,7 +1761,14 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
           if (A.debug_flags & 8u) s.pc = (s.pc + 1u) & 0xffffu;  // profiling ablation: no operand / opcode work
           else exec_decoded(P, sh, s, d);
         }
+#ifdef ZKW_PROFILE
+        if (tid == (u32)__ffsll((long long)__ballot(1)) - 1u) {
+          zp_op[wib][ZKW_ATTR_OPCODE(u_attr) & 15u][0] += __builtin_readcyclecounter() - zp_g0;
+          zp_op[wib][ZKW_ATTR_OPCODE(u_attr) & 15u][1] += 1;
+        }
+#endif
       }
+      ZKW_PHASE(1)  // group loop: decode, operands, opcode body, destination writes
       // prefetch for the next cycle (used only if that cycle does not fetch a new code word): its opcode slot of the
       // current word and the ISA entry of that opcode — two chained LDS reads that complete behind the record stores
       next_slot = sh.pcw[(3u - (s.pc & 3u)) * sh.L + tid];
@@ -1740,6 +1789,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
           }
         }
       }
+      ZKW_PHASE(2)  // prefetch + end-of-cycle bookkeeping
       if (lane_ok(s) && (A.debug_flags & 1u)) s.n_cycles++;
       if (!(A.debug_flags & 1u)) {
         // CycleRecord, delta form: the 512-byte snapshot the tracer observes (15 registers + 32-byte tail) is emitted as
@@ -1756,7 +1806,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
           if (cj == 0) break;
           total += cj;
         }
-        const u32 base = ZKW_LDS_WORD(sh.cursor)[3];
+        const u32 base = delta_cur;
         const bool fits = base + total <= cap_delta;  // wave-uniform: either every lane's deltas fit or none are written
         if (ok && !fits) lane_fail(s, ZKW_STATUS_LIMIT);
         if (ok && fits) {
@@ -1779,11 +1829,13 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
           s.n_cycles++;
         }
         if (fits && total) {
-          zkw_wave_lds_fence();
-          if (__ballot(true) != 0 && tid == (u32)__ffsll((long long)__ballot(true)) - 1u) ZKW_LDS_WORD(sh.cursor)[3] = base + total;
-          zkw_wave_lds_fence();
+          // `total` is the same for every lane still in the loop (ballots over exactly those lanes); the LDS copy is
+          // only read after the loop (final directory entry), and a wave's LDS operations complete in order
+          delta_cur = base + total;
+          if (tid == (u32)__ffsll((long long)__ballot(true)) - 1u) ZKW_LDS_WORD(sh.cursor)[3] = delta_cur;
         }
       }
+      ZKW_PHASE(3)  // CycleRecord: delta ranks, delta + tail stores
       k++;
       dir_ptr += 4;
       tail_ptr += tail_step;
@@ -1794,6 +1846,14 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
       }
     }
   }
+#ifdef ZKW_PROFILE
+  if (blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0)
+    printf("ZKW_PROFILE wave-cycles %u: fetch %llu group %llu eoc %llu record %llu (shader clocks)\n", k, zp_t[0], zp_t[1], zp_t[2], zp_t[3]);
+  if (blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0)
+    printf("ZKW_PROFILE uma marks: pre %llu reads %llu rd-shift %llu wr-shift %llu writes %llu dst %llu\n", zp_mark[1], zp_mark[2], zp_mark[3], zp_mark[4], zp_mark[5], zp_mark[6]);
+  if (blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x < 16 && zp_op[0][threadIdx.x][1])
+    printf("ZKW_PROFILE opcode %u: %llu group iterations, %llu clocks each\n", threadIdx.x, zp_op[0][threadIdx.x][1], zp_op[0][threadIdx.x][0] / zp_op[0][threadIdx.x][1]);
+#endif
   // wave-cycles executed = the maximum over the lanes (lanes leave the loop at different iterations)
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
