@@ -217,7 +217,9 @@ typedef struct zkw_storage_slot {
   uint8_t reserved0[3];
 } zkw_storage_slot; /* 88 bytes */
 
-/* capacities of one batch; every per-instance arena is sized from these */
+/* capacities of one batch; every per-instance arena is sized from these.  An instance that WRITES beyond a capacity
+ * (or emits more records than a stream holds) stops with ZKW_STATUS_LIMIT; reading a stack / heap word that was never
+ * written is not an overrun — it reads zero, as in the reference's zero-filled pages (memory.rs:427-473). */
 typedef struct zkw_limits {
   uint32_t max_cycles;            /* cycles recorded per instance and per run                      */
   uint32_t max_far_frames;        /* far-call frames (incl. the bootloader frame) opened per run   */
@@ -228,7 +230,7 @@ typedef struct zkw_limits {
   uint32_t storage_slots;         /* distinct (shard,address,key) per instance, power of two        */
   uint32_t storage_journal;       /* storage writes per instance and per run                        */
   uint32_t max_mem_queries;       /* MemoryQuery records per instance and per run; 0 = 6*max_cycles */
-  uint32_t max_log_queries;       /* LogQuery records per instance and per run; 0 = 2*max_cycles    */
+  uint32_t max_log_queries;       /* LogQuery records per instance and per run; 0 = max_cycles/2+16 */
   uint32_t max_aux_events;        /* aux events per instance and per run; 0 = derived               */
   uint32_t lanes_per_wave;        /* 0 = let the library choose (1..64, power of two)               */
   uint32_t max_reg_deltas;        /* register writes recorded per instance and per run; 0 = 2*max_cycles + 32 */
