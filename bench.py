@@ -28,8 +28,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--instances", type=int, default=4096, help="VM instances per GPU (weak scaling)")
     ap.add_argument("--cycles", type=int, default=256)
-    ap.add_argument("--lanes", type=int, default=0, help="lanes per wave (0 = library default)")
-    ap.add_argument("--fuse", type=int, default=32, help="batches (steps) per fused launch (zkw_batches_step), <= 32")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per wave (0 = full waves for fused launches, the library default for --fuse 1)")
+    ap.add_argument("--fuse", type=int, default=128, help="batches (steps) per fused launch (zkw_batches_step), <= 256 (ZKW_MAX_FUSED)")
     ap.add_argument("--streams", type=int, default=0, help="fused groups in flight (1 = everything on one stream; >= 2 = restore + cycle kernels on the main stream, commitments and the digest exchange on side streams; 0 = 1 on a single GPU, 2 when there is a digest all-gather to hide)")
     ap.add_argument("--side", choices=["commit", "commit+reset"], default="commit", help="what the side streams carry when --streams >= 2")
     ap.add_argument("--force-collective", action="store_true", help="run the digest all-gather even with one rank (exercises the multi-GPU code path on a single GPU)")
@@ -69,13 +69,15 @@ def main():
         wl.blobs[0] = K.pack_code(ops)
     else:
         wl = synth.make(args.cfg, isa, n_instances=args.instances, n_cycles=args.cycles, seed=0x5EED0000 + args.cfg + 0x100 * rank)
-    wl.limits["lanes_per_wave"] = args.lanes
+    # full waves when several batches share a launch: the library's default thins the waves of a SMALL batch so that a
+    # lone launch of it reaches more CUs, which only multiplies the waves of a fused launch (256 x 4096: 0.8 -> 2.9 G cycles/s)
+    wl.limits["lanes_per_wave"] = args.lanes if args.lanes or args.fuse <= 1 else 64
     # A 4096-instance batch is 64 waves and every instance is a sequential chain of cycles, so ONE batch cannot fill
     # 256 CUs (the cycle kernel is latency-bound per wave) and the hardware overlaps only ~4 kernels of different
     # streams.  The K steps (one step = one 1M-cycle batch, every cycle of it executed and witnessed) are therefore
     # issued `--fuse` batches per launch through zkw_batches_step (one reset launch, one cycle-kernel launch, one set
     # of commitment launches; grid.y = batch) and `--streams` such groups are in flight on separate HIP streams.
-    fuse = max(1, min(args.fuse, 32, args.steps))
+    fuse = max(1, min(args.fuse, 256, args.steps))
     n_groups = max(1, min(args.streams, (args.steps + fuse - 1) // fuse))
     groups = [[prod.create_batch(wl) for _ in range(fuse)] for _ in range(n_groups)]
     # the main stream (cycle kernels) gets the higher queue priority, the side streams fill in behind it

@@ -103,7 +103,7 @@ typedef struct zkw_dev_history {
 #else
 #define ZKW_CONST_AS
 #endif
-#define ZKW_MAX_FUSED 32 /* batches per fused launch */
+#define ZKW_MAX_FUSED 256 /* batches per fused launch (the by-value tables stay under the 4 KB kernel-argument segment) */
 
 /* kernel parameter block */
 typedef struct zkw_kparams {

@@ -440,7 +440,7 @@ int zkw_batch_run(zkw_batch* batch, uint32_t max_cycles, void* hip_stream);
  * The first call runs eagerly and captures the sequence into a hipGraph; later calls with the same arguments replay
  * it with a single launch (the launch-bound regime of small batches). */
 int zkw_batch_step(zkw_batch* batch, uint32_t max_cycles, uint32_t queue_mask, void* hip_stream);
-/* The same step for up to 32 (ZKW_MAX_FUSED) uploaded batches of one context with FUSED launches: one reset launch,
+/* The same step for up to 256 (ZKW_MAX_FUSED) uploaded batches of one context with FUSED launches: one reset launch,
  * one cycle-kernel launch and one set of commitment launches cover all of them (one batch per grid row).  A cycle
  * kernel launch of a small batch cannot fill the GPU (one wave per 64 instances, latency-bound), and the hardware
  * runs only a few kernels of different streams concurrently, so independent small batches are stepped together.

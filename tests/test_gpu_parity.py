@@ -336,3 +336,9 @@ def test_fuzz_tapes(oracle, product, isa, seed, lanes):
     assert executed > 40 * compared  # the tapes survive: ~60 of 96 cycles on average
     bo.destroy()
     bp.destroy()
+
+
+def test_cfg2_long_traces(oracle, product, isa):
+    """The second shape of cfg 2: 256 instances x 4096 cycles, full waves — every record of every instance."""
+    wl = synth.make(2, isa, n_instances=256, n_cycles=4096)
+    _compare(oracle, product, wl, 64)
