@@ -1576,6 +1576,9 @@ ZD void lane_writeback(ZKW_KP P, Shared& sh, Lane& s) {
 
 __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kernel(zkw_launch_args A) {
   extern __shared__ uint4 zkw_lds[];
+#ifdef ZKW_PROFILE
+  const unsigned long long zp_k0 = __builtin_readcyclecounter();
+#endif
   ZKW_KP P = *(const zkw_kparams ZKW_CONST_AS*)A.kp[blockIdx.y];
   // one wave = one independent group of L VM instances; ZKW_WAVES_PER_GROUP waves per workgroup (one per SIMD)
   // share the ISA table so that four of them fit the 160 KB of a CU
@@ -1667,6 +1670,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   if (exists && s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0) {
 #ifdef ZKW_PROFILE
     zp_last = __builtin_readcyclecounter();
+    zp_t[4] = zp_last - zp_k0;  // prologue: ISA table staging, state load
 #endif
     for (;;) {
       // directory: stream cursors at the start of wave-cycle (cycle_base + k).  Read here (one broadcast 16-B LDS read),
@@ -1841,14 +1845,20 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
       tail_ptr += tail_step;
       // leave: failed / out of cycles / execution_has_ended() (mod.rs:96-98: callers stop cycling at depth 0)
       if (!lane_ok(s) || k >= run_cycles || s.depth == 0) {
+#ifdef ZKW_PROFILE
+        zp_last = __builtin_readcyclecounter();
+#endif
         lane_writeback(P, sh, s);
+#ifdef ZKW_PROFILE
+        zp_t[5] = __builtin_readcyclecounter() - zp_last;  // state write-back
+#endif
         break;
       }
     }
   }
 #ifdef ZKW_PROFILE
   if (blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0)
-    printf("ZKW_PROFILE wave-cycles %u: fetch %llu group %llu eoc %llu record %llu (shader clocks)\n", k, zp_t[0], zp_t[1], zp_t[2], zp_t[3]);
+    printf("ZKW_PROFILE wave-cycles %u: fetch %llu group %llu eoc %llu record %llu; prologue %llu write-back %llu (shader clocks)\n", k, zp_t[0], zp_t[1], zp_t[2], zp_t[3], zp_t[4], zp_t[5]);
   if (blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0)
     printf("ZKW_PROFILE uma marks: pre %llu reads %llu rd-shift %llu wr-shift %llu writes %llu dst %llu\n", zp_mark[1], zp_mark[2], zp_mark[3], zp_mark[4], zp_mark[5], zp_mark[6]);
   if (blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x < 16 && zp_op[0][threadIdx.x][1])
