@@ -144,7 +144,7 @@ typedef struct zkw_kparams {
   const zkw_dev_preimage* preimages; /* [n_preimages]                    */
   /* outputs */
   uint4* tails;                /* [n_waves][max_cycles][2][L]: the 32-B record tail of every executed cycle (+ dirty-register mask) */
-  uint4* deltas;               /* [n_waves][cap_delta][2]: 32-B values of the registers a cycle wrote, dense per wave               */
+  uint4* deltas;               /* [n_waves][2][cap_delta]: 32-B values of the registers a cycle wrote, dense per wave, as two planes (low / high 16 B) */
   uint32_t* wave_cycles;       /* [n_waves] wave-cycles run since the reset */
   uint32_t* heap_dirty;        /* [n_waves][ceil(heap_image_words / 32)][L]: words of the heap image overwritten since the reset */
   uint32_t heap_image_words;   /* words of the uploaded heap image (frame slot 0) */

@@ -1822,8 +1822,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
             m &= m - 1u;
             const u32 pos = base + before + (u32)__popcll(part & ((1ull << tid) - 1ull));
             before += (u32)__popcll(part);
-            zkw_stream_store(dl + (u64)pos * 2, sh_reg(sh, 2 * r, tid));
-            zkw_stream_store(dl + (u64)pos * 2 + 1, sh_reg(sh, 2 * r + 1, tid));
+            // two planes (low / high 16 bytes) so that each store instruction covers whole 64-byte lines
+            zkw_stream_store(dl + (u64)pos, sh_reg(sh, 2 * r, tid));
+            zkw_stream_store(dl + (u64)cap_delta + pos, sh_reg(sh, 2 * r + 1, tid));
           }
           const u32 cnt = (s.n_mem > 255u ? 255u : s.n_mem) | ((s.n_log > 255u ? 255u : s.n_log) << 8) | ((s.n_aux > 255u ? 255u : s.n_aux) << 16);
           // dirty mask: bits 0-7 in the tail's reserved byte, bits 8-14 in the top byte of the event counts

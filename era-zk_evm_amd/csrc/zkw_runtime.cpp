@@ -975,7 +975,8 @@ int zkw_batch_download_all(zkw_batch* b, uint64_t* n_bytes, double* ms) {
   for (uint32_t w = 0; w < W; w++) {
     const uint32_t* cur = &b->h_cursors[(size_t)w * 4];
     pieces.push_back({b->d_tails.p + (size_t)w * MC * 2 * L, 0, (size_t)max_cyc * 2 * L * 16});
-    pieces.push_back({b->d_deltas.p + (size_t)w * b->cap_delta * 2, 0, (size_t)std::min(cur[3], b->cap_delta) * 32});
+    pieces.push_back({b->d_deltas.p + (size_t)w * b->cap_delta * 2, 0, (size_t)std::min(cur[3], b->cap_delta) * 16});                   // low plane
+    pieces.push_back({b->d_deltas.p + (size_t)w * b->cap_delta * 2 + b->cap_delta, 0, (size_t)std::min(cur[3], b->cap_delta) * 16});  // high plane
     pieces.push_back({b->d_mem.p + (size_t)w * b->cap_mem * 3, 0, (size_t)std::min(cur[0], b->cap_mem) * 48});
     pieces.push_back({b->d_log.p + (size_t)w * b->cap_log * 8, 0, (size_t)std::min(cur[1], b->cap_log) * 128});
     pieces.push_back({b->d_auxs.p + (size_t)w * b->cap_aux * 16, 0, (size_t)std::min(cur[2], b->cap_aux) * 256});
@@ -1060,8 +1061,11 @@ static int build_wave(zkw_batch* b, uint32_t w) {
   if (max_cycles_lane)
     HIP_TRY(c, hipMemcpy(tails.data(), b->d_tails.p + (size_t)w * MC * 2 * L, tails.size() * sizeof(uint4), hipMemcpyDeviceToHost));
   const uint32_t n_delta = std::min(b->h_cursors[(size_t)w * 4 + 3], b->cap_delta);
-  std::vector<uint4> deltas((size_t)n_delta * 2);
-  if (n_delta) HIP_TRY(c, hipMemcpy(deltas.data(), b->d_deltas.p + (size_t)w * b->cap_delta * 2, deltas.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+  std::vector<uint4> deltas((size_t)n_delta * 2);  // [2][n_delta]: the used extents of the two planes
+  if (n_delta) {
+    HIP_TRY(c, hipMemcpy(deltas.data(), b->d_deltas.p + (size_t)w * b->cap_delta * 2, (size_t)n_delta * sizeof(uint4), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(deltas.data() + n_delta, b->d_deltas.p + (size_t)w * b->cap_delta * 2 + b->cap_delta, (size_t)n_delta * sizeof(uint4), hipMemcpyDeviceToHost));
+  }
   std::vector<uint4> regs0((size_t)ZKW_REG_CHUNKS * L);
   HIP_TRY(c, hipMemcpy(regs0.data(), b->d_regs0.p + (size_t)w * ZKW_REG_CHUNKS * L, regs0.size() * sizeof(uint4), hipMemcpyDeviceToHost));
   std::vector<std::array<uint4, ZKW_REG_CHUNKS>> cur(L);
@@ -1092,8 +1096,8 @@ static int build_wave(zkw_batch* b, uint32_t w) {
           const uint32_t r = (uint32_t)__builtin_ctz(m);
           const uint32_t pos = base + before + rank;
           if (pos < n_delta) {
-            cur[l][2 * r] = deltas[(size_t)pos * 2];
-            cur[l][2 * r + 1] = deltas[(size_t)pos * 2 + 1];
+            cur[l][2 * r] = deltas[(size_t)pos];
+            cur[l][2 * r + 1] = deltas[(size_t)n_delta + pos];
           }
           rank++;
         }
