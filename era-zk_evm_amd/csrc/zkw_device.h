@@ -131,10 +131,10 @@ typedef struct zkw_kparams {
   zkw_dev_scalars* scalars;    /* [n_instances]                          */
   zkw_dev_entry* callstack;    /* [n_instances][D + 1]                   */
   zkw_dev_frame_meta* frames;  /* [n_instances][F]                       */
-  uint4* stack_vals;           /* [n_waves][F][S][L][2]                  */
+  uint4* stack_vals;           /* [n_waves][F][S][2][L]                  */
   uint8_t* stack_ptrs;         /* [n_waves][F][S][L]                     */
-  uint4* heap;                 /* [n_waves][F][H][L][2]                  */
-  uint4* aux_heap;             /* [n_waves][F][A][L][2]                  */
+  uint4* heap;                 /* [n_waves][F][H][2][L]                  */
+  uint4* aux_heap;             /* [n_waves][F][A][2][L]                  */
   zkw_dev_storage_entry* storage;  /* [n_instances][storage_slots]       */
   zkw_dev_journal_entry* journal;  /* [n_instances][storage_journal]     */
   zkw_dev_history* history;        /* [n_instances][F]                   */
@@ -187,7 +187,7 @@ typedef struct zkw_reset_params {
   uint32_t cs_row16;         /* callstack ([2]): 16-byte units to restore per instance (entries 0..initial depth) ... */
   uint32_t cs_pitch16;       /* ... out of this many per instance; n16[2] = n_instances * cs_row16 */
   uint4* heap_dst;           /* working heap arena */
-  const uint4* heap_src;     /* [n_waves][heap_image_words][L][2] */
+  const uint4* heap_src;     /* [n_waves][heap_image_words][2][L] */
   uint32_t heap_row16;       /* 16-byte units per wave row of the image */
   uint32_t heap_pitch16;     /* 16-byte units between wave rows in the arena */
   uint32_t n_waves;

@@ -239,6 +239,9 @@ ZD void reg_write(Shared& sh, Lane& s, u32 idx, const u256& v, bool is_ptr) {
 // ---------------------------------------------------------------------------------------------
 // memory arenas — the device-side SimpleMemory (reference_impls/memory.rs:403-528)
 // ---------------------------------------------------------------------------------------------
+// A 32-byte word of a lane is stored as two 16-byte halves in two lane-minor planes of its word row
+// ([word][2][L] x 16 B: element 2 * w - lane and that + L for the index w returned here), so that each of the two
+// load / store instructions of a word access covers whole 64-byte lines.
 ZD u64 page_word_index(const Shared& sh, const Lane& s, u32 slot, u32 words_per_page, u32 idx) {
   return (((u64)s.wave * sh.F + slot) * words_per_page + idx) * sh.L + s.lane;
 }
@@ -251,7 +254,7 @@ ZD u256 stack_read(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, bool& is_ptr) {
   if (idx >= s.stack_hwm) return u256_zero();
   const u64 w = page_word_index(sh, s, s.slot, sh.S, idx);
   is_ptr = sh.stack_ptrs[w] != 0;
-  return u256_from_uint4(sh.stack_vals[2 * w], sh.stack_vals[2 * w + 1]);
+  return u256_from_uint4(sh.stack_vals[2 * w - s.lane], sh.stack_vals[2 * w - s.lane + sh.L]);
 }
 // MemoryType::Stack write (memory.rs:413-425)
 ZD void stack_write(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, const u256& v, bool is_ptr) {
@@ -261,13 +264,13 @@ ZD void stack_write(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, const u256& v,
   }
   for (u32 g = s.stack_hwm; g < idx; g++) {  // lazily zero the gap
     const u64 w = page_word_index(sh, s, s.slot, sh.S, g);
-    sh.stack_vals[2 * w] = make_uint4(0, 0, 0, 0);
-    sh.stack_vals[2 * w + 1] = make_uint4(0, 0, 0, 0);
+    sh.stack_vals[2 * w - s.lane] = make_uint4(0, 0, 0, 0);
+    sh.stack_vals[2 * w - s.lane + sh.L] = make_uint4(0, 0, 0, 0);
     sh.stack_ptrs[w] = 0;
   }
   const u64 w = page_word_index(sh, s, s.slot, sh.S, idx);
-  sh.stack_vals[2 * w] = u256_lo4(v);
-  sh.stack_vals[2 * w + 1] = u256_hi4(v);
+  sh.stack_vals[2 * w - s.lane] = u256_lo4(v);
+  sh.stack_vals[2 * w - s.lane + sh.L] = u256_hi4(v);
   sh.stack_ptrs[w] = is_ptr ? 1 : 0;
   if (idx >= s.stack_hwm) s.stack_hwm = idx + 1;
 }
@@ -278,7 +281,7 @@ ZD u256 heap_read_at(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 slot,
   if (idx >= hwm) return u256_zero();  // the reference grows its Vec on a read (memory.rs:464,468): not observable; hwm <= words
   const uint4* base = is_aux ? sh.aux_heap : sh.heap;
   const u64 w = page_word_index(sh, s, slot, words, idx);
-  return u256_from_uint4(base[2 * w], base[2 * w + 1]);
+  return u256_from_uint4(base[2 * w - s.lane], base[2 * w - s.lane + sh.L]);
 }
 // MemoryType::Heap / AuxHeap of the current frame (memory.rs:439-473; the page number of the query
 // is only debug_assert'ed there, i.e. ignored in release builds)
@@ -295,12 +298,12 @@ ZD void heap_write_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx
   u32 hwm = is_aux ? s.aux_hwm : s.heap_hwm;
   for (u32 g = hwm; g < idx; g++) {
     const u64 w = page_word_index(sh, s, s.slot, words, g);
-    base[2 * w] = make_uint4(0, 0, 0, 0);
-    base[2 * w + 1] = make_uint4(0, 0, 0, 0);
+    base[2 * w - s.lane] = make_uint4(0, 0, 0, 0);
+    base[2 * w - s.lane + sh.L] = make_uint4(0, 0, 0, 0);
   }
   const u64 w = page_word_index(sh, s, s.slot, words, idx);
-  base[2 * w] = u256_lo4(v);
-  base[2 * w + 1] = u256_hi4(v);
+  base[2 * w - s.lane] = u256_lo4(v);
+  base[2 * w - s.lane + sh.L] = u256_hi4(v);
   if (!is_aux && s.slot == 0 && idx < P.heap_image_words) {
     // a word of the uploaded heap image is overwritten: remember it, the next reset restores only those words
     u32* d = P.heap_dirty + ((u64)s.wave * ((P.heap_image_words + 31u) >> 5) + (idx >> 5)) * sh.L + s.lane;
@@ -351,7 +354,7 @@ ZD u256 fat_ptr_read(ZKW_KP P, const Shared& sh, Lane& s, u32 page, u32 idx) {
   if (idx >= hwm || idx >= words) return u256_zero();  // `.get(index).unwrap_or(zero)` (:490-495)
   const uint4* base = is_aux ? sh.aux_heap : sh.heap;
   const u64 w = page_word_index(sh, s, slot, words, idx);
-  return u256_from_uint4(base[2 * w], base[2 * w + 1]);
+  return u256_from_uint4(base[2 * w - s.lane], base[2 * w - s.lane + sh.L]);
 }
 
 // read_code_query (memory.rs:556-569) against the blob backing the current code page
@@ -1939,10 +1942,10 @@ __global__ void zkw_reset_kernel(zkw_fused_table T) {
       while (m) {
         const u32 word = g * 32u + (u32)__ffsll((long long)m) - 1u;
         m &= m - 1u;
-        const u32 off = (word * R.L + lane) * 2u;  // [word][lane][2] inside the wave's row
-        const uint4 a = R.heap_src[(u64)w * row + off], c = R.heap_src[(u64)w * row + off + 1];
+        const u32 off = word * 2u * R.L + lane;  // [word][2][lane] inside the wave's row: low halves, then high halves
+        const uint4 a = R.heap_src[(u64)w * row + off], c = R.heap_src[(u64)w * row + off + R.L];
         R.heap_dst[(u64)w * R.heap_pitch16 + off] = a;
-        R.heap_dst[(u64)w * R.heap_pitch16 + off + 1] = c;
+        R.heap_dst[(u64)w * R.heap_pitch16 + off + R.L] = c;
       }
     }
   }

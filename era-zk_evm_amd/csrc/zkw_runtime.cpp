@@ -117,7 +117,7 @@ struct zkw_batch {
   DevBuf<zkw_dev_entry> d_callstack0;
   DevBuf<zkw_dev_frame_meta> d_frames0;
   DevBuf<zkw_dev_storage_entry> d_storage0;
-  DevBuf<uint4> d_heap0;  // [n_waves][heap_image_words][L][2]
+  DevBuf<uint4> d_heap0;  // [n_waves][heap_image_words][2][L]
   // device: working
   DevBuf<uint4> d_regs;
   DevBuf<zkw_dev_scalars> d_scalars;
@@ -608,8 +608,8 @@ int zkw_batch_upload(zkw_batch* b) {
       frames[(size_t)i * F + cur_slot].heap_hwm = (uint32_t)s.heap.size();
       for (size_t k = 0; k < s.heap.size(); k++) {
         const uint32_t* v = (const uint32_t*)s.heap[k].l;
-        heap0[(((size_t)w * himg + k) * L + l) * 2] = make_uint4(v[0], v[1], v[2], v[3]);
-        heap0[(((size_t)w * himg + k) * L + l) * 2 + 1] = make_uint4(v[4], v[5], v[6], v[7]);
+        heap0[(((size_t)w * himg + k) * 2) * L + l] = make_uint4(v[0], v[1], v[2], v[3]);      // [word][2][L]: low halves,
+        heap0[(((size_t)w * himg + k) * 2 + 1) * L + l] = make_uint4(v[4], v[5], v[6], v[7]);  // then high halves
       }
     }
     // storage snapshot
