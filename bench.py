@@ -72,6 +72,12 @@ def main():
     # full waves when several batches share a launch: the library's default thins the waves of a SMALL batch so that a
     # lone launch of it reaches more CUs, which only multiplies the waves of a fused launch (256 x 4096: 0.8 -> 2.9 G cycles/s)
     wl.limits["lanes_per_wave"] = args.lanes if args.lanes or args.fuse <= 1 else 64
+    if args.cfg == 2:
+        # stream capacities sized for this tape (332 memory queries, 2 log queries, 8 aux events per 256 cycles and
+        # instance) instead of the library's generic defaults (6 / 0.5 / 0.25 per cycle): 0.67 instead of 0.97 GB of
+        # device memory per batch, so that the 2 x 128 batches of a multi-GPU rank stay well inside 288 GB.  An
+        # overrun would show as failed instances, which the run refuses below.
+        wl.limits.update(max_mem_queries=2 * args.cycles + 64, max_log_queries=16, max_aux_events=32)
     # A 4096-instance batch is 64 waves and every instance is a sequential chain of cycles, so ONE batch cannot fill
     # 256 CUs (the cycle kernel is latency-bound per wave) and the hardware overlaps only ~4 kernels of different
     # streams.  The K steps (one step = one 1M-cycle batch, every cycle of it executed and witnessed) are therefore
@@ -197,6 +203,8 @@ def main():
     k_ms_alone = drain_timing()[0]
     batch.sync()
     st = batch.stats()
+    if int(st["instances_failed"]) != 0:
+        raise RuntimeError("bench: %d instances of the batch stopped on a capacity limit or an error status" % int(st["instances_failed"]))
     # untimed: what pulling one step's whole trace over PCIe would cost
     dl_bytes, dl_ms = C.c_uint64(0), C.c_double(0)
     prod.call("batch_download_all", batch.h, C.byref(dl_bytes), C.byref(dl_ms))
@@ -245,6 +253,9 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(isa, args)
+    if os.environ.get("ZKW_BENCH_MEMINFO"):
+        free_b, total_b = torch.cuda.mem_get_info(local_rank)
+        print("rank %d: device memory in use %.1f GB of %.1f GB" % (rank, (total_b - free_b) / 2**30, total_b / 2**30), file=sys.stderr)
     if collective:
         dist.destroy_process_group()
     if rank == 0:  # the JSON line is the last thing on stdout (RCCL prints its own banner lines during init / teardown)
