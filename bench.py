@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--cfg", type=int, default=2)
     ap.add_argument("--min-warmup-s", type=float, default=0.6, help="untimed warm-up is extended to at least this long (clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--nop-only", action="store_true")
+    ap.add_argument("--nop-only", action="store_true", help="with --cfg 0: a tape of NOPs only instead of alternating NOP / ADD")
     ap.add_argument("--commit-mask", type=int, default=4, help="queue commitments computed inside every step: bit0 memory, bit1 log, bit2 decommit (BASELINE configs[2]: decommit queue)")
     args = ap.parse_args()
 
