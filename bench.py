@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--cycles", type=int, default=256)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per wave (0 = full waves for fused launches, the library default for --fuse 1)")
     ap.add_argument("--fuse", type=int, default=128, help="batches (steps) per fused launch (zkw_batches_step), <= 256 (ZKW_MAX_FUSED)")
-    ap.add_argument("--streams", type=int, default=0, help="fused groups in flight (1 = everything on one stream; >= 2 = restore + cycle kernels on the main stream, commitments and the digest exchange on side streams; 0 = 1 on a single GPU, 2 when there is a digest all-gather to hide)")
+    ap.add_argument("--streams", type=int, default=0, help="fused groups in flight (1 = everything on one stream; >= 2 = restore + cycle kernels on the main stream, commitments and the digest exchange on side streams; 0 = 2)")
     ap.add_argument("--side", choices=["commit", "commit+reset"], default="commit", help="what the side streams carry when --streams >= 2")
     ap.add_argument("--force-collective", action="store_true", help="run the digest all-gather even with one rank (exercises the multi-GPU code path on a single GPU)")
     ap.add_argument("--main-priority", type=int, default=0, help="1 = create the main stream with high priority")
@@ -50,7 +50,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     collective = world > 1 or args.force_collective
     if args.streams <= 0:
-        args.streams = 2 if collective else 1
+        args.streams = 2
     if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")

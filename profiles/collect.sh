@@ -11,7 +11,7 @@ cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
 hipcc --offload-arch=gfx950 -O2 profiles/tools/occupancy_probe.hip -o /tmp/occ_probe 2>/dev/null && /tmp/occ_probe > $OUT/occupancy_probe.txt 2>&1
 python bench.py > $OUT/bench.log 2>&1; grep '^{' $OUT/bench.log > $OUT/bench.json
-CMD="python bench.py --no-cpu-baseline"   # the default command itself (128 batches per fused launch, one stream on a single GPU) minus the CPU leg
+CMD="python bench.py --no-cpu-baseline"   # the default command itself (128 batches per fused launch, two fused groups in flight: commitments on a side stream) minus the CPU leg
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_insts -o $TAG -- $CMD > $OUT/pmc_insts.log 2>&1
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_wait -o $TAG -- $CMD > $OUT/pmc_wait.log 2>&1
