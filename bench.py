@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--instances", type=int, default=4096, help="VM instances per GPU (weak scaling)")
     ap.add_argument("--cycles", type=int, default=256)
-    ap.add_argument("--lanes", type=int, default=0, help="lanes per wave (0 = full waves for fused launches, the library default for --fuse 1)")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per wave (0 = library default: full waves)")
     ap.add_argument("--fuse", type=int, default=128, help="batches (steps) per fused launch (zkw_batches_step), <= 256 (ZKW_MAX_FUSED)")
     ap.add_argument("--streams", type=int, default=0, help="fused groups in flight (1 = everything on one stream; >= 2 = restore + cycle kernels on the main stream, commitments and the digest exchange on side streams; 0 = 2)")
     ap.add_argument("--side", choices=["commit", "commit+reset"], default="commit", help="what the side streams carry when --streams >= 2")
@@ -69,9 +69,7 @@ def main():
         wl.blobs[0] = K.pack_code(ops)
     else:
         wl = synth.make(args.cfg, isa, n_instances=args.instances, n_cycles=args.cycles, seed=0x5EED0000 + args.cfg + 0x100 * rank)
-    # full waves when several batches share a launch: the library's default thins the waves of a SMALL batch so that a
-    # lone launch of it reaches more CUs, which only multiplies the waves of a fused launch (256 x 4096: 0.8 -> 2.9 G cycles/s)
-    wl.limits["lanes_per_wave"] = args.lanes if args.lanes or args.fuse <= 1 else 64
+    wl.limits["lanes_per_wave"] = args.lanes
     if args.cfg == 2:
         # stream capacities sized for this tape (332 memory queries, 2 log queries, 8 aux events per 256 cycles and
         # instance) instead of the library's generic defaults (6 / 0.5 / 0.25 per cycle): 0.67 instead of 0.97 GB of

@@ -267,11 +267,12 @@ int zkw_batch_create(zkw_ctx* c, uint32_t n, const zkw_limits* limits, zkw_batch
   uint32_t L = lim.lanes_per_wave;
   if (const char* env = getenv("ZKW_LANES_PER_WAVE")) L = (uint32_t)atoi(env);
   if (L == 0) {
-    // Measured on MI355X (profiles/r01_lane_sweep.md): the kernel is bound by the per-wave latency of one
-    // VM cycle, which does not depend on the number of active lanes, so fill waves first and only thin
-    // them out when that would leave fewer than one wave per 4 CUs.
-    const uint32_t min_waves = std::max(1u, (uint32_t)c->n_cus / 4);
-    L = pow2_ceil((n + min_waves - 1) / min_waves);
+    // Measured on MI355X (profiles/r01_lane_sweep.md): the kernel is bound by the per-wave latency of one VM
+    // cycle, which does not depend on the number of active lanes, so waves are filled: thin waves make a lone
+    // launch of a small batch no faster (shared tape) and multiply the waves of a fused launch (256 x 4096 in
+    // 256 batches: 0.8 G cycles/s with 4-lane waves, 19.6 G with full ones).  A caller whose instances run
+    // DIFFERENT programs in a small batch can ask for thinner waves (fewer opcode groups per wave-cycle).
+    L = pow2_ceil(std::min<uint32_t>(n, (uint32_t)c->wave_width));
   }
   L = pow2_ceil(L);
   if (L > (uint32_t)c->wave_width) L = (uint32_t)c->wave_width;
