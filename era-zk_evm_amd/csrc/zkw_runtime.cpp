@@ -101,6 +101,7 @@ struct zkw_batch {
   uint32_t n;
   zkw_limits lim;
   uint32_t L, n_waves;
+  bool auto_L = false;  // limits.lanes_per_wave == 0: the wave width is settled at upload, when the programs are known
   uint32_t cap_mem, cap_log, cap_aux, cap_delta;
   // staging
   std::vector<std::vector<zkw_u256>> blobs;
@@ -267,11 +268,13 @@ int zkw_batch_create(zkw_ctx* c, uint32_t n, const zkw_limits* limits, zkw_batch
   uint32_t L = lim.lanes_per_wave;
   if (const char* env = getenv("ZKW_LANES_PER_WAVE")) L = (uint32_t)atoi(env);
   if (L == 0) {
+    b->auto_L = true;
     // Measured on MI355X (profiles/r01_lane_sweep.md): the kernel is bound by the per-wave latency of one VM
     // cycle, which does not depend on the number of active lanes, so waves are filled: thin waves make a lone
     // launch of a small batch no faster (shared tape) and multiply the waves of a fused launch (256 x 4096 in
     // 256 batches: 0.8 G cycles/s with 4-lane waves, 19.6 G with full ones).  A caller whose instances run
-    // DIFFERENT programs in a small batch can ask for thinner waves (fewer opcode groups per wave-cycle).
+    // DIFFERENT programs can ask for thinner waves (fewer opcode groups per wave-cycle); zkw_batch_upload does that
+    // by itself when it sees that the instances were given different code (below).
     L = pow2_ceil(std::min<uint32_t>(n, (uint32_t)c->wave_width));
   }
   L = pow2_ceil(L);
@@ -415,14 +418,34 @@ int zkw_batch_upload(zkw_batch* b) {
   if (!b) return ZKW_ERR_INVALID;
   zkw_ctx* c = b->ctx;
   HIP_TRY(c, hipSetDevice(c->device));
-  const uint32_t n = b->n, L = b->L, W = b->n_waves;
-  const zkw_limits& lim = b->lim;
-  const uint32_t F = lim.max_far_frames, D = lim.max_callstack_depth;
-  for (uint32_t i = 0; i < n; i++)
+  for (uint32_t i = 0; i < b->n; i++)
     if (!b->staged[i].has_state) {
       c->last_error = "instance " + std::to_string(i) + " has no state (zkw_batch_set_state)";
       return ZKW_ERR_INVALID;
     }
+  if (b->auto_L) {
+    // Wave width when the caller left it to the library.  Lanes of a wave that hold different instruction words are
+    // served one after the other (opcode-word grouping), so instances that were given DIFFERENT code get thin waves:
+    // as few lanes per wave as still fill the chip's wave slots once (4 per CU).  Measured with 4096 different
+    // arithmetic tapes (profiles/tools/divergent_tapes.py): 28 M cycles/s with 64-lane waves, 284 M with 4-lane waves.
+    // Instances that share their code keep full waves.
+    bool same_code = true;
+    for (uint32_t i = 1; i < b->n && same_code; i++) same_code = b->staged[i].code_pages == b->staged[0].code_pages;
+    uint32_t L2 = pow2_ceil(std::min<uint32_t>(b->n, (uint32_t)c->wave_width));
+    if (!same_code) {
+      const uint32_t slots = 4u * (uint32_t)std::max(1, c->n_cus);
+      L2 = std::min<uint32_t>(L2, pow2_ceil((b->n + slots - 1) / slots));
+    }
+    b->L = L2;
+    b->n_waves = (b->n + L2 - 1) / L2;
+    b->cap_mem = b->lim.max_mem_queries * L2;
+    b->cap_log = b->lim.max_log_queries * L2;
+    b->cap_aux = b->lim.max_aux_events * L2;
+    b->cap_delta = b->lim.max_reg_deltas * L2;
+  }
+  const uint32_t n = b->n, L = b->L, W = b->n_waves;
+  const zkw_limits& lim = b->lim;
+  const uint32_t F = lim.max_far_frames, D = lim.max_callstack_depth;
   // ---- blobs ----
   std::vector<uint2> dir(b->blobs.size());
   size_t total_words = 0;

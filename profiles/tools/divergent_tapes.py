@@ -11,7 +11,7 @@ wl = synth.make(1, isa, n_instances=4096)
 for i in range(1, 4096):
     wl.blobs.append(K.pack_code(synth.arith_tape(isa, 256, synth.ScalarRng(1000 + i))))
     wl.code_pages.append((i, 1, synth.BOOTLOADER_CODE_PAGE, len(wl.blobs) - 1))
-for lanes in (64, 16, 4, 1):
+for lanes in (0, 64, 16, 4, 1):  # 0 = the library's choice (thin waves: the instances were given different code)
     wl.limits["lanes_per_wave"] = lanes
     b = be.create_batch(wl)
     for rep in range(3):
