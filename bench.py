@@ -24,8 +24,8 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=1024, help="timed steps (1M-cycle batches); the default is 8 fused launches, so that the fill and drain of the two-group pipeline are a small part of the timed region")
+    ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--instances", type=int, default=4096, help="VM instances per GPU (weak scaling)")
     ap.add_argument("--cycles", type=int, default=256)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per wave (0 = library default: full waves)")

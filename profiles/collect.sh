@@ -22,7 +22,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o $TAG -- $CMD
 for N in 256 1024 4096 16384 65536 262144; do S=10; [ $N -ge 65536 ] && S=3; python bench.py --instances $N --steps $S --warmup 1 --fuse 1 --streams 1 --no-cpu-baseline 2>/dev/null | grep '^{' >> $OUT/instance_sweep.jsonl; done
 # fused-launch sweep on the default 4096 x 256 batch
 # and the second shape of cfg 2 (256 instances x 4096 cycles; 256 batches = 1024 waves fill the chip)
-for FS in "1 1" "4 1" "8 1" "16 1" "16 2" "32 1" "32 2" "64 1" "128 1" "128 2" "256 1"; do set -- $FS; python bench.py --steps 256 --warmup 2 --fuse $1 --streams $2 --no-cpu-baseline 2>/dev/null | grep '^{' >> $OUT/fuse_sweep.jsonl; done
+for FS in "1 1" "4 1" "8 1" "16 1" "16 2" "32 1" "32 2" "64 1" "128 1" "128 2" "256 1"; do set -- $FS; python bench.py --steps 1024 --warmup 2 --fuse $1 --streams $2 --no-cpu-baseline 2>/dev/null | grep '^{' >> $OUT/fuse_sweep.jsonl; done
 for A in "--fuse 32 --steps 64 --warmup 32" "--fuse 128 --steps 256 --warmup 128" "--fuse 256 --steps 512 --warmup 256"; do python bench.py --no-cpu-baseline --instances 256 --cycles 4096 $A 2>/dev/null | grep '^{' >> $OUT/long_traces.jsonl; done
 find $OUT -name "*.csv" | head -40
 python - "$OUT" "$TAG" <<'PY'
