@@ -29,9 +29,9 @@ def main():
     ap.add_argument("--instances", type=int, default=4096, help="VM instances per GPU (weak scaling)")
     ap.add_argument("--cycles", type=int, default=256)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per wave (0 = library default: full waves)")
-    ap.add_argument("--fuse", type=int, default=128, help="batches (steps) per fused launch (zkw_batches_step), <= 256 (ZKW_MAX_FUSED)")
+    ap.add_argument("--fuse", type=int, default=64, help="batches (steps) per fused launch (zkw_batches_step), <= 256 (ZKW_MAX_FUSED)")
     ap.add_argument("--streams", type=int, default=0, help="fused groups in flight (1 = everything on one stream; >= 2 = restore + cycle kernels on the main stream, commitments and the digest exchange on side streams; 0 = 2)")
-    ap.add_argument("--side", choices=["commit", "commit+reset"], default="commit", help="what the side streams carry when --streams >= 2")
+    ap.add_argument("--side", choices=["commit", "commit+reset"], default="commit+reset", help="what the side streams carry when --streams >= 2")
     ap.add_argument("--force-collective", action="store_true", help="run the digest all-gather even with one rank (exercises the multi-GPU code path on a single GPU)")
     ap.add_argument("--main-priority", type=int, default=0, help="1 = create the main stream with high priority")
     ap.add_argument("--cfg", type=int, default=2)
@@ -108,13 +108,14 @@ def main():
     q_index = torch.tensor(committed if committed else [0], dtype=torch.long, device="cuda")
     digest_bytes = args.instances * 3 * 4 * 8
 
-    # Pipelining over streams (--streams >= 2): the main stream carries the restore + cycle kernel of every group, back
-    # to back; every group has a side stream that carries its commitment kernels (integer-ALU bound) and the digest
-    # exchange (--side commit+reset: also the restore for the group's next use), ordered by events.  The commitments
-    # therefore run in the shadow of the HBM-bound cycle kernel of another group, while the cycle kernels themselves
-    # stay serialised (their durations are inflated only by that side work, not by a second cycle kernel).
-    # Measured (profiles/r01_kernel_variants.md): 1 stream 6.2 G cycles/s, kernel at 0.76 of peak; commit on the side
-    # stream 6.8 G, kernel 0.66; commit + restore on the side stream 6.6 G, kernel 0.53.
+    # Pipelining over streams (--streams >= 2): the main stream carries the cycle kernels of the groups back to back;
+    # every group has a side stream that carries its commitment kernels (integer-ALU bound), the digest exchange and
+    # (--side commit+reset, the default) the restore of the group's inputs for its next use, ordered by events.  Kernel
+    # trace of the other arrangement (restore on the main stream, profiles/r01_kernel_variants.md step 51): the restore
+    # of group B then starts together with the commitment of group A the moment a cycle kernel ends, both take 1.6 ms
+    # instead of 0.6 / 1.3 ms, and the next cycle kernel waits for the restore — the step time was the SUM of all kernels.
+    # With the restore behind the commitment on the side stream, the side work runs beside the next cycle kernel (which
+    # has idle issue slots: it is latency-bound) and the main stream never waits.
     main_stream = streams[0]
     side_streams = [torch.cuda.Stream(device=local_rank) for _ in range(n_groups)]
     ev_run = [torch.cuda.Event() for _ in range(n_groups)]
@@ -177,7 +178,7 @@ def main():
     # ~20% slower): keep warming up, untimed, until 0.6 s of device work has been issued
     t_w = time.perf_counter()
     while time.perf_counter() - t_w < args.min_warmup_s:
-        run_steps(fuse * n_groups)
+        run_steps(4 * fuse * n_groups)  # long bursts: the launches of the warm-up then run in the same pipelined regime as the timed ones
         for st_ in streams + side_streams:
             st_.synchronize()
     drain_timing()  # the event pairs of the warm-up launches do not count

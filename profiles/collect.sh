@@ -11,7 +11,7 @@ cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
 hipcc --offload-arch=gfx950 -O2 profiles/tools/occupancy_probe.hip -o /tmp/occ_probe 2>/dev/null && /tmp/occ_probe > $OUT/occupancy_probe.txt 2>&1
 python bench.py > $OUT/bench.log 2>&1; grep '^{' $OUT/bench.log > $OUT/bench.json
-CMD="python bench.py --no-cpu-baseline"   # the default command itself (128 batches per fused launch, two fused groups in flight: commitments on a side stream) minus the CPU leg
+CMD="python bench.py --no-cpu-baseline"   # the default command itself (64 batches per fused launch, two fused groups in flight: commitments + restore on a side stream) minus the CPU leg
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_insts -o $TAG -- $CMD > $OUT/pmc_insts.log 2>&1
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_wait -o $TAG -- $CMD > $OUT/pmc_wait.log 2>&1
@@ -22,7 +22,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o $TAG -- $CMD
 for N in 256 1024 4096 16384 65536 262144; do S=10; [ $N -ge 65536 ] && S=3; python bench.py --instances $N --steps $S --warmup 1 --fuse 1 --streams 1 --no-cpu-baseline 2>/dev/null | grep '^{' >> $OUT/instance_sweep.jsonl; done
 # fused-launch sweep on the default 4096 x 256 batch
 # and the second shape of cfg 2 (256 instances x 4096 cycles; 256 batches = 1024 waves fill the chip)
-for FS in "1 1" "4 1" "8 1" "16 1" "16 2" "32 1" "32 2" "64 1" "128 1" "128 2" "256 1"; do set -- $FS; python bench.py --steps 1024 --warmup 2 --fuse $1 --streams $2 --no-cpu-baseline 2>/dev/null | grep '^{' >> $OUT/fuse_sweep.jsonl; done
+for FS in "1 1" "4 1" "8 1" "16 1" "16 2" "32 1" "32 2" "48 2" "64 1" "64 2" "64 3" "96 2" "128 1" "128 2" "256 1"; do set -- $FS; python bench.py --steps 1024 --warmup 2 --fuse $1 --streams $2 --no-cpu-baseline 2>/dev/null | grep '^{' >> $OUT/fuse_sweep.jsonl; done
 for A in "--fuse 32 --steps 64 --warmup 32" "--fuse 128 --steps 256 --warmup 128" "--fuse 256 --steps 512 --warmup 256"; do python bench.py --no-cpu-baseline --instances 256 --cycles 4096 $A 2>/dev/null | grep '^{' >> $OUT/long_traces.jsonl; done
 find $OUT -name "*.csv" | head -40
 python - "$OUT" "$TAG" <<'PY'
