@@ -2,7 +2,7 @@
 
   libzkw.so          hipcc --offload-arch=gfx950  (the product: HIP kernels + C ABI)
   libzkw_isa.so      g++   (host-only ISA helpers of include/zkw.h, also linked into libzkw.so)
-  oracle/_build/...  g++   (TEST INFRASTRUCTURE: CPU restatement of the reference)
+(The checker — oracle/ — is built by tests/_oracle.py, not from here.)
 """
 import os
 import subprocess
@@ -12,8 +12,6 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libzkw.so")
 ISA_LIB = os.path.join(PKG, "libzkw_isa.so")
-ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_LIB = os.path.join(ORACLE_DIR, "_build", "libzkw_oracle.so")
 
 HIP_SOURCES = ["zkw_kernels.hip", "zkw_commit.hip", "zkw_runtime.cpp", "isa_default.cpp"]
 
@@ -58,19 +56,6 @@ def build_isa(force=False):
     return ISA_LIB
 
 
-def build_oracle(force=False, native=False):
-    """TEST INFRASTRUCTURE ONLY. `native=True` builds the -march=native flavour bench.py times."""
-    out = ORACLE_LIB if not native else ORACLE_LIB.replace(".so", "_native.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("vm.cpp", "zkwo_api.cpp")]
-    deps = srcs + [os.path.join(ORACLE_DIR, f) for f in ("vm.hpp", "u256.hpp", "hashes.hpp", "commit.hpp", "callback_log.hpp")] + [os.path.join(ROOT, "include", "zkw.h")]
-    if force or _stale(out, deps):
-        os.makedirs(os.path.dirname(out), exist_ok=True)
-        flags = ["-O3", "-std=c++17", "-fPIC", "-shared", "-pthread"] + (["-march=native"] if native else [])
-        _run(["g++"] + flags + ["-o", out] + srcs)
-    return out
-
-
 def build_all(force=False):
     build_isa(force)
     build_lib(force)
-    build_oracle(force)

@@ -1,9 +1,8 @@
 """ctypes / numpy binding of include/zkw.h.
 
-`Backend` wraps one shared library and one symbol prefix, so the same harness drives
-  * the product  — libzkw.so,  prefix `zkw_`  (HIP kernels; needs a GPU to run), and
-  * the oracle   — oracle/_build/libzkw_oracle.so, prefix `zkwo_` (TEST INFRASTRUCTURE; only
-    tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it).
+`Backend` wraps one shared library and one symbol prefix: the product is libzkw.so, prefix `zkw_`
+(HIP kernels; needs a GPU to run).  (The tests drive their CPU checker through the same class with
+another library and prefix — tests/_oracle.py; nothing in this package refers to it.)
 Structs are mirrored as numpy structured dtypes (byte-exact with the C layout; checked by
 tests/test_capi_layout.py through zkw_abi_sizeof).
 """
@@ -262,12 +261,6 @@ class Backend:
 def load_product():
     """libzkw.so — the HIP library. Raises if it has not been built; never falls back."""
     return Backend(_build.LIB, "zkw_")
-
-
-def load_oracle(native=False):
-    """TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py cpu_baseline)."""
-    path = _build.build_oracle(native=native)
-    return Backend(path, "zkwo_")
 
 
 class Batch:

@@ -1,23 +1,31 @@
 // EraVM batch witness kernel for MI355X (gfx950).
 //
-// One VM instance per lane, one wave per workgroup.  Every active lane of a wave executes
-// `cycle()` of the reference (src/vm_state/cycle.rs:257-429) once per loop iteration, in lockstep:
-//   * the 15 x 256-bit register file of each lane lives in LDS, laid out [chunk][lane] in 16-byte
-//     units so that lanes using the same register index hit consecutive banks (conflict-free
-//     ds_read/write_b128) and so that the per-cycle snapshot is a straight LDS -> HBM copy;
-//   * the opcode stream is fetched from HBM as 32-byte code words (4 opcodes), cached in VGPRs
-//     exactly like `previous_code_word` (cycle.rs:53-101);
+// One VM instance per lane, one wave per 64 instances, 4 waves per workgroup, TWO workgroups per CU (two waves per SIMD:
+// the kernel is bound by the latency of one VM cycle of one wave, so the second wave of a SIMD fills the first one's
+// stalls).  Every active lane of a wave executes `cycle()` of the reference (src/vm_state/cycle.rs:257-429) once per
+// loop iteration, in lockstep:
+//   * the 15 x 256-bit register file of each lane lives in the upper half of the lane's vector registers (v128..v255,
+//     struct RegFile).  Decode is scalar per group of lanes that hold the same opcode word, so a register number is
+//     wave-uniform and a register access is VGPR-indexed addressing (s_set_gpr_idx_on + 8 v_mov): no LDS round trip,
+//     and the LDS footprint of a wave drops from 32 KB to 6 KB, which is what lets a second workgroup share the CU;
+//   * the cold per-lane scalars (context value, pubdata counters, arena bookkeeping) live in LDS ([field][lane]),
+//     the hot ones in VGPRs; the heavy, rare opcode bodies (far_call, ret, near_call, log + precompiles) are one
+//     out-of-line function so that their register demand does not add to the 120 + ~130 registers of the hot loop;
+//   * the opcode stream is fetched from HBM as 32-byte code words (4 opcodes), cached in LDS exactly like
+//     `previous_code_word` (cycle.rs:53-101);
 //   * the packed ISA table (host-uploaded, 2048 x 8 B) is staged in LDS once per workgroup;
-//   * stack / heap / aux-heap pages are interleaved across the lanes of a wave ([word][lane]) so a
-//     shared tape gives fully coalesced 32-byte accesses; pages are lazily zeroed through a
-//     per-page high-water mark instead of memsets;
-//   * the sparse per-cycle query logs (memory / log / aux) are compacted per wave with
-//     ballot + popcount prefix sums into dense streams (lane- and sequence-tagged records);
-//   * one 512-byte CycleRecord per lane and cycle goes out as 32 fully coalesced 16-byte stores.
+//   * stack / heap / aux-heap pages are interleaved across the lanes of a wave ([word][2][lane]) so a shared tape gives
+//     fully coalesced accesses; pages are lazily zeroed through a per-page high-water mark instead of memsets;
+//   * the sparse per-cycle query logs (memory / log / aux) are compacted per wave with ballot + popcount prefix sums
+//     into dense streams (lane- and sequence-tagged records);
+//   * the CycleRecord goes out in delta form: a 32-byte tail per lane and cycle plus the values of the registers the
+//     cycle wrote, compacted per wave.
 // No MFMA: there is no dense contraction on this path (256-bit integer ALU, byte shuffles, hashes).
 //
 // Reference citations (file:line) are relative to /root/reference/src.
 #include <hip/hip_runtime.h>
+
+#include <mutex>
 
 #include "zkw_device.h"
 #include "zkw_u256.hip.h"
@@ -28,20 +36,28 @@
 struct Lane {
   // identity
   u32 inst, wave, lane;
-  // VmLocalState scalars (mod.rs:54-73)
-  u32 ctx_reg[4];
-  u32 ptr_bitmap, flags, prev_code_page, timestamp, cycle_counter, spent_pubdata, mpc, ergs_pp, tx_number, prev_super_pc, depth;
+  // VmLocalState scalars (mod.rs:54-73) that every cycle touches
+  u32 ptr_bitmap, flags, prev_code_page, timestamp, cycle_counter, prev_super_pc, depth;
   // run bookkeeping
-  u32 status, n_cycles, first_dyn, n_initial_slots, next_slot, journal_len, n_history;
+  u32 status, n_cycles;
   // hot fields of callstack.current (execution_stack.rs:6-24)
   u32 base_page, code_page, sp, pc, ergs, heap_bound, aux_bound;
   u32 is_kernel, is_static, is_local;
-  u32 code_off, code_len, code_blob, slot;
+  u32 code_off, code_len, slot;
   u32 stack_hwm, heap_hwm, aux_hwm;
   // per-cycle
   u32 seq, n_mem, n_log, n_aux, cold_dirty;
   u32 reg_dirty;  // registers written in this cycle (bit r = register r + 1)
 };
+// The rest of the per-lane state is touched by rare opcodes only and lives in LDS, [field][lane] (conflict-free
+// dword accesses): CF(sh, s, field) is an lvalue.
+enum {
+  CF_CTX0 = 0,  // context_u128_register, 4 dwords
+  CF_SPENT_PUBDATA = 4, CF_MPC, CF_ERGS_PP, CF_TX_NUMBER,
+  CF_FIRST_DYN, CF_N_INITIAL_SLOTS, CF_NEXT_SLOT, CF_JOURNAL_LEN, CF_N_HISTORY,
+  ZKW_COLD_FIELDS = 16
+};
+#define CF(sh, s, f) ((sh).cold[(u32)(f) * (sh).L + (s).lane])
 
 #define FLAG_LT 1u
 #define FLAG_EQ 2u
@@ -123,17 +139,19 @@ ZD void zkw_wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// LDS view of one wave.  A workgroup holds ZKW_WAVES_PER_GROUP waves that share the 16 KB ISA table; each wave
-// owns 16 B of cursors + 30*16 B per lane of register file.  The Keccak row (rare, precompile only) is in HBM.
+// LDS view of one wave.  A workgroup holds ZKW_WAVES_PER_GROUP waves that share the 16 KB ISA table; each wave owns
+// 16 B of cursors + per lane: 64 B of cold state and 32 B of previous_code_word.
+// The Keccak row (rare, precompile only) is in HBM.
 struct Shared {
   uint2* isa;     // [2048] packed ISA table (shared by the waves of the workgroup)
   u32* cursor;    // [4] stream cursors of this wave
-  uint4* regs;    // [30][L] register file, 16-byte chunks, lane-minor
+  u32* cold;      // [ZKW_COLD_FIELDS][L] cold per-lane state (CF_*)
   u32* krow;      // [34][L] Keccak rate block assembly rows (global memory)
   uint2* pcw;     // [4][L] previous_code_word as 4 opcode slots (u64 limb k), lane-minor — read once per cycle, LDS
   uint4 *mem_base, *log_base, *aux_base;  // this wave's rows of the query streams (computed once per launch)
   u32 L;
   u32 debug_flags;
+  u32 wib;        // wave in workgroup
   // launch-invariant geometry and arena bases, loaded once and pinned in scalar registers (ZKW_PIN_SGPR): left to
   // itself the compiler re-loads them from the parameter block at every use (s_load + s_waitcnt lgkmcnt(0), which
   // also drains the outstanding LDS reads) because an invariant load is cheaper to rematerialise than to keep
@@ -147,7 +165,30 @@ struct Shared {
 #else
 #define ZKW_PIN_SGPR(x) ((void)0)
 #endif
-ZD uint4& sh_reg(Shared& sh, u32 chunk, u32 lane) { return sh.regs[chunk * sh.L + lane]; }
+extern __shared__ uint4 zkw_lds[];
+// 16-byte units of LDS per wave: cursors | cold | previous_code_word
+ZD u32 zkw_wave_lds_units(u32 L) { return 1u + (ZKW_COLD_FIELDS / 4u) * L + 2u * L; }
+// `wib` (wave in workgroup), `wave` and `dbg` must be wave-uniform
+ZD void shared_setup(Shared& sh, ZKW_KP P, u32 dbg, u32 wib, u32 wave, bool pin) {
+  sh.L = P.L;
+  sh.debug_flags = dbg;
+  sh.wib = wib;
+  sh.F = P.F; sh.S = P.S; sh.H = P.H; sh.A = P.A; sh.cap_mem = P.cap_mem;
+  sh.stack_vals = P.stack_vals; sh.stack_ptrs = P.stack_ptrs; sh.heap = P.heap; sh.aux_heap = P.aux_heap; sh.blob_words = P.blob_words;
+  if (pin) {
+    ZKW_PIN_SGPR(sh.L); ZKW_PIN_SGPR(sh.F); ZKW_PIN_SGPR(sh.S); ZKW_PIN_SGPR(sh.H); ZKW_PIN_SGPR(sh.A); ZKW_PIN_SGPR(sh.cap_mem);
+    ZKW_PIN_SGPR(sh.stack_vals); ZKW_PIN_SGPR(sh.stack_ptrs); ZKW_PIN_SGPR(sh.heap); ZKW_PIN_SGPR(sh.aux_heap); ZKW_PIN_SGPR(sh.blob_words);
+  }
+  uint4* wl = zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + wib * zkw_wave_lds_units(P.L);
+  sh.isa = (uint2*)zkw_lds;                                  // 16 KB
+  sh.cursor = (u32*)wl;                                      // 16 B
+  sh.cold = (u32*)(wl + 1);                                  // ZKW_COLD_FIELDS * L * 4 B
+  sh.pcw = (uint2*)(wl + 1 + (ZKW_COLD_FIELDS / 4u) * P.L);  // 4 * L * 8 B
+  sh.krow = P.krow + (u64)wave * ZKW_KROW_WORDS * P.L;
+  sh.mem_base = P.mem_stream + (u64)wave * P.cap_mem * 3;
+  sh.log_base = P.log_stream + (u64)wave * P.cap_log * 8;
+  sh.aux_base = P.aux_stream + (u64)wave * P.cap_aux * 16;
+}
 
 ZD u32 next_seq(Lane& s) {
   u32 q = s.seq > 255u ? 255u : s.seq;
@@ -216,22 +257,71 @@ ZD uint4* aux_alloc(ZKW_KP P, Shared& sh, Lane& s, u32 type, u32 flag, u32 a, u3
 }
 
 // ---------------------------------------------------------------------------------------------
-// register file (LDS) — select_register_value / update_register_value (helpers.rs:318-334)
+// register file — select_register_value / update_register_value (helpers.rs:318-334)
+//
+// The 16 x 256-bit registers of a lane (r0 = the constant zero, r1..r15) live in the UPPER HALF of the lane's vector
+// register file: register i, limb k is v[128 + 8 i + k].  The kernel is compiled for 128 vector registers
+// (__launch_bounds__(256, 4): the compiler — in the kernel and, through the propagated waves-per-eu attribute, in the
+// out-of-line functions — allocates v0..v127 only), so v128..v255 are never touched by compiled code and the kernel
+// descriptor ends up with 256 registers = two waves per SIMD.  Decode is scalar per group of lanes that hold the same
+// opcode word, so a register number is wave-uniform and an access is VGPR-indexed addressing: s_set_gpr_idx_on with
+// the scalar offset 8 i, eight v_mov, s_set_gpr_idx_off — no LDS round trip, no branch, and reading r0 needs no
+// special case.  (Compared with the register file in LDS: 32 KB less LDS per wave, which is what lets a second
+// workgroup share the CU.)  The accesses are `asm volatile`, so they stay in program order among themselves.
 // ---------------------------------------------------------------------------------------------
-ZD u256 reg_read(Shared& sh, const Lane& s, u32 idx, bool& is_ptr) {
-  if (idx == 0) {
-    is_ptr = false;
-    return u256_zero();
-  }
-  const u32 r = idx - 1;
-  is_ptr = (s.ptr_bitmap >> r) & 1u;
-  return u256_from_uint4(sh_reg(sh, 2 * r, s.lane), sh_reg(sh, 2 * r + 1, s.lane));
+#ifdef __HIP_DEVICE_COMPILE__
+struct RegFile {};
+// `reg` = 0..15, wave-uniform
+ZD u256 rf_get(const RegFile&, u32 reg) {
+  u256 v;
+  const u32 off = (u32)__builtin_amdgcn_readfirstlane((int)(reg * 8u));
+  asm volatile(
+      "s_set_gpr_idx_on %8, gpr_idx(SRC0)\n\t"
+      "v_mov_b32 %0, v128\n\tv_mov_b32 %1, v129\n\tv_mov_b32 %2, v130\n\tv_mov_b32 %3, v131\n\t"
+      "v_mov_b32 %4, v132\n\tv_mov_b32 %5, v133\n\tv_mov_b32 %6, v134\n\tv_mov_b32 %7, v135\n\t"
+      "s_set_gpr_idx_off"
+      : "=v"(v.w[0]), "=v"(v.w[1]), "=v"(v.w[2]), "=v"(v.w[3]), "=v"(v.w[4]), "=v"(v.w[5]), "=v"(v.w[6]), "=v"(v.w[7])
+      : "s"(off)
+      : "m0");
+  return v;
 }
-ZD void reg_write(Shared& sh, Lane& s, u32 idx, const u256& v, bool is_ptr) {
+// `reg` = 1..15, wave-uniform; only the active lanes are written
+ZD void rf_set(RegFile&, u32 reg, const u256& v) {
+  const u32 off = (u32)__builtin_amdgcn_readfirstlane((int)(reg * 8u));
+  asm volatile(
+      "s_set_gpr_idx_on %8, gpr_idx(DST)\n\t"
+      "v_mov_b32 v128, %0\n\tv_mov_b32 v129, %1\n\tv_mov_b32 v130, %2\n\tv_mov_b32 v131, %3\n\t"
+      "v_mov_b32 v132, %4\n\tv_mov_b32 v133, %5\n\tv_mov_b32 v134, %6\n\tv_mov_b32 v135, %7\n\t"
+      "s_set_gpr_idx_off"
+      :
+      : "v"(v.w[0]), "v"(v.w[1]), "v"(v.w[2]), "v"(v.w[3]), "v"(v.w[4]), "v"(v.w[5]), "v"(v.w[6]), "v"(v.w[7]), "s"(off)
+      : "m0");
+}
+// all lanes: r0 := 0 (and the top of the register file is named once, so that the kernel descriptor covers it)
+ZD void rf_init(RegFile&) {
+  asm volatile(
+      "v_mov_b32 v128, 0\n\tv_mov_b32 v129, 0\n\tv_mov_b32 v130, 0\n\tv_mov_b32 v131, 0\n\t"
+      "v_mov_b32 v132, 0\n\tv_mov_b32 v133, 0\n\tv_mov_b32 v134, 0\n\tv_mov_b32 v135, 0\n\tv_mov_b32 v255, 0"
+      :
+      :
+      : "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v255");
+}
+#else  // single-lane CPU emulation build of tests/emu
+struct RegFile {
+  u256 r[16];
+};
+ZD u256 rf_get(const RegFile& rf, u32 reg) { return rf.r[reg]; }
+ZD void rf_set(RegFile& rf, u32 reg, const u256& v) { rf.r[reg] = v; }
+ZD void rf_init(RegFile& rf) { rf.r[0] = u256_zero(); }
+#endif
+ZD u256 reg_read(Shared& sh, const RegFile& rf, const Lane& s, u32 idx, bool& is_ptr) {
+  is_ptr = idx != 0 && ((s.ptr_bitmap >> (idx - 1)) & 1u);
+  return rf_get(rf, idx);
+}
+ZD void reg_write(Shared& sh, RegFile& rf, Lane& s, u32 idx, const u256& v, bool is_ptr) {
   if (idx == 0) return;
   const u32 r = idx - 1;
-  sh_reg(sh, 2 * r, s.lane) = u256_lo4(v);
-  sh_reg(sh, 2 * r + 1, s.lane) = u256_hi4(v);
+  rf_set(rf, idx, v);
   s.reg_dirty |= 1u << r;
   s.ptr_bitmap = (s.ptr_bitmap & ~(1u << r)) | ((is_ptr ? 1u : 0u) << r);
 }
@@ -320,16 +410,16 @@ ZD u256 fat_ptr_read(ZKW_KP P, const Shared& sh, Lane& s, u32 page, u32 idx) {
   if (page == 0) return u256_zero();
   u32 slot, kind;
   bool found = false;
-  if (page >= s.first_dyn) {
-    const u32 rel = page - s.first_dyn;
+  if (page >= CF(sh, s, CF_FIRST_DYN)) {
+    const u32 rel = page - CF(sh, s, CF_FIRST_DYN);
     const u32 stride = P.consts.new_memory_pages_per_far_call;
-    slot = s.n_initial_slots + rel / stride;
+    slot = CF(sh, s, CF_N_INITIAL_SLOTS) + rel / stride;
     kind = rel % stride;
-    found = slot < s.next_slot;
+    found = slot < CF(sh, s, CF_NEXT_SLOT);
   } else {
     slot = 0;
     kind = 0;
-    for (u32 i = 0; i < s.n_initial_slots; i++) {
+    for (u32 i = 0; i < CF(sh, s, CF_N_INITIAL_SLOTS); i++) {
       const u32 bp = P.frames[(u64)s.inst * P.F + i].base_page;
       if (page >= bp && page < bp + 4) {
         slot = i;
@@ -385,7 +475,7 @@ ZD void hwm_writeback(ZKW_KP P, const Lane& s) {
   fm->aux_hwm = s.aux_hwm;
 }
 // load the hot fields of entry `s.depth` into the lane
-ZD void frame_load(ZKW_KP P, Lane& s) {
+ZD void frame_load(ZKW_KP P, const Shared& sh, Lane& s) {
   const u32* e = (const u32*)entry_ptr(P, s, s.depth);
   s.base_page = e[E_BASE_PAGE];
   s.code_page = e[E_CODE_PAGE];
@@ -399,9 +489,8 @@ ZD void frame_load(ZKW_KP P, Lane& s) {
   s.heap_bound = e[E_HEAP_BOUND];
   s.aux_bound = e[E_AUX_BOUND];
   s.is_kernel = (e[E_THIS] < 0x10000u && (e[E_THIS + 1] | e[E_THIS + 2] | e[E_THIS + 3] | e[E_THIS + 4]) == 0) ? 1u : 0u;  // execution_stack.rs:83-87
-  s.code_blob = e[E_CODE_BLOB];
   const u32 new_slot = e[E_SLOT];
-  const uint2 bd = P.blob_dir[s.code_blob];
+  const uint2 bd = P.blob_dir[e[E_CODE_BLOB]];
   s.code_off = bd.x;
   s.code_len = bd.y;
   s.slot = new_slot;
@@ -465,18 +554,18 @@ ZD void access_storage(ZKW_KP P, Shared& sh, Lane& s, LogQ& q) {
   e->shard_state |= 0x200u;  // warm marker
   q.read_value = cur;
   if (q.rw) {
-    if (s.journal_len >= P.storage_journal) {
+    if (CF(sh, s, CF_JOURNAL_LEN) >= P.storage_journal) {
       lane_fail(s, ZKW_STATUS_LIMIT);
       return;
     }
-    zkw_dev_journal_entry* j = P.journal + (u64)s.inst * P.storage_journal + s.journal_len;
+    zkw_dev_journal_entry* j = P.journal + (u64)s.inst * P.storage_journal + CF(sh, s, CF_JOURNAL_LEN);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       j->old_value[k] = cur.w[k];
       e->value[k] = q.written_value.w[k];
     }
     j->slot = slot;
-    s.journal_len++;
+    CF(sh, s, CF_JOURNAL_LEN)++;
     e->shard_state |= 0x400u;  // the key now exists in the reference's `inner` map and stays there across rollbacks
   } else {
     q.written_value = q.read_value;
@@ -484,11 +573,11 @@ ZD void access_storage(ZKW_KP P, Shared& sh, Lane& s, LogQ& q) {
   emit_log(P, sh, s, q, ZKW_LQ_LOG);
 }
 // Storage::finish_frame(panicked) (storage.rs:144-186): undo this frame's writes newest-first
-ZD void storage_finish_frame(ZKW_KP P, Lane& s, u32 mark, bool panicked) {
+ZD void storage_finish_frame(ZKW_KP P, const Shared& sh, Lane& s, u32 mark, bool panicked) {
   if (!panicked) return;
-  while (s.journal_len > mark) {
-    s.journal_len--;
-    const zkw_dev_journal_entry* j = P.journal + (u64)s.inst * P.storage_journal + s.journal_len;
+  while (CF(sh, s, CF_JOURNAL_LEN) > mark) {
+    CF(sh, s, CF_JOURNAL_LEN)--;
+    const zkw_dev_journal_entry* j = P.journal + (u64)s.inst * P.storage_journal + CF(sh, s, CF_JOURNAL_LEN);
     zkw_dev_storage_entry* e = P.storage + (u64)s.inst * P.storage_slots + j->slot;
 #pragma unroll
     for (int k = 0; k < 8; k++) e->value[k] = j->old_value[k];
@@ -541,12 +630,12 @@ ZD Operand compute_address(ZKW_KP P, Lane& s, u32& sp, const u256& reg_value, u3
 }
 
 // perform_dst0_update (helpers.rs:266-283)
-ZD void dst0_update(ZKW_KP P, Shared& sh, Lane& s, const Operand& dst0, u32 dst0_idx, const u256& v, bool is_ptr) {
+ZD void dst0_update(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Operand& dst0, u32 dst0_idx, const u256& v, bool is_ptr) {
   if (dst0.has_loc) {
     stack_write(P, sh, s, dst0.index, v, is_ptr);
     emit_mem(P, sh, s, s.timestamp + 3, ZKW_MEM_STACK, dst0.page, dst0.index, v, is_ptr, true, 0);
   } else {
-    reg_write(sh, s, dst0_idx, v, is_ptr);
+    reg_write(sh, rf, s, dst0_idx, v, is_ptr);
   }
 }
 
@@ -594,7 +683,7 @@ ZD void entry_image_current(ZKW_KP P, const Lane& s, u32 img[32]) {
 // VmState::start_frame (helpers.rs:225-246): Storage/EventSink::start_frame are a journal mark here
 // (the event sink is replayed on the host); emits WT.start_new_execution_context and pushes.
 ZD void start_frame(ZKW_KP P, Shared& sh, Lane& s, const u32 prev[32], u32 next[32], bool far) {
-  next[E_JOURNAL_MARK] = s.journal_len;
+  next[E_JOURNAL_MARK] = CF(sh, s, CF_JOURNAL_LEN);
   uint4* a = aux_alloc(P, sh, s, ZKW_AUX_FRAME_START, far ? 1u : 0u, 0, 0, 0);
   if (a) {
 #pragma unroll
@@ -618,7 +707,7 @@ ZD void start_frame(ZKW_KP P, Shared& sh, Lane& s, const u32 prev[32], u32 next[
   }
   hwm_writeback(P, s);
   s.depth++;
-  frame_load(P, s);
+  frame_load(P, sh, s);
 }
 
 // =============================================================================================
@@ -634,6 +723,18 @@ struct Pre {  // PreState (cycle.rs:8-14)
   bool src0_ptr, src1_ptr;
   Operand dst0;
   u32 new_pc;
+};
+
+// The heavy opcode bodies (near_call, log, far_call, ret) run out of line (zkw_heavy_entry) and have no access to the
+// VGPR register file: what they want written to registers comes back as a HeavyOut and is applied by the caller.
+#define ZKW_ACT_DST0 1u       /* perform_dst0_update(v1) */
+#define ZKW_ACT_FAR 2u        /* far_call.rs:573-610: r1 = v1 (pointer), r2 = v2, r3..r12 cleared unless ZKW_ACT_TO_SYSTEM, r13..r15 = 0 */
+#define ZKW_ACT_TO_SYSTEM 4u
+#define ZKW_ACT_RET 8u        /* ret.rs:213-233: r1 = v1 (pointer), r2..r15 = 0 */
+struct HeavyOut {
+  Lane s;
+  u256 v1, v2;
+  u32 action;
 };
 
 // near_call.rs:6-68
@@ -662,7 +763,7 @@ ZD void op_near_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre&
 }
 
 // context.rs:6-111
-ZD void op_context(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+ZD void op_context(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, const Pre& ps) {
   s.pc = ps.new_pc;
   const u32 v = ZKW_ATTR_VARIANT(d.attr);
   u256 value = u256_zero();
@@ -670,19 +771,19 @@ ZD void op_context(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& p
     bool changed = false;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      changed = changed || s.ctx_reg[i] != ps.src0.w[i];
-      s.ctx_reg[i] = ps.src0.w[i];
+      changed = changed || CF(sh, s, CF_CTX0 + i) != ps.src0.w[i];
+      CF(sh, s, CF_CTX0 + i) = ps.src0.w[i];
     }
     if (changed) s.cold_dirty = 1;
     return;
   }
   if (v == ZKW_CTX_SET_ERGS_PER_PUBDATA) {
-    if (s.ergs_pp != ps.src0.w[0]) s.cold_dirty = 1;
-    s.ergs_pp = ps.src0.w[0];
+    if (CF(sh, s, CF_ERGS_PP) != ps.src0.w[0]) s.cold_dirty = 1;
+    CF(sh, s, CF_ERGS_PP) = ps.src0.w[0];
     return;
   }
   if (v == ZKW_CTX_INC_TX_NUMBER) {
-    s.tx_number = (s.tx_number + 1) & 0xffffu;
+    CF(sh, s, CF_TX_NUMBER) = (CF(sh, s, CF_TX_NUMBER) + 1) & 0xffffu;
     s.cold_dirty = 1;
     return;
   }
@@ -693,7 +794,7 @@ ZD void op_context(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& p
     for (int i = 0; i < 5; i++) value.w[i] = e[off + i];
   } else if (v == ZKW_CTX_META) {  // VmMetaParameters::to_u256 (Appendix B layout)
     const u32 sh3 = e[E_SHARDS];
-    value.w[0] = s.ergs_pp;
+    value.w[0] = CF(sh, s, CF_ERGS_PP);
     value.w[2] = s.heap_bound;
     value.w[3] = s.aux_bound;
     value.w[7] = (sh3 & 0xffu) | (((sh3 >> 8) & 0xffu) << 8) | (((sh3 >> 16) & 0xffu) << 16);
@@ -705,11 +806,11 @@ ZD void op_context(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& p
 #pragma unroll
     for (int i = 0; i < 4; i++) value.w[i] = e[E_CTX + i];
   }
-  dst0_update(P, sh, s, ps.dst0, d.dst0, value, false);
+  dst0_update(P, sh, rf, s, ps.dst0, d.dst0, value, false);
 }
 
 // ptr.rs:6-194
-ZD void op_ptr(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+ZD void op_ptr(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, const Pre& ps) {
   s.pc = ps.new_pc;
   const u32 v = ZKW_ATTR_VARIANT(d.attr);
   if (!ps.src0_ptr || ps.src1_ptr) {  // :35-45
@@ -750,18 +851,11 @@ ZD void op_ptr(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
     }
     result.w[3] = ps.src0.w[3] - off;
   }
-  dst0_update(P, sh, s, ps.dst0, d.dst0, result, true);
+  dst0_update(P, sh, rf, s, ps.dst0, d.dst0, result, true);
 }
 
 // uma.rs:26-425
-#ifdef ZKW_PROFILE
-__shared__ unsigned long long zp_mark[12];  // [0] last stamp, [1..] accumulated clocks between the marks of op_uma (wave 0 of the workgroup)
-#define ZKW_MARK(i) { if (threadIdx.x < 64u && threadIdx.x == (u32)__ffsll((long long)__ballot(1)) - 1u) { const unsigned long long zp_n = __builtin_readcyclecounter(); if (i) zp_mark[i] += zp_n - zp_mark[0]; zp_mark[0] = zp_n; } }
-#else
-#define ZKW_MARK(i)
-#endif
-ZD void op_uma(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
-  ZKW_MARK(0)
+ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, const Pre& ps) {
   const u32 v = ZKW_ATTR_VARIANT(d.attr);
   s.pc = ps.new_pc;
   const bool increment = ZKW_ATTR_FLAGS(d.attr) & 1u;
@@ -822,7 +916,6 @@ ZD void op_uma(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
   const bool unaligned = unal != 0;
   const u32 ts_r = s.timestamp, ts_w = s.timestamp + 3;
   u256 w0v = u256_zero(), w1v = u256_zero();
-  ZKW_MARK(1)  // exceptions, growth
   if (!skip) {  // :265-288
     // both word loads are issued before the first query is emitted: the emission needs the loaded value, so reading
     // and emitting word by word would serialise two memory round trips (the dominant cost of this opcode)
@@ -831,7 +924,6 @@ ZD void op_uma(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
     emit_mem(P, sh, s, ts_r, mem_type, fp.page, word0, w0v, false, false, 0);
     if (unaligned) emit_mem(P, sh, s, ts_r, mem_type, fp.page, word1, w1v, false, false, 0);
   }
-  ZKW_MARK(2)  // word reads + read queries
   if (!is_write) {  // :291-348
     u256 result = u256_or(u256_shl(w0v, unal * 8), u256_shr(w1v, (32 - unal) * 8));
     if (is_ptr_read) {
@@ -840,13 +932,12 @@ ZD void op_uma(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
       beyond &= 31u;
       result = u256_shl(u256_shr(result, beyond * 8), beyond * 8);
     }
-    ZKW_MARK(3)  // read: shifts
     if (!set_panic) {
-      dst0_update(P, sh, s, ps.dst0, d.dst0, result, false);
+      dst0_update(P, sh, rf, s, ps.dst0, d.dst0, result, false);
       if (increment) {
         u256 upd = ps.src0;
         upd.w[0] = incremented;  // (l[0] & TOP_32) + incremented :337-338
-        reg_write(sh, s, d.dst1, upd, ps.src0_ptr);
+        reg_write(sh, rf, s, d.dst1, upd, ps.src0_ptr);
       }
     } else {
       s.flags |= FLAG_PENDING;
@@ -857,7 +948,6 @@ ZD void op_uma(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
     n0 = u256_or(n0, u256_shr(ps.src1, unal * 8));
     u256 n1 = u256_shr(u256_shl(w1v, unal * 8), unal * 8);
     n1 = u256_or(n1, u256_shl(ps.src1, (32 - unal) * 8));
-    ZKW_MARK(4)  // write: shifts
     if (!skip) {
       heap_write_cur(P, sh, s, !is_heap, word0, n0);
       emit_mem(P, sh, s, ts_w, mem_type, fp.page, word0, n0, false, true, 0);
@@ -866,24 +956,22 @@ ZD void op_uma(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
         emit_mem(P, sh, s, ts_w, mem_type, fp.page, word1, n1, false, true, 0);
       }
     }
-    ZKW_MARK(5)  // write: heap writes + write queries
     if (!set_panic) {
       if (increment) {
         u256 upd = ps.src0;
         upd.w[0] = incremented;
-        dst0_update(P, sh, s, ps.dst0, d.dst0, upd, false);
+        dst0_update(P, sh, rf, s, ps.dst0, d.dst0, upd, false);
       }
     } else {
       s.flags |= FLAG_PENDING;
     }
   }
-  ZKW_MARK(6)  // destination updates
 }
 
 // log.rs:11-330 (precompile calls: see zkw_precompiles below)
 ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q);
 
-ZD void op_log(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+ZD void op_log(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, HeavyOut& out) {
   const u32 v = ZKW_ATTR_VARIANT(d.attr);
   s.pc = ps.new_pc;
   const bool is_first = ZKW_ATTR_FLAGS(d.attr) & 1u;
@@ -893,7 +981,7 @@ ZD void op_log(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
   const zkw_isa_consts ZKW_CONST_AS& K = P.consts;
   LogQ q;
   q.timestamp = s.timestamp + 1;
-  q.tx_number = s.tx_number;
+  q.tx_number = CF(sh, s, CF_TX_NUMBER);
   q.shard_id = shard;
 #pragma unroll
   for (int i = 0; i < 5; i++) q.address[i] = e[E_THIS + i];
@@ -908,9 +996,9 @@ ZD void op_log(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
     q.is_service = false;
     emit_log(P, sh, s, q, ZKW_LQ_REFUND);  // refund_for_partial_query: InMemoryStorage refunds nothing (storage.rs:80-86)
     const u32 net = shard == 0 ? K.initial_storage_write_pubdata_bytes : 0u;
-    ergs_on_pubdata = s.ergs_pp * net;
+    ergs_on_pubdata = CF(sh, s, CF_ERGS_PP) * net;
   } else if (v == ZKW_LOG_TO_L1) {
-    ergs_on_pubdata = s.ergs_pp * K.l1_message_pubdata_bytes;
+    ergs_on_pubdata = CF(sh, s, CF_ERGS_PP) * K.l1_message_pubdata_bytes;
   }
   const u32 extra = v == ZKW_LOG_PRECOMPILE ? ps.src1.w[0] : 0u;
   const u32 total = extra + ergs_on_pubdata;
@@ -924,7 +1012,7 @@ ZD void op_log(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
     spent = ergs_on_pubdata;
   }
   if (spent) {
-    s.spent_pubdata += spent;
+    CF(sh, s, CF_SPENT_PUBDATA) += spent;
     s.cold_dirty = 1;
   }
   q.is_service = is_first;
@@ -937,7 +1025,8 @@ ZD void op_log(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
     q.rw = false;
     q.written_value = u256_zero();
     access_storage(P, sh, s, q);
-    dst0_update(P, sh, s, ps.dst0, d.dst0, q.read_value, false);
+    out.v1 = q.read_value;
+    out.action = ZKW_ACT_DST0;
   } else if (v == ZKW_LOG_STORAGE_WRITE) {  // :196-220
     if (not_enough) return;
     access_storage(P, sh, s, q);
@@ -951,7 +1040,8 @@ ZD void op_log(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
     emit_log(P, sh, s, q, ZKW_LQ_LOG);
   } else {  // PrecompileCall :252-328
     if (not_enough) {
-      dst0_update(P, sh, s, ps.dst0, d.dst0, u256_zero(), false);
+      out.v1 = u256_zero();
+      out.action = ZKW_ACT_DST0;
       return;
     }
     const u32 heap_page = s.base_page + 2;
@@ -961,7 +1051,8 @@ ZD void op_log(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
     q.rw = false;
     q.written_value = u256_zero();
     call_precompile(P, sh, s, q);
-    dst0_update(P, sh, s, ps.dst0, d.dst0, u256_from_u32(1), false);
+    out.v1 = u256_from_u32(1);
+    out.action = ZKW_ACT_DST0;
   }
 }
 
@@ -975,7 +1066,7 @@ ZD void versioned_hash(const u256& h, bool& ok, u32& marker, u32& len_words, u25
 }
 
 // far_call.rs:35-613
-ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, const u256& r15, HeavyOut& out) {
   const zkw_isa_consts ZKW_CONST_AS& K = P.consts;
   const u32 variant = ZKW_ATTR_VARIANT(d.attr);
   s.flags &= FLAG_PENDING;  // :69
@@ -1000,7 +1091,7 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
   const u32 remaining_ergs = s.ergs;
   const u32 new_code_shard = is_call_shard ? abi_shard : caller_shard;
   const u32 new_this_shard = variant == ZKW_FAR_DELEGATE ? caller_shard : new_code_shard;
-  const u32 new_base = s.mpc;  // :118
+  const u32 new_base = CF(sh, s, CF_MPC);  // :118
   u256 code_hash;
   bool map_to_trivial;
   if (new_code_shard != 0 && !P.props.zkporter_is_available) {  // :123-129
@@ -1009,7 +1100,7 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
   } else {
     LogQ q;
     q.timestamp = s.timestamp + 1;
-    q.tx_number = s.tx_number;
+    q.tx_number = CF(sh, s, CF_TX_NUMBER);
     q.aux_byte = K.storage_aux_byte;
     q.shard_id = new_code_shard;
     q.address[0] = K.deployer_address_low;
@@ -1133,7 +1224,7 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
     zkw_dev_history* hist = P.history + (u64)s.inst * P.F;
     bool fresh = true;
     u32 page = candidate_page;
-    for (u32 i = 0; i < s.n_history; i++) {
+    for (u32 i = 0; i < CF(sh, s, CF_N_HISTORY); i++) {
       if (hist[i].preimage == pre && pre != 0xffffffffu) {
         fresh = false;
         page = hist[i].page;
@@ -1146,13 +1237,13 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
     const u32 blob = P.preimages[pre].blob;
     const u32 blob_len = P.blob_dir[blob].y & 0xffffu;  // `values.len() as u16`
     if (fresh) {
-      if (s.n_history >= P.F) {
+      if (CF(sh, s, CF_N_HISTORY) >= P.F) {
         lane_fail(s, ZKW_STATUS_LIMIT);
         return;
       }
-      hist[s.n_history].preimage = pre;
-      hist[s.n_history].page = page;
-      s.n_history++;
+      hist[CF(sh, s, CF_N_HISTORY)].preimage = pre;
+      hist[CF(sh, s, CF_N_HISTORY)].page = page;
+      CF(sh, s, CF_N_HISTORY)++;
     } else {
       after_decommit += decommit_cost;  // :450-453 refund
     }
@@ -1185,10 +1276,9 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
   prev[E_HEAP_BOUND] = s.heap_bound;
   prev[E_AUX_BOUND] = s.aux_bound;
   const u32 new_static = (s.is_static | (is_static_call ? 1u : 0u)) ? 1u : 0u;
-  s.mpc += K.new_memory_pages_per_far_call;  // :503
+  CF(sh, s, CF_MPC) += K.new_memory_pages_per_far_call;  // :503
   s.cold_dirty = 1;
-  bool r15p;
-  const u256 r15 = reg_read(sh, s, 15, r15p);  // CALL_IMPLICIT_PARAMETER_REG_IDX :506-508
+  // r15 = CALL_IMPLICIT_PARAMETER_REG_IDX :506-508 (read by the caller)
   u32 next[32];
 #pragma unroll
   for (int i = 0; i < 32; i++) next[i] = 0;
@@ -1216,18 +1306,18 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
   next[E_ERGS] = passed;
   next[E_SHARDS] = new_this_shard | (caller_shard << 8) | (new_code_shard << 16);
 #pragma unroll
-  for (int i = 0; i < 4; i++) next[E_CTX + i] = variant == ZKW_FAR_DELEGATE ? prev[E_CTX + i] : s.ctx_reg[i];
+  for (int i = 0; i < 4; i++) next[E_CTX + i] = variant == ZKW_FAR_DELEGATE ? prev[E_CTX + i] : CF(sh, s, CF_CTX0 + i);
   next[E_HEAP_BOUND] = K.new_frame_memory_stipend;
   next[E_AUX_BOUND] = K.new_frame_memory_stipend;
   next[E_CODE_BLOB] = mapped_blob;
-  s.ctx_reg[0] = s.ctx_reg[1] = s.ctx_reg[2] = s.ctx_reg[3] = 0;  // :558
+  CF(sh, s, CF_CTX0 + 0) = CF(sh, s, CF_CTX0 + 1) = CF(sh, s, CF_CTX0 + 2) = CF(sh, s, CF_CTX0 + 3) = 0;  // :558
   // memory.start_global_frame (memory.rs:573-657): a fresh arena slot, pages lazily zero
-  const u32 new_slot = s.next_slot;
+  const u32 new_slot = CF(sh, s, CF_NEXT_SLOT);
   if (new_slot >= P.F) {
     lane_fail(s, ZKW_STATUS_LIMIT);
     return;
   }
-  s.next_slot++;
+  CF(sh, s, CF_NEXT_SLOT)++;
   next[E_SLOT] = new_slot;
   {
     zkw_dev_frame_meta* fm = P.frames + (u64)s.inst * P.F + new_slot;
@@ -1238,23 +1328,15 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
   }
   start_frame(P, sh, s, prev, next, true);  // :562
   if (!lane_ok(s)) return;
-  // registers :573-610
-  reg_write(sh, s, 1, fat_ptr_to_u256(abi), true);
-  u256 r2 = u256_zero();
-  r2.w[0] = (constructor_call ? 1u : 0u) | (to_system ? 2u : 0u);
-  reg_write(sh, s, 2, r2, false);
-  if (!to_system) {
-    for (u32 r = 3; r <= 12; r++) reg_write(sh, s, r, u256_zero(), false);
-  } else {
-    s.ptr_bitmap &= ~(0x3ffu << 2);  // CALL_SYSTEM_ABI_REGISTERS = 2..12: drop the pointer markers only
-  }
-  reg_write(sh, s, 13, u256_zero(), false);
-  reg_write(sh, s, 14, u256_zero(), false);
-  reg_write(sh, s, 15, u256_zero(), false);
+  // registers :573-610 (applied by the caller)
+  out.v1 = fat_ptr_to_u256(abi);
+  out.v2 = u256_zero();
+  out.v2.w[0] = (constructor_call ? 1u : 0u) | (to_system ? 2u : 0u);
+  out.action = ZKW_ACT_FAR | (to_system ? ZKW_ACT_TO_SYSTEM : 0u);
 }
 
 // ret.rs:9-265
-ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
+ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, HeavyOut& out) {
   const zkw_isa_consts ZKW_CONST_AS& K = P.consts;
   u32 variant = ZKW_ATTR_VARIANT(d.attr);
   s.flags &= FLAG_PENDING;  // :27
@@ -1315,7 +1397,7 @@ ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
   const u32 fin_eh = fin[E_EH_FLAGS] & 0xffffu;
   const u32 fin_mark = fin[E_JOURNAL_MARK];
   const u32 fin_heap_bound = s.heap_bound, fin_aux_bound = s.aux_bound;
-  storage_finish_frame(P, s, fin_mark, panicked);
+  storage_finish_frame(P, sh, s, fin_mark, panicked);
   {
     uint4* a = aux_alloc(P, sh, s, ZKW_AUX_FRAME_FINISH, panicked ? 1u : 0u, 0, 0, 0);
     if (a) {
@@ -1329,13 +1411,13 @@ ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
   }
   hwm_writeback(P, s);
   s.depth--;
-  frame_load(P, s);
+  frame_load(P, sh, s);
   to_label = to_label && local;  // :202
   if (!local) {  // :204-236; memory.finish_global_frame (memory.rs:660-758) is pure bookkeeping here: arena slots are never recycled
-    reg_write(sh, s, 1, fat_ptr_to_u256(ptr), true);
-    for (u32 r = 2; r <= 15; r++) reg_write(sh, s, r, u256_zero(), false);
-    if (s.ctx_reg[0] | s.ctx_reg[1] | s.ctx_reg[2] | s.ctx_reg[3]) s.cold_dirty = 1;
-    s.ctx_reg[0] = s.ctx_reg[1] = s.ctx_reg[2] = s.ctx_reg[3] = 0;
+    out.v1 = fat_ptr_to_u256(ptr);
+    out.action = ZKW_ACT_RET;
+    if (CF(sh, s, CF_CTX0 + 0) | CF(sh, s, CF_CTX0 + 1) | CF(sh, s, CF_CTX0 + 2) | CF(sh, s, CF_CTX0 + 3)) s.cold_dirty = 1;
+    CF(sh, s, CF_CTX0 + 0) = CF(sh, s, CF_CTX0 + 1) = CF(sh, s, CF_CTX0 + 2) = CF(sh, s, CF_CTX0 + 3) = 0;
   }
   s.ergs += ergs_remaining;  // :243
   if (to_label) s.pc = label_pc;
@@ -1356,13 +1438,18 @@ ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps) {
 // ---------------------------------------------------------------------------------------------
 #include "zkw_precompiles.hip.h"
 
+// wave-uniform value that reached a function through a (vector) argument register: back into a scalar register
+ZD u32 zkw_uniform(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
+
 // The precompile bodies (Keccak-f state of 50 VGPRs, SHA-256 schedule, secp256k1) are compiled as ONE out-of-line
-// function that takes and returns the lane state by value.  Inlined, their register demand made the allocator park the
-// hot per-cycle state in AGPRs for the whole kernel (256 VGPR + 256 AGPR, ~1000 v_accvgpr_read in the code, a reload
-// per use); out of line, the cycle loop itself fits 254 VGPRs with no AGPR traffic and only the lanes that execute a
-// precompile call pay for the call (profiles/r01_kernel_variants.md).
-__device__ __noinline__ Lane zkw_precompile_entry(const zkw_kparams ZKW_CONST_AS* Pp, Shared sh, Lane s, LogQ q, u32 which) {
+// function that takes and returns the lane state by value (the wave's Shared view is rebuilt from the uniform wave
+// coordinates instead of being passed through ~30 vector argument registers).
+__device__ __noinline__ Lane zkw_precompile_entry(const zkw_kparams ZKW_CONST_AS* Pp, u32 dbg, u32 wib, Lane s, LogQ q, u32 which) {
   ZKW_KP P = *Pp;
+  Shared sh;
+  s.wave = zkw_uniform(s.wave);
+  shared_setup(sh, P, zkw_uniform(dbg), zkw_uniform(wib), s.wave, false);
+  which = zkw_uniform(which);
   if (which == 0) precompile_keccak256(P, sh, s, q);
   else if (which == 1) precompile_sha256(P, sh, s, q);
   else precompile_ecrecover(P, sh, s, q);
@@ -1377,8 +1464,38 @@ ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   if (addr_low == P.consts.keccak_precompile_address) which = 0;
   else if (addr_low == P.consts.sha256_precompile_address) which = 1;
   else if (addr_low == P.consts.ecrecover_precompile_address) which = 2;
-  // anything else behaves as an unknown precompile: no memory traffic
-  if (which < 3) s = zkw_precompile_entry(&P, sh, s, q, which);
+  // anything else behaves as an unknown precompile: no memory traffic.  The lanes of a group may call different
+  // precompiles (the address is per lane): one call per kind present.
+  for (u32 k = 0; k < 3; k++) {
+    if (which == k) {
+      s = zkw_precompile_entry(&P, sh.debug_flags, sh.wib, s, q, k);
+    }
+  }
+}
+
+// One out-of-line function for the heavy, rare opcode bodies: near_call, log (storage, events, precompile calls),
+// far_call, ret.  Inlined into the cycle loop their live ranges (two 32-dword callstack images, a 40-dword LogQuery,
+// the storage probe) would add to the 120 VGPRs of the register file and to the ~60 of the per-lane state, and the
+// kernel would not fit the 256 registers that two waves per SIMD allow.  All lanes of a call hold the same decoded
+// instruction, so `d` is made scalar again on entry.
+__device__ __noinline__ HeavyOut zkw_heavy_entry(const zkw_kparams ZKW_CONST_AS* Pp, u32 dbg, u32 wib, Lane s, Decoded d, Pre ps, u256 r15) {
+  ZKW_KP P = *Pp;
+  Shared sh;
+  s.wave = zkw_uniform(s.wave);
+  shared_setup(sh, P, zkw_uniform(dbg), zkw_uniform(wib), s.wave, false);
+  d.attr = zkw_uniform(d.attr); d.cond = zkw_uniform(d.cond); d.src0 = zkw_uniform(d.src0); d.src1 = zkw_uniform(d.src1);
+  d.dst0 = zkw_uniform(d.dst0); d.dst1 = zkw_uniform(d.dst1); d.imm0 = zkw_uniform(d.imm0); d.imm1 = zkw_uniform(d.imm1);
+  HeavyOut out;
+  out.v1 = u256_zero();
+  out.v2 = u256_zero();
+  out.action = 0;
+  const u32 opcode = ZKW_ATTR_OPCODE(d.attr);
+  if (opcode == ZKW_OP_LOG) op_log(P, sh, s, d, ps, out);
+  else if (opcode == ZKW_OP_NEAR_CALL) op_near_call(P, sh, s, d, ps);
+  else if (opcode == ZKW_OP_FAR_CALL) op_far_call(P, sh, s, d, ps, r15, out);
+  else op_ret(P, sh, s, d, ps, out);
+  out.s = s;
+  return out;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1401,7 +1518,7 @@ ZD bool condition_resolved(u32 cond, u32 flags) {
 // depends on the opcode, the addressing modes or the register indices is a scalar branch; only the data
 // path (256-bit values, sp, ergs, memory addresses) is per lane.
 // ---------------------------------------------------------------------------------------------
-ZD void exec_decoded(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d) {
+ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d) {
   const u32 opcode = ZKW_ATTR_OPCODE(d.attr);
   const u32 props = ZKW_ATTR_PROPS(d.attr);
   const bool set_flags = ZKW_ATTR_FLAGS(d.attr) & 1u;
@@ -1412,9 +1529,9 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d) {
   u32 sp = s.sp;
   // all register-file reads of the cycle are issued back to back (one LDS round trip instead of three)
   bool src0_reg_ptr, dummy_ptr;
-  const u256 src0_reg = reg_read(sh, s, d.src0, src0_reg_ptr);
-  ps.src1 = reg_read(sh, s, d.src1, ps.src1_ptr);  // :339
-  const u256 dst0_reg = ZKW_ATTR_DST0(d.attr) == ZKW_MODE_REG ? u256_zero() : reg_read(sh, s, d.dst0, dummy_ptr);  // only addressing modes use it
+  const u256 src0_reg = reg_read(sh, rf, s, d.src0, src0_reg_ptr);
+  ps.src1 = reg_read(sh, rf, s, d.src1, ps.src1_ptr);  // :339
+  const u256 dst0_reg = ZKW_ATTR_DST0(d.attr) == ZKW_MODE_REG ? u256_zero() : reg_read(sh, rf, s, d.dst0, dummy_ptr);  // only addressing modes use it
   Operand src0_loc = compute_address(P, s, sp, src0_reg, d.imm0, ZKW_ATTR_SRC0(d.attr), false);
   ps.dst0 = compute_address(P, s, sp, dst0_reg, d.imm1, ZKW_ATTR_DST0(d.attr), true);
   s.sp = sp;                                            // :297
@@ -1475,7 +1592,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d) {
         const u256 r = opcode == ZKW_OP_ADD ? u256_add(ps.src0, ps.src1, of) : u256_sub(ps.src0, ps.src1, of);
         const bool eq = u256_is_zero(r);
         if (set_flags) set_flags3(s, of, eq, !eq && !of);
-        dst0_update(P, sh, s, ps.dst0, d.dst0, r, false);
+        dst0_update(P, sh, rf, s, ps.dst0, d.dst0, r, false);
         break;
       }
       case ZKW_OP_MUL: {  // mul.rs:35-65
@@ -1486,22 +1603,22 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d) {
           const bool of = !u256_is_zero(hi), eq = u256_is_zero(lo);
           set_flags3(s, of, eq, !of && !eq);
         }
-        dst0_update(P, sh, s, ps.dst0, d.dst0, lo, false);
-        reg_write(sh, s, d.dst1, hi, false);
+        dst0_update(P, sh, rf, s, ps.dst0, d.dst0, lo, false);
+        reg_write(sh, rf, s, d.dst1, hi, false);
         break;
       }
       case ZKW_OP_DIV: {  // div.rs:35-75
         s.pc = ps.new_pc;
         if (u256_is_zero(ps.src1)) {
           if (set_flags) set_flags3(s, true, false, false);
-          dst0_update(P, sh, s, ps.dst0, d.dst0, u256_zero(), false);
-          reg_write(sh, s, d.dst1, u256_zero(), false);
+          dst0_update(P, sh, rf, s, ps.dst0, d.dst0, u256_zero(), false);
+          reg_write(sh, rf, s, d.dst1, u256_zero(), false);
         } else {
           u256 q, r;
           u256_divmod(ps.src0, ps.src1, q, r);
           if (set_flags) set_flags3(s, false, u256_is_zero(q), u256_is_zero(r));
-          dst0_update(P, sh, s, ps.dst0, d.dst0, q, false);
-          reg_write(sh, s, d.dst1, r, false);
+          dst0_update(P, sh, rf, s, ps.dst0, d.dst0, q, false);
+          reg_write(sh, rf, s, d.dst1, r, false);
         }
         break;
       }
@@ -1521,7 +1638,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d) {
           if (cyclic) r = u256_or(r, u256_shr(ps.src0, 256u - n));
         }
         if (set_flags) set_flags3(s, false, u256_is_zero(r), false);
-        dst0_update(P, sh, s, ps.dst0, d.dst0, r, false);
+        dst0_update(P, sh, rf, s, ps.dst0, d.dst0, r, false);
         break;
       }
       case ZKW_OP_BINOP: {  // binop.rs:42-61
@@ -1529,16 +1646,34 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d) {
         const u32 v = ZKW_ATTR_VARIANT(d.attr);
         const u256 r = v == ZKW_BINOP_XOR ? u256_xor(ps.src0, ps.src1) : (v == ZKW_BINOP_AND ? u256_and(ps.src0, ps.src1) : u256_or(ps.src0, ps.src1));
         if (set_flags) set_flags3(s, false, u256_is_zero(r), false);
-        dst0_update(P, sh, s, ps.dst0, d.dst0, r, false);
+        dst0_update(P, sh, rf, s, ps.dst0, d.dst0, r, false);
         break;
       }
-      case ZKW_OP_CONTEXT: op_context(P, sh, s, d, ps); break;
-      case ZKW_OP_PTR: op_ptr(P, sh, s, d, ps); break;
-      case ZKW_OP_LOG: op_log(P, sh, s, d, ps); break;
-      case ZKW_OP_NEAR_CALL: op_near_call(P, sh, s, d, ps); break;
-      case ZKW_OP_FAR_CALL: op_far_call(P, sh, s, d, ps); break;
-      case ZKW_OP_RET: op_ret(P, sh, s, d, ps); break;
-      case ZKW_OP_UMA: op_uma(P, sh, s, d, ps); break;
+      case ZKW_OP_CONTEXT: op_context(P, sh, rf, s, d, ps); break;
+      case ZKW_OP_PTR: op_ptr(P, sh, rf, s, d, ps); break;
+      case ZKW_OP_LOG:
+      case ZKW_OP_NEAR_CALL:
+      case ZKW_OP_FAR_CALL:
+      case ZKW_OP_RET: {  // out of line; what they write to registers comes back as actions
+        const u256 r15 = opcode == ZKW_OP_FAR_CALL ? rf_get(rf, 15) : u256_zero();
+        const HeavyOut out = zkw_heavy_entry(&P, sh.debug_flags, sh.wib, s, d, ps, r15);
+        s = out.s;
+        if (out.action & ZKW_ACT_DST0) dst0_update(P, sh, rf, s, ps.dst0, d.dst0, out.v1, false);
+        if (out.action & (ZKW_ACT_FAR | ZKW_ACT_RET)) {
+          reg_write(sh, rf, s, 1, out.v1, true);
+          reg_write(sh, rf, s, 2, out.v2, false);  // ret: zero
+          if (out.action & ZKW_ACT_TO_SYSTEM) {
+            s.ptr_bitmap &= ~(0x3ffu << 2);  // CALL_SYSTEM_ABI_REGISTERS = 2..12: drop the pointer markers only
+          } else {
+#pragma unroll
+            for (u32 r = 3; r <= 12; r++) reg_write(sh, rf, s, r, u256_zero(), false);
+          }
+#pragma unroll
+          for (u32 r = 13; r <= 15; r++) reg_write(sh, rf, s, r, u256_zero(), false);
+        }
+        break;
+      }
+      case ZKW_OP_UMA: op_uma(P, sh, rf, s, d, ps); break;
       default: lane_fail(s, ZKW_STATUS_REFERENCE_PANIC); break;  // Opcode::Invalid => unreachable!() parsing.rs:77
     }
   }
@@ -1551,7 +1686,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d) {
 // moment it LEAVES the cycle loop, from inside the loop: nothing of the lane state is then live after the loop, so the
 // compiler does not have to keep a per-iteration copy of ~30 registers for the lanes that have already left
 // (a loop with divergent exits preserves every live-out value of the exited lanes on each iteration).
-ZD void lane_writeback(ZKW_KP P, Shared& sh, Lane& s) {
+ZD void lane_writeback(ZKW_KP P, Shared& sh, const RegFile& rf, Lane& s) {
   const u32 tid = s.lane;
   if (s.status == ZKW_STATUS_RUNNING && s.depth == 0) s.status = ZKW_STATUS_ENDED;  // execution_has_ended() (mod.rs:96-98)
   frame_writeback(P, s);
@@ -1564,47 +1699,36 @@ ZD void lane_writeback(ZKW_KP P, Shared& sh, Lane& s) {
     sc.prev_code_word[2 * i + 1] = v.y;
   }
 #pragma unroll
-  for (int i = 0; i < 4; i++) sc.ctx_u128_reg[i] = s.ctx_reg[i];
+  for (int i = 0; i < 4; i++) sc.ctx_u128_reg[i] = CF(sh, s, CF_CTX0 + i);
   sc.ptr_bitmap = s.ptr_bitmap; sc.flags = s.flags; sc.prev_code_page = s.prev_code_page; sc.timestamp = s.timestamp;
-  sc.cycle_counter = s.cycle_counter; sc.spent_pubdata = s.spent_pubdata; sc.memory_page_counter = s.mpc;
-  sc.absolute_execution_step = P.scalars[s.inst].absolute_execution_step; sc.ergs_per_pubdata = s.ergs_pp; sc.tx_number = s.tx_number;
-  sc.prev_super_pc = s.prev_super_pc; sc.depth = s.depth; sc.status = s.status; sc.n_cycles = s.n_cycles; sc.first_dynamic_page = s.first_dyn;
-  sc.n_initial_slots = s.n_initial_slots; sc.next_slot = s.next_slot; sc.journal_len = s.journal_len; sc.n_history = s.n_history;
+  sc.cycle_counter = s.cycle_counter; sc.spent_pubdata = CF(sh, s, CF_SPENT_PUBDATA); sc.memory_page_counter = CF(sh, s, CF_MPC);
+  sc.absolute_execution_step = P.scalars[s.inst].absolute_execution_step; sc.ergs_per_pubdata = CF(sh, s, CF_ERGS_PP); sc.tx_number = CF(sh, s, CF_TX_NUMBER);
+  sc.prev_super_pc = s.prev_super_pc; sc.depth = s.depth; sc.status = s.status; sc.n_cycles = s.n_cycles; sc.first_dynamic_page = CF(sh, s, CF_FIRST_DYN);
+  sc.n_initial_slots = CF(sh, s, CF_N_INITIAL_SLOTS); sc.next_slot = CF(sh, s, CF_NEXT_SLOT); sc.journal_len = CF(sh, s, CF_JOURNAL_LEN); sc.n_history = CF(sh, s, CF_N_HISTORY);
   sc.reserved[0] = 0;
   P.scalars[s.inst] = sc;
-  uint4* rg = P.regs + (u64)s.wave * ZKW_REG_CHUNKS * sh.L;
-#pragma unroll 6
-  for (int c = 0; c < ZKW_REG_CHUNKS; c++) rg[(u64)c * sh.L + tid] = sh_reg(sh, c, tid);
+  uint4* rg = P.regs + (u64)s.wave * ZKW_REG_CHUNKS * sh.L + tid;
+  for (u32 r = 0; r < ZKW_REGISTERS_COUNT; r++) {
+    const u256 v = rf_get(rf, r + 1);
+    rg[(u64)(2 * r) * sh.L] = u256_lo4(v);
+    rg[(u64)(2 * r + 1) * sh.L] = u256_hi4(v);
+  }
 }
 
-__global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kernel(zkw_launch_args A) {
-  extern __shared__ uint4 zkw_lds[];
-#ifdef ZKW_PROFILE
-  const unsigned long long zp_k0 = __builtin_readcyclecounter();
+// compiled for 128 vector registers (v0..v127); v128..v255 hold the register file (see RegFile): 256 in all = two waves per SIMD
+#ifndef ZKW_MIN_WAVES_PER_SIMD
+#define ZKW_MIN_WAVES_PER_SIMD 4
 #endif
+__global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_PER_SIMD) zkw_cycle_kernel(zkw_launch_args A) {
   ZKW_KP P = *(const zkw_kparams ZKW_CONST_AS*)A.kp[blockIdx.y];
-  // one wave = one independent group of L VM instances; ZKW_WAVES_PER_GROUP waves per workgroup (one per SIMD)
-  // share the ISA table so that four of them fit the 160 KB of a CU
+  // one wave = one independent group of L VM instances; ZKW_WAVES_PER_GROUP waves per workgroup share the ISA table
   const u32 tid = threadIdx.x % P.wave_threads;
   const u32 wib = threadIdx.x / P.wave_threads;
   const u32 wave = blockIdx.x * P.waves_per_group + wib;
   Shared sh;
-  sh.L = P.L;
-  sh.debug_flags = A.debug_flags;
-  sh.F = P.F; sh.S = P.S; sh.H = P.H; sh.A = P.A; sh.cap_mem = P.cap_mem;
-  sh.stack_vals = P.stack_vals; sh.stack_ptrs = P.stack_ptrs; sh.heap = P.heap; sh.aux_heap = P.aux_heap; sh.blob_words = P.blob_words;
-  ZKW_PIN_SGPR(sh.L); ZKW_PIN_SGPR(sh.F); ZKW_PIN_SGPR(sh.S); ZKW_PIN_SGPR(sh.H); ZKW_PIN_SGPR(sh.A); ZKW_PIN_SGPR(sh.cap_mem);
-  ZKW_PIN_SGPR(sh.stack_vals); ZKW_PIN_SGPR(sh.stack_ptrs); ZKW_PIN_SGPR(sh.heap); ZKW_PIN_SGPR(sh.aux_heap); ZKW_PIN_SGPR(sh.blob_words);
+  shared_setup(sh, P, A.debug_flags, wib, wave, true);
   u32 run_cycles = A.run_cycles, time_delta = P.consts.time_delta_per_cycle, cap_delta = P.cap_delta, max_depth = P.consts.vm_max_stack_depth;
   ZKW_PIN_SGPR(run_cycles); ZKW_PIN_SGPR(time_delta); ZKW_PIN_SGPR(cap_delta); ZKW_PIN_SGPR(max_depth);
-  sh.isa = (uint2*)zkw_lds;                                                        // 16 KB
-  sh.cursor = (u32*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + wib * (1 + ZKW_REG_CHUNKS * P.L));  // 16 B
-  sh.regs = (uint4*)sh.cursor + 1;                                                  // 30 * L * 16 B
-  sh.pcw = (uint2*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + P.waves_per_group * (1 + ZKW_REG_CHUNKS * P.L)) + wib * 4 * P.L;  // 4 * L * 8 B
-  sh.krow = P.krow + (u64)wave * ZKW_KROW_WORDS * P.L;
-  sh.mem_base = P.mem_stream + (u64)wave * P.cap_mem * 3;
-  sh.log_base = P.log_stream + (u64)wave * P.cap_log * 8;
-  sh.aux_base = P.aux_stream + (u64)wave * P.cap_aux * 16;
   // stage the packed ISA table in LDS (all threads of the workgroup, 16 B each per step)
   {
     const uint4* src = (const uint4*)P.isa;
@@ -1623,22 +1747,23 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   s.inst = inst;
   s.wave = wave;
   s.lane = tid;
+  RegFile rf;
+  rf_init(rf);
   if (exists) {
     const zkw_dev_scalars sc = P.scalars[inst];
 #pragma unroll
     for (int i = 0; i < 4; i++) sh.pcw[i * P.L + tid] = make_uint2(sc.prev_code_word[2 * i], sc.prev_code_word[2 * i + 1]);
 #pragma unroll
-    for (int i = 0; i < 4; i++) s.ctx_reg[i] = sc.ctx_u128_reg[i];
+    for (int i = 0; i < 4; i++) CF(sh, s, CF_CTX0 + i) = sc.ctx_u128_reg[i];
     s.ptr_bitmap = sc.ptr_bitmap; s.flags = sc.flags; s.prev_code_page = sc.prev_code_page; s.timestamp = sc.timestamp;
-    s.cycle_counter = sc.cycle_counter; s.spent_pubdata = sc.spent_pubdata; s.mpc = sc.memory_page_counter; s.ergs_pp = sc.ergs_per_pubdata;
-    s.tx_number = sc.tx_number; s.prev_super_pc = sc.prev_super_pc; s.depth = sc.depth; s.status = sc.status; s.n_cycles = sc.n_cycles;
-    s.first_dyn = sc.first_dynamic_page; s.n_initial_slots = sc.n_initial_slots; s.next_slot = sc.next_slot; s.journal_len = sc.journal_len;
-    s.n_history = sc.n_history;
-    frame_load(P, s);
-    // register file -> LDS
-    const uint4* rg = P.regs + (u64)wave * ZKW_REG_CHUNKS * P.L;
-#pragma unroll 6
-    for (int c = 0; c < ZKW_REG_CHUNKS; c++) sh_reg(sh, c, tid) = rg[(u64)c * P.L + tid];
+    s.cycle_counter = sc.cycle_counter; CF(sh, s, CF_SPENT_PUBDATA) = sc.spent_pubdata; CF(sh, s, CF_MPC) = sc.memory_page_counter; CF(sh, s, CF_ERGS_PP) = sc.ergs_per_pubdata;
+    CF(sh, s, CF_TX_NUMBER) = sc.tx_number; s.prev_super_pc = sc.prev_super_pc; s.depth = sc.depth; s.status = sc.status; s.n_cycles = sc.n_cycles;
+    CF(sh, s, CF_FIRST_DYN) = sc.first_dynamic_page; CF(sh, s, CF_N_INITIAL_SLOTS) = sc.n_initial_slots; CF(sh, s, CF_NEXT_SLOT) = sc.next_slot; CF(sh, s, CF_JOURNAL_LEN) = sc.journal_len;
+    CF(sh, s, CF_N_HISTORY) = sc.n_history;
+    frame_load(P, sh, s);
+    // register file -> v136..v255
+    const uint4* rg = P.regs + (u64)wave * ZKW_REG_CHUNKS * P.L + tid;
+    for (u32 r = 0; r < ZKW_REGISTERS_COUNT; r++) rf_set(rf, r + 1, u256_from_uint4(rg[(u64)(2 * r) * P.L], rg[(u64)(2 * r + 1) * P.L]));
   } else {
     s.status = ZKW_STATUS_ENDED;  // parked lane
     s.depth = 0;
@@ -1655,26 +1780,13 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
   // an `if (active)` region of every iteration (whose merge points cost ~75 register copies per VM cycle).
   u32 k = 0;
   u32 delta_cur = ZKW_LDS_WORD(sh.cursor)[3];
-#ifdef ZKW_PROFILE  // profiling build only (profiles/tools/phase_profile.sh): shader-clock time of the phases of a VM cycle
-  unsigned long long zp_t[6] = {0, 0, 0, 0, 0, 0}, zp_last = 0;
-  __shared__ unsigned long long zp_op[ZKW_WAVES_PER_GROUP][16][2];  // per opcode: clocks, group iterations
-  for (u32 i = tid; i < 32; i += P.wave_threads) (&zp_op[wib][0][0])[i] = 0;
-  if (threadIdx.x < 12) zp_mark[threadIdx.x] = 0;
-#define ZKW_PHASE(i) { const unsigned long long zp_now = __builtin_readcyclecounter(); zp_t[i] += zp_now - zp_last; zp_last = zp_now; }
-#else
-#define ZKW_PHASE(i)
-#endif
   uint2 next_slot = make_uint2(0, 0), next_e = make_uint2(0, 0);
   if (exists) {
     next_slot = sh.pcw[(3u - (s.pc & 3u)) * sh.L + tid];
     next_e = sh.isa[next_slot.x & (ZKW_ISA_TABLE_SIZE - 1)];
   }
-  if (exists && !(s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0)) lane_writeback(P, sh, s);  // does not cycle
+  if (exists && !(s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0)) lane_writeback(P, sh, rf, s);  // does not cycle
   if (exists && s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0) {
-#ifdef ZKW_PROFILE
-    zp_last = __builtin_readcyclecounter();
-    zp_t[4] = zp_last - zp_k0;  // prologue: ISA table staging, state load
-#endif
     for (;;) {
       // directory: stream cursors at the start of wave-cycle (cycle_base + k).  Read here (one broadcast 16-B LDS read),
       // stored by the first remaining lane after the fetch below, so that the LDS latency hides behind it.  The
@@ -1724,7 +1836,6 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
       // Lanes whose decode raises an exception (masked into panic, cycle.rs:187-190) or whose condition
       // fails (masked into nop, :212-217) are served by extra passes with the panic / nop variant.
       // ----------------------------------------------------------------------------------------
-      ZKW_PHASE(0)  // fetch + directory
       u32 enc_lo = (u32)enc, enc_hi = (u32)(enc >> 32);
       bool charged = false;  // price taken and exceptions / condition resolved for this lane (once per cycle)
       u64 todo = __ballot(1);
@@ -1757,25 +1868,15 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
           }
         }
         todo &= ~__ballot(mine);
-#ifdef ZKW_PROFILE
-        const unsigned long long zp_g0 = __builtin_readcyclecounter();
-#endif
         if (mine) {
           Decoded d;
           d.attr = u_attr;
           d.cond = (u_lo >> 13) & 7u; d.src0 = (u_lo >> 16) & 15u; d.src1 = (u_lo >> 20) & 15u; d.dst0 = (u_lo >> 24) & 15u; d.dst1 = u_lo >> 28;
           d.imm0 = u_hi & 0xffffu; d.imm1 = u_hi >> 16;
           if (A.debug_flags & 8u) s.pc = (s.pc + 1u) & 0xffffu;  // profiling ablation: no operand / opcode work
-          else exec_decoded(P, sh, s, d);
+          else exec_decoded(P, sh, rf, s, d);
         }
-#ifdef ZKW_PROFILE
-        if (tid == (u32)__ffsll((long long)__ballot(1)) - 1u) {
-          zp_op[wib][ZKW_ATTR_OPCODE(u_attr) & 15u][0] += __builtin_readcyclecounter() - zp_g0;
-          zp_op[wib][ZKW_ATTR_OPCODE(u_attr) & 15u][1] += 1;
-        }
-#endif
       }
-      ZKW_PHASE(1)  // group loop: decode, operands, opcode body, destination writes
       // prefetch for the next cycle (used only if that cycle does not fetch a new code word): its opcode slot of the
       // current word and the ISA entry of that opcode — two chained LDS reads that complete behind the record stores
       next_slot = sh.pcw[(3u - (s.pc & 3u)) * sh.L + tid];
@@ -1787,48 +1888,64 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
         s.timestamp += time_delta;
         s.cycle_counter += 1;
         if (s.cold_dirty) {
-          uint4* a = aux_alloc(P, sh, s, ZKW_AUX_COLD_STATE, 0, s.spent_pubdata, s.ergs_pp, s.tx_number);
+          uint4* a = aux_alloc(P, sh, s, ZKW_AUX_COLD_STATE, 0, CF(sh, s, CF_SPENT_PUBDATA), CF(sh, s, CF_ERGS_PP), CF(sh, s, CF_TX_NUMBER));
           if (a) {
-            a[1] = make_uint4(s.ctx_reg[0], s.ctx_reg[1], s.ctx_reg[2], s.ctx_reg[3]);
-            a[2] = make_uint4(s.mpc, 0, 0, 0);
+            a[1] = make_uint4(CF(sh, s, CF_CTX0 + 0), CF(sh, s, CF_CTX0 + 1), CF(sh, s, CF_CTX0 + 2), CF(sh, s, CF_CTX0 + 3));
+            a[2] = make_uint4(CF(sh, s, CF_MPC), 0, 0, 0);
 #pragma unroll
             for (int i = 3; i < 16; i++) a[i] = make_uint4(0, 0, 0, 0);
           }
         }
       }
-      ZKW_PHASE(2)  // prefetch + end-of-cycle bookkeeping
       if (lane_ok(s) && (A.debug_flags & 1u)) s.n_cycles++;
       if (!(A.debug_flags & 1u)) {
         // CycleRecord, delta form: the 512-byte snapshot the tracer observes (15 registers + 32-byte tail) is emitted as
         // the tail (dense [cycle][lane], coalesced) plus the 32-byte values of the registers THIS cycle wrote, compacted
-        // per wave.  Delta j of a lane sits at base + (number of lanes with more than j' deltas, summed over j' < j) +
-        // (rank of the lane among the lanes with more than j deltas): no tags and no atomics — the host (and any
-        // consumer) recomputes the positions from the dirty masks in the tails and rebuilds the snapshots from the
-        // initial register file.  A cycle writes one register on average, so this is ~70 B instead of 512 B.
+        // per wave.  The delta of register r of a lane sits at base + (deltas of registers below r in this wave-cycle) +
+        // (rank of the lane among the lanes that wrote r): no tags and no atomics — the host (and any consumer)
+        // recomputes the positions from the dirty masks in the tails and rebuilds the snapshots from the initial
+        // register file.  A cycle writes one register on average, so this is ~70 B instead of 512 B.
+        // Order inside a wave-cycle: by register (ascending), lanes in lane order within a register — the register
+        // index of a store is then wave-uniform (the values come straight from the VGPR register file).
         const bool ok = lane_ok(s);
-        const u32 n_dirty = ok ? (u32)__popcll((u64)s.reg_dirty) : 0u;
-        u32 total = 0;
-        for (u32 j = 0; j < ZKW_REGISTERS_COUNT; j++) {
-          const u32 cj = (u32)__popcll(__ballot(n_dirty > j));
-          if (cj == 0) break;
-          total += cj;
+        const u32 dm = ok ? s.reg_dirty : 0u;
+        // union of the lanes' dirty masks and the number of deltas of this wave-cycle; a shared tape makes all masks equal
+        const u32 dm0 = (u32)__builtin_amdgcn_readfirstlane((int)dm);
+        u32 any, total;
+        if (__ballot(dm != dm0) == 0) {
+          any = dm0;
+          total = (u32)__popcll((u64)dm0) * (u32)__popcll(__ballot(true));
+        } else {
+          any = 0;
+          total = 0;
+#pragma unroll
+          for (u32 r = 0; r < ZKW_REGISTERS_COUNT; r++) {
+            const u32 c = (u32)__popcll(__ballot((dm >> r) & 1u));
+            total += c;
+            any |= c ? 1u << r : 0u;
+          }
         }
         const u32 base = delta_cur;
         const bool fits = base + total <= cap_delta;  // wave-uniform: either every lane's deltas fit or none are written
         if (ok && !fits) lane_fail(s, ZKW_STATUS_LIMIT);
-        if (ok && fits) {
+        if (fits) {
           uint4* dl = delta_base;
-          u32 m = s.reg_dirty, before = 0;
-          for (u32 j = 0; j < n_dirty; j++) {
-            const u64 part = __ballot(true);  // the lanes with more than j deltas (this loop runs n_dirty times per lane)
-            const u32 r = (u32)__ffsll((long long)m) - 1u;
-            m &= m - 1u;
-            const u32 pos = base + before + (u32)__popcll(part & ((1ull << tid) - 1ull));
-            before += (u32)__popcll(part);
-            // two planes (low / high 16 bytes) so that each store instruction covers whole 64-byte lines
-            zkw_stream_store(dl + (u64)pos, sh_reg(sh, 2 * r, tid));
-            zkw_stream_store(dl + (u64)cap_delta + pos, sh_reg(sh, 2 * r + 1, tid));
+          u32 pos = base;
+          for (u32 left = any; left; left &= left - 1u) {  // scalar loop over the registers written in this wave-cycle
+            const u32 r = (u32)__ffsll((long long)left) - 1u;
+            const bool has = (dm >> r) & 1u;
+            const u64 part = __ballot(has);
+            if (has) {
+              const u256 v = rf_get(rf, r + 1u);
+              const u32 at = pos + (u32)__popcll(part & ((1ull << tid) - 1ull));
+              // two planes (low / high 16 bytes) so that each store instruction covers whole 64-byte lines
+              zkw_stream_store(dl + (u64)at, u256_lo4(v));
+              zkw_stream_store(dl + (u64)cap_delta + at, u256_hi4(v));
+            }
+            pos += (u32)__popcll(part);
           }
+        }
+        if (ok && fits) {
           const u32 cnt = (s.n_mem > 255u ? 255u : s.n_mem) | ((s.n_log > 255u ? 255u : s.n_log) << 8) | ((s.n_aux > 255u ? 255u : s.n_aux) << 16);
           // dirty mask: bits 0-7 in the tail's reserved byte, bits 8-14 in the top byte of the event counts
           zkw_stream_store(tail_ptr, make_uint4((s.ptr_bitmap & 0xffffu) | ((s.flags & 0xfu) << 16) | ((s.reg_dirty & 0xffu) << 24),
@@ -1843,31 +1960,16 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP) zkw_cycle_kern
           if (tid == (u32)__ffsll((long long)__ballot(true)) - 1u) ZKW_LDS_WORD(sh.cursor)[3] = delta_cur;
         }
       }
-      ZKW_PHASE(3)  // CycleRecord: delta ranks, delta + tail stores
       k++;
       dir_ptr += 4;
       tail_ptr += tail_step;
       // leave: failed / out of cycles / execution_has_ended() (mod.rs:96-98: callers stop cycling at depth 0)
       if (!lane_ok(s) || k >= run_cycles || s.depth == 0) {
-#ifdef ZKW_PROFILE
-        zp_last = __builtin_readcyclecounter();
-#endif
-        lane_writeback(P, sh, s);
-#ifdef ZKW_PROFILE
-        zp_t[5] = __builtin_readcyclecounter() - zp_last;  // state write-back
-#endif
+        lane_writeback(P, sh, rf, s);
         break;
       }
     }
   }
-#ifdef ZKW_PROFILE
-  if (blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0)
-    printf("ZKW_PROFILE wave-cycles %u: fetch %llu group %llu eoc %llu record %llu; prologue %llu write-back %llu (shader clocks)\n", k, zp_t[0], zp_t[1], zp_t[2], zp_t[3], zp_t[4], zp_t[5]);
-  if (blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0)
-    printf("ZKW_PROFILE uma marks: pre %llu reads %llu rd-shift %llu wr-shift %llu writes %llu dst %llu\n", zp_mark[1], zp_mark[2], zp_mark[3], zp_mark[4], zp_mark[5], zp_mark[6]);
-  if (blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x < 16 && zp_op[0][threadIdx.x][1])
-    printf("ZKW_PROFILE opcode %u: %llu group iterations, %llu clocks each\n", threadIdx.x, zp_op[0][threadIdx.x][1], zp_op[0][threadIdx.x][0] / zp_op[0][threadIdx.x][1]);
-#endif
   // wave-cycles executed = the maximum over the lanes (lanes leave the loop at different iterations)
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -1962,20 +2064,30 @@ extern "C" hipError_t zkw_launch_reset_kernel(const zkw_fused_table* T, hipStrea
   return hipGetLastError();
 }
 
-// dynamic LDS per workgroup: ISA table + per wave (cursors + per-lane register file)
+// dynamic LDS per workgroup: ISA table + per wave (cursors + per-lane cold state and previous_code_word)
 extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_group) {
-  return ZKW_ISA_TABLE_SIZE * 8 + waves_per_group * (16 + L * ZKW_REG_CHUNKS * 16 + L * 32);  // + previous_code_word: 32 B per lane
+  return ZKW_ISA_TABLE_SIZE * 8 + waves_per_group * (16 + L * (ZKW_COLD_FIELDS * 4 + 32));
 }
 
 // host-callable launcher (keeps <<<>>> out of the runtime)
 extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_launch_args* A, hipStream_t stream) {
   const u32 g = A->waves_per_group;
-  static uint32_t lds_opt_in = 0;  // dynamic LDS above the 64 KB default needs an explicit opt-in, once per size
   const uint32_t lds = zkw_cycle_kernel_lds_bytes(A->max_L, g);
-  if (lds > lds_opt_in) {
-    const hipError_t e = hipFuncSetAttribute((const void*)zkw_cycle_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64u * 1024u) {
+    // dynamic LDS above the 64 KB default needs an explicit opt-in (not reached by the current layout: 41 KB per workgroup).  The
+    // attribute is per device: remember the opted-in size per device, under a lock (contexts on several devices and
+    // launches from several host threads share this function).
+    static std::mutex mu;
+    static uint32_t opted[64] = {0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    lds_opt_in = lds;
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev < 0 || dev >= 64 || lds > opted[dev]) {
+      e = hipFuncSetAttribute((const void*)zkw_cycle_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 64) opted[dev] = lds;
+    }
   }
   hipLaunchKernelGGL(zkw_cycle_kernel, dim3((A->max_waves + g - 1) / g, A->n_batches), dim3(A->wave_threads * g), lds, stream, *A);
   return hipGetLastError();

@@ -310,6 +310,15 @@ void zkw_batch_destroy(zkw_batch* b) {
   delete b;
 }
 
+// Any change of the staged inputs (and every upload) invalidates the captured step graph: it holds the launch
+// geometry and the dynamic-LDS size of the upload it was captured under by value.
+static void invalidate_inputs(zkw_batch* b) {
+  b->uploaded = false;
+  if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
+  if (b->graph) { (void)hipGraphDestroy(b->graph); b->graph = nullptr; }
+  b->graph_failed = false;
+}
+
 int zkw_batch_add_code_blob(zkw_batch* b, const zkw_u256* words, uint32_t n_words, uint32_t* blob_id) {
   if (!b || !blob_id || (n_words && !words)) return ZKW_ERR_INVALID;
   if (n_words > (1u << 16)) {  // MAX_CODE_PAGE_SIZE_IN_WORDS (memory.rs:276)
@@ -318,7 +327,7 @@ int zkw_batch_add_code_blob(zkw_batch* b, const zkw_u256* words, uint32_t n_word
   }
   b->blobs.emplace_back(words, words + n_words);
   *blob_id = (uint32_t)b->blobs.size() - 1;
-  b->uploaded = false;
+  invalidate_inputs(b);
   return ZKW_OK;
 }
 
@@ -330,14 +339,14 @@ int zkw_batch_add_decommit_preimage(zkw_batch* b, const zkw_u256* hash, uint32_t
       return ZKW_ERR_INVALID;
     }
   b->preimages.emplace_back(*hash, blob_id);
-  b->uploaded = false;
+  invalidate_inputs(b);
   return ZKW_OK;
 }
 
 int zkw_batch_set_code_page(zkw_batch* b, uint32_t first, uint32_t count, uint32_t page, uint32_t blob_id) {
   if (!b || (uint64_t)first + count > b->n || blob_id >= b->blobs.size()) return ZKW_ERR_INVALID;
   for (uint32_t i = first; i < first + count; i++) b->staged[i].code_pages.emplace_back(page, blob_id);
-  b->uploaded = false;
+  invalidate_inputs(b);
   return ZKW_OK;
 }
 
@@ -358,7 +367,7 @@ int zkw_batch_set_state(zkw_batch* b, uint32_t first, uint32_t count, const zkw_
     s.inner.assign(inner + (size_t)i * inner_depth, inner + (size_t)(i + 1) * inner_depth);
     s.has_state = true;
   }
-  b->uploaded = false;
+  invalidate_inputs(b);
   return ZKW_OK;
 }
 
@@ -369,7 +378,7 @@ int zkw_batch_set_heap(zkw_batch* b, uint32_t instance, const zkw_u256* words, u
     return ZKW_ERR_LIMIT;
   }
   b->staged[instance].heap.assign(words, words + n_words);
-  b->uploaded = false;
+  invalidate_inputs(b);
   return ZKW_OK;
 }
 
@@ -380,7 +389,7 @@ int zkw_batch_set_storage(zkw_batch* b, uint32_t instance, const zkw_storage_slo
     return ZKW_ERR_LIMIT;
   }
   b->staged[instance].storage.assign(slots, slots + n_slots);
-  b->uploaded = false;
+  invalidate_inputs(b);
   return ZKW_OK;
 }
 
@@ -418,6 +427,7 @@ int zkw_batch_upload(zkw_batch* b) {
   if (!b) return ZKW_ERR_INVALID;
   zkw_ctx* c = b->ctx;
   HIP_TRY(c, hipSetDevice(c->device));
+  invalidate_inputs(b);  // a re-upload may change the geometry (wave width, wave count) a captured step graph holds by value
   for (uint32_t i = 0; i < b->n; i++)
     if (!b->staged[i].has_state) {
       c->last_error = "instance " + std::to_string(i) + " has no state (zkw_batch_set_state)";
@@ -426,14 +436,14 @@ int zkw_batch_upload(zkw_batch* b) {
   if (b->auto_L) {
     // Wave width when the caller left it to the library.  Lanes of a wave that hold different instruction words are
     // served one after the other (opcode-word grouping), so instances that were given DIFFERENT code get thin waves:
-    // as few lanes per wave as still fill the chip's wave slots once (4 per CU).  Measured with 4096 different
+    // as few lanes per wave as still fill the chip's wave slots once (8 per CU: two waves per SIMD).  Measured with 4096 different
     // arithmetic tapes (profiles/tools/divergent_tapes.py): 28 M cycles/s with 64-lane waves, 284 M with 4-lane waves.
     // Instances that share their code keep full waves.
     bool same_code = true;
     for (uint32_t i = 1; i < b->n && same_code; i++) same_code = b->staged[i].code_pages == b->staged[0].code_pages;
     uint32_t L2 = pow2_ceil(std::min<uint32_t>(b->n, (uint32_t)c->wave_width));
     if (!same_code) {
-      const uint32_t slots = 4u * (uint32_t)std::max(1, c->n_cus);
+      const uint32_t slots = 8u * (uint32_t)std::max(1, c->n_cus);
       L2 = std::min<uint32_t>(L2, pow2_ceil((b->n + slots - 1) / slots));
     }
     b->L = L2;
@@ -1110,22 +1120,17 @@ static int build_wave(zkw_batch* b, uint32_t w) {
         cnt[l] = (uint32_t)__builtin_popcount(mask[l]);
         max_cnt = std::max(max_cnt, cnt[l]);
       }
-      uint32_t before = 0;
-      for (uint32_t j = 0; j < max_cnt; j++) {  // round j: the lanes with more than j deltas, in lane order
-        uint32_t rank = 0;
+      // order inside a wave-cycle: by register (ascending), lanes in lane order within a register (zkw_cycle_kernel)
+      uint32_t pos = base;
+      for (uint32_t r = 0; r < ZKW_REGISTERS_COUNT && max_cnt; r++) {
         for (uint32_t l = 0; l < L; l++) {
-          if (cnt[l] <= j) continue;
-          uint32_t m = mask[l];
-          for (uint32_t skip = 0; skip < j; skip++) m &= m - 1;
-          const uint32_t r = (uint32_t)__builtin_ctz(m);
-          const uint32_t pos = base + before + rank;
+          if (!((mask[l] >> r) & 1u)) continue;
           if (pos < n_delta) {
             cur[l][2 * r] = deltas[(size_t)pos];
             cur[l][2 * r + 1] = deltas[(size_t)n_delta + pos];
           }
-          rank++;
+          pos++;
         }
-        before += rank;
       }
       for (uint32_t l = 0; l < L; l++) {
         if (k >= ncyc[l]) continue;
@@ -1177,7 +1182,6 @@ static int build_wave(zkw_batch* b, uint32_t w) {
         wt->aux_off[l].push_back((uint32_t)wt->aux[l].size());
       }
   }
-  if (b->wave_cache.size() >= 64) b->wave_cache.clear();
   b->wave_cache[w] = std::move(wt);
   return ZKW_OK;
 }
@@ -1402,6 +1406,10 @@ int zkw_batch_step(zkw_batch* b, uint32_t max_cycles, uint32_t queue_mask, void*
   if (!b) return ZKW_ERR_INVALID;
   zkw_ctx* c = b->ctx;
   hipStream_t st = (hipStream_t)hip_stream;
+  {
+    const int grc = check_group(&b, 1);  // not uploaded / staged inputs changed since the upload: fail, never replay old inputs
+    if (grc != ZKW_OK) return grc;
+  }
   if (b->graph_exec && b->graph_cycles == max_cycles && b->graph_mask == queue_mask && b->graph_stream == st) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipGraphLaunch(b->graph_exec, st));

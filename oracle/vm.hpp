@@ -221,8 +221,13 @@ struct Recorder {
   uint32_t cold_spent = 0, cold_ergs_pp = 0, cold_tx = 0, cold_mpc = 0;
   uint64_t cold_ctx[2] = {0, 0};
 
-  void init(const VmLocalState& s) {
+  // `cycles_hint` > 0: capacity for that many cycles is reserved up front, so that a timed run does not reallocate
+  void init(const VmLocalState& s, uint32_t cycles_hint = 0) {
     records.clear(); mem.clear(); log.clear(); aux.clear();
+    if (cycles_hint) {
+      records.reserve(cycles_hint); mem.reserve(2 * (size_t)cycles_hint + 64);
+      mem_off.reserve(cycles_hint + 1); log_off.reserve(cycles_hint + 1); aux_off.reserve(cycles_hint + 1);
+    }
     mem_off.assign(1, 0); log_off.assign(1, 0); aux_off.assign(1, 0);
     capture_cold(s);
   }

@@ -6,7 +6,13 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
+
+#include <pthread.h>
+#include <sched.h>
 
 #include "commit.hpp"
 #include "vm.hpp"
@@ -38,7 +44,59 @@ struct InstanceResult {
   cblog::Log cb;
 };
 
+// Persistent, pinned worker threads for the cpu_baseline leg of bench.py: the timed region of a run then contains
+// no thread creation, and every worker owns a contiguous block of instances ("one VmState per thread").
+struct Pool {
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv_go, cv_done;
+  uint64_t gen = 0;
+  unsigned done = 0;
+  bool stop = false;
+  std::function<void(unsigned)> job;
+  explicit Pool(const std::vector<int>& cpus, unsigned n) {
+    for (unsigned t = 0; t < n; t++)
+      th.emplace_back([this, t, cpus]() {
+        if (!cpus.empty()) {
+          cpu_set_t set;
+          CPU_ZERO(&set);
+          CPU_SET(cpus[t % cpus.size()], &set);
+          (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+        }
+        uint64_t seen = 0;
+        for (;;) {
+          std::unique_lock<std::mutex> lk(m);
+          cv_go.wait(lk, [&] { return stop || gen != seen; });
+          if (stop) return;
+          seen = gen;
+          lk.unlock();
+          job(t);
+          lk.lock();
+          if (++done == th.size()) cv_done.notify_all();
+        }
+      });
+  }
+  void run(std::function<void(unsigned)> f) {
+    std::unique_lock<std::mutex> lk(m);
+    job = std::move(f);
+    done = 0;
+    gen++;
+    cv_go.notify_all();
+    cv_done.wait(lk, [&] { return done == th.size(); });
+  }
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv_go.notify_all();
+    for (auto& x : th) x.join();
+  }
+};
+
 struct zkwo_batch {
+  std::unique_ptr<Pool> pool;
+  ~zkwo_batch() { pool.reset(); }
   zkwo_ctx* ctx;
   uint32_t n;
   zkw_limits limits;
@@ -88,6 +146,14 @@ int zkwo_batch_create(zkwo_ctx* c, uint32_t n, const zkw_limits* limits, zkwo_ba
 void zkwo_batch_destroy(zkwo_batch* b) { delete b; }
 int zkwo_batch_set_threads(zkwo_batch* b, uint32_t t) {
   b->threads = t ? t : 1;
+  b->pool.reset();
+  return ZKW_OK;
+}
+// `n_threads` persistent workers, worker t pinned to cpus[t % n_cpus] (n_cpus = 0: not pinned)
+int zkwo_batch_set_pool(zkwo_batch* b, uint32_t n_threads, const int32_t* cpus, uint32_t n_cpus) {
+  b->threads = n_threads ? n_threads : 1;
+  b->pool.reset();
+  if (b->threads > 1) b->pool.reset(new Pool(std::vector<int>(cpus, cpus + n_cpus), b->threads));
   return ZKW_OK;
 }
 
@@ -196,7 +262,7 @@ static void build_vm(zkwo_batch* b, uint32_t i) {
     vm->storage.populate(sl.shard_id, a, k, v);
   }
   b->results[i] = InstanceResult();
-  b->results[i].rec.init(L);
+  b->results[i].rec.init(L, b->pool ? b->limits.max_cycles : 0);  // pre-reserved only for the timed cpu_baseline runs
   b->results[i].rec.cb = b->callback_log ? &b->results[i].cb : nullptr;
   b->vms[i] = std::move(vm);
 }
@@ -207,7 +273,25 @@ int zkwo_batch_reset(zkwo_batch* b, void*) {
   b->results.clear();
   b->results.resize(b->n);
   try {
-    for (uint32_t i = 0; i < b->n; i++) build_vm(b, i);
+    if (b->pool) {
+      std::atomic<bool> failed{false};
+      std::string msg;
+      std::mutex mm;
+      const unsigned T = (unsigned)b->pool->th.size();
+      b->pool->run([&](unsigned t) {
+        const uint32_t lo = (uint32_t)((uint64_t)b->n * t / T), hi = (uint32_t)((uint64_t)b->n * (t + 1) / T);
+        try {
+          for (uint32_t i = lo; i < hi; i++) build_vm(b, i);
+        } catch (const std::exception& e) {
+          std::lock_guard<std::mutex> lk(mm);
+          failed = true;
+          msg = e.what();
+        }
+      });
+      if (failed) throw std::runtime_error(msg);
+    } else {
+      for (uint32_t i = 0; i < b->n; i++) build_vm(b, i);
+    }
   } catch (const std::exception& e) {
     b->ctx->last_error = std::string("reset: ") + e.what();
     return ZKW_ERR_INVALID;
@@ -252,6 +336,12 @@ int zkwo_batch_run(zkwo_batch* b, uint32_t max_cycles, void*) {
   unsigned T = b->threads;
   if (T <= 1) {
     for (uint32_t i = 0; i < b->n; i++) run_instance(b, i, max_cycles);
+  } else if (b->pool) {  // persistent pinned workers, one contiguous block of instances each
+    const unsigned TP = (unsigned)b->pool->th.size();
+    b->pool->run([&](unsigned t) {
+      const uint32_t lo = (uint32_t)((uint64_t)b->n * t / TP), hi = (uint32_t)((uint64_t)b->n * (t + 1) / TP);
+      for (uint32_t i = lo; i < hi; i++) run_instance(b, i, max_cycles);
+    });
   } else {
     std::atomic<uint32_t> next{0};
     std::vector<std::thread> th;

@@ -21,7 +21,7 @@ def isa():
 @pytest.fixture(scope="session")
 def oracle(isa):
     """TEST INFRASTRUCTURE: the CPU restatement of the reference (oracle/)."""
-    from era_zk_evm_amd import capi
-    be = capi.load_oracle().open(isa)
+    from _oracle import load_oracle
+    be = load_oracle().open(isa)
     yield be
     be.close()

@@ -56,7 +56,9 @@ if __name__ == "__main__":
     from era_zk_evm_amd import capi as K
     from test_emu_parity import CASES
     isa = K.Isa()
-    orc = K.load_oracle().open(isa)
+    from _oracle import load_oracle
+
+    orc = load_oracle().open(isa)
     out = {name: digest_case(orc, CASES[name](isa)) for name in sorted(CASES)}
     json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "trace_digests.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1))

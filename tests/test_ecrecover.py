@@ -92,7 +92,9 @@ def test_ecrecover_evm_word_order(oracle, isa):
     isa2 = K.Isa()
     isa2.table["consts"]["ecrecover_input_layout"] = 1
     import build_emu
-    orc2 = K.load_oracle().open(isa2)
+    from _oracle import load_oracle
+
+    orc2 = load_oracle().open(isa2)
     emu2 = K.Backend(build_emu.build(), "zkw_").open(isa2)
     words, expect = make_signatures(2, 2, seed=7, layout=1)
     wl = synth.ecrecover_workload(isa2, words)

@@ -27,7 +27,9 @@ def _worker(rank, world, port, n_total, out_dir):
     from era_zk_evm_amd import capi as K, synth, shard
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     isa = K.Isa()
-    orc = K.load_oracle().open(isa)
+    from tests._oracle import load_oracle
+
+    orc = load_oracle().open(isa)
     wl_all = synth.make(2, isa, n_instances=n_total)
     first, count = shard.shard_range(n_total, rank, world)
     wl = synth.make(2, isa, n_instances=n_total)
