@@ -44,7 +44,7 @@ def build_lib(force=False, extra_flags=()):
         # decode per opcode-word group); leaving those regions unstructurized removes ~35 % of the AGPR spill reloads
         # (measured: lone launch 0.986 -> 0.888 ms, fused 1.25 -> 1.20 ms, profiles/r01_kernel_variants.md)
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-structurizecfg-skip-uniform-regions",
-               "-I", os.path.join(ROOT, "include"), "-o", LIB] + list(extra_flags) + srcs
+               "-I", os.path.join(ROOT, "include"), "-o", LIB] + list(extra_flags) + srcs + ["-ldl"]
         _run(cmd)
     return LIB
 

@@ -258,6 +258,96 @@ class Backend:
         self.call("batches_step", arr, C.c_uint32(len(batches)), C.c_uint32(max_cycles), C.c_uint32(queue_mask), C.c_void_p(stream))
 
 
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32)
+
+
+class Comm:
+    """zkw_comm: the communicator of the final exchange (zkw_reduce_commitments, include/zkw.h).
+
+    Comm.rccl(backend, rank, world, id_bytes)   RCCL over xGMI (id from Comm.unique_id(), shared by the caller)
+    Comm.external(backend, rank, world, allgather, allreduce_sum)   caller-supplied collectives on host buffers:
+        allgather(send: np.uint8[bytes]) -> np.uint8[world * bytes];  allreduce_sum(np.uint64[count]) -> np.uint64[count]
+    """
+
+    def __init__(self, backend):
+        self.be = backend
+        self.h = C.c_void_p()
+        self.world = 1
+        self._keep = []
+
+    @staticmethod
+    def unique_id(backend):
+        buf = (C.c_uint8 * 128)()
+        backend.call("comm_get_unique_id", buf)
+        return bytes(buf)
+
+    @classmethod
+    def rccl(cls, backend, rank, world, id_bytes):
+        self = cls(backend)
+        self.world = world
+        buf = (C.c_uint8 * 128)(*id_bytes)
+        backend.call("comm_create_rccl", backend.ctx, C.c_int(rank), C.c_int(world), buf, C.byref(self.h))
+        self.device_buffers = True
+        return self
+
+    @classmethod
+    def external(cls, backend, rank, world, allgather=None, allreduce_sum=None):
+        self = cls(backend)
+        self.world = world
+
+        def _ag(user, send, recv, nbytes):
+            try:
+                s = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
+                out = np.ascontiguousarray(allgather(s.copy()), dtype=np.uint8).reshape(-1)
+                assert out.size == nbytes * world
+                C.memmove(recv, out.ctypes.data, out.size)
+                return 0
+            except Exception:  # noqa: BLE001  (reported to C as a failed collective)
+                return 1
+
+        def _ar(user, inout, count):
+            try:
+                a = np.ctypeslib.as_array(inout, shape=(count,))
+                a[:] = np.asarray(allreduce_sum(a.copy()), dtype=np.uint64)
+                return 0
+            except Exception:  # noqa: BLE001
+                return 1
+
+        ag = ALLGATHER_FN(_ag) if allgather else C.cast(None, ALLGATHER_FN)
+        ar = ALLREDUCE_FN(_ar) if allreduce_sum else C.cast(None, ALLREDUCE_FN)
+        self._keep = [ag, ar]
+        backend.call("comm_create_external", backend.ctx, C.c_int(rank), C.c_int(world), ag, ar, None, C.byref(self.h))
+        self.device_buffers = False
+        return self
+
+    def reduce(self, batches, queue_mask, gathered=None, want_total=False, stream=None):
+        """zkw_reduce_commitments.  `gathered`: a device pointer (int) for an RCCL communicator, None or a numpy u64
+        array for an external one (allocated here when None).  Returns (gathered, n_max, sizes, total_stats | None)."""
+        arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])
+        n_max = C.c_uint32()
+        sizes = (C.c_uint32 * self.world)()
+        total = np.zeros(1, dtype=RUN_STATS)
+        nq = bin(queue_mask & 7).count("1")
+        gptr = None
+        if self.device_buffers:
+            gptr = C.c_void_p(gathered) if gathered else None
+        else:
+            if gathered is None and nq:
+                # rows per rank are only known after the size exchange: ask for it first
+                self.be.call("reduce_commitments", self.h, arr, C.c_uint32(len(batches)), C.c_uint32(0), None, C.byref(n_max), sizes, None, C.c_void_p(stream))
+                gathered = np.zeros((self.world, len(batches), n_max.value, nq, 4), dtype="<u8")
+            gptr = _ptr(gathered) if gathered is not None else None
+        self.be.call("reduce_commitments", self.h, arr, C.c_uint32(len(batches)), C.c_uint32(queue_mask), gptr, C.byref(n_max), sizes,
+                     _ptr(total) if want_total else None, C.c_void_p(stream))
+        return gathered, n_max.value, list(sizes), (total[0] if want_total else None)
+
+    def close(self):
+        if self.h:
+            self.be.fn("comm_destroy")(self.h)
+            self.h = C.c_void_p()
+
+
 def load_product():
     """libzkw.so — the HIP library. Raises if it has not been built; never falls back."""
     return Backend(_build.LIB, "zkw_")

@@ -571,3 +571,32 @@ extern "C" hipError_t zkw_launch_commit(const zkw_fused_table* T, int stage, hip
   }
   return hipGetLastError();
 }
+
+// Packs the digests of the committed queues of several batches into the send buffer of the final all-gather:
+// dst[batch][row < n_max][q in mask][4] u64 (rows >= n are zero: ragged shards are padded to the largest rank).
+// T.p[batch] = that batch's digests [n][ZKW_QUEUE_COUNT][4].
+__global__ void zkw_pack_digests_kernel(zkw_fused_table T, uint64_t* dst, u32 n, u32 n_max, u32 mask) {
+  const uint64_t* src = (const uint64_t*)T.p[blockIdx.y];
+  const u32 nq = (u32)__popcll((unsigned long long)(mask & 7u));
+  const u32 total = n_max * nq * 4u;
+  uint64_t* out = dst + (size_t)blockIdx.y * total;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const u32 row = i / (nq * 4u), rem = i % (nq * 4u), qi = rem / 4u, e = rem % 4u;
+    u32 q = 0, seen = 0;  // the qi-th set bit of the mask
+    for (u32 b = 0; b < ZKW_QUEUE_COUNT; b++)
+      if ((mask >> b) & 1u) {
+        if (seen == qi) q = b;
+        seen++;
+      }
+    out[i] = row < n ? src[((size_t)row * ZKW_QUEUE_COUNT + q) * 4u + e] : 0ull;
+  }
+}
+extern "C" hipError_t zkw_launch_pack_digests(const zkw_fused_table* T, uint64_t* dst, uint32_t n, uint32_t n_max, uint32_t mask, hipStream_t stream) {
+  const u32 threads = T->wave_threads > 1 ? 256 : 1;
+  const u32 total = n_max * (u32)__builtin_popcount(mask & 7u) * 4u;
+  u32 blocks = (total + threads - 1) / threads;
+  if (blocks > 64) blocks = 64;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(zkw_pack_digests_kernel, dim3(blocks, T->n), dim3(threads), 0, stream, *T, dst, n, n_max, mask);
+  return hipGetLastError();
+}

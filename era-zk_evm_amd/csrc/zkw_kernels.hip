@@ -34,30 +34,44 @@
 // per-lane execution context (lives in VGPRs; every helper below is force-inlined)
 // ---------------------------------------------------------------------------------------------
 struct Lane {
-  // identity
-  u32 inst, wave, lane;
-  // VmLocalState scalars (mod.rs:54-73) that every cycle touches
-  u32 ptr_bitmap, flags, prev_code_page, timestamp, cycle_counter, prev_super_pc, depth;
-  // run bookkeeping
-  u32 status, n_cycles;
-  // hot fields of callstack.current (execution_stack.rs:6-24)
-  u32 base_page, code_page, sp, pc, ergs, heap_bound, aux_bound;
-  u32 is_kernel, is_static, is_local;
-  u32 code_off, code_len, slot;
-  u32 stack_hwm, heap_hwm, aux_hwm;
-  // per-cycle
-  u32 seq, n_mem, n_log, n_aux, cold_dirty;
-  u32 reg_dirty;  // registers written in this cycle (bit r = register r + 1)
+  u32 lane;  // lane of the wave = thread index in the wave
+  // what every cycle touches stays in vector registers (13 of them)
+  u32 pc, sp, ergs, timestamp, prev_super_pc, depth, status;
+  u32 flags;       // FLAG_*
+  u32 kflags;      // KF_*: frame properties + per-cycle markers
+  u32 ptr_bitmap;  // bit r = register r + 1 holds a pointer
+  u32 reg_dirty;   // registers written in this cycle (bit r = register r + 1)
+  u32 counts;      // per-cycle, saturating bytes: in-cycle sequence number | memory queries << 8 | log queries << 16 | aux events << 24
 };
-// The rest of the per-lane state is touched by rare opcodes only and lives in LDS, [field][lane] (conflict-free
-// dword accesses): CF(sh, s, field) is an lvalue.
+#define KF_KERNEL 1u       /* callstack.current.is_kernel_mode() */
+#define KF_STATIC 2u       /* callstack.current.is_static */
+#define KF_LOCAL 4u        /* callstack.current.is_local_frame */
+#define KF_COLD_DIRTY 8u   /* a cold VmLocalState field changed in this cycle (ZKW_AUX_COLD_STATE goes out) */
+#define KF_CODE_PAGE_CHANGED 16u /* previous_code_memory_page != callstack.current.code_page (cycle.rs:49,59) */
+// The rest of the per-lane state lives in LDS, [field][lane] (conflict-free dword accesses); CF(sh, s, field) is an
+// lvalue.  Rare opcodes touch the first block, memory operands / frame changes the second.
 enum {
   CF_CTX0 = 0,  // context_u128_register, 4 dwords
   CF_SPENT_PUBDATA = 4, CF_MPC, CF_ERGS_PP, CF_TX_NUMBER,
   CF_FIRST_DYN, CF_N_INITIAL_SLOTS, CF_NEXT_SLOT, CF_JOURNAL_LEN, CF_N_HISTORY,
-  ZKW_COLD_FIELDS = 16
+  // hot fields of callstack.current (execution_stack.rs:6-24) and of its memory arena slot
+  CF_BASE_PAGE, CF_CODE_PAGE, CF_PREV_CODE_PAGE /* valid while KF_CODE_PAGE_CHANGED */, CF_HEAP_BOUND, CF_AUX_BOUND, CF_CODE_OFF, CF_CODE_LEN, CF_SLOT,
+  CF_STACK_HWM, CF_HEAP_HWM, CF_AUX_HWM,
+  // run bookkeeping as of the kernel start (the kernel derives the final values from its cycle count)
+  CF_N_CYCLES0, CF_CYCLE_COUNTER0,
+  ZKW_COLD_FIELDS = 28
 };
-#define CF(sh, s, f) ((sh).cold[(u32)(f) * (sh).L + (s).lane])
+// LDS rows have a compile-time lane stride (thin waves leave the rest of a row unused), so that a field access is one
+// base register + an immediate offset
+#ifndef ZKW_EMU_BUILD
+#define ZKW_LDS_STRIDE ZKW_WAVE /* the same in the host pass: zkw_cycle_kernel_lds_bytes sizes the launch with it */
+#else
+#define ZKW_LDS_STRIDE 1 /* single-lane CPU emulation build (tests/emu) */
+#endif
+// (the lane index goes through zkw_opaque at every access: a shared, long-lived address register would be the first
+// thing the allocator spills around the opcode switch — one v_lshl_add per access is cheaper than that reload)
+#define CF(sh, s, f) ((sh).cold[(u32)(f) * ZKW_LDS_STRIDE + zkw_opaque((s).lane)])
+#define lane_inst(sh, s) ((sh).wave * (sh).L + (s).lane)
 
 #define FLAG_LT 1u
 #define FLAG_EQ 2u
@@ -111,13 +125,35 @@ ZD uint4 zkw_lds_read4(const u32* p) { return make_uint4(ZKW_LDS_WORD(p)[0], ZKW
 // LDS and belongs to this wave alone, and a wave's LDS operations complete in program order, so the base is a plain
 // broadcast read by every participating lane followed by one plain write of the leader — no atomic, no shuffle.
 // ---------------------------------------------------------------------------------------------
+// number of set bits of `mask` below this lane (v_mbcnt_lo/hi: no per-lane mask register to keep alive)
+#ifdef __HIP_DEVICE_COMPILE__
+ZD u32 zkw_rank_below(u64 mask) { return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u)); }
+// An opaque copy: what is derived from the result cannot be hoisted out of the enclosing loop.  Left alone, the
+// optimiser hoists some forty per-lane address computations (LDS field addresses, lane masks, stream offsets) out of
+// the cycle loop; each then owns a vector register for the whole loop, and with 128 registers they all end up in
+// scratch memory — a reload (a vector-memory round trip behind the outstanding stream stores) where one v_lshl_add
+// would have done.
+ZD u32 zkw_opaque(u32 x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+// bit `lane` of a wave mask: a select on the mask itself (no 1 << lane register to keep alive)
+ZD bool zkw_lane_bit(u64 mask) {
+  u32 r;
+  asm("v_cndmask_b32 %0, 0, 1, %1" : "=v"(r) : "s"(mask));
+  return r != 0;
+}
+#else
+ZD bool zkw_lane_bit(u64 mask) { return ((mask >> (threadIdx.x & (ZKW_WAVE - 1))) & 1ull) != 0; }
+ZD u32 zkw_rank_below(u64 mask) { return (u32)__popcll(mask & ((1ull << (threadIdx.x & (ZKW_WAVE - 1))) - 1ull)); }
+ZD u32 zkw_opaque(u32 x) { return x; }
+#endif
+
 ZD u32 stream_alloc(u32* cursor) {
   const u64 mask = __ballot(1);
-  const u32 lane = threadIdx.x & (ZKW_WAVE - 1);
-  const u32 leader = (u32)__ffsll((long long)mask) - 1u;
-  const u32 rank = (u32)__popcll(mask & ((1ull << lane) - 1ull));
+  const u32 rank = zkw_rank_below(mask);
   const u32 base = *ZKW_LDS_WORD(cursor);
-  if (lane == leader) *ZKW_LDS_WORD(cursor) = base + (u32)__popcll(mask);
+  if (rank == 0) *ZKW_LDS_WORD(cursor) = base + (u32)__popcll(mask);
   return base + rank;
 }
 
@@ -140,7 +176,7 @@ ZD void zkw_wave_lds_fence() {
 }
 
 // LDS view of one wave.  A workgroup holds ZKW_WAVES_PER_GROUP waves that share the 16 KB ISA table; each wave owns
-// 16 B of cursors + per lane: 64 B of cold state and 32 B of previous_code_word.
+// 16 B of cursors + per lane: 112 B of state fields (CF_*) and 32 B of previous_code_word.
 // The Keccak row (rare, precompile only) is in HBM.
 struct Shared {
   uint2* isa;     // [2048] packed ISA table (shared by the waves of the workgroup)
@@ -152,6 +188,7 @@ struct Shared {
   u32 L;
   u32 debug_flags;
   u32 wib;        // wave in workgroup
+  u32 wave;       // wave in batch
   // launch-invariant geometry and arena bases, loaded once and pinned in scalar registers (ZKW_PIN_SGPR): left to
   // itself the compiler re-loads them from the parameter block at every use (s_load + s_waitcnt lgkmcnt(0), which
   // also drains the outstanding LDS reads) because an invariant load is cheaper to rematerialise than to keep
@@ -167,23 +204,24 @@ struct Shared {
 #endif
 extern __shared__ uint4 zkw_lds[];
 // 16-byte units of LDS per wave: cursors | cold | previous_code_word
-ZD u32 zkw_wave_lds_units(u32 L) { return 1u + (ZKW_COLD_FIELDS / 4u) * L + 2u * L; }
+ZD u32 zkw_wave_lds_units() { return 1u + (ZKW_COLD_FIELDS / 4u) * ZKW_LDS_STRIDE + 2u * ZKW_LDS_STRIDE; }
 // `wib` (wave in workgroup), `wave` and `dbg` must be wave-uniform
 ZD void shared_setup(Shared& sh, ZKW_KP P, u32 dbg, u32 wib, u32 wave, bool pin) {
   sh.L = P.L;
   sh.debug_flags = dbg;
   sh.wib = wib;
+  sh.wave = wave;
   sh.F = P.F; sh.S = P.S; sh.H = P.H; sh.A = P.A; sh.cap_mem = P.cap_mem;
   sh.stack_vals = P.stack_vals; sh.stack_ptrs = P.stack_ptrs; sh.heap = P.heap; sh.aux_heap = P.aux_heap; sh.blob_words = P.blob_words;
   if (pin) {
     ZKW_PIN_SGPR(sh.L); ZKW_PIN_SGPR(sh.F); ZKW_PIN_SGPR(sh.S); ZKW_PIN_SGPR(sh.H); ZKW_PIN_SGPR(sh.A); ZKW_PIN_SGPR(sh.cap_mem);
     ZKW_PIN_SGPR(sh.stack_vals); ZKW_PIN_SGPR(sh.stack_ptrs); ZKW_PIN_SGPR(sh.heap); ZKW_PIN_SGPR(sh.aux_heap); ZKW_PIN_SGPR(sh.blob_words);
   }
-  uint4* wl = zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + wib * zkw_wave_lds_units(P.L);
+  uint4* wl = zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + wib * zkw_wave_lds_units();
   sh.isa = (uint2*)zkw_lds;                                  // 16 KB
   sh.cursor = (u32*)wl;                                      // 16 B
-  sh.cold = (u32*)(wl + 1);                                  // ZKW_COLD_FIELDS * L * 4 B
-  sh.pcw = (uint2*)(wl + 1 + (ZKW_COLD_FIELDS / 4u) * P.L);  // 4 * L * 8 B
+  sh.cold = (u32*)(wl + 1);                                  // ZKW_COLD_FIELDS * stride * 4 B
+  sh.pcw = (uint2*)(wl + 1 + (ZKW_COLD_FIELDS / 4u) * ZKW_LDS_STRIDE);  // 4 * stride * 8 B
   sh.krow = P.krow + (u64)wave * ZKW_KROW_WORDS * P.L;
   sh.mem_base = P.mem_stream + (u64)wave * P.cap_mem * 3;
   sh.log_base = P.log_stream + (u64)wave * P.cap_log * 8;
@@ -191,8 +229,8 @@ ZD void shared_setup(Shared& sh, ZKW_KP P, u32 dbg, u32 wib, u32 wave, bool pin)
 }
 
 ZD u32 next_seq(Lane& s) {
-  u32 q = s.seq > 255u ? 255u : s.seq;
-  s.seq++;
+  const u32 q = s.counts & 255u;
+  if (q != 255u) s.counts++;
   return q;
 }
 
@@ -200,7 +238,7 @@ ZD u32 next_seq(Lane& s) {
 ZD void emit_mem(ZKW_KP P, Shared& sh, Lane& s, u32 ts, u32 type, u32 page, u32 index, const u256& value, bool is_ptr, bool rw, u32 kind) {
   const u32 pos = stream_alloc(sh.cursor + 0);
   const u32 seq = next_seq(s);
-  s.n_mem++;
+  if ((s.counts & 0xff00u) != 0xff00u) s.counts += 0x100u;
   if (pos >= sh.cap_mem) {
     lane_fail(s, ZKW_STATUS_LIMIT);
     return;
@@ -224,7 +262,7 @@ struct LogQ {  // LogQuery (log.rs:85-97)
 ZD void emit_log(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q, u32 kind) {
   const u32 pos = stream_alloc(sh.cursor + 1);
   const u32 seq = next_seq(s);
-  s.n_log++;
+  if ((s.counts & 0xff0000u) != 0xff0000u) s.counts += 0x10000u;
   if (pos >= P.cap_log) {
     lane_fail(s, ZKW_STATUS_LIMIT);
     return;
@@ -246,7 +284,7 @@ ZD void emit_log(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q, u32 kind) {
 ZD uint4* aux_alloc(ZKW_KP P, Shared& sh, Lane& s, u32 type, u32 flag, u32 a, u32 b, u32 c) {
   const u32 pos = stream_alloc(sh.cursor + 2);
   const u32 seq = next_seq(s);
-  s.n_aux++;
+  if ((s.counts & 0xff000000u) != 0xff000000u) s.counts += 0x1000000u;
   if (pos >= P.cap_aux) {
     lane_fail(s, ZKW_STATUS_LIMIT);
     return nullptr;
@@ -333,7 +371,7 @@ ZD void reg_write(Shared& sh, RegFile& rf, Lane& s, u32 idx, const u256& v, bool
 // ([word][2][L] x 16 B: element 2 * w - lane and that + L for the index w returned here), so that each of the two
 // load / store instructions of a word access covers whole 64-byte lines.
 ZD u64 page_word_index(const Shared& sh, const Lane& s, u32 slot, u32 words_per_page, u32 idx) {
-  return (((u64)s.wave * sh.F + slot) * words_per_page + idx) * sh.L + s.lane;
+  return (((u64)sh.wave * sh.F + slot) * words_per_page + idx) * sh.L + s.lane;
 }
 
 // MemoryType::Stack read of the current frame (memory.rs:427-436)
@@ -341,8 +379,8 @@ ZD u256 stack_read(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, bool& is_ptr) {
   is_ptr = false;
   // a word that was never written reads as zero in the reference (the stack page is a zero-filled Vec); only WRITES
   // need capacity, and stack_hwm <= S
-  if (idx >= s.stack_hwm) return u256_zero();
-  const u64 w = page_word_index(sh, s, s.slot, sh.S, idx);
+  if (idx >= CF(sh, s, CF_STACK_HWM)) return u256_zero();
+  const u64 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), sh.S, idx);
   is_ptr = sh.stack_ptrs[w] != 0;
   return u256_from_uint4(sh.stack_vals[2 * w - s.lane], sh.stack_vals[2 * w - s.lane + sh.L]);
 }
@@ -352,17 +390,17 @@ ZD void stack_write(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, const u256& v,
     lane_fail(s, ZKW_STATUS_LIMIT);
     return;
   }
-  for (u32 g = s.stack_hwm; g < idx; g++) {  // lazily zero the gap
-    const u64 w = page_word_index(sh, s, s.slot, sh.S, g);
+  for (u32 g = CF(sh, s, CF_STACK_HWM); g < idx; g++) {  // lazily zero the gap
+    const u64 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), sh.S, g);
     sh.stack_vals[2 * w - s.lane] = make_uint4(0, 0, 0, 0);
     sh.stack_vals[2 * w - s.lane + sh.L] = make_uint4(0, 0, 0, 0);
     sh.stack_ptrs[w] = 0;
   }
-  const u64 w = page_word_index(sh, s, s.slot, sh.S, idx);
+  const u64 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), sh.S, idx);
   sh.stack_vals[2 * w - s.lane] = u256_lo4(v);
   sh.stack_vals[2 * w - s.lane + sh.L] = u256_hi4(v);
   sh.stack_ptrs[w] = is_ptr ? 1 : 0;
-  if (idx >= s.stack_hwm) s.stack_hwm = idx + 1;
+  if (idx >= CF(sh, s, CF_STACK_HWM)) CF(sh, s, CF_STACK_HWM) = idx + 1;
 }
 
 // heap / aux heap of an arbitrary arena slot; `hwm` is that page's high-water mark
@@ -376,7 +414,7 @@ ZD u256 heap_read_at(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 slot,
 // MemoryType::Heap / AuxHeap of the current frame (memory.rs:439-473; the page number of the query
 // is only debug_assert'ed there, i.e. ignored in release builds)
 ZD u256 heap_read_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx) {
-  return heap_read_at(P, sh, s, is_aux, s.slot, is_aux ? s.aux_hwm : s.heap_hwm, idx);
+  return heap_read_at(P, sh, s, is_aux, CF(sh, s, CF_SLOT), is_aux ? CF(sh, s, CF_AUX_HWM) : CF(sh, s, CF_HEAP_HWM), idx);
 }
 ZD void heap_write_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx, const u256& v) {
   const u32 words = is_aux ? sh.A : sh.H;
@@ -385,22 +423,22 @@ ZD void heap_write_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx
     return;
   }
   uint4* base = is_aux ? sh.aux_heap : sh.heap;
-  u32 hwm = is_aux ? s.aux_hwm : s.heap_hwm;
+  u32 hwm = is_aux ? CF(sh, s, CF_AUX_HWM) : CF(sh, s, CF_HEAP_HWM);
   for (u32 g = hwm; g < idx; g++) {
-    const u64 w = page_word_index(sh, s, s.slot, words, g);
+    const u64 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), words, g);
     base[2 * w - s.lane] = make_uint4(0, 0, 0, 0);
     base[2 * w - s.lane + sh.L] = make_uint4(0, 0, 0, 0);
   }
-  const u64 w = page_word_index(sh, s, s.slot, words, idx);
+  const u64 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), words, idx);
   base[2 * w - s.lane] = u256_lo4(v);
   base[2 * w - s.lane + sh.L] = u256_hi4(v);
-  if (!is_aux && s.slot == 0 && idx < P.heap_image_words) {
+  if (!is_aux && CF(sh, s, CF_SLOT) == 0 && idx < P.heap_image_words) {
     // a word of the uploaded heap image is overwritten: remember it, the next reset restores only those words
-    u32* d = P.heap_dirty + ((u64)s.wave * ((P.heap_image_words + 31u) >> 5) + (idx >> 5)) * sh.L + s.lane;
+    u32* d = P.heap_dirty + ((u64)sh.wave * ((P.heap_image_words + 31u) >> 5) + (idx >> 5)) * sh.L + s.lane;
     atomicOr(d, 1u << (idx & 31u));  // result unused: a fire-and-forget atomic instead of a load + store round trip
   }
   if (idx >= hwm) hwm = idx + 1;
-  if (is_aux) s.aux_hwm = hwm; else s.heap_hwm = hwm;
+  if (is_aux) CF(sh, s, CF_AUX_HWM) = hwm; else CF(sh, s, CF_HEAP_HWM) = hwm;
 }
 
 // MemoryType::FatPointer read (memory.rs:475-521): resolve the page to an arena slot.
@@ -420,7 +458,7 @@ ZD u256 fat_ptr_read(ZKW_KP P, const Shared& sh, Lane& s, u32 page, u32 idx) {
     slot = 0;
     kind = 0;
     for (u32 i = 0; i < CF(sh, s, CF_N_INITIAL_SLOTS); i++) {
-      const u32 bp = P.frames[(u64)s.inst * P.F + i].base_page;
+      const u32 bp = P.frames[(u64)lane_inst(sh, s) * P.F + i].base_page;
       if (page >= bp && page < bp + 4) {
         slot = i;
         kind = page - bp;
@@ -434,10 +472,10 @@ ZD u256 fat_ptr_read(ZKW_KP P, const Shared& sh, Lane& s, u32 page, u32 idx) {
   }
   const bool is_aux = kind == 3;
   u32 hwm;
-  if (slot == s.slot) {
-    hwm = is_aux ? s.aux_hwm : s.heap_hwm;
+  if (slot == CF(sh, s, CF_SLOT)) {
+    hwm = is_aux ? CF(sh, s, CF_AUX_HWM) : CF(sh, s, CF_HEAP_HWM);
   } else {
-    const zkw_dev_frame_meta fm = P.frames[(u64)s.inst * P.F + slot];
+    const zkw_dev_frame_meta fm = P.frames[(u64)lane_inst(sh, s) * P.F + slot];
     hwm = is_aux ? fm.aux_hwm : fm.heap_hwm;
   }
   const u32 words = is_aux ? sh.A : sh.H;
@@ -449,55 +487,63 @@ ZD u256 fat_ptr_read(ZKW_KP P, const Shared& sh, Lane& s, u32 page, u32 idx) {
 
 // read_code_query (memory.rs:556-569) against the blob backing the current code page
 ZD u256 code_read(const Shared& sh, const Lane& s, u32 idx) {
-  if (idx >= s.code_len) return u256_zero();
-  const u64 w = (u64)s.code_off + idx;
+  if (idx >= CF(sh, s, CF_CODE_LEN)) return u256_zero();
+  const u64 w = (u64)CF(sh, s, CF_CODE_OFF) + idx;
   return u256_from_uint4(sh.blob_words[2 * w], sh.blob_words[2 * w + 1]);
 }
 
 // ---------------------------------------------------------------------------------------------
 // callstack entries in HBM ([inst][depth] x 8 uint4)
 // ---------------------------------------------------------------------------------------------
-ZD uint4* entry_ptr(ZKW_KP P, const Lane& s, u32 depth) { return (uint4*)(P.callstack + ((u64)s.inst * (P.D + 1) + depth)); }
-ZD u32 entry_dword(ZKW_KP P, const Lane& s, u32 depth, u32 d) { return ((const u32*)entry_ptr(P, s, depth))[d]; }
+ZD uint4* entry_ptr(ZKW_KP P, const Shared& sh, const Lane& s, u32 depth) { return (uint4*)(P.callstack + ((u64)lane_inst(sh, s) * (P.D + 1) + depth)); }
+ZD u32 entry_dword(ZKW_KP P, const Shared& sh, const Lane& s, u32 depth, u32 d) { return ((const u32*)entry_ptr(P, sh, s, depth))[d]; }
 
 // write the hot fields of callstack.current back into its HBM entry
-ZD void frame_writeback(ZKW_KP P, const Lane& s) {
-  u32* e = (u32*)entry_ptr(P, s, s.depth);
+ZD void frame_writeback(ZKW_KP P, const Shared& sh, const Lane& s) {
+  u32* e = (u32*)entry_ptr(P, sh, s, s.depth);
   e[E_SP_PC] = (s.sp & 0xffffu) | (s.pc << 16);
   e[E_ERGS] = s.ergs;
-  e[E_HEAP_BOUND] = s.heap_bound;
-  e[E_AUX_BOUND] = s.aux_bound;
+  e[E_HEAP_BOUND] = CF(sh, s, CF_HEAP_BOUND);
+  e[E_AUX_BOUND] = CF(sh, s, CF_AUX_BOUND);
 }
-ZD void hwm_writeback(ZKW_KP P, const Lane& s) {
-  zkw_dev_frame_meta* fm = P.frames + (u64)s.inst * P.F + s.slot;
-  fm->stack_hwm = s.stack_hwm;
-  fm->heap_hwm = s.heap_hwm;
-  fm->aux_hwm = s.aux_hwm;
+ZD void hwm_writeback(ZKW_KP P, const Shared& sh, const Lane& s) {
+  zkw_dev_frame_meta* fm = P.frames + (u64)lane_inst(sh, s) * P.F + CF(sh, s, CF_SLOT);
+  fm->stack_hwm = CF(sh, s, CF_STACK_HWM);
+  fm->heap_hwm = CF(sh, s, CF_HEAP_HWM);
+  fm->aux_hwm = CF(sh, s, CF_AUX_HWM);
 }
 // load the hot fields of entry `s.depth` into the lane
 ZD void frame_load(ZKW_KP P, const Shared& sh, Lane& s) {
-  const u32* e = (const u32*)entry_ptr(P, s, s.depth);
-  s.base_page = e[E_BASE_PAGE];
-  s.code_page = e[E_CODE_PAGE];
+  const u32* e = (const u32*)entry_ptr(P, sh, s, s.depth);
+  CF(sh, s, CF_BASE_PAGE) = e[E_BASE_PAGE];
+  {
+    // previous_code_memory_page := the code page of the cycle that is executing (cycle.rs:49 ran before the opcode), so
+    // a frame change makes the next cycle fetch exactly when the page differs (cycle.rs:59)
+    const u32 old_page = CF(sh, s, CF_CODE_PAGE), new_page = e[E_CODE_PAGE];
+    CF(sh, s, CF_CODE_PAGE) = new_page;
+    if (!(s.kflags & KF_CODE_PAGE_CHANGED)) CF(sh, s, CF_PREV_CODE_PAGE) = old_page;
+    s.kflags = new_page != CF(sh, s, CF_PREV_CODE_PAGE) ? (s.kflags | KF_CODE_PAGE_CHANGED) : (s.kflags & ~KF_CODE_PAGE_CHANGED);
+  }
   const u32 sppc = e[E_SP_PC];
   s.sp = sppc & 0xffffu;
   s.pc = sppc >> 16;
   const u32 ehf = e[E_EH_FLAGS];
-  s.is_static = (ehf >> 16) & 0xffu;
-  s.is_local = (ehf >> 24) & 0xffu;
+  s.kflags &= ~(KF_KERNEL | KF_STATIC | KF_LOCAL);
+  if ((ehf >> 16) & 0xffu) s.kflags |= KF_STATIC;
+  if ((ehf >> 24) & 0xffu) s.kflags |= KF_LOCAL;
   s.ergs = e[E_ERGS];
-  s.heap_bound = e[E_HEAP_BOUND];
-  s.aux_bound = e[E_AUX_BOUND];
-  s.is_kernel = (e[E_THIS] < 0x10000u && (e[E_THIS + 1] | e[E_THIS + 2] | e[E_THIS + 3] | e[E_THIS + 4]) == 0) ? 1u : 0u;  // execution_stack.rs:83-87
+  CF(sh, s, CF_HEAP_BOUND) = e[E_HEAP_BOUND];
+  CF(sh, s, CF_AUX_BOUND) = e[E_AUX_BOUND];
+  if (e[E_THIS] < 0x10000u && (e[E_THIS + 1] | e[E_THIS + 2] | e[E_THIS + 3] | e[E_THIS + 4]) == 0) s.kflags |= KF_KERNEL;  // execution_stack.rs:83-87
   const u32 new_slot = e[E_SLOT];
   const uint2 bd = P.blob_dir[e[E_CODE_BLOB]];
-  s.code_off = bd.x;
-  s.code_len = bd.y;
-  s.slot = new_slot;
-  const zkw_dev_frame_meta fm = P.frames[(u64)s.inst * P.F + new_slot];
-  s.stack_hwm = fm.stack_hwm;
-  s.heap_hwm = fm.heap_hwm;
-  s.aux_hwm = fm.aux_hwm;
+  CF(sh, s, CF_CODE_OFF) = bd.x;
+  CF(sh, s, CF_CODE_LEN) = bd.y;
+  CF(sh, s, CF_SLOT) = new_slot;
+  const zkw_dev_frame_meta fm = P.frames[(u64)lane_inst(sh, s) * P.F + new_slot];
+  CF(sh, s, CF_STACK_HWM) = fm.stack_hwm;
+  CF(sh, s, CF_HEAP_HWM) = fm.heap_hwm;
+  CF(sh, s, CF_AUX_HWM) = fm.aux_hwm;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -512,10 +558,10 @@ ZD u32 storage_hash(u32 shard, const u32 addr[5], const u256& key) {
   return h;
 }
 // returns the entry index of (shard,address,key), inserting an empty (value 0) entry when absent
-ZD u32 storage_find(ZKW_KP P, Lane& s, u32 shard, const u32 addr[5], const u256& key) {
+ZD u32 storage_find(ZKW_KP P, const Shared& sh, Lane& s, u32 shard, const u32 addr[5], const u256& key) {
   const u32 mask = P.storage_slots - 1;
   u32 i = storage_hash(shard, addr, key) & mask;
-  zkw_dev_storage_entry* tab = P.storage + (u64)s.inst * P.storage_slots;
+  zkw_dev_storage_entry* tab = P.storage + (u64)lane_inst(sh, s) * P.storage_slots;
   for (u32 probe = 0; probe < P.storage_slots; probe++, i = (i + 1) & mask) {
     zkw_dev_storage_entry* e = tab + i;
     // key (2 x 16 B) and address + state (2 x 16 B) in four wide loads issued together: a short-circuit compare of
@@ -545,9 +591,9 @@ ZD u32 storage_find(ZKW_KP P, Lane& s, u32 shard, const u32 addr[5], const u256&
 }
 // Storage::execute_partial_query (storage.rs:88-139) + access_storage's read convention (helpers.rs:145-148)
 ZD void access_storage(ZKW_KP P, Shared& sh, Lane& s, LogQ& q) {
-  const u32 slot = storage_find(P, s, q.shard_id, q.address, q.key);
+  const u32 slot = storage_find(P, sh, s, q.shard_id, q.address, q.key);
   if (!lane_ok(s)) return;
-  zkw_dev_storage_entry* e = P.storage + (u64)s.inst * P.storage_slots + slot;
+  zkw_dev_storage_entry* e = P.storage + (u64)lane_inst(sh, s) * P.storage_slots + slot;
   u256 cur;
 #pragma unroll
   for (int k = 0; k < 8; k++) cur.w[k] = e->value[k];
@@ -558,7 +604,7 @@ ZD void access_storage(ZKW_KP P, Shared& sh, Lane& s, LogQ& q) {
       lane_fail(s, ZKW_STATUS_LIMIT);
       return;
     }
-    zkw_dev_journal_entry* j = P.journal + (u64)s.inst * P.storage_journal + CF(sh, s, CF_JOURNAL_LEN);
+    zkw_dev_journal_entry* j = P.journal + (u64)lane_inst(sh, s) * P.storage_journal + CF(sh, s, CF_JOURNAL_LEN);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       j->old_value[k] = cur.w[k];
@@ -577,8 +623,8 @@ ZD void storage_finish_frame(ZKW_KP P, const Shared& sh, Lane& s, u32 mark, bool
   if (!panicked) return;
   while (CF(sh, s, CF_JOURNAL_LEN) > mark) {
     CF(sh, s, CF_JOURNAL_LEN)--;
-    const zkw_dev_journal_entry* j = P.journal + (u64)s.inst * P.storage_journal + CF(sh, s, CF_JOURNAL_LEN);
-    zkw_dev_storage_entry* e = P.storage + (u64)s.inst * P.storage_slots + j->slot;
+    const zkw_dev_journal_entry* j = P.journal + (u64)lane_inst(sh, s) * P.storage_journal + CF(sh, s, CF_JOURNAL_LEN);
+    zkw_dev_storage_entry* e = P.storage + (u64)lane_inst(sh, s) * P.storage_slots + j->slot;
 #pragma unroll
     for (int k = 0; k < 8; k++) e->value[k] = j->old_value[k];
   }
@@ -598,11 +644,11 @@ struct Operand {
 };
 
 // MemOpsProcessor::compute_addresses_and_select_operands (mem_ops.rs:14-125)
-ZD Operand compute_address(ZKW_KP P, Lane& s, u32& sp, const u256& reg_value, u32 imm, u32 mode, bool is_write) {
+ZD Operand compute_address(ZKW_KP P, const Shared& sh, Lane& s, u32& sp, const u256& reg_value, u32 imm, u32 mode, bool is_write) {
   Operand o;
   o.has_loc = false;
   o.type = ZKW_MEM_STACK;
-  o.page = s.base_page + 1;  // stack_page_from_base
+  o.page = CF(sh, s, CF_BASE_PAGE) + 1;  // stack_page_from_base
   o.index = 0;
   const u32 vaddr = (clip16(P, reg_value) + imm) & 0xffffu;  // :34-35
   if (mode == ZKW_MODE_STACK_PP) {
@@ -619,7 +665,7 @@ ZD Operand compute_address(ZKW_KP P, Lane& s, u32& sp, const u256& reg_value, u3
     o.has_loc = true;
   } else if (mode == ZKW_MODE_CODE) {  // :100-110
     o.type = ZKW_MEM_CODE;
-    o.page = s.code_page;
+    o.page = CF(sh, s, CF_CODE_PAGE);
     o.index = vaddr;
     o.has_loc = true;
   } else if (mode == ZKW_MODE_STACK_ABS) {  // :111-121
@@ -667,8 +713,8 @@ ZD u32 fat_ptr_validate(const FatPtr& p, bool fresh) {
 ZD u32 forward_type(u32 b) { return b == 1u ? 1u : (b == 2u ? 2u : 0u); }  // 0 UseHeap, 1 ForwardFatPointer, 2 UseAuxHeap
 
 // build a callstack entry image (32 dwords) from the lane's current frame: cold fields come from HBM
-ZD void entry_image_current(ZKW_KP P, const Lane& s, u32 img[32]) {
-  const uint4* e = entry_ptr(P, s, s.depth);
+ZD void entry_image_current(ZKW_KP P, const Shared& sh, const Lane& s, u32 img[32]) {
+  const uint4* e = entry_ptr(P, sh, s, s.depth);
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     const uint4 v = e[i];
@@ -676,8 +722,8 @@ ZD void entry_image_current(ZKW_KP P, const Lane& s, u32 img[32]) {
   }
   img[E_SP_PC] = (s.sp & 0xffffu) | (s.pc << 16);
   img[E_ERGS] = s.ergs;
-  img[E_HEAP_BOUND] = s.heap_bound;
-  img[E_AUX_BOUND] = s.aux_bound;
+  img[E_HEAP_BOUND] = CF(sh, s, CF_HEAP_BOUND);
+  img[E_AUX_BOUND] = CF(sh, s, CF_AUX_BOUND);
 }
 
 // VmState::start_frame (helpers.rs:225-246): Storage/EventSink::start_frame are a journal mark here
@@ -698,14 +744,14 @@ ZD void start_frame(ZKW_KP P, Shared& sh, Lane& s, const u32 prev[32], u32 next[
     return;
   }
   // callstack.push_entry: the old current (with its hot fields) stays at [depth], the new one goes to [depth+1]
-  uint4* cur = entry_ptr(P, s, s.depth);
-  uint4* nxt = entry_ptr(P, s, s.depth + 1);
+  uint4* cur = entry_ptr(P, sh, s, s.depth);
+  uint4* nxt = entry_ptr(P, sh, s, s.depth + 1);
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     cur[i] = make_uint4(prev[4 * i], prev[4 * i + 1], prev[4 * i + 2], prev[4 * i + 3]);
     nxt[i] = make_uint4(next[4 * i], next[4 * i + 1], next[4 * i + 2], next[4 * i + 3]);
   }
-  hwm_writeback(P, s);
+  hwm_writeback(P, sh, s);
   s.depth++;
   frame_load(P, sh, s);
 }
@@ -753,7 +799,7 @@ ZD void op_near_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre&
   s.ergs = left;
   s.pc = ps.new_pc;
   u32 prev[32], next[32];
-  entry_image_current(P, s, prev);
+  entry_image_current(P, sh, s, prev);
 #pragma unroll
   for (int i = 0; i < 32; i++) next[i] = prev[i];
   next[E_SP_PC] = (s.sp & 0xffffu) | (d.imm0 << 16);
@@ -774,20 +820,20 @@ ZD void op_context(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d,
       changed = changed || CF(sh, s, CF_CTX0 + i) != ps.src0.w[i];
       CF(sh, s, CF_CTX0 + i) = ps.src0.w[i];
     }
-    if (changed) s.cold_dirty = 1;
+    if (changed) s.kflags |= KF_COLD_DIRTY;
     return;
   }
   if (v == ZKW_CTX_SET_ERGS_PER_PUBDATA) {
-    if (CF(sh, s, CF_ERGS_PP) != ps.src0.w[0]) s.cold_dirty = 1;
+    if (CF(sh, s, CF_ERGS_PP) != ps.src0.w[0]) s.kflags |= KF_COLD_DIRTY;
     CF(sh, s, CF_ERGS_PP) = ps.src0.w[0];
     return;
   }
   if (v == ZKW_CTX_INC_TX_NUMBER) {
     CF(sh, s, CF_TX_NUMBER) = (CF(sh, s, CF_TX_NUMBER) + 1) & 0xffffu;
-    s.cold_dirty = 1;
+    s.kflags |= KF_COLD_DIRTY;
     return;
   }
-  const u32* e = (const u32*)entry_ptr(P, s, s.depth);
+  const u32* e = (const u32*)entry_ptr(P, sh, s, s.depth);
   if (v == ZKW_CTX_THIS || v == ZKW_CTX_CALLER || v == ZKW_CTX_CODE_ADDRESS) {
     const u32 off = v == ZKW_CTX_THIS ? E_THIS : (v == ZKW_CTX_CALLER ? E_SENDER : E_CODE_ADDR);
 #pragma unroll
@@ -795,8 +841,8 @@ ZD void op_context(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d,
   } else if (v == ZKW_CTX_META) {  // VmMetaParameters::to_u256 (Appendix B layout)
     const u32 sh3 = e[E_SHARDS];
     value.w[0] = CF(sh, s, CF_ERGS_PP);
-    value.w[2] = s.heap_bound;
-    value.w[3] = s.aux_bound;
+    value.w[2] = CF(sh, s, CF_HEAP_BOUND);
+    value.w[3] = CF(sh, s, CF_AUX_BOUND);
     value.w[7] = (sh3 & 0xffu) | (((sh3 >> 8) & 0xffu) << 8) | (((sh3 >> 16) & 0xffu) << 16);
   } else if (v == ZKW_CTX_ERGS_LEFT) {
     value.w[0] = s.ergs;
@@ -870,10 +916,10 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
   if (is_ptr_read) {
     mem_type = ZKW_MEM_FAT_PTR;
   } else if (is_heap) {
-    fp.page = s.base_page + 2;
+    fp.page = CF(sh, s, CF_BASE_PAGE) + 2;
     mem_type = ZKW_MEM_HEAP;
   } else {
-    fp.page = s.base_page + 3;
+    fp.page = CF(sh, s, CF_BASE_PAGE) + 3;
     mem_type = ZKW_MEM_AUX_HEAP;
   }
   u32 src_offset;
@@ -896,10 +942,10 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
   }
   u32 growth = 0;  // :152-194
   if (!is_ptr_read) {
-    const u32 bound = is_heap ? s.heap_bound : s.aux_bound;
+    const u32 bound = is_heap ? CF(sh, s, CF_HEAP_BOUND) : CF(sh, s, CF_AUX_BOUND);
     if (incremented >= bound) {
       growth = incremented - bound;
-      if (is_heap) s.heap_bound = incremented; else s.aux_bound = incremented;
+      if (is_heap) CF(sh, s, CF_HEAP_BOUND) = incremented; else CF(sh, s, CF_AUX_BOUND) = incremented;
     }
   }
   u32 cost = growth * P.consts.memory_growth_ergs_per_byte;  // :196-197
@@ -975,7 +1021,7 @@ ZD void op_log(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, H
   const u32 v = ZKW_ATTR_VARIANT(d.attr);
   s.pc = ps.new_pc;
   const bool is_first = ZKW_ATTR_FLAGS(d.attr) & 1u;
-  const u32* e = (const u32*)entry_ptr(P, s, s.depth);
+  const u32* e = (const u32*)entry_ptr(P, sh, s, s.depth);
   const u32 shard = e[E_SHARDS] & 0xffu;
   const u32 ergs_available = s.ergs;
   const zkw_isa_consts ZKW_CONST_AS& K = P.consts;
@@ -1013,7 +1059,7 @@ ZD void op_log(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, H
   }
   if (spent) {
     CF(sh, s, CF_SPENT_PUBDATA) += spent;
-    s.cold_dirty = 1;
+    s.kflags |= KF_COLD_DIRTY;
   }
   q.is_service = is_first;
   if (v == ZKW_LOG_STORAGE_READ) {  // :163-195
@@ -1044,7 +1090,7 @@ ZD void op_log(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, H
       out.action = ZKW_ACT_DST0;
       return;
     }
-    const u32 heap_page = s.base_page + 2;
+    const u32 heap_page = CF(sh, s, CF_BASE_PAGE) + 2;
     if (q.key.w[4] == 0) q.key.w[4] = heap_page;  // memory_page_to_read  :273-283
     if (q.key.w[5] == 0) q.key.w[5] = heap_page;  // memory_page_to_write :285-295
     q.aux_byte = K.precompile_aux_byte;
@@ -1083,10 +1129,10 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
   const u32 abi_shard = (ps.src0.w[7] >> 8) & 0xffu;
   bool constructor_call = ((ps.src0.w[7] >> 16) & 0xffu) != 0;
   bool to_system = ((ps.src0.w[7] >> 24) & 0xffu) != 0;
-  constructor_call = constructor_call && s.is_kernel;  // :85
+  constructor_call = constructor_call && (s.kflags & KF_KERNEL) != 0;  // :85
   to_system = to_system && dst_is_kernel;               // :86
   u32 prev[32];
-  entry_image_current(P, s, prev);
+  entry_image_current(P, sh, s, prev);
   const u32 caller_shard = prev[E_SHARDS] & 0xffu;
   const u32 remaining_ergs = s.ergs;
   const u32 new_code_shard = is_call_shard ? abi_shard : caller_shard;
@@ -1176,9 +1222,9 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
     abi.length = abi.length - abi.offset;
     abi.offset = 0;
   } else if (fwd == 0u) {
-    abi.page = s.base_page + 2;
+    abi.page = CF(sh, s, CF_BASE_PAGE) + 2;
   } else {
-    abi.page = s.base_page + 3;
+    abi.page = CF(sh, s, CF_BASE_PAGE) + 3;
   }
   if (exceptions) {  // :321-325
     abi.offset = abi.page = abi.start = abi.length = 0;
@@ -1187,10 +1233,10 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
   if (fwd != 1u) {
     u32 upper = abi.start + abi.length;
     if (pve & FPV_DEREF_BEYOND) upper = 0xffffffffu;
-    const u32 bound = fwd == 0u ? s.heap_bound : s.aux_bound;
+    const u32 bound = fwd == 0u ? CF(sh, s, CF_HEAP_BOUND) : CF(sh, s, CF_AUX_BOUND);
     if (upper >= bound) {
       growth = upper - bound;
-      if (fwd == 0u) s.heap_bound = upper; else s.aux_bound = upper;
+      if (fwd == 0u) CF(sh, s, CF_HEAP_BOUND) = upper; else CF(sh, s, CF_AUX_BOUND) = upper;
     }
   }
   const u32 growth_cost = growth * K.memory_growth_ergs_per_byte;
@@ -1221,7 +1267,7 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
                        (h1.y ^ code_hash.w[5]) | (h1.z ^ code_hash.w[6]) | (h1.w ^ code_hash.w[7]);
       if (diff == 0) pre = i;
     }
-    zkw_dev_history* hist = P.history + (u64)s.inst * P.F;
+    zkw_dev_history* hist = P.history + (u64)lane_inst(sh, s) * P.F;
     bool fresh = true;
     u32 page = candidate_page;
     for (u32 i = 0; i < CF(sh, s, CF_N_HISTORY); i++) {
@@ -1273,11 +1319,11 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
   s.pc = ps.new_pc;
   prev[E_SP_PC] = (s.sp & 0xffffu) | (s.pc << 16);
   prev[E_ERGS] = s.ergs;
-  prev[E_HEAP_BOUND] = s.heap_bound;
-  prev[E_AUX_BOUND] = s.aux_bound;
-  const u32 new_static = (s.is_static | (is_static_call ? 1u : 0u)) ? 1u : 0u;
+  prev[E_HEAP_BOUND] = CF(sh, s, CF_HEAP_BOUND);
+  prev[E_AUX_BOUND] = CF(sh, s, CF_AUX_BOUND);
+  const u32 new_static = ((s.kflags & KF_STATIC) != 0 || is_static_call) ? 1u : 0u;
   CF(sh, s, CF_MPC) += K.new_memory_pages_per_far_call;  // :503
-  s.cold_dirty = 1;
+  s.kflags |= KF_COLD_DIRTY;
   // r15 = CALL_IMPLICIT_PARAMETER_REG_IDX :506-508 (read by the caller)
   u32 next[32];
 #pragma unroll
@@ -1320,7 +1366,7 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
   CF(sh, s, CF_NEXT_SLOT)++;
   next[E_SLOT] = new_slot;
   {
-    zkw_dev_frame_meta* fm = P.frames + (u64)s.inst * P.F + new_slot;
+    zkw_dev_frame_meta* fm = P.frames + (u64)lane_inst(sh, s) * P.F + new_slot;
     fm->base_page = new_base;
     fm->stack_hwm = 0;
     fm->heap_hwm = 0;
@@ -1351,11 +1397,11 @@ ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, H
   bool to_label = ZKW_ATTR_FLAGS(d.attr) & 1u;
   const u32 label_pc = d.imm0;
   u32 pve = 0;
-  const bool local = s.is_local != 0;
+  const bool local = (s.kflags & KF_LOCAL) != 0;
   if (!local) {  // :58-96
     if (fwd == 1u) {
       if (!src0_ptr) variant = ZKW_RET_PANIC;
-      if (ptr.page < s.base_page) variant = ZKW_RET_PANIC;
+      if (ptr.page < CF(sh, s, CF_BASE_PAGE)) variant = ZKW_RET_PANIC;
     }
     pve = fat_ptr_validate(ptr, fwd != 1u);
     if (pve) variant = ZKW_RET_PANIC;
@@ -1370,16 +1416,16 @@ ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, H
         ptr.length = ptr.length - ptr.offset;
         ptr.offset = 0;
       } else if (fwd == 0u) {
-        ptr.page = s.base_page + 2;
+        ptr.page = CF(sh, s, CF_BASE_PAGE) + 2;
       } else {
-        ptr.page = s.base_page + 3;
+        ptr.page = CF(sh, s, CF_BASE_PAGE) + 3;
       }
     }
     u32 growth = 0;
     if (fwd != 1u) {
       u32 upper = ptr.start + ptr.length;
       if (pve & FPV_DEREF_BEYOND) upper = 0xffffffffu;
-      const u32 bound = fwd == 0u ? s.heap_bound : s.aux_bound;
+      const u32 bound = fwd == 0u ? CF(sh, s, CF_HEAP_BOUND) : CF(sh, s, CF_AUX_BOUND);
       growth = upper < bound ? 0u : upper - bound;
     }
     const u32 cost = growth * K.memory_growth_ergs_per_byte;
@@ -1393,10 +1439,10 @@ ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, H
   }
   const bool panicked = variant == ZKW_RET_REVERT || variant == ZKW_RET_PANIC;  // :196
   // finish_frame (helpers.rs:248-264)
-  const u32* fin = (const u32*)entry_ptr(P, s, s.depth);
+  const u32* fin = (const u32*)entry_ptr(P, sh, s, s.depth);
   const u32 fin_eh = fin[E_EH_FLAGS] & 0xffffu;
   const u32 fin_mark = fin[E_JOURNAL_MARK];
-  const u32 fin_heap_bound = s.heap_bound, fin_aux_bound = s.aux_bound;
+  const u32 fin_heap_bound = CF(sh, s, CF_HEAP_BOUND), fin_aux_bound = CF(sh, s, CF_AUX_BOUND);
   storage_finish_frame(P, sh, s, fin_mark, panicked);
   {
     uint4* a = aux_alloc(P, sh, s, ZKW_AUX_FRAME_FINISH, panicked ? 1u : 0u, 0, 0, 0);
@@ -1409,26 +1455,26 @@ ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, H
     lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
     return;
   }
-  hwm_writeback(P, s);
+  hwm_writeback(P, sh, s);
   s.depth--;
   frame_load(P, sh, s);
   to_label = to_label && local;  // :202
   if (!local) {  // :204-236; memory.finish_global_frame (memory.rs:660-758) is pure bookkeeping here: arena slots are never recycled
     out.v1 = fat_ptr_to_u256(ptr);
     out.action = ZKW_ACT_RET;
-    if (CF(sh, s, CF_CTX0 + 0) | CF(sh, s, CF_CTX0 + 1) | CF(sh, s, CF_CTX0 + 2) | CF(sh, s, CF_CTX0 + 3)) s.cold_dirty = 1;
+    if (CF(sh, s, CF_CTX0 + 0) | CF(sh, s, CF_CTX0 + 1) | CF(sh, s, CF_CTX0 + 2) | CF(sh, s, CF_CTX0 + 3)) s.kflags |= KF_COLD_DIRTY;
     CF(sh, s, CF_CTX0 + 0) = CF(sh, s, CF_CTX0 + 1) = CF(sh, s, CF_CTX0 + 2) = CF(sh, s, CF_CTX0 + 3) = 0;
   }
   s.ergs += ergs_remaining;  // :243
   if (to_label) s.pc = label_pc;
   else if (panicked) s.pc = fin_eh;
   if (local) {  // :254-260
-    if (fin_heap_bound < s.heap_bound || fin_aux_bound < s.aux_bound) {
+    if (fin_heap_bound < CF(sh, s, CF_HEAP_BOUND) || fin_aux_bound < CF(sh, s, CF_AUX_BOUND)) {
       lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
       return;
     }
-    s.heap_bound = fin_heap_bound;
-    s.aux_bound = fin_aux_bound;
+    CF(sh, s, CF_HEAP_BOUND) = fin_heap_bound;
+    CF(sh, s, CF_AUX_BOUND) = fin_aux_bound;
   }
   if (variant == ZKW_RET_PANIC) s.flags |= FLAG_LT;  // :262-264
 }
@@ -1444,11 +1490,10 @@ ZD u32 zkw_uniform(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); 
 // The precompile bodies (Keccak-f state of 50 VGPRs, SHA-256 schedule, secp256k1) are compiled as ONE out-of-line
 // function that takes and returns the lane state by value (the wave's Shared view is rebuilt from the uniform wave
 // coordinates instead of being passed through ~30 vector argument registers).
-__device__ __noinline__ Lane zkw_precompile_entry(const zkw_kparams ZKW_CONST_AS* Pp, u32 dbg, u32 wib, Lane s, LogQ q, u32 which) {
+__device__ __noinline__ Lane zkw_precompile_entry(const zkw_kparams ZKW_CONST_AS* Pp, u32 dbg, u32 wib, u32 wave, Lane s, LogQ q, u32 which) {
   ZKW_KP P = *Pp;
   Shared sh;
-  s.wave = zkw_uniform(s.wave);
-  shared_setup(sh, P, zkw_uniform(dbg), zkw_uniform(wib), s.wave, false);
+  shared_setup(sh, P, zkw_uniform(dbg), zkw_uniform(wib), zkw_uniform(wave), false);
   which = zkw_uniform(which);
   if (which == 0) precompile_keccak256(P, sh, s, q);
   else if (which == 1) precompile_sha256(P, sh, s, q);
@@ -1468,7 +1513,7 @@ ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   // precompiles (the address is per lane): one call per kind present.
   for (u32 k = 0; k < 3; k++) {
     if (which == k) {
-      s = zkw_precompile_entry(&P, sh.debug_flags, sh.wib, s, q, k);
+      s = zkw_precompile_entry(&P, sh.debug_flags, sh.wib, sh.wave, s, q, k);
     }
   }
 }
@@ -1478,11 +1523,10 @@ ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
 // the storage probe) would add to the 120 VGPRs of the register file and to the ~60 of the per-lane state, and the
 // kernel would not fit the 256 registers that two waves per SIMD allow.  All lanes of a call hold the same decoded
 // instruction, so `d` is made scalar again on entry.
-__device__ __noinline__ HeavyOut zkw_heavy_entry(const zkw_kparams ZKW_CONST_AS* Pp, u32 dbg, u32 wib, Lane s, Decoded d, Pre ps, u256 r15) {
+__device__ __noinline__ HeavyOut zkw_heavy_entry(const zkw_kparams ZKW_CONST_AS* Pp, u32 dbg, u32 wib, u32 wave, Lane s, Decoded d, Pre ps, u256 r15) {
   ZKW_KP P = *Pp;
   Shared sh;
-  s.wave = zkw_uniform(s.wave);
-  shared_setup(sh, P, zkw_uniform(dbg), zkw_uniform(wib), s.wave, false);
+  shared_setup(sh, P, zkw_uniform(dbg), zkw_uniform(wib), zkw_uniform(wave), false);
   d.attr = zkw_uniform(d.attr); d.cond = zkw_uniform(d.cond); d.src0 = zkw_uniform(d.src0); d.src1 = zkw_uniform(d.src1);
   d.dst0 = zkw_uniform(d.dst0); d.dst1 = zkw_uniform(d.dst1); d.imm0 = zkw_uniform(d.imm0); d.imm1 = zkw_uniform(d.imm1);
   HeavyOut out;
@@ -1503,8 +1547,8 @@ __device__ __noinline__ HeavyOut zkw_heavy_entry(const zkw_kparams ZKW_CONST_AS*
 // ---------------------------------------------------------------------------------------------
 ZD bool decode_exception(u32 max_depth, const Lane& s, u32 attr, u32 price) {
   const u32 props = ZKW_ATTR_PROPS(attr);
-  return ((props & ZKW_PROP_EXPLICIT_PANIC) != 0) | (s.ergs < price) | (((props & ZKW_PROP_KERNEL_ONLY) != 0) & (s.is_kernel == 0)) |
-         (((props & ZKW_PROP_STATIC_OK) == 0) & (s.is_static != 0)) | (s.depth == max_depth);
+  return ((props & ZKW_PROP_EXPLICIT_PANIC) != 0) | (s.ergs < price) | (((props & ZKW_PROP_KERNEL_ONLY) != 0) & ((s.kflags & KF_KERNEL) == 0)) |
+         (((props & ZKW_PROP_STATIC_OK) == 0) & ((s.kflags & KF_STATIC) != 0)) | (s.depth == max_depth);
 }
 // one bit per (condition, lt|eq<<1|gt<<2): Always, Gt, Lt, Eq, Ge, Le, Ne, GtOrLt
 ZD bool condition_resolved(u32 cond, u32 flags) {
@@ -1532,8 +1576,8 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
   const u256 src0_reg = reg_read(sh, rf, s, d.src0, src0_reg_ptr);
   ps.src1 = reg_read(sh, rf, s, d.src1, ps.src1_ptr);  // :339
   const u256 dst0_reg = ZKW_ATTR_DST0(d.attr) == ZKW_MODE_REG ? u256_zero() : reg_read(sh, rf, s, d.dst0, dummy_ptr);  // only addressing modes use it
-  Operand src0_loc = compute_address(P, s, sp, src0_reg, d.imm0, ZKW_ATTR_SRC0(d.attr), false);
-  ps.dst0 = compute_address(P, s, sp, dst0_reg, d.imm1, ZKW_ATTR_DST0(d.attr), true);
+  Operand src0_loc = compute_address(P, sh, s, sp, src0_reg, d.imm0, ZKW_ATTR_SRC0(d.attr), false);
+  ps.dst0 = compute_address(P, sh, s, sp, dst0_reg, d.imm1, ZKW_ATTR_DST0(d.attr), true);
   s.sp = sp;                                            // :297
   if (opcode == ZKW_OP_NOP) src0_loc.has_loc = false;  // :298-301
   u256 src0_mem = u256_zero();
@@ -1567,7 +1611,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
     ps.src1_ptr = sw ? ap : bp;
   }
   ps.new_pc = (s.pc + 1) & 0xffffu;  // :347-350 (never a skip cycle here)
-  if (!s.is_kernel) {                // erase_fat_pointer_metadata :374-396
+  if (!(s.kflags & KF_KERNEL)) {     // erase_fat_pointer_metadata :374-396
     if (!(props & ZKW_PROP_SRC0_PTR_OK) && ps.src0_ptr) {
       ps.src0.w[1] = 0;
       ps.src0.w[2] = 0;
@@ -1656,7 +1700,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
       case ZKW_OP_FAR_CALL:
       case ZKW_OP_RET: {  // out of line; what they write to registers comes back as actions
         const u256 r15 = opcode == ZKW_OP_FAR_CALL ? rf_get(rf, 15) : u256_zero();
-        const HeavyOut out = zkw_heavy_entry(&P, sh.debug_flags, sh.wib, s, d, ps, r15);
+        const HeavyOut out = zkw_heavy_entry(&P, sh.debug_flags, sh.wib, sh.wave, s, d, ps, r15);
         s = out.s;
         if (out.action & ZKW_ACT_DST0) dst0_update(P, sh, rf, s, ps.dst0, d.dst0, out.v1, false);
         if (out.action & (ZKW_ACT_FAR | ZKW_ACT_RET)) {
@@ -1686,28 +1730,29 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
 // moment it LEAVES the cycle loop, from inside the loop: nothing of the lane state is then live after the loop, so the
 // compiler does not have to keep a per-iteration copy of ~30 registers for the lanes that have already left
 // (a loop with divergent exits preserves every live-out value of the exited lanes on each iteration).
-ZD void lane_writeback(ZKW_KP P, Shared& sh, const RegFile& rf, Lane& s) {
+// `completed` = cycles this lane completed in this launch
+ZD void lane_writeback(ZKW_KP P, Shared& sh, const RegFile& rf, Lane& s, u32 completed) {
   const u32 tid = s.lane;
   if (s.status == ZKW_STATUS_RUNNING && s.depth == 0) s.status = ZKW_STATUS_ENDED;  // execution_has_ended() (mod.rs:96-98)
-  frame_writeback(P, s);
-  hwm_writeback(P, s);
+  frame_writeback(P, sh, s);
+  hwm_writeback(P, sh, s);
   zkw_dev_scalars sc;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const uint2 v = sh.pcw[i * sh.L + tid];
+    const uint2 v = sh.pcw[i * ZKW_LDS_STRIDE + tid];
     sc.prev_code_word[2 * i] = v.x;
     sc.prev_code_word[2 * i + 1] = v.y;
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) sc.ctx_u128_reg[i] = CF(sh, s, CF_CTX0 + i);
-  sc.ptr_bitmap = s.ptr_bitmap; sc.flags = s.flags; sc.prev_code_page = s.prev_code_page; sc.timestamp = s.timestamp;
-  sc.cycle_counter = s.cycle_counter; sc.spent_pubdata = CF(sh, s, CF_SPENT_PUBDATA); sc.memory_page_counter = CF(sh, s, CF_MPC);
-  sc.absolute_execution_step = P.scalars[s.inst].absolute_execution_step; sc.ergs_per_pubdata = CF(sh, s, CF_ERGS_PP); sc.tx_number = CF(sh, s, CF_TX_NUMBER);
-  sc.prev_super_pc = s.prev_super_pc; sc.depth = s.depth; sc.status = s.status; sc.n_cycles = s.n_cycles; sc.first_dynamic_page = CF(sh, s, CF_FIRST_DYN);
+  sc.ptr_bitmap = s.ptr_bitmap; sc.flags = s.flags; sc.prev_code_page = (s.kflags & KF_CODE_PAGE_CHANGED) ? CF(sh, s, CF_PREV_CODE_PAGE) : CF(sh, s, CF_CODE_PAGE); sc.timestamp = s.timestamp;
+  sc.cycle_counter = CF(sh, s, CF_CYCLE_COUNTER0) + completed; sc.spent_pubdata = CF(sh, s, CF_SPENT_PUBDATA); sc.memory_page_counter = CF(sh, s, CF_MPC);
+  sc.absolute_execution_step = P.scalars[lane_inst(sh, s)].absolute_execution_step; sc.ergs_per_pubdata = CF(sh, s, CF_ERGS_PP); sc.tx_number = CF(sh, s, CF_TX_NUMBER);
+  sc.prev_super_pc = s.prev_super_pc; sc.depth = s.depth; sc.status = s.status; sc.n_cycles = CF(sh, s, CF_N_CYCLES0) + completed; sc.first_dynamic_page = CF(sh, s, CF_FIRST_DYN);
   sc.n_initial_slots = CF(sh, s, CF_N_INITIAL_SLOTS); sc.next_slot = CF(sh, s, CF_NEXT_SLOT); sc.journal_len = CF(sh, s, CF_JOURNAL_LEN); sc.n_history = CF(sh, s, CF_N_HISTORY);
   sc.reserved[0] = 0;
-  P.scalars[s.inst] = sc;
-  uint4* rg = P.regs + (u64)s.wave * ZKW_REG_CHUNKS * sh.L + tid;
+  P.scalars[lane_inst(sh, s)] = sc;
+  uint4* rg = P.regs + (u64)sh.wave * ZKW_REG_CHUNKS * sh.L + tid;
   for (u32 r = 0; r < ZKW_REGISTERS_COUNT; r++) {
     const u256 v = rf_get(rf, r + 1);
     rg[(u64)(2 * r) * sh.L] = u256_lo4(v);
@@ -1723,7 +1768,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
   ZKW_KP P = *(const zkw_kparams ZKW_CONST_AS*)A.kp[blockIdx.y];
   // one wave = one independent group of L VM instances; ZKW_WAVES_PER_GROUP waves per workgroup share the ISA table
   const u32 tid = threadIdx.x % P.wave_threads;
-  const u32 wib = threadIdx.x / P.wave_threads;
+  const u32 wib = zkw_uniform(threadIdx.x / P.wave_threads);  // a scalar: the per-wave bases below then live in SGPRs
   const u32 wave = blockIdx.x * P.waves_per_group + wib;
   Shared sh;
   shared_setup(sh, P, A.debug_flags, wib, wave, true);
@@ -1744,20 +1789,20 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
   const u32 inst = wave * P.L + tid;
   const bool exists = tid < P.L && inst < P.n_instances;
   Lane s;
-  s.inst = inst;
-  s.wave = wave;
   s.lane = tid;
+  s.pc = s.sp = s.ergs = s.timestamp = s.prev_super_pc = s.flags = s.kflags = s.ptr_bitmap = s.reg_dirty = s.counts = 0;
   RegFile rf;
   rf_init(rf);
   if (exists) {
     const zkw_dev_scalars sc = P.scalars[inst];
 #pragma unroll
-    for (int i = 0; i < 4; i++) sh.pcw[i * P.L + tid] = make_uint2(sc.prev_code_word[2 * i], sc.prev_code_word[2 * i + 1]);
+    for (int i = 0; i < 4; i++) sh.pcw[i * ZKW_LDS_STRIDE + tid] = make_uint2(sc.prev_code_word[2 * i], sc.prev_code_word[2 * i + 1]);
 #pragma unroll
     for (int i = 0; i < 4; i++) CF(sh, s, CF_CTX0 + i) = sc.ctx_u128_reg[i];
-    s.ptr_bitmap = sc.ptr_bitmap; s.flags = sc.flags; s.prev_code_page = sc.prev_code_page; s.timestamp = sc.timestamp;
-    s.cycle_counter = sc.cycle_counter; CF(sh, s, CF_SPENT_PUBDATA) = sc.spent_pubdata; CF(sh, s, CF_MPC) = sc.memory_page_counter; CF(sh, s, CF_ERGS_PP) = sc.ergs_per_pubdata;
-    CF(sh, s, CF_TX_NUMBER) = sc.tx_number; s.prev_super_pc = sc.prev_super_pc; s.depth = sc.depth; s.status = sc.status; s.n_cycles = sc.n_cycles;
+    s.ptr_bitmap = sc.ptr_bitmap; s.flags = sc.flags; s.timestamp = sc.timestamp;
+    CF(sh, s, CF_PREV_CODE_PAGE) = sc.prev_code_page; s.kflags = KF_CODE_PAGE_CHANGED;  // frame_load settles the marker
+    CF(sh, s, CF_CYCLE_COUNTER0) = sc.cycle_counter; CF(sh, s, CF_SPENT_PUBDATA) = sc.spent_pubdata; CF(sh, s, CF_MPC) = sc.memory_page_counter; CF(sh, s, CF_ERGS_PP) = sc.ergs_per_pubdata;
+    CF(sh, s, CF_TX_NUMBER) = sc.tx_number; s.prev_super_pc = sc.prev_super_pc; s.depth = sc.depth; s.status = sc.status; CF(sh, s, CF_N_CYCLES0) = sc.n_cycles;
     CF(sh, s, CF_FIRST_DYN) = sc.first_dynamic_page; CF(sh, s, CF_N_INITIAL_SLOTS) = sc.n_initial_slots; CF(sh, s, CF_NEXT_SLOT) = sc.next_slot; CF(sh, s, CF_JOURNAL_LEN) = sc.journal_len;
     CF(sh, s, CF_N_HISTORY) = sc.n_history;
     frame_load(P, sh, s);
@@ -1767,12 +1812,16 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
   } else {
     s.status = ZKW_STATUS_ENDED;  // parked lane
     s.depth = 0;
-    s.n_cycles = 0;
   }
 
+#ifdef ZKW_DEBUG_PRINT
+  if (tid == 0 && wave == 0 && blockIdx.y == 0)
+    printf("ZKWDBG exists %d depth %u status %u ergs %u pc %u code_page %u prev %u base %u code_len %u code_off %u kflags %x L %u wave %u wib %u inst %u\n", (int)exists, s.depth, s.status, s.ergs,
+           s.pc, CF(sh, s, CF_CODE_PAGE), CF(sh, s, CF_PREV_CODE_PAGE), CF(sh, s, CF_BASE_PAGE), CF(sh, s, CF_CODE_LEN), CF(sh, s, CF_CODE_OFF), s.kflags, sh.L, sh.wave, sh.wib, inst);
+#endif
   // running output pointers of this wave (advanced once per cycle instead of re-derived from the parameter block)
   u32* dir_ptr = P.dir + ((u64)wave * (P.max_cycles + 1) + cycle_base) * 4;
-  uint4* tail_ptr = P.tails + ((u64)wave * P.max_cycles + cycle_base) * 2 * sh.L + tid;
+  uint4* const tails_wave = P.tails + ((u64)wave * P.max_cycles + cycle_base) * 2 * sh.L;  // wave-uniform
   uint4* const delta_base = P.deltas + (u64)wave * P.cap_delta * 2;
   const u32 tail_step = 2 * sh.L;
   // The cycle loop is entered once by the lanes that are running and left per lane (divergent exit) when the lane ends,
@@ -1782,18 +1831,19 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
   u32 delta_cur = ZKW_LDS_WORD(sh.cursor)[3];
   uint2 next_slot = make_uint2(0, 0), next_e = make_uint2(0, 0);
   if (exists) {
-    next_slot = sh.pcw[(3u - (s.pc & 3u)) * sh.L + tid];
+    next_slot = sh.pcw[(3u - (s.pc & 3u)) * ZKW_LDS_STRIDE + tid];
     next_e = sh.isa[next_slot.x & (ZKW_ISA_TABLE_SIZE - 1)];
   }
-  if (exists && !(s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0)) lane_writeback(P, sh, rf, s);  // does not cycle
+  if (exists && !(s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0)) lane_writeback(P, sh, rf, s, 0);  // does not cycle
   if (exists && s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0) {
     for (;;) {
+      s.lane = zkw_opaque(tid);  // per-lane addresses are derived inside the iteration (see zkw_opaque)
       // directory: stream cursors at the start of wave-cycle (cycle_base + k).  Read here (one broadcast 16-B LDS read),
       // stored by the first remaining lane after the fetch below, so that the LDS latency hides behind it.  The
       // register-delta cursor is carried in a register: only the end of the cycle advances it.
       uint4 dir_entry = zkw_lds_read4(sh.cursor);
       dir_entry.w = delta_cur;
-      s.seq = 0; s.n_mem = 0; s.n_log = 0; s.n_aux = 0; s.cold_dirty = 0; s.reg_dirty = 0;
+      s.counts = 0; s.kflags &= ~KF_COLD_DIRTY; s.reg_dirty = 0;
       // ----------------------------------------------------------------------------------------
       // read_and_decode (cycle.rs:19-236)
       // ----------------------------------------------------------------------------------------
@@ -1802,11 +1852,11 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
       u64 enc;
       uint2 my_e;  // this lane's packed ISA entry (prefetched at the end of the previous cycle when no fetch is due)
       if (!pending) {
-        if (s.code_page != s.prev_code_page || s.prev_super_pc != super_pc) {  // :59-95
+        if ((s.kflags & KF_CODE_PAGE_CHANGED) || s.prev_super_pc != super_pc) {  // :59-95
           const u256 word = code_read(sh, s, super_pc);
-          emit_mem(P, sh, s, s.timestamp, ZKW_MEM_CODE, s.code_page, super_pc, word, false, false, 0);
+          emit_mem(P, sh, s, s.timestamp, ZKW_MEM_CODE, CF(sh, s, CF_CODE_PAGE), super_pc, word, false, false, 0);
 #pragma unroll
-          for (int i = 0; i < 4; i++) sh.pcw[i * sh.L + tid] = make_uint2(word.w[2 * i], word.w[2 * i + 1]);
+          for (int i = 0; i < 4; i++) sh.pcw[i * ZKW_LDS_STRIDE + s.lane] = make_uint2(word.w[2 * i], word.w[2 * i + 1]);
           s.prev_super_pc = super_pc;
           // integer_representaiton_from_u256: opcode k of a word is u64 limb 3-k (:86-94) — straight from the registers
           const u32 lo = sub_pc == 0 ? word.w[6] : (sub_pc == 1 ? word.w[4] : (sub_pc == 2 ? word.w[2] : word.w[0]));
@@ -1823,10 +1873,10 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
         enc = P.consts.exception_revert_encoding;
         my_e = sh.isa[(u32)enc & (ZKW_ISA_TABLE_SIZE - 1)];
       }
-      s.prev_code_page = s.code_page;  // :49
+      s.kflags &= ~KF_CODE_PAGE_CHANGED;  // previous_code_memory_page := code_page (:49)
       {
         const u64 in_loop = __ballot(1);
-        if (tid == (u32)__ffsll((long long)in_loop) - 1u) *(uint4*)dir_ptr = dir_entry;
+        if (s.lane == (u32)__ffsll((long long)in_loop) - 1u) *(uint4*)dir_ptr = dir_entry;
       }
       // ----------------------------------------------------------------------------------------
       // decode + execute, grouped by instruction word: take the first lane that has
@@ -1846,8 +1896,8 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
         const bool u_charged = __builtin_amdgcn_readlane((int)charged, (int)leader) != 0;
         // only lanes that are still waiting: a lane that already ran a genuine `nop` must not join the group of lanes
         // that were masked into the nop encoding later in the same cycle
-        bool mine = ((todo >> (threadIdx.x & (ZKW_WAVE - 1))) & 1ull) != 0 && enc_lo == u_lo && enc_hi == u_hi && charged == u_charged;
-        if (A.debug_flags & 4u) mine = (threadIdx.x & (ZKW_WAVE - 1)) == leader;  // test hook: one lane per group
+        bool mine = zkw_lane_bit(todo) && enc_lo == u_lo && enc_hi == u_hi && charged == u_charged;
+        if (A.debug_flags & 4u) mine = s.lane == leader;  // test hook: one lane per group
         const u32 u_attr = (u32)__builtin_amdgcn_readlane((int)my_e.x, (int)leader);  // the leader's entry: no LDS access in the loop
         const u32 u_price = (u32)__builtin_amdgcn_readlane((int)my_e.y, (int)leader);
         if (!u_charged) {  // uniform: first visit of this opcode word
@@ -1879,15 +1929,14 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
       }
       // prefetch for the next cycle (used only if that cycle does not fetch a new code word): its opcode slot of the
       // current word and the ISA entry of that opcode — two chained LDS reads that complete behind the record stores
-      next_slot = sh.pcw[(3u - (s.pc & 3u)) * sh.L + tid];
+      next_slot = sh.pcw[(3u - (s.pc & 3u)) * ZKW_LDS_STRIDE + s.lane];
       next_e = sh.isa[next_slot.x & (ZKW_ISA_TABLE_SIZE - 1)];
       // ----------------------------------------------------------------------------------------
       // end of cycle (cycle.rs:408-413)
       // ----------------------------------------------------------------------------------------
       if (lane_ok(s)) {
         s.timestamp += time_delta;
-        s.cycle_counter += 1;
-        if (s.cold_dirty) {
+        if (s.kflags & KF_COLD_DIRTY) {
           uint4* a = aux_alloc(P, sh, s, ZKW_AUX_COLD_STATE, 0, CF(sh, s, CF_SPENT_PUBDATA), CF(sh, s, CF_ERGS_PP), CF(sh, s, CF_TX_NUMBER));
           if (a) {
             a[1] = make_uint4(CF(sh, s, CF_CTX0 + 0), CF(sh, s, CF_CTX0 + 1), CF(sh, s, CF_CTX0 + 2), CF(sh, s, CF_CTX0 + 3));
@@ -1897,7 +1946,6 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
           }
         }
       }
-      if (lane_ok(s) && (A.debug_flags & 1u)) s.n_cycles++;
       if (!(A.debug_flags & 1u)) {
         // CycleRecord, delta form: the 512-byte snapshot the tracer observes (15 registers + 32-byte tail) is emitted as
         // the tail (dense [cycle][lane], coalesced) plus the 32-byte values of the registers THIS cycle wrote, compacted
@@ -1937,7 +1985,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
             const u64 part = __ballot(has);
             if (has) {
               const u256 v = rf_get(rf, r + 1u);
-              const u32 at = pos + (u32)__popcll(part & ((1ull << tid) - 1ull));
+              const u32 at = pos + zkw_rank_below(part);
               // two planes (low / high 16 bytes) so that each store instruction covers whole 64-byte lines
               zkw_stream_store(dl + (u64)at, u256_lo4(v));
               zkw_stream_store(dl + (u64)cap_delta + at, u256_hi4(v));
@@ -1946,26 +1994,25 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
           }
         }
         if (ok && fits) {
-          const u32 cnt = (s.n_mem > 255u ? 255u : s.n_mem) | ((s.n_log > 255u ? 255u : s.n_log) << 8) | ((s.n_aux > 255u ? 255u : s.n_aux) << 16);
+          const u32 cnt = s.counts >> 8;  // memory queries | log queries << 8 | aux events << 16 (saturating bytes)
           // dirty mask: bits 0-7 in the tail's reserved byte, bits 8-14 in the top byte of the event counts
+          uint4* const tail_ptr = tails_wave + (u64)k * tail_step + s.lane;
           zkw_stream_store(tail_ptr, make_uint4((s.ptr_bitmap & 0xffffu) | ((s.flags & 0xfu) << 16) | ((s.reg_dirty & 0xffu) << 24),
                                                 (s.pc & 0xffffu) | (s.sp << 16), s.ergs, s.timestamp));
-          zkw_stream_store(tail_ptr + sh.L, make_uint4(s.heap_bound, s.aux_bound, (s.depth & 0xffffu) | (s.prev_super_pc << 16), cnt | ((s.reg_dirty >> 8) << 24)));
-          s.n_cycles++;
+          zkw_stream_store(tail_ptr + sh.L, make_uint4(CF(sh, s, CF_HEAP_BOUND), CF(sh, s, CF_AUX_BOUND), (s.depth & 0xffffu) | (s.prev_super_pc << 16), cnt | ((s.reg_dirty >> 8) << 24)));
         }
         if (fits && total) {
           // `total` is the same for every lane still in the loop (ballots over exactly those lanes); the LDS copy is
           // only read after the loop (final directory entry), and a wave's LDS operations complete in order
           delta_cur = base + total;
-          if (tid == (u32)__ffsll((long long)__ballot(true)) - 1u) ZKW_LDS_WORD(sh.cursor)[3] = delta_cur;
+          if (s.lane == (u32)__ffsll((long long)__ballot(true)) - 1u) ZKW_LDS_WORD(sh.cursor)[3] = delta_cur;
         }
       }
       k++;
       dir_ptr += 4;
-      tail_ptr += tail_step;
       // leave: failed / out of cycles / execution_has_ended() (mod.rs:96-98: callers stop cycling at depth 0)
       if (!lane_ok(s) || k >= run_cycles || s.depth == 0) {
-        lane_writeback(P, sh, rf, s);
+        lane_writeback(P, sh, rf, s, lane_ok(s) ? k : k - 1u);  // a lane that failed did not complete its last cycle
         break;
       }
     }
@@ -2066,7 +2113,8 @@ extern "C" hipError_t zkw_launch_reset_kernel(const zkw_fused_table* T, hipStrea
 
 // dynamic LDS per workgroup: ISA table + per wave (cursors + per-lane cold state and previous_code_word)
 extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_group) {
-  return ZKW_ISA_TABLE_SIZE * 8 + waves_per_group * (16 + L * (ZKW_COLD_FIELDS * 4 + 32));
+  (void)L;  // rows have a fixed lane stride
+  return ZKW_ISA_TABLE_SIZE * 8 + waves_per_group * (16 + ZKW_LDS_STRIDE * (ZKW_COLD_FIELDS * 4 + 32));
 }
 
 // host-callable launcher (keeps <<<>>> out of the runtime)

@@ -1501,3 +1501,286 @@ uint32_t zkw_abi_sizeof(uint32_t which) {
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// Final exchange across the ranks of a job (include/zkw.h: zkw_comm_*, zkw_reduce_commitments).
+// RCCL is loaded at run time (dlopen): libzkw.so does not link it, so the library loads on hosts without RCCL and a
+// process that already carries an RCCL (e.g. the one inside a PyTorch wheel) keeps using that one.
+// =================================================================================================
+extern "C" hipError_t zkw_launch_pack_digests(const zkw_fused_table* T, uint64_t* dst, uint32_t n, uint32_t n_max, uint32_t mask, hipStream_t stream);
+
+#ifndef ZKW_EMU_BUILD
+#include <dlfcn.h>
+namespace {
+// the slice of the NCCL/RCCL C API this file uses (rccl.h: ncclUniqueId is 128 bytes, ncclComm_t an opaque pointer,
+// ncclUint64 = 5, ncclSum = 0, ncclMax = 2)
+struct RcclApi {
+  void* handle = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, zkw_comm_id, int) = nullptr;  // ncclUniqueId is passed by value
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string error;
+};
+RcclApi* rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return &api;
+  tried = true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char* n : names) {
+    api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (api.handle) break;
+  }
+  if (!api.handle) {
+    api.error = "librccl.so not found (dlopen)";
+    return &api;
+  }
+  api.GetUniqueId = (int (*)(void*))dlsym(api.handle, "ncclGetUniqueId");
+  api.CommInitRank = (int (*)(void**, int, zkw_comm_id, int))dlsym(api.handle, "ncclCommInitRank");
+  api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.handle, "ncclAllGather");
+  api.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(api.handle, "ncclAllReduce");
+  api.CommDestroy = (int (*)(void*))dlsym(api.handle, "ncclCommDestroy");
+  api.GetErrorString = (const char* (*)(int))dlsym(api.handle, "ncclGetErrorString");
+  if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.AllReduce || !api.CommDestroy) {
+    api.error = "librccl.so lacks the ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclAllReduce symbols";
+    api.handle = nullptr;
+  }
+  return &api;
+}
+}  // namespace
+#endif
+
+struct zkw_comm {
+  zkw_ctx* ctx = nullptr;
+  int rank = 0, world = 1;
+  void* nccl = nullptr;  // ncclComm_t (RCCL transport)
+  zkw_allgather_fn ext_allgather = nullptr;
+  zkw_allreduce_sum_u64_fn ext_allreduce = nullptr;
+  void* ext_user = nullptr;
+  // sizes of the ranks' shards, exchanged once per n_instances of this rank
+  uint32_t sizes_for_n = 0xffffffffu, n_max = 0;
+  std::vector<uint32_t> sizes;
+  DevBuf<uint64_t> d_send, d_small;  // packed digests of this rank; staging of the small exchanges
+  std::vector<uint64_t> h_send;      // external transport: host copy of the packed digests
+};
+
+static int comm_fail(zkw_comm* cm, const std::string& what) {
+  cm->ctx->last_error = what;
+  return ZKW_ERR_DEVICE;
+}
+
+// all-gather of `count` u64 per rank / all-reduce of `count` u64 on HOST buffers, over the communicator's transport
+static int comm_allgather_host(zkw_comm* cm, const uint64_t* send, uint64_t* recv, uint32_t count, hipStream_t st) {
+  if (cm->world == 1 && !cm->nccl) {  // (an RCCL communicator of one rank still goes through RCCL)
+    std::memcpy(recv, send, (size_t)count * 8);
+    return ZKW_OK;
+  }
+  if (cm->ext_allgather) return cm->ext_allgather(cm->ext_user, send, recv, (uint64_t)count * 8) == 0 ? ZKW_OK : comm_fail(cm, "external all-gather failed");
+#ifndef ZKW_EMU_BUILD
+  zkw_ctx* c = cm->ctx;
+  RcclApi* api = rccl_api();
+  if (cm->d_small.n < (size_t)count * (cm->world + 1)) {
+    cm->d_small.release();
+    HIP_TRY(c, cm->d_small.alloc((size_t)count * (cm->world + 1)));
+  }
+  HIP_TRY(c, hipMemcpyAsync(cm->d_small.p, send, (size_t)count * 8, hipMemcpyHostToDevice, st));
+  const int e = api->AllGather(cm->d_small.p, cm->d_small.p + count, count, 5 /* ncclUint64 */, cm->nccl, st);
+  if (e != 0) return comm_fail(cm, std::string("ncclAllGather: ") + (api->GetErrorString ? api->GetErrorString(e) : "error"));
+  HIP_TRY(c, hipMemcpyAsync(recv, cm->d_small.p + count, (size_t)count * cm->world * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  return ZKW_OK;
+#else
+  (void)st;
+  return comm_fail(cm, "no transport");
+#endif
+}
+static int comm_allreduce_host(zkw_comm* cm, uint64_t* inout, uint32_t count, bool max_op, hipStream_t st) {
+  if (cm->world == 1 && !cm->nccl) return ZKW_OK;
+  if (cm->ext_allreduce) {
+    if (!max_op) return cm->ext_allreduce(cm->ext_user, inout, count) == 0 ? ZKW_OK : comm_fail(cm, "external all-reduce failed");
+    // a maximum over the ranks through the all-gather (the external interface only offers a sum)
+    std::vector<uint64_t> all((size_t)count * cm->world);
+    int rc = comm_allgather_host(cm, inout, all.data(), count, st);
+    if (rc != ZKW_OK) return rc;
+    for (uint32_t i = 0; i < count; i++)
+      for (int r = 0; r < cm->world; r++) inout[i] = std::max(inout[i], all[(size_t)r * count + i]);
+    return ZKW_OK;
+  }
+#ifndef ZKW_EMU_BUILD
+  zkw_ctx* c = cm->ctx;
+  RcclApi* api = rccl_api();
+  if (cm->d_small.n < count) {
+    cm->d_small.release();
+    HIP_TRY(c, cm->d_small.alloc(count));
+  }
+  HIP_TRY(c, hipMemcpyAsync(cm->d_small.p, inout, (size_t)count * 8, hipMemcpyHostToDevice, st));
+  const int e = api->AllReduce(cm->d_small.p, cm->d_small.p, count, 5 /* ncclUint64 */, max_op ? 2 /* ncclMax */ : 0 /* ncclSum */, cm->nccl, st);
+  if (e != 0) return comm_fail(cm, std::string("ncclAllReduce: ") + (api->GetErrorString ? api->GetErrorString(e) : "error"));
+  HIP_TRY(c, hipMemcpyAsync(inout, cm->d_small.p, (size_t)count * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  return ZKW_OK;
+#else
+  (void)st;
+  return comm_fail(cm, "no transport");
+#endif
+}
+
+extern "C" {
+
+int zkw_comm_get_unique_id(zkw_comm_id* out) {
+  if (!out) return ZKW_ERR_INVALID;
+#ifndef ZKW_EMU_BUILD
+  RcclApi* api = rccl_api();
+  if (!api->handle) {
+    g_create_error = api->error;
+    return ZKW_ERR_DEVICE;
+  }
+  static_assert(sizeof(zkw_comm_id) == 128, "ncclUniqueId");
+  const int e = api->GetUniqueId(out);
+  if (e != 0) {
+    g_create_error = std::string("ncclGetUniqueId: ") + (api->GetErrorString ? api->GetErrorString(e) : "error");
+    return ZKW_ERR_DEVICE;
+  }
+  return ZKW_OK;
+#else
+  g_create_error = "RCCL is not part of the CPU emulation build";
+  return ZKW_ERR_DEVICE;
+#endif
+}
+
+int zkw_comm_create_rccl(zkw_ctx* ctx, int rank, int world, const zkw_comm_id* id, zkw_comm** out) {
+  if (!ctx || !id || !out || world < 1 || rank < 0 || rank >= world) return ZKW_ERR_INVALID;
+#ifndef ZKW_EMU_BUILD
+  RcclApi* api = rccl_api();
+  if (!api->handle) {
+    ctx->last_error = api->error;
+    return ZKW_ERR_DEVICE;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  auto* cm = new zkw_comm();
+  cm->ctx = ctx; cm->rank = rank; cm->world = world;
+  const int e = api->CommInitRank(&cm->nccl, world, *id, rank);
+  if (e != 0) {
+    ctx->last_error = std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(e) : "error");
+    delete cm;
+    return ZKW_ERR_DEVICE;
+  }
+  *out = cm;
+  return ZKW_OK;
+#else
+  ctx->last_error = "RCCL is not part of the CPU emulation build";
+  return ZKW_ERR_DEVICE;
+#endif
+}
+
+int zkw_comm_create_external(zkw_ctx* ctx, int rank, int world, zkw_allgather_fn allgather, zkw_allreduce_sum_u64_fn allreduce_sum, void* user,
+                             zkw_comm** out) {
+  if (!ctx || !out || world < 1 || rank < 0 || rank >= world || (world > 1 && (!allgather || !allreduce_sum))) return ZKW_ERR_INVALID;
+  auto* cm = new zkw_comm();
+  cm->ctx = ctx; cm->rank = rank; cm->world = world;
+  cm->ext_allgather = allgather; cm->ext_allreduce = allreduce_sum; cm->ext_user = user;
+  *out = cm;
+  return ZKW_OK;
+}
+
+void zkw_comm_destroy(zkw_comm* cm) {
+  if (!cm) return;
+#ifndef ZKW_EMU_BUILD
+  if (cm->nccl) (void)rccl_api()->CommDestroy(cm->nccl);
+#endif
+  cm->d_send.release();
+  cm->d_small.release();
+  delete cm;
+}
+
+int zkw_reduce_commitments(zkw_comm* cm, zkw_batch* const* batches, uint32_t n_batches, uint32_t queue_mask, void* gathered, uint32_t* n_max_out,
+                           uint32_t* sizes_out, zkw_run_stats* total, void* hip_stream) {
+  if (!cm || !batches || n_batches == 0) return ZKW_ERR_INVALID;
+  int rc = check_group(batches, n_batches);
+  if (rc != ZKW_OK) return rc;
+  zkw_ctx* c = cm->ctx;
+  if (batches[0]->ctx != c) {
+    c->last_error = "zkw_reduce_commitments: the batches belong to another context than the communicator";
+    return ZKW_ERR_INVALID;
+  }
+  const uint32_t n = batches[0]->n;
+  for (uint32_t i = 1; i < n_batches; i++)
+    if (batches[i]->n != n) {
+      c->last_error = "zkw_reduce_commitments: the batches of one rank must have the same number of instances";
+      return ZKW_ERR_INVALID;
+    }
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const bool external = !cm->nccl;
+  // shard sizes: once per n (the exchange waits for the stream)
+  if (cm->sizes_for_n != n) {
+    std::vector<uint64_t> all((size_t)cm->world);
+    const uint64_t mine = n;
+    rc = comm_allgather_host(cm, &mine, all.data(), 1, st);
+    if (rc != ZKW_OK) return rc;
+    cm->sizes.assign(cm->world, 0);
+    cm->n_max = 0;
+    for (int r = 0; r < cm->world; r++) {
+      cm->sizes[r] = (uint32_t)all[r];
+      cm->n_max = std::max(cm->n_max, cm->sizes[r]);
+    }
+    cm->sizes_for_n = n;
+  }
+  if (n_max_out) *n_max_out = cm->n_max;
+  if (sizes_out) std::memcpy(sizes_out, cm->sizes.data(), (size_t)cm->world * 4);
+  queue_mask &= 7u;
+  const uint32_t nq = (uint32_t)__builtin_popcount(queue_mask);
+  if (gathered && nq) {
+    const size_t per_rank = (size_t)n_batches * cm->n_max * nq * 4;  // u64
+    if (cm->d_send.n < per_rank) {
+      cm->d_send.release();
+      HIP_TRY(c, cm->d_send.alloc(per_rank));
+    }
+    zkw_fused_table T;
+    std::memset(&T, 0, sizeof T);
+    T.n = n_batches;
+    T.wave_threads = (uint32_t)c->wave_width;
+    for (uint32_t i = 0; i < n_batches; i++) T.p[i] = batches[i]->d_commit.p;
+    HIP_TRY(c, zkw_launch_pack_digests(&T, cm->d_send.p, n, cm->n_max, queue_mask, st));
+    if (!external) {
+#ifndef ZKW_EMU_BUILD
+      RcclApi* api = rccl_api();
+      const int e = api->AllGather(cm->d_send.p, gathered, per_rank, 5 /* ncclUint64 */, cm->nccl, st);
+      if (e != 0) return comm_fail(cm, std::string("ncclAllGather: ") + (api->GetErrorString ? api->GetErrorString(e) : "error"));
+#endif
+    } else {  // host transport: the packed digests cross to the host, the callback exchanges them
+      cm->h_send.resize(per_rank);
+      HIP_TRY(c, hipMemcpyAsync(cm->h_send.data(), cm->d_send.p, per_rank * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipStreamSynchronize(st));
+      if (cm->world == 1) std::memcpy(gathered, cm->h_send.data(), per_rank * 8);
+      else if (cm->ext_allgather(cm->ext_user, cm->h_send.data(), gathered, (uint64_t)per_rank * 8) != 0) return comm_fail(cm, "external all-gather failed");
+    }
+  }
+  if (total) {
+    uint64_t cnt[7] = {0, 0, 0, 0, 0, 0, 0};
+    double kernel_ms = 0;
+    for (uint32_t i = 0; i < n_batches; i++) {
+      zkw_run_stats s;
+      rc = zkw_batch_get_stats(batches[i], &s);  // waits for the batch's run
+      if (rc != ZKW_OK) return rc;
+      cnt[0] += s.cycles; cnt[1] += s.mem_queries; cnt[2] += s.log_queries; cnt[3] += s.aux_events;
+      cnt[4] += s.instances_ended; cnt[5] += s.instances_failed; cnt[6] += s.reg_deltas;
+      kernel_ms = std::max(kernel_ms, s.kernel_ms);
+    }
+    rc = comm_allreduce_host(cm, cnt, 7, false, st);
+    if (rc != ZKW_OK) return rc;
+    uint64_t ms_bits = (uint64_t)(kernel_ms * 1e6);  // ns, as an integer for the max-reduction
+    rc = comm_allreduce_host(cm, &ms_bits, 1, true, st);
+    if (rc != ZKW_OK) return rc;
+    std::memset(total, 0, sizeof *total);
+    total->cycles = cnt[0]; total->mem_queries = cnt[1]; total->log_queries = cnt[2]; total->aux_events = cnt[3];
+    total->instances_ended = cnt[4]; total->instances_failed = cnt[5]; total->reg_deltas = cnt[6];
+    total->kernel_ms = (double)ms_bits * 1e-6;
+  }
+  return ZKW_OK;
+}
+
+}  // extern "C"

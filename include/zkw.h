@@ -477,6 +477,43 @@ int zkw_batch_copy_commitments(zkw_batch* batch, void* dst_device, void* hip_str
 /* device pointer (n_instances * ZKW_QUEUE_COUNT * 4 u64) for the RCCL all-gather */
 int zkw_batch_commitments_device_ptr(zkw_batch* batch, void** dptr, uint64_t* n_bytes);
 
+/* ---- final exchange across the ranks of a job (SURVEY §8b `zkw_reduce_commitments`, §8e) ----
+ * VM instances shard across GPUs with no data-path collective; the only exchange is the final one: an all-gather of
+ * the per-instance queue digests and an all-reduce (sum) of the run counters.  One process per GPU.  Two transports:
+ *   RCCL over xGMI   rank 0 calls zkw_comm_get_unique_id, hands the 128 bytes to the other ranks over any side
+ *                    channel (a file, a socket, torch.distributed), then every rank calls zkw_comm_create_rccl;
+ *                    librccl is loaded at that moment (dlopen), libzkw.so itself does not link it;
+ *   external         the caller supplies the two collectives over HOST buffers (MPI, gloo, ...): same entry point,
+ *                    same packing, the exchange itself runs through the callbacks. */
+typedef struct zkw_comm zkw_comm;
+typedef struct zkw_comm_id {
+  uint8_t bytes[128]; /* ncclUniqueId */
+} zkw_comm_id;
+int zkw_comm_get_unique_id(zkw_comm_id* out);
+int zkw_comm_create_rccl(zkw_ctx* ctx, int rank, int world, const zkw_comm_id* id, zkw_comm** out);
+/* recv = world x bytes_per_rank, rank order; return 0 on success */
+typedef int (*zkw_allgather_fn)(void* user, const void* send, void* recv, uint64_t bytes_per_rank);
+typedef int (*zkw_allreduce_sum_u64_fn)(void* user, uint64_t* inout, uint32_t count);
+int zkw_comm_create_external(zkw_ctx* ctx, int rank, int world, zkw_allgather_fn allgather, zkw_allreduce_sum_u64_fn allreduce_sum,
+                             void* user, zkw_comm** out);
+void zkw_comm_destroy(zkw_comm* comm);
+/* The final exchange for `n_batches` committed batches of this rank (zkw_batch_commit / zkw_batches_commit with at
+ * least the queues of `queue_mask`, enqueued earlier on `hip_stream` or ordered before it by the caller).  Every rank
+ * passes the same n_batches and queue_mask; ranks may own different numbers of instances per batch (ragged shards: all
+ * batches of one rank have the same n_instances; rows are padded to the largest rank, sizes[] tells them apart).
+ *   gathered   [world][n_batches][n_max][popcount(queue_mask)][4] u64, queues in ascending order — DEVICE memory for an
+ *              RCCL communicator (the all-gather is enqueued on `hip_stream`, asynchronously), HOST memory for an
+ *              external one (the call then waits for the stream).  NULL: no digest exchange.
+ *   n_max_out  optional: rows per rank in `gathered` (= max over the ranks of n_instances)
+ *   sizes_out  optional [world]: n_instances of every rank
+ *   total      optional: the run counters of these batches summed over all ranks (cycles, queries, aux events, ended /
+ *              failed instances, register deltas; kernel_ms = max over the ranks).  Waits for the stream (the counters
+ *              come from the finished runs).  NULL: no counter exchange.
+ * The first call of a communicator with a given n_instances exchanges the sizes (and waits for it); later calls with
+ * gathered != NULL and total == NULL are fully asynchronous. */
+int zkw_reduce_commitments(zkw_comm* comm, zkw_batch* const* batches, uint32_t n_batches, uint32_t queue_mask, void* gathered,
+                           uint32_t* n_max_out, uint32_t* sizes_out, zkw_run_stats* total, void* hip_stream);
+
 /* ---- final net states: what the reference's get_final_net_states (testing/mod.rs:42-71) returns ----
  * The device nets the log stream of every instance against its frame events exactly like
  * InMemoryStorage::finish_frame / flatten_and_net_history (testing/storage.rs:34-76,144-186) and

@@ -7,6 +7,7 @@
 // on a box without a GPU.  Lane-parallel behaviour (ballot ranks across 64 lanes, LDS banking,
 // coalescing) is only exercised by the `-m gpu` tests on a real MI355X.
 #pragma once
+#define ZKW_EMU_BUILD 1 /* the product sources see this only in the tests/emu build */
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
