@@ -41,6 +41,23 @@ def main():
     ap.add_argument("--commit-mask", type=int, default=4, help="queue commitments computed inside every step: bit0 memory, bit1 log, bit2 decommit (BASELINE configs[2]: decommit queue)")
     args = ap.parse_args()
 
+    # `--gpus N` must mean N ranks.  Under torchrun (the driver's launch for N > 1) WORLD_SIZE says so; started plainly
+    # with N > 1 this process re-executes itself under torch.distributed.run, one rank per GPU — it never runs one
+    # rank and reports N.
+    if "WORLD_SIZE" in os.environ:
+        if int(os.environ["WORLD_SIZE"]) != args.gpus:
+            sys.exit("bench.py: --gpus %d but WORLD_SIZE=%s (launch with --nproc-per-node %d)" % (args.gpus, os.environ["WORLD_SIZE"], args.gpus))
+    elif args.gpus > 1:
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     import torch
     import torch.distributed as dist
     from era_zk_evm_amd import capi as K, synth
@@ -62,6 +79,16 @@ def main():
 
     isa = K.Isa()
     prod = K.load_product().open(isa, device=local_rank)
+    # The final exchange goes through the library's own entry point (zkw_reduce_commitments, include/zkw.h): an RCCL
+    # communicator created from an id that rank 0 generates and hands to the others (here over the process group that
+    # also serves the barriers).  One rank without --force-collective: a one-rank communicator without RCCL, used for
+    # the counter totals only.
+    if collective:
+        ids = [K.Comm.unique_id(prod) if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0, device=torch.device("cuda", local_rank))
+        comm = K.Comm.rccl(prod, rank, world, ids[0])
+    else:
+        comm = K.Comm.external(prod, 0, 1)
     # shard: every rank owns `instances` independent VM instances (different seeds), no data-path collective
     if args.cfg == 0:  # NOP/ADD plumbing tape replicated over many instances (loop-overhead floor)
         wl = synth.make(1, isa, n_instances=args.instances, n_cycles=args.cycles, seed=0x5EED0000 + 0x100 * rank)
@@ -96,17 +123,13 @@ def main():
         torch.cuda.synchronize()
 
     import ctypes as C
-    from era_zk_evm_amd import shard  # noqa: F401  (final_reduce is exercised by tests; the bench keeps the raw collective)
 
     # final exchange: all-gather of the per-instance queue digests over RCCL, once per fused group
     # only the committed queues travel: [fuse, instances, n_committed, 4] u64 per group
+    # only the committed queues travel: [world][batches][instances][n_committed][4] u64 per group (layout of zkw_reduce_commitments)
     committed = [q for q in range(3) if (args.commit_mask >> q) & 1]
-    digests = [torch.zeros((fuse, args.instances, 3, 4), dtype=torch.int64, device="cuda") for _ in range(n_groups)]
-    packed = [torch.zeros((fuse, args.instances, max(1, len(committed)), 4), dtype=torch.int64, device="cuda") for _ in range(n_groups)]
-    gathered = [torch.zeros((world * fuse, args.instances, max(1, len(committed)), 4), dtype=torch.int64, device="cuda") if collective else None
+    gathered = [torch.zeros((world, fuse, args.instances, max(1, len(committed)), 4), dtype=torch.int64, device="cuda") if collective else None
                 for _ in range(n_groups)]
-    q_index = torch.tensor(committed if committed else [0], dtype=torch.long, device="cuda")
-    digest_bytes = args.instances * 3 * 4 * 8
 
     # Pipelining over streams (--streams >= 2): the main stream carries the cycle kernels of the groups back to back;
     # every group has a side stream that carries its commitment kernels (integer-ALU bound), the digest exchange and
@@ -142,12 +165,8 @@ def main():
             sptr = stream.cuda_stream
             stream.wait_event(ev_run[g])
             prod.commit_many(groups[g][:n], args.commit_mask, sptr)
-        if args.commit_mask and collective:
-            for j, b in enumerate(groups[g][:n]):
-                prod.call("batch_copy_commitments", b.h, C.c_void_p(digests[g].data_ptr() + j * digest_bytes), C.c_void_p(sptr))
-            with torch.cuda.stream(stream):
-                torch.index_select(digests[g], 2, q_index, out=packed[g])  # drop the queues that were not committed
-                dist.all_gather_into_tensor(gathered[g], packed[g])
+        if args.commit_mask and collective:  # pack kernel + ncclAllGather, enqueued on the group's stream (asynchronous)
+            comm.reduce(groups[g][:n], args.commit_mask, gathered=gathered[g].data_ptr(), stream=sptr)
         if overlap:
             if side_reset:
                 prod.reset_many(groups[g], sptr)  # the whole group, so that a later partial launch finds it restored
@@ -200,10 +219,26 @@ def main():
         prod.run_many(groups[0], wl.n_cycles, main_stream.cuda_stream)
         main_stream.synchronize()
     k_ms_alone = drain_timing()[0]
+    # verification pass (untimed): the pipelined loop leaves every group restored for its next use, so the counters
+    # of the timed runs are gone; every step replays the same inputs, so one more run of every group shows what each
+    # of them did
+    for g_ in groups[1:]:
+        prod.reset_many(g_, main_stream.cuda_stream)
+        prod.run_many(g_, wl.n_cycles, main_stream.cuda_stream)
+    main_stream.synchronize()
+    drain_timing()
     batch.sync()
     st = batch.stats()
-    if int(st["instances_failed"]) != 0:
-        raise RuntimeError("bench: %d instances of the batch stopped on a capacity limit or an error status" % int(st["instances_failed"]))
+    # every batch of every group, every rank: the last run of each must have executed all of its cycles with no instance
+    # stopped on a capacity limit or an error status (counters summed by zkw_reduce_commitments — RCCL all-reduce at N > 1)
+    tot_cycles = tot_failed = 0
+    for i in range(0, len(batches), 128):
+        _, _, _, tot = comm.reduce(batches[i:i + 128], 0, want_total=True, stream=main_stream.cuda_stream)
+        tot_cycles += int(tot["cycles"])
+        tot_failed += int(tot["instances_failed"])
+    expect = world * len(batches) * args.instances * args.cycles
+    if tot_failed != 0 or (args.cfg in (0, 1, 2) and tot_cycles != expect):
+        raise RuntimeError("bench: %d instances stopped on a capacity limit or an error status; %d of %d cycles executed" % (tot_failed, tot_cycles, expect))
     # untimed: what pulling one step's whole trace over PCIe would cost
     dl_bytes, dl_ms = C.c_uint64(0), C.c_double(0)
     prod.call("batch_download_all", batch.h, C.byref(dl_bytes), C.byref(dl_ms))
@@ -223,7 +258,15 @@ def main():
         # roofline: algorithmic bytes per cycle x cycles of one launch / kernel time
         n_mem = float(st["mem_queries"]) / max(1, cycles_per_step)
         n_log = float(st["log_queries"]) / max(1, cycles_per_step)
-        heap_words = 0.9 if args.cfg == 2 else 0.0
+        # heap / aux-heap words touched per cycle: counted on the first wave's traces of this run (every UMA word
+        # access is one memory query of type heap / aux heap)
+        hw = cy = 0
+        for i in range(min(64, args.instances)):
+            tr = batch.trace(i)
+            ty = tr["mem"]["meta"] & K.MQ_TYPE_MASK
+            hw += int(((ty == K.MEM_HEAP) | (ty == K.MEM_AUX_HEAP)).sum())
+            cy += int(tr["n_cycles"])
+        heap_words = hw / max(1, cy)
         n_delta = float(st["reg_deltas"]) / max(1, cycles_per_step)
         # bytes the kernel has to move per VM cycle: code word + record tail + register deltas + queries + heap words
         # (the 512-B snapshot of SURVEY §8d is stored losslessly as 32-B tail + 32 B per written register)
@@ -246,15 +289,17 @@ def main():
             "pcie_download_of_one_step": {"bytes": dl_bytes.value, "ms": dl_ms.value, "GBps": dl_bytes.value / max(dl_ms.value, 1e-9) / 1e6,
                                           "cycles_per_s_if_every_step_were_downloaded": cycles_per_step / (1e-3 * (dl_ms.value + ms_per_step))}, "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
             "kernel_cycles_per_s": cycles_per_step * batches_per_launch / (k_ms * 1e-3),
+            "checked": {"batches": len(batches) * world, "cycles_executed": tot_cycles, "instances_failed": tot_failed},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "frac_alone": b_cycle * cycles_per_step * len(groups[0]) / (k_ms_alone * 1e-3) / 1e9 / 8000.0, "bytes_per_cycle": b_cycle, "snapshot_equivalent_bytes_per_cycle": b_cycle_snapshot, "snapshot_equivalent_GBps": b_cycle_snapshot * cycles_per_step * batches_per_launch / (k_ms * 1e-3) / 1e9, "cycles_per_launch": cycles_per_step * batches_per_launch,
+                         "frac_alone": b_cycle * cycles_per_step * len(groups[0]) / (k_ms_alone * 1e-3) / 1e9 / 8000.0, "bytes_per_cycle": b_cycle, "heap_words_per_cycle": heap_words, "snapshot_equivalent_bytes_per_cycle": b_cycle_snapshot, "snapshot_equivalent_GBps": b_cycle_snapshot * cycles_per_step * batches_per_launch / (k_ms * 1e-3) / 1e9, "cycles_per_launch": cycles_per_step * batches_per_launch,
                          "chip_achieved": b_cycle * value / 1e9, "chip_frac": b_cycle * value / 1e9 / 8000.0},
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(isa, args)
+            out["cpu_baseline"] = cpu_baseline(isa, args, prod)
     if os.environ.get("ZKW_BENCH_MEMINFO"):
         free_b, total_b = torch.cuda.mem_get_info(local_rank)
         print("rank %d: device memory in use %.1f GB of %.1f GB" % (rank, (total_b - free_b) / 2**30, total_b / 2**30), file=sys.stderr)
+    comm.close()
     if collective:
         dist.destroy_process_group()
     if rank == 0:  # the JSON line is the last thing on stdout (RCCL prints its own banner lines during init / teardown)
@@ -278,36 +323,99 @@ def measured_traffic(args, batches_per_launch):
     return per_launch * batches_per_launch / float(j.get("fused_batches", 1))
 
 
-def cpu_baseline(isa, args):
-    """The oracle (C++ restatement of zk_evm v1.4.1 cycle(), -O3 -march=native) timed on this box's
-    host cores on a bounded sample of the same workload."""
+def _cpu_topology():
+    """(model name, {package id: [logical cpus, one hardware thread per core first, then the SMT siblings]})"""
+    model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    pk = {}
+    base = "/sys/devices/system/cpu"
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    for cpu in allowed:
+        try:
+            pkg = int(open("%s/cpu%d/topology/physical_package_id" % (base, cpu)).read())
+            core = int(open("%s/cpu%d/topology/core_id" % (base, cpu)).read())
+        except (OSError, ValueError):
+            pkg, core = 0, cpu
+        pk.setdefault(pkg, {}).setdefault(core, []).append(cpu)
+    out = {}
+    for pkg, cores in pk.items():
+        first = [c[0] for c in cores.values()]
+        rest = [x for c in cores.values() for x in c[1:]]
+        out[pkg] = sorted(first) + sorted(rest)
+    return model, out
+
+
+def cpu_baseline(isa, args, prod=None):
+    """The oracle (C++ restatement of zk_evm v1.4.1 cycle(), -O3 -march=native) timed on this box's host cores on a
+    bounded sample of the same workload: persistent pinned worker threads (no thread creation in the timed region),
+    one contiguous block of >= 64 instances per worker, recorder capacity reserved before the clock starts.  Three
+    figures: one core, one socket (every hardware thread of package 0), the whole box."""
     from era_zk_evm_amd import capi as K, synth
     import ctypes as C
-
-    cores = os.cpu_count() or 1
+    import numpy as np
     from tests._oracle import load_oracle  # the checker: only the cpu_baseline leg touches it
 
+    model, packages = _cpu_topology()
+    all_cpus = [c for p in sorted(packages) for c in packages[p]]
+    socket0 = packages[sorted(packages)[0]]
     orc = load_oracle(native=True).open(isa)
-    n = 1024
-    wl = synth.make(args.cfg, isa, n_instances=n, n_cycles=args.cycles)
-    b = orc.create_batch(wl)
     res = {}
-    for label, threads in (("1", 1), ("all", cores)):
-        orc.lib.zkwo_batch_set_threads(b.h, C.c_uint32(threads))
-        best = None
-        reps = 0
-        t_start = time.perf_counter()
-        while reps < 3 or time.perf_counter() - t_start < 4.0:
-            b.reset()
+    t_leg = time.perf_counter()
+
+    def timed(label, cpus, n_inst):
+        wl = synth.make(args.cfg, isa, n_instances=n_inst, n_cycles=args.cycles)
+        wl.limits["max_cycles"] = args.cycles
+        b = orc.create_batch(wl)
+        arr = (C.c_int32 * len(cpus))(*cpus)
+        orc.lib.zkwo_batch_set_pool(b.h, C.c_uint32(len(cpus)), arr, C.c_uint32(len(cpus)))
+        best, reps, t0 = None, 0, time.perf_counter()
+        while reps < 3 or (time.perf_counter() - t0 < 3.0 and reps < 40):
+            b.reset()  # rebuilds the VMs and reserves the recorders (untimed)
             b.run(wl.n_cycles)
             ms = float(b.stats()["kernel_ms"])
             best = ms if best is None else min(best, ms)
             reps += 1
-            if reps >= 50:
-                break
-        res[label] = n * wl.n_cycles / (best * 1e-3)
-    return {"value": res["all"], "unit": "cycles/s", "cores": cores, "kind": "port", "single_core_value": res["1"],
-            "sample": "%d instances x %d cycles of the same cfg-%d tape, best of repeated runs, one instance per worker thread" % (n, wl.n_cycles, args.cfg)}
+        res[label] = {"value": n_inst * wl.n_cycles / (best * 1e-3), "threads": len(cpus), "instances": n_inst, "best_ms": best, "runs": reps}
+        b.destroy()
+
+    timed("one_core", all_cpus[:1], 256)
+    timed("one_socket", socket0, max(64 * len(socket0), 4096))
+    if len(all_cpus) > len(socket0):
+        timed("whole_box", all_cpus, max(64 * len(all_cpus), 4096))
+    else:
+        res["whole_box"] = res["one_socket"]
+    phys = len(set(all_cpus))
+    out = {"value": res["whole_box"]["value"], "unit": "cycles/s", "cores": res["whole_box"]["threads"], "kind": "port",
+           "single_core_value": res["one_core"]["value"], "single_socket_value": res["one_socket"]["value"], "single_socket_threads": res["one_socket"]["threads"],
+           "cpu_model": model, "nproc": os.cpu_count(), "packages": len(packages), "logical_cpus_used": phys,
+           "scaling_all_over_one": res["whole_box"]["value"] / res["one_core"]["value"],
+           "sample": "cfg-%d tape, %d cycles per instance: %d instances on one core, %d on socket 0 (%d threads), %d on the whole box (%d threads); "
+                     "persistent pinned workers, >= 64 instances each, recorders pre-reserved, best of %d-%d runs; the whole leg took %.1f s"
+                     % (args.cfg, args.cycles, res["one_core"]["instances"], res["one_socket"]["instances"], res["one_socket"]["threads"],
+                        res["whole_box"]["instances"], res["whole_box"]["threads"], min(r["runs"] for r in res.values()), max(r["runs"] for r in res.values()),
+                        time.perf_counter() - t_leg)}
+    # the same leg validates the product against the checker on a fresh small batch of the bench's workload: every
+    # queue commitment of every instance and the full traces of a few instances, bit for bit
+    if prod is not None:
+        wl = synth.make(args.cfg, isa, n_instances=128, n_cycles=args.cycles, seed=0x5EED0000 + args.cfg)
+        bo, bp = orc.create_batch(wl), prod.create_batch(wl)
+        for b in (bo, bp):
+            b.reset(); b.run(wl.n_cycles); b.sync()
+        same = bool(np.array_equal(bo.commitments(), bp.commitments()))
+        traces = all(K.traces_equal(bo.trace(i), bp.trace(i))[0] for i in (0, 1, 63, 64, 127))
+        out["product_vs_oracle"] = {"instances": 128, "commitments_equal": same, "traces_equal": traces}
+        if not (same and traces):
+            raise RuntimeError("bench: the product's witness differs from the oracle's on the validation batch")
+    return out
 
 
 if __name__ == "__main__":

@@ -34,8 +34,12 @@
 // per-lane execution context (lives in VGPRs; every helper below is force-inlined)
 // ---------------------------------------------------------------------------------------------
 struct Lane {
-  u32 lane;  // lane of the wave = thread index in the wave
-  // what every cycle touches stays in vector registers (13 of them)
+  // Lane of the wave.  Re-derived from the hardware (zkw_lane_id) at the top of every cycle and of every opcode body
+  // instead of being kept from the kernel start: the addresses derived from it then cannot be hoisted out of the cycle
+  // loop (some forty of them were, each owning a register for the whole loop, all of them in scratch memory), and the
+  // handful of asm statements per cycle this costs does not fence the scheduler the way one per access would.
+  u32 lane;
+  // what every cycle touches stays in vector registers (12 more)
   u32 pc, sp, ergs, timestamp, prev_super_pc, depth, status;
   u32 flags;       // FLAG_*
   u32 kflags;      // KF_*: frame properties + per-cycle markers
@@ -47,6 +51,8 @@ struct Lane {
 #define KF_STATIC 2u       /* callstack.current.is_static */
 #define KF_LOCAL 4u        /* callstack.current.is_local_frame */
 #define KF_COLD_DIRTY 8u   /* a cold VmLocalState field changed in this cycle (ZKW_AUX_COLD_STATE goes out) */
+#define KF_CHARGED 32u     /* this cycle's price is taken and its exceptions / condition are resolved (group loop) */
+#define KF_MASKED 64u      /* the instruction of this cycle is the one in sh.enc (pending exception, masked into nop / panic), not the slot of the code word */
 #define KF_CODE_PAGE_CHANGED 16u /* previous_code_memory_page != callstack.current.code_page (cycle.rs:49,59) */
 // The rest of the per-lane state lives in LDS, [field][lane] (conflict-free dword accesses); CF(sh, s, field) is an
 // lvalue.  Rare opcodes touch the first block, memory operands / frame changes the second.
@@ -70,7 +76,7 @@ enum {
 #endif
 // (the lane index goes through zkw_opaque at every access: a shared, long-lived address register would be the first
 // thing the allocator spills around the opcode switch — one v_lshl_add per access is cheaper than that reload)
-#define CF(sh, s, f) ((sh).cold[(u32)(f) * ZKW_LDS_STRIDE + zkw_opaque((s).lane)])
+#define CF(sh, s, f) ((sh).cold[(u32)(f) * ZKW_LDS_STRIDE + (s).lane])
 #define lane_inst(sh, s) ((sh).wave * (sh).L + (s).lane)
 
 #define FLAG_LT 1u
@@ -119,6 +125,17 @@ ZD uint4 zkw_lds_read4(const u32* p) {
 ZD uint4 zkw_lds_read4(const u32* p) { return make_uint4(ZKW_LDS_WORD(p)[0], ZKW_LDS_WORD(p)[1], ZKW_LDS_WORD(p)[2], ZKW_LDS_WORD(p)[3]); }
 #endif
 
+#ifdef __HIP_DEVICE_COMPILE__
+ZD void zkw_lds_write4(uint4* p, const uint4 v) {
+  typedef unsigned int zkw_lds_v4 __attribute__((ext_vector_type(4)));
+  zkw_lds_v4 t;
+  t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  *(volatile zkw_lds_v4 __attribute__((address_space(3)))*)(p) = t;
+}
+#else
+ZD void zkw_lds_write4(uint4* p, const uint4 v) { *p = v; }
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // wave-level stream compaction: every lane that reaches this point (possibly under divergence)
 // gets a unique, dense slot of the wave's stream: ballot -> rank by popcount of lower lanes.  The cursor lives in
@@ -137,6 +154,13 @@ ZD u32 zkw_opaque(u32 x) {
   asm volatile("" : "+v"(x));
   return x;
 }
+// lane of the wave from the hardware (two v_mbcnt): nothing to keep in a register (or to reload from scratch)
+// (inside the volatile asm: the builtins are pure functions of constants and would be hoisted to one kernel-long value)
+ZD u32 zkw_lane_id() {
+  u32 x;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+  return x;
+}
 // bit `lane` of a wave mask: a select on the mask itself (no 1 << lane register to keep alive)
 ZD bool zkw_lane_bit(u64 mask) {
   u32 r;
@@ -147,6 +171,7 @@ ZD bool zkw_lane_bit(u64 mask) {
 ZD bool zkw_lane_bit(u64 mask) { return ((mask >> (threadIdx.x & (ZKW_WAVE - 1))) & 1ull) != 0; }
 ZD u32 zkw_rank_below(u64 mask) { return (u32)__popcll(mask & ((1ull << (threadIdx.x & (ZKW_WAVE - 1))) - 1ull)); }
 ZD u32 zkw_opaque(u32 x) { return x; }
+ZD u32 zkw_lane_id() { return threadIdx.x & (ZKW_WAVE - 1); }
 #endif
 
 ZD u32 stream_alloc(u32* cursor) {
@@ -176,14 +201,15 @@ ZD void zkw_wave_lds_fence() {
 }
 
 // LDS view of one wave.  A workgroup holds ZKW_WAVES_PER_GROUP waves that share the 16 KB ISA table; each wave owns
-// 16 B of cursors + per lane: 112 B of state fields (CF_*) and 32 B of previous_code_word.
+// 16 B of cursors + per lane: 112 B of state fields (CF_*), 64 B of pre-decoded previous_code_word and 16 B for the pending instruction.
 // The Keccak row (rare, precompile only) is in HBM.
 struct Shared {
   uint2* isa;     // [2048] packed ISA table (shared by the waves of the workgroup)
   u32* cursor;    // [4] stream cursors of this wave
   u32* cold;      // [ZKW_COLD_FIELDS][L] cold per-lane state (CF_*)
   u32* krow;      // [34][L] Keccak rate block assembly rows (global memory)
-  uint2* pcw;     // [4][L] previous_code_word as 4 opcode slots (u64 limb k), lane-minor — read once per cycle, LDS
+  uint4* pcw;     // [4][L] previous_code_word as 4 pre-decoded opcode slots: (u64 limb k of the word, packed ISA entry of its opcode), lane-minor
+  uint4* enc;     // [L] the instruction a lane is about to execute in this cycle: opcode word (lo, hi) + packed ISA entry (attributes, price)
   uint4 *mem_base, *log_base, *aux_base;  // this wave's rows of the query streams (computed once per launch)
   u32 L;
   u32 debug_flags;
@@ -203,8 +229,8 @@ struct Shared {
 #define ZKW_PIN_SGPR(x) ((void)0)
 #endif
 extern __shared__ uint4 zkw_lds[];
-// 16-byte units of LDS per wave: cursors | cold | previous_code_word
-ZD u32 zkw_wave_lds_units() { return 1u + (ZKW_COLD_FIELDS / 4u) * ZKW_LDS_STRIDE + 2u * ZKW_LDS_STRIDE; }
+// 16-byte units of LDS per wave: cursors | cold | previous_code_word | pending instruction
+ZD u32 zkw_wave_lds_units() { return 1u + (ZKW_COLD_FIELDS / 4u) * ZKW_LDS_STRIDE + 4u * ZKW_LDS_STRIDE + ZKW_LDS_STRIDE; }
 // `wib` (wave in workgroup), `wave` and `dbg` must be wave-uniform
 ZD void shared_setup(Shared& sh, ZKW_KP P, u32 dbg, u32 wib, u32 wave, bool pin) {
   sh.L = P.L;
@@ -212,7 +238,9 @@ ZD void shared_setup(Shared& sh, ZKW_KP P, u32 dbg, u32 wib, u32 wave, bool pin)
   sh.wib = wib;
   sh.wave = wave;
   sh.F = P.F; sh.S = P.S; sh.H = P.H; sh.A = P.A; sh.cap_mem = P.cap_mem;
-  sh.stack_vals = P.stack_vals; sh.stack_ptrs = P.stack_ptrs; sh.heap = P.heap; sh.aux_heap = P.aux_heap; sh.blob_words = P.blob_words;
+  // this wave's rows: stack_vals / heap / aux_heap [F][words][2][L] x 16 B, stack_ptrs [F][S][L] x 1 B
+  sh.stack_vals = P.stack_vals + (u64)wave * P.F * P.S * 2u * P.L; sh.stack_ptrs = P.stack_ptrs + (u64)wave * P.F * P.S * P.L;
+  sh.heap = P.heap + (u64)wave * P.F * P.H * 2u * P.L; sh.aux_heap = P.aux_heap + (u64)wave * P.F * P.A * 2u * P.L; sh.blob_words = P.blob_words;
   if (pin) {
     ZKW_PIN_SGPR(sh.L); ZKW_PIN_SGPR(sh.F); ZKW_PIN_SGPR(sh.S); ZKW_PIN_SGPR(sh.H); ZKW_PIN_SGPR(sh.A); ZKW_PIN_SGPR(sh.cap_mem);
     ZKW_PIN_SGPR(sh.stack_vals); ZKW_PIN_SGPR(sh.stack_ptrs); ZKW_PIN_SGPR(sh.heap); ZKW_PIN_SGPR(sh.aux_heap); ZKW_PIN_SGPR(sh.blob_words);
@@ -221,7 +249,8 @@ ZD void shared_setup(Shared& sh, ZKW_KP P, u32 dbg, u32 wib, u32 wave, bool pin)
   sh.isa = (uint2*)zkw_lds;                                  // 16 KB
   sh.cursor = (u32*)wl;                                      // 16 B
   sh.cold = (u32*)(wl + 1);                                  // ZKW_COLD_FIELDS * stride * 4 B
-  sh.pcw = (uint2*)(wl + 1 + (ZKW_COLD_FIELDS / 4u) * ZKW_LDS_STRIDE);  // 4 * stride * 8 B
+  sh.pcw = wl + 1 + (ZKW_COLD_FIELDS / 4u) * ZKW_LDS_STRIDE;  // 4 * stride * 16 B
+  sh.enc = wl + 1 + (ZKW_COLD_FIELDS / 4u) * ZKW_LDS_STRIDE + 4u * ZKW_LDS_STRIDE;  // stride * 16 B
   sh.krow = P.krow + (u64)wave * ZKW_KROW_WORDS * P.L;
   sh.mem_base = P.mem_stream + (u64)wave * P.cap_mem * 3;
   sh.log_base = P.log_stream + (u64)wave * P.cap_log * 8;
@@ -236,7 +265,8 @@ ZD u32 next_seq(Lane& s) {
 
 // WT.add_memory_query (witness_trace/mod.rs:19) / payload of add_precompile_call_result (:43-50)
 ZD void emit_mem(ZKW_KP P, Shared& sh, Lane& s, u32 ts, u32 type, u32 page, u32 index, const u256& value, bool is_ptr, bool rw, u32 kind) {
-  const u32 pos = stream_alloc(sh.cursor + 0);
+  s.lane = zkw_lane_id();  // fresh, short-lived lane index (see struct Lane)
+  const u32 pos = stream_alloc(sh.cursor + zkw_opaque(0u));  // (the offset is opaque: the LDS address is formed here, not hoisted into a register for the whole kernel)
   const u32 seq = next_seq(s);
   if ((s.counts & 0xff00u) != 0xff00u) s.counts += 0x100u;
   if (pos >= sh.cap_mem) {
@@ -260,7 +290,7 @@ struct LogQ {  // LogQuery (log.rs:85-97)
 
 // WT.add_log_query / WT.record_refund_for_query (witness_trace/mod.rs:22-33)
 ZD void emit_log(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q, u32 kind) {
-  const u32 pos = stream_alloc(sh.cursor + 1);
+  const u32 pos = stream_alloc(sh.cursor + zkw_opaque(1u));
   const u32 seq = next_seq(s);
   if ((s.counts & 0xff0000u) != 0xff0000u) s.counts += 0x10000u;
   if (pos >= P.cap_log) {
@@ -282,7 +312,7 @@ ZD void emit_log(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q, u32 kind) {
 
 // aux events: header + up to 60 payload dwords
 ZD uint4* aux_alloc(ZKW_KP P, Shared& sh, Lane& s, u32 type, u32 flag, u32 a, u32 b, u32 c) {
-  const u32 pos = stream_alloc(sh.cursor + 2);
+  const u32 pos = stream_alloc(sh.cursor + zkw_opaque(2u));
   const u32 seq = next_seq(s);
   if ((s.counts & 0xff000000u) != 0xff000000u) s.counts += 0x1000000u;
   if (pos >= P.cap_aux) {
@@ -370,33 +400,38 @@ ZD void reg_write(Shared& sh, RegFile& rf, Lane& s, u32 idx, const u256& v, bool
 // A 32-byte word of a lane is stored as two 16-byte halves in two lane-minor planes of its word row
 // ([word][2][L] x 16 B: element 2 * w - lane and that + L for the index w returned here), so that each of the two
 // load / store instructions of a word access covers whole 64-byte lines.
-ZD u64 page_word_index(const Shared& sh, const Lane& s, u32 slot, u32 words_per_page, u32 idx) {
-  return (((u64)sh.wave * sh.F + slot) * words_per_page + idx) * sh.L + s.lane;
+// `Shared` holds the bases of THIS wave's rows of the arenas (scalar registers); a word is addressed by a 32-bit
+// element offset inside the row (the runtime refuses limits whose rows exceed 2^32 elements), so that an access is
+// "scalar base + 32-bit vector offset" instead of 64-bit vector arithmetic on a base that has to sit in vector registers.
+ZD u32 page_word_index(const Shared& sh, const Lane& s, u32 slot, u32 words_per_page, u32 idx) {
+  return (slot * words_per_page + idx) * sh.L + s.lane;
 }
 
 // MemoryType::Stack read of the current frame (memory.rs:427-436)
 ZD u256 stack_read(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, bool& is_ptr) {
+  s.lane = zkw_lane_id();  // fresh, short-lived lane index (see struct Lane)
   is_ptr = false;
   // a word that was never written reads as zero in the reference (the stack page is a zero-filled Vec); only WRITES
   // need capacity, and stack_hwm <= S
   if (idx >= CF(sh, s, CF_STACK_HWM)) return u256_zero();
-  const u64 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), sh.S, idx);
+  const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), sh.S, idx);
   is_ptr = sh.stack_ptrs[w] != 0;
   return u256_from_uint4(sh.stack_vals[2 * w - s.lane], sh.stack_vals[2 * w - s.lane + sh.L]);
 }
 // MemoryType::Stack write (memory.rs:413-425)
 ZD void stack_write(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, const u256& v, bool is_ptr) {
+  s.lane = zkw_lane_id();  // fresh, short-lived lane index (see struct Lane)
   if (idx >= sh.S) {
     lane_fail(s, ZKW_STATUS_LIMIT);
     return;
   }
   for (u32 g = CF(sh, s, CF_STACK_HWM); g < idx; g++) {  // lazily zero the gap
-    const u64 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), sh.S, g);
+    const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), sh.S, g);
     sh.stack_vals[2 * w - s.lane] = make_uint4(0, 0, 0, 0);
     sh.stack_vals[2 * w - s.lane + sh.L] = make_uint4(0, 0, 0, 0);
     sh.stack_ptrs[w] = 0;
   }
-  const u64 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), sh.S, idx);
+  const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), sh.S, idx);
   sh.stack_vals[2 * w - s.lane] = u256_lo4(v);
   sh.stack_vals[2 * w - s.lane + sh.L] = u256_hi4(v);
   sh.stack_ptrs[w] = is_ptr ? 1 : 0;
@@ -405,10 +440,11 @@ ZD void stack_write(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, const u256& v,
 
 // heap / aux heap of an arbitrary arena slot; `hwm` is that page's high-water mark
 ZD u256 heap_read_at(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 slot, u32 hwm, u32 idx) {
+  s.lane = zkw_lane_id();  // fresh, short-lived lane index (see struct Lane)
   const u32 words = is_aux ? sh.A : sh.H;
   if (idx >= hwm) return u256_zero();  // the reference grows its Vec on a read (memory.rs:464,468): not observable; hwm <= words
   const uint4* base = is_aux ? sh.aux_heap : sh.heap;
-  const u64 w = page_word_index(sh, s, slot, words, idx);
+  const u32 w = page_word_index(sh, s, slot, words, idx);
   return u256_from_uint4(base[2 * w - s.lane], base[2 * w - s.lane + sh.L]);
 }
 // MemoryType::Heap / AuxHeap of the current frame (memory.rs:439-473; the page number of the query
@@ -417,6 +453,7 @@ ZD u256 heap_read_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx)
   return heap_read_at(P, sh, s, is_aux, CF(sh, s, CF_SLOT), is_aux ? CF(sh, s, CF_AUX_HWM) : CF(sh, s, CF_HEAP_HWM), idx);
 }
 ZD void heap_write_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx, const u256& v) {
+  s.lane = zkw_lane_id();  // fresh, short-lived lane index (see struct Lane)
   const u32 words = is_aux ? sh.A : sh.H;
   if (idx >= words) {
     lane_fail(s, ZKW_STATUS_LIMIT);
@@ -425,11 +462,11 @@ ZD void heap_write_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx
   uint4* base = is_aux ? sh.aux_heap : sh.heap;
   u32 hwm = is_aux ? CF(sh, s, CF_AUX_HWM) : CF(sh, s, CF_HEAP_HWM);
   for (u32 g = hwm; g < idx; g++) {
-    const u64 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), words, g);
+    const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), words, g);
     base[2 * w - s.lane] = make_uint4(0, 0, 0, 0);
     base[2 * w - s.lane + sh.L] = make_uint4(0, 0, 0, 0);
   }
-  const u64 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), words, idx);
+  const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), words, idx);
   base[2 * w - s.lane] = u256_lo4(v);
   base[2 * w - s.lane + sh.L] = u256_hi4(v);
   if (!is_aux && CF(sh, s, CF_SLOT) == 0 && idx < P.heap_image_words) {
@@ -445,6 +482,7 @@ ZD void heap_write_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx
 // Page 0 is Indirection::Empty; pages that never were a heap/aux page of a frame of this
 // instance are "unreachable memory" (the reference's expect() at :478-481).
 ZD u256 fat_ptr_read(ZKW_KP P, const Shared& sh, Lane& s, u32 page, u32 idx) {
+  s.lane = zkw_lane_id();  // fresh, short-lived lane index (see struct Lane)
   if (page == 0) return u256_zero();
   u32 slot, kind;
   bool found = false;
@@ -481,7 +519,7 @@ ZD u256 fat_ptr_read(ZKW_KP P, const Shared& sh, Lane& s, u32 page, u32 idx) {
   const u32 words = is_aux ? sh.A : sh.H;
   if (idx >= hwm || idx >= words) return u256_zero();  // `.get(index).unwrap_or(zero)` (:490-495)
   const uint4* base = is_aux ? sh.aux_heap : sh.heap;
-  const u64 w = page_word_index(sh, s, slot, words, idx);
+  const u32 w = page_word_index(sh, s, slot, words, idx);
   return u256_from_uint4(base[2 * w - s.lane], base[2 * w - s.lane + sh.L]);
 }
 
@@ -677,6 +715,7 @@ ZD Operand compute_address(ZKW_KP P, const Shared& sh, Lane& s, u32& sp, const u
 
 // perform_dst0_update (helpers.rs:266-283)
 ZD void dst0_update(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Operand& dst0, u32 dst0_idx, const u256& v, bool is_ptr) {
+  s.lane = zkw_lane_id();  // fresh, short-lived lane index (see struct Lane)
   if (dst0.has_loc) {
     stack_write(P, sh, s, dst0.index, v, is_ptr);
     emit_mem(P, sh, s, s.timestamp + 3, ZKW_MEM_STACK, dst0.page, dst0.index, v, is_ptr, true, 0);
@@ -902,6 +941,7 @@ ZD void op_ptr(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
 
 // uma.rs:26-425
 ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, const Pre& ps) {
+  s.lane = zkw_lane_id();
   const u32 v = ZKW_ATTR_VARIANT(d.attr);
   s.pc = ps.new_pc;
   const bool increment = ZKW_ATTR_FLAGS(d.attr) & 1u;
@@ -1566,6 +1606,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
   const u32 opcode = ZKW_ATTR_OPCODE(d.attr);
   const u32 props = ZKW_ATTR_PROPS(d.attr);
   const bool set_flags = ZKW_ATTR_FLAGS(d.attr) & 1u;
+  s.lane = zkw_lane_id();
   // ----------------------------------------------------------------------------------------
   // operands (cycle.rs:275-350)
   // ----------------------------------------------------------------------------------------
@@ -1739,7 +1780,7 @@ ZD void lane_writeback(ZKW_KP P, Shared& sh, const RegFile& rf, Lane& s, u32 com
   zkw_dev_scalars sc;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const uint2 v = sh.pcw[i * ZKW_LDS_STRIDE + tid];
+    const uint4 v = sh.pcw[i * ZKW_LDS_STRIDE + tid];
     sc.prev_code_word[2 * i] = v.x;
     sc.prev_code_word[2 * i + 1] = v.y;
   }
@@ -1796,7 +1837,10 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
   if (exists) {
     const zkw_dev_scalars sc = P.scalars[inst];
 #pragma unroll
-    for (int i = 0; i < 4; i++) sh.pcw[i * ZKW_LDS_STRIDE + tid] = make_uint2(sc.prev_code_word[2 * i], sc.prev_code_word[2 * i + 1]);
+    for (int i = 0; i < 4; i++) {
+      const uint2 e = sh.isa[sc.prev_code_word[2 * i] & (ZKW_ISA_TABLE_SIZE - 1)];
+      sh.pcw[i * ZKW_LDS_STRIDE + tid] = make_uint4(sc.prev_code_word[2 * i], sc.prev_code_word[2 * i + 1], e.x, e.y);
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) CF(sh, s, CF_CTX0 + i) = sc.ctx_u128_reg[i];
     s.ptr_bitmap = sc.ptr_bitmap; s.flags = sc.flags; s.timestamp = sc.timestamp;
@@ -1829,19 +1873,14 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
   // an `if (active)` region of every iteration (whose merge points cost ~75 register copies per VM cycle).
   u32 k = 0;
   u32 delta_cur = ZKW_LDS_WORD(sh.cursor)[3];
-  uint2 next_slot = make_uint2(0, 0), next_e = make_uint2(0, 0);
-  if (exists) {
-    next_slot = sh.pcw[(3u - (s.pc & 3u)) * ZKW_LDS_STRIDE + tid];
-    next_e = sh.isa[next_slot.x & (ZKW_ISA_TABLE_SIZE - 1)];
-  }
   if (exists && !(s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0)) lane_writeback(P, sh, rf, s, 0);  // does not cycle
   if (exists && s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0) {
     for (;;) {
-      s.lane = zkw_opaque(tid);  // per-lane addresses are derived inside the iteration (see zkw_opaque)
+      s.lane = zkw_lane_id();
       // directory: stream cursors at the start of wave-cycle (cycle_base + k).  Read here (one broadcast 16-B LDS read),
       // stored by the first remaining lane after the fetch below, so that the LDS latency hides behind it.  The
       // register-delta cursor is carried in a register: only the end of the cycle advances it.
-      uint4 dir_entry = zkw_lds_read4(sh.cursor);
+      uint4 dir_entry = zkw_lds_read4(sh.cursor + zkw_opaque(0u));
       dir_entry.w = delta_cur;
       s.counts = 0; s.kflags &= ~KF_COLD_DIRTY; s.reg_dirty = 0;
       // ----------------------------------------------------------------------------------------
@@ -1849,34 +1888,33 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
       // ----------------------------------------------------------------------------------------
       const bool pending = (s.flags & FLAG_PENDING) != 0;
       const u32 super_pc = s.pc >> 2, sub_pc = s.pc & 3u;
-      u64 enc;
-      uint2 my_e;  // this lane's packed ISA entry (prefetched at the end of the previous cycle when no fetch is due)
       if (!pending) {
         if ((s.kflags & KF_CODE_PAGE_CHANGED) || s.prev_super_pc != super_pc) {  // :59-95
           const u256 word = code_read(sh, s, super_pc);
           emit_mem(P, sh, s, s.timestamp, ZKW_MEM_CODE, CF(sh, s, CF_CODE_PAGE), super_pc, word, false, false, 0);
+          // pre-decode the four opcodes of the word (four independent table reads) next to their encodings: a cycle
+          // then needs ONE LDS read for its opcode and the packed ISA entry
+          uint2 e4[4];
 #pragma unroll
-          for (int i = 0; i < 4; i++) sh.pcw[i * ZKW_LDS_STRIDE + s.lane] = make_uint2(word.w[2 * i], word.w[2 * i + 1]);
+          for (int i = 0; i < 4; i++) e4[i] = sh.isa[word.w[2 * i] & (ZKW_ISA_TABLE_SIZE - 1)];
+#pragma unroll
+          for (int i = 0; i < 4; i++) sh.pcw[i * ZKW_LDS_STRIDE + s.lane] = make_uint4(word.w[2 * i], word.w[2 * i + 1], e4[i].x, e4[i].y);
           s.prev_super_pc = super_pc;
-          // integer_representaiton_from_u256: opcode k of a word is u64 limb 3-k (:86-94) — straight from the registers
-          const u32 lo = sub_pc == 0 ? word.w[6] : (sub_pc == 1 ? word.w[4] : (sub_pc == 2 ? word.w[2] : word.w[0]));
-          const u32 hi = sub_pc == 0 ? word.w[7] : (sub_pc == 1 ? word.w[5] : (sub_pc == 2 ? word.w[3] : word.w[1]));
-          enc = ((u64)hi << 32) | lo;
-          my_e = sh.isa[lo & (ZKW_ISA_TABLE_SIZE - 1)];
-        } else {
-          enc = ((u64)next_slot.y << 32) | next_slot.x;
-          my_e = next_e;
         }
       } else {  // :104-115
         s.flags &= ~FLAG_PENDING;
         s.prev_super_pc = super_pc;
-        enc = P.consts.exception_revert_encoding;
-        my_e = sh.isa[(u32)enc & (ZKW_ISA_TABLE_SIZE - 1)];
       }
-      s.kflags &= ~KF_CODE_PAGE_CHANGED;  // previous_code_memory_page := code_page (:49)
+      s.kflags &= ~(KF_CODE_PAGE_CHANGED | KF_CHARGED | KF_MASKED);  // previous_code_memory_page := code_page (:49)
+      if (pending) {  // the instruction is exception_revert_encoding() instead of the slot of the code word (:104-115)
+        const u64 rv = P.consts.exception_revert_encoding;
+        const uint2 e0 = sh.isa[(u32)rv & (ZKW_ISA_TABLE_SIZE - 1)];
+        zkw_lds_write4(sh.enc + s.lane, make_uint4((u32)rv, (u32)(rv >> 32), e0.x, e0.y));
+        s.kflags |= KF_MASKED;
+      }
       {
         const u64 in_loop = __ballot(1);
-        if (s.lane == (u32)__ffsll((long long)in_loop) - 1u) *(uint4*)dir_ptr = dir_entry;
+        if (zkw_rank_below(in_loop) == 0) *(uint4*)dir_ptr = dir_entry;
       }
       // ----------------------------------------------------------------------------------------
       // decode + execute, grouped by instruction word: take the first lane that has
@@ -1885,34 +1923,40 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
       // tape needs one iteration per cycle; lanes running different programs need one per distinct word.
       // Lanes whose decode raises an exception (masked into panic, cycle.rs:187-190) or whose condition
       // fails (masked into nop, :212-217) are served by extra passes with the panic / nop variant.
+      // The instruction of a lane — opcode word + packed ISA entry, 16 bytes — is read from LDS at the top of every
+      // iteration (its pre-decoded slot of the code word, integer_representaiton_from_u256: opcode k of a word is u64
+      // limb 3-k, :86-94 — or sh.enc once the lane was masked): held in registers across the opcode bodies these four
+      // values are what the allocator spills to scratch memory.
       // ----------------------------------------------------------------------------------------
-      u32 enc_lo = (u32)enc, enc_hi = (u32)(enc >> 32);
-      bool charged = false;  // price taken and exceptions / condition resolved for this lane (once per cycle)
       u64 todo = __ballot(1);
       while (todo) {
         const u32 leader = (u32)__ffsll((long long)todo) - 1u;
-        const u32 u_lo = (u32)__builtin_amdgcn_readlane((int)enc_lo, (int)leader);
-        const u32 u_hi = (u32)__builtin_amdgcn_readlane((int)enc_hi, (int)leader);
-        const bool u_charged = __builtin_amdgcn_readlane((int)charged, (int)leader) != 0;
+        const u32 lane_now = zkw_lane_id();
+        // (a lane that was already served reads a slot it no longer cares about: it is not in `todo`)
+        const uint4 me = *((s.kflags & KF_MASKED) ? sh.enc + lane_now : sh.pcw + (3u - (s.pc & 3u)) * ZKW_LDS_STRIDE + lane_now);
+        const u32 charged = s.kflags & KF_CHARGED;
+        const u32 u_lo = (u32)__builtin_amdgcn_readlane((int)me.x, (int)leader);
+        const u32 u_hi = (u32)__builtin_amdgcn_readlane((int)me.y, (int)leader);
+        const u32 u_charged = (u32)__builtin_amdgcn_readlane((int)charged, (int)leader);
         // only lanes that are still waiting: a lane that already ran a genuine `nop` must not join the group of lanes
         // that were masked into the nop encoding later in the same cycle
-        bool mine = zkw_lane_bit(todo) && enc_lo == u_lo && enc_hi == u_hi && charged == u_charged;
-        if (A.debug_flags & 4u) mine = s.lane == leader;  // test hook: one lane per group
-        const u32 u_attr = (u32)__builtin_amdgcn_readlane((int)my_e.x, (int)leader);  // the leader's entry: no LDS access in the loop
-        const u32 u_price = (u32)__builtin_amdgcn_readlane((int)my_e.y, (int)leader);
+        bool mine = zkw_lane_bit(todo) && me.x == u_lo && me.y == u_hi && charged == u_charged;
+        if (A.debug_flags & 4u) mine = lane_now == leader;  // test hook: one lane per group
+        const u32 u_attr = (u32)__builtin_amdgcn_readlane((int)me.z, (int)leader);
+        const u32 u_price = (u32)__builtin_amdgcn_readlane((int)me.w, (int)leader);
         if (!u_charged) {  // uniform: first visit of this opcode word
           if (mine) {
             const bool err = decode_exception(max_depth, s, u_attr, u_price);  // :142-184
             if (s.ergs < u_price) s.ergs = 0; else s.ergs -= u_price;  // :153-161
             const bool nop = !err && !condition_resolved((u_lo >> 13) & 7u, s.flags);
-            charged = true;
+            s.kflags |= KF_CHARGED;
             if (err | nop) {
               // mask_into_panic (:187-190) / mask_into_nop (:212-217): the lane re-enters the loop as a member of
               // the group of the panic / nop encoding (all operand fields zero, condition Always)
               const u64 masked = err ? P.consts.exception_revert_encoding : P.consts.nop_encoding;
-              enc_lo = (u32)masked;
-              enc_hi = (u32)(masked >> 32);
-              my_e = sh.isa[enc_lo & (ZKW_ISA_TABLE_SIZE - 1)];
+              const uint2 e1 = sh.isa[(u32)masked & (ZKW_ISA_TABLE_SIZE - 1)];
+              zkw_lds_write4(sh.enc + lane_now, make_uint4((u32)masked, (u32)(masked >> 32), e1.x, e1.y));
+              s.kflags |= KF_MASKED;
               mine = false;
             }
           }
@@ -1927,15 +1971,17 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
           else exec_decoded(P, sh, rf, s, d);
         }
       }
-      // prefetch for the next cycle (used only if that cycle does not fetch a new code word): its opcode slot of the
-      // current word and the ISA entry of that opcode — two chained LDS reads that complete behind the record stores
-      next_slot = sh.pcw[(3u - (s.pc & 3u)) * ZKW_LDS_STRIDE + s.lane];
-      next_e = sh.isa[next_slot.x & (ZKW_ISA_TABLE_SIZE - 1)];
       // ----------------------------------------------------------------------------------------
       // end of cycle (cycle.rs:408-413)
       // ----------------------------------------------------------------------------------------
       if (lane_ok(s)) {
+#ifdef __HIP_DEVICE_COMPILE__
+        // the scalar operand spelled out: left to itself the optimiser hoists a vector copy of `time_delta` out of the
+        // loop and then keeps that copy in scratch memory
+        asm("v_add_u32 %0, %1, %0" : "+v"(s.timestamp) : "s"(time_delta));
+#else
         s.timestamp += time_delta;
+#endif
         if (s.kflags & KF_COLD_DIRTY) {
           uint4* a = aux_alloc(P, sh, s, ZKW_AUX_COLD_STATE, 0, CF(sh, s, CF_SPENT_PUBDATA), CF(sh, s, CF_ERGS_PP), CF(sh, s, CF_TX_NUMBER));
           if (a) {
@@ -1955,6 +2001,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
         // register file.  A cycle writes one register on average, so this is ~70 B instead of 512 B.
         // Order inside a wave-cycle: by register (ascending), lanes in lane order within a register — the register
         // index of a store is then wave-uniform (the values come straight from the VGPR register file).
+        s.lane = zkw_lane_id();
         const bool ok = lane_ok(s);
         const u32 dm = ok ? s.reg_dirty : 0u;
         // union of the lanes' dirty masks and the number of deltas of this wave-cycle; a shared tape makes all masks equal
@@ -2005,7 +2052,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
           // `total` is the same for every lane still in the loop (ballots over exactly those lanes); the LDS copy is
           // only read after the loop (final directory entry), and a wave's LDS operations complete in order
           delta_cur = base + total;
-          if (s.lane == (u32)__ffsll((long long)__ballot(true)) - 1u) ZKW_LDS_WORD(sh.cursor)[3] = delta_cur;
+          if (zkw_rank_below(__ballot(true)) == 0) ZKW_LDS_WORD(sh.cursor + zkw_opaque(3u))[0] = delta_cur;
         }
       }
       k++;
@@ -2114,7 +2161,7 @@ extern "C" hipError_t zkw_launch_reset_kernel(const zkw_fused_table* T, hipStrea
 // dynamic LDS per workgroup: ISA table + per wave (cursors + per-lane cold state and previous_code_word)
 extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_group) {
   (void)L;  // rows have a fixed lane stride
-  return ZKW_ISA_TABLE_SIZE * 8 + waves_per_group * (16 + ZKW_LDS_STRIDE * (ZKW_COLD_FIELDS * 4 + 32));
+  return ZKW_ISA_TABLE_SIZE * 8 + waves_per_group * (16 + ZKW_LDS_STRIDE * (ZKW_COLD_FIELDS * 4 + 64 + 16));
 }
 
 // host-callable launcher (keeps <<<>>> out of the runtime)

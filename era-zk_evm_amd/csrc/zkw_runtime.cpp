@@ -255,6 +255,13 @@ int zkw_batch_create(zkw_ctx* c, uint32_t n, const zkw_limits* limits, zkw_batch
     c->last_error = "zkw_limits: zero capacity";
     return ZKW_ERR_INVALID;
   }
+  {  // the kernel addresses a word of a wave's arena row with a 32-bit element offset (16-byte elements)
+    const uint64_t words = std::max<uint64_t>(lim.stack_words, std::max<uint64_t>(lim.heap_words, lim.aux_heap_words));
+    if ((uint64_t)lim.max_far_frames * words * 2u * ZKW_WAVE >= (1ull << 32)) {
+      c->last_error = "zkw_limits: max_far_frames x page words exceeds 2^25 (a wave's arena row must stay below 2^32 elements)";
+      return ZKW_ERR_LIMIT;
+    }
+  }
   lim.storage_slots = pow2_ceil(std::max(lim.storage_slots, 4u));
   if (lim.storage_journal == 0) lim.storage_journal = 4;
   if (lim.max_mem_queries == 0) lim.max_mem_queries = 6 * lim.max_cycles;

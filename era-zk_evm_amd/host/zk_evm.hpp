@@ -82,6 +82,22 @@ struct DecommittmentQuery {
   bool is_fresh;
 };
 
+// PrecompileCyclesWitness (zk_evm_abstractions::precompiles, the 5th argument of add_precompile_call_result,
+// witness_trace/mod.rs:43-50): an enum over the precompile kinds, each a Vec of per-round witnesses
+// {new_request: Option<LogQuery>, reads: [..MemoryQuery..], writes: Option<[MemoryQuery; n]>}.  The crate is not on disk
+// (recalled, unverified): one struct covers the three kinds here, `has_new_request` = Some/None, empty
+// `writes` = None.  The rounds are rebuilt from the call's ordered read / write lists by the round schedule of the
+// precompile (precompile_round_witness below) — the device emits every read exactly once, in round order.
+struct PrecompileRoundWitness {
+  bool has_new_request;
+  LogQuery new_request;
+  std::vector<MemoryQuery> reads, writes;
+};
+struct PrecompileCyclesWitness {
+  enum Kind { Sha256 = 0, Keccak256 = 1, ECRecover = 2 } kind;
+  std::vector<PrecompileRoundWitness> rounds;
+};
+
 // witness_trace/mod.rs:11-72 — same callbacks, same argument order
 struct VmWitnessTracer {
   virtual ~VmWitnessTracer() {}
@@ -92,7 +108,7 @@ struct VmWitnessTracer {
   virtual void add_log_query(uint32_t, const LogQuery&) {}
   virtual void add_decommittment(uint32_t, const DecommittmentQuery&, const std::vector<U256>& /*mem_witness*/) {}
   virtual void add_precompile_call_result(uint32_t, const LogQuery& /*call_params*/, const std::vector<MemoryQuery>& /*mem_witness_in*/,
-                                          const std::vector<MemoryQuery>& /*memory_witness_out*/) {}
+                                          const std::vector<MemoryQuery>& /*memory_witness_out*/, const PrecompileCyclesWitness& /*round_witness*/) {}
   virtual void add_revertable_precompile_call(uint32_t, const LogQuery&) {}  // never invoked by the reference
   virtual void start_new_execution_context(uint32_t, const CallStackEntry& /*previous*/, const CallStackEntry& /*new*/) {}
   virtual void finish_execution_context(uint32_t, bool /*panicked*/) {}
@@ -162,6 +178,52 @@ struct InMemoryEventSink : EventSink {
   }
 };
 
+// Splits the ordered reads / writes of one precompile call into its rounds.  sha256: `precompile_interpreted_data`
+// rounds of two reads, the digest write in the last; ecrecover: one round (4 reads, 2 writes); keccak256: one round per
+// 136-byte block (plus the padding-only round when the length is a multiple of 136), each reading — up to 6 words —
+// what its buffer still lacks, the write in the last round.
+inline PrecompileCyclesWitness precompile_round_witness(PrecompileCyclesWitness::Kind kind, const LogQuery& call, const std::vector<MemoryQuery>& in,
+                                                        const std::vector<MemoryQuery>& out) {
+  PrecompileCyclesWitness w;
+  w.kind = kind;
+  std::vector<std::pair<size_t, size_t>> plan;  // (reads, writes) per round
+  const uint32_t in_off = (uint32_t)call.key.l[0], in_len = (uint32_t)(call.key.l[0] >> 32);
+  if (kind == PrecompileCyclesWitness::Sha256) {
+    const size_t rounds = (size_t)call.key.l[3];
+    for (size_t r = 0; r < rounds; r++) plan.emplace_back(2, r + 1 == rounds ? 1 : 0);
+  } else if (kind == PrecompileCyclesWitness::ECRecover) {
+    plan.emplace_back(4, 2);
+  } else {
+    const size_t RATE = 136, PER_CYCLE = 6, BUF = PER_CYCLE * 32;
+    size_t offset = in_off, left = in_len, rounds = (left + RATE - 1) / RATE, filled = 0;
+    const bool extra = left % RATE == 0;
+    if (extra) rounds++;
+    for (size_t r = 0; r < rounds; r++) {
+      const bool last = r + 1 == rounds, pad_only = extra && last;
+      size_t n = 0;
+      for (size_t i = 0; i < PER_CYCLE; i++) {
+        const size_t at_most = 32 - offset % 32, meaningful = left >= at_most ? at_most : left;
+        if (meaningful != 0 && !pad_only && filled + meaningful <= BUF) {
+          offset += meaningful; left -= meaningful; filled += meaningful;
+          n++;
+        }
+      }
+      filled = filled < RATE ? 0 : filled - RATE;
+      plan.emplace_back(n, last ? 1 : 0);
+    }
+  }
+  size_t ri = 0, wi = 0;
+  for (size_t r = 0; r < plan.size(); r++) {
+    PrecompileRoundWitness rw;
+    rw.has_new_request = r == 0;
+    rw.new_request = call;
+    for (size_t k = 0; k < plan[r].first && ri < in.size(); k++) rw.reads.push_back(in[ri++]);
+    for (size_t k = 0; k < plan[r].second && wi < out.size(); k++) rw.writes.push_back(out[wi++]);
+    w.rounds.push_back(std::move(rw));
+  }
+  return w;
+}
+
 inline U256 to_u256(const zkw_u256& v) {
   U256 r;
   std::memcpy(r.l, v.l, 32);
@@ -176,6 +238,9 @@ class BatchedVmState {
   // code words for add_decommittment's mem_witness (blob id -> words); may be empty (then `B = false` behaviour: no payload)
   std::function<std::vector<U256>(uint32_t /*blob id*/)> code_of_blob;
   uint8_t event_aux_byte = 1, l1_message_aux_byte = 2, precompile_aux_byte = 3;  // system_params, log.rs:6-8
+  // DefaultPrecompilesProcessor's dispatch on the low 16 address bits (zkw_isa_consts): calls to these are the ones
+  // execute_precompile answers with Some(..), i.e. the ones add_precompile_call_result is invoked for (helpers.rs:210-221)
+  uint32_t keccak_precompile_address = 0x8010, sha256_precompile_address = 0x02, ecrecover_precompile_address = 0x01;
 
   BatchedVmState(const zkw_vm_local_state& initial, const zkw_callstack_entry* inner, const zkw_instance_trace& trace, VmWitnessTracer* wt, EventSink* ev)
       : witness_tracer(wt), event_sink(ev), trace_(trace), k_(0) {
@@ -220,7 +285,15 @@ class BatchedVmState {
     LogQuery precompile_call{};
     std::vector<MemoryQuery> pin, pout;
     auto flush_precompile = [&]() {
-      if (in_precompile && (!pin.empty() || !pout.empty())) witness_tracer->add_precompile_call_result(cc, precompile_call, pin, pout);
+      if (in_precompile) {  // every call to a known precompile, also one with no rounds (Some with empty vectors)
+        const uint32_t low = (uint32_t)precompile_call.address.b[0] | ((uint32_t)precompile_call.address.b[1] << 8);
+        int kind = low == keccak_precompile_address ? PrecompileCyclesWitness::Keccak256
+                   : low == sha256_precompile_address ? PrecompileCyclesWitness::Sha256
+                   : low == ecrecover_precompile_address ? PrecompileCyclesWitness::ECRecover : -1;
+        if (kind >= 0)
+          witness_tracer->add_precompile_call_result(cc, precompile_call, pin, pout,
+                                                     precompile_round_witness((PrecompileCyclesWitness::Kind)kind, precompile_call, pin, pout));
+      }
       in_precompile = false;
       pin.clear();
       pout.clear();

@@ -75,11 +75,19 @@ struct Log {
     h.bytes(words, n_words * 32);
     entries.push_back(h.h);
   }
-  void precompile(uint32_t cc, const LogQ& call, const std::vector<MemQ>& in, const std::vector<MemQ>& out) {
+  // round witness (PrecompileCyclesWitness, witness_trace/mod.rs:43-50): per round, whether it carries the request,
+  // how many of the call's reads it consumed and whether it performed the call's writes
+  struct Round {
+    uint8_t has_new_request;
+    uint32_t n_reads, n_writes;
+  };
+  void precompile(uint32_t cc, const LogQ& call, const std::vector<MemQ>& in, const std::vector<MemQ>& out, uint32_t kind, const std::vector<Round>& rounds) {
     Hasher h; h.u32(ADD_PRECOMPILE_CALL_RESULT); h.u32(cc); put(h, call); h.u64(in.size());
     for (auto& q : in) put(h, q);
     h.u64(out.size());
     for (auto& q : out) put(h, q);
+    h.u32(kind); h.u64(rounds.size());
+    for (auto& r : rounds) { h.u32(r.has_new_request); h.u32(r.n_reads); h.u32(r.n_writes); }
     entries.push_back(h.h);
   }
   void frame_start(uint32_t cc, const zkw_callstack_entry& prev, const zkw_callstack_entry& next) {

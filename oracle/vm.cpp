@@ -481,19 +481,25 @@ void Vm::call_precompile(uint32_t cc, const LogQuery& query) {
   witness_tracer.add_log(query, ZKW_LQ_LOG, cc);
   uint32_t address_low = (uint32_t)query.address.b[0] | ((uint32_t)query.address.b[1] << 8);
   std::vector<MemoryQuery> reads, writes;
+  // round witness: (reads consumed, writes performed) per round; round 0 carries the request (PrecompileCyclesWitness::
+  // {Sha256, Keccak256, ECRecover}(Vec<..RoundWitness{new_request, reads, writes}>), crate zk_evm_abstractions — recalled)
+  std::vector<std::pair<uint32_t, uint32_t>> rounds;
+  uint32_t kind;
   if (address_low == isa->consts.keccak_precompile_address)
-    keccak256_rounds_function(cc, query, memory, reads, writes);
+    kind = 1, keccak256_rounds_function(cc, query, memory, reads, writes, rounds);
   else if (address_low == isa->consts.sha256_precompile_address)
-    sha256_rounds_function(cc, query, memory, reads, writes);
+    kind = 0, sha256_rounds_function(cc, query, memory, reads, writes, rounds);
   else if (address_low == isa->consts.ecrecover_precompile_address)
-    ecrecover_function(cc, query, memory, isa->consts.ecrecover_input_layout, reads, writes);
+    kind = 2, ecrecover_function(cc, query, memory, isa->consts.ecrecover_input_layout, reads, writes, rounds);
   else
     return;  // unknown precompile address: the default processor does nothing
   if (witness_tracer.cb) {  // add_precompile_call_result(cc, query, mem_in, mem_out, round_witness) helpers.rs:214-221
     std::vector<cblog::MemQ> in, out;
     for (const MemoryQuery& q : reads) in.push_back(Recorder::cb_mem(q));
     for (const MemoryQuery& q : writes) out.push_back(Recorder::cb_mem(q));
-    witness_tracer.cb->precompile(cc, Recorder::cb_log(query), in, out);
+    std::vector<cblog::Log::Round> rw;
+    for (size_t r = 0; r < rounds.size(); r++) rw.push_back(cblog::Log::Round{(uint8_t)(r == 0), rounds[r].first, rounds[r].second});
+    witness_tracer.cb->precompile(cc, Recorder::cb_log(query), in, out, kind, rw);
   }
   for (const MemoryQuery& q : reads) witness_tracer.add_memory_query(q, 1);
   for (const MemoryQuery& q : writes) witness_tracer.add_memory_query(q, 2);
@@ -1007,7 +1013,8 @@ struct PrecompileCallABI {
   }
 };
 
-void keccak256_rounds_function(uint32_t cc, const LogQuery& params, SimpleMemory& memory, std::vector<MemoryQuery>& reads, std::vector<MemoryQuery>& writes) {
+void keccak256_rounds_function(uint32_t cc, const LogQuery& params, SimpleMemory& memory, std::vector<MemoryQuery>& reads, std::vector<MemoryQuery>& writes,
+                               std::vector<std::pair<uint32_t, uint32_t>>& rounds) {
   const size_t KECCAK_RATE_BYTES = 136, MEMORY_READS_PER_CYCLE = 6, BUFFER_SIZE = MEMORY_READS_PER_CYCLE * 32;
   PrecompileCallABI abi = PrecompileCallABI::from_u256(params.key);
   uint32_t timestamp_to_read = params.timestamp;
@@ -1026,6 +1033,7 @@ void keccak256_rounds_function(uint32_t cc, const LogQuery& params, SimpleMemory
   for (size_t round = 0; round < num_rounds; round++) {
     bool is_last = round == num_rounds - 1;
     bool paddings_round = needs_extra_padding_round && is_last;
+    const size_t reads_before = reads.size(), writes_before = writes.size();
     uint8_t bytes32_buffer[32];
     std::memset(bytes32_buffer, 0, 32);
     for (size_t idx = 0; idx < MEMORY_READS_PER_CYCLE; idx++) {
@@ -1082,13 +1090,14 @@ void keccak256_rounds_function(uint32_t cc, const LogQuery& params, SimpleMemory
       w = memory.execute_partial_query(cc, w);
       writes.push_back(w);
     }
+    rounds.emplace_back((uint32_t)(reads.size() - reads_before), (uint32_t)(writes.size() - writes_before));
   }
 }
 
 // ecrecover precompile (absent crate zk_evm_abstractions; layout per the reference's test
 // src/testing/tests/precompiles/ecrecover.rs:3-95): 4 reads @timestamp, 2 writes @timestamp + 1
 void ecrecover_function(uint32_t cc, const LogQuery& params, SimpleMemory& memory, uint32_t layout, std::vector<MemoryQuery>& reads,
-                        std::vector<MemoryQuery>& writes) {
+                        std::vector<MemoryQuery>& writes, std::vector<std::pair<uint32_t, uint32_t>>& rounds) {
   PrecompileCallABI abi = PrecompileCallABI::from_u256(params.key);
   uint32_t timestamp_to_read = params.timestamp, timestamp_to_write = timestamp_to_read + 1;
   U256 w[4];
@@ -1112,9 +1121,11 @@ void ecrecover_function(uint32_t cc, const LogQuery& params, SimpleMemory& memor
   MemoryQuery a{timestamp_to_write, MemoryLocation{ZKW_MEM_HEAP, abi.memory_page_to_write, abi.output_memory_offset + 1}, from_big_endian(word), false, true};
   a = memory.execute_partial_query(cc, a);
   writes.push_back(a);
+  rounds.emplace_back(4u, 2u);  // one round
 }
 
-void sha256_rounds_function(uint32_t cc, const LogQuery& params, SimpleMemory& memory, std::vector<MemoryQuery>& reads, std::vector<MemoryQuery>& writes) {
+void sha256_rounds_function(uint32_t cc, const LogQuery& params, SimpleMemory& memory, std::vector<MemoryQuery>& reads, std::vector<MemoryQuery>& writes,
+                            std::vector<std::pair<uint32_t, uint32_t>>& rounds) {
   PrecompileCallABI abi = PrecompileCallABI::from_u256(params.key);
   uint32_t timestamp_to_read = params.timestamp;
   uint32_t timestamp_to_write = timestamp_to_read + 1;
@@ -1142,6 +1153,7 @@ void sha256_rounds_function(uint32_t cc, const LogQuery& params, SimpleMemory& m
       w = memory.execute_partial_query(cc, w);
       writes.push_back(w);
     }
+    rounds.emplace_back(2u, round == num_rounds - 1 ? 1u : 0u);
   }
 }
 

@@ -936,9 +936,12 @@ struct Vm {
 };
 
 // precompiles (zk_evm_abstractions::precompiles, absent crate — see hashes.hpp header)
-void keccak256_rounds_function(uint32_t cc, const LogQuery& params, SimpleMemory& memory, std::vector<MemoryQuery>& reads, std::vector<MemoryQuery>& writes);
-void sha256_rounds_function(uint32_t cc, const LogQuery& params, SimpleMemory& memory, std::vector<MemoryQuery>& reads, std::vector<MemoryQuery>& writes);
+// `rounds`: the round witness — (reads consumed, writes performed) of every round, round 0 carries the request
+void keccak256_rounds_function(uint32_t cc, const LogQuery& params, SimpleMemory& memory, std::vector<MemoryQuery>& reads, std::vector<MemoryQuery>& writes,
+                               std::vector<std::pair<uint32_t, uint32_t>>& rounds);
+void sha256_rounds_function(uint32_t cc, const LogQuery& params, SimpleMemory& memory, std::vector<MemoryQuery>& reads, std::vector<MemoryQuery>& writes,
+                            std::vector<std::pair<uint32_t, uint32_t>>& rounds);
 void ecrecover_function(uint32_t cc, const LogQuery& params, SimpleMemory& memory, uint32_t layout, std::vector<MemoryQuery>& reads,
-                        std::vector<MemoryQuery>& writes);
+                        std::vector<MemoryQuery>& writes, std::vector<std::pair<uint32_t, uint32_t>>& rounds);
 
 }  // namespace zko

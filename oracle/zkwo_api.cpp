@@ -530,9 +530,10 @@ int zkwo_precompile_test(int which, uint32_t page, const zkw_u256* heap_words, u
     lq.timestamp = 1;
     std::memcpy(lq.key.l, abi_key->l, 32);
     std::vector<MemoryQuery> reads, writes;
-    if (which == 0) keccak256_rounds_function(4, lq, memory, reads, writes);
-    else if (which == 1) sha256_rounds_function(4, lq, memory, reads, writes);
-    else ecrecover_function(4, lq, memory, (uint32_t)(which - 2), reads, writes);  // 2: (hash, r, s, v)   3: (hash, v, r, s)
+    std::vector<std::pair<uint32_t, uint32_t>> rounds;
+    if (which == 0) keccak256_rounds_function(4, lq, memory, reads, writes, rounds);
+    else if (which == 1) sha256_rounds_function(4, lq, memory, reads, writes, rounds);
+    else ecrecover_function(4, lq, memory, (uint32_t)(which - 2), reads, writes, rounds);  // 2: (hash, r, s, v)   3: (hash, v, r, s)
     *n_reads = (uint32_t)reads.size();
     *n_writes = (uint32_t)writes.size();
     U256 w = SimpleMemory::get_or_zero(memory.heaps.back().heap, out_index);

@@ -59,11 +59,14 @@ struct LoggingTracer : VmWitnessTracer {
   void add_decommittment(uint32_t cc, const DecommittmentQuery& q, const std::vector<U256>& w) override {
     log->decommit(cc, q.hash.l, q.timestamp, q.memory_page, q.decommitted_length, q.is_fresh, (const uint64_t*)w.data(), w.size());
   }
-  void add_precompile_call_result(uint32_t cc, const LogQuery& call, const std::vector<MemoryQuery>& in, const std::vector<MemoryQuery>& out) override {
+  void add_precompile_call_result(uint32_t cc, const LogQuery& call, const std::vector<MemoryQuery>& in, const std::vector<MemoryQuery>& out,
+                                  const PrecompileCyclesWitness& rw) override {
     std::vector<cblog::MemQ> a, b;
     for (auto& q : in) a.push_back(cb_mem(q));
     for (auto& q : out) b.push_back(cb_mem(q));
-    log->precompile(cc, cb_log(call), a, b);
+    std::vector<cblog::Log::Round> rounds;
+    for (auto& r : rw.rounds) rounds.push_back(cblog::Log::Round{(uint8_t)r.has_new_request, (uint32_t)r.reads.size(), (uint32_t)r.writes.size()});
+    log->precompile(cc, cb_log(call), a, b, (uint32_t)rw.kind, rounds);
   }
   void start_new_execution_context(uint32_t cc, const CallStackEntry& p, const CallStackEntry& n) override { log->frame_start(cc, p, n); }
   void finish_execution_context(uint32_t cc, bool panicked) override { log->simple(cblog::FINISH_CONTEXT, cc, panicked); }

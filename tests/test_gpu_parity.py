@@ -342,3 +342,28 @@ def test_cfg2_long_traces(oracle, product, isa):
     """The second shape of cfg 2: 256 instances x 4096 cycles, full waves — every record of every instance."""
     wl = synth.make(2, isa, n_instances=256, n_cycles=4096)
     _compare(oracle, product, wl, 64)
+
+
+def test_reduce_commitments_rccl_world1(oracle, product, isa):
+    """zkw_reduce_commitments (include/zkw.h) over an RCCL communicator of one rank: the same entry point bench.py
+    drives at N GPUs — id exchange, size exchange, packed digests through ncclAllGather on the stream, counters
+    through ncclAllReduce — against the oracle's digests and counters."""
+    import torch
+    wl = synth.make(2, isa, n_instances=96)
+    bo = _run(oracle, wl)
+    want = bo.commitments()  # [n][3][4]
+    batches = [product.create_batch(wl) for _ in range(3)]
+    stream = torch.cuda.Stream()
+    product.step_many(batches, wl.n_cycles, 7, stream.cuda_stream)
+    comm = K.Comm.rccl(product, 0, 1, K.Comm.unique_id(product))
+    out = torch.zeros((1, 3, wl.n_instances, 2, 4), dtype=torch.int64, device="cuda")
+    _, n_max, sizes, total = comm.reduce(batches, 0b110, gathered=out.data_ptr(), want_total=True, stream=stream.cuda_stream)
+    stream.synchronize()
+    got = out.cpu().numpy().view(np.uint64)
+    assert n_max == wl.n_instances and sizes == [wl.n_instances]
+    for j in range(3):
+        assert np.array_equal(got[0, j, :, 0], want[:, 1]) and np.array_equal(got[0, j, :, 1], want[:, 2])  # log, decommit
+    so = bo.stats()
+    assert int(total["cycles"]) == 3 * int(so["cycles"]) and int(total["mem_queries"]) == 3 * int(so["mem_queries"])
+    assert int(total["instances_failed"]) == 0
+    comm.close()

@@ -1,7 +1,10 @@
 """N > 1 path on CPU: two gloo ranks each own a block of instances (no data-path collective), compute
-their queue digests, and the final all-gather / all-reduce (era-zk_evm_amd/shard.py) reproduces the
-single-process result.  The per-rank compute here is the oracle (no GPU in this suite); on the GPU box
-bench.py runs the same reduce over RCCL."""
+their queue digests, and the final all-gather / all-reduce reproduces the single-process result.
+Two variants: the Python reduce of era-zk_evm_amd/shard.py over the oracle's digests, and the PRODUCT's own
+entry point zkw_reduce_commitments (include/zkw.h) — the product sources built for the CPU by tests/emu compute
+each rank's shard and its commitments, and the exchange runs through an external communicator whose two
+collectives are gloo calls (on the GPU box the same entry point runs over RCCL: tests/test_gpu_parity.py,
+bench.py)."""
 import os
 import socket
 import sys
@@ -74,3 +77,72 @@ def test_shard_range_covers_everything():
             assert blocks[0][0] == 0 and sum(c for _, c in blocks) == n
             for (f0, c0), (f1, _) in zip(blocks, blocks[1:]):
                 assert f0 + c0 == f1
+
+
+def _worker_capi(rank, world, port, n_total, out_dir):
+    """each rank: the emulated product (kernel logic + host runtime) on its shard, then zkw_reduce_commitments"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import torch
+    import torch.distributed as dist
+    import era_zk_evm_amd  # noqa: F401
+    from era_zk_evm_amd import capi as K, synth, shard
+    import build_emu
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    isa = K.Isa()
+    prod = K.Backend(build_emu.build(), "zkw_").open(isa)
+    wl_all = synth.make(2, isa, n_instances=n_total)
+    first, count = shard.shard_range(n_total, rank, world)
+    wl = synth.make(2, isa, n_instances=n_total)
+    wl.n_instances = count
+    wl.states, wl.inner, wl.heaps = wl_all.states[first:first + count], wl_all.inner[first:first + count], wl_all.heaps[first:first + count]
+    wl.storage = wl_all.storage[first:first + count]
+    wl.code_pages = [(0, count, p, b) for (_, _, p, b) in wl_all.code_pages]
+    batches = [prod.create_batch(wl) for _ in range(2)]  # two batches per rank, as the fused bench groups are
+    prod.step_many(batches, wl.n_cycles, 7)
+
+    def allgather(send):
+        mine = torch.from_numpy(send)
+        outs = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(outs, mine)
+        return torch.cat(outs).numpy()
+
+    def allreduce_sum(a):
+        x = torch.from_numpy(a.astype(np.int64))
+        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        return x.numpy().astype(np.uint64)
+
+    comm = K.Comm.external(prod, rank, world, allgather, allreduce_sum)
+    gathered, n_max, sizes, total = comm.reduce(batches, 0b101, want_total=True)  # memory + decommit queues
+    if rank == 0:
+        np.save(os.path.join(out_dir, "gathered.npy"), gathered)
+        np.save(os.path.join(out_dir, "meta.npy"), np.array([n_max] + sizes + [int(total["cycles"]), int(total["mem_queries"]), int(total["log_queries"]),
+                                                                       int(total["aux_events"])], dtype=np.int64))
+    comm.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [6, 7])
+def test_two_rank_reduce_commitments_entry(tmp_path, oracle, isa, n_total):
+    """zkw_reduce_commitments (the C-ABI entry) over gloo: gathered digests in rank order, ragged shards padded"""
+    import torch.multiprocessing as mp
+    from era_zk_evm_amd import synth, shard
+    port = _free_port()
+    mp.spawn(_worker_capi, args=(2, port, n_total, str(tmp_path)), nprocs=2, join=True)
+    gathered = np.load(tmp_path / "gathered.npy")  # [world][batches][n_max][2 queues][4]
+    meta = np.load(tmp_path / "meta.npy")
+    wl = synth.make(2, isa, n_instances=n_total)
+    b = oracle.create_batch(wl)
+    b.reset(); b.run(wl.n_cycles); b.sync()
+    want = b.commitments()  # [n][3][4]
+    sizes = [shard.shard_range(n_total, r, 2)[1] for r in range(2)]
+    assert int(meta[0]) == max(sizes) and list(meta[1:3]) == sizes
+    assert gathered.shape == (2, 2, max(sizes), 2, 4)
+    for r in range(2):
+        first = shard.shard_range(n_total, r, 2)[0]
+        for j in range(2):
+            assert np.array_equal(gathered[r, j, :sizes[r], 0], want[first:first + sizes[r], 0])  # memory queue
+            assert np.array_equal(gathered[r, j, :sizes[r], 1], want[first:first + sizes[r], 2])  # decommit queue
+            assert not gathered[r, j, sizes[r]:].any()  # padding rows
+    st = b.stats()
+    assert list(meta[3:]) == [2 * int(st["cycles"]), 2 * int(st["mem_queries"]), 2 * int(st["log_queries"]), 2 * int(st["aux_events"])]
