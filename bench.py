@@ -159,7 +159,7 @@ def main():
             group_used[g] = True
             if not side_reset:
                 prod.reset_many(groups[g][:n], main_stream.cuda_stream)
-            prod.run_many(groups[g][:n], wl.n_cycles, main_stream.cuda_stream)
+            prod.run_many_committing(groups[g][:n], wl.n_cycles, args.commit_mask, main_stream.cuda_stream)  # the decommit queue is chained inside the run
             ev_run[g].record(main_stream)
             stream = side_streams[g]
             sptr = stream.cuda_stream
@@ -216,7 +216,7 @@ def main():
     # untimed epilogue: the same fused launch with nothing else in flight (duration of the kernel on its own)
     for _ in range(3):
         prod.reset_many(groups[0], main_stream.cuda_stream)
-        prod.run_many(groups[0], wl.n_cycles, main_stream.cuda_stream)
+        prod.run_many_committing(groups[0], wl.n_cycles, args.commit_mask, main_stream.cuda_stream)
         main_stream.synchronize()
     k_ms_alone = drain_timing()[0]
     # verification pass (untimed): the pipelined loop leaves every group restored for its next use, so the counters
@@ -224,7 +224,7 @@ def main():
     # of them did
     for g_ in groups[1:]:
         prod.reset_many(g_, main_stream.cuda_stream)
-        prod.run_many(g_, wl.n_cycles, main_stream.cuda_stream)
+        prod.run_many_committing(g_, wl.n_cycles, args.commit_mask, main_stream.cuda_stream)
     main_stream.synchronize()
     drain_timing()
     batch.sync()

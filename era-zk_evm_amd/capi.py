@@ -247,6 +247,11 @@ class Backend:
         arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])
         self.call("batches_run", arr, C.c_uint32(len(batches)), C.c_uint32(max_cycles), C.c_void_p(stream))
 
+    def run_many_committing(self, batches, max_cycles, queue_mask, stream=None):
+        """zkw_batches_run_committing: the run chains the queue commitments it can (the decommit queue) itself"""
+        arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])
+        self.call("batches_run_committing", arr, C.c_uint32(len(batches)), C.c_uint32(max_cycles), C.c_uint32(queue_mask), C.c_void_p(stream))
+
     def commit_many(self, batches, queue_mask, stream=None):
         """zkw_batches_commit: the fused commitment launches alone (caller orders the streams)."""
         arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])

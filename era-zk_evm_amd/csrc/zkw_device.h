@@ -149,9 +149,15 @@ typedef struct zkw_kparams {
   uint32_t* heap_dirty;        /* [n_waves][ceil(heap_image_words / 32)][L]: words of the heap image overwritten since the reset */
   uint32_t heap_image_words;   /* words of the uploaded heap image (frame slot 0) */
   uint32_t reserved4;
-  uint4* mem_stream;           /* [n_waves][cap_mem][3]                  */
+  uint4* mem_stream;           /* [n_waves][3][cap_mem]: planes header | value low | value high of the 48-byte zkw_mem_query */
   uint4* log_stream;           /* [n_waves][cap_log][8]                  */
   uint4* aux_stream;           /* [n_waves][cap_aux][16]                 */
+  /* decommit-queue commitment, chained by the cycle kernel itself at every decommit (zkw_commit.hip spec) */
+  const uint64_t* commit_rc;    /* [ZKW_GL_RC_COUNT] round constants */
+  const uint64_t* midstates;    /* [n_preimages][12] sponge state after absorbing a code hash */
+  const uint64_t* blob_digests; /* [n_blobs][4] */
+  uint64_t* commit_out;         /* [n_instances][ZKW_QUEUE_COUNT][4]: the DECOMMIT slot is the running tail */
+  uint32_t* dq_count;           /* [n_instances] decommit-queue length so far */
   uint32_t* dir;               /* [n_waves][max_cycles + 1][4] (mem, log, aux cursors at cycle start) */
   uint32_t* cursors;           /* [n_waves][4] persistent stream cursors: mem, log, aux, register deltas */
 } zkw_kparams;
@@ -196,4 +202,8 @@ typedef struct zkw_reset_params {
   uint32_t* heap_dirty;      /* [n_waves][ceil(image_words / 32)][L] */
   uint32_t image_words;      /* words of the heap image */
   uint32_t L;
+  uint64_t* commit_out;      /* [n_instances][ZKW_QUEUE_COUNT][4]: the running decommit-queue tails are zeroed */
+  uint32_t* dq_count;        /* [n_instances] */
+  uint32_t n_instances;
+  uint32_t reserved0;
 } zkw_reset_params;

@@ -1,0 +1,195 @@
+// Goldilocks field arithmetic and the "ZKW-GL-sponge v1" permutation / leaf / chain step (the build's own spec, see
+// zkw_commit.hip and DESIGN.md §commitments).  Shared by the commitment kernels (zkw_commit.hip) and by the cycle kernel,
+// which chains the decommit queue while it runs (zkw_kernels.hip: op_far_call).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef ZD
+#define ZD __device__ __forceinline__
+#endif
+// The round constants are read through the constant address space: uniform addresses, so the loads are scalar
+// (s_load_dwordx8/x16 through the scalar cache, issued ahead by the compiler) instead of a vector-memory round trip per
+// constant — a lone wave chaining inside the cycle kernel otherwise waits for 118 dependent global loads per permutation.
+#ifdef __HIP_DEVICE_COMPILE__
+#define ZKW_GL_RC const u64 __attribute__((address_space(4)))*
+#else
+#define ZKW_GL_RC const u64*
+#endif
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// ---------------------------------------------------------------------------------------------
+// Goldilocks
+// ---------------------------------------------------------------------------------------------
+#define GL_P 0xffffffff00000001ULL
+#define GL_EPS 0xffffffffULL
+
+ZD u64 gl_add(u64 a, u64 b) {
+  u64 r = a + b;
+  if (r < a) r += GL_EPS;  // wrapped past 2^64: 2^64 = EPS (mod p); cannot wrap again since a, b < p
+  if (r >= GL_P) r -= GL_P;
+  return r;
+}
+ZD void mul64(u64 a, u64 b, u64& lo, u64& hi) {
+  const u64 a0 = (u32)a, a1 = a >> 32, b0 = (u32)b, b1 = b >> 32;
+  const u64 p00 = a0 * b0, p01 = a0 * b1, p10 = a1 * b0, p11 = a1 * b1;
+  const u64 mid = (p00 >> 32) + (u32)p01 + (u32)p10;
+  lo = (mid << 32) | (u32)p00;
+  hi = p11 + (p01 >> 32) + (p10 >> 32) + (mid >> 32);
+}
+ZD u64 gl_reduce128(u64 lo, u64 hi) {
+  const u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+  u64 t0 = lo - hi_hi;
+  if (lo < hi_hi) t0 -= GL_EPS;  // borrow: subtract 2^64 = EPS (mod p) once more
+  const u64 t1 = (hi_lo << 32) - hi_lo;  // hi_lo * (2^32 - 1) without a multiply (integer multiplies are quarter rate)
+  u64 r = t0 + t1;
+  if (r < t1) r += GL_EPS;
+  if (r >= GL_P) r -= GL_P;
+  return r;
+}
+ZD u64 gl_mul(u64 a, u64 b) {
+  u64 lo, hi;
+  mul64(a, b, lo, hi);
+  return gl_reduce128(lo, hi);
+}
+// a^2: the two cross products are equal (3 wide multiplies instead of 4)
+ZD void sqr64(u64 a, u64& lo, u64& hi) {
+  const u64 a0 = (u32)a, a1 = a >> 32;
+  const u64 p00 = a0 * a0, p01 = a0 * a1, p11 = a1 * a1;
+  const u64 mid = (p00 >> 32) + 2 * (u64)(u32)p01;
+  lo = (mid << 32) | (u32)p00;
+  hi = p11 + 2 * (p01 >> 32) + (mid >> 32);
+}
+// reduction without the final conditional subtraction: the result is < 2^64 and congruent, possibly >= p.  Such a value
+// is a valid INPUT of mul64 / sqr64 / gl_reduce128 (they accept any u64), so the canonical form is only restored at the
+// end of a multiplication chain.
+ZD u64 gl_reduce128_lazy(u64 lo, u64 hi) {
+  const u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+  u64 t0 = lo - hi_hi;
+  if (lo < hi_hi) t0 -= GL_EPS;
+  const u64 t1 = (hi_lo << 32) - hi_lo;
+  u64 r = t0 + t1;
+  if (r < t1) r += GL_EPS;
+  return r;
+}
+ZD u64 gl_pow7(u64 x) {
+  u64 lo, hi;
+  sqr64(x, lo, hi);
+  const u64 x2 = gl_reduce128_lazy(lo, hi);
+  mul64(x2, x, lo, hi);
+  const u64 x3 = gl_reduce128_lazy(lo, hi);
+  sqr64(x2, lo, hi);
+  const u64 x4 = gl_reduce128_lazy(lo, hi);
+  mul64(x4, x3, lo, hi);
+  return gl_reduce128_lazy(lo, hi);
+}
+
+// The linear layers are evaluated over the integers in 128-bit accumulators and reduced once per output element:
+// every coefficient pattern below sums to at most 64 * 2^64 (external) / 2^76 (internal), far inside 128 bits, and
+// gl_reduce128 accepts any 128-bit value.  (The element-wise form cost ~40 modular additions per layer.)
+typedef unsigned __int128 u128;
+// Inside the permutation every value is kept only congruent (< 2^64, possibly >= p): products, 128-bit sums and the
+// round-constant addition below accept that, and gl_permute canonicalises the state once at the end.
+ZD u64 gl_reduce_wide(u128 x) { return gl_reduce128_lazy((u64)x, (u64)(x >> 64)); }
+// the same for x < 2^96 (every sum of the linear layers: <= 64 * 2^64 externally, < 2^77 internally): the high half fits
+// 32 bits, so 2^64 = 2^32 - 1 (mod p) folds it in with one shift, one subtraction and one add
+ZD u64 gl_reduce_small(u128 x) {
+  const u64 lo = (u64)x, hi = (u64)(x >> 64);
+  const u64 t1 = (hi << 32) - hi;
+  u64 r = lo + t1;
+  if (r < t1) r += GL_EPS;
+  return r;
+}
+// s + rc for any s < 2^64 and a canonical constant: s + rc < 2^65 - 2^32, so one wrap correction suffices
+ZD u64 gl_add_rc(u64 s, u64 rc) {
+  u64 x = s + rc;
+  if (x < s) x += GL_EPS;
+  return x;
+}
+
+// M4 of the Poseidon2 paper: [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] — unreduced (row sums <= 16)
+ZD void gl_m4_wide(u64 a, u64 b, u64 c, u64 d, u128& o0, u128& o1, u128& o2, u128& o3) {
+  const u128 t0 = (u128)a + b, t1 = (u128)c + d;
+  const u128 t2 = ((u128)b << 1) + t1, t3 = ((u128)d << 1) + t0;
+  const u128 t4 = (t1 << 2) + t3, t5 = (t0 << 2) + t2;
+  o0 = t3 + t5; o1 = t5; o2 = t2 + t4; o3 = t4;
+}
+ZD void gl_external(u64 s[12]) {
+  u128 o[12];
+#pragma unroll
+  for (int i = 0; i < 12; i += 4) gl_m4_wide(s[i], s[i + 1], s[i + 2], s[i + 3], o[i], o[i + 1], o[i + 2], o[i + 3]);
+  u128 sum[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) sum[j] = o[j] + o[4 + j] + o[8 + j];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl_reduce_small(o[i] + sum[i & 3]);
+}
+ZD void gl_internal(u64 s[12]) {
+  u128 sum = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) sum += s[i];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl_reduce_small(sum + ((u128)s[i] << i));
+}
+
+ZD void gl_permute(const u64* rc_, u64 s[12]) {
+  ZKW_GL_RC rc = (ZKW_GL_RC)rc_;
+  gl_external(s);
+  int k = 0;
+  for (int r = 0; r < 4; r++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_pow7(gl_add_rc(s[i], rc[k + i]));
+    k += 12;
+    gl_external(s);
+  }
+  for (int r = 0; r < 22; r++) {
+    s[0] = gl_pow7(gl_add_rc(s[0], rc[k]));
+    k += 1;
+    gl_internal(s);
+  }
+  for (int r = 0; r < 4; r++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_pow7(gl_add_rc(s[i], rc[k + i]));
+    k += 12;
+    gl_external(s);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++)
+    if (s[i] >= GL_P) s[i] -= GL_P;  // canonical representatives out
+}
+
+// sponge over n <= 32 field elements held in a statically indexed array
+template <int N>
+ZD void gl_leaf(const u64* rc, u32 type, const u64 f[N], u64 out[4]) {
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = 0;
+  s[8] = ((u64)type << 32) | (u64)N;
+#pragma unroll
+  for (int b = 0; b < (N + 7) / 8; b++) {
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (b * 8 + j < N) s[j] = gl_add(s[j], f[b * 8 + j]);
+    gl_permute(rc, s);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[i] = s[i];
+}
+
+ZD void gl_chain_step(const u64* rc, const u64 leaf[4], u64 tail[4], u64 index_plus_1, u32 queue_id) {
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    s[i] = leaf[i];
+    s[4 + i] = tail[i];
+  }
+  s[8] = index_plus_1;
+  s[9] = queue_id;
+  s[10] = 0;
+  s[11] = 0;
+  gl_permute(rc, s);
+#pragma unroll
+  for (int i = 0; i < 4; i++) tail[i] = s[i];
+}
+

@@ -29,6 +29,7 @@
 
 #include "zkw_device.h"
 #include "zkw_u256.hip.h"
+#include "zkw_goldilocks.hip.h"
 
 // ---------------------------------------------------------------------------------------------
 // per-lane execution context (lives in VGPRs; every helper below is force-inlined)
@@ -136,6 +137,24 @@ ZD void zkw_lds_write4(uint4* p, const uint4 v) {
 ZD void zkw_lds_write4(uint4* p, const uint4 v) { *p = v; }
 #endif
 
+// Phase timing of a VM cycle (profiling build only: -DZKW_PROFILE, profiles/tools/r02_phase.sh): shader clocks between
+// marks, accumulated per workgroup wave in LDS by the first active lane; printed by one workgroup at the end.
+#ifdef ZKW_PROFILE
+__shared__ unsigned long long zp_acc[ZKW_WAVES_PER_GROUP][40];
+#define ZKW_PROF_DECL unsigned long long zp_last = __builtin_readcyclecounter();
+#define ZKW_PROF(i)                                                                      \
+  {                                                                                      \
+    const unsigned long long zp_now = __builtin_readcyclecounter();                      \
+    if (zkw_rank_below(__ballot(1)) == 0) zp_acc[sh.wib][(i)] += zp_now - zp_last;       \
+    zp_last = zp_now;                                                                    \
+  }
+#define ZKW_PROF_RESET zp_last = __builtin_readcyclecounter();
+#else
+#define ZKW_PROF_DECL
+#define ZKW_PROF(i)
+#define ZKW_PROF_RESET
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // wave-level stream compaction: every lane that reaches this point (possibly under divergence)
 // gets a unique, dense slot of the wave's stream: ballot -> rank by popcount of lower lanes.  The cursor lives in
@@ -174,13 +193,42 @@ ZD u32 zkw_opaque(u32 x) { return x; }
 ZD u32 zkw_lane_id() { return threadIdx.x & (ZKW_WAVE - 1); }
 #endif
 
-ZD u32 stream_alloc(u32* cursor) {
+// On the device the four cursors of a wave (memory / log / aux stream, register deltas) are lanes 0..3 of v128 — a
+// register the compiled code never touches (see RegFile) — read and written with v_readlane / v_writelane, which ignore
+// the execution mask: a true wave-level scalar that survives divergent control flow, at the price of three instructions
+// instead of an LDS round trip per allocation.
+#ifdef __HIP_DEVICE_COMPILE__
+template <int WHICH>
+ZD u32 zkw_cursor_get() {
+  u32 v;
+  asm volatile("v_readlane_b32 %0, v128, %1" : "=s"(v) : "n"(WHICH));
+  return v;
+}
+template <int WHICH>
+ZD void zkw_cursor_set(u32 v) {
+  asm volatile("v_writelane_b32 v128, %0, %1" : : "s"(v), "n"(WHICH));
+}
+template <int WHICH>
+ZD u32 stream_alloc(u32*) {
+  const u64 mask = __ballot(1);
+  const u32 cnt = (u32)__popcll(mask);
+  u32 base, next;
+  asm volatile("v_readlane_b32 %0, v128, %2\n\ts_nop 0\n\ts_add_u32 %1, %0, %3\n\ts_nop 0\n\tv_writelane_b32 v128, %1, %2"
+               : "=&s"(base), "=&s"(next)
+               : "n"(WHICH), "s"(cnt)
+               : "scc");
+  return base + zkw_rank_below(mask);
+}
+#else
+template <int WHICH>
+ZD u32 stream_alloc(u32* cursors) {
   const u64 mask = __ballot(1);
   const u32 rank = zkw_rank_below(mask);
-  const u32 base = *ZKW_LDS_WORD(cursor);
-  if (rank == 0) *ZKW_LDS_WORD(cursor) = base + (u32)__popcll(mask);
+  const u32 base = *ZKW_LDS_WORD(cursors + WHICH);
+  if (rank == 0) *ZKW_LDS_WORD(cursors + WHICH) = base + (u32)__popcll(mask);
   return base + rank;
 }
+#endif
 
 // streaming store of a 16-byte unit of a witness stream: written once, read by a later kernel / the host
 #ifdef __HIP_DEVICE_COMPILE__
@@ -209,6 +257,7 @@ struct Shared {
   u32* cold;      // [ZKW_COLD_FIELDS][L] cold per-lane state (CF_*)
   u32* krow;      // [34][L] Keccak rate block assembly rows (global memory)
   uint4* pcw;     // [4][L] previous_code_word as 4 pre-decoded opcode slots: (u64 limb k of the word, packed ISA entry of its opcode), lane-minor
+  u32* xfer;      // [8][L] one 256-bit value per lane handed to / returned by the out-of-line opcode bodies (zkw_heavy_entry)
   uint4* enc;     // [L] the instruction a lane is about to execute in this cycle: opcode word (lo, hi) + packed ISA entry (attributes, price)
   uint4 *mem_base, *log_base, *aux_base;  // this wave's rows of the query streams (computed once per launch)
   u32 L;
@@ -229,8 +278,8 @@ struct Shared {
 #define ZKW_PIN_SGPR(x) ((void)0)
 #endif
 extern __shared__ uint4 zkw_lds[];
-// 16-byte units of LDS per wave: cursors | cold | previous_code_word | pending instruction
-ZD u32 zkw_wave_lds_units() { return 1u + (ZKW_COLD_FIELDS / 4u) * ZKW_LDS_STRIDE + 4u * ZKW_LDS_STRIDE + ZKW_LDS_STRIDE; }
+// 16-byte units of LDS per wave: cursors | parameter-block pointer, debug flags | cold | previous_code_word | pending instruction | transfer value
+ZD u32 zkw_wave_lds_units() { return 2u + (ZKW_COLD_FIELDS / 4u) * ZKW_LDS_STRIDE + 4u * ZKW_LDS_STRIDE + ZKW_LDS_STRIDE + 2u * ZKW_LDS_STRIDE; }
 // `wib` (wave in workgroup), `wave` and `dbg` must be wave-uniform
 ZD void shared_setup(Shared& sh, ZKW_KP P, u32 dbg, u32 wib, u32 wave, bool pin) {
   sh.L = P.L;
@@ -248,9 +297,10 @@ ZD void shared_setup(Shared& sh, ZKW_KP P, u32 dbg, u32 wib, u32 wave, bool pin)
   uint4* wl = zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + wib * zkw_wave_lds_units();
   sh.isa = (uint2*)zkw_lds;                                  // 16 KB
   sh.cursor = (u32*)wl;                                      // 16 B
-  sh.cold = (u32*)(wl + 1);                                  // ZKW_COLD_FIELDS * stride * 4 B
-  sh.pcw = wl + 1 + (ZKW_COLD_FIELDS / 4u) * ZKW_LDS_STRIDE;  // 4 * stride * 16 B
-  sh.enc = wl + 1 + (ZKW_COLD_FIELDS / 4u) * ZKW_LDS_STRIDE + 4u * ZKW_LDS_STRIDE;  // stride * 16 B
+  sh.cold = (u32*)(wl + 2);                                  // ZKW_COLD_FIELDS * stride * 4 B   (wl[1]: see zkw_heavy_entry)
+  sh.pcw = wl + 2 + (ZKW_COLD_FIELDS / 4u) * ZKW_LDS_STRIDE;  // 4 * stride * 16 B
+  sh.enc = wl + 2 + (ZKW_COLD_FIELDS / 4u) * ZKW_LDS_STRIDE + 4u * ZKW_LDS_STRIDE;  // stride * 16 B
+  sh.xfer = (u32*)(sh.enc + ZKW_LDS_STRIDE);                 // 8 * stride * 4 B
   sh.krow = P.krow + (u64)wave * ZKW_KROW_WORDS * P.L;
   sh.mem_base = P.mem_stream + (u64)wave * P.cap_mem * 3;
   sh.log_base = P.log_stream + (u64)wave * P.cap_log * 8;
@@ -266,7 +316,7 @@ ZD u32 next_seq(Lane& s) {
 // WT.add_memory_query (witness_trace/mod.rs:19) / payload of add_precompile_call_result (:43-50)
 ZD void emit_mem(ZKW_KP P, Shared& sh, Lane& s, u32 ts, u32 type, u32 page, u32 index, const u256& value, bool is_ptr, bool rw, u32 kind) {
   s.lane = zkw_lane_id();  // fresh, short-lived lane index (see struct Lane)
-  const u32 pos = stream_alloc(sh.cursor + zkw_opaque(0u));  // (the offset is opaque: the LDS address is formed here, not hoisted into a register for the whole kernel)
+  const u32 pos = stream_alloc<0>(sh.cursor);
   const u32 seq = next_seq(s);
   if ((s.counts & 0xff00u) != 0xff00u) s.counts += 0x100u;
   if (pos >= sh.cap_mem) {
@@ -275,10 +325,13 @@ ZD void emit_mem(ZKW_KP P, Shared& sh, Lane& s, u32 ts, u32 type, u32 page, u32 
   }
   if (sh.debug_flags & 2u) return;
   const u32 meta = (type & ZKW_MQ_TYPE_MASK) | (is_ptr ? ZKW_MQ_IS_PTR : 0u) | (rw ? ZKW_MQ_RW : 0u) | (kind << ZKW_MQ_KIND_SHIFT);
-  uint4* dst = sh.mem_base + (u64)pos * 3;
+  // three planes of 16-byte units (header | value low | value high), each [cap_mem]: every store instruction of the
+  // wave then covers whole 64-byte lines.  As 48-byte records (three partial-line stores per record) the stream cost
+  // 1.7x its own bytes in HBM writes (profiles/r02_traffic.json) — and the kernel is bound by its stores.
+  uint4* dst = sh.mem_base + pos;
   zkw_stream_store(dst, make_uint4(ts, page, index, s.lane | (seq << 8) | (meta << 16)));
-  zkw_stream_store(dst + 1, u256_lo4(value));
-  zkw_stream_store(dst + 2, u256_hi4(value));
+  zkw_stream_store(dst + sh.cap_mem, u256_lo4(value));
+  zkw_stream_store(dst + 2u * (u64)sh.cap_mem, u256_hi4(value));
 }
 
 struct LogQ {  // LogQuery (log.rs:85-97)
@@ -290,7 +343,7 @@ struct LogQ {  // LogQuery (log.rs:85-97)
 
 // WT.add_log_query / WT.record_refund_for_query (witness_trace/mod.rs:22-33)
 ZD void emit_log(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q, u32 kind) {
-  const u32 pos = stream_alloc(sh.cursor + zkw_opaque(1u));
+  const u32 pos = stream_alloc<1>(sh.cursor);
   const u32 seq = next_seq(s);
   if ((s.counts & 0xff0000u) != 0xff0000u) s.counts += 0x10000u;
   if (pos >= P.cap_log) {
@@ -312,7 +365,7 @@ ZD void emit_log(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q, u32 kind) {
 
 // aux events: header + up to 60 payload dwords
 ZD uint4* aux_alloc(ZKW_KP P, Shared& sh, Lane& s, u32 type, u32 flag, u32 a, u32 b, u32 c) {
-  const u32 pos = stream_alloc(sh.cursor + zkw_opaque(2u));
+  const u32 pos = stream_alloc<2>(sh.cursor);
   const u32 seq = next_seq(s);
   if ((s.counts & 0xff000000u) != 0xff000000u) s.counts += 0x1000000u;
   if (pos >= P.cap_aux) {
@@ -327,14 +380,14 @@ ZD uint4* aux_alloc(ZKW_KP P, Shared& sh, Lane& s, u32 type, u32 flag, u32 a, u3
 // ---------------------------------------------------------------------------------------------
 // register file — select_register_value / update_register_value (helpers.rs:318-334)
 //
-// The 16 x 256-bit registers of a lane (r0 = the constant zero, r1..r15) live in the UPPER HALF of the lane's vector
-// register file: register i, limb k is v[128 + 8 i + k].  The kernel is compiled for 128 vector registers
+// The 15 x 256-bit registers of a lane live in the UPPER HALF of the lane's vector register file: register i = 1..15,
+// limb k is v[128 + 8 i + k] (r0 is the constant zero and is not stored: v128 carries the wave's stream cursors in its
+// lanes 0..3 instead, v129..v135 are free).  The kernel is compiled for 128 vector registers
 // (__launch_bounds__(256, 4): the compiler — in the kernel and, through the propagated waves-per-eu attribute, in the
 // out-of-line functions — allocates v0..v127 only), so v128..v255 are never touched by compiled code and the kernel
 // descriptor ends up with 256 registers = two waves per SIMD.  Decode is scalar per group of lanes that hold the same
 // opcode word, so a register number is wave-uniform and an access is VGPR-indexed addressing: s_set_gpr_idx_on with
-// the scalar offset 8 i, eight v_mov, s_set_gpr_idx_off — no LDS round trip, no branch, and reading r0 needs no
-// special case.  (Compared with the register file in LDS: 32 KB less LDS per wave, which is what lets a second
+// the scalar offset 8 i, eight v_mov, s_set_gpr_idx_off — no LDS round trip.  (Compared with the register file in LDS: 32 KB less LDS per wave, which is what lets a second
 // workgroup share the CU.)  The accesses are `asm volatile`, so they stay in program order among themselves.
 // ---------------------------------------------------------------------------------------------
 #ifdef __HIP_DEVICE_COMPILE__
@@ -342,6 +395,7 @@ struct RegFile {};
 // `reg` = 0..15, wave-uniform
 ZD u256 rf_get(const RegFile&, u32 reg) {
   u256 v;
+  if (reg == 0) return u256_zero();  // r0 reads as zero; its slot (v128..v135) holds the wave's stream cursors instead
   const u32 off = (u32)__builtin_amdgcn_readfirstlane((int)(reg * 8u));
   asm volatile(
       "s_set_gpr_idx_on %8, gpr_idx(SRC0)\n\t"
@@ -365,14 +419,9 @@ ZD void rf_set(RegFile&, u32 reg, const u256& v) {
       : "v"(v.w[0]), "v"(v.w[1]), "v"(v.w[2]), "v"(v.w[3]), "v"(v.w[4]), "v"(v.w[5]), "v"(v.w[6]), "v"(v.w[7]), "s"(off)
       : "m0");
 }
-// all lanes: r0 := 0 (and the top of the register file is named once, so that the kernel descriptor covers it)
+// the ends of the reserved register range are named once, so that the kernel descriptor covers it
 ZD void rf_init(RegFile&) {
-  asm volatile(
-      "v_mov_b32 v128, 0\n\tv_mov_b32 v129, 0\n\tv_mov_b32 v130, 0\n\tv_mov_b32 v131, 0\n\t"
-      "v_mov_b32 v132, 0\n\tv_mov_b32 v133, 0\n\tv_mov_b32 v134, 0\n\tv_mov_b32 v135, 0\n\tv_mov_b32 v255, 0"
-      :
-      :
-      : "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v255");
+  asm volatile("v_mov_b32 v129, 0\n\tv_mov_b32 v255, 0" : : : "v128", "v129", "v255");  // (v128 holds the stream cursors: not touched here)
 }
 #else  // single-lane CPU emulation build of tests/emu
 struct RegFile {
@@ -776,7 +825,7 @@ ZD void start_frame(ZKW_KP P, Shared& sh, Lane& s, const u32 prev[32], u32 next[
       a[1 + i] = make_uint4(prev[4 * i], prev[4 * i + 1], prev[4 * i + 2], prev[4 * i + 3]);
       a[8 + i] = make_uint4(next[4 * i], next[4 * i + 1], next[4 * i + 2], next[4 * i + 3]);
     }
-    a[15] = make_uint4(0, 0, 0, 0);
+    // (the unused tail of an aux record is not written: zkw_batch_get_instance_trace zeroes it by record type)
   }
   if (s.depth + 1 > P.D) {
     lane_fail(s, ZKW_STATUS_LIMIT);
@@ -800,6 +849,7 @@ ZD void start_frame(ZKW_KP P, Shared& sh, Lane& s, const u32 prev[32], u32 next[
 // =============================================================================================
 
 struct Decoded {
+  u32 word_lo, word_hi;  // the 64-bit instruction word
   u32 attr;
   u32 cond, src0, src1, dst0, dst1, imm0, imm1;
 };
@@ -817,7 +867,6 @@ struct Pre {  // PreState (cycle.rs:8-14)
 #define ZKW_ACT_TO_SYSTEM 4u
 #define ZKW_ACT_RET 8u        /* ret.rs:213-233: r1 = v1 (pointer), r2..r15 = 0 */
 struct HeavyOut {
-  Lane s;
   u256 v1, v2;
   u32 action;
 };
@@ -1338,8 +1387,29 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
       a[1] = u256_lo4(code_hash);
       a[2] = u256_hi4(code_hash);
       a[3] = make_uint4(pre, 0, 0, 0);  // preimage index: selects the cached sponge midstate of this code hash (zkw_commit.hip)
+    }
+    if (a && P.commit_out && (sh.debug_flags & 16u)) {  // requested per launch (zkw_batches_step with the decommit queue in its mask)
+      // decommit-queue commitment, chained here (zkw_commit.hip spec: leaf = sponge(code hash | timestamp, page, length,
+      // fresh, blob digest), the first block comes from the per-hash midstate; tail' = P(leaf | tail | index | queue)):
+      // a handful of permutations per instance, in the shadow of a far call that costs tens of microseconds anyway —
+      // instead of a bucket pass and a chain kernel over the aux stream after the run
+      const u32 inst = lane_inst(sh, s);
+      u64* tail_p = P.commit_out + ((u64)inst * ZKW_QUEUE_COUNT + ZKW_QUEUE_DECOMMIT) * 4;
+      const u32 j = P.dq_count[inst];
+      const u64* ms = P.midstates + (u64)pre * 12;
+      const u64* bd = P.blob_digests + (u64)blob * 4;
+      u64 st[12];
 #pragma unroll
-      for (int i = 4; i < 16; i++) a[i] = make_uint4(0, 0, 0, 0);
+      for (int i = 0; i < 12; i++) st[i] = ms[i];
+      const u64 f[8] = {(u64)(s.timestamp + 1), (u64)page, (u64)blob_len, fresh ? 1ull : 0ull, bd[0], bd[1], bd[2], bd[3]};
+#pragma unroll
+      for (int i = 0; i < 8; i++) st[i] = gl_add(st[i], f[i]);
+      gl_permute(P.commit_rc, st);
+      const u64 leaf[4] = {st[0], st[1], st[2], st[3]};
+      u64 tail[4] = {tail_p[0], tail_p[1], tail_p[2], tail_p[3]};
+      gl_chain_step(P.commit_rc, leaf, tail, (u64)j + 1, ZKW_QUEUE_DECOMMIT);
+      tail_p[0] = tail[0]; tail_p[1] = tail[1]; tail_p[2] = tail[2]; tail_p[3] = tail[3];
+      P.dq_count[inst] = j + 1;
     }
     mapped_code_page = page;
     mapped_blob = blob;
@@ -1486,10 +1556,7 @@ ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, H
   storage_finish_frame(P, sh, s, fin_mark, panicked);
   {
     uint4* a = aux_alloc(P, sh, s, ZKW_AUX_FRAME_FINISH, panicked ? 1u : 0u, 0, 0, 0);
-    if (a) {
-#pragma unroll
-      for (int i = 1; i < 16; i++) a[i] = make_uint4(0, 0, 0, 0);
-    }
+    (void)a;  // header only
   }
   if (s.depth == 0) {  // pop on an empty callstack: unwrap() panic (execution_stack.rs:112)
     lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
@@ -1560,26 +1627,86 @@ ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
 
 // One out-of-line function for the heavy, rare opcode bodies: near_call, log (storage, events, precompile calls),
 // far_call, ret.  Inlined into the cycle loop their live ranges (two 32-dword callstack images, a 40-dword LogQuery,
-// the storage probe) would add to the 120 VGPRs of the register file and to the ~60 of the per-lane state, and the
-// kernel would not fit the 256 registers that two waves per SIMD allow.  All lanes of a call hold the same decoded
-// instruction, so `d` is made scalar again on entry.
-__device__ __noinline__ HeavyOut zkw_heavy_entry(const zkw_kparams ZKW_CONST_AS* Pp, u32 dbg, u32 wib, u32 wave, Lane s, Decoded d, Pre ps, u256 r15) {
+// the storage probe) would add to the per-lane state, and the kernel would not fit the 128 registers the compiler has.
+// Everything crosses the call in vector registers (two 16-dword arguments, one 16-dword result: the AMDGPU calling
+// convention passes 32 argument dwords in registers, anything more — and any struct result — goes through scratch
+// memory, i.e. through HBM at this kernel's footprint) or in LDS: the parameter-block pointer and the debug flags sit in
+// the wave's LDS header, one 256-bit value per lane (r15 in, the value for dst0 / r1 out) in sh.xfer.  All lanes of a
+// call hold the same instruction word, so it is made scalar again on entry.
+#ifndef ZKW_EMU_BUILD
+typedef u32 zkw_v16 __attribute__((ext_vector_type(16)));
+#else  // g++ (tests/emu) has no ext_vector_type
+struct zkw_v16 {
+  u32 v[16];
+  u32& operator[](int i) { return v[i]; }
+  const u32& operator[](int i) const { return v[i]; }
+};
+#endif
+ZD zkw_v16 lane_pack(const Lane& s) {
+  zkw_v16 a;
+  a[0] = s.pc; a[1] = s.sp; a[2] = s.ergs; a[3] = s.timestamp; a[4] = s.prev_super_pc; a[5] = s.depth; a[6] = s.status; a[7] = s.flags;
+  a[8] = s.kflags; a[9] = s.ptr_bitmap; a[10] = s.reg_dirty; a[11] = s.counts; a[12] = 0; a[13] = 0; a[14] = 0; a[15] = 0;
+  return a;
+}
+ZD void lane_unpack(Lane& s, const zkw_v16& a) {
+  s.pc = a[0]; s.sp = a[1]; s.ergs = a[2]; s.timestamp = a[3]; s.prev_super_pc = a[4]; s.depth = a[5]; s.status = a[6]; s.flags = a[7];
+  s.kflags = a[8]; s.ptr_bitmap = a[9]; s.reg_dirty = a[10]; s.counts = a[11];
+}
+// a: lane state (lane_pack) + [12] opcode word low, [13] high, [14] packed ISA attributes | src0_ptr << 30 | src1_ptr << 31
+// b: src0 (8 dwords), src1 (8 dwords)
+// result: lane state + [12] action bits (ZKW_ACT_*), [13] low dword of the second value (far call: r2)
+__device__ __noinline__ zkw_v16 zkw_heavy_entry(zkw_v16 a, zkw_v16 b) {
+  const u32 wib = zkw_uniform(threadIdx.x / ZKW_WAVE);
+  const uint4 hdr = *(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + wib * zkw_wave_lds_units() + 1);  // written by the kernel prologue
+  const zkw_kparams ZKW_CONST_AS* Pp = (const zkw_kparams ZKW_CONST_AS*)(((u64)zkw_uniform(hdr.y) << 32) | zkw_uniform(hdr.x));
   ZKW_KP P = *Pp;
   Shared sh;
-  shared_setup(sh, P, zkw_uniform(dbg), zkw_uniform(wib), zkw_uniform(wave), false);
-  d.attr = zkw_uniform(d.attr); d.cond = zkw_uniform(d.cond); d.src0 = zkw_uniform(d.src0); d.src1 = zkw_uniform(d.src1);
-  d.dst0 = zkw_uniform(d.dst0); d.dst1 = zkw_uniform(d.dst1); d.imm0 = zkw_uniform(d.imm0); d.imm1 = zkw_uniform(d.imm1);
+  shared_setup(sh, P, zkw_uniform(hdr.z), wib, blockIdx.x * P.waves_per_group + wib, false);
+  Lane s;
+  s.lane = zkw_lane_id();
+  lane_unpack(s, a);
+  Decoded d;
+  const u32 u_lo = zkw_uniform(a[12]), u_hi = zkw_uniform(a[13]);
+  d.word_lo = u_lo; d.word_hi = u_hi;
+  d.attr = zkw_uniform(a[14] & 0x3fffffffu);
+  d.cond = (u_lo >> 13) & 7u; d.src0 = (u_lo >> 16) & 15u; d.src1 = (u_lo >> 20) & 15u; d.dst0 = (u_lo >> 24) & 15u; d.dst1 = u_lo >> 28;
+  d.imm0 = u_hi & 0xffffu; d.imm1 = u_hi >> 16;
+  Pre ps;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    ps.src0.w[i] = b[i];
+    ps.src1.w[i] = b[8 + i];
+  }
+  ps.src0_ptr = (a[14] >> 30) & 1u;
+  ps.src1_ptr = (a[14] >> 31) & 1u;
+  ps.dst0.has_loc = false; ps.dst0.type = 0; ps.dst0.page = 0; ps.dst0.index = 0;  // the destination is the caller's business
+  ps.new_pc = (s.pc + 1) & 0xffffu;
   HeavyOut out;
   out.v1 = u256_zero();
   out.v2 = u256_zero();
   out.action = 0;
   const u32 opcode = ZKW_ATTR_OPCODE(d.attr);
-  if (opcode == ZKW_OP_LOG) op_log(P, sh, s, d, ps, out);
-  else if (opcode == ZKW_OP_NEAR_CALL) op_near_call(P, sh, s, d, ps);
-  else if (opcode == ZKW_OP_FAR_CALL) op_far_call(P, sh, s, d, ps, r15, out);
-  else op_ret(P, sh, s, d, ps, out);
-  out.s = s;
-  return out;
+  if (opcode == ZKW_OP_LOG) {
+    op_log(P, sh, s, d, ps, out);
+  } else if (opcode == ZKW_OP_NEAR_CALL) {
+    op_near_call(P, sh, s, d, ps);
+  } else if (opcode == ZKW_OP_FAR_CALL) {
+    u256 r15;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r15.w[i] = sh.xfer[i * ZKW_LDS_STRIDE + s.lane];
+    op_far_call(P, sh, s, d, ps, r15, out);
+  } else {
+    op_ret(P, sh, s, d, ps, out);
+  }
+  s.lane = zkw_lane_id();
+  if (out.action & (ZKW_ACT_DST0 | ZKW_ACT_FAR | ZKW_ACT_RET)) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) sh.xfer[i * ZKW_LDS_STRIDE + s.lane] = out.v1.w[i];
+  }
+  zkw_v16 r = lane_pack(s);
+  r[12] = out.action;
+  r[13] = out.v2.w[0];
+  return r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1740,14 +1867,32 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
       case ZKW_OP_NEAR_CALL:
       case ZKW_OP_FAR_CALL:
       case ZKW_OP_RET: {  // out of line; what they write to registers comes back as actions
-        const u256 r15 = opcode == ZKW_OP_FAR_CALL ? rf_get(rf, 15) : u256_zero();
-        const HeavyOut out = zkw_heavy_entry(&P, sh.debug_flags, sh.wib, sh.wave, s, d, ps, r15);
-        s = out.s;
-        if (out.action & ZKW_ACT_DST0) dst0_update(P, sh, rf, s, ps.dst0, d.dst0, out.v1, false);
-        if (out.action & (ZKW_ACT_FAR | ZKW_ACT_RET)) {
-          reg_write(sh, rf, s, 1, out.v1, true);
-          reg_write(sh, rf, s, 2, out.v2, false);  // ret: zero
-          if (out.action & ZKW_ACT_TO_SYSTEM) {
+        if (opcode == ZKW_OP_FAR_CALL) {  // CALL_IMPLICIT_PARAMETER_REG_IDX, far_call.rs:506-508
+          const u256 r15 = rf_get(rf, 15);
+#pragma unroll
+          for (int i = 0; i < 8; i++) sh.xfer[i * ZKW_LDS_STRIDE + s.lane] = r15.w[i];
+        }
+        zkw_v16 a = lane_pack(s), b;
+        a[12] = d.word_lo; a[13] = d.word_hi; a[14] = d.attr | ((ps.src0_ptr ? 1u : 0u) << 30) | ((ps.src1_ptr ? 1u : 0u) << 31);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          b[i] = ps.src0.w[i];
+          b[8 + i] = ps.src1.w[i];
+        }
+        const zkw_v16 r = zkw_heavy_entry(a, b);
+        lane_unpack(s, r);
+        s.lane = zkw_lane_id();
+        const u32 action = r[12];
+        u256 v1 = u256_zero();
+        if (action & (ZKW_ACT_DST0 | ZKW_ACT_FAR | ZKW_ACT_RET)) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) v1.w[i] = sh.xfer[i * ZKW_LDS_STRIDE + s.lane];
+        }
+        if (action & ZKW_ACT_DST0) dst0_update(P, sh, rf, s, ps.dst0, d.dst0, v1, false);
+        if (action & (ZKW_ACT_FAR | ZKW_ACT_RET)) {
+          reg_write(sh, rf, s, 1, v1, true);
+          reg_write(sh, rf, s, 2, u256_from_u32(r[13]), false);  // ret: zero
+          if (action & ZKW_ACT_TO_SYSTEM) {
             s.ptr_bitmap &= ~(0x3ffu << 2);  // CALL_SYSTEM_ABI_REGISTERS = 2..12: drop the pointer markers only
           } else {
 #pragma unroll
@@ -1821,10 +1966,24 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
     uint4* dst = (uint4*)sh.isa;
     for (u32 i = threadIdx.x; i < ZKW_ISA_TABLE_SIZE / 2; i += blockDim.x) dst[i] = src[i];
   }
+#ifdef ZKW_PROFILE
+  for (u32 i = threadIdx.x; i < ZKW_WAVES_PER_GROUP * 40; i += blockDim.x) (&zp_acc[0][0])[i] = 0;
+#endif
   __syncthreads();
   if (wave >= P.n_waves) return;  // tail workgroup: no further workgroup-level barrier below
+  if (tid == 0) {  // what zkw_heavy_entry needs and cannot take through its argument registers
+    const u64 kp = (u64)A.kp[blockIdx.y];
+    zkw_lds[ZKW_ISA_TABLE_SIZE / 2 + wib * zkw_wave_lds_units() + 1] = make_uint4((u32)kp, (u32)(kp >> 32), A.debug_flags, 0);
+  }
+#ifdef __HIP_DEVICE_COMPILE__
+  {  // the wave's stream cursors -> lanes 0..3 of v128 (see stream_alloc); uniform loads
+    const u32* cp = P.cursors + wave * 4;
+    zkw_cursor_set<0>(zkw_uniform(cp[0])); zkw_cursor_set<1>(zkw_uniform(cp[1])); zkw_cursor_set<2>(zkw_uniform(cp[2])); zkw_cursor_set<3>(zkw_uniform(cp[3]));
+  }
+#else
   for (u32 i = tid; i < 4; i += P.wave_threads) sh.cursor[i] = P.cursors[wave * 4 + i];
   zkw_wave_lds_fence();
+#endif
   const u32 cycle_base = P.wave_cycles[wave];  // wave-cycles run since the reset (records / directory index)
 
   const u32 inst = wave * P.L + tid;
@@ -1872,16 +2031,26 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
   // fails or has used its cycles: the lane state is then modified unconditionally inside the loop body instead of inside
   // an `if (active)` region of every iteration (whose merge points cost ~75 register copies per VM cycle).
   u32 k = 0;
+#ifdef __HIP_DEVICE_COMPILE__
+  u32 delta_cur = zkw_cursor_get<3>();
+#else
   u32 delta_cur = ZKW_LDS_WORD(sh.cursor)[3];
+#endif
   if (exists && !(s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0)) lane_writeback(P, sh, rf, s, 0);  // does not cycle
   if (exists && s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0) {
+    ZKW_PROF_DECL
     for (;;) {
       s.lane = zkw_lane_id();
+      ZKW_PROF_RESET
       // directory: stream cursors at the start of wave-cycle (cycle_base + k).  Read here (one broadcast 16-B LDS read),
       // stored by the first remaining lane after the fetch below, so that the LDS latency hides behind it.  The
       // register-delta cursor is carried in a register: only the end of the cycle advances it.
-      uint4 dir_entry = zkw_lds_read4(sh.cursor + zkw_opaque(0u));
+#ifdef __HIP_DEVICE_COMPILE__
+      const uint4 dir_entry = make_uint4(zkw_cursor_get<0>(), zkw_cursor_get<1>(), zkw_cursor_get<2>(), delta_cur);
+#else
+      uint4 dir_entry = zkw_lds_read4(sh.cursor);
       dir_entry.w = delta_cur;
+#endif
       s.counts = 0; s.kflags &= ~KF_COLD_DIRTY; s.reg_dirty = 0;
       // ----------------------------------------------------------------------------------------
       // read_and_decode (cycle.rs:19-236)
@@ -1928,6 +2097,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
       // limb 3-k, :86-94 — or sh.enc once the lane was masked): held in registers across the opcode bodies these four
       // values are what the allocator spills to scratch memory.
       // ----------------------------------------------------------------------------------------
+      ZKW_PROF(0)  // fetch, directory
       u64 todo = __ballot(1);
       while (todo) {
         const u32 leader = (u32)__ffsll((long long)todo) - 1u;
@@ -1962,13 +2132,25 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
           }
         }
         todo &= ~__ballot(mine);
+        ZKW_PROF(1)  // group selection, price, exceptions, condition
         if (mine) {
           Decoded d;
+          d.word_lo = u_lo; d.word_hi = u_hi;
           d.attr = u_attr;
           d.cond = (u_lo >> 13) & 7u; d.src0 = (u_lo >> 16) & 15u; d.src1 = (u_lo >> 20) & 15u; d.dst0 = (u_lo >> 24) & 15u; d.dst1 = u_lo >> 28;
           d.imm0 = u_hi & 0xffffu; d.imm1 = u_hi >> 16;
           if (A.debug_flags & 8u) s.pc = (s.pc + 1u) & 0xffffu;  // profiling ablation: no operand / opcode work
           else exec_decoded(P, sh, rf, s, d);
+#ifdef ZKW_PROFILE
+          {
+            const unsigned long long zp_now = __builtin_readcyclecounter();
+            if (zkw_rank_below(__ballot(1)) == 0) {
+              zp_acc[sh.wib][8 + (ZKW_ATTR_OPCODE(u_attr) & 15u)] += zp_now - zp_last;
+              zp_acc[sh.wib][24 + (ZKW_ATTR_OPCODE(u_attr) & 15u)] += 1;
+            }
+            zp_last = zp_now;
+          }
+#endif
         }
       }
       // ----------------------------------------------------------------------------------------
@@ -1987,8 +2169,6 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
           if (a) {
             a[1] = make_uint4(CF(sh, s, CF_CTX0 + 0), CF(sh, s, CF_CTX0 + 1), CF(sh, s, CF_CTX0 + 2), CF(sh, s, CF_CTX0 + 3));
             a[2] = make_uint4(CF(sh, s, CF_MPC), 0, 0, 0);
-#pragma unroll
-            for (int i = 3; i < 16; i++) a[i] = make_uint4(0, 0, 0, 0);
           }
         }
       }
@@ -2001,6 +2181,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
         // register file.  A cycle writes one register on average, so this is ~70 B instead of 512 B.
         // Order inside a wave-cycle: by register (ascending), lanes in lane order within a register — the register
         // index of a store is then wave-uniform (the values come straight from the VGPR register file).
+        ZKW_PROF(2)  // end-of-cycle bookkeeping
         s.lane = zkw_lane_id();
         const bool ok = lane_ok(s);
         const u32 dm = ok ? s.reg_dirty : 0u;
@@ -2052,9 +2233,14 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
           // `total` is the same for every lane still in the loop (ballots over exactly those lanes); the LDS copy is
           // only read after the loop (final directory entry), and a wave's LDS operations complete in order
           delta_cur = base + total;
-          if (zkw_rank_below(__ballot(true)) == 0) ZKW_LDS_WORD(sh.cursor + zkw_opaque(3u))[0] = delta_cur;
+#ifdef __HIP_DEVICE_COMPILE__
+          zkw_cursor_set<3>(delta_cur);
+#else
+          if (zkw_rank_below(__ballot(true)) == 0) ZKW_LDS_WORD(sh.cursor)[3] = delta_cur;
+#endif
         }
       }
+      ZKW_PROF(3)  // CycleRecord: delta ranks, delta + tail stores
       k++;
       dir_ptr += 4;
       // leave: failed / out of cycles / execution_has_ended() (mod.rs:96-98: callers stop cycling at depth 0)
@@ -2064,6 +2250,14 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
       }
     }
   }
+#ifdef ZKW_PROFILE
+  __syncthreads();
+  if (blockIdx.x == 5 && blockIdx.y == 0 && threadIdx.x == 0) {
+    printf("ZKWPROF cycles %u: fetch %llu select %llu eoc %llu record %llu\n", k, zp_acc[0][0], zp_acc[0][1], zp_acc[0][2], zp_acc[0][3]);
+    for (int o = 0; o < 16; o++)
+      if (zp_acc[0][24 + o]) printf("ZKWPROF opcode %d: %llu iterations, %llu clocks each\n", o, zp_acc[0][24 + o], zp_acc[0][8 + o] / zp_acc[0][24 + o]);
+  }
+#endif
   // wave-cycles executed = the maximum over the lanes (lanes leave the loop at different iterations)
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -2072,11 +2266,21 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
   }
   dir_ptr = P.dir + ((u64)wave * (P.max_cycles + 1) + cycle_base + k) * 4;
   // final directory entry
+#ifdef __HIP_DEVICE_COMPILE__
+  {
+    const uint4 fin = make_uint4(zkw_cursor_get<0>(), zkw_cursor_get<1>(), zkw_cursor_get<2>(), zkw_cursor_get<3>());
+    if (tid == 0) {
+      *(uint4*)dir_ptr = fin;
+      *(uint4*)(P.cursors + wave * 4) = fin;
+    }
+  }
+#else
   for (u32 i = tid; i < 4; i += P.wave_threads) {
     const u32 cur = ZKW_LDS_WORD(sh.cursor)[i];
     dir_ptr[i] = cur;
     P.cursors[wave * 4 + i] = cur;
   }
+#endif
   if (tid == 0) P.wave_cycles[wave] = cycle_base + k;
 }
 
@@ -2145,6 +2349,12 @@ __global__ void zkw_reset_kernel(zkw_fused_table T) {
       }
     }
   }
+  if (R.commit_out)
+    for (u32 i = t0; i < R.n_instances; i += stride) {
+      u64* tl = R.commit_out + ((u64)i * ZKW_QUEUE_COUNT + ZKW_QUEUE_DECOMMIT) * 4;
+      tl[0] = tl[1] = tl[2] = tl[3] = 0;
+      R.dq_count[i] = 0;
+    }
   for (u32 i = t0; i < R.n_waves * 4; i += stride) R.cursors[i] = 0;
   for (u32 i = t0; i < R.n_waves; i += stride) R.wave_cycles[i] = 0;
 }
@@ -2161,7 +2371,7 @@ extern "C" hipError_t zkw_launch_reset_kernel(const zkw_fused_table* T, hipStrea
 // dynamic LDS per workgroup: ISA table + per wave (cursors + per-lane cold state and previous_code_word)
 extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_group) {
   (void)L;  // rows have a fixed lane stride
-  return ZKW_ISA_TABLE_SIZE * 8 + waves_per_group * (16 + ZKW_LDS_STRIDE * (ZKW_COLD_FIELDS * 4 + 64 + 16));
+  return ZKW_ISA_TABLE_SIZE * 8 + waves_per_group * (32 + ZKW_LDS_STRIDE * (ZKW_COLD_FIELDS * 4 + 64 + 16 + 32));
 }
 
 // host-callable launcher (keeps <<<>>> out of the runtime)

@@ -138,7 +138,8 @@ struct zkw_batch {
   bool full_reset_pending = true;  // the first reset after an upload copies the whole heap image
   DevBuf<uint32_t> d_dir, d_cursors, d_krow;
   DevBuf<uint64_t> d_commit, d_rc, d_blob_digests, d_leaves, d_midstates;
-  DevBuf<uint32_t> d_idx, d_counts;
+  DevBuf<uint32_t> d_idx, d_counts, d_dq_count;
+  int dq_mode = 0;  // decommit-queue commitment since the last reset: 0 undecided, 1 chained by the cycle kernel, 2 by the commitment kernels
   // hipGraph of one whole step (reset -> cycle kernel -> commitment kernels), replayed by zkw_batch_step
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -310,7 +311,7 @@ void zkw_batch_destroy(zkw_batch* b) {
   b->d_ns_log_idx.release(); b->d_ns_log_cnt.release(); b->d_ns_aux_idx.release(); b->d_ns_aux_cnt.release(); b->d_ns_st_hist.release();
   b->d_ns_ev_hist.release(); b->d_ns_rb_st.release(); b->d_ns_rb_ev.release(); b->d_ns_marks.release(); b->d_ns_counts.release();
   b->d_ns_bucket_params.release(); b->d_ns_params.release(); b->d_commit.release(); b->d_rc.release(); b->d_blob_digests.release(); b->d_leaves.release(); b->d_midstates.release();
-  b->d_idx.release(); b->d_counts.release();
+  b->d_idx.release(); b->d_counts.release(); b->d_dq_count.release();
   if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
   if (b->graph) (void)hipGraphDestroy(b->graph);
   for (hipEvent_t e : b->evs) (void)hipEventDestroy(e);
@@ -717,6 +718,7 @@ int zkw_batch_upload(zkw_batch* b) {
   HIP_TRY(c, ensure(b->d_cursors, (size_t)W * 4));
   HIP_TRY(c, ensure(b->d_krow, (size_t)W * ZKW_KROW_WORDS * L));
   HIP_TRY(c, ensure(b->d_commit, (size_t)n * ZKW_QUEUE_COUNT * 4));
+  HIP_TRY(c, ensure(b->d_dq_count, (size_t)n));
   if (b->evs.empty()) {
     b->evs.resize(2 * zkw_batch::EV_RING, nullptr);
     for (auto& e : b->evs) HIP_TRY(c, hipEventCreate(&e));
@@ -742,6 +744,7 @@ int zkw_batch_upload(zkw_batch* b) {
   P.stack_vals = b->d_stack_vals.p; P.stack_ptrs = b->d_stack_ptrs.p; P.heap = b->d_heap.p; P.aux_heap = b->d_aux.p;
   P.storage = b->d_storage.p; P.journal = b->d_journal.p; P.history = b->d_history.p;
   P.blob_words = b->d_blob_words.p; P.blob_dir = b->d_blob_dir.p; P.preimages = b->d_preimages.p;
+  P.commit_rc = b->d_rc.p; P.midstates = b->d_midstates.p; P.blob_digests = b->d_blob_digests.p; P.commit_out = b->d_commit.p; P.dq_count = b->d_dq_count.p;
   P.tails = b->d_tails.p; P.deltas = b->d_deltas.p; P.wave_cycles = b->d_wave_cycles.p; P.cap_delta = b->cap_delta; P.heap_dirty = b->d_heap_dirty.p; P.heap_image_words = b->heap_image_words; P.mem_stream = b->d_mem.p; P.log_stream = b->d_log.p; P.aux_stream = b->d_auxs.p;
   P.dir = b->d_dir.p; P.cursors = b->d_cursors.p;
   P.props = b->props;
@@ -764,6 +767,7 @@ int zkw_batch_upload(zkw_batch* b) {
     R.cursors = b->d_cursors.p;
     R.wave_cycles = b->d_wave_cycles.p;
     R.heap_dirty = b->d_heap_dirty.p; R.image_words = b->heap_image_words; R.L = b->L;
+    R.commit_out = b->d_commit.p; R.dq_count = b->d_dq_count.p; R.n_instances = b->n;
     HIP_TRY(c, ensure(b->d_reset_params, 1));
     HIP_TRY(c, hipMemcpy(b->d_reset_params.p, &R, sizeof R, hipMemcpyHostToDevice));
     const uint32_t caps[3] = {b->cap_mem, b->cap_log, b->cap_aux};
@@ -834,6 +838,7 @@ static int enqueue_reset(zkw_batch* const* bs, uint32_t n, hipStream_t st) {
   for (uint32_t i = 0; i < n; i++) {
     zkw_batch* b = bs[i];
     b->cycles_run = 0;
+    b->dq_mode = 0;
     b->ran = false;
     b->synced = false;
     b->ns_done = false;
@@ -843,8 +848,21 @@ static int enqueue_reset(zkw_batch* const* bs, uint32_t n, hipStream_t st) {
   return ZKW_OK;
 }
 
-static int enqueue_run(zkw_batch* const* bs, uint32_t n, uint32_t max_cycles, hipStream_t st) {
+// `inline_decommit`: the cycle kernel chains the decommit-queue commitment itself (a step that runs and commits in one
+// call has nothing to overlap the commitment kernels with); otherwise zkw_batch_commit computes it from the aux stream
+static int enqueue_run(zkw_batch* const* bs, uint32_t n, uint32_t max_cycles, hipStream_t st, bool inline_decommit = false) {
   zkw_ctx* c = bs[0]->ctx;
+  if (getenv("ZKW_NO_INLINE_DECOMMIT")) inline_decommit = false;  // A/B switch
+  for (uint32_t i = 0; i < n; i++) {
+    const int want = inline_decommit ? 1 : 2;
+    if (bs[i]->dq_mode == 0) bs[i]->dq_mode = want;
+    else if (bs[i]->dq_mode != want) inline_decommit = bs[i]->dq_mode == 1;  // a continued run keeps the mode of its first launch
+  }
+  for (uint32_t i = 0; i < n; i++)
+    if (bs[i]->dq_mode != (inline_decommit ? 1 : 2)) {
+      c->last_error = "fused run: the batches disagree on how their decommit queue is committed since their last reset";
+      return ZKW_ERR_INVALID;
+    }
   for (uint32_t i = 0; i < n; i++)
     if (max_cycles == 0 || (uint64_t)bs[i]->cycles_run + max_cycles > bs[i]->lim.max_cycles) {
       c->last_error = "run exceeds limits.max_cycles since the last reset";
@@ -863,6 +881,7 @@ static int enqueue_run(zkw_batch* const* bs, uint32_t n, uint32_t max_cycles, hi
     A.max_L = std::max(A.max_L, bs[i]->L);
   }
   if (const char* dbg = getenv("ZKW_DEBUG_FLAGS")) A.debug_flags = (uint32_t)atoi(dbg);  // profiling ablations / test hooks only
+  if (inline_decommit) A.debug_flags |= 16u;
   // HIP events around the launch: on the first batch of the group (its kernel_ms is the launch's duration)
   zkw_batch* lead = bs[0];
   const uint32_t slot = lead->pending_runs % zkw_batch::EV_RING;
@@ -891,6 +910,16 @@ static int enqueue_commit(zkw_batch* const* bs, uint32_t n, uint32_t queue_mask,
   HIP_TRY(c, hipSetDevice(c->device));
   for (uint32_t q = 0; q < ZKW_QUEUE_COUNT; q++) {
     if (!((queue_mask >> q) & 1u)) continue;
+    if (q == ZKW_QUEUE_DECOMMIT) {  // already chained by the cycle kernel (op_far_call) when the run was part of a fused step
+      bool all_inline = true;
+      for (uint32_t i = 0; i < n; i++) all_inline = all_inline && bs[i]->dq_mode == 1;
+      if (all_inline) continue;
+      for (uint32_t i = 0; i < n; i++)
+        if (bs[i]->dq_mode == 1) {
+          c->last_error = "fused commit: some batches chained their decommit queue in the cycle kernel, others did not";
+          return ZKW_ERR_INVALID;
+        }
+    }
     zkw_fused_table T;
     std::memset(&T, 0, sizeof T);
     T.n = n;
@@ -930,6 +959,11 @@ int zkw_batches_run(zkw_batch* const* batches, uint32_t n_batches, uint32_t max_
   return rc != ZKW_OK ? rc : enqueue_run(batches, n_batches, max_cycles, (hipStream_t)hip_stream);
 }
 
+int zkw_batches_run_committing(zkw_batch* const* batches, uint32_t n_batches, uint32_t max_cycles, uint32_t queue_mask, void* hip_stream) {
+  int rc = check_group(batches, n_batches);
+  return rc != ZKW_OK ? rc : enqueue_run(batches, n_batches, max_cycles, (hipStream_t)hip_stream, (queue_mask >> ZKW_QUEUE_DECOMMIT) & 1u);
+}
+
 int zkw_batches_commit(zkw_batch* const* batches, uint32_t n_batches, uint32_t queue_mask, void* hip_stream) {
   int rc = check_group(batches, n_batches);
   if (rc != ZKW_OK) return rc;
@@ -941,7 +975,7 @@ int zkw_batches_step(zkw_batch* const* batches, uint32_t n_batches, uint32_t max
   if (rc != ZKW_OK) return rc;
   hipStream_t st = (hipStream_t)hip_stream;
   rc = enqueue_reset(batches, n_batches, st);
-  if (rc == ZKW_OK) rc = enqueue_run(batches, n_batches, max_cycles, st);
+  if (rc == ZKW_OK) rc = enqueue_run(batches, n_batches, max_cycles, st, (queue_mask >> ZKW_QUEUE_DECOMMIT) & 1u);
   if (rc == ZKW_OK && queue_mask) rc = enqueue_commit(batches, n_batches, queue_mask, st);
   return rc;
 }
@@ -1018,7 +1052,8 @@ int zkw_batch_download_all(zkw_batch* b, uint64_t* n_bytes, double* ms) {
     pieces.push_back({b->d_tails.p + (size_t)w * MC * 2 * L, 0, (size_t)max_cyc * 2 * L * 16});
     pieces.push_back({b->d_deltas.p + (size_t)w * b->cap_delta * 2, 0, (size_t)std::min(cur[3], b->cap_delta) * 16});                   // low plane
     pieces.push_back({b->d_deltas.p + (size_t)w * b->cap_delta * 2 + b->cap_delta, 0, (size_t)std::min(cur[3], b->cap_delta) * 16});  // high plane
-    pieces.push_back({b->d_mem.p + (size_t)w * b->cap_mem * 3, 0, (size_t)std::min(cur[0], b->cap_mem) * 48});
+    for (int pl = 0; pl < 3; pl++)  // three planes
+      pieces.push_back({b->d_mem.p + ((size_t)w * 3 + pl) * b->cap_mem, 0, (size_t)std::min(cur[0], b->cap_mem) * 16});
     pieces.push_back({b->d_log.p + (size_t)w * b->cap_log * 8, 0, (size_t)std::min(cur[1], b->cap_log) * 128});
     pieces.push_back({b->d_auxs.p + (size_t)w * b->cap_aux * 16, 0, (size_t)std::min(cur[2], b->cap_aux) * 256});
     pieces.push_back({b->d_dir.p + (size_t)w * (MC + 1) * 4, 0, (size_t)(max_cyc + 1) * 16});
@@ -1093,9 +1128,21 @@ static int build_wave(zkw_batch* b, uint32_t w) {
   std::vector<zkw_mem_query> mem(n_mem);
   std::vector<zkw_log_query> log(n_log);
   std::vector<zkw_aux_event> aux(n_aux);
-  if (n_mem) HIP_TRY(c, hipMemcpy(mem.data(), b->d_mem.p + (size_t)w * b->cap_mem * 3, (size_t)n_mem * 48, hipMemcpyDeviceToHost));
+  if (n_mem) {  // the stream is stored as three planes of 16-byte units (header | value low | value high)
+    std::vector<uint4> planes((size_t)n_mem * 3);
+    for (int pl = 0; pl < 3; pl++)
+      HIP_TRY(c, hipMemcpy(planes.data() + (size_t)pl * n_mem, b->d_mem.p + ((size_t)w * 3 + pl) * b->cap_mem, (size_t)n_mem * 16, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n_mem; i++) {
+      uint4* q = (uint4*)&mem[i];
+      q[0] = planes[i]; q[1] = planes[(size_t)n_mem + i]; q[2] = planes[(size_t)2 * n_mem + i];
+    }
+  }
   if (n_log) HIP_TRY(c, hipMemcpy(log.data(), b->d_log.p + (size_t)w * b->cap_log * 8, (size_t)n_log * 128, hipMemcpyDeviceToHost));
   if (n_aux) HIP_TRY(c, hipMemcpy(aux.data(), b->d_auxs.p + (size_t)w * b->cap_aux * 16, (size_t)n_aux * 256, hipMemcpyDeviceToHost));
+  for (uint32_t i = 0; i < n_aux; i++) {  // the kernel writes only the bytes a record type uses: the rest of the 256 bytes is zero in the ABI
+    const uint32_t used = aux[i].type == ZKW_AUX_FRAME_START ? 240u : aux[i].type == ZKW_AUX_DECOMMIT ? 64u : aux[i].type == ZKW_AUX_COLD_STATE ? 48u : 16u;
+    std::memset((uint8_t*)&aux[i] + used, 0, 256 - used);
+  }
   // records: tails [cycle][2][L] + register deltas of the wave; the 512-byte snapshots are rebuilt from the initial
   // register file by replaying every lane's deltas (positions from the dirty masks, see zkw_cycle_kernel)
   std::vector<uint4> tails((size_t)max_cycles_lane * 2 * L);

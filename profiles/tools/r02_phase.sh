@@ -1,0 +1,13 @@
+# Phase timing of the cycle kernel: a profiling build (-DZKW_PROFILE, built on the box into a scratch copy of libzkw.so)
+# prints shader clocks per phase / opcode for one wave.  usage: r02_phase.sh <tag>
+cd $GRAFT_REPO_ROOT
+T=gpurun_out/$1; mkdir -p $T
+cp era-zk_evm_amd/libzkw.so /tmp/libzkw_keep.so
+python -c "
+import sys; sys.path.insert(0,'.')
+import era_zk_evm_amd
+from era_zk_evm_amd import build as b
+b.build_lib(force=True, extra_flags=['-DZKW_PROFILE'])"
+for F in 1 20 64; do echo "fuse $F" >> $T/phase.txt; python bench.py --no-cpu-baseline --steps $((F*2)) --warmup $F --fuse $F --streams 1 2>&1 | grep ZKWPROF | tail -12 >> $T/phase.txt; done
+cp /tmp/libzkw_keep.so era-zk_evm_amd/libzkw.so
+cat $T/phase.txt

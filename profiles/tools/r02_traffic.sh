@@ -35,6 +35,16 @@ if "f0" in res:
     if "w0" in res:
         summary["hbm_bytes_per_launch"] = kb("w0") + 2.0 * kb("f0")
         summary["hbm_bytes_per_cycle"] = summary["hbm_bytes_per_launch"] / cycles
+# kernel time of each ablation (HIP events inside bench.py; profiled runs, so only their ratios matter)
+km = {}
+for fl in "0123":
+    try:
+        for ln in open(os.path.join(out, "w%s.log" % fl)):
+            if ln.startswith("{"):
+                km["w" + fl] = json.loads(ln)["kernel_ms"]
+    except OSError:
+        pass
+summary["kernel_ms_by_ablation"] = km
 json.dump(summary, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
 PY

@@ -1,0 +1,316 @@
+//! `#[repr(C)]` mirror of include/zkw.h — field for field (sizes are asserted against `zkw_abi_sizeof` in `check_abi`).
+#![allow(non_camel_case_types, dead_code)]
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+#[derive(Clone, Copy, Default, Debug, PartialEq, Eq)]
+pub struct zkw_u256 {
+    pub l: [u64; 4],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkw_isa_entry {
+    pub opcode: u8,
+    pub variant: u8,
+    pub src0_mode: u8,
+    pub dst0_mode: u8,
+    pub flags: u8,
+    pub props: u8,
+    pub reserved: u16,
+    pub price: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkw_isa_consts {
+    pub nop_encoding: u64,
+    pub exception_revert_encoding: u64,
+    pub panic_variant_idx: u32,
+    pub nop_variant_idx: u32,
+    pub clip_mode: u32,
+    pub time_delta_per_cycle: u32,
+    pub new_memory_pages_per_far_call: u32,
+    pub vm_max_stack_depth: u32,
+    pub initial_sp_on_far_call: u32,
+    pub new_frame_memory_stipend: u32,
+    pub memory_growth_ergs_per_byte: u32,
+    pub ergs_per_code_word_decommittment: u32,
+    pub initial_storage_write_pubdata_bytes: u32,
+    pub l1_message_pubdata_bytes: u32,
+    pub max_offset_to_deref_low: u32,
+    pub deployer_address_low: u32,
+    pub keccak_precompile_address: u32,
+    pub sha256_precompile_address: u32,
+    pub ecrecover_precompile_address: u32,
+    pub storage_aux_byte: u8,
+    pub event_aux_byte: u8,
+    pub l1_message_aux_byte: u8,
+    pub precompile_aux_byte: u8,
+    pub ecrecover_input_layout: u32,
+    pub reserved: [u32; 7],
+}
+
+#[repr(C)]
+pub struct zkw_isa_table {
+    pub entries: [zkw_isa_entry; 2048],
+    pub consts: zkw_isa_consts,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkw_callstack_entry {
+    pub this_address: [u8; 20],
+    pub msg_sender: [u8; 20],
+    pub code_address: [u8; 20],
+    pub base_memory_page: u32,
+    pub code_page: u32,
+    pub sp: u16,
+    pub pc: u16,
+    pub exception_handler_location: u16,
+    pub is_static: u8,
+    pub is_local_frame: u8,
+    pub ergs_remaining: u32,
+    pub this_shard_id: u8,
+    pub caller_shard_id: u8,
+    pub code_shard_id: u8,
+    pub reserved0: u8,
+    pub reserved1: u32,
+    pub context_u128_value: [u64; 2],
+    pub heap_bound: u32,
+    pub aux_heap_bound: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkw_vm_local_state {
+    pub previous_code_word: zkw_u256,
+    pub registers: [zkw_u256; 15],
+    pub register_ptr_bitmap: u16,
+    pub flags: u8,
+    pub pending_exception: u8,
+    pub previous_code_memory_page: u32,
+    pub timestamp: u32,
+    pub monotonic_cycle_counter: u32,
+    pub spent_pubdata_counter: u32,
+    pub memory_page_counter: u32,
+    pub absolute_execution_step: u32,
+    pub current_ergs_per_pubdata_byte: u32,
+    pub tx_number_in_block: u16,
+    pub previous_super_pc: u16,
+    pub callstack_depth: u32,
+    pub context_u128_register: [u64; 2],
+    pub current: zkw_callstack_entry,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkw_cycle_tail {
+    pub register_ptr_bitmap: u16,
+    pub flags: u8, // bits 0..2 lt/eq/gt, bit 3 pending_exception
+    pub reserved0: u8,
+    pub pc: u16,
+    pub sp: u16,
+    pub ergs_remaining: u32,
+    pub timestamp: u32,
+    pub heap_bound: u32,
+    pub aux_heap_bound: u32,
+    pub callstack_depth: u16,
+    pub previous_super_pc: u16,
+    pub event_counts: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkw_cycle_record {
+    pub registers: [zkw_u256; 15],
+    pub tail: zkw_cycle_tail,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkw_mem_query {
+    pub timestamp: u32,
+    pub page: u32,
+    pub index: u32,
+    pub lane: u8,
+    pub seq: u8,
+    pub meta: u8, // bits 0-2 MemoryType, 3 value_is_pointer, 4 rw_flag, 5-7 kind (0 plain, 1 precompile read, 2 precompile write)
+    pub reserved0: u8,
+    pub value: zkw_u256,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkw_log_query {
+    pub key: zkw_u256,
+    pub read_value: zkw_u256,
+    pub written_value: zkw_u256,
+    pub address: [u8; 20],
+    pub timestamp: u32,
+    pub tx_number_in_block: u16,
+    pub aux_byte: u8,
+    pub shard_id: u8,
+    pub bools: u8, // 1 rw_flag, 2 rollback, 4 is_service
+    pub kind: u8,  // 0 add_log_query, 1 record_refund_for_query
+    pub lane: u8,
+    pub seq: u8,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkw_aux_frame {
+    pub previous: zkw_callstack_entry,
+    pub next: zkw_callstack_entry,
+}
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkw_aux_cold {
+    pub context_u128_register: [u64; 2],
+    pub memory_page_counter: u32,
+}
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub union zkw_aux_payload {
+    pub frame: zkw_aux_frame,
+    pub hash: zkw_u256,
+    pub cold: zkw_aux_cold,
+    pub raw: [u8; 240],
+}
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkw_aux_event {
+    pub r#type: u8, // 1 FRAME_START, 2 FRAME_FINISH, 3 DECOMMIT, 4 COLD_STATE
+    pub lane: u8,
+    pub seq: u8,
+    pub flag: u8,
+    pub a: u32,
+    pub b: u32,
+    pub c: u32,
+    pub u: zkw_aux_payload,
+}
+
+#[repr(C)]
+pub struct zkw_instance_trace {
+    pub status: u32,
+    pub n_cycles: u32,
+    pub n_mem: u32,
+    pub n_log: u32,
+    pub n_aux: u32,
+    pub reserved0: u32,
+    pub records: *const zkw_cycle_record,
+    pub mem: *const zkw_mem_query,
+    pub log: *const zkw_log_query,
+    pub aux: *const zkw_aux_event,
+    pub mem_off: *const u32,
+    pub log_off: *const u32,
+    pub aux_off: *const u32,
+    pub final_state: zkw_vm_local_state,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct zkw_limits {
+    pub max_cycles: u32,
+    pub max_far_frames: u32,
+    pub max_callstack_depth: u32,
+    pub stack_words: u32,
+    pub heap_words: u32,
+    pub aux_heap_words: u32,
+    pub storage_slots: u32,
+    pub storage_journal: u32,
+    pub max_mem_queries: u32,
+    pub max_log_queries: u32,
+    pub max_aux_events: u32,
+    pub lanes_per_wave: u32,
+    pub max_reg_deltas: u32,
+    pub reserved: [u32; 3],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkw_storage_slot {
+    pub key: zkw_u256,
+    pub value: zkw_u256,
+    pub address: [u8; 20],
+    pub shard_id: u8,
+    pub reserved0: [u8; 3],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkw_block_properties {
+    pub default_aa_code_hash: zkw_u256,
+    pub zkporter_is_available: u32,
+    pub reserved0: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct zkw_run_stats {
+    pub cycles: u64,
+    pub mem_queries: u64,
+    pub log_queries: u64,
+    pub aux_events: u64,
+    pub instances_ended: u64,
+    pub instances_failed: u64,
+    pub kernel_ms: f64,
+    pub reg_deltas: u64,
+}
+
+pub enum zkw_ctx {}
+pub enum zkw_batch {}
+pub enum zkw_comm {}
+#[repr(C)]
+pub struct zkw_comm_id {
+    pub bytes: [u8; 128],
+}
+
+pub const ZKW_OK: c_int = 0;
+pub const ZKW_STATUS_RUNNING: u32 = 0;
+pub const ZKW_STATUS_ENDED: u32 = 1;
+pub const ZKW_STATUS_UNKNOWN_CODE_HASH: u32 = 2;
+pub const ZKW_STATUS_REFERENCE_PANIC: u32 = 3;
+pub const ZKW_STATUS_LIMIT: u32 = 4;
+
+extern "C" {
+    pub fn zkw_ctx_create(device: c_int, out: *mut *mut zkw_ctx) -> c_int;
+    pub fn zkw_ctx_destroy(ctx: *mut zkw_ctx);
+    pub fn zkw_last_error(ctx: *mut zkw_ctx) -> *const c_char;
+    pub fn zkw_ctx_set_isa(ctx: *mut zkw_ctx, table: *const zkw_isa_table) -> c_int;
+    pub fn zkw_batch_create(ctx: *mut zkw_ctx, n_instances: u32, limits: *const zkw_limits, out: *mut *mut zkw_batch) -> c_int;
+    pub fn zkw_batch_destroy(batch: *mut zkw_batch);
+    pub fn zkw_batch_add_code_blob(batch: *mut zkw_batch, words: *const zkw_u256, n_words: u32, blob_id: *mut u32) -> c_int;
+    pub fn zkw_batch_add_decommit_preimage(batch: *mut zkw_batch, hash: *const zkw_u256, blob_id: u32) -> c_int;
+    pub fn zkw_batch_set_code_page(batch: *mut zkw_batch, first: u32, count: u32, page: u32, blob_id: u32) -> c_int;
+    pub fn zkw_batch_set_state(batch: *mut zkw_batch, first: u32, count: u32, states: *const zkw_vm_local_state, inner: *const zkw_callstack_entry, inner_depth: u32) -> c_int;
+    pub fn zkw_batch_set_heap(batch: *mut zkw_batch, instance: u32, words: *const zkw_u256, n_words: u32) -> c_int;
+    pub fn zkw_batch_set_storage(batch: *mut zkw_batch, instance: u32, slots: *const zkw_storage_slot, n_slots: u32) -> c_int;
+    pub fn zkw_batch_set_block_properties(batch: *mut zkw_batch, p: *const zkw_block_properties) -> c_int;
+    pub fn zkw_batch_upload(batch: *mut zkw_batch) -> c_int;
+    pub fn zkw_batch_reset(batch: *mut zkw_batch, stream: *mut c_void) -> c_int;
+    pub fn zkw_batch_run(batch: *mut zkw_batch, max_cycles: u32, stream: *mut c_void) -> c_int;
+    pub fn zkw_batches_step(batches: *const *mut zkw_batch, n: u32, max_cycles: u32, queue_mask: u32, stream: *mut c_void) -> c_int;
+    pub fn zkw_batch_sync(batch: *mut zkw_batch) -> c_int;
+    pub fn zkw_batch_get_stats(batch: *mut zkw_batch, out: *mut zkw_run_stats) -> c_int;
+    pub fn zkw_batch_get_instance_trace(batch: *mut zkw_batch, instance: u32, out: *mut zkw_instance_trace) -> c_int;
+    pub fn zkw_batch_get_commitments(batch: *mut zkw_batch, out: *mut u64) -> c_int;
+    pub fn zkw_comm_get_unique_id(out: *mut zkw_comm_id) -> c_int;
+    pub fn zkw_comm_create_rccl(ctx: *mut zkw_ctx, rank: c_int, world: c_int, id: *const zkw_comm_id, out: *mut *mut zkw_comm) -> c_int;
+    pub fn zkw_comm_destroy(comm: *mut zkw_comm);
+    pub fn zkw_reduce_commitments(comm: *mut zkw_comm, batches: *const *mut zkw_batch, n_batches: u32, queue_mask: u32, gathered: *mut c_void,
+                                  n_max_out: *mut u32, sizes_out: *mut u32, total: *mut zkw_run_stats, stream: *mut c_void) -> c_int;
+    pub fn zkw_abi_sizeof(which: u32) -> u32;
+}
+
+/// the layouts above against the library that was actually linked
+pub fn check_abi() {
+    use std::mem::size_of;
+    assert_eq!(size_of::<zkw_callstack_entry>(), 112);
+    assert_eq!(size_of::<zkw_vm_local_state>(), 680);
+    assert_eq!(size_of::<zkw_cycle_record>(), 512);
+    assert_eq!(size_of::<zkw_mem_query>(), 48);
+    assert_eq!(size_of::<zkw_log_query>(), 128);
+    assert_eq!(size_of::<zkw_aux_event>(), 256);
+    assert_eq!(unsafe { zkw_abi_sizeof(6) }, 512);
+}

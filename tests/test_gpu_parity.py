@@ -95,13 +95,13 @@ def test_cfg3_baseline_sizes_sampled(oracle, product, isa):
     # a sample of them against the oracle, and every digest against hashlib / an independent Keccak
     import hashlib
     from test_oracle_precompiles import _keccak256_py
-    wl = synth.make(3, isa, n_instances=128)
+    wl = synth.make(3, isa, n_instances=512)  # one GPU's shard of BASELINE configs[3] (4096 instances over 8 GPUs)
     bp = _run(product, wl)
     bo = _run(oracle, wl)
-    for i in (0, 63, 64, 127):
+    for i in (0, 63, 64, 127, 255, 256, 448, 511):
         ok, why = K.traces_equal(bo.trace(i), bp.trace(i))
         assert ok, "instance %d: %s" % (i, why)
-    for i in range(0, 128, 9):
+    for i in range(0, 512, 37):
         t = bp.trace(i)
         writes = [q for q in t["mem"] if (q["meta"] >> K.MQ_KIND_SHIFT) == 2]
         data = wl.heap_bytes[i].tobytes()
@@ -367,3 +367,50 @@ def test_reduce_commitments_rccl_world1(oracle, product, isa):
     assert int(total["cycles"]) == 3 * int(so["cycles"]) and int(total["mem_queries"]) == 3 * int(so["mem_queries"])
     assert int(total["instances_failed"]) == 0
     comm.close()
+
+
+@pytest.mark.parametrize("unalignment", [0, 31])
+def test_reference_keccak_kats_through_the_gpu_precompile(product, isa, unalignment):
+    """The reference's own 8 keccak256 cases (0 / 50 / 136 / 200 bytes of 0x7b at byte misalignment 0 and 31, preceded
+    by 0xff filler — src/testing/tests/precompiles/keccak256.rs:144-196) through libzkw.so: the digests the GPU
+    precompile writes are asserted against the literal SURVEY Appendix C values, with no oracle in between."""
+    from test_oracle_precompiles import KECCAK_KATS
+    lens = (0, 50, 136, 200)
+    wl = synth.make(3, isa, n_instances=70, keccak_bytes=lens, keccak_unalign=(unalignment,) * 4, sha_rounds=(1, 1, 1, 1))
+    by = wl.heap_bytes
+    for (start, length, _) in wl.keccak_messages:
+        by[:, start - unalignment:start] = 0xFF
+        by[:, start:start + length] = 123
+    n, hw = by.shape[0], by.shape[1] // 32
+    wl.heaps = np.ascontiguousarray(by.reshape(n, hw, 4, 8).view(">u8").reshape(n, hw, 4)[:, :, ::-1].astype("<u8"))
+    bp = _run(product, wl)
+    for i in (0, 1, 33, 63, 64, 69):
+        t = bp.trace(i)
+        assert int(t["status"]) in (K.STATUS_RUNNING, K.STATUS_ENDED)
+        writes = [q for q in t["mem"] if (q["meta"] >> K.MQ_KIND_SHIFT) == 2]
+        kec = writes[4:8]  # the four sha256 results come first
+        assert len(kec) == 4
+        for length, q in zip(lens, kec):
+            assert K.u256_to_int(q["value"]).to_bytes(32, "big").hex() == KECCAK_KATS[length], (i, length, unalignment)
+
+
+def test_reference_ecrecover_vectors_through_the_gpu_precompile(product, isa):
+    """The two literal vectors of the reference's ecrecover test (src/testing/tests/precompiles/ecrecover.rs:128-143)
+    through libzkw.so: ok marker 1 and the expected address, asserted directly."""
+    from test_oracle_precompiles import ECRECOVER_VECTORS
+    sigs = []
+    for raw, _ in ECRECOVER_VECTORS:
+        b = bytes.fromhex(raw)
+        h, v, r, s = (int.from_bytes(b[i:i + 32], "big") for i in (0, 32, 64, 96))
+        v = {27: 0, 28: 1, 0: 0, 1: 1}[v]  # ecrecover.rs:107-117
+        sigs.append([h, r, s, v] if int(isa.consts["ecrecover_input_layout"]) == 0 else [h, v, r, s])
+    wl = synth.ecrecover_workload(isa, [sigs] * 66)
+    bp = _run(product, wl)
+    for i in (0, 7, 63, 64, 65):
+        writes = [q for q in bp.trace(i)["mem"] if (q["meta"] >> K.MQ_KIND_SHIFT) == 2]
+        assert len(writes) == 4
+        for j, (_, address) in enumerate(ECRECOVER_VECTORS):
+            marker, word = writes[2 * j], writes[2 * j + 1]
+            assert K.u256_to_int(marker["value"]) == 1
+            w = K.u256_to_int(word["value"]).to_bytes(32, "big")
+            assert w[:12] == bytes(12) and w[12:].hex() == address
