@@ -140,7 +140,14 @@ ZD void zkw_lds_write4(uint4* p, const uint4 v) { *p = v; }
 // Phase timing of a VM cycle (profiling build only: -DZKW_PROFILE, profiles/tools/r02_phase.sh): shader clocks between
 // marks, accumulated per workgroup wave in LDS by the first active lane; printed by one workgroup at the end.
 #ifdef ZKW_PROFILE
-__shared__ unsigned long long zp_acc[ZKW_WAVES_PER_GROUP][40];
+__shared__ unsigned long long zp_acc[ZKW_WAVES_PER_GROUP][64];  // 0-3 phases, 8-23 / 24-39 opcode clocks / counts, 40-63 sub-phases
+#define ZKW_SUB_DECL unsigned long long zs_last = __builtin_readcyclecounter();
+#define ZKW_SUB(i)                                                                       \
+  {                                                                                      \
+    const unsigned long long zs_now = __builtin_readcyclecounter();                      \
+    if (zkw_rank_below(__ballot(1)) == 0) zp_acc[sh.wib][(i)] += zs_now - zs_last;       \
+    zs_last = zs_now;                                                                    \
+  }
 #define ZKW_PROF_DECL unsigned long long zp_last = __builtin_readcyclecounter();
 #define ZKW_PROF(i)                                                                      \
   {                                                                                      \
@@ -149,10 +156,28 @@ __shared__ unsigned long long zp_acc[ZKW_WAVES_PER_GROUP][40];
     zp_last = zp_now;                                                                    \
   }
 #define ZKW_PROF_RESET zp_last = __builtin_readcyclecounter();
+// time stamps that cross the out-of-line call: the previous stamp lives in LDS slot 63
+#define ZKW_STAMP0                                                                        \
+  {                                                                                      \
+    const unsigned long long zt_now = __builtin_readcyclecounter();                      \
+    if (zkw_rank_below(__ballot(1)) == 0) zp_acc[sh.wib][63] = zt_now;                    \
+  }
+#define ZKW_STAMP(i)                                                                     \
+  {                                                                                      \
+    const unsigned long long zt_now = __builtin_readcyclecounter();                      \
+    if (zkw_rank_below(__ballot(1)) == 0) {                                              \
+      zp_acc[sh.wib][(i)] += zt_now - zp_acc[sh.wib][63];                                \
+      zp_acc[sh.wib][63] = zt_now;                                                       \
+    }                                                                                    \
+  }
 #else
 #define ZKW_PROF_DECL
 #define ZKW_PROF(i)
 #define ZKW_PROF_RESET
+#define ZKW_SUB_DECL
+#define ZKW_SUB(i)
+#define ZKW_STAMP0
+#define ZKW_STAMP(i)
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -990,6 +1015,7 @@ ZD void op_ptr(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
 
 // uma.rs:26-425
 ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, const Pre& ps) {
+  ZKW_SUB_DECL
   s.lane = zkw_lane_id();
   const u32 v = ZKW_ATTR_VARIANT(d.attr);
   s.pc = ps.new_pc;
@@ -1051,6 +1077,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
   const bool unaligned = unal != 0;
   const u32 ts_r = s.timestamp, ts_w = s.timestamp + 3;
   u256 w0v = u256_zero(), w1v = u256_zero();
+  ZKW_SUB(41)  // exceptions, growth, cost
   if (!skip) {  // :265-288
     // both word loads are issued before the first query is emitted: the emission needs the loaded value, so reading
     // and emitting word by word would serialise two memory round trips (the dominant cost of this opcode)
@@ -1059,6 +1086,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
     emit_mem(P, sh, s, ts_r, mem_type, fp.page, word0, w0v, false, false, 0);
     if (unaligned) emit_mem(P, sh, s, ts_r, mem_type, fp.page, word1, w1v, false, false, 0);
   }
+  ZKW_SUB(42)  // word reads + read queries
   if (!is_write) {  // :291-348
     u256 result = u256_or(u256_shl(w0v, unal * 8), u256_shr(w1v, (32 - unal) * 8));
     if (is_ptr_read) {
@@ -1067,6 +1095,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
       beyond &= 31u;
       result = u256_shl(u256_shr(result, beyond * 8), beyond * 8);
     }
+    ZKW_SUB(43)  // read: shifts
     if (!set_panic) {
       dst0_update(P, sh, rf, s, ps.dst0, d.dst0, result, false);
       if (increment) {
@@ -1077,12 +1106,14 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
     } else {
       s.flags |= FLAG_PENDING;
     }
+    ZKW_SUB(44)  // read: destination
   } else {  // :349-423
     const u32 lowest = 32 - unal;
     u256 n0 = u256_shl(u256_shr(w0v, lowest * 8), lowest * 8);
     n0 = u256_or(n0, u256_shr(ps.src1, unal * 8));
     u256 n1 = u256_shr(u256_shl(w1v, unal * 8), unal * 8);
     n1 = u256_or(n1, u256_shl(ps.src1, (32 - unal) * 8));
+    ZKW_SUB(45)  // write: shifts
     if (!skip) {
       heap_write_cur(P, sh, s, !is_heap, word0, n0);
       emit_mem(P, sh, s, ts_w, mem_type, fp.page, word0, n0, false, true, 0);
@@ -1091,6 +1122,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
         emit_mem(P, sh, s, ts_w, mem_type, fp.page, word1, n1, false, true, 0);
       }
     }
+    ZKW_SUB(46)  // write: heap writes + write queries
     if (!set_panic) {
       if (increment) {
         u256 upd = ps.src0;
@@ -1100,6 +1132,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
     } else {
       s.flags |= FLAG_PENDING;
     }
+    ZKW_SUB(47)  // write: destination
   }
 }
 
@@ -1262,6 +1295,7 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
     }
     map_to_trivial = false;
   }
+  ZKW_STAMP(57)  // far call: entry image, code-hash storage read
   const u32 candidate_page = map_to_trivial ? 0u : new_base;  // :161-165
   u32 exceptions = 0;
   u32 code_len_words = 0;
@@ -1382,6 +1416,7 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
     } else {
       after_decommit += decommit_cost;  // :450-453 refund
     }
+    ZKW_STAMP(58)  // far call: exceptions, preimage + history lookup
     uint4* a = aux_alloc(P, sh, s, ZKW_AUX_DECOMMIT, fresh ? 1u : 0u, s.timestamp + 1, page, blob_len | (blob << 16));
     if (a) {
       a[1] = u256_lo4(code_hash);
@@ -1411,6 +1446,7 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
       tail_p[0] = tail[0]; tail_p[1] = tail[1]; tail_p[2] = tail[2]; tail_p[3] = tail[3];
       P.dq_count[inst] = j + 1;
     }
+    ZKW_STAMP(59)  // far call: decommit event + chained commitment
     mapped_code_page = page;
     mapped_blob = blob;
   }
@@ -1482,7 +1518,9 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
     fm->heap_hwm = 0;
     fm->aux_hwm = 0;
   }
+  ZKW_STAMP(60)  // far call: next-frame image
   start_frame(P, sh, s, prev, next, true);  // :562
+  ZKW_STAMP(61)  // far call: start_frame
   if (!lane_ok(s)) return;
   // registers :573-610 (applied by the caller)
   out.v1 = fat_ptr_to_u256(abi);
@@ -1562,6 +1600,7 @@ ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, H
     lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
     return;
   }
+  ZKW_STAMP(62)  // ret: validation, finish_frame
   hwm_writeback(P, sh, s);
   s.depth--;
   frame_load(P, sh, s);
@@ -1597,7 +1636,7 @@ ZD u32 zkw_uniform(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); 
 // The precompile bodies (Keccak-f state of 50 VGPRs, SHA-256 schedule, secp256k1) are compiled as ONE out-of-line
 // function that takes and returns the lane state by value (the wave's Shared view is rebuilt from the uniform wave
 // coordinates instead of being passed through ~30 vector argument registers).
-__device__ __noinline__ Lane zkw_precompile_entry(const zkw_kparams ZKW_CONST_AS* Pp, u32 dbg, u32 wib, u32 wave, Lane s, LogQ q, u32 which) {
+static __device__ __noinline__ Lane zkw_precompile_entry(const zkw_kparams ZKW_CONST_AS* Pp, u32 dbg, u32 wib, u32 wave, Lane s, LogQ q, u32 which) {
   ZKW_KP P = *Pp;
   Shared sh;
   shared_setup(sh, P, zkw_uniform(dbg), zkw_uniform(wib), zkw_uniform(wave), false);
@@ -1655,13 +1694,15 @@ ZD void lane_unpack(Lane& s, const zkw_v16& a) {
 // a: lane state (lane_pack) + [12] opcode word low, [13] high, [14] packed ISA attributes | src0_ptr << 30 | src1_ptr << 31
 // b: src0 (8 dwords), src1 (8 dwords)
 // result: lane state + [12] action bits (ZKW_ACT_*), [13] low dword of the second value (far call: r2)
-__device__ __noinline__ zkw_v16 zkw_heavy_entry(zkw_v16 a, zkw_v16 b) {
+template <u32 OPCODE>
+ZD zkw_v16 zkw_heavy_body(zkw_v16 a, zkw_v16 b) {
   const u32 wib = zkw_uniform(threadIdx.x / ZKW_WAVE);
   const uint4 hdr = *(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + wib * zkw_wave_lds_units() + 1);  // written by the kernel prologue
   const zkw_kparams ZKW_CONST_AS* Pp = (const zkw_kparams ZKW_CONST_AS*)(((u64)zkw_uniform(hdr.y) << 32) | zkw_uniform(hdr.x));
   ZKW_KP P = *Pp;
   Shared sh;
   shared_setup(sh, P, zkw_uniform(hdr.z), wib, blockIdx.x * P.waves_per_group + wib, false);
+  ZKW_STAMP(48)  // marshalling, call, prologue, parameter block
   Lane s;
   s.lane = zkw_lane_id();
   lane_unpack(s, a);
@@ -1685,7 +1726,8 @@ __device__ __noinline__ zkw_v16 zkw_heavy_entry(zkw_v16 a, zkw_v16 b) {
   out.v1 = u256_zero();
   out.v2 = u256_zero();
   out.action = 0;
-  const u32 opcode = ZKW_ATTR_OPCODE(d.attr);
+  const u32 opcode = OPCODE;  // one out-of-line function per opcode: each saves only the callee-saved registers IT uses
+  ZKW_STAMP(49)
   if (opcode == ZKW_OP_LOG) {
     op_log(P, sh, s, d, ps, out);
   } else if (opcode == ZKW_OP_NEAR_CALL) {
@@ -1699,6 +1741,7 @@ __device__ __noinline__ zkw_v16 zkw_heavy_entry(zkw_v16 a, zkw_v16 b) {
     op_ret(P, sh, s, d, ps, out);
   }
   s.lane = zkw_lane_id();
+  ZKW_STAMP(50 + (opcode == ZKW_OP_FAR_CALL ? 0 : opcode == ZKW_OP_RET ? 1 : opcode == ZKW_OP_NEAR_CALL ? 2 : 3))  // rest of the body
   if (out.action & (ZKW_ACT_DST0 | ZKW_ACT_FAR | ZKW_ACT_RET)) {
 #pragma unroll
     for (int i = 0; i < 8; i++) sh.xfer[i * ZKW_LDS_STRIDE + s.lane] = out.v1.w[i];
@@ -1707,6 +1750,19 @@ __device__ __noinline__ zkw_v16 zkw_heavy_entry(zkw_v16 a, zkw_v16 b) {
   r[12] = out.action;
   r[13] = out.v2.w[0];
   return r;
+}
+
+// (the call sequence of a function saves every callee-saved register the function touches — scalar ones through a
+// memory round trip each when no vector register is free — so the four bodies do not share one function)
+static __device__ __noinline__ zkw_v16 zkw_heavy_log(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_LOG>(a, b); }
+static __device__ __noinline__ zkw_v16 zkw_heavy_near_call(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_NEAR_CALL>(a, b); }
+static __device__ __noinline__ zkw_v16 zkw_heavy_far_call(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_FAR_CALL>(a, b); }
+static __device__ __noinline__ zkw_v16 zkw_heavy_ret(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_RET>(a, b); }
+ZD zkw_v16 zkw_heavy_entry(u32 opcode, zkw_v16 a, zkw_v16 b) {  // `opcode` is wave-uniform
+  if (opcode == ZKW_OP_LOG) return zkw_heavy_log(a, b);
+  if (opcode == ZKW_OP_NEAR_CALL) return zkw_heavy_near_call(a, b);
+  if (opcode == ZKW_OP_FAR_CALL) return zkw_heavy_far_call(a, b);
+  return zkw_heavy_ret(a, b);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1733,6 +1789,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
   const u32 opcode = ZKW_ATTR_OPCODE(d.attr);
   const u32 props = ZKW_ATTR_PROPS(d.attr);
   const bool set_flags = ZKW_ATTR_FLAGS(d.attr) & 1u;
+  ZKW_SUB_DECL
   s.lane = zkw_lane_id();
   // ----------------------------------------------------------------------------------------
   // operands (cycle.rs:275-350)
@@ -1794,7 +1851,38 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
   // ----------------------------------------------------------------------------------------
   // apply (opcodes/parsing.rs:47-79)
   // ----------------------------------------------------------------------------------------
+  ZKW_SUB(40)  // operands
   if (lane_ok(s)) {
+#ifdef ZKW_HEAVY_INLINE
+    if (__builtin_expect(opcode == ZKW_OP_LOG || opcode == ZKW_OP_NEAR_CALL || opcode == ZKW_OP_FAR_CALL || opcode == ZKW_OP_RET, 0)) {  // experiment: bodies inline, in a region marked cold
+        HeavyOut out;
+        out.v1 = u256_zero();
+        out.v2 = u256_zero();
+        out.action = 0;
+        Pre hp = ps;
+        hp.dst0.has_loc = false;
+        if (opcode == ZKW_OP_LOG) op_log(P, sh, s, d, hp, out);
+        else if (opcode == ZKW_OP_NEAR_CALL) op_near_call(P, sh, s, d, hp);
+        else if (opcode == ZKW_OP_FAR_CALL) op_far_call(P, sh, s, d, hp, rf_get(rf, 15), out);
+        else op_ret(P, sh, s, d, hp, out);
+        s.lane = zkw_lane_id();
+        const u32 action = out.action;
+        const u256 v1 = out.v1;
+        if (action & ZKW_ACT_DST0) dst0_update(P, sh, rf, s, ps.dst0, d.dst0, v1, false);
+        if (action & (ZKW_ACT_FAR | ZKW_ACT_RET)) {
+          reg_write(sh, rf, s, 1, v1, true);
+          reg_write(sh, rf, s, 2, u256_from_u32(out.v2.w[0]), false);
+          if (action & ZKW_ACT_TO_SYSTEM) {
+            s.ptr_bitmap &= ~(0x3ffu << 2);
+          } else {
+#pragma unroll
+            for (u32 r = 3; r <= 12; r++) reg_write(sh, rf, s, r, u256_zero(), false);
+          }
+#pragma unroll
+          for (u32 r = 13; r <= 15; r++) reg_write(sh, rf, s, r, u256_zero(), false);
+        }
+    } else
+#endif
     switch (opcode) {
       case ZKW_OP_NOP: s.pc = ps.new_pc; break;  // noop.rs:16-19
       case ZKW_OP_ADD:
@@ -1863,10 +1951,12 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
       }
       case ZKW_OP_CONTEXT: op_context(P, sh, rf, s, d, ps); break;
       case ZKW_OP_PTR: op_ptr(P, sh, rf, s, d, ps); break;
+#ifndef ZKW_HEAVY_INLINE
       case ZKW_OP_LOG:
       case ZKW_OP_NEAR_CALL:
       case ZKW_OP_FAR_CALL:
       case ZKW_OP_RET: {  // out of line; what they write to registers comes back as actions
+        ZKW_STAMP0
         if (opcode == ZKW_OP_FAR_CALL) {  // CALL_IMPLICIT_PARAMETER_REG_IDX, far_call.rs:506-508
           const u256 r15 = rf_get(rf, 15);
 #pragma unroll
@@ -1879,9 +1969,10 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
           b[i] = ps.src0.w[i];
           b[8 + i] = ps.src1.w[i];
         }
-        const zkw_v16 r = zkw_heavy_entry(a, b);
+        const zkw_v16 r = zkw_heavy_entry(opcode, a, b);
         lane_unpack(s, r);
         s.lane = zkw_lane_id();
+        ZKW_STAMP(55)  // return + epilogue of the callee
         const u32 action = r[12];
         u256 v1 = u256_zero();
         if (action & (ZKW_ACT_DST0 | ZKW_ACT_FAR | ZKW_ACT_RET)) {
@@ -1901,8 +1992,10 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
 #pragma unroll
           for (u32 r = 13; r <= 15; r++) reg_write(sh, rf, s, r, u256_zero(), false);
         }
+        ZKW_STAMP(56)  // actions
         break;
       }
+#endif
       case ZKW_OP_UMA: op_uma(P, sh, rf, s, d, ps); break;
       default: lane_fail(s, ZKW_STATUS_REFERENCE_PANIC); break;  // Opcode::Invalid => unreachable!() parsing.rs:77
     }
@@ -1967,7 +2060,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
     for (u32 i = threadIdx.x; i < ZKW_ISA_TABLE_SIZE / 2; i += blockDim.x) dst[i] = src[i];
   }
 #ifdef ZKW_PROFILE
-  for (u32 i = threadIdx.x; i < ZKW_WAVES_PER_GROUP * 40; i += blockDim.x) (&zp_acc[0][0])[i] = 0;
+  for (u32 i = threadIdx.x; i < ZKW_WAVES_PER_GROUP * 64; i += blockDim.x) (&zp_acc[0][0])[i] = 0;
 #endif
   __syncthreads();
   if (wave >= P.n_waves) return;  // tail workgroup: no further workgroup-level barrier below
@@ -2256,6 +2349,8 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
     printf("ZKWPROF cycles %u: fetch %llu select %llu eoc %llu record %llu\n", k, zp_acc[0][0], zp_acc[0][1], zp_acc[0][2], zp_acc[0][3]);
     for (int o = 0; o < 16; o++)
       if (zp_acc[0][24 + o]) printf("ZKWPROF opcode %d: %llu iterations, %llu clocks each\n", o, zp_acc[0][24 + o], zp_acc[0][8 + o] / zp_acc[0][24 + o]);
+    for (int o = 40; o < 63; o++)
+      if (zp_acc[0][o]) printf("ZKWPROF sub %d: %llu clocks in total\n", o, zp_acc[0][o]);
   }
 #endif
   // wave-cycles executed = the maximum over the lanes (lanes leave the loop at different iterations)

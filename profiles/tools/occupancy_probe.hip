@@ -43,7 +43,7 @@ void run(const char* name, int lds_bytes, int threads) {
   hipMalloc(&sink, 4);
   hipFuncSetAttribute((const void*)probe<REGS, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   const unsigned long long spin = 100000;  // 1 ms at the 100 MHz wall clock
-  for (int wgs : {128, 192, 256, 320, 512, 1024}) {
+  for (int wgs : {256, 320, 512, 640, 768, 1024}) {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     hipLaunchKernelGGL((probe<REGS, BIG>), dim3(wgs), dim3(threads), lds_bytes, 0, spin, ids, sink);
@@ -74,11 +74,12 @@ int main() {
   hipDeviceProp_t p;
   hipGetDeviceProperties(&p, 0);
   printf("%s: %d CUs, LDS/block %zu, regs/block %d, maxThreadsPerMP %d\n", p.name, p.multiProcessorCount, p.sharedMemPerBlock, p.regsPerBlock, p.maxThreadsPerMultiProcessor);
-  run<8, 0>("small-regs", 139328, 256);
-  run<8, 1>("256v", 139328, 256);
-  run<8, 2>("256v+174a", 139328, 256);
-  run<8, 3>("256v+256a", 139328, 256);
+  // round 2: the cycle kernel is 256 threads, 256 unified registers (v0..v127 compiled + v128..v255 register file), 73,856 B
+  // of dynamic LDS: two workgroups per CU = two waves per SIMD -> 512 workgroups (2048 waves) resident
+  run<8, 1>("r02 cycle kernel shape (256v, 73856 B LDS)", 73856, 256);
+  run<8, 1>("256v, 41 KB LDS", 41984, 256);
+  // round 1 shapes, for reference
+  run<8, 2>("r01: 256v+174a, 139328 B LDS", 139328, 256);
   run<8, 3>("256v+256a", 1024, 256);
-  run<8, 3>("256v+256a 64 threads", 1024, 64);
   return 0;
 }
