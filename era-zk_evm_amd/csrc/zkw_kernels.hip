@@ -1758,7 +1758,10 @@ static __device__ __noinline__ zkw_v16 zkw_heavy_log(zkw_v16 a, zkw_v16 b) { ret
 static __device__ __noinline__ zkw_v16 zkw_heavy_near_call(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_NEAR_CALL>(a, b); }
 static __device__ __noinline__ zkw_v16 zkw_heavy_far_call(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_FAR_CALL>(a, b); }
 static __device__ __noinline__ zkw_v16 zkw_heavy_ret(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_RET>(a, b); }
-ZD zkw_v16 zkw_heavy_entry(u32 opcode, zkw_v16 a, zkw_v16 b) {  // `opcode` is wave-uniform
+// One call site in the cycle loop (several would change the register allocation of the whole loop): the dispatcher
+// forwards its own arguments, so each branch is a tail call (a scalar jump; the opcode travels in a[14]).
+static __device__ __noinline__ zkw_v16 zkw_heavy_entry(zkw_v16 a, zkw_v16 b) {
+  const u32 opcode = ZKW_ATTR_OPCODE(zkw_uniform(a[14] & 0x3fffffffu));
   if (opcode == ZKW_OP_LOG) return zkw_heavy_log(a, b);
   if (opcode == ZKW_OP_NEAR_CALL) return zkw_heavy_near_call(a, b);
   if (opcode == ZKW_OP_FAR_CALL) return zkw_heavy_far_call(a, b);
@@ -1969,7 +1972,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
           b[i] = ps.src0.w[i];
           b[8 + i] = ps.src1.w[i];
         }
-        const zkw_v16 r = zkw_heavy_entry(opcode, a, b);
+        const zkw_v16 r = zkw_heavy_entry(a, b);
         lane_unpack(s, r);
         s.lane = zkw_lane_id();
         ZKW_STAMP(55)  // return + epilogue of the callee
