@@ -73,16 +73,58 @@ ZD u64 gl_reduce128_lazy(u64 lo, u64 hi) {
   if (r < t1) r += GL_EPS;
   return r;
 }
-ZD u64 gl_pow7(u64 x) {
+// a * b, reduced lazily (any u64 in, a congruent u64 out) — the S-box is four of these.  Written out in gfx950
+// instructions: v_mad_u64_u32 is a full-rate 32 x 32 + 64 multiply-add WITH a carry out, which the compiler never uses;
+// with it the product and the fold 2^64 = 2^32 - 1, 2^96 = -1 (mod p) take 19 instructions instead of ~30:
+//   a b = p00 + 2^32 (p01 + p10) + 2^64 p11,  M = p01 + p10 = m0 + 2^32 m1 + 2^64 cm
+//       = [p00 + 2^32 m0]  +  (2^32 - 1) (m1 + p11.lo + c1)  -  (p11.hi + c2 + cm)        (c1, c2: the carries of the sums)
+//       =  X               +  EPS q                           -  h
+// T = X + EPS q is one multiply-add (carry c3), U = T - h one subtraction (borrow b); the result is U + (c3 - b) EPS,
+// which neither wraps nor goes negative (|value| bounds in profiles/tools/mulred_check.py, which also checks the sequence
+// against integer arithmetic).  A scalar register written by a vector instruction (vcc or a carry pair) may be read by a
+// vector instruction two issue slots later at the earliest on gfx940+: the s_nops, where no independent instruction
+// fits.  The temporaries are fixed registers (an asm operand cannot name the halves of a 64-bit register pair).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZKW_GL_PORTABLE)
+ZD u64 gl_mulred(u64 a, u64 b) {
+  u32 r0, r1;
+  u64 s0, s1;
+  asm("v_mad_u64_u32 v[112:113], %2, %4, %6, 0\n\t"             // P = a0 b0
+      "v_mad_u64_u32 v[114:115], %2, %4, %7, 0\n\t"             // M = a0 b1
+      "v_mad_u64_u32 v[116:117], %3, %5, %7, 0\n\t"             // Q = a1 b1
+      "v_mad_u64_u32 v[114:115], %2, %5, %6, v[114:115]\n\t"    // M += a1 b0, cm -> %2
+      "v_add_co_u32 v113, vcc, v113, v114\n\t"                  // X.hi = P.hi + m0, c1
+      "s_nop 1\n\t"
+      "v_addc_co_u32 v115, vcc, v115, v116, vcc\n\t"            // q = m1 + Q.lo + c1, c2
+      "v_mad_u64_u32 v[112:113], %3, v115, -1, v[112:113]\n\t"  // T = X + EPS q, c3 -> %3
+      "s_nop 0\n\t"
+      "v_addc_co_u32 v117, vcc, 0, v117, vcc\n\t"               // h = Q.hi + c2
+      "v_cndmask_b32 v118, 0, 1, %3\n\t"                        // e = c3
+      "v_addc_co_u32 v117, %3, 0, v117, %2\n\t"                 // h += cm
+      "v_sub_co_u32 v112, vcc, v112, v117\n\t"                  // U = T - h
+      "s_nop 1\n\t"
+      "v_subbrev_co_u32 v113, vcc, 0, v113, vcc\n\t"            // borrow b
+      "s_nop 1\n\t"
+      "v_subbrev_co_u32 v118, vcc, 0, v118, vcc\n\t"            // e = c3 - b
+      "v_mad_i64_i32 v[112:113], %2, v118, -1, v[112:113]\n\t"  // U - e
+      "v_add_u32 %1, v113, v118\n\t"                            // + e 2^32
+      "v_mov_b32 %0, v112"
+      : "=&v"(r0), "=&v"(r1), "=&s"(s0), "=&s"(s1)
+      : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
+      : "vcc", "v112", "v113", "v114", "v115", "v116", "v117", "v118");
+  return ((u64)r1 << 32) | r0;
+}
+#else
+ZD u64 gl_mulred(u64 a, u64 b) {
   u64 lo, hi;
-  sqr64(x, lo, hi);
-  const u64 x2 = gl_reduce128_lazy(lo, hi);
-  mul64(x2, x, lo, hi);
-  const u64 x3 = gl_reduce128_lazy(lo, hi);
-  sqr64(x2, lo, hi);
-  const u64 x4 = gl_reduce128_lazy(lo, hi);
-  mul64(x4, x3, lo, hi);
+  mul64(a, b, lo, hi);
   return gl_reduce128_lazy(lo, hi);
+}
+#endif
+ZD u64 gl_pow7(u64 x) {
+  const u64 x2 = gl_mulred(x, x);
+  const u64 x3 = gl_mulred(x2, x);
+  const u64 x4 = gl_mulred(x2, x2);
+  return gl_mulred(x4, x3);
 }
 
 // The linear layers are evaluated over the integers in 128-bit accumulators and reduced once per output element:
