@@ -147,6 +147,9 @@ typedef struct zkw_kparams {
   uint4* deltas;               /* [n_waves][2][cap_delta]: 32-B values of the registers a cycle wrote, dense per wave, as two planes (low / high 16 B) */
   uint32_t* wave_cycles;       /* [n_waves] wave-cycles run since the reset */
   uint32_t* heap_dirty;        /* [n_waves][ceil(heap_image_words / 32)][L]: words of the heap image overwritten since the reset */
+  const uint4* regs0;          /* pristine register files / scalars: what a wave starts from in its first launch after a  */
+  const zkw_dev_scalars* scalars0; /* reset (wave_cycles == 0) — the reset does not copy them into the working buffers   */
+  uint32_t* storage_dirty;     /* [n_instances]: bit (slot % 32) set for every storage-table slot written since the reset */
   uint32_t heap_image_words;   /* words of the uploaded heap image (frame slot 0) */
   uint32_t reserved4;
   uint4* mem_stream;           /* [n_waves][3][cap_mem]: planes header | value low | value high of the 48-byte zkw_mem_query */
@@ -182,7 +185,7 @@ typedef struct zkw_fused_table {
   uint32_t wave_threads;
   uint32_t n_blobs;      /* blob-chain stage only */
   uint32_t reserved[3];  /* [0]: leaf stage: the queue (ZKW_QUEUE_* / ZKW_QUEUE_CODE_WORDS) of the blocks in the table;
-                            [1]: reset kernel: 1 = copy the whole heap image (first reset after an upload) */
+                            [1]: reset kernel: 1 = copy the whole heap image (first reset after an upload); [2]: reset kernel: parts left out (ablation) */
 } zkw_fused_table;
 
 /* zkw_reset_kernel: working state := pristine images, one launch */
@@ -205,5 +208,6 @@ typedef struct zkw_reset_params {
   uint64_t* commit_out;      /* [n_instances][ZKW_QUEUE_COUNT][4]: the running decommit-queue tails are zeroed */
   uint32_t* dq_count;        /* [n_instances] */
   uint32_t n_instances;
-  uint32_t reserved0;
+  uint32_t storage_slots;    /* slots per instance of the storage table ([4]: restored per dirty slot after the first reset) */
+  uint32_t* storage_dirty;   /* [n_instances] */
 } zkw_reset_params;

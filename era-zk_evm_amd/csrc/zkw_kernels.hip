@@ -140,7 +140,7 @@ ZD void zkw_lds_write4(uint4* p, const uint4 v) { *p = v; }
 // Phase timing of a VM cycle (profiling build only: -DZKW_PROFILE, profiles/tools/r02_phase.sh): shader clocks between
 // marks, accumulated per workgroup wave in LDS by the first active lane; printed by one workgroup at the end.
 #ifdef ZKW_PROFILE
-__shared__ unsigned long long zp_acc[ZKW_WAVES_PER_GROUP][64];  // 0-3 phases, 8-23 / 24-39 opcode clocks / counts, 40-63 sub-phases
+__shared__ unsigned long long zp_acc[ZKW_WAVES_PER_GROUP][80];  // 0-3 phases, 8-23 / 24-39 opcode clocks / counts, 40-63 sub-phases
 #define ZKW_SUB_DECL unsigned long long zs_last = __builtin_readcyclecounter();
 #define ZKW_SUB(i)                                                                       \
   {                                                                                      \
@@ -506,9 +506,11 @@ ZD void stack_write(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, const u256& v,
     sh.stack_ptrs[w] = 0;
   }
   const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), sh.S, idx);
-  sh.stack_vals[2 * w - s.lane] = u256_lo4(v);
-  sh.stack_vals[2 * w - s.lane + sh.L] = u256_hi4(v);
-  sh.stack_ptrs[w] = is_ptr ? 1 : 0;
+  if (!(sh.debug_flags & 128u)) {  // (128: traffic ablation — the run is then wrong)
+    sh.stack_vals[2 * w - s.lane] = u256_lo4(v);
+    sh.stack_vals[2 * w - s.lane + sh.L] = u256_hi4(v);
+    sh.stack_ptrs[w] = is_ptr ? 1 : 0;
+  }
   if (idx >= CF(sh, s, CF_STACK_HWM)) CF(sh, s, CF_STACK_HWM) = idx + 1;
 }
 
@@ -541,9 +543,11 @@ ZD void heap_write_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx
     base[2 * w - s.lane + sh.L] = make_uint4(0, 0, 0, 0);
   }
   const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), words, idx);
-  base[2 * w - s.lane] = u256_lo4(v);
-  base[2 * w - s.lane + sh.L] = u256_hi4(v);
-  if (!is_aux && CF(sh, s, CF_SLOT) == 0 && idx < P.heap_image_words) {
+  if (!(sh.debug_flags & 64u)) {  // (64: traffic ablation — the run is then wrong)
+    base[2 * w - s.lane] = u256_lo4(v);
+    base[2 * w - s.lane + sh.L] = u256_hi4(v);
+  }
+  if (!is_aux && CF(sh, s, CF_SLOT) == 0 && idx < P.heap_image_words && !(sh.debug_flags & 32u)) {  // (32: traffic ablation)
     // a word of the uploaded heap image is overwritten: remember it, the next reset restores only those words
     u32* d = P.heap_dirty + ((u64)sh.wave * ((P.heap_image_words + 31u) >> 5) + (idx >> 5)) * sh.L + s.lane;
     atomicOr(d, 1u << (idx & 31u));  // result unused: a fire-and-forget atomic instead of a load + store round trip
@@ -682,6 +686,7 @@ ZD u32 storage_find(ZKW_KP P, const Shared& sh, Lane& s, u32 shard, const u32 ad
     const uint4 k0 = e4[0], k1 = e4[1], a0 = e4[4], a1 = e4[5];
     const u32 st = a1.y;
     if (!(st & 0x100u)) {  // free: claim
+      atomicOr(P.storage_dirty + lane_inst(sh, s), 1u << (i & 31u));  // fire-and-forget: the next reset restores only marked slots
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         e->key[k] = key.w[k];
@@ -709,6 +714,7 @@ ZD void access_storage(ZKW_KP P, Shared& sh, Lane& s, LogQ& q) {
   u256 cur;
 #pragma unroll
   for (int k = 0; k < 8; k++) cur.w[k] = e->value[k];
+  atomicOr(P.storage_dirty + lane_inst(sh, s), 1u << (slot & 31u));
   e->shard_state |= 0x200u;  // warm marker
   q.read_value = cur;
   if (q.rw) {
@@ -1078,12 +1084,22 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
   const u32 ts_r = s.timestamp, ts_w = s.timestamp + 3;
   u256 w0v = u256_zero(), w1v = u256_zero();
   ZKW_SUB(41)  // exceptions, growth, cost
+#ifdef ZKW_PROFILE_DRAIN
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ZKW_SUB(70)  // drain of the stores issued before this point
+#endif
   if (!skip) {  // :265-288
     // both word loads are issued before the first query is emitted: the emission needs the loaded value, so reading
     // and emitting word by word would serialise two memory round trips (the dominant cost of this opcode)
     w0v = is_ptr_read ? fat_ptr_read(P, sh, s, fp.page, word0) : heap_read_cur(P, sh, s, !is_heap, word0);
     if (unaligned) w1v = is_ptr_read ? fat_ptr_read(P, sh, s, fp.page, word1) : heap_read_cur(P, sh, s, !is_heap, word1);
+    ZKW_SUB(64)  // loads issued
+#ifdef ZKW_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ZKW_SUB(65)  // loads returned
+#endif
     emit_mem(P, sh, s, ts_r, mem_type, fp.page, word0, w0v, false, false, 0);
+    ZKW_SUB(66)  // first read query
     if (unaligned) emit_mem(P, sh, s, ts_r, mem_type, fp.page, word1, w1v, false, false, 0);
   }
   ZKW_SUB(42)  // word reads + read queries
@@ -1804,17 +1820,20 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
   const u256 src0_reg = reg_read(sh, rf, s, d.src0, src0_reg_ptr);
   ps.src1 = reg_read(sh, rf, s, d.src1, ps.src1_ptr);  // :339
   const u256 dst0_reg = ZKW_ATTR_DST0(d.attr) == ZKW_MODE_REG ? u256_zero() : reg_read(sh, rf, s, d.dst0, dummy_ptr);  // only addressing modes use it
+  ZKW_SUB(67)  // operands: register reads
   Operand src0_loc = compute_address(P, sh, s, sp, src0_reg, d.imm0, ZKW_ATTR_SRC0(d.attr), false);
   ps.dst0 = compute_address(P, sh, s, sp, dst0_reg, d.imm1, ZKW_ATTR_DST0(d.attr), true);
   s.sp = sp;                                            // :297
   if (opcode == ZKW_OP_NOP) src0_loc.has_loc = false;  // :298-301
   u256 src0_mem = u256_zero();
   bool src0_mem_ptr = false;
+  ZKW_SUB(68)  // operands: addresses
   if (src0_loc.has_loc) {  // :304-325
     if (src0_loc.type == ZKW_MEM_CODE) src0_mem = code_read(sh, s, src0_loc.index);
     else src0_mem = stack_read(P, sh, s, src0_loc.index, src0_mem_ptr);
     emit_mem(P, sh, s, s.timestamp, src0_loc.type, src0_loc.page, src0_loc.index, src0_mem, src0_mem_ptr, false, 0);
   }
+  ZKW_SUB(69)  // operands: memory operand + its query
   const u32 src0_mode = ZKW_ATTR_SRC0(d.attr);
   if (src0_mode == ZKW_MODE_REG) {
     ps.src0 = src0_reg;
@@ -2029,7 +2048,7 @@ ZD void lane_writeback(ZKW_KP P, Shared& sh, const RegFile& rf, Lane& s, u32 com
   for (int i = 0; i < 4; i++) sc.ctx_u128_reg[i] = CF(sh, s, CF_CTX0 + i);
   sc.ptr_bitmap = s.ptr_bitmap; sc.flags = s.flags; sc.prev_code_page = (s.kflags & KF_CODE_PAGE_CHANGED) ? CF(sh, s, CF_PREV_CODE_PAGE) : CF(sh, s, CF_CODE_PAGE); sc.timestamp = s.timestamp;
   sc.cycle_counter = CF(sh, s, CF_CYCLE_COUNTER0) + completed; sc.spent_pubdata = CF(sh, s, CF_SPENT_PUBDATA); sc.memory_page_counter = CF(sh, s, CF_MPC);
-  sc.absolute_execution_step = P.scalars[lane_inst(sh, s)].absolute_execution_step; sc.ergs_per_pubdata = CF(sh, s, CF_ERGS_PP); sc.tx_number = CF(sh, s, CF_TX_NUMBER);
+  sc.absolute_execution_step = P.scalars0[lane_inst(sh, s)].absolute_execution_step;  // never changed by a run sc.ergs_per_pubdata = CF(sh, s, CF_ERGS_PP); sc.tx_number = CF(sh, s, CF_TX_NUMBER);
   sc.prev_super_pc = s.prev_super_pc; sc.depth = s.depth; sc.status = s.status; sc.n_cycles = CF(sh, s, CF_N_CYCLES0) + completed; sc.first_dynamic_page = CF(sh, s, CF_FIRST_DYN);
   sc.n_initial_slots = CF(sh, s, CF_N_INITIAL_SLOTS); sc.next_slot = CF(sh, s, CF_NEXT_SLOT); sc.journal_len = CF(sh, s, CF_JOURNAL_LEN); sc.n_history = CF(sh, s, CF_N_HISTORY);
   sc.reserved[0] = 0;
@@ -2063,7 +2082,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
     for (u32 i = threadIdx.x; i < ZKW_ISA_TABLE_SIZE / 2; i += blockDim.x) dst[i] = src[i];
   }
 #ifdef ZKW_PROFILE
-  for (u32 i = threadIdx.x; i < ZKW_WAVES_PER_GROUP * 64; i += blockDim.x) (&zp_acc[0][0])[i] = 0;
+  for (u32 i = threadIdx.x; i < ZKW_WAVES_PER_GROUP * 80; i += blockDim.x) (&zp_acc[0][0])[i] = 0;
 #endif
   __syncthreads();
   if (wave >= P.n_waves) return;  // tail workgroup: no further workgroup-level barrier below
@@ -2081,6 +2100,18 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
   zkw_wave_lds_fence();
 #endif
   const u32 cycle_base = P.wave_cycles[wave];  // wave-cycles run since the reset (records / directory index)
+  // first launch after a reset: the lanes start from the pristine images (the reset does not copy them — 2.5 MB per 4096
+  // instances it would read and write); the write-back at the end of the launch fills the working buffers
+  const bool fresh = cycle_base == 0;
+  const zkw_dev_scalars* const scalars_in = fresh ? P.scalars0 : P.scalars;
+  const uint4* const regs_in = fresh ? P.regs0 : P.regs;
+  if (fresh && tid < P.L && wave * P.L + tid < P.n_instances) {
+    // ... and the marks of what the previous run overwrote (the reset kernel has restored those words and slots; it only
+    // reads the masks, so that it needs no ordering between its threads)
+    const u32 groups = (P.heap_image_words + 31u) >> 5;
+    for (u32 g = 0; g < groups; g++) P.heap_dirty[((u64)wave * groups + g) * P.L + tid] = 0;
+    P.storage_dirty[wave * P.L + tid] = 0;
+  }
 
   const u32 inst = wave * P.L + tid;
   const bool exists = tid < P.L && inst < P.n_instances;
@@ -2090,7 +2121,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
   RegFile rf;
   rf_init(rf);
   if (exists) {
-    const zkw_dev_scalars sc = P.scalars[inst];
+    const zkw_dev_scalars sc = scalars_in[inst];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const uint2 e = sh.isa[sc.prev_code_word[2 * i] & (ZKW_ISA_TABLE_SIZE - 1)];
@@ -2106,7 +2137,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
     CF(sh, s, CF_N_HISTORY) = sc.n_history;
     frame_load(P, sh, s);
     // register file -> v136..v255
-    const uint4* rg = P.regs + (u64)wave * ZKW_REG_CHUNKS * P.L + tid;
+    const uint4* rg = regs_in + (u64)wave * ZKW_REG_CHUNKS * P.L + tid;
     for (u32 r = 0; r < ZKW_REGISTERS_COUNT; r++) rf_set(rf, r + 1, u256_from_uint4(rg[(u64)(2 * r) * P.L], rg[(u64)(2 * r + 1) * P.L]));
   } else {
     s.status = ZKW_STATUS_ENDED;  // parked lane
@@ -2352,8 +2383,8 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
     printf("ZKWPROF cycles %u: fetch %llu select %llu eoc %llu record %llu\n", k, zp_acc[0][0], zp_acc[0][1], zp_acc[0][2], zp_acc[0][3]);
     for (int o = 0; o < 16; o++)
       if (zp_acc[0][24 + o]) printf("ZKWPROF opcode %d: %llu iterations, %llu clocks each\n", o, zp_acc[0][24 + o], zp_acc[0][8 + o] / zp_acc[0][24 + o]);
-    for (int o = 40; o < 63; o++)
-      if (zp_acc[0][o]) printf("ZKWPROF sub %d: %llu clocks in total\n", o, zp_acc[0][o]);
+    for (int o = 40; o < 80; o++)
+      if (zp_acc[0][o] && o != 63) printf("ZKWPROF sub %d: %llu clocks in total\n", o, zp_acc[0][o]);
   }
 #endif
   // wave-cycles executed = the maximum over the lanes (lanes leave the loop at different iterations)
@@ -2389,8 +2420,10 @@ __global__ void zkw_reset_kernel(zkw_fused_table T) {
   const u32 stride = gridDim.x * blockDim.x;
   const u32 t0 = blockIdx.x * blockDim.x + threadIdx.x;
   // four independent 16-byte loads in flight per thread before the stores (a latency-bound copy otherwise)
+  const bool first = T.reserved[1] != 0;  // first reset after an upload: everything is copied
+  const u32 skip = T.reserved[2];         // profiling ablation (ZKW_RESET_SKIP): parts left out
 #pragma unroll 1
-  for (int b = 0; b < 5; b++) {
+  for (int b = (skip & 1u) ? 5 : 0; b < (first ? 5 : 4); b++) {
     const uint4* src = R.src[b];
     uint4* dst = R.dst[b];
     const u32 n = R.n16[b];
@@ -2411,6 +2444,29 @@ __global__ void zkw_reset_kernel(zkw_fused_table T) {
       b = 2;  // skip the flat copy of buffer 2
     }
   }
+  if (first) {
+    for (u32 i = t0; i < R.n_instances; i += stride) R.storage_dirty[i] = 0;
+  } else if (!(skip & 2u)) {
+    // storage table: only the slots the run wrote (claimed, marked warm, written) — one thread per instance mask.  The
+    // masks are read-only here (the first launch after a reset clears them: zkw_cycle_kernel), and the six 16-byte units
+    // of a slot are loaded before any is stored: one dependent memory round trip per dirty slot, not twelve.
+    const u32 e16 = (u32)(sizeof(zkw_dev_storage_entry) / 16);
+    for (u32 i = t0; i < R.n_instances; i += stride) {
+      u32 m = R.storage_dirty[i];
+      while (m) {
+        const u32 bit = (u32)__ffsll((long long)m) - 1u;
+        m &= m - 1u;
+        for (u32 slot = bit; slot < R.storage_slots; slot += 32u) {
+          const u64 at = ((u64)i * R.storage_slots + slot) * e16;
+          uint4 v[sizeof(zkw_dev_storage_entry) / 16];
+#pragma unroll
+          for (u32 k = 0; k < e16; k++) v[k] = R.src[4][at + k];
+#pragma unroll
+          for (u32 k = 0; k < e16; k++) R.dst[4][at + k] = v[k];
+        }
+      }
+    }
+  }
   // heap image: [n_waves][heap_row16] (dense) -> rows of the working arena
   const u32 row = R.heap_row16;
   if (row && T.reserved[1]) {  // first reset after an upload: the whole image, one flat index space
@@ -2427,27 +2483,39 @@ __global__ void zkw_reset_kernel(zkw_fused_table T) {
     for (; i < total; i += stride) R.heap_dst[(u64)(i / row) * R.heap_pitch16 + i % row] = R.heap_src[i];
     const u32 nd = R.n_waves * ((R.image_words + 31u) >> 5) * R.L;
     for (u32 j = t0; j < nd; j += stride) R.heap_dirty[j] = 0;
-  } else if (row) {
-    // later resets: only the words the run overwrote (the cycle kernel sets one bit per overwritten image word).  One
-    // thread owns one 32-word mask of one lane: it restores those words and clears the mask, so no second pass is needed.
+  } else if (row && !(skip & 4u)) {
+    // later resets: only the words the run overwrote (the cycle kernel sets one bit per overwritten image word; the
+    // first launch after a reset clears the masks, here they are read-only).  One thread owns one 32-word mask of one
+    // lane and restores four words per round — eight loads in flight, then eight stores; a mask with fewer words left
+    // repeats its last word (the same bytes are written twice).  One word per round is a chain of dependent ~2 us
+    // round trips: at ~50 overwritten words per cfg-2 instance that chain was most of this kernel's 105 us.
     const u32 groups = (R.image_words + 31u) >> 5;
     const u32 nd = R.n_waves * groups * R.L;
     for (u32 j = t0; j < nd; j += stride) {
       u32 m = R.heap_dirty[j];
       if (!m) continue;
-      R.heap_dirty[j] = 0;
       const u32 lane = j % R.L, g = (j / R.L) % groups, w = j / (R.L * groups);
+      const uint4* src = R.heap_src + (u64)w * row + lane;
+      uint4* dst = R.heap_dst + (u64)w * R.heap_pitch16 + lane;
+      const u32 two_l = 2u * R.L, base = g * 32u;
       while (m) {
-        const u32 word = g * 32u + (u32)__ffsll((long long)m) - 1u;
-        m &= m - 1u;
-        const u32 off = word * 2u * R.L + lane;  // [word][2][lane] inside the wave's row: low halves, then high halves
-        const uint4 a = R.heap_src[(u64)w * row + off], c = R.heap_src[(u64)w * row + off + R.L];
-        R.heap_dst[(u64)w * R.heap_pitch16 + off] = a;
-        R.heap_dst[(u64)w * R.heap_pitch16 + off + R.L] = c;
+        u32 o[4], last = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (m) {
+            last = (base + (u32)__ffsll((long long)m) - 1u) * two_l;  // [word][2][lane] inside the wave's row
+            m &= m - 1u;
+          }
+          o[q] = last;
+        }
+        const uint4 a0 = src[o[0]], c0 = src[o[0] + R.L], a1 = src[o[1]], c1 = src[o[1] + R.L];
+        const uint4 a2 = src[o[2]], c2 = src[o[2] + R.L], a3 = src[o[3]], c3 = src[o[3] + R.L];
+        dst[o[0]] = a0; dst[o[0] + R.L] = c0; dst[o[1]] = a1; dst[o[1] + R.L] = c1;
+        dst[o[2]] = a2; dst[o[2] + R.L] = c2; dst[o[3]] = a3; dst[o[3] + R.L] = c3;
       }
     }
   }
-  if (R.commit_out)
+  if (R.commit_out && !(skip & 8u))
     for (u32 i = t0; i < R.n_instances; i += stride) {
       u64* tl = R.commit_out + ((u64)i * ZKW_QUEUE_COUNT + ZKW_QUEUE_DECOMMIT) * 4;
       tl[0] = tl[1] = tl[2] = tl[3] = 0;
@@ -2459,8 +2527,8 @@ __global__ void zkw_reset_kernel(zkw_fused_table T) {
 
 extern "C" hipError_t zkw_launch_reset_kernel(const zkw_fused_table* T, hipStream_t stream) {
   const u32 threads = T->wave_threads > 1 ? 256 : 1;
-  // ~8 workgroups per CU in total, however many batches share the launch
-  u32 blocks = T->wave_threads > 1 ? (2048 + T->n - 1) / T->n : 1;
+  // ~16 workgroups per CU in total, however many batches share the launch (one dirty mask per thread at 4096 instances)
+  u32 blocks = T->wave_threads > 1 ? (4096 + T->n - 1) / T->n : 1;
   if (blocks < 64 && T->wave_threads > 1) blocks = 64;
   hipLaunchKernelGGL(zkw_reset_kernel, dim3(blocks, T->n), dim3(threads), 0, stream, *T);
   return hipGetLastError();

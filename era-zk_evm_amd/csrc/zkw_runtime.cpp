@@ -134,7 +134,7 @@ struct zkw_batch {
   DevBuf<zkw_dev_preimage> d_preimages;
   // device: outputs
   DevBuf<uint4> d_tails, d_deltas, d_mem, d_log, d_auxs;
-  DevBuf<uint32_t> d_wave_cycles, d_heap_dirty;
+  DevBuf<uint32_t> d_wave_cycles, d_heap_dirty, d_storage_dirty;
   bool full_reset_pending = true;  // the first reset after an upload copies the whole heap image
   DevBuf<uint32_t> d_dir, d_cursors, d_krow;
   DevBuf<uint64_t> d_commit, d_rc, d_blob_digests, d_leaves, d_midstates;
@@ -306,7 +306,7 @@ void zkw_batch_destroy(zkw_batch* b) {
   b->d_regs0.release(); b->d_scalars0.release(); b->d_callstack0.release(); b->d_frames0.release(); b->d_storage0.release(); b->d_heap0.release();
   b->d_regs.release(); b->d_scalars.release(); b->d_callstack.release(); b->d_frames.release(); b->d_storage.release(); b->d_journal.release();
   b->d_history.release(); b->d_stack_vals.release(); b->d_heap.release(); b->d_aux.release(); b->d_stack_ptrs.release(); b->d_blob_words.release();
-  b->d_blob_dir.release(); b->d_preimages.release(); b->d_tails.release(); b->d_deltas.release(); b->d_wave_cycles.release(); b->d_heap_dirty.release(); b->d_mem.release(); b->d_log.release(); b->d_auxs.release();
+  b->d_blob_dir.release(); b->d_preimages.release(); b->d_tails.release(); b->d_deltas.release(); b->d_wave_cycles.release(); b->d_heap_dirty.release(); b->d_storage_dirty.release(); b->d_mem.release(); b->d_log.release(); b->d_auxs.release();
   b->d_dir.release(); b->d_cursors.release(); b->d_krow.release(); b->d_kp.release(); b->d_reset_params.release(); b->d_commit_params.release();
   b->d_ns_log_idx.release(); b->d_ns_log_cnt.release(); b->d_ns_aux_idx.release(); b->d_ns_aux_cnt.release(); b->d_ns_st_hist.release();
   b->d_ns_ev_hist.release(); b->d_ns_rb_st.release(); b->d_ns_rb_ev.release(); b->d_ns_marks.release(); b->d_ns_counts.release();
@@ -710,6 +710,7 @@ int zkw_batch_upload(zkw_batch* b) {
   HIP_TRY(c, ensure(b->d_deltas, (size_t)W * b->cap_delta * 2));
   HIP_TRY(c, ensure(b->d_wave_cycles, (size_t)W));
   HIP_TRY(c, ensure(b->d_heap_dirty, std::max<size_t>(1, (size_t)W * ((b->heap_image_words + 31) / 32) * L)));
+  HIP_TRY(c, ensure(b->d_storage_dirty, std::max<size_t>(1, b->n)));
   b->full_reset_pending = true;
   HIP_TRY(c, ensure(b->d_mem, (size_t)W * b->cap_mem * 3));
   HIP_TRY(c, ensure(b->d_log, (size_t)W * b->cap_log * 8));
@@ -747,14 +748,17 @@ int zkw_batch_upload(zkw_batch* b) {
   P.commit_rc = b->d_rc.p; P.midstates = b->d_midstates.p; P.blob_digests = b->d_blob_digests.p; P.commit_out = b->d_commit.p; P.dq_count = b->d_dq_count.p;
   P.tails = b->d_tails.p; P.deltas = b->d_deltas.p; P.wave_cycles = b->d_wave_cycles.p; P.cap_delta = b->cap_delta; P.heap_dirty = b->d_heap_dirty.p; P.heap_image_words = b->heap_image_words; P.mem_stream = b->d_mem.p; P.log_stream = b->d_log.p; P.aux_stream = b->d_auxs.p;
   P.dir = b->d_dir.p; P.cursors = b->d_cursors.p;
+  P.regs0 = b->d_regs0.p; P.scalars0 = b->d_scalars0.p; P.storage_dirty = b->d_storage_dirty.p;
   P.props = b->props;
   HIP_TRY(c, ensure(b->d_kp, 1));
   HIP_TRY(c, hipMemcpy(b->d_kp.p, &P, sizeof P, hipMemcpyHostToDevice));
   {  // parameter blocks of the reset and commitment kernels (device copies, constant per upload)
     zkw_reset_params R;
     std::memset(&R, 0, sizeof R);
-    R.dst[0] = b->d_regs.p; R.src[0] = b->d_regs0.p; R.n16[0] = (uint32_t)(b->d_regs0.bytes() / 16);
-    R.dst[1] = (uint4*)b->d_scalars.p; R.src[1] = (const uint4*)b->d_scalars0.p; R.n16[1] = (uint32_t)(b->d_scalars0.bytes() / 16);
+    // register files and scalars are not restored: a wave's first launch after a reset reads the pristine images
+    // (zkw_kparams.regs0 / scalars0) and its write-back fills the working buffers, which nothing reads before a run
+    R.dst[0] = b->d_regs.p; R.src[0] = b->d_regs0.p; R.n16[0] = 0;
+    R.dst[1] = (uint4*)b->d_scalars.p; R.src[1] = (const uint4*)b->d_scalars0.p; R.n16[1] = 0;
     R.dst[2] = (uint4*)b->d_callstack.p; R.src[2] = (const uint4*)b->d_callstack0.p; R.cs_pitch16 = (b->lim.max_callstack_depth + 1) * (uint32_t)(sizeof(zkw_dev_entry) / 16);
     R.cs_row16 = std::min(R.cs_pitch16, (b->max_initial_depth + 1) * (uint32_t)(sizeof(zkw_dev_entry) / 16));
     R.n16[2] = b->n * R.cs_row16;
@@ -768,6 +772,7 @@ int zkw_batch_upload(zkw_batch* b) {
     R.wave_cycles = b->d_wave_cycles.p;
     R.heap_dirty = b->d_heap_dirty.p; R.image_words = b->heap_image_words; R.L = b->L;
     R.commit_out = b->d_commit.p; R.dq_count = b->d_dq_count.p; R.n_instances = b->n;
+    R.storage_slots = b->lim.storage_slots; R.storage_dirty = b->d_storage_dirty.p;
     HIP_TRY(c, ensure(b->d_reset_params, 1));
     HIP_TRY(c, hipMemcpy(b->d_reset_params.p, &R, sizeof R, hipMemcpyHostToDevice));
     const uint32_t caps[3] = {b->cap_mem, b->cap_log, b->cap_aux};
@@ -834,6 +839,7 @@ static int enqueue_reset(zkw_batch* const* bs, uint32_t n, hipStream_t st) {
     if (bs[i]->full_reset_pending) T.reserved[1] = 1;  // any freshly uploaded batch in the group: whole heap images for all
     bs[i]->full_reset_pending = false;
   }
+  if (const char* sk = getenv("ZKW_RESET_SKIP")) T.reserved[2] = (uint32_t)atoi(sk);  // profiling ablation only
   HIP_TRY(c, zkw_launch_reset_kernel(&T, st));
   for (uint32_t i = 0; i < n; i++) {
     zkw_batch* b = bs[i];

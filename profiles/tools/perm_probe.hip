@@ -68,7 +68,7 @@ int main(int argc, char** argv) {
   u64 *rc, *out;
   CK(hipMalloc(&rc, 118 * 8)); CK(hipMemcpy(rc, h.data(), 118 * 8, hipMemcpyHostToDevice));
   CK(hipMalloc(&out, (size_t)16384 * 256 * 8));
-  for (int wgs : {1024, 2048, 4096, 8192}) {
+  for (int wgs : {256, 512, 1024, 2048, 4096, 8192}) {  // 256 workgroups of 4 waves = one wave per SIMD: the latency of a lone chain
     const float ms = timed([&] { perm_kernel<<<wgs, 256>>>(rc, out, iters); });
     printf("perm: wgs %d x 256 lanes x %d perms: %.3f ms  %.3f G perms/s\n", wgs, iters, ms, (double)wgs * 256 * iters / ms / 1e6);
   }

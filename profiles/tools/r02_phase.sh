@@ -4,10 +4,10 @@ cd $GRAFT_REPO_ROOT
 T=gpurun_out/$1; mkdir -p $T
 cp era-zk_evm_amd/libzkw.so /tmp/libzkw_keep.so
 python -c "
-import sys; sys.path.insert(0,'.')
+import sys, os; sys.path.insert(0,'.')
 import era_zk_evm_amd
 from era_zk_evm_amd import build as b
-b.build_lib(force=True, extra_flags=['-DZKW_PROFILE'])"
+b.build_lib(force=True, extra_flags=['-DZKW_PROFILE'] + os.environ.get('ZKW_PROFILE_EXTRA', '').split())"
 for F in 20; do echo "fuse $F" >> $T/phase.txt; python bench.py --no-cpu-baseline --steps $((F*2)) --warmup $F --fuse $F --streams 1 2>&1 | grep ZKWPROF | tail -40 >> $T/phase.txt; done
 cp /tmp/libzkw_keep.so era-zk_evm_amd/libzkw.so
 cat $T/phase.txt
