@@ -149,7 +149,7 @@ typedef struct zkw_kparams {
   uint32_t* heap_dirty;        /* [n_waves][ceil(heap_image_words / 32)][L]: words of the heap image overwritten since the reset */
   const uint4* regs0;          /* pristine register files / scalars: what a wave starts from in its first launch after a  */
   const zkw_dev_scalars* scalars0; /* reset (wave_cycles == 0) — the reset does not copy them into the working buffers   */
-  uint32_t* storage_dirty;     /* [n_instances]: bit (slot % 32) set for every storage-table slot written since the reset */
+  uint32_t* storage_dirty;     /* [n_instances][ceil(storage_slots / 32)]: one bit per storage-table slot written since the reset */
   uint32_t heap_image_words;   /* words of the uploaded heap image (frame slot 0) */
   uint32_t reserved4;
   uint4* mem_stream;           /* [n_waves][3][cap_mem]: planes header | value low | value high of the 48-byte zkw_mem_query */
@@ -209,5 +209,5 @@ typedef struct zkw_reset_params {
   uint32_t* dq_count;        /* [n_instances] */
   uint32_t n_instances;
   uint32_t storage_slots;    /* slots per instance of the storage table ([4]: restored per dirty slot after the first reset) */
-  uint32_t* storage_dirty;   /* [n_instances] */
+  uint32_t* storage_dirty;   /* [n_instances][ceil(storage_slots / 32)] */
 } zkw_reset_params;

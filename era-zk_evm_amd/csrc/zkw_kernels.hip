@@ -686,7 +686,7 @@ ZD u32 storage_find(ZKW_KP P, const Shared& sh, Lane& s, u32 shard, const u32 ad
     const uint4 k0 = e4[0], k1 = e4[1], a0 = e4[4], a1 = e4[5];
     const u32 st = a1.y;
     if (!(st & 0x100u)) {  // free: claim
-      atomicOr(P.storage_dirty + lane_inst(sh, s), 1u << (i & 31u));  // fire-and-forget: the next reset restores only marked slots
+      atomicOr(P.storage_dirty + (u64)lane_inst(sh, s) * ((P.storage_slots + 31u) >> 5) + (i >> 5), 1u << (i & 31u));  // fire-and-forget: the next reset restores only marked slots
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         e->key[k] = key.w[k];
@@ -714,7 +714,7 @@ ZD void access_storage(ZKW_KP P, Shared& sh, Lane& s, LogQ& q) {
   u256 cur;
 #pragma unroll
   for (int k = 0; k < 8; k++) cur.w[k] = e->value[k];
-  atomicOr(P.storage_dirty + lane_inst(sh, s), 1u << (slot & 31u));
+  atomicOr(P.storage_dirty + (u64)lane_inst(sh, s) * ((P.storage_slots + 31u) >> 5) + (slot >> 5), 1u << (slot & 31u));
   e->shard_state |= 0x200u;  // warm marker
   q.read_value = cur;
   if (q.rw) {
@@ -1155,8 +1155,15 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
 // log.rs:11-330 (precompile calls: see zkw_precompiles below)
 ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q);
 
+// KIND: 0 = storage read / write, 1 = event / L1 message, 2 = precompile call — one out-of-line function each
+// (zkw_heavy_log*), so that the storage probe and the 40-dword query do not share a register budget and a set of
+// callee-saved registers with the precompile call; the variant checks below then fold away
+template <int KIND>
 ZD void op_log(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, HeavyOut& out) {
   const u32 v = ZKW_ATTR_VARIANT(d.attr);
+  if (KIND == 0 && !(v == ZKW_LOG_STORAGE_READ || v == ZKW_LOG_STORAGE_WRITE)) return;
+  if (KIND == 1 && !(v == ZKW_LOG_EVENT || v == ZKW_LOG_TO_L1)) return;
+  if (KIND == 2 && (v == ZKW_LOG_STORAGE_READ || v == ZKW_LOG_STORAGE_WRITE || v == ZKW_LOG_EVENT || v == ZKW_LOG_TO_L1)) return;
   s.pc = ps.new_pc;
   const bool is_first = ZKW_ATTR_FLAGS(d.attr) & 1u;
   const u32* e = (const u32*)entry_ptr(P, sh, s, s.depth);
@@ -1710,7 +1717,7 @@ ZD void lane_unpack(Lane& s, const zkw_v16& a) {
 // a: lane state (lane_pack) + [12] opcode word low, [13] high, [14] packed ISA attributes | src0_ptr << 30 | src1_ptr << 31
 // b: src0 (8 dwords), src1 (8 dwords)
 // result: lane state + [12] action bits (ZKW_ACT_*), [13] low dword of the second value (far call: r2)
-template <u32 OPCODE>
+template <u32 OPCODE, int KIND>
 ZD zkw_v16 zkw_heavy_body(zkw_v16 a, zkw_v16 b) {
   const u32 wib = zkw_uniform(threadIdx.x / ZKW_WAVE);
   const uint4 hdr = *(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + wib * zkw_wave_lds_units() + 1);  // written by the kernel prologue
@@ -1745,7 +1752,7 @@ ZD zkw_v16 zkw_heavy_body(zkw_v16 a, zkw_v16 b) {
   const u32 opcode = OPCODE;  // one out-of-line function per opcode: each saves only the callee-saved registers IT uses
   ZKW_STAMP(49)
   if (opcode == ZKW_OP_LOG) {
-    op_log(P, sh, s, d, ps, out);
+    op_log<KIND>(P, sh, s, d, ps, out);
   } else if (opcode == ZKW_OP_NEAR_CALL) {
     op_near_call(P, sh, s, d, ps);
   } else if (opcode == ZKW_OP_FAR_CALL) {
@@ -1770,15 +1777,23 @@ ZD zkw_v16 zkw_heavy_body(zkw_v16 a, zkw_v16 b) {
 
 // (the call sequence of a function saves every callee-saved register the function touches — scalar ones through a
 // memory round trip each when no vector register is free — so the four bodies do not share one function)
-static __device__ __noinline__ zkw_v16 zkw_heavy_log(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_LOG>(a, b); }
-static __device__ __noinline__ zkw_v16 zkw_heavy_near_call(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_NEAR_CALL>(a, b); }
-static __device__ __noinline__ zkw_v16 zkw_heavy_far_call(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_FAR_CALL>(a, b); }
-static __device__ __noinline__ zkw_v16 zkw_heavy_ret(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_RET>(a, b); }
+static __device__ __noinline__ zkw_v16 zkw_heavy_log_storage(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_LOG, 0>(a, b); }
+static __device__ __noinline__ zkw_v16 zkw_heavy_log_event(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_LOG, 1>(a, b); }
+static __device__ __noinline__ zkw_v16 zkw_heavy_log_precompile(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_LOG, 2>(a, b); }
+static __device__ __noinline__ zkw_v16 zkw_heavy_near_call(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_NEAR_CALL, 0>(a, b); }
+static __device__ __noinline__ zkw_v16 zkw_heavy_far_call(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_FAR_CALL, 0>(a, b); }
+static __device__ __noinline__ zkw_v16 zkw_heavy_ret(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_RET, 0>(a, b); }
 // One call site in the cycle loop (several would change the register allocation of the whole loop): the dispatcher
 // forwards its own arguments, so each branch is a tail call (a scalar jump; the opcode travels in a[14]).
 static __device__ __noinline__ zkw_v16 zkw_heavy_entry(zkw_v16 a, zkw_v16 b) {
-  const u32 opcode = ZKW_ATTR_OPCODE(zkw_uniform(a[14] & 0x3fffffffu));
-  if (opcode == ZKW_OP_LOG) return zkw_heavy_log(a, b);
+  const u32 attr = zkw_uniform(a[14] & 0x3fffffffu);
+  const u32 opcode = ZKW_ATTR_OPCODE(attr);
+  if (opcode == ZKW_OP_LOG) {
+    const u32 v = ZKW_ATTR_VARIANT(attr);
+    if (v == ZKW_LOG_STORAGE_READ || v == ZKW_LOG_STORAGE_WRITE) return zkw_heavy_log_storage(a, b);
+    if (v == ZKW_LOG_EVENT || v == ZKW_LOG_TO_L1) return zkw_heavy_log_event(a, b);
+    return zkw_heavy_log_precompile(a, b);
+  }
   if (opcode == ZKW_OP_NEAR_CALL) return zkw_heavy_near_call(a, b);
   if (opcode == ZKW_OP_FAR_CALL) return zkw_heavy_far_call(a, b);
   return zkw_heavy_ret(a, b);
@@ -1875,36 +1890,6 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
   // ----------------------------------------------------------------------------------------
   ZKW_SUB(40)  // operands
   if (lane_ok(s)) {
-#ifdef ZKW_HEAVY_INLINE
-    if (__builtin_expect(opcode == ZKW_OP_LOG || opcode == ZKW_OP_NEAR_CALL || opcode == ZKW_OP_FAR_CALL || opcode == ZKW_OP_RET, 0)) {  // experiment: bodies inline, in a region marked cold
-        HeavyOut out;
-        out.v1 = u256_zero();
-        out.v2 = u256_zero();
-        out.action = 0;
-        Pre hp = ps;
-        hp.dst0.has_loc = false;
-        if (opcode == ZKW_OP_LOG) op_log(P, sh, s, d, hp, out);
-        else if (opcode == ZKW_OP_NEAR_CALL) op_near_call(P, sh, s, d, hp);
-        else if (opcode == ZKW_OP_FAR_CALL) op_far_call(P, sh, s, d, hp, rf_get(rf, 15), out);
-        else op_ret(P, sh, s, d, hp, out);
-        s.lane = zkw_lane_id();
-        const u32 action = out.action;
-        const u256 v1 = out.v1;
-        if (action & ZKW_ACT_DST0) dst0_update(P, sh, rf, s, ps.dst0, d.dst0, v1, false);
-        if (action & (ZKW_ACT_FAR | ZKW_ACT_RET)) {
-          reg_write(sh, rf, s, 1, v1, true);
-          reg_write(sh, rf, s, 2, u256_from_u32(out.v2.w[0]), false);
-          if (action & ZKW_ACT_TO_SYSTEM) {
-            s.ptr_bitmap &= ~(0x3ffu << 2);
-          } else {
-#pragma unroll
-            for (u32 r = 3; r <= 12; r++) reg_write(sh, rf, s, r, u256_zero(), false);
-          }
-#pragma unroll
-          for (u32 r = 13; r <= 15; r++) reg_write(sh, rf, s, r, u256_zero(), false);
-        }
-    } else
-#endif
     switch (opcode) {
       case ZKW_OP_NOP: s.pc = ps.new_pc; break;  // noop.rs:16-19
       case ZKW_OP_ADD:
@@ -1973,7 +1958,6 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
       }
       case ZKW_OP_CONTEXT: op_context(P, sh, rf, s, d, ps); break;
       case ZKW_OP_PTR: op_ptr(P, sh, rf, s, d, ps); break;
-#ifndef ZKW_HEAVY_INLINE
       case ZKW_OP_LOG:
       case ZKW_OP_NEAR_CALL:
       case ZKW_OP_FAR_CALL:
@@ -2017,7 +2001,6 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
         ZKW_STAMP(56)  // actions
         break;
       }
-#endif
       case ZKW_OP_UMA: op_uma(P, sh, rf, s, d, ps); break;
       default: lane_fail(s, ZKW_STATUS_REFERENCE_PANIC); break;  // Opcode::Invalid => unreachable!() parsing.rs:77
     }
@@ -2048,7 +2031,7 @@ ZD void lane_writeback(ZKW_KP P, Shared& sh, const RegFile& rf, Lane& s, u32 com
   for (int i = 0; i < 4; i++) sc.ctx_u128_reg[i] = CF(sh, s, CF_CTX0 + i);
   sc.ptr_bitmap = s.ptr_bitmap; sc.flags = s.flags; sc.prev_code_page = (s.kflags & KF_CODE_PAGE_CHANGED) ? CF(sh, s, CF_PREV_CODE_PAGE) : CF(sh, s, CF_CODE_PAGE); sc.timestamp = s.timestamp;
   sc.cycle_counter = CF(sh, s, CF_CYCLE_COUNTER0) + completed; sc.spent_pubdata = CF(sh, s, CF_SPENT_PUBDATA); sc.memory_page_counter = CF(sh, s, CF_MPC);
-  sc.absolute_execution_step = P.scalars0[lane_inst(sh, s)].absolute_execution_step;  // never changed by a run sc.ergs_per_pubdata = CF(sh, s, CF_ERGS_PP); sc.tx_number = CF(sh, s, CF_TX_NUMBER);
+  sc.absolute_execution_step = P.scalars0[lane_inst(sh, s)].absolute_execution_step /* never changed by a run */; sc.ergs_per_pubdata = CF(sh, s, CF_ERGS_PP); sc.tx_number = CF(sh, s, CF_TX_NUMBER);
   sc.prev_super_pc = s.prev_super_pc; sc.depth = s.depth; sc.status = s.status; sc.n_cycles = CF(sh, s, CF_N_CYCLES0) + completed; sc.first_dynamic_page = CF(sh, s, CF_FIRST_DYN);
   sc.n_initial_slots = CF(sh, s, CF_N_INITIAL_SLOTS); sc.next_slot = CF(sh, s, CF_NEXT_SLOT); sc.journal_len = CF(sh, s, CF_JOURNAL_LEN); sc.n_history = CF(sh, s, CF_N_HISTORY);
   sc.reserved[0] = 0;
@@ -2110,7 +2093,8 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
     // reads the masks, so that it needs no ordering between its threads)
     const u32 groups = (P.heap_image_words + 31u) >> 5;
     for (u32 g = 0; g < groups; g++) P.heap_dirty[((u64)wave * groups + g) * P.L + tid] = 0;
-    P.storage_dirty[wave * P.L + tid] = 0;
+    const u32 sw = (P.storage_slots + 31u) >> 5;
+    for (u32 g = 0; g < sw; g++) P.storage_dirty[(u64)(wave * P.L + tid) * sw + g] = 0;
   }
 
   const u32 inst = wave * P.L + tid;
@@ -2445,25 +2429,25 @@ __global__ void zkw_reset_kernel(zkw_fused_table T) {
     }
   }
   if (first) {
-    for (u32 i = t0; i < R.n_instances; i += stride) R.storage_dirty[i] = 0;
+    for (u32 i = t0; i < R.n_instances * ((R.storage_slots + 31u) >> 5); i += stride) R.storage_dirty[i] = 0;
   } else if (!(skip & 2u)) {
-    // storage table: only the slots the run wrote (claimed, marked warm, written) — one thread per instance mask.  The
+    // storage table: only the slots the run wrote (claimed, marked warm, written) — one thread per 32-slot mask.  The
     // masks are read-only here (the first launch after a reset clears them: zkw_cycle_kernel), and the six 16-byte units
     // of a slot are loaded before any is stored: one dependent memory round trip per dirty slot, not twelve.
     const u32 e16 = (u32)(sizeof(zkw_dev_storage_entry) / 16);
-    for (u32 i = t0; i < R.n_instances; i += stride) {
+    const u32 sw = (R.storage_slots + 31u) >> 5;  // mask words per instance: one bit per slot
+    for (u32 i = t0; i < R.n_instances * sw; i += stride) {
       u32 m = R.storage_dirty[i];
+      const u64 first_slot = (u64)(i / sw) * R.storage_slots + (i % sw) * 32u;
       while (m) {
         const u32 bit = (u32)__ffsll((long long)m) - 1u;
         m &= m - 1u;
-        for (u32 slot = bit; slot < R.storage_slots; slot += 32u) {
-          const u64 at = ((u64)i * R.storage_slots + slot) * e16;
-          uint4 v[sizeof(zkw_dev_storage_entry) / 16];
+        const u64 at = (first_slot + bit) * e16;
+        uint4 v[sizeof(zkw_dev_storage_entry) / 16];
 #pragma unroll
-          for (u32 k = 0; k < e16; k++) v[k] = R.src[4][at + k];
+        for (u32 k = 0; k < e16; k++) v[k] = R.src[4][at + k];
 #pragma unroll
-          for (u32 k = 0; k < e16; k++) R.dst[4][at + k] = v[k];
-        }
+        for (u32 k = 0; k < e16; k++) R.dst[4][at + k] = v[k];
       }
     }
   }

@@ -710,7 +710,7 @@ int zkw_batch_upload(zkw_batch* b) {
   HIP_TRY(c, ensure(b->d_deltas, (size_t)W * b->cap_delta * 2));
   HIP_TRY(c, ensure(b->d_wave_cycles, (size_t)W));
   HIP_TRY(c, ensure(b->d_heap_dirty, std::max<size_t>(1, (size_t)W * ((b->heap_image_words + 31) / 32) * L)));
-  HIP_TRY(c, ensure(b->d_storage_dirty, std::max<size_t>(1, b->n)));
+  HIP_TRY(c, ensure(b->d_storage_dirty, std::max<size_t>(1, (size_t)b->n * ((b->lim.storage_slots + 31) / 32))));
   b->full_reset_pending = true;
   HIP_TRY(c, ensure(b->d_mem, (size_t)W * b->cap_mem * 3));
   HIP_TRY(c, ensure(b->d_log, (size_t)W * b->cap_log * 8));
