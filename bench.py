@@ -313,7 +313,7 @@ def measured_traffic(args, batches_per_launch):
     (FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM): measured per
     launch with `fused_batches` batches in it, scaled to this run's batches per launch.  Only valid for the
     default workload the profile was taken on; null otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
     if args.cfg != 2 or args.instances != 4096 or args.cycles != 256 or not os.path.exists(path):
         return None
     j = json.load(open(path))

@@ -19,3 +19,17 @@ for lanes in (0, 64, 16, 4, 1):  # 0 = the library's choice (thin waves: the ins
     st = b.stats()
     print("lanes %2d: %8d cycles in %.3f ms kernel time = %.1f M cycles/s" % (lanes, int(st["cycles"]), float(st["kernel_ms"]), int(st["cycles"]) / float(st["kernel_ms"]) / 1e3))
     b.destroy()
+# the same 4096 divergent instances per batch, several batches per fused launch (zkw_batches_run): full waves and the
+# library's thin waves.  One batch is 64 full waves on 1024 SIMDs; a prover that owns many blocks fills the chip with them.
+for lanes, nb in ((64, 8), (64, 16), (64, 32), (0, 4), (0, 8)):
+    wl.limits["lanes_per_wave"] = lanes
+    bs = [be.create_batch(wl) for _ in range(nb)]
+    for rep in range(3):
+        be.reset_many(bs); be.run_many(bs, wl.n_cycles); bs[0].sync()
+    for b in bs[1:]:
+        b.sync()
+    cyc = sum(int(b.stats()["cycles"]) for b in bs)
+    ms = float(bs[0].stats()["kernel_ms"])
+    print("lanes %2d, %2d batches per launch: %9d cycles in %.3f ms kernel time = %.1f M cycles/s" % (lanes, nb, cyc, ms, cyc / ms / 1e3))
+    for b in bs:
+        b.destroy()
