@@ -2401,36 +2401,59 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
 // image) and stream cursors := 0 — one launch instead of seven copies per reset
 __global__ void zkw_reset_kernel(zkw_fused_table T) {
   const zkw_reset_params ZKW_CONST_AS& R = *(const zkw_reset_params ZKW_CONST_AS*)T.p[blockIdx.y];
-  const u32 stride = gridDim.x * blockDim.x;
-  const u32 t0 = blockIdx.x * blockDim.x + threadIdx.x;
-  // four independent 16-byte loads in flight per thread before the stores (a latency-bound copy otherwise)
   const bool first = T.reserved[1] != 0;  // first reset after an upload: everything is copied
   const u32 skip = T.reserved[2];         // profiling ablation (ZKW_RESET_SKIP): parts left out
+  // Every part below is a short chain of dependent memory round trips per thread (mask -> words -> stores), each several
+  // microseconds on cold pages, so the parts run side by side in disjoint ranges of the grid instead of one after the
+  // other in every thread: 1/8 of the workgroups copy the flat images and clear the small state, 1/8 restore storage
+  // slots, 3/4 restore heap words (one dirty mask per thread at 4096 instances).  (A grid of fewer than 8 workgroups —
+  // the emulation build launches one thread — does everything in every thread.)
+  const u32 nb = gridDim.x, e8 = nb / 8;
+  u32 part = 3, pb = blockIdx.x, pn = nb;
+  if (nb >= 8) {
+    if (blockIdx.x < e8) { part = 0; pn = e8; }
+    else if (blockIdx.x < 2 * e8) { part = 1; pb = blockIdx.x - e8; pn = e8; }
+    else { part = 2; pb = blockIdx.x - 2 * e8; pn = nb - 2 * e8; }
+  }
+  const u32 stride = pn * blockDim.x;
+  const u32 t0 = pb * blockDim.x + threadIdx.x;
+  const bool copies = part == 3 || part == 0, storage = part == 3 || part == 1, heap = part == 3 || part == 2;
+  // four independent 16-byte loads in flight per thread before the stores (a latency-bound copy otherwise)
+  if (copies) {
 #pragma unroll 1
-  for (int b = (skip & 1u) ? 5 : 0; b < (first ? 5 : 4); b++) {
-    const uint4* src = R.src[b];
-    uint4* dst = R.dst[b];
-    const u32 n = R.n16[b];
-    u32 i = t0;
-    for (; i + 3 * stride < n; i += 4 * stride) {
-      const uint4 a = src[i], c = src[i + stride], d = src[i + 2 * stride], e = src[i + 3 * stride];
-      dst[i] = a; dst[i + stride] = c; dst[i + 2 * stride] = d; dst[i + 3 * stride] = e;
-    }
-    for (; i < n; i += stride) dst[i] = src[i];
-    if (b == 1) {  // callstack next: only the entries a run can read before writing them (0 .. initial depth) are restored
-      const u32 rows = R.n16[2], r16 = R.cs_row16, p16 = R.cs_pitch16;
-      const uint4* cs = R.src[2];
-      uint4* cd = R.dst[2];
-      for (u32 j = t0; j < rows; j += stride) {
-        const u32 at = (j / r16) * p16 + j % r16;
-        cd[at] = cs[at];
+    for (int b = (skip & 1u) ? 5 : 0; b < (first ? 5 : 4); b++) {
+      const uint4* src = R.src[b];
+      uint4* dst = R.dst[b];
+      const u32 n = R.n16[b];
+      u32 i = t0;
+      for (; i + 3 * stride < n; i += 4 * stride) {
+        const uint4 a = src[i], c = src[i + stride], d = src[i + 2 * stride], e = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = c; dst[i + 2 * stride] = d; dst[i + 3 * stride] = e;
       }
-      b = 2;  // skip the flat copy of buffer 2
+      for (; i < n; i += stride) dst[i] = src[i];
+      if (b == 1) {  // callstack next: only the entries a run can read before writing them (0 .. initial depth) are restored
+        const u32 rows = R.n16[2], r16 = R.cs_row16, p16 = R.cs_pitch16;
+        const uint4* cs = R.src[2];
+        uint4* cd = R.dst[2];
+        u32 j = t0;
+        for (; j + 3 * stride < rows; j += 4 * stride) {
+          const u32 j1 = j + stride, j2 = j + 2 * stride, j3 = j + 3 * stride;
+          const u32 a0 = (j / r16) * p16 + j % r16, a1 = (j1 / r16) * p16 + j1 % r16, a2 = (j2 / r16) * p16 + j2 % r16, a3 = (j3 / r16) * p16 + j3 % r16;
+          const uint4 v0 = cs[a0], v1 = cs[a1], v2 = cs[a2], v3 = cs[a3];
+          cd[a0] = v0; cd[a1] = v1; cd[a2] = v2; cd[a3] = v3;
+        }
+        for (; j < rows; j += stride) {
+          const u32 at = (j / r16) * p16 + j % r16;
+          cd[at] = cs[at];
+        }
+        b = 2;  // skip the flat copy of buffer 2
+      }
     }
   }
   if (first) {
-    for (u32 i = t0; i < R.n_instances * ((R.storage_slots + 31u) >> 5); i += stride) R.storage_dirty[i] = 0;
-  } else if (!(skip & 2u)) {
+    if (storage)
+      for (u32 i = t0; i < R.n_instances * ((R.storage_slots + 31u) >> 5); i += stride) R.storage_dirty[i] = 0;
+  } else if (storage && !(skip & 2u)) {
     // storage table: only the slots the run wrote (claimed, marked warm, written) — one thread per 32-slot mask.  The
     // masks are read-only here (the first launch after a reset clears them: zkw_cycle_kernel), and the six 16-byte units
     // of a slot are loaded before any is stored: one dependent memory round trip per dirty slot, not twelve.
@@ -2453,26 +2476,28 @@ __global__ void zkw_reset_kernel(zkw_fused_table T) {
   }
   // heap image: [n_waves][heap_row16] (dense) -> rows of the working arena
   const u32 row = R.heap_row16;
-  if (row && T.reserved[1]) {  // first reset after an upload: the whole image, one flat index space
-    const u32 total = R.n_waves * row;
-    u32 i = t0;
-    for (; i + 3 * stride < total; i += 4 * stride) {
-      const u32 i1 = i + stride, i2 = i + 2 * stride, i3 = i + 3 * stride;
-      const uint4 a = R.heap_src[i], c = R.heap_src[i1], d = R.heap_src[i2], e = R.heap_src[i3];
-      R.heap_dst[(u64)(i / row) * R.heap_pitch16 + i % row] = a;
-      R.heap_dst[(u64)(i1 / row) * R.heap_pitch16 + i1 % row] = c;
-      R.heap_dst[(u64)(i2 / row) * R.heap_pitch16 + i2 % row] = d;
-      R.heap_dst[(u64)(i3 / row) * R.heap_pitch16 + i3 % row] = e;
+  if (row && first) {  // first reset after an upload: the whole image, one flat index space
+    if (heap) {
+      const u32 total = R.n_waves * row;
+      u32 i = t0;
+      for (; i + 3 * stride < total; i += 4 * stride) {
+        const u32 i1 = i + stride, i2 = i + 2 * stride, i3 = i + 3 * stride;
+        const uint4 a = R.heap_src[i], c = R.heap_src[i1], d = R.heap_src[i2], e = R.heap_src[i3];
+        R.heap_dst[(u64)(i / row) * R.heap_pitch16 + i % row] = a;
+        R.heap_dst[(u64)(i1 / row) * R.heap_pitch16 + i1 % row] = c;
+        R.heap_dst[(u64)(i2 / row) * R.heap_pitch16 + i2 % row] = d;
+        R.heap_dst[(u64)(i3 / row) * R.heap_pitch16 + i3 % row] = e;
+      }
+      for (; i < total; i += stride) R.heap_dst[(u64)(i / row) * R.heap_pitch16 + i % row] = R.heap_src[i];
+      const u32 nd = R.n_waves * ((R.image_words + 31u) >> 5) * R.L;
+      for (u32 j = t0; j < nd; j += stride) R.heap_dirty[j] = 0;
     }
-    for (; i < total; i += stride) R.heap_dst[(u64)(i / row) * R.heap_pitch16 + i % row] = R.heap_src[i];
-    const u32 nd = R.n_waves * ((R.image_words + 31u) >> 5) * R.L;
-    for (u32 j = t0; j < nd; j += stride) R.heap_dirty[j] = 0;
-  } else if (row && !(skip & 4u)) {
+  } else if (row && heap && !(skip & 4u)) {
     // later resets: only the words the run overwrote (the cycle kernel sets one bit per overwritten image word; the
     // first launch after a reset clears the masks, here they are read-only).  One thread owns one 32-word mask of one
     // lane and restores four words per round — eight loads in flight, then eight stores; a mask with fewer words left
-    // repeats its last word (the same bytes are written twice).  One word per round is a chain of dependent ~2 us
-    // round trips: at ~50 overwritten words per cfg-2 instance that chain was most of this kernel's 105 us.
+    // repeats its last word (the same bytes are written twice).  One word per round is a chain of dependent memory
+    // round trips: at ~50 overwritten words per cfg-2 instance that chain was most of the 105 us this kernel took.
     const u32 groups = (R.image_words + 31u) >> 5;
     const u32 nd = R.n_waves * groups * R.L;
     for (u32 j = t0; j < nd; j += stride) {
@@ -2499,20 +2524,23 @@ __global__ void zkw_reset_kernel(zkw_fused_table T) {
       }
     }
   }
-  if (R.commit_out && !(skip & 8u))
-    for (u32 i = t0; i < R.n_instances; i += stride) {
-      u64* tl = R.commit_out + ((u64)i * ZKW_QUEUE_COUNT + ZKW_QUEUE_DECOMMIT) * 4;
-      tl[0] = tl[1] = tl[2] = tl[3] = 0;
-      R.dq_count[i] = 0;
-    }
-  for (u32 i = t0; i < R.n_waves * 4; i += stride) R.cursors[i] = 0;
-  for (u32 i = t0; i < R.n_waves; i += stride) R.wave_cycles[i] = 0;
+  if (copies) {
+    if (R.commit_out && !(skip & 8u))
+      for (u32 i = t0; i < R.n_instances; i += stride) {
+        u64* tl = R.commit_out + ((u64)i * ZKW_QUEUE_COUNT + ZKW_QUEUE_DECOMMIT) * 4;
+        tl[0] = tl[1] = tl[2] = tl[3] = 0;
+        R.dq_count[i] = 0;
+      }
+    for (u32 i = t0; i < R.n_waves * 4; i += stride) R.cursors[i] = 0;
+    for (u32 i = t0; i < R.n_waves; i += stride) R.wave_cycles[i] = 0;
+  }
 }
 
 extern "C" hipError_t zkw_launch_reset_kernel(const zkw_fused_table* T, hipStream_t stream) {
   const u32 threads = T->wave_threads > 1 ? 256 : 1;
-  // ~16 workgroups per CU in total, however many batches share the launch (one dirty mask per thread at 4096 instances)
-  u32 blocks = T->wave_threads > 1 ? (4096 + T->n - 1) / T->n : 1;
+  // ~20 workgroups per CU in total, however many batches share the launch (3/4 of them restore heap words: one dirty
+  // mask per thread at 4096 instances and 20 batches)
+  u32 blocks = T->wave_threads > 1 ? (5120 + T->n - 1) / T->n : 1;
   if (blocks < 64 && T->wave_threads > 1) blocks = 64;
   hipLaunchKernelGGL(zkw_reset_kernel, dim3(blocks, T->n), dim3(threads), 0, stream, *T);
   return hipGetLastError();

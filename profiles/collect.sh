@@ -32,6 +32,12 @@ python bench.py --cfg 4 --instances 4096 --cycles 1024 --steps 64 --warmup 16 --
 python bench.py --cfg 4 --instances 4096 --cycles 1024 --steps 32 --warmup 16 --fuse 16 --commit-mask 7 --no-cpu-baseline 2>/dev/null | grep '^{' >> $OUT/other_cfgs.jsonl
 python bench.py --cfg 2 --steps 64 --warmup 32 --fuse 32 --commit-mask 7 --no-cpu-baseline 2>/dev/null | grep '^{' >> $OUT/other_cfgs.jsonl
 python bench.py --cfg 3 --instances 512 --cycles 64 --steps 64 --warmup 16 --fuse 16 --commit-mask 0 --no-cpu-baseline 2>/dev/null | grep '^{' >> $OUT/other_cfgs.jsonl
+# the files the judge (and tests/test_bench_contract.py) read: copied under profiles/ with the tag
+cp $OUT/bench.json profiles/${TAG}_bench.json; cp $OUT/bench_driver.json profiles/${TAG}_driver_bench.json
+cp $OUT/trace/${TAG}_kernel_stats.csv profiles/${TAG}_kernel_stats.csv; cp $OUT/trace_driver/${TAG}_kernel_stats.csv profiles/${TAG}_driver_kernel_stats.csv
+for f in instance_sweep fuse_sweep long_traces other_cfgs; do cp $OUT/$f.jsonl profiles/${TAG}_$f.jsonl; done
+cp $OUT/occupancy_probe.txt profiles/${TAG}_occupancy_probe.txt
+mkdir -p gpurun_out/profiles_$TAG; cp profiles/${TAG}_* gpurun_out/profiles_$TAG/   # profiles/ itself does not travel back: gpurun_out/ does
 python - "$OUT" "$TAG" <<'PY'
 import csv, glob, sys, json, collections, os
 out, tag = sys.argv[1], sys.argv[2]
@@ -56,5 +62,6 @@ if "WRITE_SIZE" in pm and "FETCH_SIZE" in pm:
     f = 2.0 * sum(pm["FETCH_SIZE"]) / len(pm["FETCH_SIZE"]) * 1024.0  # FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md, HBM)
     res["traffic"] = {"fused_batches": 20, "write_bytes": w, "fetch_bytes_corrected_x2": f, "hbm_bytes_per_launch": w + f, "hbm_bytes_per_vm_cycle": (w + f) / (20 * 4096 * 256.0)}
 json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
+json.dump(res, open(os.path.join("gpurun_out", "profiles_" + tag, tag + "_summary.json"), "w"), indent=1)
 print(json.dumps(res, indent=1)[:3500])
 PY

@@ -47,16 +47,30 @@ def test_bench_accepts_the_driver_flags():
 
 
 def test_traffic_file_matches_the_profile_summary():
-    t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+    t = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
     assert abs(t["hbm_bytes_per_launch"] - (t["fetch_bytes_corrected_x2"] + t["write_bytes"])) < 1
     assert abs(t["fetch_bytes_corrected_x2"] - 2 * 1024 * t["FETCH_SIZE_KB"]) < 1
 
 
 def test_rocprof_kernel_duration_agrees_with_the_bench_line():
-    """The committed rocprofv3 --kernel-trace --stats summary of the default command and the HIP-event duration the
-    bench line carries describe the same launches of zkw_cycle_kernel: they must agree (within 5 %)."""
+    """The committed rocprofv3 --kernel-trace --stats summary of a command and the HIP-event duration its bench line
+    carries describe the same launches of zkw_cycle_kernel: they must agree (within 5 %).  Checked on the newest line
+    (the driver's command: profiles/rNN_driver_bench.json) — test_every_round2_bench_line_has_its_rocprof_summary covers
+    the default command's pair."""
     import csv
     j, path = latest_bench_line()
+    _check_pair(j, path)
+
+
+def test_every_round2_bench_line_has_its_rocprof_summary():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_bench.json")))
+    assert len(files) >= 2, files  # the driver's command and the default command
+    for f in files:
+        _check_pair(json.load(open(f)), f)
+
+
+def _check_pair(j, path):
+    import csv
     stats = path.replace("_bench.json", "_kernel_stats.csv")
     assert os.path.exists(stats), stats
     rows = [r for r in csv.DictReader(open(stats)) if r["Name"].startswith("zkw_cycle_kernel")]
