@@ -267,6 +267,30 @@ ZD void zkw_stream_store(uint4* p, const uint4 v) {
 ZD void zkw_stream_store(uint4* p, const uint4 v) { *p = v; }
 #endif
 
+// Loads / stores of the working arenas (stack, heap, aux heap, code blobs) with the address space spelled out.  Their
+// base pointers pass through ZKW_PIN_SGPR (an opaque asm), after which the compiler no longer knows that they point to
+// global memory and emits FLAT instructions — which count on BOTH vmcnt and lgkmcnt, so every LDS wait behind one of
+// them (the cold lane state lives in LDS) also waits for it to leave the vector-memory queue.
+#ifdef __HIP_DEVICE_COMPILE__
+#define ZKW_GLOBAL_AS __attribute__((address_space(1)))
+ZD uint4 zkw_gload4(const uint4* p) {
+  const zkw_v4u v = *(const ZKW_GLOBAL_AS zkw_v4u*)p;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+ZD void zkw_gstore4(uint4* p, const uint4 v) {
+  zkw_v4u t;
+  t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  *(ZKW_GLOBAL_AS zkw_v4u*)p = t;
+}
+ZD uint8_t zkw_gload1(const uint8_t* p) { return *(const ZKW_GLOBAL_AS uint8_t*)p; }
+ZD void zkw_gstore1(uint8_t* p, uint8_t v) { *(ZKW_GLOBAL_AS uint8_t*)p = v; }
+#else
+ZD uint4 zkw_gload4(const uint4* p) { return *p; }
+ZD void zkw_gstore4(uint4* p, const uint4 v) { *p = v; }
+ZD uint8_t zkw_gload1(const uint8_t* p) { return *p; }
+ZD void zkw_gstore1(uint8_t* p, uint8_t v) { *p = v; }
+#endif
+
 // orders this wave's own LDS stores before later cross-lane LDS reads/atomics (no workgroup barrier involved)
 ZD void zkw_wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -489,8 +513,8 @@ ZD u256 stack_read(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, bool& is_ptr) {
   // need capacity, and stack_hwm <= S
   if (idx >= CF(sh, s, CF_STACK_HWM)) return u256_zero();
   const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), sh.S, idx);
-  is_ptr = sh.stack_ptrs[w] != 0;
-  return u256_from_uint4(sh.stack_vals[2 * w - s.lane], sh.stack_vals[2 * w - s.lane + sh.L]);
+  is_ptr = zkw_gload1(sh.stack_ptrs + w) != 0;
+  return u256_from_uint4(zkw_gload4(sh.stack_vals + (2 * w - s.lane)), zkw_gload4(sh.stack_vals + (2 * w - s.lane + sh.L)));
 }
 // MemoryType::Stack write (memory.rs:413-425)
 ZD void stack_write(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, const u256& v, bool is_ptr) {
@@ -501,15 +525,15 @@ ZD void stack_write(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, const u256& v,
   }
   for (u32 g = CF(sh, s, CF_STACK_HWM); g < idx; g++) {  // lazily zero the gap
     const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), sh.S, g);
-    sh.stack_vals[2 * w - s.lane] = make_uint4(0, 0, 0, 0);
-    sh.stack_vals[2 * w - s.lane + sh.L] = make_uint4(0, 0, 0, 0);
-    sh.stack_ptrs[w] = 0;
+    zkw_gstore4(sh.stack_vals + (2 * w - s.lane), make_uint4(0, 0, 0, 0));
+    zkw_gstore4(sh.stack_vals + (2 * w - s.lane + sh.L), make_uint4(0, 0, 0, 0));
+    zkw_gstore1(sh.stack_ptrs + w, 0);
   }
   const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), sh.S, idx);
   if (!(sh.debug_flags & 128u)) {  // (128: traffic ablation — the run is then wrong)
-    sh.stack_vals[2 * w - s.lane] = u256_lo4(v);
-    sh.stack_vals[2 * w - s.lane + sh.L] = u256_hi4(v);
-    sh.stack_ptrs[w] = is_ptr ? 1 : 0;
+    zkw_gstore4(sh.stack_vals + (2 * w - s.lane), u256_lo4(v));
+    zkw_gstore4(sh.stack_vals + (2 * w - s.lane + sh.L), u256_hi4(v));
+    zkw_gstore1(sh.stack_ptrs + w, is_ptr ? 1 : 0);
   }
   if (idx >= CF(sh, s, CF_STACK_HWM)) CF(sh, s, CF_STACK_HWM) = idx + 1;
 }
@@ -521,7 +545,7 @@ ZD u256 heap_read_at(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 slot,
   if (idx >= hwm) return u256_zero();  // the reference grows its Vec on a read (memory.rs:464,468): not observable; hwm <= words
   const uint4* base = is_aux ? sh.aux_heap : sh.heap;
   const u32 w = page_word_index(sh, s, slot, words, idx);
-  return u256_from_uint4(base[2 * w - s.lane], base[2 * w - s.lane + sh.L]);
+  return u256_from_uint4(zkw_gload4(base + (2 * w - s.lane)), zkw_gload4(base + (2 * w - s.lane + sh.L)));
 }
 // MemoryType::Heap / AuxHeap of the current frame (memory.rs:439-473; the page number of the query
 // is only debug_assert'ed there, i.e. ignored in release builds)
@@ -539,13 +563,13 @@ ZD void heap_write_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx
   u32 hwm = is_aux ? CF(sh, s, CF_AUX_HWM) : CF(sh, s, CF_HEAP_HWM);
   for (u32 g = hwm; g < idx; g++) {
     const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), words, g);
-    base[2 * w - s.lane] = make_uint4(0, 0, 0, 0);
-    base[2 * w - s.lane + sh.L] = make_uint4(0, 0, 0, 0);
+    zkw_gstore4(base + (2 * w - s.lane), make_uint4(0, 0, 0, 0));
+    zkw_gstore4(base + (2 * w - s.lane + sh.L), make_uint4(0, 0, 0, 0));
   }
   const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), words, idx);
   if (!(sh.debug_flags & 64u)) {  // (64: traffic ablation — the run is then wrong)
-    base[2 * w - s.lane] = u256_lo4(v);
-    base[2 * w - s.lane + sh.L] = u256_hi4(v);
+    zkw_gstore4(base + (2 * w - s.lane), u256_lo4(v));
+    zkw_gstore4(base + (2 * w - s.lane + sh.L), u256_hi4(v));
   }
   if (!is_aux && CF(sh, s, CF_SLOT) == 0 && idx < P.heap_image_words && !(sh.debug_flags & 32u)) {  // (32: traffic ablation)
     // a word of the uploaded heap image is overwritten: remember it, the next reset restores only those words
@@ -598,14 +622,14 @@ ZD u256 fat_ptr_read(ZKW_KP P, const Shared& sh, Lane& s, u32 page, u32 idx) {
   if (idx >= hwm || idx >= words) return u256_zero();  // `.get(index).unwrap_or(zero)` (:490-495)
   const uint4* base = is_aux ? sh.aux_heap : sh.heap;
   const u32 w = page_word_index(sh, s, slot, words, idx);
-  return u256_from_uint4(base[2 * w - s.lane], base[2 * w - s.lane + sh.L]);
+  return u256_from_uint4(zkw_gload4(base + (2 * w - s.lane)), zkw_gload4(base + (2 * w - s.lane + sh.L)));
 }
 
 // read_code_query (memory.rs:556-569) against the blob backing the current code page
 ZD u256 code_read(const Shared& sh, const Lane& s, u32 idx) {
   if (idx >= CF(sh, s, CF_CODE_LEN)) return u256_zero();
   const u64 w = (u64)CF(sh, s, CF_CODE_OFF) + idx;
-  return u256_from_uint4(sh.blob_words[2 * w], sh.blob_words[2 * w + 1]);
+  return u256_from_uint4(zkw_gload4(sh.blob_words + 2 * w), zkw_gload4(sh.blob_words + 2 * w + 1));
 }
 
 // ---------------------------------------------------------------------------------------------
