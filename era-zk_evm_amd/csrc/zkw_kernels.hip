@@ -77,7 +77,19 @@ enum {
 #endif
 // (the lane index goes through zkw_opaque at every access: a shared, long-lived address register would be the first
 // thing the allocator spills around the opcode switch — one v_lshl_add per access is cheaper than that reload)
+#if defined(__HIP_DEVICE_COMPILE__)
+// On the device the per-lane LDS addresses of a wave live in registers of the reserved range the compiled code never
+// touches (see RegFile): v131 = LDS byte address of this lane's column of the cold fields, v132 = of its column of
+// the 16-byte slots (pre-decoded code word, masked instruction), v133 = the lane index.  An access copies the
+// address out with one volatile v_mov (volatile: as an ordinary value it would be hoisted to one kernel-long register
+// and spilled); before, every access recomputed the lane with two v_mbcnt and added a wave base that the allocator
+// kept in a spilled scalar register (v_readlane at 41 sites).
+#define CF(sh, s, f) (*(ZKW_LDS_AS u32*)(zkw_cold_addr() + (u32)(f) * (ZKW_LDS_STRIDE * 4u)))
+#define ZKW_XFER(sh, s, i) (*(ZKW_LDS_AS u32*)(zkw_cold_addr() + ZKW_XFER_OFF + (u32)(i) * (ZKW_LDS_STRIDE * 4u)))
+#else
 #define CF(sh, s, f) ((sh).cold[(u32)(f) * ZKW_LDS_STRIDE + (s).lane])
+#define ZKW_XFER(sh, s, i) ((sh).xfer[(u32)(i) * ZKW_LDS_STRIDE + (s).lane])
+#endif
 #define lane_inst(sh, s) ((sh).wave * (sh).L + (s).lane)
 
 #define FLAG_LT 1u
@@ -202,8 +214,23 @@ ZD u32 zkw_opaque(u32 x) {
 // (inside the volatile asm: the builtins are pure functions of constants and would be hoisted to one kernel-long value)
 ZD u32 zkw_lane_id() {
   u32 x;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+  asm volatile("v_mov_b32 %0, v133" : "=v"(x));  // set by zkw_set_lane_regs (was: two v_mbcnt)
   return x;
+}
+#define ZKW_LDS_AS __attribute__((address_space(3)))
+ZD u32 zkw_cold_addr() {
+  u32 x;
+  asm volatile("v_mov_b32 %0, v131" : "=v"(x));
+  return x;
+}
+ZD u32 zkw_slot_addr() {
+  u32 x;
+  asm volatile("v_mov_b32 %0, v132" : "=v"(x));
+  return x;
+}
+// cold_lds / slot_lds: LDS byte addresses of the wave's cold-field block / 16-byte-slot block; every lane of the wave
+ZD void zkw_set_lane_regs(u32 cold_lds, u32 slot_lds, u32 lane) {
+  asm volatile("v_mov_b32 v131, %0\n\tv_mov_b32 v132, %1\n\tv_mov_b32 v133, %2" : : "v"(cold_lds + lane * 4u), "v"(slot_lds + lane * 16u), "v"(lane) : "v131", "v132", "v133");
 }
 // bit `lane` of a wave mask: a select on the mask itself (no 1 << lane register to keep alive)
 ZD bool zkw_lane_bit(u64 mask) {
@@ -216,6 +243,27 @@ ZD bool zkw_lane_bit(u64 mask) { return ((mask >> (threadIdx.x & (ZKW_WAVE - 1))
 ZD u32 zkw_rank_below(u64 mask) { return (u32)__popcll(mask & ((1ull << (threadIdx.x & (ZKW_WAVE - 1))) - 1ull)); }
 ZD u32 zkw_opaque(u32 x) { return x; }
 ZD u32 zkw_lane_id() { return threadIdx.x & (ZKW_WAVE - 1); }
+#endif
+
+// the 16-byte per-lane LDS slots of a wave: 0..3 = the pre-decoded opcodes of previous_code_word, 4 = the instruction a
+// masked / pending lane executes instead (Shared::pcw / enc)
+#define ZKW_XFER_OFF ((ZKW_COLD_FIELDS * 4u + 4u * 16u + 16u) * ZKW_LDS_STRIDE)  /* bytes from the cold block to the transfer slot */
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned int zkw_lds_vec4 __attribute__((ext_vector_type(4)));
+ZD uint4 zkw_slot_read_at(u32 byte_off) {  // byte_off = slot * 16 * ZKW_LDS_STRIDE (may be a per-lane value)
+  const zkw_lds_vec4 v = *(volatile ZKW_LDS_AS zkw_lds_vec4*)(zkw_slot_addr() + byte_off);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+ZD void zkw_slot_write_at(u32 byte_off, const uint4 v) {
+  zkw_lds_vec4 t;
+  t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  *(volatile ZKW_LDS_AS zkw_lds_vec4*)(zkw_slot_addr() + byte_off) = t;
+}
+#define ZKW_SLOT_READ(sh, lane, slot) zkw_slot_read_at((u32)(slot) * (16u * ZKW_LDS_STRIDE))
+#define ZKW_SLOT_WRITE(sh, lane, slot, v) zkw_slot_write_at((u32)(slot) * (16u * ZKW_LDS_STRIDE), (v))
+#else
+#define ZKW_SLOT_READ(sh, lane, slot) ((sh).pcw[(u32)(slot) * ZKW_LDS_STRIDE + (lane)])
+#define ZKW_SLOT_WRITE(sh, lane, slot, v) ((sh).pcw[(u32)(slot) * ZKW_LDS_STRIDE + (lane)] = (v))
 #endif
 
 // On the device the four cursors of a wave (memory / log / aux stream, register deltas) are lanes 0..3 of v128 — a
@@ -1782,7 +1830,7 @@ ZD zkw_v16 zkw_heavy_body(zkw_v16 a, zkw_v16 b) {
   } else if (opcode == ZKW_OP_FAR_CALL) {
     u256 r15;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r15.w[i] = sh.xfer[i * ZKW_LDS_STRIDE + s.lane];
+    for (int i = 0; i < 8; i++) r15.w[i] = ZKW_XFER(sh, s, i);
     op_far_call(P, sh, s, d, ps, r15, out);
   } else {
     op_ret(P, sh, s, d, ps, out);
@@ -1791,7 +1839,7 @@ ZD zkw_v16 zkw_heavy_body(zkw_v16 a, zkw_v16 b) {
   ZKW_STAMP(50 + (opcode == ZKW_OP_FAR_CALL ? 0 : opcode == ZKW_OP_RET ? 1 : opcode == ZKW_OP_NEAR_CALL ? 2 : 3))  // rest of the body
   if (out.action & (ZKW_ACT_DST0 | ZKW_ACT_FAR | ZKW_ACT_RET)) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) sh.xfer[i * ZKW_LDS_STRIDE + s.lane] = out.v1.w[i];
+    for (int i = 0; i < 8; i++) ZKW_XFER(sh, s, i) = out.v1.w[i];
   }
   zkw_v16 r = lane_pack(s);
   r[12] = out.action;
@@ -1990,7 +2038,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
         if (opcode == ZKW_OP_FAR_CALL) {  // CALL_IMPLICIT_PARAMETER_REG_IDX, far_call.rs:506-508
           const u256 r15 = rf_get(rf, 15);
 #pragma unroll
-          for (int i = 0; i < 8; i++) sh.xfer[i * ZKW_LDS_STRIDE + s.lane] = r15.w[i];
+          for (int i = 0; i < 8; i++) ZKW_XFER(sh, s, i) = r15.w[i];
         }
         zkw_v16 a = lane_pack(s), b;
         a[12] = d.word_lo; a[13] = d.word_hi; a[14] = d.attr | ((ps.src0_ptr ? 1u : 0u) << 30) | ((ps.src1_ptr ? 1u : 0u) << 31);
@@ -2007,7 +2055,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
         u256 v1 = u256_zero();
         if (action & (ZKW_ACT_DST0 | ZKW_ACT_FAR | ZKW_ACT_RET)) {
 #pragma unroll
-          for (int i = 0; i < 8; i++) v1.w[i] = sh.xfer[i * ZKW_LDS_STRIDE + s.lane];
+          for (int i = 0; i < 8; i++) v1.w[i] = ZKW_XFER(sh, s, i);
         }
         if (action & ZKW_ACT_DST0) dst0_update(P, sh, rf, s, ps.dst0, d.dst0, v1, false);
         if (action & (ZKW_ACT_FAR | ZKW_ACT_RET)) {
@@ -2047,7 +2095,7 @@ ZD void lane_writeback(ZKW_KP P, Shared& sh, const RegFile& rf, Lane& s, u32 com
   zkw_dev_scalars sc;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const uint4 v = sh.pcw[i * ZKW_LDS_STRIDE + tid];
+    const uint4 v = ZKW_SLOT_READ(sh, tid, i);
     sc.prev_code_word[2 * i] = v.x;
     sc.prev_code_word[2 * i + 1] = v.y;
   }
@@ -2080,6 +2128,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
   const u32 wave = blockIdx.x * P.waves_per_group + wib;
   Shared sh;
   shared_setup(sh, P, A.debug_flags, wib, wave, true);
+#ifdef __HIP_DEVICE_COMPILE__
+  zkw_set_lane_regs((u32)(size_t)(ZKW_LDS_AS u32*)sh.cold, (u32)(size_t)(ZKW_LDS_AS uint4*)sh.pcw, tid);  // v131..v133: see CF
+#endif
   u32 run_cycles = A.run_cycles, time_delta = P.consts.time_delta_per_cycle, cap_delta = P.cap_delta, max_depth = P.consts.vm_max_stack_depth;
   ZKW_PIN_SGPR(run_cycles); ZKW_PIN_SGPR(time_delta); ZKW_PIN_SGPR(cap_delta); ZKW_PIN_SGPR(max_depth);
   // stage the packed ISA table in LDS (all threads of the workgroup, 16 B each per step)
@@ -2133,7 +2184,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const uint2 e = sh.isa[sc.prev_code_word[2 * i] & (ZKW_ISA_TABLE_SIZE - 1)];
-      sh.pcw[i * ZKW_LDS_STRIDE + tid] = make_uint4(sc.prev_code_word[2 * i], sc.prev_code_word[2 * i + 1], e.x, e.y);
+      ZKW_SLOT_WRITE(sh, tid, i, make_uint4(sc.prev_code_word[2 * i], sc.prev_code_word[2 * i + 1], e.x, e.y));
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) CF(sh, s, CF_CTX0 + i) = sc.ctx_u128_reg[i];
@@ -2202,7 +2253,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
 #pragma unroll
           for (int i = 0; i < 4; i++) e4[i] = sh.isa[word.w[2 * i] & (ZKW_ISA_TABLE_SIZE - 1)];
 #pragma unroll
-          for (int i = 0; i < 4; i++) sh.pcw[i * ZKW_LDS_STRIDE + s.lane] = make_uint4(word.w[2 * i], word.w[2 * i + 1], e4[i].x, e4[i].y);
+          for (int i = 0; i < 4; i++) ZKW_SLOT_WRITE(sh, s.lane, i, make_uint4(word.w[2 * i], word.w[2 * i + 1], e4[i].x, e4[i].y));
           s.prev_super_pc = super_pc;
         }
       } else {  // :104-115
@@ -2213,7 +2264,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
       if (pending) {  // the instruction is exception_revert_encoding() instead of the slot of the code word (:104-115)
         const u64 rv = P.consts.exception_revert_encoding;
         const uint2 e0 = sh.isa[(u32)rv & (ZKW_ISA_TABLE_SIZE - 1)];
-        zkw_lds_write4(sh.enc + s.lane, make_uint4((u32)rv, (u32)(rv >> 32), e0.x, e0.y));
+        ZKW_SLOT_WRITE(sh, s.lane, 4, make_uint4((u32)rv, (u32)(rv >> 32), e0.x, e0.y));
         s.kflags |= KF_MASKED;
       }
       {
@@ -2238,7 +2289,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
         const u32 leader = (u32)__ffsll((long long)todo) - 1u;
         const u32 lane_now = zkw_lane_id();
         // (a lane that was already served reads a slot it no longer cares about: it is not in `todo`)
-        const uint4 me = *((s.kflags & KF_MASKED) ? sh.enc + lane_now : sh.pcw + (3u - (s.pc & 3u)) * ZKW_LDS_STRIDE + lane_now);
+        const uint4 me = ZKW_SLOT_READ(sh, lane_now, (s.kflags & KF_MASKED) ? 4u : 3u - (s.pc & 3u));
         const u32 charged = s.kflags & KF_CHARGED;
         const u32 u_lo = (u32)__builtin_amdgcn_readlane((int)me.x, (int)leader);
         const u32 u_hi = (u32)__builtin_amdgcn_readlane((int)me.y, (int)leader);
@@ -2260,7 +2311,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
               // the group of the panic / nop encoding (all operand fields zero, condition Always)
               const u64 masked = err ? P.consts.exception_revert_encoding : P.consts.nop_encoding;
               const uint2 e1 = sh.isa[(u32)masked & (ZKW_ISA_TABLE_SIZE - 1)];
-              zkw_lds_write4(sh.enc + lane_now, make_uint4((u32)masked, (u32)(masked >> 32), e1.x, e1.y));
+              ZKW_SLOT_WRITE(sh, lane_now, 4, make_uint4((u32)masked, (u32)(masked >> 32), e1.x, e1.y));
               s.kflags |= KF_MASKED;
               mine = false;
             }
