@@ -365,6 +365,10 @@ struct Shared {
   // itself the compiler re-loads them from the parameter block at every use (s_load + s_waitcnt lgkmcnt(0), which
   // also drains the outstanding LDS reads) because an invariant load is cheaper to rematerialise than to keep
   u32 F, S, H, A, cap_mem;
+  // constants the hot path reads every cycle (operand addressing, UMA): as loads from the parameter block at their use
+  // they were 3.5 scalar-memory round trips per VM cycle (PMC), each followed by s_waitcnt lgkmcnt(0)
+  u32 clip_mode, growth_per_byte, max_deref_low, image_words;
+  u32* heap_dirty;
   uint4 *stack_vals, *heap, *aux_heap;
   uint8_t* stack_ptrs;
   const uint4* blob_words;
@@ -384,10 +388,13 @@ ZD void shared_setup(Shared& sh, ZKW_KP P, u32 dbg, u32 wib, u32 wave, bool pin)
   sh.wib = wib;
   sh.wave = wave;
   sh.F = P.F; sh.S = P.S; sh.H = P.H; sh.A = P.A; sh.cap_mem = P.cap_mem;
+  sh.clip_mode = P.consts.clip_mode; sh.growth_per_byte = P.consts.memory_growth_ergs_per_byte; sh.max_deref_low = P.consts.max_offset_to_deref_low;
+  sh.image_words = P.heap_image_words; sh.heap_dirty = P.heap_dirty;
   // this wave's rows: stack_vals / heap / aux_heap [F][words][2][L] x 16 B, stack_ptrs [F][S][L] x 1 B
   sh.stack_vals = P.stack_vals + (u64)wave * P.F * P.S * 2u * P.L; sh.stack_ptrs = P.stack_ptrs + (u64)wave * P.F * P.S * P.L;
   sh.heap = P.heap + (u64)wave * P.F * P.H * 2u * P.L; sh.aux_heap = P.aux_heap + (u64)wave * P.F * P.A * 2u * P.L; sh.blob_words = P.blob_words;
   if (pin) {
+    ZKW_PIN_SGPR(sh.clip_mode); ZKW_PIN_SGPR(sh.growth_per_byte); ZKW_PIN_SGPR(sh.max_deref_low); ZKW_PIN_SGPR(sh.image_words); ZKW_PIN_SGPR(sh.heap_dirty);
     ZKW_PIN_SGPR(sh.L); ZKW_PIN_SGPR(sh.F); ZKW_PIN_SGPR(sh.S); ZKW_PIN_SGPR(sh.H); ZKW_PIN_SGPR(sh.A); ZKW_PIN_SGPR(sh.cap_mem);
     ZKW_PIN_SGPR(sh.stack_vals); ZKW_PIN_SGPR(sh.stack_ptrs); ZKW_PIN_SGPR(sh.heap); ZKW_PIN_SGPR(sh.aux_heap); ZKW_PIN_SGPR(sh.blob_words);
   }
@@ -619,9 +626,9 @@ ZD void heap_write_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx
     zkw_gstore4(base + (2 * w - s.lane), u256_lo4(v));
     zkw_gstore4(base + (2 * w - s.lane + sh.L), u256_hi4(v));
   }
-  if (!is_aux && CF(sh, s, CF_SLOT) == 0 && idx < P.heap_image_words && !(sh.debug_flags & 32u)) {  // (32: traffic ablation)
+  if (!is_aux && CF(sh, s, CF_SLOT) == 0 && idx < sh.image_words && !(sh.debug_flags & 32u)) {  // (32: traffic ablation)
     // a word of the uploaded heap image is overwritten: remember it, the next reset restores only those words
-    u32* d = P.heap_dirty + ((u64)sh.wave * ((P.heap_image_words + 31u) >> 5) + (idx >> 5)) * sh.L + s.lane;
+    u32* d = sh.heap_dirty + ((u64)sh.wave * ((sh.image_words + 31u) >> 5) + (idx >> 5)) * sh.L + s.lane;
     atomicOr(d, 1u << (idx & 31u));  // result unused: a fire-and-forget atomic instead of a load + store round trip
   }
   if (idx >= hwm) hwm = idx + 1;
@@ -823,8 +830,8 @@ ZD void storage_finish_frame(ZKW_KP P, const Shared& sh, Lane& s, u32 mark, bool
 // ---------------------------------------------------------------------------------------------
 // helpers shared by opcodes
 // ---------------------------------------------------------------------------------------------
-ZD u32 clip16(ZKW_KP P, const u256& v) {  // AllowedPcOrImm::from_u64_clipped(value.low_u64())
-  if (P.consts.clip_mode == 0) return (v.w[1] != 0 || v.w[0] > 0xffffu) ? 0xffffu : v.w[0];
+ZD u32 clip16(const Shared& sh, const u256& v) {  // AllowedPcOrImm::from_u64_clipped(value.low_u64())
+  if (sh.clip_mode == 0) return (v.w[1] != 0 || v.w[0] > 0xffffu) ? 0xffffu : v.w[0];
   return v.w[0] & 0xffffu;
 }
 
@@ -840,7 +847,7 @@ ZD Operand compute_address(ZKW_KP P, const Shared& sh, Lane& s, u32& sp, const u
   o.type = ZKW_MEM_STACK;
   o.page = CF(sh, s, CF_BASE_PAGE) + 1;  // stack_page_from_base
   o.index = 0;
-  const u32 vaddr = (clip16(P, reg_value) + imm) & 0xffffu;  // :34-35
+  const u32 vaddr = (clip16(sh, reg_value) + imm) & 0xffffu;  // :34-35
   if (mode == ZKW_MODE_STACK_PP) {
     if (is_write) {  // :55-70
       o.index = sp;
@@ -1121,7 +1128,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
     src_offset = fp.start + fp.offset;
   } else {  // :121-135  src0 > MAX_OFFSET_TO_DEREF
     const bool beyond = (ps.src0.w[1] | ps.src0.w[2] | ps.src0.w[3] | ps.src0.w[4] | ps.src0.w[5] | ps.src0.w[6] | ps.src0.w[7]) != 0 ||
-                        ps.src0.w[0] > P.consts.max_offset_to_deref_low;
+                        ps.src0.w[0] > sh.max_deref_low;
     if (beyond) {
       exceptions |= 2u;  // DEREF_BEYOND_HEAP_RANGE
       skip_legit = true;
@@ -1141,7 +1148,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
       if (is_heap) CF(sh, s, CF_HEAP_BOUND) = incremented; else CF(sh, s, CF_AUX_BOUND) = incremented;
     }
   }
-  u32 cost = growth * P.consts.memory_growth_ergs_per_byte;  // :196-197
+  u32 cost = growth * sh.growth_per_byte;  // :196-197
   if (exceptions & 2u) cost = 0xffffffffu;                   // :202-207
   if (s.ergs < cost) {
     s.ergs = 0;
@@ -2001,7 +2008,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
         }
         break;
       }
-      case ZKW_OP_JUMP: s.pc = clip16(P, ps.src0); break;  // jump.rs:23-25
+      case ZKW_OP_JUMP: s.pc = clip16(sh, ps.src0); break;  // jump.rs:23-25
       case ZKW_OP_SHIFT: {  // shift.rs:44-78
         s.pc = ps.new_pc;
         const u32 n = ps.src1.w[0] & 0xffu;
