@@ -607,7 +607,9 @@ ZD u256 heap_read_at(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 slot,
 ZD u256 heap_read_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx) {
   return heap_read_at(P, sh, s, is_aux, CF(sh, s, CF_SLOT), is_aux ? CF(sh, s, CF_AUX_HWM) : CF(sh, s, CF_HEAP_HWM), idx);
 }
-ZD void heap_write_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx, const u256& v) {
+// write into page `slot` whose high-water mark is `hwm` (updated; the caller stores it back): the frame fields come in
+// as values so that a caller with several accesses reads them from LDS once, together
+ZD void heap_write_at(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 slot, u32& hwm, u32 idx, const u256& v) {
   s.lane = zkw_lane_id();  // fresh, short-lived lane index (see struct Lane)
   const u32 words = is_aux ? sh.A : sh.H;
   if (idx >= words) {
@@ -615,23 +617,26 @@ ZD void heap_write_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx
     return;
   }
   uint4* base = is_aux ? sh.aux_heap : sh.heap;
-  u32 hwm = is_aux ? CF(sh, s, CF_AUX_HWM) : CF(sh, s, CF_HEAP_HWM);
   for (u32 g = hwm; g < idx; g++) {
-    const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), words, g);
+    const u32 w = page_word_index(sh, s, slot, words, g);
     zkw_gstore4(base + (2 * w - s.lane), make_uint4(0, 0, 0, 0));
     zkw_gstore4(base + (2 * w - s.lane + sh.L), make_uint4(0, 0, 0, 0));
   }
-  const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), words, idx);
+  const u32 w = page_word_index(sh, s, slot, words, idx);
   if (!(sh.debug_flags & 64u)) {  // (64: traffic ablation — the run is then wrong)
     zkw_gstore4(base + (2 * w - s.lane), u256_lo4(v));
     zkw_gstore4(base + (2 * w - s.lane + sh.L), u256_hi4(v));
   }
-  if (!is_aux && CF(sh, s, CF_SLOT) == 0 && idx < sh.image_words && !(sh.debug_flags & 32u)) {  // (32: traffic ablation)
+  if (!is_aux && slot == 0 && idx < sh.image_words && !(sh.debug_flags & 32u)) {  // (32: traffic ablation)
     // a word of the uploaded heap image is overwritten: remember it, the next reset restores only those words
     u32* d = sh.heap_dirty + ((u64)sh.wave * ((sh.image_words + 31u) >> 5) + (idx >> 5)) * sh.L + s.lane;
     atomicOr(d, 1u << (idx & 31u));  // result unused: a fire-and-forget atomic instead of a load + store round trip
   }
   if (idx >= hwm) hwm = idx + 1;
+}
+ZD void heap_write_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx, const u256& v) {
+  u32 hwm = is_aux ? CF(sh, s, CF_AUX_HWM) : CF(sh, s, CF_HEAP_HWM);
+  heap_write_at(P, sh, s, is_aux, CF(sh, s, CF_SLOT), hwm, idx, v);
   if (is_aux) CF(sh, s, CF_AUX_HWM) = hwm; else CF(sh, s, CF_HEAP_HWM) = hwm;
 }
 
@@ -845,9 +850,19 @@ ZD Operand compute_address(ZKW_KP P, const Shared& sh, Lane& s, u32& sp, const u
   Operand o;
   o.has_loc = false;
   o.type = ZKW_MEM_STACK;
-  o.page = CF(sh, s, CF_BASE_PAGE) + 1;  // stack_page_from_base
+  o.page = 0;
   o.index = 0;
+  // (`mode` is wave-uniform: a register / immediate operand costs neither the clip nor the LDS read of the base page)
+  if (mode != ZKW_MODE_STACK_PP && mode != ZKW_MODE_STACK_OFF && mode != ZKW_MODE_CODE && mode != ZKW_MODE_STACK_ABS) return o;
   const u32 vaddr = (clip16(sh, reg_value) + imm) & 0xffffu;  // :34-35
+  if (mode == ZKW_MODE_CODE) {  // :100-110
+    o.type = ZKW_MEM_CODE;
+    o.page = CF(sh, s, CF_CODE_PAGE);
+    o.index = vaddr;
+    o.has_loc = true;
+    return o;
+  }
+  o.page = CF(sh, s, CF_BASE_PAGE) + 1;  // stack_page_from_base
   if (mode == ZKW_MODE_STACK_PP) {
     if (is_write) {  // :55-70
       o.index = sp;
@@ -860,12 +875,7 @@ ZD Operand compute_address(ZKW_KP P, const Shared& sh, Lane& s, u32& sp, const u
   } else if (mode == ZKW_MODE_STACK_OFF) {  // :88-98
     o.index = (sp - vaddr) & 0xffffu;
     o.has_loc = true;
-  } else if (mode == ZKW_MODE_CODE) {  // :100-110
-    o.type = ZKW_MEM_CODE;
-    o.page = CF(sh, s, CF_CODE_PAGE);
-    o.index = vaddr;
-    o.has_loc = true;
-  } else if (mode == ZKW_MODE_STACK_ABS) {  // :111-121
+  } else {  // ZKW_MODE_STACK_ABS :111-121
     o.index = vaddr;
     o.has_loc = true;
   }
@@ -1112,14 +1122,24 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
   const bool is_heap = v == ZKW_UMA_HEAP_READ || v == ZKW_UMA_HEAP_WRITE;
   const bool is_write = v == ZKW_UMA_HEAP_WRITE || v == ZKW_UMA_AUX_WRITE;
   if (is_ptr_read && !ps.src0_ptr) exceptions |= 1u;  // INPUT_IS_NOT_POINTER_WHEN_EXPECTED :73-78
+  // the frame fields this access needs, read from LDS together (one wait instead of one per use; the variant is
+  // wave-uniform, so these selections are scalar branches)
+  u32 f_base_page = 0, f_slot = 0, f_hwm = 0, f_bound = 0;
+  if (!is_ptr_read) {
+    f_base_page = CF(sh, s, CF_BASE_PAGE);
+    f_slot = CF(sh, s, CF_SLOT);
+    f_hwm = is_heap ? CF(sh, s, CF_HEAP_HWM) : CF(sh, s, CF_AUX_HWM);
+    f_bound = is_heap ? CF(sh, s, CF_HEAP_BOUND) : CF(sh, s, CF_AUX_BOUND);
+  }
+  const u32 f_hwm_in = f_hwm;
   u32 mem_type;
   if (is_ptr_read) {
     mem_type = ZKW_MEM_FAT_PTR;
   } else if (is_heap) {
-    fp.page = CF(sh, s, CF_BASE_PAGE) + 2;
+    fp.page = f_base_page + 2;
     mem_type = ZKW_MEM_HEAP;
   } else {
-    fp.page = CF(sh, s, CF_BASE_PAGE) + 3;
+    fp.page = f_base_page + 3;
     mem_type = ZKW_MEM_AUX_HEAP;
   }
   u32 src_offset;
@@ -1142,7 +1162,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
   }
   u32 growth = 0;  // :152-194
   if (!is_ptr_read) {
-    const u32 bound = is_heap ? CF(sh, s, CF_HEAP_BOUND) : CF(sh, s, CF_AUX_BOUND);
+    const u32 bound = f_bound;
     if (incremented >= bound) {
       growth = incremented - bound;
       if (is_heap) CF(sh, s, CF_HEAP_BOUND) = incremented; else CF(sh, s, CF_AUX_BOUND) = incremented;
@@ -1170,8 +1190,8 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
   if (!skip) {  // :265-288
     // both word loads are issued before the first query is emitted: the emission needs the loaded value, so reading
     // and emitting word by word would serialise two memory round trips (the dominant cost of this opcode)
-    w0v = is_ptr_read ? fat_ptr_read(P, sh, s, fp.page, word0) : heap_read_cur(P, sh, s, !is_heap, word0);
-    if (unaligned) w1v = is_ptr_read ? fat_ptr_read(P, sh, s, fp.page, word1) : heap_read_cur(P, sh, s, !is_heap, word1);
+    w0v = is_ptr_read ? fat_ptr_read(P, sh, s, fp.page, word0) : heap_read_at(P, sh, s, !is_heap, f_slot, f_hwm, word0);
+    if (unaligned) w1v = is_ptr_read ? fat_ptr_read(P, sh, s, fp.page, word1) : heap_read_at(P, sh, s, !is_heap, f_slot, f_hwm, word1);
     ZKW_SUB(64)  // loads issued
 #ifdef ZKW_PROFILE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1210,12 +1230,15 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
     n1 = u256_or(n1, u256_shl(ps.src1, (32 - unal) * 8));
     ZKW_SUB(45)  // write: shifts
     if (!skip) {
-      heap_write_cur(P, sh, s, !is_heap, word0, n0);
+      heap_write_at(P, sh, s, !is_heap, f_slot, f_hwm, word0, n0);
       emit_mem(P, sh, s, ts_w, mem_type, fp.page, word0, n0, false, true, 0);
       if (unaligned) {
-        heap_write_cur(P, sh, s, !is_heap, word1, n1);
+        heap_write_at(P, sh, s, !is_heap, f_slot, f_hwm, word1, n1);
         emit_mem(P, sh, s, ts_w, mem_type, fp.page, word1, n1, false, true, 0);
       }
+    }
+    if (f_hwm != f_hwm_in) {
+      if (is_heap) CF(sh, s, CF_HEAP_HWM) = f_hwm; else CF(sh, s, CF_AUX_HWM) = f_hwm;
     }
     ZKW_SUB(46)  // write: heap writes + write queries
     if (!set_panic) {
