@@ -73,6 +73,25 @@ def test_rerun_after_reset_is_identical(product, isa):
         assert ok, why
 
 
+@pytest.mark.parametrize("cfg,kw", [(2, dict(n_instances=192)), (4, dict(n_instances=96, n_cycles=1024))])
+def test_reset_restores_everything_a_run_changed(oracle, product, isa, cfg, kw):
+    """reset -> run three times on one batch (the middle run is partial, so it dirties other words / slots): a reset
+    restores only what the run marked and the first launch after it starts from the pristine images — the full runs
+    must reproduce the oracle's traces and commitments (cfg 4: storage writes, rollbacks, events)."""
+    wl = synth.make(cfg, isa, **kw)
+    bo = oracle.create_batch(wl)
+    bo.reset(); bo.run(wl.n_cycles)
+    bp = product.create_batch(wl)
+    for rnd in range(3):
+        bp.reset(); bp.run(wl.n_cycles if rnd != 1 else wl.n_cycles // 2); bp.sync()
+        if rnd == 1:
+            continue
+        for i in range(0, wl.n_instances, 7):
+            ok, why = K.traces_equal(bo.trace(i), bp.trace(i))
+            assert ok, "cfg %d round %d instance %d: %s" % (cfg, rnd, i, why)
+        assert np.array_equal(bo.commitments(), bp.commitments()), (cfg, rnd)
+
+
 def test_split_run_equals_single_run(product, isa):
     wl = synth.make(2, isa, n_instances=64)
     b = product.create_batch(wl)
