@@ -38,9 +38,7 @@ ZD void zkw_commit_wave_fence() {
 // ---------------------------------------------------------------------------------------------
 
 // one stream record per thread -> leaf[wave][pos] (4 x u64)
-// One instantiation per queue (Q = ZKW_QUEUE_* or ZKW_QUEUE_CODE_WORDS): the decommit instantiation needs <= 80
-// VGPRs so that its waves fit beside a resident cycle-kernel wave (256 VGPR + 174 AGPR of the 512 per SIMD lane) and
-// the hashing can run in the shadow of the HBM-bound cycle kernel of the next group.
+// One instantiation per queue with a leaf pass (Q = ZKW_QUEUE_MEMORY / ZKW_QUEUE_LOG or ZKW_QUEUE_CODE_WORDS).
 template <int Q>
 __global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) zkw_leaf_kernel(zkw_fused_table T) {
   const zkw_commit_params ZKW_CONST_AS& C = *(const zkw_commit_params ZKW_CONST_AS*)T.p[blockIdx.z];
@@ -48,56 +46,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) zkw_leaf_kernel(zkw_f
   const u32 wave = blockIdx.y;
   u32 n = C.n_override;
   if (!n) n = C.cursors[wave * 4 + C.queue] < C.cap ? C.cursors[wave * 4 + C.queue] : C.cap;
-  if (Q == ZKW_QUEUE_DECOMMIT) {
-    // Only the DECOMMIT events of the aux stream carry a leaf (about one record in six): every wavefront scans its
-    // share of the stream, compacts the positions of the DECOMMIT records into an LDS list with ballot + popcount,
-    // and hashes them 64 at a time, so the permutation runs on full wavefronts.
-    __shared__ u32 s_list[4][2 * ZKW_WAVE];
-    const u32 wt = C.wave_threads;
-    const u32 wf = threadIdx.x / wt, ln = threadIdx.x % wt, nwf = blockDim.x / wt;
-    u32 pending = 0;
-    for (u32 base = (blockIdx.x * nwf + wf) * wt; base < n || pending; base += gridDim.x * nwf * wt) {
-      const u32 pos = base + ln;
-      bool is = false;
-      if (base < n) {
-        if (pos < n) is = (C.stream[((u64)wave * C.cap + pos) * 16].x & 0xffu) == ZKW_AUX_DECOMMIT;
-        const u64 mask = __ballot(is);
-        const u32 rank = (u32)__popcll(mask & ((1ull << ln) - 1ull));
-        if (is) s_list[wf][pending + rank] = pos;
-        pending += (u32)__popcll(mask);
-        zkw_commit_wave_fence();
-      }
-      if (pending >= wt || (base + gridDim.x * nwf * wt >= n && pending)) {  // a full wavefront of work, or the tail
-        const u32 take = pending < wt ? pending : wt;
-        u32 carry = 0;
-        if (ln + take < pending) carry = s_list[wf][ln + take];
-        if (ln < take) {
-          const u32 p = s_list[wf][ln];
-          const uint4* e = C.stream + ((u64)wave * C.cap + p) * 16;
-          const uint4 h = e[0];
-          const u32 pre = e[3].x, blob = h.w >> 16;
-          // the first sponge block (the 8 limbs of the code hash) is cached per preimage at upload: one permutation here
-          const u64* ms = C.midstates + (u64)pre * 12;
-          const u64* bd = C.blob_digests + (u64)blob * 4;
-          u64 st[12];
-#pragma unroll
-          for (int i = 0; i < 12; i++) st[i] = ms[i];
-          const u64 f[8] = {h.y, h.z, h.w & 0xffffu, (h.x >> 24) & 0xffu, bd[0], bd[1], bd[2], bd[3]};
-#pragma unroll
-          for (int i = 0; i < 8; i++) st[i] = gl_add(st[i], f[i]);
-          gl_permute(C.rc, st);
-          u64* dst = C.leaves + ((u64)wave * C.cap + p) * 4;
-          dst[0] = st[0]; dst[1] = st[1]; dst[2] = st[2]; dst[3] = st[3];
-        }
-        zkw_commit_wave_fence();
-        if (ln + take < pending) s_list[wf][ln] = carry;
-        pending -= take;
-        zkw_commit_wave_fence();
-      }
-      if (base >= n && !pending) break;
-    }
-    return;
-  }
+  // (the decommit queue has no leaf pass: its leaves are cached per preimage, zkw_midstate_kernel)
   for (u32 pos = blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += gridDim.x * blockDim.x) {
     u64 out[4];
     if (Q == ZKW_QUEUE_MEMORY) {
@@ -205,23 +154,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) zkw_chain_kernel(zkw_
   const u32* idx = C.idx + (u64)inst * C.per_instance_cap;
   u64 tail[4] = {0, 0, 0, 0};
   if (C.queue == ZKW_QUEUE_DECOMMIT) {
-    // few records per instance (one per decommit): the leaf is computed here from the cached sponge midstate of the
-    // code hash (one permutation) instead of in a separate pass over the whole aux stream
+    // one permutation per decommit: the leaf depends only on the code (hash, length, blob digest) and was computed per
+    // preimage at upload (zkw_midstate_kernel); the per-record fields ride in the two spare elements of the chain step
     for (u32 j = 0; j < cnt; j++) {
       const uint4* e = C.stream + ((u64)wave * C.cap + idx[j]) * 16;
       const uint4 h = e[0];
-      const u32 pre = e[3].x, blob = h.w >> 16;
+      const u32 pre = e[3].x;
       const u64* ms = C.midstates + (u64)pre * 12;
-      const u64* bd = C.blob_digests + (u64)blob * 4;
-      u64 st[12];
-#pragma unroll
-      for (int i = 0; i < 12; i++) st[i] = ms[i];
-      const u64 f[8] = {h.y, h.z, h.w & 0xffffu, (h.x >> 24) & 0xffu, bd[0], bd[1], bd[2], bd[3]};
-#pragma unroll
-      for (int i = 0; i < 8; i++) st[i] = gl_add(st[i], f[i]);
-      gl_permute(C.rc, st);
-      const u64 leaf[4] = {st[0], st[1], st[2], st[3]};
-      gl_chain_step(C.rc, leaf, tail, (u64)j + 1, C.queue);
+      const u64 leaf[4] = {ms[0], ms[1], ms[2], ms[3]};
+      gl_chain_step(C.rc, leaf, tail, (u64)j + 1, C.queue, (u64)h.y | ((u64)((h.x >> 24) & 0xffu) << 32), (u64)h.z);
     }
   } else {
     for (u32 j = 0; j < cnt; j++) {
@@ -272,20 +213,23 @@ __global__ void zkw_blob_chain_kernel(zkw_fused_table T) {
   }
 }
 
-// sponge state after the first block of a decommit leaf: domain (ZKW_LEAF_DECOMMIT, 16 elements) + the 8 limbs of the
-// code hash, one permutation — once per (hash -> blob) pair and upload instead of once per decommit
+// leaf of a decommit record = sponge over what identifies the code: the 8 limbs of the code hash, the length of the blob
+// it maps to and the blob's digest (13 elements, two permutations) — once per (hash -> blob) pair and upload; a
+// decommit then costs one permutation (chain step).  Stored in the first 4 of the 12 elements of the preimage's slot.
 __global__ void zkw_midstate_kernel(zkw_fused_table T) {
   const zkw_commit_params ZKW_CONST_AS& C = *(const zkw_commit_params ZKW_CONST_AS*)T.p[0];
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < C.n_preimages; i += gridDim.x * blockDim.x) {
-    u64 st[12];
+    const u32 blob = C.preimages[i].blob;
+    const u64* bd = C.blob_digests + (u64)blob * 4;
+    u64 f[13];
 #pragma unroll
-    for (int k = 0; k < 12; k++) st[k] = 0;
-    st[8] = ((u64)ZKW_LEAF_DECOMMIT << 32) | 16u;
+    for (int k = 0; k < 8; k++) f[k] = C.preimages[i].hash[k];
+    f[8] = C.blob_dir[blob].y & 0xffffu;
+    f[9] = bd[0]; f[10] = bd[1]; f[11] = bd[2]; f[12] = bd[3];
+    u64 out[4];
+    gl_leaf<13>(C.rc, ZKW_LEAF_DECOMMIT, f, out);
 #pragma unroll
-    for (int k = 0; k < 8; k++) st[k] = C.preimages[i].hash[k];
-    gl_permute(C.rc, st);
-#pragma unroll
-    for (int k = 0; k < 12; k++) C.midstates[(u64)i * 12 + k] = st[k];
+    for (int k = 0; k < 12; k++) C.midstates[(u64)i * 12 + k] = k < 4 ? out[k] : 0;
   }
 }
 
@@ -387,7 +331,6 @@ extern "C" hipError_t zkw_launch_commit(const zkw_fused_table* T, int stage, hip
     switch (T->reserved[0]) {  // the queue of every block in the table
       case ZKW_QUEUE_MEMORY: hipLaunchKernelGGL(zkw_leaf_kernel<ZKW_QUEUE_MEMORY>, grid, dim3(threads), 0, stream, *T); break;
       case ZKW_QUEUE_LOG: hipLaunchKernelGGL(zkw_leaf_kernel<ZKW_QUEUE_LOG>, grid, dim3(threads), 0, stream, *T); break;
-      case ZKW_QUEUE_DECOMMIT: hipLaunchKernelGGL(zkw_leaf_kernel<ZKW_QUEUE_DECOMMIT>, grid, dim3(threads), 0, stream, *T); break;
       default: hipLaunchKernelGGL(zkw_leaf_kernel<ZKW_QUEUE_CODE_WORDS>, grid, dim3(threads), 0, stream, *T); break;
     }
   } else if (stage == ZKW_COMMIT_STAGE_BUCKET) {

@@ -219,7 +219,10 @@ ZD void gl_leaf(const u64* rc, u32 type, const u64 f[N], u64 out[4]) {
   for (int i = 0; i < 4; i++) out[i] = s[i];
 }
 
-ZD void gl_chain_step(const u64* rc, const u64 leaf[4], u64 tail[4], u64 index_plus_1, u32 queue_id) {
+// tail' = P(leaf | tail | index + 1 | queue | x10 | x11)[0..4].  x10 / x11 are zero except for the decommit queue, whose
+// per-record fields ride there (timestamp | fresh << 32, page) next to a leaf that depends only on the code (cached per
+// preimage at upload): one permutation per decommit.
+ZD void gl_chain_step(const u64* rc, const u64 leaf[4], u64 tail[4], u64 index_plus_1, u32 queue_id, u64 x10 = 0, u64 x11 = 0) {
   u64 s[12];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -228,10 +231,9 @@ ZD void gl_chain_step(const u64* rc, const u64 leaf[4], u64 tail[4], u64 index_p
   }
   s[8] = index_plus_1;
   s[9] = queue_id;
-  s[10] = 0;
-  s[11] = 0;
+  s[10] = x10;
+  s[11] = x11;
   gl_permute(rc, s);
 #pragma unroll
   for (int i = 0; i < 4; i++) tail[i] = s[i];
 }
-

@@ -1549,25 +1549,17 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
       a[3] = make_uint4(pre, 0, 0, 0);  // preimage index: selects the cached sponge midstate of this code hash (zkw_commit.hip)
     }
     if (a && P.commit_out && (sh.debug_flags & 16u)) {  // requested per launch (zkw_batches_step with the decommit queue in its mask)
-      // decommit-queue commitment, chained here (zkw_commit.hip spec: leaf = sponge(code hash | timestamp, page, length,
-      // fresh, blob digest), the first block comes from the per-hash midstate; tail' = P(leaf | tail | index | queue)):
-      // a handful of permutations per instance, in the shadow of a far call that costs tens of microseconds anyway —
-      // instead of a bucket pass and a chain kernel over the aux stream after the run
+      // decommit-queue commitment, chained here (zkw_commit.hip spec: leaf = sponge(code hash | length | blob digest),
+      // cached per preimage at upload; tail' = P(leaf | tail | index | queue | timestamp, fresh | page)): one permutation
+      // per decommit, in the shadow of a far call — instead of a bucket pass and a chain kernel over the aux stream
+      // after the run
       const u32 inst = lane_inst(sh, s);
       u64* tail_p = P.commit_out + ((u64)inst * ZKW_QUEUE_COUNT + ZKW_QUEUE_DECOMMIT) * 4;
       const u32 j = P.dq_count[inst];
-      const u64* ms = P.midstates + (u64)pre * 12;
-      const u64* bd = P.blob_digests + (u64)blob * 4;
-      u64 st[12];
-#pragma unroll
-      for (int i = 0; i < 12; i++) st[i] = ms[i];
-      const u64 f[8] = {(u64)(s.timestamp + 1), (u64)page, (u64)blob_len, fresh ? 1ull : 0ull, bd[0], bd[1], bd[2], bd[3]};
-#pragma unroll
-      for (int i = 0; i < 8; i++) st[i] = gl_add(st[i], f[i]);
-      gl_permute(P.commit_rc, st);
-      const u64 leaf[4] = {st[0], st[1], st[2], st[3]};
+      const u64* ms = P.midstates + (u64)pre * 12;  // the leaf of this code (zkw_midstate_kernel)
+      const u64 leaf[4] = {ms[0], ms[1], ms[2], ms[3]};
       u64 tail[4] = {tail_p[0], tail_p[1], tail_p[2], tail_p[3]};
-      gl_chain_step(P.commit_rc, leaf, tail, (u64)j + 1, ZKW_QUEUE_DECOMMIT);
+      gl_chain_step(P.commit_rc, leaf, tail, (u64)j + 1, ZKW_QUEUE_DECOMMIT, (u64)(s.timestamp + 1) | ((u64)(fresh ? 1u : 0u) << 32), (u64)page);
       tail_p[0] = tail[0]; tail_p[1] = tail[1]; tail_p[2] = tail[2]; tail_p[3] = tail[3];
       P.dq_count[inst] = j + 1;
     }

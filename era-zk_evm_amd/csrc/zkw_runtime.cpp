@@ -555,6 +555,7 @@ int zkw_batch_upload(zkw_batch* b) {
     HIP_TRY(c, b->d_midstates.alloc(std::max<size_t>(1, b->preimages.size()) * 12));
     if (!b->preimages.empty()) {
       C.preimages = b->d_preimages.p; C.midstates = b->d_midstates.p; C.n_preimages = (uint32_t)b->preimages.size();
+      C.blob_digests = b->d_blob_digests.p;  // the leaf of a decommit commits to the digest of the blob the hash maps to
       HIP_TRY(c, hipMemcpy(b->d_commit_params.p + ZKW_QUEUE_COUNT, &C, sizeof C, hipMemcpyHostToDevice));
       T.n_blobs = C.n_preimages;
       HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_MIDSTATE, nullptr));

@@ -84,8 +84,9 @@ inline Digest leaf(const Perm& perm, uint32_t type, const std::vector<uint64_t>&
   }
   return Digest{{s[0], s[1], s[2], s[3]}};
 }
-inline void chain_step(const Perm& perm, const Digest& lf, Digest& tail, uint64_t index_plus_1, uint32_t queue_id) {
-  uint64_t s[12] = {lf.v[0], lf.v[1], lf.v[2], lf.v[3], tail.v[0], tail.v[1], tail.v[2], tail.v[3], index_plus_1, queue_id, 0, 0};
+// x10 / x11: the two spare inputs of the chain permutation (decommit queue: the per-record fields; zero elsewhere)
+inline void chain_step(const Perm& perm, const Digest& lf, Digest& tail, uint64_t index_plus_1, uint32_t queue_id, uint64_t x10 = 0, uint64_t x11 = 0) {
+  uint64_t s[12] = {lf.v[0], lf.v[1], lf.v[2], lf.v[3], tail.v[0], tail.v[1], tail.v[2], tail.v[3], index_plus_1, queue_id, x10 % P, x11 % P};
   perm(s);
   for (int i = 0; i < 4; i++) tail.v[i] = s[i];
 }
@@ -146,12 +147,13 @@ inline Digest decommit_queue(const Perm& perm, const zkw_aux_event* e, size_t n,
   uint64_t j = 0;
   for (size_t k = 0; k < n; k++) {
     if (e[k].type != ZKW_AUX_DECOMMIT) continue;
-    // first sponge block = the 8 limbs of the code hash (cacheable per hash), second = the query fields + blob digest
+    // leaf = what identifies the code (8 limbs of the code hash, blob length, blob digest: cacheable per hash); the
+    // per-record fields (timestamp | fresh << 32, page) are the spare inputs of the chain step: one permutation per record
     std::vector<uint64_t> f = limbs(e[k].u.hash);
-    for (uint64_t x : {(uint64_t)e[k].a, (uint64_t)e[k].b, (uint64_t)(e[k].c & 0xffffu), (uint64_t)e[k].flag}) f.push_back(x);
+    f.push_back((uint64_t)(e[k].c & 0xffffu));
     const Digest& bd = blob_digests[e[k].c >> 16];
     for (int i = 0; i < 4; i++) f.push_back(bd.v[i]);
-    chain_step(perm, leaf(perm, 3, f), tail, ++j, ZKW_QUEUE_DECOMMIT);
+    chain_step(perm, leaf(perm, 3, f), tail, ++j, ZKW_QUEUE_DECOMMIT, (uint64_t)e[k].a | ((uint64_t)e[k].flag << 32), (uint64_t)e[k].b);
   }
   return tail;
 }
