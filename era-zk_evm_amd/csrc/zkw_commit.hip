@@ -38,7 +38,8 @@ ZD void zkw_commit_wave_fence() {
 // ---------------------------------------------------------------------------------------------
 
 // one stream record per thread -> leaf[wave][pos] (4 x u64)
-// One instantiation per queue with a leaf pass (Q = ZKW_QUEUE_MEMORY / ZKW_QUEUE_LOG or ZKW_QUEUE_CODE_WORDS).
+// Leaves exist only for the code words of the blobs (Q = ZKW_QUEUE_CODE_WORDS, at upload): the records of the memory and
+// log queues are the inputs of their chain permutations, the decommit leaves are cached per preimage.
 template <int Q>
 __global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) zkw_leaf_kernel(zkw_fused_table T) {
   const zkw_commit_params ZKW_CONST_AS& C = *(const zkw_commit_params ZKW_CONST_AS*)T.p[blockIdx.z];
@@ -49,26 +50,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) zkw_leaf_kernel(zkw_f
   // (the decommit queue has no leaf pass: its leaves are cached per preimage, zkw_midstate_kernel)
   for (u32 pos = blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += gridDim.x * blockDim.x) {
     u64 out[4];
-    if (Q == ZKW_QUEUE_MEMORY) {
-      const uint4* e = C.stream + (u64)wave * C.cap * 3 + pos;  // three planes per wave: header | value low | value high
-      const uint4 h = e[0], lo = e[C.cap], hi = e[2 * (u64)C.cap];
-      u64 f[12] = {h.x, h.y, h.z, (h.w >> 16) & 0xffu, lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      gl_leaf<12>(C.rc, ZKW_LEAF_MEM, f, out);
-    } else if (Q == ZKW_QUEUE_LOG) {
-      const uint4* e = C.stream + ((u64)wave * C.cap + pos) * 8;
-      u64 f[32];
-      const uint4 a6 = e[6], a7 = e[7];
-      f[0] = a7.y;                                              // timestamp
-      f[1] = a7.z & 0xffffu;                                    // tx number
-      f[2] = ((a7.z >> 16) & 0xffu) | (((a7.z >> 24) & 0xffu) << 8) | ((a7.w & 0xffu) << 16) | (((a7.w >> 8) & 0xffu) << 24);  // aux|shard|bools|kind
-      f[3] = a6.x; f[4] = a6.y; f[5] = a6.z; f[6] = a6.w; f[7] = a7.x;  // address
-#pragma unroll
-      for (int q = 0; q < 6; q++) {
-        const uint4 v = e[q];
-        f[8 + 4 * q] = v.x; f[9 + 4 * q] = v.y; f[10 + 4 * q] = v.z; f[11 + 4 * q] = v.w;
-      }
-      gl_leaf<32>(C.rc, ZKW_LEAF_LOG, f, out);
-    } else {  // code words of the blobs: stream = blob words (2 x uint4 per word), wave = 0
+    {  // code words of the blobs: stream = blob words (2 x uint4 per word), wave = 0
       const uint4 lo = C.stream[(u64)pos * 2], hi = C.stream[(u64)pos * 2 + 1];
       u64 f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
       gl_leaf<8>(C.rc, ZKW_LEAF_CODE_WORD, f, out);
@@ -84,8 +66,18 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) zkw_leaf_kernel(zkw_f
 // leader bumps the per-lane running count in LDS.  Records of cycles the instance did not complete
 // (failed cycles) are dropped through the stream directory: record p of lane l counts iff
 // p < dir[n_cycles[l]].
+// bucket / chain launches cover several queues of a batch at once: T.reserved[1] = mask of the queues, blockIdx.z = which
+// of them; T.p[batch] then points to the batch's parameter block of queue 0.  (mask 0: T.p[batch] is the block itself.)
+ZD const zkw_commit_params ZKW_CONST_AS& zkw_commit_block(const zkw_fused_table& T, u32 batch, u32 z) {
+  const zkw_commit_params ZKW_CONST_AS* p = (const zkw_commit_params ZKW_CONST_AS*)T.p[batch];
+  u32 mask = T.reserved[1];
+  if (!mask) return *p;
+  for (u32 k = 0; k < z; k++) mask &= mask - 1u;
+  return p[(u32)__ffsll((long long)mask) - 1u];
+}
+
 __global__ void zkw_bucket_kernel(zkw_fused_table T) {
-  const zkw_commit_params ZKW_CONST_AS& C = *(const zkw_commit_params ZKW_CONST_AS*)T.p[blockIdx.y];
+  const zkw_commit_params ZKW_CONST_AS& C = zkw_commit_block(T, blockIdx.y, blockIdx.z);
   __shared__ u32 s_count[ZKW_WAVE];
   __shared__ u32 s_limit[ZKW_WAVE];
   const u32 wave = blockIdx.x;
@@ -145,7 +137,7 @@ __global__ void zkw_bucket_kernel(zkw_fused_table T) {
 
 // one instance per lane: sequential chain over its leaves
 __global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) zkw_chain_kernel(zkw_fused_table T) {
-  const zkw_commit_params ZKW_CONST_AS& C = *(const zkw_commit_params ZKW_CONST_AS*)T.p[blockIdx.y];
+  const zkw_commit_params ZKW_CONST_AS& C = zkw_commit_block(T, blockIdx.y, blockIdx.z);
   const u32 wave = blockIdx.x;
   const u32 lane = threadIdx.x;
   const u32 inst = wave * C.L + lane;
@@ -164,11 +156,29 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) zkw_chain_kernel(zkw_
       const u64 leaf[4] = {ms[0], ms[1], ms[2], ms[3]};
       gl_chain_step(C.rc, leaf, tail, (u64)j + 1, C.queue, (u64)h.y | ((u64)((h.x >> 24) & 0xffu) << 32), (u64)h.z);
     }
-  } else {
+  } else if (C.queue == ZKW_QUEUE_MEMORY) {
+    // the record is the input of the chain permutation (zkw_goldilocks.hip.h: gl_chain_record): one permutation per query
     for (u32 j = 0; j < cnt; j++) {
-      const u64* lf = C.leaves + ((u64)wave * C.cap + idx[j]) * 4;
-      const u64 leaf[4] = {lf[0], lf[1], lf[2], lf[3]};
-      gl_chain_step(C.rc, leaf, tail, (u64)j + 1, C.queue);
+      const uint4* e = C.stream + (u64)wave * C.cap * 3 + idx[j];  // three planes per wave: header | value low | value high
+      const uint4 h = e[0], lo = e[C.cap], hi = e[2 * (u64)C.cap];
+      const u32 w[12] = {h.x, h.y, h.z, (h.w >> 16) & 0xffu, lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      gl_chain_record<6>(C.rc, w, tail, (u64)j + 1, ZKW_QUEUE_MEMORY);
+    }
+  } else {  // log queue: 32 words -> 19 elements -> three permutations per query
+    for (u32 j = 0; j < cnt; j++) {
+      const uint4* e = C.stream + ((u64)wave * C.cap + idx[j]) * 8;
+      u32 w[32];
+      const uint4 a6 = e[6], a7 = e[7];
+      w[0] = a7.y;                                              // timestamp
+      w[1] = a7.z & 0xffffu;                                    // tx number
+      w[2] = ((a7.z >> 16) & 0xffu) | (((a7.z >> 24) & 0xffu) << 8) | ((a7.w & 0xffu) << 16) | (((a7.w >> 8) & 0xffu) << 24);  // aux|shard|bools|kind
+      w[3] = a6.x; w[4] = a6.y; w[5] = a6.z; w[6] = a6.w; w[7] = a7.x;  // address
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        const uint4 v = e[q];
+        w[8 + 4 * q] = v.x; w[9 + 4 * q] = v.y; w[10 + 4 * q] = v.z; w[11 + 4 * q] = v.w;
+      }
+      gl_chain_record<16>(C.rc, w, tail, (u64)j + 1, ZKW_QUEUE_LOG);
     }
   }
   u64* dst = C.out + ((u64)inst * ZKW_QUEUE_COUNT + C.queue) * 4;
@@ -324,19 +334,16 @@ __global__ void zkw_netstate_kernel(zkw_fused_table T) {
 
 extern "C" hipError_t zkw_launch_commit(const zkw_fused_table* T, int stage, hipStream_t stream) {
   const u32 wt = T->wave_threads;
+  const u32 nq = T->reserved[1] ? (u32)__builtin_popcount(T->reserved[1]) : 1u;  // queues per launch (bucket / chain)
   if (stage == ZKW_COMMIT_STAGE_LEAF) {
     const u32 threads = wt > 1 ? 256 : 1;
     const u32 per_wave_blocks = (T->max_cap + threads - 1) / threads;
     const dim3 grid(per_wave_blocks < 64 ? (per_wave_blocks ? per_wave_blocks : 1) : 64, T->max_waves, T->n);
-    switch (T->reserved[0]) {  // the queue of every block in the table
-      case ZKW_QUEUE_MEMORY: hipLaunchKernelGGL(zkw_leaf_kernel<ZKW_QUEUE_MEMORY>, grid, dim3(threads), 0, stream, *T); break;
-      case ZKW_QUEUE_LOG: hipLaunchKernelGGL(zkw_leaf_kernel<ZKW_QUEUE_LOG>, grid, dim3(threads), 0, stream, *T); break;
-      default: hipLaunchKernelGGL(zkw_leaf_kernel<ZKW_QUEUE_CODE_WORDS>, grid, dim3(threads), 0, stream, *T); break;
-    }
+    hipLaunchKernelGGL(zkw_leaf_kernel<ZKW_QUEUE_CODE_WORDS>, grid, dim3(threads), 0, stream, *T);  // code words only (upload)
   } else if (stage == ZKW_COMMIT_STAGE_BUCKET) {
-    hipLaunchKernelGGL(zkw_bucket_kernel, dim3(T->max_waves, T->n), dim3(wt), 0, stream, *T);
+    hipLaunchKernelGGL(zkw_bucket_kernel, dim3(T->max_waves, T->n, nq), dim3(wt), 0, stream, *T);
   } else if (stage == ZKW_COMMIT_STAGE_CHAIN) {
-    hipLaunchKernelGGL(zkw_chain_kernel, dim3(T->max_waves, T->n), dim3(wt), 0, stream, *T);
+    hipLaunchKernelGGL(zkw_chain_kernel, dim3(T->max_waves, T->n, nq), dim3(wt), 0, stream, *T);
   } else if (stage == ZKW_COMMIT_STAGE_BLOB_CHUNKS) {
     const u32 threads = wt > 1 ? 64 : 1;
     const u32 max_chunks = (T->max_cap + ZKW_BLOB_CHUNK_WORDS - 1) / ZKW_BLOB_CHUNK_WORDS;  // max_cap = words of the longest blob (upper bound: all words)

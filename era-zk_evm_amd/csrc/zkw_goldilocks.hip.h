@@ -237,3 +237,40 @@ ZD void gl_chain_step(const u64* rc, const u64 leaf[4], u64 tail[4], u64 index_p
 #pragma unroll
   for (int i = 0; i < 4; i++) tail[i] = s[i];
 }
+
+// Memory / log queues: the record is the input of the chain permutation (no leaf).  `w` = the record's 2K u32 words;
+// elements below 2^56: K pairs (even word | low 24 bits of the odd word << 32), then the dropped top bytes, seven per
+// element; every block of 7 elements is one permutation  tail' = P(e | tail | (j + 1) | queue << 40 | block << 48)[0..4].
+template <int K>
+ZD void gl_chain_record(const u64* rc, const u32 w[2 * K], u64 tail[4], u64 index_plus_1, u32 queue_id) {
+  constexpr int NE = K + (K + 6) / 7;  // elements
+  u64 e[NE];
+#pragma unroll
+  for (int i = 0; i < K; i++) e[i] = (u64)w[2 * i] | ((u64)(w[2 * i + 1] & 0xffffffu) << 32);
+#pragma unroll
+  for (int f = 0; f < (K + 6) / 7; f++) {
+    u64 x = 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++)
+      if (7 * f + i < K) x |= (u64)(w[2 * (7 * f + i) + 1] >> 24) << (8 * i);
+    e[K + f] = x;
+  }
+#pragma unroll 1
+  for (int b = 0; b < (NE + 6) / 7; b++) {
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+      u64 v = 0;
+#pragma unroll
+      for (int k = 0; k < NE; k++)
+        if (k == 7 * b + i) v = e[k];  // static indexing: `e` stays in registers
+      s[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[7 + i] = tail[i];
+    s[11] = index_plus_1 | ((u64)queue_id << 40) | ((u64)b << 48);
+    gl_permute(rc, s);
+#pragma unroll
+    for (int i = 0; i < 4; i++) tail[i] = s[i];
+  }
+}

@@ -780,9 +780,10 @@ int zkw_batch_upload(zkw_batch* b) {
     const uint32_t per_inst[3] = {b->lim.max_mem_queries, b->lim.max_log_queries, b->lim.max_aux_events};
     const uint32_t max_cap = std::max(caps[0], std::max(caps[1], caps[2]));
     const uint32_t max_per = std::max(per_inst[0], std::max(per_inst[1], per_inst[2]));
-    HIP_TRY(c, ensure(b->d_leaves, (size_t)b->n_waves * max_cap * 4));
-    HIP_TRY(c, ensure(b->d_idx, (size_t)b->n * max_per));
-    HIP_TRY(c, ensure(b->d_counts, b->n));
+    (void)max_cap; (void)max_per;
+    // per-instance index lists and counts of every queue side by side: the queues of a step are chained in ONE launch
+    HIP_TRY(c, ensure(b->d_idx, (size_t)b->n * ((size_t)per_inst[0] + per_inst[1] + per_inst[2])));
+    HIP_TRY(c, ensure(b->d_counts, (size_t)b->n * ZKW_QUEUE_COUNT));
     const uint4* streams[3] = {b->d_mem.p, b->d_log.p, b->d_auxs.p};
     zkw_commit_params CP[ZKW_QUEUE_COUNT];
     std::memset(CP, 0, sizeof CP);
@@ -791,7 +792,8 @@ int zkw_batch_upload(zkw_batch* b) {
       C.n_instances = b->n; C.L = b->L; C.n_waves = b->n_waves; C.max_cycles = b->lim.max_cycles; C.wave_threads = (uint32_t)c->wave_width;
       C.queue = q; C.cap = caps[q]; C.per_instance_cap = per_inst[q]; C.n_blobs = (uint32_t)b->blobs.size();
       C.rc = b->d_rc.p; C.stream = streams[q]; C.cursors = b->d_cursors.p; C.dir = b->d_dir.p; C.scalars = b->d_scalars.p;
-      C.blob_digests = b->d_blob_digests.p; C.blob_dir = b->d_blob_dir.p; C.leaves = b->d_leaves.p; C.idx = b->d_idx.p; C.counts = b->d_counts.p;
+      C.blob_digests = b->d_blob_digests.p; C.blob_dir = b->d_blob_dir.p; C.leaves = nullptr;
+      C.idx = b->d_idx.p + (size_t)b->n * (q == 0 ? 0 : (q == 1 ? per_inst[0] : (size_t)per_inst[0] + per_inst[1])); C.counts = b->d_counts.p + (size_t)b->n * q;
       C.out = b->d_commit.p; C.midstates = b->d_midstates.p; C.preimages = b->d_preimages.p; C.n_preimages = (uint32_t)b->preimages.size();
     }
     HIP_TRY(c, ensure(b->d_commit_params, ZKW_QUEUE_COUNT + 1));
@@ -915,6 +917,7 @@ static int enqueue_commit(zkw_batch* const* bs, uint32_t n, uint32_t queue_mask,
   for (uint32_t i = 0; i < n; i++)
     if (!bs[i]->ran) return ZKW_ERR_NOT_RUN;
   HIP_TRY(c, hipSetDevice(c->device));
+  uint32_t todo = 0;
   for (uint32_t q = 0; q < ZKW_QUEUE_COUNT; q++) {
     if (!((queue_mask >> q) & 1u)) continue;
     if (q == ZKW_QUEUE_DECOMMIT) {  // already chained by the cycle kernel (op_far_call) when the run was part of a fused step
@@ -927,22 +930,27 @@ static int enqueue_commit(zkw_batch* const* bs, uint32_t n, uint32_t queue_mask,
           return ZKW_ERR_INVALID;
         }
     }
-    zkw_fused_table T;
-    std::memset(&T, 0, sizeof T);
-    T.n = n;
-    T.reserved[0] = q;
-    T.wave_threads = (uint32_t)c->wave_width;
-    for (uint32_t i = 0; i < n; i++) {
-      const uint32_t caps[3] = {bs[i]->cap_mem, bs[i]->cap_log, bs[i]->cap_aux};
-      T.p[i] = bs[i]->d_commit_params.p + q;
-      T.max_waves = std::max(T.max_waves, bs[i]->n_waves);
-      T.max_cap = std::max(T.max_cap, caps[q]);
-    }
-    // the decommit queue has a handful of records per instance: its leaves are computed inside the chain kernel
-    if (q != ZKW_QUEUE_DECOMMIT) HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_LEAF, st));
-    HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_BUCKET, st));
-    HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_CHAIN, st));
+    todo |= 1u << q;
   }
+  if (!todo) return ZKW_OK;
+  // One bucket launch and one chain launch for all requested queues (grid.z = queue): the chains of a queue are sequential
+  // per instance, so the queues side by side double / triple the waves that hide each other's latency.  No leaf pass: the
+  // chain kernel hashes the records themselves (memory / log) or uses the cached leaf of the code (decommit).
+  zkw_fused_table T;
+  std::memset(&T, 0, sizeof T);
+  T.n = n;
+  T.reserved[0] = 0;
+  T.reserved[1] = todo;  // queue mask: T.p[i] is the batch's parameter block of queue 0, the kernels index it by queue
+  T.wave_threads = (uint32_t)c->wave_width;
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t caps[3] = {bs[i]->cap_mem, bs[i]->cap_log, bs[i]->cap_aux};
+    T.p[i] = bs[i]->d_commit_params.p;
+    T.max_waves = std::max(T.max_waves, bs[i]->n_waves);
+    for (uint32_t q = 0; q < ZKW_QUEUE_COUNT; q++)
+      if ((todo >> q) & 1u) T.max_cap = std::max(T.max_cap, caps[q]);
+  }
+  HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_BUCKET, st));
+  HIP_TRY(c, zkw_launch_commit(&T, ZKW_COMMIT_STAGE_CHAIN, st));
   return ZKW_OK;
 }
 

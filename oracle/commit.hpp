@@ -1,5 +1,5 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.
-// CPU restatement of the build's OWN queue-commitment spec "ZKW-GL-sponge v1" (DESIGN.md
+// CPU restatement of the build's OWN queue-commitment spec "ZKW-GL-sponge v2" (DESIGN.md
 // §commitments).  The reference has no sponge / queue commitment at all, so this
 // checks the HIP kernels (era-zk_evm_amd/csrc/zkw_commit.hip) against an independently written
 // implementation of the same spec — arithmetic here is plain `unsigned __int128 % p`.
@@ -114,31 +114,66 @@ inline Digest blob_digest(const Perm& perm, const zkw_u256* words, size_t n) {
   return top;
 }
 
+// Memory and log queues: the record itself is the input of the chain permutation — no leaf.  A record of 2k u32 words
+// w[0..2k) is packed into field elements below 2^56 (a 64-bit value need not be a canonical element, 7 bytes always are):
+// element i < k = w[2i] | (w[2i+1] & 0xffffff) << 32, then the k dropped top bytes of the odd words, seven per element.
+// Each block of 7 elements is one permutation:  tail' = P(e[7b..7b+7) | tail | (j + 1) | queue << 40 | b << 48)[0..4].
+// A memory query (12 words -> 6 + 1 elements) is one permutation, a log query (32 words -> 16 + 3) is three.
+inline std::vector<uint64_t> pack56(const std::vector<uint32_t>& w) {
+  std::vector<uint64_t> e;
+  const size_t k = w.size() / 2;
+  for (size_t i = 0; i < k; i++) e.push_back((uint64_t)w[2 * i] | ((uint64_t)(w[2 * i + 1] & 0xffffffu) << 32));
+  for (size_t first = 0; first < k; first += 7) {
+    uint64_t x = 0;
+    for (size_t i = first; i < k && i < first + 7; i++) x |= (uint64_t)(w[2 * i + 1] >> 24) << (8 * (i - first));
+    e.push_back(x);
+  }
+  return e;
+}
+inline void chain_record(const Perm& perm, const std::vector<uint64_t>& e, Digest& tail, uint64_t index_plus_1, uint32_t queue_id) {
+  for (size_t b = 0; b * 7 < e.size(); b++) {
+    uint64_t s[12] = {0};
+    for (size_t i = 0; i < 7 && b * 7 + i < e.size(); i++) s[i] = e[b * 7 + i];
+    for (int i = 0; i < 4; i++) s[7 + i] = tail.v[i];
+    s[11] = index_plus_1 | ((uint64_t)queue_id << 40) | ((uint64_t)b << 48);
+    perm(s);
+    for (int i = 0; i < 4; i++) tail.v[i] = s[i];
+  }
+}
+inline std::vector<uint32_t> words32(const zkw_u256& v) {
+  std::vector<uint32_t> r;
+  for (int i = 0; i < 4; i++) {
+    r.push_back((uint32_t)v.l[i]);
+    r.push_back((uint32_t)(v.l[i] >> 32));
+  }
+  return r;
+}
+
 inline Digest mem_queue(const Perm& perm, const zkw_mem_query* q, size_t n) {
   Digest tail{{0, 0, 0, 0}};
   for (size_t j = 0; j < n; j++) {
-    std::vector<uint64_t> f = {q[j].timestamp, q[j].page, q[j].index, q[j].meta};
-    auto v = limbs(q[j].value);
-    f.insert(f.end(), v.begin(), v.end());
-    chain_step(perm, leaf(perm, 1, f), tail, j + 1, ZKW_QUEUE_MEMORY);
+    std::vector<uint32_t> w = {q[j].timestamp, q[j].page, q[j].index, q[j].meta};
+    auto v = words32(q[j].value);
+    w.insert(w.end(), v.begin(), v.end());
+    chain_record(perm, pack56(w), tail, j + 1, ZKW_QUEUE_MEMORY);
   }
   return tail;
 }
 inline Digest log_queue(const Perm& perm, const zkw_log_query* q, size_t n) {
   Digest tail{{0, 0, 0, 0}};
   for (size_t j = 0; j < n; j++) {
-    std::vector<uint64_t> f = {q[j].timestamp, q[j].tx_number_in_block,
-                               (uint64_t)q[j].aux_byte | ((uint64_t)q[j].shard_id << 8) | ((uint64_t)q[j].bools << 16) | ((uint64_t)q[j].kind << 24)};
+    std::vector<uint32_t> w = {q[j].timestamp, q[j].tx_number_in_block,
+                               (uint32_t)q[j].aux_byte | ((uint32_t)q[j].shard_id << 8) | ((uint32_t)q[j].bools << 16) | ((uint32_t)q[j].kind << 24)};
     for (int a = 0; a < 5; a++) {
-      uint32_t w;
-      std::memcpy(&w, q[j].address + 4 * a, 4);
-      f.push_back(w);
+      uint32_t x;
+      std::memcpy(&x, q[j].address + 4 * a, 4);
+      w.push_back(x);
     }
     for (const zkw_u256* x : {&q[j].key, &q[j].read_value, &q[j].written_value}) {
-      auto v = limbs(*x);
-      f.insert(f.end(), v.begin(), v.end());
+      auto v = words32(*x);
+      w.insert(w.end(), v.begin(), v.end());
     }
-    chain_step(perm, leaf(perm, 2, f), tail, j + 1, ZKW_QUEUE_LOG);
+    chain_record(perm, pack56(w), tail, j + 1, ZKW_QUEUE_LOG);
   }
   return tail;
 }
