@@ -2,7 +2,7 @@
 //
 // The reference crate has NO sponge or queue commitment (only a comment, far_call.rs:29-32, and a
 // dead stub, vm_state/aux_data.rs:1-6): downstream circuits own that.  This file implements the
-// build's OWN spec ("ZKW-GL-sponge v1") so that the north star's
+// build's OWN spec ("ZKW-GL-sponge v2") so that the north star's
 // "algebraic sponge absorb over the emitted queues" and the multi-GPU final reduction have something
 // concrete and testable; oracle/commit.hpp restates the same spec on the CPU.  PARITY UNPINNED w.r.t.
 // any real zkEVM circuit format.
@@ -10,12 +10,14 @@
 //   field   Goldilocks p = 2^64 - 2^32 + 1, canonical representatives
 //   P       Poseidon2-shaped permutation, t = 12, x^7, 4 + 22 + 4 rounds, external layer
 //           circ(2 M4, M4, M4), internal layer J + diag(2^i), constants from splitmix64("zkwGLv1")
-//   leaf    sponge (rate 8 / capacity 4) over the record's u32 limbs, domain = (type, length)
-//   chain   tail' = P(leaf || tail || i+1 || queue id || 0 || 0)[0..4]
+//   memory / log record   its u32 words packed into elements below 2^56 (zkw_goldilocks.hip.h: gl_chain_record); every
+//           block of 7 elements is one permutation  tail' = P(e || tail || (j+1) | queue << 40 | block << 48)[0..4]
+//   decommit record       leaf = sponge (rate 8, domain (type, length)) over code hash | blob length | blob digest, cached
+//           per preimage at upload;  tail' = P(leaf || tail || j+1 || queue || timestamp | fresh << 32 || page)[0..4]
+//   code words (blob digests, upload only)  sponge leaf per word, chunk chains, one chain over the chunk tails
 //
-// Parallel structure on the GPU: leaves are hashed one record per lane over the dense wave streams
-// (embarrassingly parallel, coalesced), a bucket pass turns the lane tags of each wave stream into
-// per-instance index lists, and the sequential chains then run one instance per lane in lockstep.
+// Parallel structure on the GPU: a bucket pass turns the lane tags of each wave stream into per-instance index lists,
+// and the sequential chains run one instance per lane in lockstep, all queues of a step in one launch.
 #include <hip/hip_runtime.h>
 
 #include "zkw_device.h"

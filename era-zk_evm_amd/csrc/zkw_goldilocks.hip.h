@@ -1,4 +1,4 @@
-// Goldilocks field arithmetic and the "ZKW-GL-sponge v1" permutation / leaf / chain step (the build's own spec, see
+// Goldilocks field arithmetic and the "ZKW-GL-sponge v2" permutation / leaf / chain step (the build's own spec, see
 // zkw_commit.hip and DESIGN.md §commitments).  Shared by the commitment kernels (zkw_commit.hip) and by the cycle kernel,
 // which chains the decommit queue while it runs (zkw_kernels.hip: op_far_call).
 #pragma once
