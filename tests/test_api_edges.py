@@ -101,3 +101,25 @@ def test_download_all_reports_the_trace_volume(emu, isa):
     # tails 32 B per cycle + 32 B per register delta + the query records (+ the directory)
     expect = 32 * int(st["cycles"]) + 32 * int(st["reg_deltas"]) + 48 * int(st["mem_queries"]) + 128 * int(st["log_queries"]) + 256 * int(st["aux_events"])
     assert expect <= nb.value <= expect + 4 * (wl.n_cycles + 1) * 16
+
+
+def test_trace_pointers_stay_valid_across_more_than_64_waves(emu, isa):
+    """include/zkw.h: the arrays of a zkw_instance_trace stay valid until the next run, reset or destroy.  With one lane per
+    wave every instance is its own wave: fetch the traces of 80 waves keeping the RAW pointers (as the C++ mirror does),
+    then re-read the first ones through those pointers — the runtime must not have evicted them (round-1 finding)."""
+    import ctypes as C
+    wl = synth.make(2, isa, n_instances=80)
+    wl.limits["lanes_per_wave"] = 1
+    b = emu.create_batch(wl)
+    b.reset(); b.run(wl.n_cycles); b.sync()
+    raw, copies = [], []
+    for i in range(wl.n_instances):
+        t = K.InstanceTraceC()
+        emu.call("batch_get_instance_trace", b.h, C.c_uint32(i), C.byref(t))
+        raw.append(t)
+        copies.append((C.string_at(t.records, t.n_cycles * K.CYCLE_RECORD.itemsize), C.string_at(t.mem, t.n_mem * K.MEM_QUERY.itemsize)))
+    for i in (0, 1, 17, 63, 64, 79):
+        t = raw[i]
+        assert C.string_at(t.records, t.n_cycles * K.CYCLE_RECORD.itemsize) == copies[i][0], i
+        assert C.string_at(t.mem, t.n_mem * K.MEM_QUERY.itemsize) == copies[i][1], i
+    b.destroy()
