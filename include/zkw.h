@@ -453,7 +453,7 @@ int zkw_batches_reset(zkw_batch* const* batches, uint32_t n_batches, void* hip_s
 int zkw_batches_run(zkw_batch* const* batches, uint32_t n_batches, uint32_t max_cycles, void* hip_stream);
 int zkw_batches_commit(zkw_batch* const* batches, uint32_t n_batches, uint32_t queue_mask, void* hip_stream);
 /* zkw_batches_run for callers that will commit the queues of `queue_mask` afterwards: the cycle kernel chains what it
- * can chain while it runs (the decommit queue: a handful of sponge permutations inside every far call) and a later
+ * can chain while it runs (the decommit queue: one sponge permutation inside every far call that decommits) and a later
  * zkw_batches_commit / zkw_batch_commit skips those queues.  zkw_batches_step does the same implicitly. */
 int zkw_batches_run_committing(zkw_batch* const* batches, uint32_t n_batches, uint32_t max_cycles, uint32_t queue_mask, void* hip_stream);
 /* mean device time (ms) of the cycle-kernel launches recorded on this batch since the last call / sync — HIP event
