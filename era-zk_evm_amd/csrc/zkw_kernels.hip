@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "zkw_device.h"
 #include "zkw_u256.hip.h"
@@ -527,6 +528,38 @@ ZD void rf_set(RegFile&, u32 reg, const u256& v) {
 ZD void rf_init(RegFile&) {
   asm volatile("v_mov_b32 v129, 0\n\tv_mov_b32 v255, 0" : : : "v128", "v129", "v255");  // (v128 holds the stream cursors: not touched here)
 }
+// The same register file addressed with a PER-LANE register number (variant grouping, zkw_vec_exec): a waterfall — take
+// the first remaining lane's number, serve every lane that holds the same one with the scalar-indexed access, repeat.
+// One pass per distinct register number among the lanes of the group (at most 16).
+struct RegFileVec {};
+#define ZKW_RF_IS_VEC(RF) (std::is_same<RF, RegFileVec>::value)
+// Written as a wave-uniform loop over the lanes still to serve with the access under a divergent `if` inside it — not as
+// the textbook `for (;;) { r = readfirstlane(reg); if (reg == r) { access; break; } }`: there the access sits on the loop's
+// exit path, the optimiser moves it behind the loop (same thing for one thread), and behind a divergent loop it runs ONCE,
+// for all lanes, with the first lane's register.
+ZD u256 rf_get(const RegFileVec&, u32 reg) {
+  u256 v = u256_zero();
+  u64 todo = __ballot(1);
+  while (todo) {
+    const u32 r = (u32)__builtin_amdgcn_readlane((int)reg, (int)((u32)__ffsll((long long)todo) - 1u));
+    const bool m = reg == r;
+    if (m) v = rf_get(RegFile(), r);
+    todo &= ~__ballot(m);
+  }
+  return v;
+}
+ZD void rf_set(RegFileVec&, u32 reg, const u256& v) {
+  u64 todo = __ballot(1);
+  while (todo) {
+    const u32 r = (u32)__builtin_amdgcn_readlane((int)reg, (int)((u32)__ffsll((long long)todo) - 1u));
+    const bool m = reg == r;
+    if (m) {
+      RegFile f;
+      rf_set(f, r, v);
+    }
+    todo &= ~__ballot(m);
+  }
+}
 #else  // single-lane CPU emulation build of tests/emu
 struct RegFile {
   u256 r[16];
@@ -534,12 +567,16 @@ struct RegFile {
 ZD u256 rf_get(const RegFile& rf, u32 reg) { return rf.r[reg]; }
 ZD void rf_set(RegFile& rf, u32 reg, const u256& v) { rf.r[reg] = v; }
 ZD void rf_init(RegFile& rf) { rf.r[0] = u256_zero(); }
+typedef RegFile RegFileVec;  // (the single-lane emulation build never forms a variant group)
+#define ZKW_RF_IS_VEC(RF) false
 #endif
-ZD u256 reg_read(Shared& sh, const RegFile& rf, const Lane& s, u32 idx, bool& is_ptr) {
-  is_ptr = idx != 0 && ((s.ptr_bitmap >> (idx - 1)) & 1u);
+template <class RF>
+ZD u256 reg_read(Shared& sh, const RF& rf, const Lane& s, u32 idx, u32& is_ptr) {
+  is_ptr = ((s.ptr_bitmap << 1) >> idx) & 1u;  // bit idx - 1, nothing for r0 (no `idx - 1` shift count: undefined for a per-lane idx of 0)
   return rf_get(rf, idx);
 }
-ZD void reg_write(Shared& sh, RegFile& rf, Lane& s, u32 idx, const u256& v, bool is_ptr) {
+template <class RF>
+ZD void reg_write(Shared& sh, RF& rf, Lane& s, u32 idx, const u256& v, bool is_ptr) {
   if (idx == 0) return;
   const u32 r = idx - 1;
   rf_set(rf, idx, v);
@@ -561,14 +598,14 @@ ZD u32 page_word_index(const Shared& sh, const Lane& s, u32 slot, u32 words_per_
 }
 
 // MemoryType::Stack read of the current frame (memory.rs:427-436)
-ZD u256 stack_read(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, bool& is_ptr) {
+ZD u256 stack_read(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, u32& is_ptr) {
   s.lane = zkw_lane_id();  // fresh, short-lived lane index (see struct Lane)
-  is_ptr = false;
+  is_ptr = 0;
   // a word that was never written reads as zero in the reference (the stack page is a zero-filled Vec); only WRITES
   // need capacity, and stack_hwm <= S
   if (idx >= CF(sh, s, CF_STACK_HWM)) return u256_zero();
   const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), sh.S, idx);
-  is_ptr = zkw_gload1(sh.stack_ptrs + w) != 0;
+  is_ptr = zkw_gload1(sh.stack_ptrs + w) != 0 ? 1u : 0u;
   return u256_from_uint4(zkw_gload4(sh.stack_vals + (2 * w - s.lane)), zkw_gload4(sh.stack_vals + (2 * w - s.lane + sh.L)));
 }
 // MemoryType::Stack write (memory.rs:413-425)
@@ -883,7 +920,8 @@ ZD Operand compute_address(ZKW_KP P, const Shared& sh, Lane& s, u32& sp, const u
 }
 
 // perform_dst0_update (helpers.rs:266-283)
-ZD void dst0_update(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Operand& dst0, u32 dst0_idx, const u256& v, bool is_ptr) {
+template <class RF>
+ZD void dst0_update(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Operand& dst0, u32 dst0_idx, const u256& v, bool is_ptr) {
   s.lane = zkw_lane_id();  // fresh, short-lived lane index (see struct Lane)
   if (dst0.has_loc) {
     stack_write(P, sh, s, dst0.index, v, is_ptr);
@@ -975,7 +1013,9 @@ struct Decoded {
 };
 struct Pre {  // PreState (cycle.rs:8-14)
   u256 src0, src1;
-  bool src0_ptr, src1_ptr;
+  // (0 / 1 in vector registers, not `bool`: as lane masks carried through the divergent operand phase of the variant-group
+  // instantiation they were mis-merged — an operand that was no pointer lost its fat-pointer metadata)
+  u32 src0_ptr, src1_ptr;
   Operand dst0;
   u32 new_pc;
 };
@@ -1017,7 +1057,8 @@ ZD void op_near_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre&
 }
 
 // context.rs:6-111
-ZD void op_context(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, const Pre& ps) {
+template <class RF>
+ZD void op_context(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pre& ps) {
   s.pc = ps.new_pc;
   const u32 v = ZKW_ATTR_VARIANT(d.attr);
   u256 value = u256_zero();
@@ -1064,7 +1105,8 @@ ZD void op_context(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d,
 }
 
 // ptr.rs:6-194
-ZD void op_ptr(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, const Pre& ps) {
+template <class RF>
+ZD void op_ptr(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pre& ps) {
   s.pc = ps.new_pc;
   const u32 v = ZKW_ATTR_VARIANT(d.attr);
   if (!ps.src0_ptr || ps.src1_ptr) {  // :35-45
@@ -1109,7 +1151,8 @@ ZD void op_ptr(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, con
 }
 
 // uma.rs:26-425
-ZD void op_uma(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d, const Pre& ps) {
+template <class RF>
+ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pre& ps) {
   ZKW_SUB_DECL
   s.lane = zkw_lane_id();
   const u32 v = ZKW_ATTR_VARIANT(d.attr);
@@ -1877,9 +1920,43 @@ static __device__ __noinline__ zkw_v16 zkw_heavy_log_precompile(zkw_v16 a, zkw_v
 static __device__ __noinline__ zkw_v16 zkw_heavy_near_call(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_NEAR_CALL, 0>(a, b); }
 static __device__ __noinline__ zkw_v16 zkw_heavy_far_call(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_FAR_CALL, 0>(a, b); }
 static __device__ __noinline__ zkw_v16 zkw_heavy_ret(zkw_v16 a, zkw_v16 b) { return zkw_heavy_body<ZKW_OP_RET, 0>(a, b); }
+// A variant group's cycle (exec_decoded: `vec`): the lanes share the packed ISA entry (opcode, variant, addressing modes)
+// but hold different register numbers and immediates, so the decode of those fields is per lane and the register file
+// is reached through the waterfall accessors of RegFileVec.  a: lane state + [12] / [13] the lane's OWN instruction word,
+// [14] the shared ISA entry, [15] = 1.  Result: the lane state.
+template <class RF>
+ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bool vec, u32 vec_lo, u32 vec_hi);
+static __device__ __noinline__ zkw_v16 zkw_vec_exec(zkw_v16 a, zkw_v16 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const u32 wib = zkw_uniform(threadIdx.x / ZKW_WAVE);
+  const uint4 hdr = *(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + wib * zkw_wave_lds_units() + 1);  // written by the kernel prologue
+  const zkw_kparams ZKW_CONST_AS* Pp = (const zkw_kparams ZKW_CONST_AS*)(((u64)zkw_uniform(hdr.y) << 32) | zkw_uniform(hdr.x));
+  ZKW_KP P = *Pp;
+  Shared sh;
+  shared_setup(sh, P, zkw_uniform(hdr.z), wib, blockIdx.x * P.waves_per_group + wib, false);
+  Lane s;
+  s.lane = zkw_lane_id();
+  lane_unpack(s, a);
+  const u32 lo = a[12], hi = a[13];  // per lane
+  Decoded d;
+  d.word_lo = lo; d.word_hi = hi;
+  d.attr = zkw_uniform(a[14]);
+  d.cond = (lo >> 13) & 7u; d.src0 = (lo >> 16) & 15u; d.src1 = (lo >> 20) & 15u; d.dst0 = (lo >> 24) & 15u; d.dst1 = lo >> 28;
+  d.imm0 = hi & 0xffffu; d.imm1 = hi >> 16;
+  RegFileVec rf;
+  exec_decoded(P, sh, rf, s, d, false, 0u, 0u);
+  s.lane = zkw_lane_id();
+  return lane_pack(s);
+#else
+  (void)b;
+  return a;  // never reached in the single-lane emulation build
+#endif
+}
+
 // One call site in the cycle loop (several would change the register allocation of the whole loop): the dispatcher
 // forwards its own arguments, so each branch is a tail call (a scalar jump; the opcode travels in a[14]).
 static __device__ __noinline__ zkw_v16 zkw_heavy_entry(zkw_v16 a, zkw_v16 b) {
+  if (zkw_uniform(a[15])) return zkw_vec_exec(a, b);  // a variant group, not a heavy body
   const u32 attr = zkw_uniform(a[14] & 0x3fffffffu);
   const u32 opcode = ZKW_ATTR_OPCODE(attr);
   if (opcode == ZKW_OP_LOG) {
@@ -1913,7 +1990,15 @@ ZD bool condition_resolved(u32 cond, u32 flags) {
 // depends on the opcode, the addressing modes or the register indices is a scalar branch; only the data
 // path (256-bit values, sp, ergs, memory addresses) is per lane.
 // ---------------------------------------------------------------------------------------------
-ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& d) {
+// RF = RegFile: the scalar decode of a word group (register numbers are wave-uniform).  `vec` (wave-uniform) marks a VARIANT
+// group instead — lanes that share the ISA entry but not the register numbers / immediates: their cycle runs out of line
+// (zkw_vec_exec) in the RF = RegFileVec instantiation of this function, where `d`'s operand fields are per-lane values and
+// the register file is reached through a waterfall.  Both out-of-line paths leave through ONE call (the heavy bodies and
+// the variant groups share the dispatcher zkw_heavy_entry): a second call site changes the register allocation of the
+// whole cycle loop.
+template <class RF>
+ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bool vec, u32 vec_lo, u32 vec_hi) {
+  constexpr bool IS_VEC = ZKW_RF_IS_VEC(RF);
   const u32 opcode = ZKW_ATTR_OPCODE(d.attr);
   const u32 props = ZKW_ATTR_PROPS(d.attr);
   const bool set_flags = ZKW_ATTR_FLAGS(d.attr) & 1u;
@@ -1923,9 +2008,18 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
   // operands (cycle.rs:275-350)
   // ----------------------------------------------------------------------------------------
   Pre ps;
+  bool call_out = false;  // this lane leaves through the out-of-line call below
+  zkw_v16 oa, ob;
+#pragma unroll
+  for (int i = 0; i < 16; i++) oa[i] = ob[i] = 0;
+  if (!IS_VEC && vec) {  // wave-uniform
+    oa = lane_pack(s);
+    oa[12] = vec_lo; oa[13] = vec_hi; oa[14] = d.attr; oa[15] = 1u;
+    call_out = true;
+  } else {
   u32 sp = s.sp;
   // all register-file reads of the cycle are issued back to back (one LDS round trip instead of three)
-  bool src0_reg_ptr, dummy_ptr;
+  u32 src0_reg_ptr, dummy_ptr;
   const u256 src0_reg = reg_read(sh, rf, s, d.src0, src0_reg_ptr);
   ps.src1 = reg_read(sh, rf, s, d.src1, ps.src1_ptr);  // :339
   const u256 dst0_reg = ZKW_ATTR_DST0(d.attr) == ZKW_MODE_REG ? u256_zero() : reg_read(sh, rf, s, d.dst0, dummy_ptr);  // only addressing modes use it
@@ -1935,7 +2029,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
   s.sp = sp;                                            // :297
   if (opcode == ZKW_OP_NOP) src0_loc.has_loc = false;  // :298-301
   u256 src0_mem = u256_zero();
-  bool src0_mem_ptr = false;
+  u32 src0_mem_ptr = 0;
   ZKW_SUB(68)  // operands: addresses
   if (src0_loc.has_loc) {  // :304-325
     if (src0_loc.type == ZKW_MEM_CODE) src0_mem = code_read(sh, s, src0_loc.index);
@@ -1949,7 +2043,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
     ps.src0_ptr = src0_reg_ptr;
   } else if (src0_mode == ZKW_MODE_IMM) {
     ps.src0 = u256_from_u32(d.imm0);
-    ps.src0_ptr = false;
+    ps.src0_ptr = 0;
   } else {
     ps.src0 = src0_mem;
     ps.src0_ptr = src0_mem_ptr;
@@ -1962,7 +2056,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
       ps.src0.w[i] = sw ? b : a;
       ps.src1.w[i] = sw ? a : b;
     }
-    const bool ap = ps.src0_ptr, bp = ps.src1_ptr;
+    const u32 ap = ps.src0_ptr, bp = ps.src1_ptr;
     ps.src0_ptr = sw ? bp : ap;
     ps.src1_ptr = sw ? ap : bp;
   }
@@ -1971,12 +2065,12 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
     if (!(props & ZKW_PROP_SRC0_PTR_OK) && ps.src0_ptr) {
       ps.src0.w[1] = 0;
       ps.src0.w[2] = 0;
-      ps.src0_ptr = false;
+      ps.src0_ptr = 0;
     }
     if (!(props & ZKW_PROP_SRC1_PTR_OK) && ps.src1_ptr) {
       ps.src1.w[1] = 0;
       ps.src1.w[2] = 0;
-      ps.src1_ptr = false;
+      ps.src1_ptr = 0;
     }
   }
   // ----------------------------------------------------------------------------------------
@@ -2056,49 +2150,63 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RegFile& rf, Lane& s, const Decoded& 
       case ZKW_OP_NEAR_CALL:
       case ZKW_OP_FAR_CALL:
       case ZKW_OP_RET: {  // out of line; what they write to registers comes back as actions
+        if (IS_VEC) {  // (a variant group never holds a heavy opcode: see the group selection)
+          lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
+          break;
+        }
         ZKW_STAMP0
         if (opcode == ZKW_OP_FAR_CALL) {  // CALL_IMPLICIT_PARAMETER_REG_IDX, far_call.rs:506-508
           const u256 r15 = rf_get(rf, 15);
 #pragma unroll
           for (int i = 0; i < 8; i++) ZKW_XFER(sh, s, i) = r15.w[i];
         }
-        zkw_v16 a = lane_pack(s), b;
-        a[12] = d.word_lo; a[13] = d.word_hi; a[14] = d.attr | ((ps.src0_ptr ? 1u : 0u) << 30) | ((ps.src1_ptr ? 1u : 0u) << 31);
+        oa = lane_pack(s);
+        oa[12] = d.word_lo; oa[13] = d.word_hi; oa[14] = d.attr | ((ps.src0_ptr ? 1u : 0u) << 30) | ((ps.src1_ptr ? 1u : 0u) << 31);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-          b[i] = ps.src0.w[i];
-          b[8 + i] = ps.src1.w[i];
+          ob[i] = ps.src0.w[i];
+          ob[8 + i] = ps.src1.w[i];
         }
-        const zkw_v16 r = zkw_heavy_entry(a, b);
-        lane_unpack(s, r);
-        s.lane = zkw_lane_id();
-        ZKW_STAMP(55)  // return + epilogue of the callee
-        const u32 action = r[12];
-        u256 v1 = u256_zero();
-        if (action & (ZKW_ACT_DST0 | ZKW_ACT_FAR | ZKW_ACT_RET)) {
-#pragma unroll
-          for (int i = 0; i < 8; i++) v1.w[i] = ZKW_XFER(sh, s, i);
-        }
-        if (action & ZKW_ACT_DST0) dst0_update(P, sh, rf, s, ps.dst0, d.dst0, v1, false);
-        if (action & (ZKW_ACT_FAR | ZKW_ACT_RET)) {
-          reg_write(sh, rf, s, 1, v1, true);
-          reg_write(sh, rf, s, 2, u256_from_u32(r[13]), false);  // ret: zero
-          if (action & ZKW_ACT_TO_SYSTEM) {
-            s.ptr_bitmap &= ~(0x3ffu << 2);  // CALL_SYSTEM_ABI_REGISTERS = 2..12: drop the pointer markers only
-          } else {
-#pragma unroll
-            for (u32 r = 3; r <= 12; r++) reg_write(sh, rf, s, r, u256_zero(), false);
-          }
-#pragma unroll
-          for (u32 r = 13; r <= 15; r++) reg_write(sh, rf, s, r, u256_zero(), false);
-        }
-        ZKW_STAMP(56)  // actions
+        call_out = true;
         break;
       }
       case ZKW_OP_UMA: op_uma(P, sh, rf, s, d, ps); break;
       default: lane_fail(s, ZKW_STATUS_REFERENCE_PANIC); break;  // Opcode::Invalid => unreachable!() parsing.rs:77
     }
   }
+  }  // !vec
+#if defined(__HIP_DEVICE_COMPILE__) || defined(ZKW_EMU_BUILD)
+  if constexpr (!IS_VEC) {
+  if (call_out) {
+    const zkw_v16 r = zkw_heavy_entry(oa, ob);
+    lane_unpack(s, r);
+    s.lane = zkw_lane_id();
+    ZKW_STAMP(55)  // return + epilogue of the callee
+    if (!vec) {
+      const u32 action = r[12];
+      u256 v1 = u256_zero();
+      if (action & (ZKW_ACT_DST0 | ZKW_ACT_FAR | ZKW_ACT_RET)) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) v1.w[i] = ZKW_XFER(sh, s, i);
+      }
+      if (action & ZKW_ACT_DST0) dst0_update(P, sh, rf, s, ps.dst0, d.dst0, v1, false);
+      if (action & (ZKW_ACT_FAR | ZKW_ACT_RET)) {
+        reg_write(sh, rf, s, 1, v1, true);
+        reg_write(sh, rf, s, 2, u256_from_u32(r[13]), false);  // ret: zero
+        if (action & ZKW_ACT_TO_SYSTEM) {
+          s.ptr_bitmap &= ~(0x3ffu << 2);  // CALL_SYSTEM_ABI_REGISTERS = 2..12: drop the pointer markers only
+        } else {
+#pragma unroll
+          for (u32 q = 3; q <= 12; q++) reg_write(sh, rf, s, q, u256_zero(), false);
+        }
+#pragma unroll
+        for (u32 q = 13; q <= 15; q++) reg_write(sh, rf, s, q, u256_zero(), false);
+      }
+      ZKW_STAMP(56)  // actions
+    }
+  }
+  }
+#endif
 }
 
 // =============================================================================================
@@ -2322,11 +2430,30 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
         if (A.debug_flags & 4u) mine = lane_now == leader;  // test hook: one lane per group
         const u32 u_attr = (u32)__builtin_amdgcn_readlane((int)me.z, (int)leader);
         const u32 u_price = (u32)__builtin_amdgcn_readlane((int)me.w, (int)leader);
+        // Variant grouping.  When lanes are left over that do not hold the leader's word (the wave runs different
+        // programs), widen the group to every waiting lane with the leader's ISA entry — same opcode, variant, addressing
+        // modes and price, any register numbers / immediates / condition — if that serves more lanes: their cycle then
+        // runs with per-lane operand decode (zkw_vec_exec).  Not for the heavy opcodes, whose out-of-line bodies take the
+        // instruction word as a scalar.  A shared tape never gets here (its first group is all of `todo`).
+        bool vec = false;
+#ifdef __HIP_DEVICE_COMPILE__
+        if ((__ballot(mine) != todo || (A.debug_flags & (1u << 24))) && !(A.debug_flags & 4u)) {  // (bit 24: every group the variant way — test hook)
+          const u32 u_op = ZKW_ATTR_OPCODE(u_attr);
+          if (u_op != ZKW_OP_LOG && u_op != ZKW_OP_NEAR_CALL && u_op != ZKW_OP_FAR_CALL && u_op != ZKW_OP_RET &&
+              !((A.debug_flags >> (8u + u_op)) & 1u)) {  // (debug_flags bits 8..23: opcodes kept out of variant groups — test hook)
+            const bool wide = zkw_lane_bit(todo) && me.z == u_attr && me.w == u_price && charged == u_charged;
+            if (__popcll(__ballot(wide)) > __popcll(__ballot(mine)) || (A.debug_flags & (1u << 24))) {
+              mine = wide;
+              vec = true;
+            }
+          }
+        }
+#endif
         if (!u_charged) {  // uniform: first visit of this opcode word
           if (mine) {
             const bool err = decode_exception(max_depth, s, u_attr, u_price);  // :142-184
             if (s.ergs < u_price) s.ergs = 0; else s.ergs -= u_price;  // :153-161
-            const bool nop = !err && !condition_resolved((u_lo >> 13) & 7u, s.flags);
+            const bool nop = !err && !condition_resolved((me.x >> 13) & 7u, s.flags);  // (the lane's own condition: a variant group mixes them)
             s.kflags |= KF_CHARGED;
             if (err | nop) {
               // mask_into_panic (:187-190) / mask_into_nop (:212-217): the lane re-enters the loop as a member of
@@ -2348,7 +2475,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
           d.cond = (u_lo >> 13) & 7u; d.src0 = (u_lo >> 16) & 15u; d.src1 = (u_lo >> 20) & 15u; d.dst0 = (u_lo >> 24) & 15u; d.dst1 = u_lo >> 28;
           d.imm0 = u_hi & 0xffffu; d.imm1 = u_hi >> 16;
           if (A.debug_flags & 8u) s.pc = (s.pc + 1u) & 0xffffu;  // profiling ablation: no operand / opcode work
-          else exec_decoded(P, sh, rf, s, d);
+          else exec_decoded(P, sh, rf, s, d, vec, me.x, me.y);
 #ifdef ZKW_PROFILE
           {
             const unsigned long long zp_now = __builtin_readcyclecounter();

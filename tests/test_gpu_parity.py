@@ -197,6 +197,35 @@ def test_generic_per_lane_path_forced(oracle, product, isa, cfg, kw, monkeypatch
     _compare(oracle, product, synth.make(cfg, isa, **kw), 64)
 
 
+@pytest.mark.parametrize("cfg,kw", [(1, dict()), (2, dict(n_instances=320)), (3, dict(n_instances=64, keccak_k=(1, 2, 8, 3), sha_rounds=(1, 2, 8, 5))),
+                                    (4, dict(n_instances=128, n_cycles=512))])
+def test_variant_group_path_forced(oracle, product, isa, cfg, kw, monkeypatch):
+    """ZKW_DEBUG_FLAGS bit 24 sends every group of a light opcode through the variant-group path (per-lane operand decode,
+    waterfall register access in zkw_vec_exec) even on a shared tape: the same bits as the scalar decode."""
+    monkeypatch.setenv("ZKW_DEBUG_FLAGS", str(1 << 24))
+    _compare(oracle, product, synth.make(cfg, isa, **kw), 64)
+
+
+@pytest.mark.parametrize("seed", [0xF101, 0xF102])
+def test_fuzz_tapes_variant_groups_forced(oracle, product, isa, seed, monkeypatch):
+    """The fuzz tapes (every opcode variant, operand mode and failure path) with every light group on the variant path."""
+    monkeypatch.setenv("ZKW_DEBUG_FLAGS", str(1 << 24))
+    wl = synth.fuzz_workload(isa, n_instances=256, n_ops=96, seed=seed)
+    bo = _run(oracle, wl)
+    bp = _run(product, wl, 64)
+    compared = 0
+    for i in range(wl.n_instances):
+        tp = bp.trace(i)
+        if int(tp["status"]) == K.STATUS_LIMIT:
+            continue
+        ok, why = K.traces_equal(bo.trace(i), tp)
+        assert ok, "fuzz %x instance %d: %s" % (seed, i, why)
+        compared += 1
+    assert compared * 8 > wl.n_instances * 7
+    bo.destroy()
+    bp.destroy()
+
+
 def test_graph_replayed_step(oracle, product, isa):
     """zkw_batch_step: the first call runs eagerly and captures a hipGraph, later calls replay it — same bits."""
     import ctypes as C
