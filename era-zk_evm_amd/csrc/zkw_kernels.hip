@@ -9,8 +9,11 @@
 //     wave-uniform and a register access is VGPR-indexed addressing (s_set_gpr_idx_on + 8 v_mov): no LDS round trip,
 //     and the LDS footprint of a wave drops from 32 KB to 6 KB, which is what lets a second workgroup share the CU;
 //   * the cold per-lane scalars (context value, pubdata counters, arena bookkeeping) live in LDS ([field][lane]),
-//     the hot ones in VGPRs; the heavy, rare opcode bodies (far_call, ret, near_call, log + precompiles) are one
-//     out-of-line function so that their register demand does not add to the 120 + ~130 registers of the hot loop;
+//     the hot ones in VGPRs; the heavy, rare opcode bodies (far_call, ret, near_call, log + precompiles) are out-of-line
+//     functions (one per opcode behind a tail-calling dispatcher: one call site) so that their register demand does not
+//     add to the 120 + ~128 registers of the hot loop;
+//   * lanes of a wave that run different programs are grouped by decoded variant (same ISA entry, per-lane register
+//     numbers / immediates): such a group runs out of line with waterfall register access (zkw_vec_exec);
 //   * the opcode stream is fetched from HBM as 32-byte code words (4 opcodes), cached in LDS exactly like
 //     `previous_code_word` (cycle.rs:53-101);
 //   * the packed ISA table (host-uploaded, 2048 x 8 B) is staged in LDS once per workgroup;
