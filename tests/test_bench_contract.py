@@ -63,7 +63,7 @@ def test_rocprof_kernel_duration_agrees_with_the_bench_line():
 
 
 def test_every_round2_bench_line_has_its_rocprof_summary():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_bench.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")) if not os.path.basename(f).startswith("r01"))
     assert len(files) >= 2, files  # the driver's command and the default command
     for f in files:
         _check_pair(json.load(open(f)), f)
