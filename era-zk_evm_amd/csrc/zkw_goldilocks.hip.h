@@ -127,21 +127,51 @@ ZD u64 gl_pow7(u64 x) {
   return gl_mulred(x4, x3);
 }
 
-// The linear layers are evaluated over the integers in 128-bit accumulators and reduced once per output element:
-// every coefficient pattern below sums to at most 64 * 2^64 (external) / 2^76 (internal), far inside 128 bits, and
-// gl_reduce128 accepts any 128-bit value.  (The element-wise form cost ~40 modular additions per layer.)
-typedef unsigned __int128 u128;
-// Inside the permutation every value is kept only congruent (< 2^64, possibly >= p): products, 128-bit sums and the
-// round-constant addition below accept that, and gl_permute canonicalises the state once at the end.
-ZD u64 gl_reduce_wide(u128 x) { return gl_reduce128_lazy((u64)x, (u64)(x >> 64)); }
-// the same for x < 2^96 (every sum of the linear layers: <= 64 * 2^64 externally, < 2^77 internally): the high half fits
-// 32 bits, so 2^64 = 2^32 - 1 (mod p) folds it in with one shift, one subtraction and one add
-ZD u64 gl_reduce_small(u128 x) {
-  const u64 lo = (u64)x, hi = (u64)(x >> 64);
-  const u64 t1 = (hi << 32) - hi;
-  u64 r = lo + t1;
-  if (r < t1) r += GL_EPS;
-  return r;
+// The linear layers work on the 32-bit halves of the elements.  A 128-bit accumulator costs a carry chain per addition,
+// and on gfx940+ every link of a carry chain (v_add_co -> v_addc_co) is followed by two wait states (a scalar register
+// written by a vector instruction): the 128-bit form of the layers was one third s_nop.  Instead the low words and the
+// high words of the state go through the (integer) matrix separately — the coefficients are small, so each half stays
+// far below 2^64 and every step is one carry-free v_mad_u64_u32 (32 x 32 + 64) or v_lshl_add_u64 — and the two halves
+// L, H of an output are folded once:  L + 2^32 H  (mod p), with 2^64 = 2^32 - 1.
+// Inside the permutation every value is kept only congruent (< 2^64, possibly >= p): products, the sums below and the
+// round-constant addition accept that, and gl_permute canonicalises the state once at the end.
+//
+// a * b + c for operands whose result fits 64 bits (the carry out of the instruction goes to a scratch scalar pair)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZKW_GL_PORTABLE)
+template <int K>
+ZD u64 gl_madk(u32 a, u64 c) {  // a * K + c, K an inline constant (-16..64; -1 is 2^32 - 1 as a 32-bit operand)
+  static_assert(K >= -16 && K <= 64, "inline constant");
+  u64 d, sc;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(sc) : "v"(a), "n"(K), "v"(c));
+  return d;
+}
+template <int K>
+ZD u64 gl_mulk(u32 a) {  // a * K as 64 bits (also the zero extension, K = 1, without a second register to clear)
+  static_assert(K >= 0 && K <= 64, "inline constant");
+  u64 d, sc;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(sc) : "v"(a), "n"(K));
+  return d;
+}
+ZD u64 gl_mads(u32 a, u32 k, u64 c) {  // a * k + c, k uniform (a scalar register: VOP3 takes no literal on gfx9)
+  u64 d, sc;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(sc) : "v"(a), "s"(k), "v"(c));
+  return d;
+}
+#else
+template <int K>
+ZD u64 gl_madk(u32 a, u64 c) { return (u64)a * (u32)K + c; }
+template <int K>
+ZD u64 gl_mulk(u32 a) { return (u64)a * (u32)K; }
+ZD u64 gl_mads(u32 a, u32 k, u64 c) { return (u64)a * k + c; }
+#endif
+// L + 2^32 H (mod p) for L < 2^63 and H < 2^63 with (H >> 32) (2^32 - 1) + L < 2^64 (here L, H < 2^45): the high word of
+// H folds in through 2^64 = 2^32 - 1 without a carry; adding the low word of H at bit 32 can wrap once, and the wrapped
+// value is below 2^46, so the correction 2^64 = 2^32 - 1 cannot wrap again.  Any u64 out, congruent.
+ZD u64 gl_fold_halves(u64 L, u64 H) {
+  const u64 c = gl_madk<-1>((u32)(H >> 32), L);
+  const u32 hi = (u32)(c >> 32) + (u32)H;
+  const u32 e = hi < (u32)H ? 0xffffffffu : 0u;
+  return gl_madk<1>(e, ((u64)hi << 32) | (u32)c);
 }
 // s + rc for any s < 2^64 and a canonical constant: s + rc < 2^65 - 2^32, so one wrap correction suffices
 ZD u64 gl_add_rc(u64 s, u64 rc) {
@@ -150,29 +180,46 @@ ZD u64 gl_add_rc(u64 s, u64 rc) {
   return x;
 }
 
-// M4 of the Poseidon2 paper: [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] — unreduced (row sums <= 16)
-ZD void gl_m4_wide(u64 a, u64 b, u64 c, u64 d, u128& o0, u128& o1, u128& o2, u128& o3) {
-  const u128 t0 = (u128)a + b, t1 = (u128)c + d;
-  const u128 t2 = ((u128)b << 1) + t1, t3 = ((u128)d << 1) + t0;
-  const u128 t4 = (t1 << 2) + t3, t5 = (t0 << 2) + t2;
+// M4 of the Poseidon2 paper: [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] on 32-bit words, exact (row sums <= 16, so the
+// outputs are below 2^36)
+ZD void gl_m4_words(u32 a, u32 b, u32 c, u32 d, u64& o0, u64& o1, u64& o2, u64& o3) {
+  const u64 t0 = gl_madk<1>(a, gl_mulk<1>(b)), t1 = gl_madk<1>(c, gl_mulk<1>(d));
+  const u64 t2 = gl_madk<2>(b, t1), t3 = gl_madk<2>(d, t0);
+  const u64 t4 = (t1 << 2) + t3, t5 = (t0 << 2) + t2;
   o0 = t3 + t5; o1 = t5; o2 = t2 + t4; o3 = t4;
 }
+// external layer circ(2 M4, M4, M4): each half below 2^38
 ZD void gl_external(u64 s[12]) {
-  u128 o[12];
+  u64 lo[12], hi[12];
 #pragma unroll
-  for (int i = 0; i < 12; i += 4) gl_m4_wide(s[i], s[i + 1], s[i + 2], s[i + 3], o[i], o[i + 1], o[i + 2], o[i + 3]);
-  u128 sum[4];
+  for (int i = 0; i < 12; i += 4) {
+    gl_m4_words((u32)s[i], (u32)s[i + 1], (u32)s[i + 2], (u32)s[i + 3], lo[i], lo[i + 1], lo[i + 2], lo[i + 3]);
+    gl_m4_words((u32)(s[i] >> 32), (u32)(s[i + 1] >> 32), (u32)(s[i + 2] >> 32), (u32)(s[i + 3] >> 32), hi[i], hi[i + 1],
+                hi[i + 2], hi[i + 3]);
+  }
+  u64 sl[4], sh[4];
 #pragma unroll
-  for (int j = 0; j < 4; j++) sum[j] = o[j] + o[4 + j] + o[8 + j];
+  for (int j = 0; j < 4; j++) {
+    sl[j] = lo[j] + lo[4 + j] + lo[8 + j];
+    sh[j] = hi[j] + hi[4 + j] + hi[8 + j];
+  }
 #pragma unroll
-  for (int i = 0; i < 12; i++) s[i] = gl_reduce_small(o[i] + sum[i & 3]);
+  for (int i = 0; i < 12; i++) s[i] = gl_fold_halves(lo[i] + sl[i & 3], hi[i] + sh[i & 3]);
 }
+// internal layer  s_i' = sum + 2^i s_i: the word sums are below 2^36, a half of an output below 2^44
 ZD void gl_internal(u64 s[12]) {
-  u128 sum = 0;
+  u64 sl = gl_mulk<1>((u32)s[0]), sh = gl_mulk<1>((u32)(s[0] >> 32));
 #pragma unroll
-  for (int i = 0; i < 12; i++) sum += s[i];
-#pragma unroll
-  for (int i = 0; i < 12; i++) s[i] = gl_reduce_small(sum + ((u128)s[i] << i));
+  for (int i = 1; i < 12; i++) {
+    sl = gl_madk<1>((u32)s[i], sl);
+    sh = gl_madk<1>((u32)(s[i] >> 32), sh);
+  }
+#define GL_INT_K(i) s[i] = gl_fold_halves(gl_madk<(1 << i)>((u32)s[i], sl), gl_madk<(1 << i)>((u32)(s[i] >> 32), sh))
+#define GL_INT_S(i) s[i] = gl_fold_halves(gl_mads((u32)s[i], 1u << i, sl), gl_mads((u32)(s[i] >> 32), 1u << i, sh))
+  GL_INT_K(0); GL_INT_K(1); GL_INT_K(2); GL_INT_K(3); GL_INT_K(4); GL_INT_K(5); GL_INT_K(6);
+  GL_INT_S(7); GL_INT_S(8); GL_INT_S(9); GL_INT_S(10); GL_INT_S(11);
+#undef GL_INT_K
+#undef GL_INT_S
 }
 
 ZD void gl_permute(const u64* rc_, u64 s[12]) {

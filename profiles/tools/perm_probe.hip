@@ -1,4 +1,4 @@
-// Throughput of the ZKW-GL-sponge v1 permutation (csrc/zkw_goldilocks.hip.h) on the whole chip — every lane chains
+// Throughput of the ZKW-GL-sponge permutation (csrc/zkw_goldilocks.hip.h) on the whole chip — every lane chains
 // `iters` permutations of its own state — next to the issue rate of v_mad_u64_u32 (the 32 x 32 -> 64 multiply-add the
 // field multiplication is made of) and of a plain 32-bit add, which bound it.
 //   hipcc --offload-arch=gfx950 -O3 -I era-zk_evm_amd/csrc profiles/tools/perm_probe.hip -o /tmp/perm_probe && /tmp/perm_probe
