@@ -239,6 +239,19 @@ class Backend:
     def create_batch(self, workload):
         return Batch(self, workload)
 
+    def blake2s256(self, messages):
+        """zkw_blake2s256: BLAKE2s-256 of a list of byte strings (host buffers) -> list of 32-byte digests"""
+        n = len(messages)
+        data = b"".join(messages)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        if n:
+            offs[1:] = np.cumsum([len(m) for m in messages], dtype=np.uint64)
+        buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data if data else b"\0")
+        out = (C.c_uint8 * max(1, 32 * n))()
+        self.call("blake2s256", self.ctx, buf, offs.ctypes.data_as(C.c_void_p), C.c_uint32(n), out)
+        raw = bytes(out)
+        return [raw[32 * i:32 * i + 32] for i in range(n)]
+
     def reset_many(self, batches, stream=None):
         arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])
         self.call("batches_reset", arr, C.c_uint32(len(batches)), C.c_void_p(stream))

@@ -85,6 +85,13 @@ ZD u64 gl_reduce128_lazy(u64 lo, u64 hi) {
 // vector instruction two issue slots later at the earliest on gfx940+: the s_nops, where no independent instruction
 // fits.  The temporaries are fixed registers (an asm operand cannot name the halves of a 64-bit register pair).
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(ZKW_GL_PORTABLE)
+#ifdef ZKW_GL_TIMING_NO_NOPS  /* profiles/tools/perm_probe.hip only: what the wait states cost (results are then wrong) */
+#define ZKW_GL_NOP1
+#define ZKW_GL_NOP0
+#else
+#define ZKW_GL_NOP1 "s_nop 1\n\t"
+#define ZKW_GL_NOP0 "s_nop 0\n\t"
+#endif
 ZD u64 gl_mulred(u64 a, u64 b) {
   u32 r0, r1;
   u64 s0, s1;
@@ -93,17 +100,17 @@ ZD u64 gl_mulred(u64 a, u64 b) {
       "v_mad_u64_u32 v[116:117], %3, %5, %7, 0\n\t"             // Q = a1 b1
       "v_mad_u64_u32 v[114:115], %2, %5, %6, v[114:115]\n\t"    // M += a1 b0, cm -> %2
       "v_add_co_u32 v113, vcc, v113, v114\n\t"                  // X.hi = P.hi + m0, c1
-      "s_nop 1\n\t"
+      ZKW_GL_NOP1
       "v_addc_co_u32 v115, vcc, v115, v116, vcc\n\t"            // q = m1 + Q.lo + c1, c2
       "v_mad_u64_u32 v[112:113], %3, v115, -1, v[112:113]\n\t"  // T = X + EPS q, c3 -> %3
-      "s_nop 0\n\t"
+      ZKW_GL_NOP0
       "v_addc_co_u32 v117, vcc, 0, v117, vcc\n\t"               // h = Q.hi + c2
       "v_cndmask_b32 v118, 0, 1, %3\n\t"                        // e = c3
       "v_addc_co_u32 v117, %3, 0, v117, %2\n\t"                 // h += cm
       "v_sub_co_u32 v112, vcc, v112, v117\n\t"                  // U = T - h
-      "s_nop 1\n\t"
+      ZKW_GL_NOP1
       "v_subbrev_co_u32 v113, vcc, 0, v113, vcc\n\t"            // borrow b
-      "s_nop 1\n\t"
+      ZKW_GL_NOP1
       "v_subbrev_co_u32 v118, vcc, 0, v118, vcc\n\t"            // e = c3 - b
       "v_mad_i64_i32 v[112:113], %2, v118, -1, v[112:113]\n\t"  // U - e
       "v_add_u32 %1, v113, v118\n\t"                            // + e 2^32

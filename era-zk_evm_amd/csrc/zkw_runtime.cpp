@@ -50,6 +50,10 @@ struct zkw_ctx {
   // digests of code blobs already hashed on this context, keyed by a 128-bit content hash + length: batches that
   // share bytecode (the usual case) skip the sequential blob chain (~0.1 s for a 2000-word blob) at upload
   std::map<std::array<uint64_t, 3>, std::array<uint64_t, 4>> blob_digest_cache;
+  // staging of zkw_blake2s256 (host buffers in, host buffers out); grown on demand, freed with the context
+  void* b2_data = nullptr; size_t b2_data_cap = 0;
+  uint64_t* b2_off = nullptr; size_t b2_off_cap = 0;
+  void* b2_out = nullptr; size_t b2_out_cap = 0;
 };
 
 static std::string g_create_error;
@@ -211,7 +215,69 @@ int zkw_ctx_create(int device, zkw_ctx** out) {
 void zkw_ctx_destroy(zkw_ctx* c) {
   if (!c) return;
   if (c->d_isa) (void)hipFree(c->d_isa);
+  if (c->b2_data) (void)hipFree(c->b2_data);
+  if (c->b2_off) (void)hipFree(c->b2_off);
+  if (c->b2_out) (void)hipFree(c->b2_out);
   delete c;
+}
+
+// =================================================================================================
+// BLAKE2s-256 of a batch of byte strings (zkw_blake2s.hip) — the reference's `blake2` re-export, src/lib.rs:21
+// =================================================================================================
+extern "C" hipError_t zkw_launch_blake2s(const void* d_data, uint64_t total_bytes, const uint64_t* d_offsets, uint32_t n, void* d_digests,
+                                         uint32_t wave_threads, hipStream_t stream);
+
+int zkw_blake2s256_device(zkw_ctx* c, const void* d_data, uint64_t total_bytes, const uint64_t* d_offsets, uint32_t n_messages, void* d_digests,
+                          void* hip_stream) {
+  if (!c) return ZKW_ERR_INVALID;
+  if (n_messages == 0) return ZKW_OK;
+  if (!d_offsets || !d_digests || (!d_data && total_bytes != 0)) {
+    c->last_error = "zkw_blake2s256_device: null buffer";
+    return ZKW_ERR_INVALID;
+  }
+  if (((uintptr_t)d_data & 3u) != 0 || ((uintptr_t)d_digests & 15u) != 0 || ((uintptr_t)d_offsets & 7u) != 0) {
+    c->last_error = "zkw_blake2s256_device: data must be 4-byte, offsets 8-byte and digests 16-byte aligned";
+    return ZKW_ERR_INVALID;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, zkw_launch_blake2s(d_data, total_bytes, d_offsets, n_messages, d_digests, (uint32_t)c->wave_width, (hipStream_t)hip_stream));
+  return ZKW_OK;
+}
+
+int zkw_blake2s256(zkw_ctx* c, const uint8_t* data, const uint64_t* offsets, uint32_t n_messages, uint8_t* digests) {
+  if (!c) return ZKW_ERR_INVALID;
+  if (n_messages == 0) return ZKW_OK;
+  if (!offsets || !digests) {
+    c->last_error = "zkw_blake2s256: null buffer";
+    return ZKW_ERR_INVALID;
+  }
+  for (uint32_t i = 0; i < n_messages; i++)
+    if (offsets[i + 1] < offsets[i]) {
+      c->last_error = "zkw_blake2s256: offsets must not decrease";
+      return ZKW_ERR_INVALID;
+    }
+  const uint64_t total = offsets[n_messages];
+  if (total != 0 && !data) {
+    c->last_error = "zkw_blake2s256: null data";
+    return ZKW_ERR_INVALID;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  auto grow = [&](void** p, size_t* cap, size_t bytes) -> hipError_t {
+    if (*cap >= bytes && *p) return hipSuccess;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    const hipError_t e = hipMalloc(p, bytes < 256 ? 256 : bytes);
+    if (e == hipSuccess) *cap = bytes < 256 ? 256 : bytes;
+    return e;
+  };
+  HIP_TRY(c, grow(&c->b2_data, &c->b2_data_cap, (size_t)((total + 3u) & ~(uint64_t)3u)));
+  HIP_TRY(c, grow((void**)&c->b2_off, &c->b2_off_cap, ((size_t)n_messages + 1) * 8));
+  HIP_TRY(c, grow(&c->b2_out, &c->b2_out_cap, (size_t)n_messages * 32));
+  if (total) HIP_TRY(c, hipMemcpy(c->b2_data, data, (size_t)total, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->b2_off, offsets, ((size_t)n_messages + 1) * 8, hipMemcpyHostToDevice));
+  HIP_TRY(c, zkw_launch_blake2s(c->b2_data, total, c->b2_off, n_messages, c->b2_out, (uint32_t)c->wave_width, nullptr));
+  HIP_TRY(c, hipMemcpy(digests, c->b2_out, (size_t)n_messages * 32, hipMemcpyDeviceToHost));
+  return ZKW_OK;
 }
 
 const char* zkw_last_error(zkw_ctx* c) { return c ? c->last_error.c_str() : g_create_error.c_str(); }

@@ -558,6 +558,19 @@ int zkw_batch_get_net_state(zkw_batch* batch, uint32_t instance, zkw_net_state* 
  * consumer of the whole trace would pay (PCIe-inclusive rate).  The data is discarded. */
 int zkw_batch_download_all(zkw_batch* batch, uint64_t* n_bytes, double* ms);
 
+/* BLAKE2s-256 (RFC 7693: unkeyed, 32-byte digests, no salt / personalisation) of n_messages byte strings on the GPU,
+ * one message per lane.  Replaces: `Blake2s256::digest(bytes)` of the `blake2` crate as callers reach it through the
+ * reference's re-export `zk_evm::blake2` (/root/reference/src/lib.rs:21 — the reference itself has no call site).
+ * Message i is data[offsets[i] .. offsets[i + 1]) (offsets has n_messages + 1 non-decreasing entries; an empty message
+ * is allowed); digests receives n_messages x 32 bytes in message order.
+ * zkw_blake2s256: host buffers, synchronous (staged through device buffers the context keeps).
+ * zkw_blake2s256_device: the buffers are device memory and the kernel is enqueued on `hip_stream` without a
+ * synchronisation; d_data must be 4-byte aligned and its allocation must cover total_bytes rounded up to 4,
+ * d_offsets 8-byte and d_digests 16-byte aligned; the offsets are trusted. */
+int zkw_blake2s256(zkw_ctx* ctx, const uint8_t* data, const uint64_t* offsets, uint32_t n_messages, uint8_t* digests);
+int zkw_blake2s256_device(zkw_ctx* ctx, const void* d_data, uint64_t total_bytes, const uint64_t* d_offsets, uint32_t n_messages, void* d_digests,
+                          void* hip_stream);
+
 /* sizeof() of the ABI structs as compiled into the library (binding self-check) */
 uint32_t zkw_abi_sizeof(uint32_t which);
 

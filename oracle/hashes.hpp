@@ -108,4 +108,55 @@ inline void keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
   for (int i = 0; i < 32; i++) out[i] = (uint8_t)(st[i / 8] >> (8 * (i % 8)));
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// BLAKE2s-256 (RFC 7693 §3, unkeyed, 32-byte digest) — the `blake2` crate the reference re-exports
+// (/root/reference/src/lib.rs:21: `pub use zkevm_opcode_defs::blake2`; no call site in the reference, so the pin is
+// the RFC's own test vector and hashlib.blake2s: tests/test_blake2s.py).  Written from the RFC's pseudo-code.
+// ---------------------------------------------------------------------------------------------
+static const uint32_t BLAKE2S_IV[8] = {0x6A09E667, 0xBB67AE85, 0x3C6EF372, 0xA54FF53A, 0x510E527F, 0x9B05688C, 0x1F83D9AB, 0x5BE0CD19};
+static const uint8_t BLAKE2S_SIGMA[10][16] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+
+inline void blake2s_mix(uint32_t v[16], int a, int b, int c, int d, uint32_t x, uint32_t y) {  // RFC 7693 §3.1 (R = 16, 12, 8, 7)
+  v[a] = v[a] + v[b] + x; v[d] = rotr32(v[d] ^ v[a], 16);
+  v[c] = v[c] + v[d];     v[b] = rotr32(v[b] ^ v[c], 12);
+  v[a] = v[a] + v[b] + y; v[d] = rotr32(v[d] ^ v[a], 8);
+  v[c] = v[c] + v[d];     v[b] = rotr32(v[b] ^ v[c], 7);
+}
+inline void blake2s_F(uint32_t h[8], const uint8_t block[64], uint64_t t, bool last) {  // RFC 7693 §3.2
+  uint32_t m[16], v[16];
+  for (int i = 0; i < 16; i++) m[i] = (uint32_t)block[4 * i] | (uint32_t)block[4 * i + 1] << 8 | (uint32_t)block[4 * i + 2] << 16 | (uint32_t)block[4 * i + 3] << 24;
+  for (int i = 0; i < 8; i++) { v[i] = h[i]; v[i + 8] = BLAKE2S_IV[i]; }
+  v[12] ^= (uint32_t)t; v[13] ^= (uint32_t)(t >> 32);
+  if (last) v[14] = ~v[14];
+  for (int r = 0; r < 10; r++) {
+    const uint8_t* s = BLAKE2S_SIGMA[r];
+    blake2s_mix(v, 0, 4, 8, 12, m[s[0]], m[s[1]]);   blake2s_mix(v, 1, 5, 9, 13, m[s[2]], m[s[3]]);
+    blake2s_mix(v, 2, 6, 10, 14, m[s[4]], m[s[5]]);  blake2s_mix(v, 3, 7, 11, 15, m[s[6]], m[s[7]]);
+    blake2s_mix(v, 0, 5, 10, 15, m[s[8]], m[s[9]]);  blake2s_mix(v, 1, 6, 11, 12, m[s[10]], m[s[11]]);
+    blake2s_mix(v, 2, 7, 8, 13, m[s[12]], m[s[13]]); blake2s_mix(v, 3, 4, 9, 14, m[s[14]], m[s[15]]);
+  }
+  for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
+}
+inline void blake2s256(const uint8_t* data, size_t len, uint8_t out[32]) {  // RFC 7693 §3.3, kk = 0, nn = 32
+  uint32_t h[8];
+  for (int i = 0; i < 8; i++) h[i] = BLAKE2S_IV[i];
+  h[0] ^= 0x01010000u ^ 32u;
+  uint8_t block[64];
+  size_t off = 0;
+  while (len - off > 64) {
+    blake2s_F(h, data + off, (uint64_t)off + 64, false);
+    off += 64;
+  }
+  std::memset(block, 0, sizeof block);
+  if (len > off) std::memcpy(block, data + off, len - off);
+  blake2s_F(h, block, (uint64_t)len, true);
+  for (int i = 0; i < 8; i++) { out[4 * i] = (uint8_t)h[i]; out[4 * i + 1] = (uint8_t)(h[i] >> 8); out[4 * i + 2] = (uint8_t)(h[i] >> 16); out[4 * i + 3] = (uint8_t)(h[i] >> 24); }
+}
+
 }  // namespace zko

@@ -490,6 +490,15 @@ int zkwo_batch_get_commitments(zkwo_batch* b, uint64_t* out) {
   return ZKW_OK;
 }
 
+// zkw_blake2s256 (include/zkw.h): the CPU restatement (hashes.hpp: blake2s256), message by message
+int zkwo_blake2s256(zkwo_ctx*, const uint8_t* data, const uint64_t* offsets, uint32_t n_messages, uint8_t* digests) {
+  for (uint32_t i = 0; i < n_messages; i++) {
+    if (offsets[i + 1] < offsets[i]) return ZKW_ERR_INVALID;
+    blake2s256(data + offsets[i], (size_t)(offsets[i + 1] - offsets[i]), digests + 32 * (size_t)i);
+  }
+  return ZKW_OK;
+}
+
 // ---- unit-test hooks --------------------------------------------------------------------
 // op: 0 add (out[0]=result, out[1].l[0]=of) 1 sub 2 mul (out[0]=low,out[1]=high) 3 div (q,r) 4 shl 5 shr (b.l[0]=n)
 int zkwo_u256_op(int op, const zkw_u256* a, const zkw_u256* bb, zkw_u256* out) {
