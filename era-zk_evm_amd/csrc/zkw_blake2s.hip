@@ -68,23 +68,27 @@ ZD void blake2s_compress(u32 h[8], const u32 m[16], u64 t, bool last) {
 
 // the 16 little-endian words of the block that starts at byte `at` of `data`, bytes at or after `end` read as zero.
 // `words` = the aligned dwords of the whole buffer (its allocation covers ceil(total / 4) dwords).
-ZD void load_block(const u32* __restrict__ words, u64 n_words, u64 at, u64 end, u32 m[16]) {
+// LAST = false: a block that is not the message's last (end - at > 64) — all 17 covering dwords start before `end`, so
+// they are loaded without a test; LAST = true: nothing at or after `end` is loaded (it may lie past the buffer).
+template <bool LAST>
+ZD void load_block(const u32* __restrict__ words, u64 at, u64 end, u32 m[16]) {
   const u64 w0 = at >> 2;
   const u32 sh = (u32)(at & 3u) * 8u;
   u32 w[17];
 #pragma unroll
   for (int i = 0; i < 17; i++) {
     const u64 wi = w0 + (u64)i;
-    // nothing at or after `end` is needed: such words are not loaded (they may lie past the buffer)
-    w[i] = (wi < n_words && wi * 4u < end) ? words[wi] : 0u;
+    w[i] = (!LAST || wi * 4u < end) ? words[wi] : 0u;
   }
   const u64 valid = end > at ? end - at : 0;  // bytes of this block that belong to the message
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     u32 x = sh ? (w[i] >> sh) | (w[i + 1] << (32u - sh)) : w[i];  // v_alignbyte_b32
-    const u64 lo = 4u * (u64)i;
-    if (valid <= lo) x = 0;
-    else if (valid < lo + 4u) x &= (1u << (8u * (u32)(valid - lo))) - 1u;
+    if (LAST) {
+      const u64 lo = 4u * (u64)i;
+      if (valid <= lo) x = 0;
+      else if (valid < lo + 4u) x &= (1u << (8u * (u32)(valid - lo))) - 1u;
+    }
     m[i] = x;
   }
 }
@@ -95,7 +99,7 @@ __global__ void __launch_bounds__(256) zkw_blake2s_kernel(const u32* __restrict_
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u64 begin = offsets[i], end = offsets[i + 1];
-  const u64 n_words = (total_bytes + 3u) >> 2;
+  (void)total_bytes;
   u32 h[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) h[k] = B2S_IV[k];
@@ -104,11 +108,11 @@ __global__ void __launch_bounds__(256) zkw_blake2s_kernel(const u32* __restrict_
   u64 at = begin;
   // every block but the last: the counter is the number of message bytes absorbed so far
   while (end - at > 64u) {
-    load_block(words, n_words, at, end, m);
+    load_block<false>(words, at, end, m);
     at += 64u;
     blake2s_compress(h, m, at - begin, false);
   }
-  load_block(words, n_words, at, end, m);  // 0..64 bytes (an empty message is one zero block), zero padded
+  load_block<true>(words, at, end, m);  // 0..64 bytes (an empty message is one zero block), zero padded
   blake2s_compress(h, m, end - begin, true);
   digests[2 * (size_t)i] = make_uint4(h[0], h[1], h[2], h[3]);
   digests[2 * (size_t)i + 1] = make_uint4(h[4], h[5], h[6], h[7]);

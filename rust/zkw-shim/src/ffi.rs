@@ -300,6 +300,9 @@ extern "C" {
     pub fn zkw_comm_destroy(comm: *mut zkw_comm);
     pub fn zkw_reduce_commitments(comm: *mut zkw_comm, batches: *const *mut zkw_batch, n_batches: u32, queue_mask: u32, gathered: *mut c_void,
                                   n_max_out: *mut u32, sizes_out: *mut u32, total: *mut zkw_run_stats, stream: *mut c_void) -> c_int;
+    pub fn zkw_blake2s256(ctx: *mut zkw_ctx, data: *const u8, offsets: *const u64, n_messages: u32, digests: *mut u8) -> c_int;
+    pub fn zkw_blake2s256_device(ctx: *mut zkw_ctx, d_data: *const c_void, total_bytes: u64, d_offsets: *const u64, n_messages: u32,
+                                 d_digests: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn zkw_abi_sizeof(which: u32) -> u32;
 }
 

@@ -259,6 +259,21 @@ impl Context {
         let msg = unsafe { CStr::from_ptr(zkw_last_error(self.raw)) }.to_string_lossy().into_owned();
         anyhow::bail!("{} -> {}: {}", what, rc, msg)
     }
+    /// `Blake2s256::digest` of the re-exported `zk_evm::blake2` (reference src/lib.rs:21) for a batch of messages,
+    /// one message per GPU lane (zkw_blake2s256)
+    pub fn blake2s256_batch(&self, messages: &[&[u8]]) -> anyhow::Result<Vec<[u8; 32]>> {
+        let mut offsets = Vec::with_capacity(messages.len() + 1);
+        let mut data = Vec::with_capacity(messages.iter().map(|m| m.len()).sum());
+        offsets.push(0u64);
+        for m in messages {
+            data.extend_from_slice(m);
+            offsets.push(data.len() as u64);
+        }
+        let mut out = vec![[0u8; 32]; messages.len()];
+        let rc = unsafe { zkw_blake2s256(self.raw, data.as_ptr(), offsets.as_ptr(), messages.len() as u32, out.as_mut_ptr() as *mut u8) };
+        self.check(rc, "zkw_blake2s256")?;
+        Ok(out)
+    }
 }
 impl Drop for Context {
     fn drop(&mut self) {
