@@ -1249,12 +1249,12 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
   }
   ZKW_SUB(42)  // word reads + read queries
   if (!is_write) {  // :291-348
-    u256 result = u256_or(u256_shl(w0v, unal * 8), u256_shr(w1v, (32 - unal) * 8));
+    u256 result = u256_byte_window(w0v, w1v, unal);
     if (is_ptr_read) {
       u32 beyond = incremented - fp.length;
       if (incremented < fp.length || skip) beyond = 0;
       beyond &= 31u;
-      result = u256_shl(u256_shr(result, beyond * 8), beyond * 8);
+      result = u256_select_bits(u256_low_mask(beyond * 8), u256_zero(), result);  // the low `beyond` bytes read as zero
     }
     ZKW_SUB(43)  // read: shifts
     if (!set_panic) {

@@ -105,53 +105,83 @@ ZD void u256_mul(const u256& a, const u256& b, u256& lo, u256& hi) {
 // operand still sits in a struct, which then pins the whole operand in scratch memory.)
 ZD u32 zk_funnel_r(u32 hi, u32 lo, u32 n) { return __builtin_amdgcn_alignbit(hi, lo, n); }
 
+// Per-lane selects are bit selects with an all-ones / all-zero mask — (m & a) | (~m & b), one v_bfi_b32 and no lane
+// mask in a scalar register.  Written as `if (ws & 1) { move all limbs }`, or as `cond ? a : b` per limb (which the
+// optimiser turns back into a branch when many selects share a condition), a word-shift stage is a full copy of the
+// value plus an exec-masked block of eight moves: 72 instructions per shift instead of ~40.
+ZD u32 zk_sel(u32 m, u32 a, u32 b) { return (m & a) | (~m & b); }
+ZD u32 zk_mask(bool c) { return c ? 0xffffffffu : 0u; }
+
 ZD u256 u256_shl(const u256& a, u32 n) {
-  const u32 bs = n & 31, ws = (n >> 5) & 7;
-  u256 t;
-  t.w[0] = a.w[0] << bs;
+  const u32 bs = n & 31;
+  const u32 m1 = zk_mask((n & 32u) != 0), m2 = zk_mask((n & 64u) != 0), m4 = zk_mask((n & 128u) != 0), nz = zk_mask(n < 256);
+  const u32 mb = zk_mask(bs != 0);
+  u32 t[8], u[8], v[8];
+  t[0] = a.w[0] << bs;
 #pragma unroll
-  for (int i = 1; i < 8; i++) t.w[i] = bs ? zk_funnel_r(a.w[i], a.w[i - 1], 32u - bs) : a.w[i];
-  if (ws & 1) {
+  for (int i = 1; i < 8; i++) t[i] = zk_sel(mb, zk_funnel_r(a.w[i], a.w[i - 1], 32u - bs), a.w[i]);
 #pragma unroll
-    for (int i = 7; i >= 1; i--) t.w[i] = t.w[i - 1];
-    t.w[0] = 0;
-  }
-  if (ws & 2) {
+  for (int i = 0; i < 8; i++) u[i] = zk_sel(m1, i >= 1 ? t[i >= 1 ? i - 1 : 0] : 0u, t[i]);
 #pragma unroll
-    for (int i = 7; i >= 2; i--) t.w[i] = t.w[i - 2];
-    t.w[0] = t.w[1] = 0;
-  }
-  if (ws & 4) {
+  for (int i = 0; i < 8; i++) v[i] = zk_sel(m2, i >= 2 ? u[i >= 2 ? i - 2 : 0] : 0u, u[i]);
+  u256 r;
 #pragma unroll
-    for (int i = 7; i >= 4; i--) t.w[i] = t.w[i - 4];
-    t.w[0] = t.w[1] = t.w[2] = t.w[3] = 0;
-  }
-  if (n >= 256) t = u256_zero();
-  return t;
+  for (int i = 0; i < 8; i++) r.w[i] = zk_sel(m4, i >= 4 ? v[i >= 4 ? i - 4 : 0] : 0u, v[i]) & nz;
+  return r;
 }
 ZD u256 u256_shr(const u256& a, u32 n) {
-  const u32 bs = n & 31, ws = (n >> 5) & 7;
-  u256 t;
+  const u32 bs = n & 31;
+  const u32 m1 = zk_mask((n & 32u) != 0), m2 = zk_mask((n & 64u) != 0), m4 = zk_mask((n & 128u) != 0), nz = zk_mask(n < 256);
+  u32 t[8], u[8], v[8];
 #pragma unroll
-  for (int i = 0; i < 7; i++) t.w[i] = zk_funnel_r(a.w[i + 1], a.w[i], bs);
-  t.w[7] = a.w[7] >> bs;
-  if (ws & 1) {
+  for (int i = 0; i < 7; i++) t[i] = zk_funnel_r(a.w[i + 1], a.w[i], bs);
+  t[7] = a.w[7] >> bs;
 #pragma unroll
-    for (int i = 0; i < 7; i++) t.w[i] = t.w[i + 1];
-    t.w[7] = 0;
-  }
-  if (ws & 2) {
+  for (int i = 0; i < 8; i++) u[i] = zk_sel(m1, i <= 6 ? t[i <= 6 ? i + 1 : 7] : 0u, t[i]);
 #pragma unroll
-    for (int i = 0; i < 6; i++) t.w[i] = t.w[i + 2];
-    t.w[6] = t.w[7] = 0;
-  }
-  if (ws & 4) {
+  for (int i = 0; i < 8; i++) v[i] = zk_sel(m2, i <= 5 ? u[i <= 5 ? i + 2 : 7] : 0u, u[i]);
+  u256 r;
 #pragma unroll
-    for (int i = 0; i < 4; i++) t.w[i] = t.w[i + 4];
-    t.w[4] = t.w[5] = t.w[6] = t.w[7] = 0;
-  }
-  if (n >= 256) t = u256_zero();
-  return t;
+  for (int i = 0; i < 8; i++) r.w[i] = zk_sel(m4, i <= 3 ? v[i <= 3 ? i + 4 : 7] : 0u, v[i]) & nz;
+  return r;
+}
+// the low `nbits` bits set (0 <= nbits <= 256): all-ones shifted right by 256 - nbits, limb i a funnel over the
+// extended all-ones value
+ZD u256 u256_low_mask(u32 nbits) {
+  const u32 t = 256u - nbits, q = t >> 5, r = t & 31u;
+  u32 o[9];
+#pragma unroll
+  for (int j = 0; j < 9; j++) o[j] = zk_mask(q + (u32)j <= 7u);  // limb j + q of the extended value
+  u256 m;
+#pragma unroll
+  for (int i = 0; i < 8; i++) m.w[i] = zk_funnel_r(o[i + 1], o[i], r);
+  return m;
+}
+// (m & a) | (~m & b) per limb — v_bfi_b32
+ZD u256 u256_select_bits(const u256& m, const u256& a, const u256& b) {
+  u256 r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.w[i] = zk_sel(m.w[i], a.w[i], b.w[i]);
+  return r;
+}
+// the 32 bytes that start `unal` bytes (0..31) into the 64-byte big-endian string hi ‖ lo: (hi << 8 unal) | (lo >> (256 - 8 unal))
+// as ONE window over the 16 limbs instead of two shifts and an or (uma.rs:291-300)
+ZD u256 u256_byte_window(const u256& hi, const u256& lo, u32 unal) {
+  const u32 q = unal >> 2, r = (unal & 3u) * 8u, p = 7u - q;
+  const u32 m4 = zk_mask((p & 4u) != 0), m2 = zk_mask((p & 2u) != 0), m1 = zk_mask((p & 1u) != 0), mr = zk_mask(r != 0);
+  u32 c[16], f[12], g[10], e[9];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { c[i] = lo.w[i]; c[i + 8] = hi.w[i]; }
+#pragma unroll
+  for (int j = 0; j < 12; j++) f[j] = zk_sel(m4, c[j + 4], c[j]);
+#pragma unroll
+  for (int j = 0; j < 10; j++) g[j] = zk_sel(m2, f[j + 2], f[j]);
+#pragma unroll
+  for (int j = 0; j < 9; j++) e[j] = zk_sel(m1, g[j + 1], g[j]);   // e[j] = c[j + 7 - q]
+  u256 out;
+#pragma unroll
+  for (int i = 0; i < 8; i++) out.w[i] = zk_sel(mr, zk_funnel_r(e[i + 1], e[i], 32u - r), e[i + 1]);
+  return out;
 }
 ZD u256 u256_or(const u256& a, const u256& b) {
   u256 r;
