@@ -1,0 +1,55 @@
+"""One-off differential campaign: fuzz tapes (synth.fuzz_workload) through libzkw.so and the oracle for many seeds, lane
+widths and tape lengths, also with every light group forced onto the variant-group path, commitments included.
+   python profiles/tools/fuzz_campaign.py <first seed> <n seeds>        (prints one line per seed; exits 1 on a mismatch)"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np  # noqa: E402
+from era_zk_evm_amd import capi as K, synth  # noqa: E402
+from tests._oracle import load_oracle  # noqa: E402
+
+first, count = int(sys.argv[1], 0), int(sys.argv[2])
+isa = K.Isa()
+prod = K.load_product().open(isa)
+orc = load_oracle().open(isa)
+bad = 0
+t0 = time.time()
+for k in range(count):
+    seed = first + k
+    lanes = (64, 64, 16, 0, 8, 1)[k % 6]
+    n_ops = (96, 160, 64, 128)[k % 4]
+    forced = (k % 3) == 2
+    if forced:
+        os.environ["ZKW_DEBUG_FLAGS"] = str(1 << 24)
+    else:
+        os.environ.pop("ZKW_DEBUG_FLAGS", None)
+    wl = synth.fuzz_workload(isa, n_instances=512, n_ops=n_ops, seed=seed)
+    bo = orc.create_batch(wl); bo.reset(); bo.run(wl.n_cycles); bo.sync()
+    wl.limits["lanes_per_wave"] = lanes
+    bp = prod.create_batch(wl); bp.reset(); bp.run(wl.n_cycles); bp.sync()
+    limited = compared = executed = 0
+    msg = ""
+    for i in range(wl.n_instances):
+        tp = bp.trace(i)
+        if int(tp["status"]) == K.STATUS_LIMIT:
+            limited += 1
+            continue
+        ok, why = K.traces_equal(bo.trace(i), tp)
+        if not ok:
+            bad += 1
+            msg = "MISMATCH instance %d: %s" % (i, why[:120])
+            break
+        compared += 1
+        executed += len(tp["records"])
+    if not msg:
+        co, cp = bo.commitments(), bp.commitments()
+        keep = np.array([int(bp.trace(i)["status"]) != K.STATUS_LIMIT for i in range(wl.n_instances)])
+        if not np.array_equal(co[keep], cp[keep]):
+            bad += 1
+            msg = "COMMITMENT MISMATCH"
+    print("seed %#x lanes %2d ops %3d forced %d: compared %d limited %d cycles %d %s" % (seed, lanes, n_ops, forced, compared, limited, executed, msg), flush=True)
+    bo.destroy(); bp.destroy()
+print("done: %d seeds, %d bad, %.0f s" % (count, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
