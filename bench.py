@@ -394,7 +394,11 @@ def cpu_baseline(isa, args, prod=None):
     else:
         res["whole_box"] = res["one_socket"]
     phys = len(set(all_cpus))
-    out = {"value": res["whole_box"]["value"], "unit": "cycles/s", "cores": res["whole_box"]["threads"], "kind": "port",
+    # `value` is the best the host did in this leg: the two-socket run is often SLOWER than one socket here (the workers'
+    # recorders are first-touched on one node), and the CPU should not be understated by that
+    top = max((res["whole_box"], res["one_socket"]), key=lambda r: r["value"])
+    out = {"value": top["value"], "unit": "cycles/s", "cores": top["threads"], "kind": "port",
+           "whole_box_value": res["whole_box"]["value"], "whole_box_threads": res["whole_box"]["threads"],
            "single_core_value": res["one_core"]["value"], "single_socket_value": res["one_socket"]["value"], "single_socket_threads": res["one_socket"]["threads"],
            "cpu_model": model, "nproc": os.cpu_count(), "packages": len(packages), "logical_cpus_used": phys,
            "scaling_all_over_one": res["whole_box"]["value"] / res["one_core"]["value"],
