@@ -394,8 +394,8 @@ def cpu_baseline(isa, args, prod=None):
     else:
         res["whole_box"] = res["one_socket"]
     phys = len(set(all_cpus))
-    # `value` is the best the host did in this leg: the two-socket run is often SLOWER than one socket here (the workers'
-    # recorders are first-touched on one node), and the CPU should not be understated by that
+    # `value` is the best the host did in this leg: the two-socket run varies from run to run (110-450 M cycles/s on these
+    # boxes) and is often SLOWER than one socket; the CPU should not be understated by that
     top = max((res["whole_box"], res["one_socket"]), key=lambda r: r["value"])
     out = {"value": top["value"], "unit": "cycles/s", "cores": top["threads"], "kind": "port",
            "whole_box_value": res["whole_box"]["value"], "whole_box_threads": res["whole_box"]["threads"],
