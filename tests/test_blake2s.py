@@ -88,6 +88,11 @@ def test_gpu_matches_hashlib_and_oracle(product, oracle):
     got = product.blake2s256(msgs)
     assert got == want(msgs) and got == oracle.blake2s256(msgs)
     assert product.blake2s256([]) == [] and product.blake2s256([b""] * 130) == [EMPTY] * 130
+    # one long message beside short ones (the lanes of its wave leave the block loop 16,000 iterations earlier), ragged start
+    rng = random.Random(9)
+    big = bytes(rng.getrandbits(8) for _ in range(1 << 20))
+    batch = [b"x", big[: (1 << 20) - 3], b"", big[5:70000], b"tail"]
+    assert product.blake2s256(batch) == want(batch)
 
 
 @pytest.mark.gpu
