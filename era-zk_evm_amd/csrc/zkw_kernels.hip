@@ -343,6 +343,18 @@ ZD uint8_t zkw_gload1(const uint8_t* p) { return *p; }
 ZD void zkw_gstore1(uint8_t* p, uint8_t v) { *p = v; }
 #endif
 
+// "Every vector-memory load issued so far has landed": s_waitcnt vmcnt(0) as a BUILTIN, which the compiler's wait-count
+// insertion sees (an asm statement it does not).  Placed right after a group of loads whose values are needed at once
+// anyway.  Without it the pass carries "a load may be pending in v[..]" along one path to the next control-flow join and
+// puts an s_waitcnt vmcnt(0) THERE — after the opcode body, at the entry of the next one — where, vmcnt being one
+// in-order counter for loads and stores, it waits for the acknowledgement of every stream store the body has just issued
+// (the cycle kernel spent 54 % of its wave-cycles in s_waitcnt, SQ_WAIT_ANY; the loads account for a third of that).
+#ifdef __HIP_DEVICE_COMPILE__
+ZD void zkw_vm_settle() { __builtin_amdgcn_s_waitcnt(0x0f70); }  // vmcnt(0), expcnt / lgkmcnt untouched
+#else
+ZD void zkw_vm_settle() {}
+#endif
+
 // orders this wave's own LDS stores before later cross-lane LDS reads/atomics (no workgroup barrier involved)
 ZD void zkw_wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -608,8 +620,15 @@ ZD u256 stack_read(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, u32& is_ptr) {
   // need capacity, and stack_hwm <= S
   if (idx >= CF(sh, s, CF_STACK_HWM)) return u256_zero();
   const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), sh.S, idx);
-  is_ptr = zkw_gload1(sh.stack_ptrs + w) != 0 ? 1u : 0u;
-  return u256_from_uint4(zkw_gload4(sh.stack_vals + (2 * w - s.lane)), zkw_gload4(sh.stack_vals + (2 * w - s.lane + sh.L)));
+  // (the tag byte last: loads return in order, so a use of the tag scheduled early cannot split the three into two round trips)
+  const uint4 lo = zkw_gload4(sh.stack_vals + (2 * w - s.lane)), hi = zkw_gload4(sh.stack_vals + (2 * w - s.lane + sh.L));
+#ifdef __HIP_DEVICE_COMPILE__
+  asm volatile("" : : : "memory");  // (the scheduler otherwise issues the byte load first and waits for it alone)
+#endif
+  const uint8_t tag = zkw_gload1(sh.stack_ptrs + w);
+  zkw_vm_settle();
+  is_ptr = tag != 0 ? 1u : 0u;
+  return u256_from_uint4(lo, hi);
 }
 // MemoryType::Stack write (memory.rs:413-425)
 ZD void stack_write(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, const u256& v, bool is_ptr) {
@@ -729,7 +748,9 @@ ZD u256 fat_ptr_read(ZKW_KP P, const Shared& sh, Lane& s, u32 page, u32 idx) {
 ZD u256 code_read(const Shared& sh, const Lane& s, u32 idx) {
   if (idx >= CF(sh, s, CF_CODE_LEN)) return u256_zero();
   const u64 w = (u64)CF(sh, s, CF_CODE_OFF) + idx;
-  return u256_from_uint4(zkw_gload4(sh.blob_words + 2 * w), zkw_gload4(sh.blob_words + 2 * w + 1));
+  const uint4 lo = zkw_gload4(sh.blob_words + 2 * w), hi = zkw_gload4(sh.blob_words + 2 * w + 1);
+  zkw_vm_settle();
+  return u256_from_uint4(lo, hi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1104,6 +1125,7 @@ ZD void op_context(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, cons
 #pragma unroll
     for (int i = 0; i < 4; i++) value.w[i] = e[E_CTX + i];
   }
+  zkw_vm_settle();
   dst0_update(P, sh, rf, s, ps.dst0, d.dst0, value, false);
 }
 
@@ -1238,6 +1260,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
     // and emitting word by word would serialise two memory round trips (the dominant cost of this opcode)
     w0v = is_ptr_read ? fat_ptr_read(P, sh, s, fp.page, word0) : heap_read_at(P, sh, s, !is_heap, f_slot, f_hwm, word0);
     if (unaligned) w1v = is_ptr_read ? fat_ptr_read(P, sh, s, fp.page, word1) : heap_read_at(P, sh, s, !is_heap, f_slot, f_hwm, word1);
+    zkw_vm_settle();
     ZKW_SUB(64)  // loads issued
 #ifdef ZKW_PROFILE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2182,6 +2205,17 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
   if constexpr (!IS_VEC) {
   if (call_out) {
     const zkw_v16 r = zkw_heavy_entry(oa, ob);
+#ifdef __HIP_DEVICE_COMPILE__
+    {
+      // The register allocator keeps the loop's shared "zero high half" (every u32 -> u64 extension pairs with it) in a
+      // caller-saved register and reloads it from scratch behind this call — lazily, on the way to the join below, where
+      // the pending reload would make EVERY group iteration wait for vmcnt(0), i.e. for the stores of its opcode body.
+      // A zero extension right here pulls the reload in front of the settle.
+      const u64 z = (u64)r[0];
+      asm volatile("" : : "v"(z));
+    }
+#endif
+    zkw_vm_settle();
     lane_unpack(s, r);
     s.lane = zkw_lane_id();
     ZKW_STAMP(55)  // return + epilogue of the callee
@@ -2206,6 +2240,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
         for (u32 q = 13; q <= 15; q++) reg_write(sh, rf, s, q, u256_zero(), false);
       }
       ZKW_STAMP(56)  // actions
+      zkw_vm_settle();  // (the operand descriptor is reloaded from scratch for the actions: not carried to the join either)
     }
   }
   }
@@ -2461,7 +2496,10 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
             if (err | nop) {
               // mask_into_panic (:187-190) / mask_into_nop (:212-217): the lane re-enters the loop as a member of
               // the group of the panic / nop encoding (all operand fields zero, condition Always)
-              const u64 masked = err ? P.consts.exception_revert_encoding : P.consts.nop_encoding;
+              // (both encodings as scalar loads, then a per-lane select: `err ? a : b` on the parameter block itself became a
+              // per-lane ADDRESS select and a vector-memory load + s_waitcnt vmcnt(0) for every masked group)
+              const u64 enc_panic = P.consts.exception_revert_encoding, enc_nop = P.consts.nop_encoding;
+              const u64 masked = err ? enc_panic : enc_nop;
               const uint2 e1 = sh.isa[(u32)masked & (ZKW_ISA_TABLE_SIZE - 1)];
               ZKW_SLOT_WRITE(sh, lane_now, 4, make_uint4((u32)masked, (u32)(masked >> 32), e1.x, e1.y));
               s.kflags |= KF_MASKED;

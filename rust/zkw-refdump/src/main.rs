@@ -2,7 +2,8 @@
 //!
 //! UNBUILT in the repository's own image (no Rust toolchain, no network).  Written against the public API the
 //! reference crate itself uses (file:line below are /root/reference/src = matter-labs/era-zk_evm @ v1.4.1):
-//!   * `VmState::empty_state` / `push_bootloader_context` / `cycle`      vm_state/mod.rs:188-207, helpers.rs:289-316, cycle.rs:257
+//!   * `VmState::empty_state` / `push_bootloader_context` / `start_frame` vm_state/mod.rs:188-207, helpers.rs:289-316, :225-246
+//!   * `VmState::cycle(&mut self, tracer: &mut DT)` with the debug tracer  cycle.rs:257-260; `GenericNoopTracer` utils.rs:51-92
 //!   * `VmWitnessTracer` (10 callbacks)                                   witness_trace/mod.rs:11-72
 //!   * `SimpleMemory`, `SimpleDecommitter<true>`, `InMemoryEventSink`     reference_impls/
 //!   * `InMemoryStorage`, `DefaultPrecompilesProcessor<true>`             testing/storage.rs, testing/mod.rs:12-40
@@ -31,6 +32,7 @@ use zk_evm::zk_evm_abstractions::vm::{MemoryType, PrecompileCyclesWitness, Refun
 use zk_evm::zkevm_opcode_defs as defs;
 use zk_evm::zkevm_opcode_defs::decoding::encoding_mode_production::EncodingModeProduction;
 use zk_evm::zkevm_opcode_defs::decoding::VmEncodingMode;
+use zk_evm::GenericNoopTracer; // utils.rs:51-60, re-exported at the crate root (lib.rs:12 `pub use self::utils::*`)
 
 type E = EncodingModeProduction;
 
@@ -88,6 +90,11 @@ fn address_le(a: &Address) -> [u8; 20] {
     let mut b = a.to_fixed_bytes();
     b.reverse();
     b
+}
+/// the low 32 bits of an address (H160 is big-endian)
+fn address_low_u32(a: &Address) -> u32 {
+    let b = a.as_fixed_bytes();
+    u32::from_be_bytes([b[16], b[17], b[18], b[19]])
 }
 fn address_from_le(b: &[u8]) -> Address {
     let mut x = [0u8; 20];
@@ -214,9 +221,9 @@ fn dump_isa(out: &str) -> anyhow::Result<()> {
     put(c, 52, defs::ERGS_PER_CODE_WORD_DECOMMITTMENT);
     put(c, 56, defs::system_params::INITIAL_STORAGE_WRITE_PUBDATA_BYTES as u32);
     put(c, 60, defs::system_params::L1_MESSAGE_PUBDATA_BYTES);
-    put(c, 64, defs::uma::MAX_OFFSET_TO_DEREF_LOW_U32);
-    put(c, 68, defs::system_params::DEPLOYER_SYSTEM_CONTRACT_ADDRESS_LOW as u32);
-    put(c, 72, defs::system_params::KECCAK256_ROUND_FUNCTION_PRECOMPILE_ADDRESS as u32);
+    put(c, 64, defs::uma::MAX_OFFSET_TO_DEREF.low_u32()); // the U256 bound of uma.rs:127
+    put(c, 68, address_low_u32(&defs::system_params::DEPLOYER_SYSTEM_CONTRACT_ADDRESS)); // far_call.rs:6,136
+    put(c, 72, address_low_u32(&defs::system_params::KECCAK256_ROUND_FUNCTION_PRECOMPILE_FORMAL_ADDRESS) & 0xffff); // testing/tests/precompiles/keccak256.rs:114
     put(c, 76, defs::system_params::SHA256_ROUND_FUNCTION_PRECOMPILE_ADDRESS as u32);
     put(c, 80, defs::system_params::ECRECOVER_INNER_FUNCTION_PRECOMPILE_ADDRESS as u32);
     c[84] = defs::system_params::STORAGE_AUX_BYTE;
@@ -473,7 +480,8 @@ fn run(inputs: &str, out: &str) -> anyhow::Result<()> {
     for i in 0..n {
         let st = &c["states"][680 * i..680 * (i + 1)];
         let inner = &c["inner"][112 * depth * i..112 * depth * (i + 1)];
-        let mut memory = SimpleMemory::new_without_preallocations();
+        // (the type annotation fixes the hasher parameter: only `SimpleMemory<RandomState>` implements `Memory`, memory.rs:403)
+        let memory: SimpleMemory = SimpleMemory::new_without_preallocations();
         let mut storage = InMemoryStorage::new();
         let mut decommitter = SimpleDecommitter::<true>::new();
         decommitter.populate(
@@ -485,7 +493,7 @@ fn run(inputs: &str, out: &str) -> anyhow::Result<()> {
         }
         let mut vm = VmState::<_, _, _, _, _, _, 8, E>::empty_state(
             storage,
-            memory_placeholder(&mut memory),
+            memory,
             InMemoryEventSink::new(),
             DefaultPrecompilesProcessor::<true>,
             decommitter,
@@ -495,7 +503,16 @@ fn run(inputs: &str, out: &str) -> anyhow::Result<()> {
         // the frames alive at the start: what the host did before handing over (helpers.rs:289-316)
         let frames: Vec<CallStackEntry<8, E>> = (1..depth).map(|d| entry_from_c(&inner[112 * d..112 * (d + 1)])).chain(std::iter::once(entry_from_c(&st[568..680]))).collect();
         for f in frames.iter() {
-            vm.push_bootloader_context(0, *f);
+            // The exact entries (ergs included) are written over the callstack below; here the frames only have to exist
+            // in the oracles.  `push_bootloader_context` subtracts the new frame's ergs from the current one and asserts
+            // that it does not underflow (helpers.rs:295-302), so the frame is pushed with no ergs; a far frame also
+            // starts a global memory frame (helpers.rs:308-315), a near-call frame is `start_frame` alone (:225-246).
+            let pushed = CallStackEntry { ergs_remaining: 0, ..*f };
+            if f.is_local_frame {
+                vm.start_frame(0, pushed);
+            } else {
+                vm.push_bootloader_context(0, pushed);
+            }
         }
         // code pages, heap image of the first far frame
         let mut pages = vec![];
@@ -548,13 +565,16 @@ fn run(inputs: &str, out: &str) -> anyhow::Result<()> {
             vm.local_state.memory_page_counter,
             vm.local_state.context_u128_register,
         );
+        // the debug tracer argument of `cycle` (cycle.rs:257-260): the crate's own no-op implementation, whose four
+        // CALL_* constants are false (tracing.rs:43-46) — the hooks are compiled out
+        let mut debug_tracer = GenericNoopTracer::<SimpleMemory>::new();
         let mut status = 0u32; // ZKW_STATUS_RUNNING
         for _ in 0..n_cycles {
             if vm.execution_has_ended() {
                 status = 1; // ZKW_STATUS_ENDED
                 break;
             }
-            let r = std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| vm.cycle()));
+            let r = std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| vm.cycle(&mut debug_tracer)));
             match r {
                 Ok(Ok(())) => {}
                 Ok(Err(_)) => {
@@ -585,12 +605,6 @@ fn run(inputs: &str, out: &str) -> anyhow::Result<()> {
         w.section(&format!("final{}", i), &state_c(&vm.local_state));
     }
     w.save(out)
-}
-
-/// `SimpleMemory` is moved into the VM; this helper exists so that the call site above reads as the order of
-/// `empty_state`'s parameters (storage, memory, event sink, precompiles, decommitter, tracer, block properties).
-fn memory_placeholder(m: &mut SimpleMemory) -> SimpleMemory {
-    std::mem::replace(m, SimpleMemory::new_without_preallocations())
 }
 
 fn main() -> anyhow::Result<()> {

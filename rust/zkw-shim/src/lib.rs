@@ -3,15 +3,18 @@
 //!
 //! The reference interprets one cycle per `VmState::cycle()` call (reference src/vm_state/cycle.rs:257) and calls its
 //! `VmWitnessTracer` / `EventSink` from inside.  Here the cycles of a whole batch of instances are executed by the HIP
-//! kernels first (`Batch::run`), and `BatchedVmState::cycle()` then REPLAYS one cycle of one instance from the finished
-//! trace: the same callbacks, with the same arguments, in the same order, and `local_state` ends
-//! every call in the state the reference would be in.  A caller's loop
+//! kernels first (`Batch::run`), and `BatchedVmState::cycle(&mut tracer)` then REPLAYS one cycle of one instance from
+//! the finished trace: the same callbacks, with the same arguments, in the same order, and
+//! `local_state` ends every call in the state the reference would be in.  A caller's loop
 //!
 //! ```ignore
-//! while !vm.execution_has_ended() { vm.cycle()?; }
+//! let mut tracer = zk_evm::GenericNoopTracer::<SimpleMemory>::new();   // utils.rs:51-60
+//! while !vm.execution_has_ended() { vm.cycle(&mut tracer)?; }          // cycle.rs:257-260
 //! ```
 //!
-//! is unchanged.  Oracles whose answers the VM consumes (Memory, Storage, Decommitter, Precompiles) are snapshotted
+//! is unchanged: `cycle` keeps the reference's debug-`Tracer` parameter.  The four hooks of that trait are compiled out
+//! unless the tracer's `CALL_*` constants say otherwise (tracing.rs:43-46); a tracer that asks for them is refused
+//! loudly (they would need the decode internals of every cycle on the host — out of scope).  Oracles whose answers the VM consumes (Memory, Storage, Decommitter, Precompiles) are snapshotted
 //! into the batch before the run (`Batch::set_*`: the reference impls `SimpleMemory`, `InMemoryStorage`,
 //! `SimpleDecommitter` map one to one); oracles that only receive data (witness tracer, event sink) are driven by the
 //! replay.  The C++ form of this file — era-zk_evm_amd/host/zk_evm.hpp — is what the repository's tests exercise.
@@ -23,6 +26,7 @@ use ffi::*;
 use zk_evm::aux_structures::{DecommittmentQuery, LogQuery, MemoryIndex, MemoryLocation, MemoryPage, MemoryQuery, Timestamp};
 use zk_evm::ethereum_types::{Address, U256};
 use zk_evm::flags::Flags;
+use zk_evm::tracing::Tracer;
 use zk_evm::vm_state::{CallStackEntry, Callstack, PrimitiveValue, VmLocalState};
 use zk_evm::witness_trace::VmWitnessTracer;
 use zk_evm::zk_evm_abstractions::vm::{EventSink, MemoryType, PrecompileCyclesWitness, RefundType};
@@ -42,6 +46,11 @@ pub fn address_from_c(b: &[u8; 20]) -> Address {
     let mut x = *b;
     x.reverse();
     Address::from(x)
+}
+/// the low 32 bits of an address (H160 is big-endian)
+pub fn address_low_u32(a: &Address) -> u32 {
+    let b = a.as_fixed_bytes();
+    u32::from_be_bytes([b[16], b[17], b[18], b[19]])
 }
 pub fn address_to_c(a: &Address) -> [u8; 20] {
     let mut x = a.to_fixed_bytes();
@@ -223,9 +232,9 @@ pub fn isa_from_opcode_defs() -> Box<zkw_isa_table> {
     c.ergs_per_code_word_decommittment = defs::ERGS_PER_CODE_WORD_DECOMMITTMENT;
     c.initial_storage_write_pubdata_bytes = defs::system_params::INITIAL_STORAGE_WRITE_PUBDATA_BYTES as u32;
     c.l1_message_pubdata_bytes = defs::system_params::L1_MESSAGE_PUBDATA_BYTES;
-    c.max_offset_to_deref_low = defs::uma::MAX_OFFSET_TO_DEREF_LOW_U32;
-    c.deployer_address_low = defs::system_params::DEPLOYER_SYSTEM_CONTRACT_ADDRESS_LOW as u32;
-    c.keccak_precompile_address = defs::system_params::KECCAK256_ROUND_FUNCTION_PRECOMPILE_ADDRESS as u32;
+    c.max_offset_to_deref_low = defs::uma::MAX_OFFSET_TO_DEREF.low_u32(); // the U256 bound of uma.rs:127
+    c.deployer_address_low = address_low_u32(&defs::system_params::DEPLOYER_SYSTEM_CONTRACT_ADDRESS); // far_call.rs:6,136
+    c.keccak_precompile_address = address_low_u32(&defs::system_params::KECCAK256_ROUND_FUNCTION_PRECOMPILE_FORMAL_ADDRESS) & 0xffff; // testing/tests/precompiles/keccak256.rs:114
     c.sha256_precompile_address = defs::system_params::SHA256_ROUND_FUNCTION_PRECOMPILE_ADDRESS as u32;
     c.ecrecover_precompile_address = defs::system_params::ECRECOVER_INNER_FUNCTION_PRECOMPILE_ADDRESS as u32;
     c.storage_aux_byte = defs::system_params::STORAGE_AUX_BYTE;
@@ -397,9 +406,15 @@ impl<'b, EV: EventSink, WT: VmWitnessTracer<8, E>> BatchedVmState<'b, EV, WT> {
         self.local_state.execution_has_ended() // vm_state/mod.rs:214-216
     }
 
-    /// `VmState::cycle` (cycle.rs:257-429): Ok(()) per replayed cycle; `Err` where the reference returns `Err`
-    /// (decommitter.rs:54-56) or where the recorded cycles are exhausted; panics where the reference panics.
-    pub fn cycle(&mut self) -> anyhow::Result<()> {
+    /// `VmState::cycle` (cycle.rs:257-429, signature :257-260): Ok(()) per replayed cycle; `Err` where the reference
+    /// returns `Err` (decommitter.rs:54-56) or where the recorded cycles are exhausted; panics where the reference panics.
+    /// `tracer` is the reference's debug tracer: accepted so that the caller's loop compiles unchanged, never called —
+    /// its hooks are const-gated (tracing.rs:43-46) and a tracer that enables one is refused.
+    pub fn cycle<DT: Tracer<8, E>>(&mut self, _tracer: &mut DT) -> anyhow::Result<()> {
+        assert!(
+            !(DT::CALL_BEFORE_DECODING || DT::CALL_AFTER_DECODING || DT::CALL_BEFORE_EXECUTION || DT::CALL_AFTER_EXECUTION),
+            "zkw-shim replays finished cycles: the debug Tracer hooks (tracing.rs:40-72) are not available"
+        );
         let t = &self.trace;
         if self.k >= t.n_cycles {
             match t.status {
@@ -558,7 +573,7 @@ fn round_witness(call: &LogQuery, pin: &[MemoryQuery], pout: &[MemoryQuery]) -> 
         let b = call.address.to_fixed_bytes();
         u16::from_be_bytes([b[18], b[19]])
     };
-    if low == defs::system_params::SHA256_ROUND_FUNCTION_PRECOMPILE_ADDRESS {
+    if low as u64 == defs::system_params::SHA256_ROUND_FUNCTION_PRECOMPILE_ADDRESS as u64 { // (cast as in testing/tests/precompiles/sha256.rs:91)
         let rounds = call.key.0[3] as usize;
         let mut v = vec![];
         for r in 0..rounds {
@@ -569,9 +584,9 @@ fn round_witness(call: &LogQuery, pin: &[MemoryQuery], pout: &[MemoryQuery]) -> 
             });
         }
         Some(PrecompileCyclesWitness::Sha256(v))
-    } else if low == defs::system_params::ECRECOVER_INNER_FUNCTION_PRECOMPILE_ADDRESS {
+    } else if low as u64 == defs::system_params::ECRECOVER_INNER_FUNCTION_PRECOMPILE_ADDRESS as u64 {
         Some(PrecompileCyclesWitness::ECRecover(vec![ECRecoverRoundWitness { new_request: *call, reads: [pin[0], pin[1], pin[2], pin[3]], writes: [pout[0], pout[1]] }]))
-    } else if low == defs::system_params::KECCAK256_ROUND_FUNCTION_PRECOMPILE_ADDRESS {
+    } else if low as u32 == address_low_u32(&defs::system_params::KECCAK256_ROUND_FUNCTION_PRECOMPILE_FORMAL_ADDRESS) & 0xffff {
         const RATE: usize = 136;
         const PER_CYCLE: usize = 6;
         const BUF: usize = PER_CYCLE * 32;
