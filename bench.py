@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--fuse", type=int, default=64, help="batches (steps) per fused launch (zkw_batches_step), <= 256 (ZKW_MAX_FUSED)")
     ap.add_argument("--streams", type=int, default=0, help="fused groups in flight (1 = everything on one stream; >= 2 = restore + cycle kernels on the main stream, commitments and the digest exchange on side streams; 0 = 2)")
     ap.add_argument("--side", choices=["commit", "commit+reset"], default="commit+reset", help="what the side streams carry when --streams >= 2")
+    ap.add_argument("--no-rccl", action="store_true", help="skip libzkw.so's own RCCL communicator: the final exchange runs over the torch process group (the fallback of shard.make_comm)")
     ap.add_argument("--force-collective", action="store_true", help="run the digest all-gather even with one rank (exercises the multi-GPU code path on a single GPU)")
     ap.add_argument("--main-priority", type=int, default=0, help="1 = create the main stream with high priority")
     ap.add_argument("--cfg", type=int, default=2)
@@ -83,12 +84,13 @@ def main():
     # communicator created from an id that rank 0 generates and hands to the others (here over the process group that
     # also serves the barriers).  One rank without --force-collective: a one-rank communicator without RCCL, used for
     # the counter totals only.
+    from era_zk_evm_amd import shard
     if collective:
-        ids = [K.Comm.unique_id(prod) if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0, device=torch.device("cuda", local_rank))
-        comm = K.Comm.rccl(prod, rank, world, ids[0])
+        # RCCL inside libzkw.so when every rank can create that communicator; otherwise all ranks together fall back to
+        # the library's external transport over the process group that is already up (era-zk_evm_amd/shard.py)
+        comm, transport = shard.make_comm(prod, rank, world, device=torch.device("cuda", local_rank), prefer_rccl=not args.no_rccl)
     else:
-        comm = K.Comm.external(prod, 0, 1)
+        comm, transport = K.Comm.external(prod, 0, 1), "single rank (no transport)"
     # shard: every rank owns `instances` independent VM instances (different seeds), no data-path collective
     if args.cfg == 0:  # NOP/ADD plumbing tape replicated over many instances (loop-overhead floor)
         wl = synth.make(1, isa, n_instances=args.instances, n_cycles=args.cycles, seed=0x5EED0000 + 0x100 * rank)
@@ -128,8 +130,12 @@ def main():
     # only the committed queues travel: [fuse, instances, n_committed, 4] u64 per group
     # only the committed queues travel: [world][batches][instances][n_committed][4] u64 per group (layout of zkw_reduce_commitments)
     committed = [q for q in range(3) if (args.commit_mask >> q) & 1]
-    gathered = [torch.zeros((world, fuse, args.instances, max(1, len(committed)), 4), dtype=torch.int64, device="cuda") if collective else None
-                for _ in range(n_groups)]
+    # (device tensors for the RCCL communicator, host arrays for the external transport)
+    import numpy as np
+    gathered = [None] * n_groups
+    if collective:
+        shape = (world, fuse, args.instances, max(1, len(committed)), 4)
+        gathered = [torch.zeros(shape, dtype=torch.int64, device="cuda") if comm.device_buffers else np.zeros(shape, dtype="<u8") for _ in range(n_groups)]
 
     # Pipelining over streams (--streams >= 2): the main stream carries the cycle kernels of the groups back to back;
     # every group has a side stream that carries its commitment kernels (integer-ALU bound), the digest exchange and
@@ -166,7 +172,7 @@ def main():
             stream.wait_event(ev_run[g])
             prod.commit_many(groups[g][:n], args.commit_mask, sptr)
         if args.commit_mask and collective:  # pack kernel + ncclAllGather, enqueued on the group's stream (asynchronous)
-            comm.reduce(groups[g][:n], args.commit_mask, gathered=gathered[g].data_ptr(), stream=sptr)
+            comm.reduce(groups[g][:n], args.commit_mask, gathered=(gathered[g].data_ptr() if comm.device_buffers else (gathered[g] if n == fuse else None)), stream=sptr)
         if overlap:
             if side_reset:
                 prod.reset_many(groups[g], sptr)  # the whole group, so that a later partial launch finds it restored
@@ -284,7 +290,8 @@ def main():
             "dtype": "u256 (8 x u32 limbs)", "data": "synthetic",
             "config": {"workload": "cfg%d: %d instances x %d cycles per GPU (%s)" % (args.cfg, args.instances, args.cycles, wl.name),
                        "instances_per_gpu": args.instances, "cycles_per_instance": args.cycles, "lanes_per_wave": int(batch.limits["lanes_per_wave"][0]), "commit_mask": args.commit_mask,
-                       "batches_per_fused_launch": batches_per_launch, "fused_groups_in_flight": n_groups, "side_stream_work": (args.side if overlap else None), "cycle_kernel_launches": n_launches},
+                       "batches_per_fused_launch": batches_per_launch, "fused_groups_in_flight": n_groups, "side_stream_work": (args.side if overlap else None), "cycle_kernel_launches": n_launches,
+                       "collective": transport},
             "kernel_ms": k_ms, "kernel_ms_alone": k_ms_alone,
             "pcie_download_of_one_step": {"bytes": dl_bytes.value, "ms": dl_ms.value, "GBps": dl_bytes.value / max(dl_ms.value, 1e-9) / 1e6,
                                           "cycles_per_s_if_every_step_were_downloaded": cycles_per_step / (1e-3 * (dl_ms.value + ms_per_step))}, "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,

@@ -204,6 +204,9 @@ class ZkwError(RuntimeError):
     pass
 
 
+OPT_DEBUG_FLAGS, OPT_RESET_SKIP, OPT_NO_INLINE_DECOMMIT, OPT_DEBUG_SYNC, OPT_NO_GRAPH, OPT_WAVES_PER_GROUP, OPT_LANES_PER_WAVE = 1, 2, 3, 5, 6, 7, 8
+
+
 class Backend:
     def __init__(self, path, prefix):
         if not os.path.exists(path):
@@ -235,6 +238,12 @@ class Backend:
         if self.ctx:
             self.fn("ctx_destroy")(self.ctx)
             self.ctx = C.c_void_p()
+
+    def set_option(self, option, value):
+        """zkw_ctx_set_option: test hooks / ablations of the engine (OPT_*).  The oracle has none of them: a no-op there."""
+        if self.prefix != "zkw_":
+            return
+        self.call("ctx_set_option", self.ctx, C.c_uint32(option), C.c_uint64(value))
 
     def create_batch(self, workload):
         return Batch(self, workload)
@@ -338,6 +347,10 @@ class Comm:
         backend.call("comm_create_external", backend.ctx, C.c_int(rank), C.c_int(world), ag, ar, None, C.byref(self.h))
         self.device_buffers = False
         return self
+
+    def exchange_sizes(self, n_instances, stream=None):
+        """zkw_comm_exchange_sizes — COLLECTIVE: every rank announces the shard size it reduces from now on"""
+        self.be.call("comm_exchange_sizes", self.h, C.c_uint32(n_instances), C.c_void_p(stream))
 
     def reduce(self, batches, queue_mask, gathered=None, want_total=False, stream=None):
         """zkw_reduce_commitments.  `gathered`: a device pointer (int) for an RCCL communicator, None or a numpy u64

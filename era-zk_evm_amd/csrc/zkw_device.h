@@ -161,6 +161,7 @@ typedef struct zkw_kparams {
   const uint64_t* blob_digests; /* [n_blobs][4] */
   uint64_t* commit_out;         /* [n_instances][ZKW_QUEUE_COUNT][4]: the DECOMMIT slot is the running tail */
   uint32_t* dq_count;           /* [n_instances] decommit-queue length so far */
+  uint64_t* dq_prev;            /* [n_instances][4] the tail before the decommit chained last: what a cycle that fails AFTER its decommit restores */
   uint32_t* dir;               /* [n_waves][max_cycles + 1][4] (mem, log, aux cursors at cycle start) */
   uint32_t* cursors;           /* [n_waves][4] persistent stream cursors: mem, log, aux, register deltas */
 } zkw_kparams;

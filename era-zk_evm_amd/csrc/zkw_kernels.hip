@@ -59,6 +59,7 @@ struct Lane {
 #define KF_CHARGED 32u     /* this cycle's price is taken and its exceptions / condition are resolved (group loop) */
 #define KF_MASKED 64u      /* the instruction of this cycle is the one in sh.enc (pending exception, masked into nop / panic), not the slot of the code word */
 #define KF_CODE_PAGE_CHANGED 16u /* previous_code_memory_page != callstack.current.code_page (cycle.rs:49,59) */
+#define KF_DQ_CHAINED 128u /* this cycle chained a decommit into the running commitment (op_far_call): undone if the cycle fails afterwards */
 // The rest of the per-lane state lives in LDS, [field][lane] (conflict-free dword accesses); CF(sh, s, field) is an
 // lvalue.  Rare opcodes touch the first block, memory operands / frame changes the second.
 enum {
@@ -349,10 +350,39 @@ ZD void zkw_gstore1(uint8_t* p, uint8_t v) { *p = v; }
 // puts an s_waitcnt vmcnt(0) THERE — after the opcode body, at the entry of the next one — where, vmcnt being one
 // in-order counter for loads and stores, it waits for the acknowledgement of every stream store the body has just issued
 // (the cycle kernel spent 54 % of its wave-cycles in s_waitcnt, SQ_WAIT_ANY; the loads account for a third of that).
+#ifdef ZKW_WAITPROF  /* profiling build (profiles/tools/r03_waitprof.sh): clocks a wave spends in each of these waits */
+__shared__ unsigned long long zw_acc[ZKW_WAVES_PER_GROUP][32];  // [site] clocks, [16 + site] count
+#endif
 #ifdef __HIP_DEVICE_COMPILE__
-ZD void zkw_vm_settle() { __builtin_amdgcn_s_waitcnt(0x0f70); }  // vmcnt(0), expcnt / lgkmcnt untouched
+#ifdef ZKW_WAITPROF
+#define ZKW_SETTLE(site)                                                                                   \
+  {                                                                                                        \
+    const unsigned long long zw_t0 = __builtin_readcyclecounter();                                         \
+    __builtin_amdgcn_s_waitcnt(0x0f70);                                                                    \
+    const unsigned long long zw_t1 = __builtin_readcyclecounter();                                         \
+    if (zkw_rank_below(__ballot(1)) == 0) {                                                                \
+      zw_acc[threadIdx.x / ZKW_WAVE][(site)] += zw_t1 - zw_t0;                                             \
+      zw_acc[threadIdx.x / ZKW_WAVE][16 + (site)] += 1;                                                    \
+    }                                                                                                      \
+  }
+// the same around an LDS / scalar-memory wait (lgkmcnt(0))
+#define ZKW_LGKM_PROBE(site)                                                                               \
+  {                                                                                                        \
+    const unsigned long long zw_t0 = __builtin_readcyclecounter();                                         \
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                                                    \
+    const unsigned long long zw_t1 = __builtin_readcyclecounter();                                         \
+    if (zkw_rank_below(__ballot(1)) == 0) {                                                                \
+      zw_acc[threadIdx.x / ZKW_WAVE][(site)] += zw_t1 - zw_t0;                                             \
+      zw_acc[threadIdx.x / ZKW_WAVE][16 + (site)] += 1;                                                    \
+    }                                                                                                      \
+  }
 #else
-ZD void zkw_vm_settle() {}
+#define ZKW_SETTLE(site) __builtin_amdgcn_s_waitcnt(0x0f70) /* vmcnt(0), expcnt / lgkmcnt untouched */
+#define ZKW_LGKM_PROBE(site)
+#endif
+#else
+#define ZKW_SETTLE(site)
+#define ZKW_LGKM_PROBE(site)
 #endif
 
 // orders this wave's own LDS stores before later cross-lane LDS reads/atomics (no workgroup barrier involved)
@@ -626,7 +656,7 @@ ZD u256 stack_read(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, u32& is_ptr) {
   asm volatile("" : : : "memory");  // (the scheduler otherwise issues the byte load first and waits for it alone)
 #endif
   const uint8_t tag = zkw_gload1(sh.stack_ptrs + w);
-  zkw_vm_settle();
+  ZKW_SETTLE(1 /* stack operand */);
   is_ptr = tag != 0 ? 1u : 0u;
   return u256_from_uint4(lo, hi);
 }
@@ -749,8 +779,31 @@ ZD u256 code_read(const Shared& sh, const Lane& s, u32 idx) {
   if (idx >= CF(sh, s, CF_CODE_LEN)) return u256_zero();
   const u64 w = (u64)CF(sh, s, CF_CODE_OFF) + idx;
   const uint4 lo = zkw_gload4(sh.blob_words + 2 * w), hi = zkw_gload4(sh.blob_words + 2 * w + 1);
-  zkw_vm_settle();
+  ZKW_SETTLE(0 /* code word */);
   return u256_from_uint4(lo, hi);
+}
+// The instruction fetch of a cycle (cycle.rs:76-81).  Instances of a wave usually run the same code at the same pc: the
+// word is then ONE scalar-memory load (s_load_dwordx8 through the scalar cache, counted on lgkmcnt) broadcast to the
+// lanes, instead of a vector load per lane that queues behind the wave's stream stores (vmcnt is in order: the fetch
+// waited ~1000 clocks, 90 times per 256 cycles).  Code blobs are read-only for the lifetime of a batch, so the scalar
+// cache cannot hold a stale word.  Lanes that disagree on (blob, length, word index) take the per-lane path.
+ZD u256 code_fetch(const Shared& sh, const Lane& s, u32 idx) {
+#ifdef __HIP_DEVICE_COMPILE__
+  const u32 c_len = CF(sh, s, CF_CODE_LEN), c_off = CF(sh, s, CF_CODE_OFF);
+  const u32 u_len = (u32)__builtin_amdgcn_readfirstlane((int)c_len), u_off = (u32)__builtin_amdgcn_readfirstlane((int)c_off);
+  const u32 u_idx = (u32)__builtin_amdgcn_readfirstlane((int)idx);
+  if (__ballot((c_len != u_len) | (c_off != u_off) | (idx != u_idx)) == 0) {  // wave-uniform
+    u256 v = u256_zero();
+    if (u_idx < u_len) {
+      typedef u32 zkw_v8u __attribute__((ext_vector_type(8)));
+      const zkw_v8u w = *(const ZKW_CONST_AS zkw_v8u*)((u64)sh.blob_words + (((u64)u_off + u_idx) << 5));
+#pragma unroll
+      for (int i = 0; i < 8; i++) v.w[i] = w[i];
+    }
+    return v;
+  }
+#endif
+  return code_read(sh, s, idx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1125,7 +1178,7 @@ ZD void op_context(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, cons
 #pragma unroll
     for (int i = 0; i < 4; i++) value.w[i] = e[E_CTX + i];
   }
-  zkw_vm_settle();
+  ZKW_SETTLE(3 /* context */);
   dst0_update(P, sh, rf, s, ps.dst0, d.dst0, value, false);
 }
 
@@ -1198,6 +1251,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
     f_slot = CF(sh, s, CF_SLOT);
     f_hwm = is_heap ? CF(sh, s, CF_HEAP_HWM) : CF(sh, s, CF_AUX_HWM);
     f_bound = is_heap ? CF(sh, s, CF_HEAP_BOUND) : CF(sh, s, CF_AUX_BOUND);
+    ZKW_LGKM_PROBE(7 /* UMA frame fields */)
   }
   const u32 f_hwm_in = f_hwm;
   u32 mem_type;
@@ -1260,7 +1314,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
     // and emitting word by word would serialise two memory round trips (the dominant cost of this opcode)
     w0v = is_ptr_read ? fat_ptr_read(P, sh, s, fp.page, word0) : heap_read_at(P, sh, s, !is_heap, f_slot, f_hwm, word0);
     if (unaligned) w1v = is_ptr_read ? fat_ptr_read(P, sh, s, fp.page, word1) : heap_read_at(P, sh, s, !is_heap, f_slot, f_hwm, word1);
-    zkw_vm_settle();
+    ZKW_SETTLE(2 /* UMA words */);
     ZKW_SUB(64)  // loads issued
 #ifdef ZKW_PROFILE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1425,6 +1479,17 @@ ZD void versioned_hash(const u256& h, bool& ok, u32& marker, u32& len_words, u25
   len_words = h.w[7] & 0xffffu;
   stored = h;
   stored.w[7] &= 0xff00ffffu;
+}
+
+// takes back the decommit this cycle chained into the running commitment (the cycle failed behind it: see op_far_call)
+ZD void dq_undo(ZKW_KP P, const Shared& sh, Lane& s) {
+  if (!(s.kflags & KF_DQ_CHAINED)) return;
+  s.kflags &= ~KF_DQ_CHAINED;
+  const u32 inst = lane_inst(sh, s);
+  u64* tail_p = P.commit_out + ((u64)inst * ZKW_QUEUE_COUNT + ZKW_QUEUE_DECOMMIT) * 4;
+  const u64* prev_p = P.dq_prev + (u64)inst * 4;
+  tail_p[0] = prev_p[0]; tail_p[1] = prev_p[1]; tail_p[2] = prev_p[2]; tail_p[3] = prev_p[3];
+  P.dq_count[inst] -= 1;
 }
 
 // far_call.rs:35-613
@@ -1628,9 +1693,16 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
       const u64* ms = P.midstates + (u64)pre * 12;  // the leaf of this code (zkw_midstate_kernel)
       const u64 leaf[4] = {ms[0], ms[1], ms[2], ms[3]};
       u64 tail[4] = {tail_p[0], tail_p[1], tail_p[2], tail_p[3]};
+      // A cycle can still fail behind this point (no arena slot / callstack depth / aux or register-delta capacity left:
+      // ZKW_STATUS_LIMIT), and a failed cycle leaves no records — the chains computed from the streams after a run never
+      // see this decommit.  The previous tail is kept so that a lane that leaves the cycle loop failed takes the step back
+      // (dq_undo, at the loop exit).
+      u64* prev_p = P.dq_prev + (u64)inst * 4;
+      prev_p[0] = tail[0]; prev_p[1] = tail[1]; prev_p[2] = tail[2]; prev_p[3] = tail[3];
       gl_chain_step(P.commit_rc, leaf, tail, (u64)j + 1, ZKW_QUEUE_DECOMMIT, (u64)(s.timestamp + 1) | ((u64)(fresh ? 1u : 0u) << 32), (u64)page);
       tail_p[0] = tail[0]; tail_p[1] = tail[1]; tail_p[2] = tail[2]; tail_p[3] = tail[3];
       P.dq_count[inst] = j + 1;
+      s.kflags |= KF_DQ_CHAINED;
     }
     ZKW_STAMP(59)  // far call: decommit event + chained commitment
     mapped_code_page = page;
@@ -2215,7 +2287,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
       asm volatile("" : : "v"(z));
     }
 #endif
-    zkw_vm_settle();
+    ZKW_SETTLE(4 /* out-of-line call */);
     lane_unpack(s, r);
     s.lane = zkw_lane_id();
     ZKW_STAMP(55)  // return + epilogue of the callee
@@ -2240,7 +2312,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
         for (u32 q = 13; q <= 15; q++) reg_write(sh, rf, s, q, u256_zero(), false);
       }
       ZKW_STAMP(56)  // actions
-      zkw_vm_settle();  // (the operand descriptor is reloaded from scratch for the actions: not carried to the join either)
+      ZKW_SETTLE(5 /* call actions */);  // (the operand descriptor is reloaded from scratch for the actions: not carried to the join either)
     }
   }
   }
@@ -2309,6 +2381,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
   }
 #ifdef ZKW_PROFILE
   for (u32 i = threadIdx.x; i < ZKW_WAVES_PER_GROUP * 80; i += blockDim.x) (&zp_acc[0][0])[i] = 0;
+#endif
+#ifdef ZKW_WAITPROF
+  for (u32 i = threadIdx.x; i < ZKW_WAVES_PER_GROUP * 32; i += blockDim.x) (&zw_acc[0][0])[i] = 0;
 #endif
   __syncthreads();
   if (wave >= P.n_waves) return;  // tail workgroup: no further workgroup-level barrier below
@@ -2405,7 +2480,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
       uint4 dir_entry = zkw_lds_read4(sh.cursor);
       dir_entry.w = delta_cur;
 #endif
-      s.counts = 0; s.kflags &= ~KF_COLD_DIRTY; s.reg_dirty = 0;
+      s.counts = 0; s.kflags &= ~(KF_COLD_DIRTY | KF_DQ_CHAINED); s.reg_dirty = 0;
       // ----------------------------------------------------------------------------------------
       // read_and_decode (cycle.rs:19-236)
       // ----------------------------------------------------------------------------------------
@@ -2413,13 +2488,14 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
       const u32 super_pc = s.pc >> 2, sub_pc = s.pc & 3u;
       if (!pending) {
         if ((s.kflags & KF_CODE_PAGE_CHANGED) || s.prev_super_pc != super_pc) {  // :59-95
-          const u256 word = code_read(sh, s, super_pc);
+          const u256 word = code_fetch(sh, s, super_pc);
           emit_mem(P, sh, s, s.timestamp, ZKW_MEM_CODE, CF(sh, s, CF_CODE_PAGE), super_pc, word, false, false, 0);
           // pre-decode the four opcodes of the word (four independent table reads) next to their encodings: a cycle
           // then needs ONE LDS read for its opcode and the packed ISA entry
           uint2 e4[4];
 #pragma unroll
           for (int i = 0; i < 4; i++) e4[i] = sh.isa[word.w[2 * i] & (ZKW_ISA_TABLE_SIZE - 1)];
+          ZKW_LGKM_PROBE(8 /* pre-decode table reads */)
 #pragma unroll
           for (int i = 0; i < 4; i++) ZKW_SLOT_WRITE(sh, s.lane, i, make_uint4(word.w[2 * i], word.w[2 * i + 1], e4[i].x, e4[i].y));
           s.prev_super_pc = super_pc;
@@ -2458,6 +2534,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
         const u32 lane_now = zkw_lane_id();
         // (a lane that was already served reads a slot it no longer cares about: it is not in `todo`)
         const uint4 me = ZKW_SLOT_READ(sh, lane_now, (s.kflags & KF_MASKED) ? 4u : 3u - (s.pc & 3u));
+        ZKW_LGKM_PROBE(6 /* instruction slot */)
         const u32 charged = s.kflags & KF_CHARGED;
         const u32 u_lo = (u32)__builtin_amdgcn_readlane((int)me.x, (int)leader);
         const u32 u_hi = (u32)__builtin_amdgcn_readlane((int)me.y, (int)leader);
@@ -2621,6 +2698,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
       dir_ptr += 4;
       // leave: failed / out of cycles / execution_has_ended() (mod.rs:96-98: callers stop cycling at depth 0)
       if (!lane_ok(s) || k >= run_cycles || s.depth == 0) {
+        if (!lane_ok(s)) dq_undo(P, sh, s);  // the failed cycle leaves no records: a decommit it chained inline goes too
         lane_writeback(P, sh, rf, s, lane_ok(s) ? k : k - 1u);  // a lane that failed did not complete its last cycle
         break;
       }
@@ -2634,6 +2712,13 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
       if (zp_acc[0][24 + o]) printf("ZKWPROF opcode %d: %llu iterations, %llu clocks each\n", o, zp_acc[0][24 + o], zp_acc[0][8 + o] / zp_acc[0][24 + o]);
     for (int o = 40; o < 80; o++)
       if (zp_acc[0][o] && o != 63) printf("ZKWPROF sub %d: %llu clocks in total\n", o, zp_acc[0][o]);
+  }
+#endif
+#ifdef ZKW_WAITPROF
+  __syncthreads();
+  if (blockIdx.x == 5 && blockIdx.y == 0 && threadIdx.x == 0) {
+    for (int o = 0; o < 16; o++)
+      if (zw_acc[0][16 + o]) printf("ZKWWAIT site %d: %llu waits, %llu clocks in total\n", o, zw_acc[0][16 + o], zw_acc[0][o]);
   }
 #endif
   // wave-cycles executed = the maximum over the lanes (lanes leave the loop at different iterations)

@@ -47,6 +47,9 @@ struct zkw_ctx {
   zkw_isa_table isa;
   uint2* d_isa = nullptr;
   std::string last_error;
+  // test hooks / ablations (zkw_ctx_set_option; the environment is read once, in zkw_ctx_create)
+  uint32_t opt_debug_flags = 0, opt_reset_skip = 0, opt_waves_per_group = 0, opt_lanes_per_wave = 0;
+  bool opt_no_inline_decommit = false, opt_debug_sync = false, opt_no_graph = false;
   // digests of code blobs already hashed on this context, keyed by a 128-bit content hash + length: batches that
   // share bytecode (the usual case) skip the sequential blob chain (~0.1 s for a 2000-word blob) at upload
   std::map<std::array<uint64_t, 3>, std::array<uint64_t, 4>> blob_digest_cache;
@@ -143,11 +146,13 @@ struct zkw_batch {
   DevBuf<uint32_t> d_dir, d_cursors, d_krow;
   DevBuf<uint64_t> d_commit, d_rc, d_blob_digests, d_leaves, d_midstates;
   DevBuf<uint32_t> d_idx, d_counts, d_dq_count;
+  DevBuf<uint64_t> d_dq_prev;  // [n][4]
   int dq_mode = 0;  // decommit-queue commitment since the last reset: 0 undecided, 1 chained by the cycle kernel, 2 by the commitment kernels
   // hipGraph of one whole step (reset -> cycle kernel -> commitment kernels), replayed by zkw_batch_step
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   uint32_t graph_cycles = 0, graph_mask = 0;
+  int graph_dq_mode = 0;  // dq_mode the captured reset + run leave behind (re-established by a replay)
   hipStream_t graph_stream = nullptr;
   bool graph_failed = false;
   static const int EV_RING = 64;
@@ -208,7 +213,40 @@ int zkw_ctx_create(int device, zkw_ctx** out) {
   (void)hipDeviceGetAttribute(&c->wave_width, hipDeviceAttributeWarpSize, device);
   if (c->n_cus <= 0) c->n_cus = 256;
   if (c->wave_width <= 0 || c->wave_width > ZKW_WAVE) c->wave_width = ZKW_WAVE;
+  {  // the only place the library reads its environment: initial values of the options, said out loud
+    static const struct { const char* name; uint32_t opt; } envs[] = {
+        {"ZKW_DEBUG_FLAGS", ZKW_OPT_DEBUG_FLAGS}, {"ZKW_RESET_SKIP", ZKW_OPT_RESET_SKIP}, {"ZKW_NO_INLINE_DECOMMIT", ZKW_OPT_NO_INLINE_DECOMMIT},
+{"ZKW_DEBUG_SYNC", ZKW_OPT_DEBUG_SYNC}, {"ZKW_NO_GRAPH", ZKW_OPT_NO_GRAPH},
+        {"ZKW_WAVES_PER_GROUP", ZKW_OPT_WAVES_PER_GROUP}, {"ZKW_LANES_PER_WAVE", ZKW_OPT_LANES_PER_WAVE}};
+    for (const auto& e : envs)
+      if (const char* v = getenv(e.name)) {
+        const uint64_t val = strtoull(v, nullptr, 0);
+        fprintf(stderr, "libzkw: option %s=%llu taken from the environment (test hook / ablation)\n", e.name, (unsigned long long)val);
+        (void)zkw_ctx_set_option(c, e.opt, val);
+      }
+  }
   *out = c;
+  return ZKW_OK;
+}
+
+int zkw_ctx_set_option(zkw_ctx* c, uint32_t option, uint64_t value) {
+  if (!c) return ZKW_ERR_INVALID;
+  switch (option) {
+    case ZKW_OPT_DEBUG_FLAGS: c->opt_debug_flags = (uint32_t)value; break;
+    case ZKW_OPT_RESET_SKIP: c->opt_reset_skip = (uint32_t)value; break;
+    case ZKW_OPT_NO_INLINE_DECOMMIT: c->opt_no_inline_decommit = value != 0; break;
+    case ZKW_OPT_DEBUG_SYNC: c->opt_debug_sync = value != 0; break;
+    case ZKW_OPT_NO_GRAPH: c->opt_no_graph = value != 0; break;
+    case ZKW_OPT_WAVES_PER_GROUP:
+      if (value != 0 && value != 1 && value != 2 && value != 4) {
+        c->last_error = "ZKW_OPT_WAVES_PER_GROUP: 0 (default), 1, 2 or 4";
+        return ZKW_ERR_INVALID;
+      }
+      c->opt_waves_per_group = (uint32_t)value;
+      break;
+    case ZKW_OPT_LANES_PER_WAVE: c->opt_lanes_per_wave = (uint32_t)value; break;
+    default: c->last_error = "unknown option"; return ZKW_ERR_INVALID;
+  }
   return ZKW_OK;
 }
 
@@ -340,7 +378,7 @@ int zkw_batch_create(zkw_ctx* c, uint32_t n, const zkw_limits* limits, zkw_batch
   b->n = n;
   b->lim = lim;
   uint32_t L = lim.lanes_per_wave;
-  if (const char* env = getenv("ZKW_LANES_PER_WAVE")) L = (uint32_t)atoi(env);
+  if (c->opt_lanes_per_wave) L = c->opt_lanes_per_wave;
   if (L == 0) {
     b->auto_L = true;
     // Measured on MI355X (profiles/r01_lane_sweep.md): the kernel is bound by the per-wave latency of one VM
@@ -377,7 +415,7 @@ void zkw_batch_destroy(zkw_batch* b) {
   b->d_ns_log_idx.release(); b->d_ns_log_cnt.release(); b->d_ns_aux_idx.release(); b->d_ns_aux_cnt.release(); b->d_ns_st_hist.release();
   b->d_ns_ev_hist.release(); b->d_ns_rb_st.release(); b->d_ns_rb_ev.release(); b->d_ns_marks.release(); b->d_ns_counts.release();
   b->d_ns_bucket_params.release(); b->d_ns_params.release(); b->d_commit.release(); b->d_rc.release(); b->d_blob_digests.release(); b->d_leaves.release(); b->d_midstates.release();
-  b->d_idx.release(); b->d_counts.release(); b->d_dq_count.release();
+  b->d_idx.release(); b->d_counts.release(); b->d_dq_count.release(); b->d_dq_prev.release();
   if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
   if (b->graph) (void)hipGraphDestroy(b->graph);
   for (hipEvent_t e : b->evs) (void)hipEventDestroy(e);
@@ -787,6 +825,7 @@ int zkw_batch_upload(zkw_batch* b) {
   HIP_TRY(c, ensure(b->d_krow, (size_t)W * ZKW_KROW_WORDS * L));
   HIP_TRY(c, ensure(b->d_commit, (size_t)n * ZKW_QUEUE_COUNT * 4));
   HIP_TRY(c, ensure(b->d_dq_count, (size_t)n));
+  HIP_TRY(c, ensure(b->d_dq_prev, (size_t)n * 4));
   if (b->evs.empty()) {
     b->evs.resize(2 * zkw_batch::EV_RING, nullptr);
     for (auto& e : b->evs) HIP_TRY(c, hipEventCreate(&e));
@@ -802,17 +841,14 @@ int zkw_batch_upload(zkw_batch* b) {
   P.consts = c->isa.consts;
   P.wave_threads = (uint32_t)c->wave_width;
   P.waves_per_group = c->wave_width > 1 ? ZKW_WAVES_PER_GROUP : 1;
-  if (const char* env = getenv("ZKW_WAVES_PER_GROUP")) {  // experiments: 1, 2 or 4
-    const int g = atoi(env);
-    if (c->wave_width > 1 && (g == 1 || g == 2 || g == 4)) P.waves_per_group = (uint32_t)g;
-  }
+  if (c->wave_width > 1 && c->opt_waves_per_group) P.waves_per_group = c->opt_waves_per_group;  // experiments: 1, 2 or 4
   P.isa = c->d_isa;
   P.krow = b->d_krow.p;
   P.regs = b->d_regs.p; P.scalars = b->d_scalars.p; P.callstack = b->d_callstack.p; P.frames = b->d_frames.p;
   P.stack_vals = b->d_stack_vals.p; P.stack_ptrs = b->d_stack_ptrs.p; P.heap = b->d_heap.p; P.aux_heap = b->d_aux.p;
   P.storage = b->d_storage.p; P.journal = b->d_journal.p; P.history = b->d_history.p;
   P.blob_words = b->d_blob_words.p; P.blob_dir = b->d_blob_dir.p; P.preimages = b->d_preimages.p;
-  P.commit_rc = b->d_rc.p; P.midstates = b->d_midstates.p; P.blob_digests = b->d_blob_digests.p; P.commit_out = b->d_commit.p; P.dq_count = b->d_dq_count.p;
+  P.commit_rc = b->d_rc.p; P.midstates = b->d_midstates.p; P.blob_digests = b->d_blob_digests.p; P.commit_out = b->d_commit.p; P.dq_count = b->d_dq_count.p; P.dq_prev = b->d_dq_prev.p;
   P.tails = b->d_tails.p; P.deltas = b->d_deltas.p; P.wave_cycles = b->d_wave_cycles.p; P.cap_delta = b->cap_delta; P.heap_dirty = b->d_heap_dirty.p; P.heap_image_words = b->heap_image_words; P.mem_stream = b->d_mem.p; P.log_stream = b->d_log.p; P.aux_stream = b->d_auxs.p;
   P.dir = b->d_dir.p; P.cursors = b->d_cursors.p;
   P.regs0 = b->d_regs0.p; P.scalars0 = b->d_scalars0.p; P.storage_dirty = b->d_storage_dirty.p;
@@ -896,6 +932,20 @@ static int check_group(zkw_batch* const* bs, uint32_t n) {
   return ZKW_OK;
 }
 
+// host side of a reset (the device side is zkw_reset_kernel)
+static void reset_bookkeeping(zkw_batch* const* bs, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) {
+    zkw_batch* b = bs[i];
+    b->cycles_run = 0;
+    b->dq_mode = 0;
+    b->ran = false;
+    b->synced = false;
+    b->ns_done = false;
+    b->ns_cached_wave = 0xffffffffu;
+    b->wave_cache.clear();
+  }
+}
+
 static int enqueue_reset(zkw_batch* const* bs, uint32_t n, hipStream_t st) {
   zkw_ctx* c = bs[0]->ctx;
   HIP_TRY(c, hipSetDevice(c->device));
@@ -908,18 +958,9 @@ static int enqueue_reset(zkw_batch* const* bs, uint32_t n, hipStream_t st) {
     if (bs[i]->full_reset_pending) T.reserved[1] = 1;  // any freshly uploaded batch in the group: whole heap images for all
     bs[i]->full_reset_pending = false;
   }
-  if (const char* sk = getenv("ZKW_RESET_SKIP")) T.reserved[2] = (uint32_t)atoi(sk);  // profiling ablation only
+  T.reserved[2] = c->opt_reset_skip;  // profiling ablation only
   HIP_TRY(c, zkw_launch_reset_kernel(&T, st));
-  for (uint32_t i = 0; i < n; i++) {
-    zkw_batch* b = bs[i];
-    b->cycles_run = 0;
-    b->dq_mode = 0;
-    b->ran = false;
-    b->synced = false;
-    b->ns_done = false;
-    b->ns_cached_wave = 0xffffffffu;
-    b->wave_cache.clear();
-  }
+  reset_bookkeeping(bs, n);
   return ZKW_OK;
 }
 
@@ -927,7 +968,7 @@ static int enqueue_reset(zkw_batch* const* bs, uint32_t n, hipStream_t st) {
 // call has nothing to overlap the commitment kernels with); otherwise zkw_batch_commit computes it from the aux stream
 static int enqueue_run(zkw_batch* const* bs, uint32_t n, uint32_t max_cycles, hipStream_t st, bool inline_decommit = false) {
   zkw_ctx* c = bs[0]->ctx;
-  if (getenv("ZKW_NO_INLINE_DECOMMIT")) inline_decommit = false;  // A/B switch
+  if (c->opt_no_inline_decommit) inline_decommit = false;  // A/B switch
   for (uint32_t i = 0; i < n; i++) {
     const int want = inline_decommit ? 1 : 2;
     if (bs[i]->dq_mode == 0) bs[i]->dq_mode = want;
@@ -955,7 +996,7 @@ static int enqueue_run(zkw_batch* const* bs, uint32_t n, uint32_t max_cycles, hi
     A.max_waves = std::max(A.max_waves, bs[i]->n_waves);
     A.max_L = std::max(A.max_L, bs[i]->L);
   }
-  if (const char* dbg = getenv("ZKW_DEBUG_FLAGS")) A.debug_flags = (uint32_t)atoi(dbg);  // profiling ablations / test hooks only
+  A.debug_flags = c->opt_debug_flags;  // profiling ablations / test hooks only
   if (inline_decommit) A.debug_flags |= 16u;
   // HIP events around the launch: on the first batch of the group (its kernel_ms is the launch's duration)
   zkw_batch* lead = bs[0];
@@ -963,7 +1004,7 @@ static int enqueue_run(zkw_batch* const* bs, uint32_t n, uint32_t max_cycles, hi
   HIP_TRY(c, hipEventRecord(lead->evs[2 * slot], st));
   HIP_TRY(c, zkw_launch_cycle_kernel(&A, st));
   HIP_TRY(c, hipEventRecord(lead->evs[2 * slot + 1], st));
-  if (getenv("ZKW_DEBUG_SYNC")) HIP_TRY(c, hipStreamSynchronize(st));  // diagnostics only
+  if (c->opt_debug_sync) HIP_TRY(c, hipStreamSynchronize(st));  // diagnostics only
   lead->pending_runs++;
   for (uint32_t i = 0; i < n; i++) {
     zkw_batch* b = bs[i];
@@ -1554,6 +1595,7 @@ int zkw_batch_step(zkw_batch* b, uint32_t max_cycles, uint32_t queue_mask, void*
     b->wave_cache.clear();
     b->run_stream = st;
     b->pending_runs = 1;  // the captured run uses event pair 0
+    b->dq_mode = b->graph_dq_mode;  // (the replayed reset + run, not whatever an earlier fused step left: a continued run / commit then agree with the device)
     b->ns_done = false;
     b->ns_cached_wave = 0xffffffffu;
     return ZKW_OK;
@@ -1562,7 +1604,7 @@ int zkw_batch_step(zkw_batch* b, uint32_t max_cycles, uint32_t queue_mask, void*
   int rc = zkw_batch_reset(b, hip_stream);
   if (rc == ZKW_OK) rc = zkw_batch_run(b, max_cycles, hip_stream);
   if (rc == ZKW_OK && queue_mask) rc = zkw_batch_commit(b, queue_mask, hip_stream);
-  if (!b->graph_failed && std::getenv("ZKW_NO_GRAPH")) b->graph_failed = true;  // diagnostics: eager steps only
+  if (!b->graph_failed && c->opt_no_graph) b->graph_failed = true;  // diagnostics: eager steps only
   if (rc != ZKW_OK || b->graph_failed || !st) return rc;  // no capture on the legacy default stream
   // capture the same sequence for the following steps
   if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
@@ -1592,6 +1634,7 @@ int zkw_batch_step(zkw_batch* b, uint32_t max_cycles, uint32_t queue_mask, void*
     return ZKW_OK;
   }
   b->graph = g;
+  b->graph_dq_mode = b->dq_mode;
   b->graph_cycles = max_cycles;
   b->graph_mask = queue_mask;
   b->graph_stream = st;
@@ -1695,10 +1738,14 @@ struct zkw_comm {
   zkw_allgather_fn ext_allgather = nullptr;
   zkw_allreduce_sum_u64_fn ext_allreduce = nullptr;
   void* ext_user = nullptr;
-  // sizes of the ranks' shards, exchanged once per n_instances of this rank
+  // sizes of the ranks' shards: exchanged by the first zkw_reduce_commitments of the communicator and, after that, only
+  // by zkw_comm_exchange_sizes (both collective)
   uint32_t sizes_for_n = 0xffffffffu, n_max = 0;
   std::vector<uint32_t> sizes;
-  DevBuf<uint64_t> d_send, d_small;  // packed digests of this rank; staging of the small exchanges
+  // packed digests of this rank, one buffer per stream the caller reduces on: the pack kernel and the all-gather of a
+  // call are asynchronous, so calls on different streams must not share a send buffer (calls on one stream are ordered)
+  std::map<hipStream_t, DevBuf<uint64_t>> d_send;
+  DevBuf<uint64_t> d_small;          // staging of the small (host-synchronous) exchanges
   std::vector<uint64_t> h_send;      // external transport: host copy of the packed digests
 };
 
@@ -1826,9 +1873,27 @@ void zkw_comm_destroy(zkw_comm* cm) {
 #ifndef ZKW_EMU_BUILD
   if (cm->nccl) (void)rccl_api()->CommDestroy(cm->nccl);
 #endif
-  cm->d_send.release();
+  for (auto& kv : cm->d_send) kv.second.release();
   cm->d_small.release();
   delete cm;
+}
+
+int zkw_comm_exchange_sizes(zkw_comm* cm, uint32_t n_instances, void* hip_stream) {
+  if (!cm) return ZKW_ERR_INVALID;
+  zkw_ctx* c = cm->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<uint64_t> all((size_t)cm->world);
+  const uint64_t mine = n_instances;
+  const int rc = comm_allgather_host(cm, &mine, all.data(), 1, (hipStream_t)hip_stream);
+  if (rc != ZKW_OK) return rc;
+  cm->sizes.assign(cm->world, 0);
+  cm->n_max = 0;
+  for (int r = 0; r < cm->world; r++) {
+    cm->sizes[r] = (uint32_t)all[r];
+    cm->n_max = std::max(cm->n_max, cm->sizes[r]);
+  }
+  cm->sizes_for_n = n_instances;
+  return ZKW_OK;
 }
 
 int zkw_reduce_commitments(zkw_comm* cm, zkw_batch* const* batches, uint32_t n_batches, uint32_t queue_mask, void* gathered, uint32_t* n_max_out,
@@ -1850,19 +1915,15 @@ int zkw_reduce_commitments(zkw_comm* cm, zkw_batch* const* batches, uint32_t n_b
   hipStream_t st = (hipStream_t)hip_stream;
   HIP_TRY(c, hipSetDevice(c->device));
   const bool external = !cm->nccl;
-  // shard sizes: once per n (the exchange waits for the stream)
-  if (cm->sizes_for_n != n) {
-    std::vector<uint64_t> all((size_t)cm->world);
-    const uint64_t mine = n;
-    rc = comm_allgather_host(cm, &mine, all.data(), 1, st);
+  // Shard sizes.  The FIRST reduce of a communicator exchanges them (every rank reaches its first reduce: a collective);
+  // afterwards only zkw_comm_exchange_sizes does.  A rank whose n_instances changed on its own must not start an
+  // exchange the other ranks do not take part in (their next collective would be a digest all-gather: a hang or garbage).
+  if (cm->sizes_for_n == 0xffffffffu) {
+    rc = zkw_comm_exchange_sizes(cm, n, hip_stream);
     if (rc != ZKW_OK) return rc;
-    cm->sizes.assign(cm->world, 0);
-    cm->n_max = 0;
-    for (int r = 0; r < cm->world; r++) {
-      cm->sizes[r] = (uint32_t)all[r];
-      cm->n_max = std::max(cm->n_max, cm->sizes[r]);
-    }
-    cm->sizes_for_n = n;
+  } else if (cm->sizes_for_n != n) {
+    c->last_error = "zkw_reduce_commitments: n_instances differs from the shard size this communicator exchanged; call zkw_comm_exchange_sizes on EVERY rank first";
+    return ZKW_ERR_INVALID;
   }
   if (n_max_out) *n_max_out = cm->n_max;
   if (sizes_out) std::memcpy(sizes_out, cm->sizes.data(), (size_t)cm->world * 4);
@@ -1870,25 +1931,27 @@ int zkw_reduce_commitments(zkw_comm* cm, zkw_batch* const* batches, uint32_t n_b
   const uint32_t nq = (uint32_t)__builtin_popcount(queue_mask);
   if (gathered && nq) {
     const size_t per_rank = (size_t)n_batches * cm->n_max * nq * 4;  // u64
-    if (cm->d_send.n < per_rank) {
-      cm->d_send.release();
-      HIP_TRY(c, cm->d_send.alloc(per_rank));
+    DevBuf<uint64_t>& send = cm->d_send[st];
+    if (send.n < per_rank) {
+      if (send.p) HIP_TRY(c, hipStreamSynchronize(st));  // an earlier exchange of this stream may still read the old buffer
+      send.release();
+      HIP_TRY(c, send.alloc(per_rank));
     }
     zkw_fused_table T;
     std::memset(&T, 0, sizeof T);
     T.n = n_batches;
     T.wave_threads = (uint32_t)c->wave_width;
     for (uint32_t i = 0; i < n_batches; i++) T.p[i] = batches[i]->d_commit.p;
-    HIP_TRY(c, zkw_launch_pack_digests(&T, cm->d_send.p, n, cm->n_max, queue_mask, st));
+    HIP_TRY(c, zkw_launch_pack_digests(&T, send.p, n, cm->n_max, queue_mask, st));
     if (!external) {
 #ifndef ZKW_EMU_BUILD
       RcclApi* api = rccl_api();
-      const int e = api->AllGather(cm->d_send.p, gathered, per_rank, 5 /* ncclUint64 */, cm->nccl, st);
+      const int e = api->AllGather(send.p, gathered, per_rank, 5 /* ncclUint64 */, cm->nccl, st);
       if (e != 0) return comm_fail(cm, std::string("ncclAllGather: ") + (api->GetErrorString ? api->GetErrorString(e) : "error"));
 #endif
     } else {  // host transport: the packed digests cross to the host, the callback exchanges them
       cm->h_send.resize(per_rank);
-      HIP_TRY(c, hipMemcpyAsync(cm->h_send.data(), cm->d_send.p, per_rank * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipMemcpyAsync(cm->h_send.data(), send.p, per_rank * 8, hipMemcpyDeviceToHost, st));
       HIP_TRY(c, hipStreamSynchronize(st));
       if (cm->world == 1) std::memcpy(gathered, cm->h_send.data(), per_rank * 8);
       else if (cm->ext_allgather(cm->ext_user, cm->h_send.data(), gathered, (uint64_t)per_rank * 8) != 0) return comm_fail(cm, "external all-gather failed");

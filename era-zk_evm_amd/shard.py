@@ -2,12 +2,18 @@
 
 VM instances share no state (every reference `VmState` owns its oracles by value, mod.rs:167-174),
 so ranks own contiguous blocks of instances and run them with NO data-path collective.  The only
-exchange is the final one: an all-gather of the per-instance queue digests (3 queues x 4 x u64 per
-instance) and an all-reduce of the run counters — one collective each, default algorithm: at
-<= 400 KB per rank, xGMI link bandwidth is irrelevant (RCCL when the backend is "nccl", gloo on CPU).
+exchange is the final one, zkw_reduce_commitments (include/zkw.h): an all-gather of the per-instance queue
+digests and an all-reduce of the run counters — at <= 400 KB per rank, xGMI link bandwidth is irrelevant.
+
+`make_comm` builds the communicator of that exchange for a torch.distributed job: RCCL inside libzkw.so when
+every rank can create it, otherwise — on ALL ranks, decided together — the library's external transport with the
+two collectives served by the job's existing process group (RCCL when its backend is "nccl", gloo on CPU).
 """
+import numpy as np
 import torch
 import torch.distributed as dist
+
+from . import capi as K
 
 
 def shard_range(n_total, rank, world):
@@ -17,24 +23,54 @@ def shard_range(n_total, rank, world):
     return first, base + (1 if rank < rem else 0)
 
 
-def final_reduce(local_digests, local_counters, group=None):
-    """local_digests: int64 tensor [n_local, 3, 4] (bit pattern of the u64 field elements);
-    local_counters: int64 tensor [k] (cycles, mem, log, aux, ...).
-    Returns (all_digests [sum n_local, 3, 4] in rank order, summed counters).  Ranks may own different
-    numbers of instances (ragged): sizes are exchanged first."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
-        return local_digests.clone(), local_counters.clone()
-    n_local = torch.tensor([local_digests.shape[0]], dtype=torch.int64, device=local_digests.device)
-    sizes = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(sizes, n_local, group=group)
-    sizes = [int(s.item()) for s in sizes]
-    n_max = max(sizes)
-    pad = torch.zeros((n_max,) + tuple(local_digests.shape[1:]), dtype=local_digests.dtype, device=local_digests.device)
-    pad[: local_digests.shape[0]] = local_digests
-    gathered = torch.empty((world * n_max,) + tuple(local_digests.shape[1:]), dtype=local_digests.dtype, device=local_digests.device)
-    dist.all_gather_into_tensor(gathered, pad, group=group)
-    parts = [gathered[r * n_max: r * n_max + sizes[r]] for r in range(world)]
-    counters = local_counters.clone()
-    dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=group)
-    return torch.cat(parts, dim=0), counters
+def _pg_device(device):
+    return torch.device("cpu") if dist.get_backend() == "gloo" else (device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+
+
+def make_comm(backend, rank, world, device=None, prefer_rccl=True):
+    """-> (capi.Comm, description of the transport that will carry zkw_reduce_commitments).
+
+    world == 1 without a process group: a one-rank external communicator (no transport at all).  Otherwise the ranks
+    first try the library's own RCCL communicator (zkw_comm_get_unique_id on rank 0, the id broadcast over the process
+    group, zkw_comm_create_rccl everywhere) and agree on the outcome with one all-reduce; if ANY rank failed — librccl
+    not loadable, a second communicator refused next to torch's — every rank falls back to zkw_comm_create_external
+    with all-gather / all-reduce callbacks over the process group that is already up."""
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return K.Comm.external(backend, 0, 1), "single rank (no transport)"
+    dev = _pg_device(device)
+    comm, why = None, ""
+    if prefer_rccl:
+        ids = [None]
+        if rank == 0:
+            try:
+                ids = [K.Comm.unique_id(backend)]
+            except K.ZkwError as e:  # e.g. librccl cannot be loaded
+                why = str(e)
+        dist.broadcast_object_list(ids, src=0, device=dev)
+        if ids[0] is not None:
+            try:
+                comm = K.Comm.rccl(backend, rank, world, ids[0])
+            except K.ZkwError as e:
+                why = str(e)
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            return comm, "rccl (libzkw.so's own communicator)"
+        if comm is not None:  # some other rank failed: everyone takes the fallback
+            comm.close()
+
+    def allgather(send):
+        mine = torch.from_numpy(np.ascontiguousarray(send)).to(dev)
+        outs = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(outs, mine)
+        return torch.cat(outs).cpu().numpy()
+
+    def allreduce_sum(a):
+        x = torch.from_numpy(a.astype(np.int64)).to(dev)
+        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        return x.cpu().numpy().astype(np.uint64)
+
+    desc = "external over torch.distributed (%s)" % dist.get_backend()
+    if prefer_rccl:
+        desc += "; RCCL communicator unavailable" + (": " + why[:120] if why else " on another rank")
+    return K.Comm.external(backend, rank, world, allgather, allreduce_sum), desc

@@ -405,6 +405,19 @@ void zkw_ctx_destroy(zkw_ctx* ctx);
 const char* zkw_last_error(zkw_ctx* ctx); /* ctx may be NULL: last error of a failed zkw_ctx_create */
 int zkw_ctx_set_isa(zkw_ctx* ctx, const zkw_isa_table* table); /* copies */
 
+/* Test hooks and profiling ablations of the engine itself (nothing of the reference's surface).  Every option has an
+ * environment variable of the same name (ZKW_DEBUG_FLAGS, ...) that is read ONCE, when the context is created, and
+ * reported on stderr when it is set — a stray variable cannot silently change a production run, and the hot path reads
+ * no environment.  zkw_ctx_set_option changes an option of a live context (what the parity tests use). */
+#define ZKW_OPT_DEBUG_FLAGS 1u         /* kernel test hooks / ablations: 4 = one lane per opcode group, 1 << 24 = every light group through the variant path, 1 / 2 / 32 / 64 / 128 = store ablations (WRONG results) */
+#define ZKW_OPT_RESET_SKIP 2u          /* reset-kernel parts left out (ablation, WRONG results) */
+#define ZKW_OPT_NO_INLINE_DECOMMIT 3u  /* 1 = the decommit queue is never chained inside the cycle kernel */
+#define ZKW_OPT_DEBUG_SYNC 5u          /* 1 = synchronise after every cycle-kernel launch (diagnostics) */
+#define ZKW_OPT_NO_GRAPH 6u            /* 1 = zkw_batch_step never captures / replays a hipGraph */
+#define ZKW_OPT_WAVES_PER_GROUP 7u     /* 1, 2 or 4 waves per workgroup of the cycle kernel (batches uploaded afterwards) */
+#define ZKW_OPT_LANES_PER_WAVE 8u      /* overrides zkw_limits.lanes_per_wave (batches created afterwards) */
+int zkw_ctx_set_option(zkw_ctx* ctx, uint32_t option, uint64_t value);
+
 int zkw_batch_create(zkw_ctx* ctx, uint32_t n_instances, const zkw_limits* limits, zkw_batch** out);
 void zkw_batch_destroy(zkw_batch* batch);
 
@@ -501,6 +514,8 @@ typedef int (*zkw_allreduce_sum_u64_fn)(void* user, uint64_t* inout, uint32_t co
 int zkw_comm_create_external(zkw_ctx* ctx, int rank, int world, zkw_allgather_fn allgather, zkw_allreduce_sum_u64_fn allreduce_sum,
                              void* user, zkw_comm** out);
 void zkw_comm_destroy(zkw_comm* comm);
+/* COLLECTIVE: every rank announces the n_instances of the batches it will reduce from now on (waits for the stream). */
+int zkw_comm_exchange_sizes(zkw_comm* comm, uint32_t n_instances, void* hip_stream);
 /* The final exchange for `n_batches` committed batches of this rank (zkw_batch_commit / zkw_batches_commit with at
  * least the queues of `queue_mask`, enqueued earlier on `hip_stream` or ordered before it by the caller).  Every rank
  * passes the same n_batches and queue_mask; ranks may own different numbers of instances per batch (ragged shards: all
@@ -513,8 +528,11 @@ void zkw_comm_destroy(zkw_comm* comm);
  *   total      optional: the run counters of these batches summed over all ranks (cycles, queries, aux events, ended /
  *              failed instances, register deltas; kernel_ms = max over the ranks).  Waits for the stream (the counters
  *              come from the finished runs).  NULL: no counter exchange.
- * The first call of a communicator with a given n_instances exchanges the sizes (and waits for it); later calls with
- * gathered != NULL and total == NULL are fully asynchronous. */
+ * The FIRST call of a communicator exchanges the shard sizes (a collective, and it waits for it); later calls with
+ * gathered != NULL and total == NULL are fully asynchronous — also from several streams at once (one send buffer per
+ * stream).  A rank whose n_instances changes afterwards gets ZKW_ERR_INVALID until EVERY rank has called
+ * zkw_comm_exchange_sizes: a rank-local decision to exchange again would pair a size exchange on one rank with a digest
+ * all-gather on another. */
 int zkw_reduce_commitments(zkw_comm* comm, zkw_batch* const* batches, uint32_t n_batches, uint32_t queue_mask, void* gathered,
                            uint32_t* n_max_out, uint32_t* sizes_out, zkw_run_stats* total, void* hip_stream);
 

@@ -21,10 +21,7 @@ for k in range(count):
     lanes = (64, 64, 16, 0, 8, 1)[k % 6]
     n_ops = (96, 160, 64, 128)[k % 4]
     forced = (k % 3) == 2
-    if forced:
-        os.environ["ZKW_DEBUG_FLAGS"] = str(1 << 24)
-    else:
-        os.environ.pop("ZKW_DEBUG_FLAGS", None)
+    prod.set_option(K.OPT_DEBUG_FLAGS, (1 << 24) if forced else 0)
     wl = synth.fuzz_workload(isa, n_instances=512, n_ops=n_ops, seed=seed)
     bo = orc.create_batch(wl); bo.reset(); bo.run(wl.n_cycles); bo.sync()
     wl.limits["lanes_per_wave"] = lanes

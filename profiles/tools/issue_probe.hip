@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 typedef unsigned int u32;
@@ -97,16 +98,19 @@ static void run(const char* name, kern_t f, int n_per_iter, int iters, int threa
   printf("%-14s waves/SIMD %d  blocks %4d: clocks per instruction min %.2f median %.2f max %.2f\n", name, threads / 256, blocks, h[0] / per, h[nw / 2] / per, h[nw - 1] / per);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IONBF, 0);
+  const char* only = argc > 1 ? argv[1] : nullptr;
   u64* d_out; u32* d_sink; u32* d_src;
   CK(hipMalloc(&d_out, 1 << 20)); CK(hipMalloc(&d_sink, 64 << 20)); CK(hipMalloc(&d_src, 1 << 16));
   std::vector<u32> hs(16384);
   for (int i = 0; i < 16384; i++) hs[i] = (u32)(i * 2654435761u) & 1023u;
   CK(hipMemcpy(d_src, hs.data(), 65536, hipMemcpyHostToDevice));
 #define RUN(K, IT) \
+  if (!only || !strcmp(only, #K)) { \
   run(#K, K, K##_n, IT, 256, 256, d_out, d_sink, d_src); \
   run(#K, K, K##_n, IT, 512, 256, d_out, d_sink, d_src); \
-  run(#K, K, K##_n, IT, 1024, 256, d_out, d_sink, d_src);
+  if (strcmp(#K, "k_gpridx")) run(#K, K, K##_n, IT, 1024, 256, d_out, d_sink, d_src); }
   RUN(k_valu_dep, 200) RUN(k_valu_ind, 200) RUN(k_salu_dep, 200) RUN(k_readlane, 200) RUN(k_cmp_cnd, 200) RUN(k_carry, 200)
   RUN(k_branch, 200) RUN(k_cbranch_nt, 200) RUN(k_saveexec, 200) RUN(k_lds_dep, 200) RUN(k_lds128_dep, 200) RUN(k_gpridx, 100) RUN(k_mov8, 100)
   RUN(k_gload_dep, 200) RUN(k_sload_dep, 200)

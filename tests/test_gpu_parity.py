@@ -24,7 +24,7 @@ def _run(backend, wl, lanes=0):
     return b
 
 
-def _compare(oracle, product, wl, lanes=0, sample=None):
+def _compare(oracle, product, wl, lanes=0, sample=None, commitments=False):
     bo = _run(oracle, wl)
     bp = _run(product, wl, lanes)
     idx = range(wl.n_instances) if sample is None else sample
@@ -32,6 +32,8 @@ def _compare(oracle, product, wl, lanes=0, sample=None):
         ok, why = K.traces_equal(bo.trace(i), bp.trace(i))
         assert ok, "%s instance %d (lanes=%d): %s" % (wl.name, i, lanes, why)
     assert int(bp.stats()["cycles"]) == int(bo.stats()["cycles"])
+    if commitments:  # the three queue digests of EVERY instance (the oracle run is there anyway)
+        assert np.array_equal(bo.commitments(), bp.commitments()), wl.name
     bo.destroy()
     bp.destroy()
 
@@ -58,7 +60,7 @@ def test_cfg2_ragged_last_wave(oracle, product, isa):
 def test_cfg2_full_size_sampled(oracle, product, isa):
     # BASELINE config: 4096 x 256 = 1M cycles; every 37th instance compared record by record
     wl = synth.make(2, isa, n_instances=4096)
-    _compare(oracle, product, wl, 0, sample=range(0, 4096, 37))
+    _compare(oracle, product, wl, 0, sample=range(0, 4096, 37), commitments=True)
 
 
 def test_rerun_after_reset_is_identical(product, isa):
@@ -137,7 +139,7 @@ def test_cfg4_l2_block(oracle, product, isa, lanes):
 
 def test_cfg4_full_size_sampled(oracle, product, isa):
     wl = synth.make(4, isa, n_instances=4096, n_cycles=1024)
-    _compare(oracle, product, wl, 0, sample=range(5, 4096, 211))
+    _compare(oracle, product, wl, 0, sample=range(5, 4096, 211), commitments=True)
 
 
 def test_divergent_tapes_in_one_wave(oracle, product, isa):
@@ -191,28 +193,37 @@ def test_host_replay_on_gpu(oracle, product, isa):
 
 
 @pytest.mark.parametrize("cfg,kw", [(1, dict()), (2, dict(n_instances=320)), (4, dict(n_instances=128, n_cycles=512))])
-def test_generic_per_lane_path_forced(oracle, product, isa, cfg, kw, monkeypatch):
-    """ZKW_DEBUG_FLAGS=4 disables the wave-uniform fast path: the fully per-lane decode must give the same bits."""
-    monkeypatch.setenv("ZKW_DEBUG_FLAGS", "4")
-    _compare(oracle, product, synth.make(cfg, isa, **kw), 64)
+def test_generic_per_lane_path_forced(oracle, product, isa, cfg, kw):
+    """ZKW_OPT_DEBUG_FLAGS = 4 disables the wave-uniform fast path: the fully per-lane decode must give the same bits."""
+    product.set_option(K.OPT_DEBUG_FLAGS, 4)
+    try:
+        _compare(oracle, product, synth.make(cfg, isa, **kw), 64)
+    finally:
+        product.set_option(K.OPT_DEBUG_FLAGS, 0)
 
 
 @pytest.mark.parametrize("cfg,kw", [(1, dict()), (2, dict(n_instances=320)), (3, dict(n_instances=64, keccak_k=(1, 2, 8, 3), sha_rounds=(1, 2, 8, 5))),
                                     (4, dict(n_instances=128, n_cycles=512))])
-def test_variant_group_path_forced(oracle, product, isa, cfg, kw, monkeypatch):
-    """ZKW_DEBUG_FLAGS bit 24 sends every group of a light opcode through the variant-group path (per-lane operand decode,
+def test_variant_group_path_forced(oracle, product, isa, cfg, kw):
+    """ZKW_OPT_DEBUG_FLAGS bit 24 sends every group of a light opcode through the variant-group path (per-lane operand decode,
     waterfall register access in zkw_vec_exec) even on a shared tape: the same bits as the scalar decode."""
-    monkeypatch.setenv("ZKW_DEBUG_FLAGS", str(1 << 24))
-    _compare(oracle, product, synth.make(cfg, isa, **kw), 64)
+    product.set_option(K.OPT_DEBUG_FLAGS, 1 << 24)
+    try:
+        _compare(oracle, product, synth.make(cfg, isa, **kw), 64)
+    finally:
+        product.set_option(K.OPT_DEBUG_FLAGS, 0)
 
 
 @pytest.mark.parametrize("seed", [0xF101, 0xF102])
-def test_fuzz_tapes_variant_groups_forced(oracle, product, isa, seed, monkeypatch):
+def test_fuzz_tapes_variant_groups_forced(oracle, product, isa, seed):
     """The fuzz tapes (every opcode variant, operand mode and failure path) with every light group on the variant path."""
-    monkeypatch.setenv("ZKW_DEBUG_FLAGS", str(1 << 24))
     wl = synth.fuzz_workload(isa, n_instances=256, n_ops=96, seed=seed)
     bo = _run(oracle, wl)
-    bp = _run(product, wl, 64)
+    product.set_option(K.OPT_DEBUG_FLAGS, 1 << 24)
+    try:
+        bp = _run(product, wl, 64)
+    finally:
+        product.set_option(K.OPT_DEBUG_FLAGS, 0)
     compared = 0
     for i in range(wl.n_instances):
         tp = bp.trace(i)
@@ -266,6 +277,61 @@ def test_fused_step_of_several_batches(oracle, product, isa):
             ok, why = K.traces_equal(bo.trace(i), bp.trace(i))
             assert ok, (w.name, i, why)
         assert np.array_equal(bo.commitments(), bp.commitments()), w.name
+
+
+def test_full_steps_after_partial_ones(oracle, product, isa):
+    """zkw_batches_step: full steps after partial ones (which dirty other heap words and storage slots than a full run) and
+    after plain reset + run calls must reproduce the oracle — the reset restores exactly what the previous run marked."""
+    wls = [synth.make(2, isa, n_instances=200), synth.make(4, isa, n_instances=100)]
+    cyc = max(w.n_cycles for w in wls)
+    for w in wls:
+        w.limits["max_cycles"] = cyc
+    bos = []
+    for w in wls:
+        bo = oracle.create_batch(w)
+        bo.reset(); bo.run(cyc); bo.sync()
+        bos.append(bo)
+    if True:
+        bs = [product.create_batch(w) for w in wls]
+        for cycles in (cyc, cyc // 3, cyc, 7, cyc):
+            product.step_many(bs, cycles, 7)
+            if cycles != cyc:
+                continue
+            for w, bo, b in zip(wls, bos, bs):
+                b.sync()
+                for i in range(0, w.n_instances, 3):
+                    ok, why = K.traces_equal(bo.trace(i), b.trace(i))
+                    assert ok, (w.name, i, why)
+                assert np.array_equal(bo.commitments(), b.commitments()), w.name
+        # a plain reset + run after fused steps, and a fused step after a plain run
+        for b, w, bo in zip(bs, wls, bos):
+            b.reset(); b.run(cyc // 2); b.sync()
+        product.step_many(bs, cyc, 7)
+        for w, bo, b in zip(wls, bos, bs):
+            b.sync()
+            for i in range(0, w.n_instances, 5):
+                ok, why = K.traces_equal(bo.trace(i), b.trace(i))
+                assert ok, (w.name, i, why)
+            assert np.array_equal(bo.commitments(), b.commitments()), w.name
+
+
+@pytest.mark.parametrize("seed,limits", [(0xF301, dict(max_far_frames=2)), (0xF302, dict(max_aux_events=6)), (0xF303, dict(max_reg_deltas=40, max_far_frames=3))])
+def test_inline_decommit_chain_equals_the_post_run_chain_on_failing_instances(product, isa, seed, limits):
+    """A far call chains its decommit into the running commitment inside the cycle kernel (zkw_batches_step); the same
+    cycle can still fail afterwards — no arena slot, no aux / register-delta capacity left (ZKW_STATUS_LIMIT) — and a
+    failed cycle leaves no records, so the chains computed from the streams after a run (zkw_batch_run + _commit) never
+    see that decommit.  Both ways must agree for EVERY instance, the failed ones included."""
+    wl = synth.fuzz_workload(isa, n_instances=512, n_ops=96, seed=seed)
+    wl.limits.update(limits)
+    b1, b2 = product.create_batch(wl), product.create_batch(wl)
+    product.step_many([b1], wl.n_cycles, 7)  # inline
+    b1.sync()
+    b2.reset(); b2.run(wl.n_cycles); b2.sync()  # post-run chains (commitments() commits)
+    c1, c2 = b1.commitments(), b2.commitments()
+    failed = [i for i in range(wl.n_instances) if int(b1.trace(i)["status"]) == K.STATUS_LIMIT]
+    assert failed, "the limits were meant to stop some instances"
+    assert np.array_equal(c1, c2), [i for i in range(wl.n_instances) if not np.array_equal(c1[i], c2[i])][:8]
+    b1.destroy(); b2.destroy()
 
 
 @pytest.mark.parametrize("outer,inner,main_panics", [(K.RET_OK, K.RET_OK, False), (K.RET_PANIC, K.RET_OK, False), (K.RET_OK, K.RET_REVERT, False),

@@ -1,10 +1,11 @@
 """N > 1 path on CPU: two gloo ranks each own a block of instances (no data-path collective), compute
-their queue digests, and the final all-gather / all-reduce reproduces the single-process result.
-Two variants: the Python reduce of era-zk_evm_amd/shard.py over the oracle's digests, and the PRODUCT's own
+their queue digests, and the final all-gather / all-reduce reproduces the single-process result through the PRODUCT's own
 entry point zkw_reduce_commitments (include/zkw.h) — the product sources built for the CPU by tests/emu compute
-each rank's shard and its commitments, and the exchange runs through an external communicator whose two
-collectives are gloo calls (on the GPU box the same entry point runs over RCCL: tests/test_gpu_parity.py,
-bench.py)."""
+each rank's shard and its commitments.  The communicator comes from era-zk_evm_amd/shard.py `make_comm`, exactly as in
+bench.py: it first tries the library's RCCL communicator, which the CPU build does not have, so every rank takes the
+fallback the GPU job would take if its second communicator failed — the external transport over the process group that
+is already up (gloo here, RCCL through torch there).  On the GPU box the RCCL path itself runs in
+tests/test_gpu_parity.py and bench.py."""
 import os
 import socket
 import sys
@@ -21,52 +22,6 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
-
-
-def _worker(rank, world, port, n_total, out_dir):
-    sys.path.insert(0, ROOT)
-    import torch
-    import torch.distributed as dist
-    from era_zk_evm_amd import capi as K, synth, shard
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    isa = K.Isa()
-    from tests._oracle import load_oracle
-
-    orc = load_oracle().open(isa)
-    wl_all = synth.make(2, isa, n_instances=n_total)
-    first, count = shard.shard_range(n_total, rank, world)
-    wl = synth.make(2, isa, n_instances=n_total)
-    # this rank's slice of the global batch
-    wl.n_instances = count
-    wl.states, wl.inner, wl.heaps = wl_all.states[first:first + count], wl_all.inner[first:first + count], wl_all.heaps[first:first + count]
-    wl.storage = wl_all.storage[first:first + count]
-    wl.code_pages = [(0, count, p, b) for (_, _, p, b) in wl_all.code_pages]
-    b = orc.create_batch(wl)
-    b.reset(); b.run(wl.n_cycles); b.sync()
-    st = b.stats()
-    dig = torch.from_numpy(b.commitments().view(np.int64))
-    counters = torch.tensor([int(st["cycles"]), int(st["mem_queries"]), int(st["log_queries"]), int(st["aux_events"])], dtype=torch.int64)
-    all_dig, total = shard.final_reduce(dig, counters)
-    if rank == 0:
-        np.save(os.path.join(out_dir, "digests.npy"), all_dig.numpy().view(np.uint64))
-        np.save(os.path.join(out_dir, "counters.npy"), total.numpy())
-    dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("n_total", [6, 7])
-def test_two_rank_gloo_final_reduce(tmp_path, oracle, isa, n_total):
-    import torch.multiprocessing as mp
-    from era_zk_evm_amd import synth
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, n_total, str(tmp_path)), nprocs=2, join=True)
-    got = np.load(tmp_path / "digests.npy")
-    counters = np.load(tmp_path / "counters.npy")
-    wl = synth.make(2, isa, n_instances=n_total)
-    b = oracle.create_batch(wl)
-    b.reset(); b.run(wl.n_cycles); b.sync()
-    assert np.array_equal(got, b.commitments())
-    st = b.stats()
-    assert list(counters) == [int(st["cycles"]), int(st["mem_queries"]), int(st["log_queries"]), int(st["aux_events"])]
 
 
 def test_shard_range_covers_everything():
@@ -101,19 +56,23 @@ def _worker_capi(rank, world, port, n_total, out_dir):
     batches = [prod.create_batch(wl) for _ in range(2)]  # two batches per rank, as the fused bench groups are
     prod.step_many(batches, wl.n_cycles, 7)
 
-    def allgather(send):
-        mine = torch.from_numpy(send)
-        outs = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(outs, mine)
-        return torch.cat(outs).numpy()
-
-    def allreduce_sum(a):
-        x = torch.from_numpy(a.astype(np.int64))
-        dist.all_reduce(x, op=dist.ReduceOp.SUM)
-        return x.numpy().astype(np.uint64)
-
-    comm = K.Comm.external(prod, rank, world, allgather, allreduce_sum)
+    comm, transport = shard.make_comm(prod, rank, world)  # RCCL is not part of the CPU build: the fallback every rank agrees on
+    assert transport.startswith("external over torch.distributed (gloo)"), transport
     gathered, n_max, sizes, total = comm.reduce(batches, 0b101, want_total=True)  # memory + decommit queues
+    # a rank that changes its shard size on its own is refused (the other rank would not take part in a size exchange) ...
+    if rank == 1:
+        wl2 = synth.make(1, isa, n_instances=count + 1)
+        odd = [prod.create_batch(wl2)]
+        prod.step_many(odd, wl2.n_cycles, 7)
+        try:
+            comm.reduce(odd, 0b001, gathered=np.zeros((world, 1, 64, 1, 4), dtype="<u8"))
+            refused = False
+        except K.ZkwError as e:
+            refused = "zkw_comm_exchange_sizes" in str(e)
+        assert refused
+    # ... the same sizes again are fine, from both ranks
+    g2, _, _, _ = comm.reduce(batches, 0b100)
+    assert np.array_equal(g2[:, :, :, 0], gathered[:, :, :, 1])
     if rank == 0:
         np.save(os.path.join(out_dir, "gathered.npy"), gathered)
         np.save(os.path.join(out_dir, "meta.npy"), np.array([n_max] + sizes + [int(total["cycles"]), int(total["mem_queries"]), int(total["log_queries"]),
