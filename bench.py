@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1024, help="timed steps (1M-cycle batches); the default is 8 fused launches, so that the fill and drain of the two-group pipeline are a small part of the timed region")
     ap.add_argument("--warmup", type=int, default=256)
-    ap.add_argument("--instances", type=int, default=4096, help="VM instances per GPU (weak scaling)")
+    ap.add_argument("--instances", type=int, default=0, help="VM instances per GPU (weak scaling); default 4096, cfg 3: 512 = one GPU's share of BASELINE configs[3]'s 4096 instances over 8 GPUs")
     ap.add_argument("--cycles", type=int, default=256)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per wave (0 = library default: full waves)")
     ap.add_argument("--fuse", type=int, default=64, help="batches (steps) per fused launch (zkw_batches_step), <= 256 (ZKW_MAX_FUSED)")
@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--nop-only", action="store_true", help="with --cfg 0: a tape of NOPs only instead of alternating NOP / ADD")
     ap.add_argument("--commit-mask", type=int, default=4, help="queue commitments computed inside every step: bit0 memory, bit1 log, bit2 decommit (BASELINE configs[2]: decommit queue)")
     args = ap.parse_args()
+    if args.instances <= 0:
+        args.instances = 512 if args.cfg == 3 else 4096
 
     # `--gpus N` must mean N ranks.  Under torchrun (the driver's launch for N > 1) WORLD_SIZE says so; started plainly
     # with N > 1 this process re-executes itself under torch.distributed.run, one rank per GPU — it never runs one
@@ -99,6 +101,9 @@ def main():
     else:
         wl = synth.make(args.cfg, isa, n_instances=args.instances, n_cycles=args.cycles, seed=0x5EED0000 + args.cfg + 0x100 * rank)
     wl.limits["lanes_per_wave"] = args.lanes
+    args.cycles_executed = wl.n_cycles
+    if args.cfg == 3:
+        args.cycles = wl.n_cycles  # the tape decides (8 precompile calls + the frame changes around them)
     if args.cfg == 2:
         # stream capacities sized for this tape (332 memory queries, 2 log queries, 8 aux events per 256 cycles and
         # instance) instead of the library's generic defaults (6 / 0.5 / 0.25 per cycle): 0.67 instead of 0.97 GB of
@@ -303,6 +308,39 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(isa, args, prod)
+        if args.cfg == 3:
+            # BASELINE configs[3] (precompile-dominant): SURVEY §8d asks for message bytes/s against the HBM roofline at
+            # 2.5 B per message byte (the message read once + one 48-B memory query per 32-B word in, digest + query out)
+            # with the keccak-f / sha256 round rates beside it.  (The honest bound of this path is the integer ALU: a
+            # keccak-f[1600] is ~10k 32-bit instructions per lane — the fraction of the HBM roofline only says how far
+            # from a streaming kernel a hash-bound one sits.)
+            kec_bytes = sum(m[1] for m in wl.keccak_messages)
+            sha_bytes = sum(64 * ((m[1] + 9 + 63) // 64) for m in wl.sha_messages)
+            kec_f = sum(m[1] // 136 + 1 for m in wl.keccak_messages)
+            sha_c = sum((m[1] + 9 + 63) // 64 for m in wl.sha_messages)
+            msg_step = float(args.instances * world) * (kec_bytes + sha_bytes)
+            per_launch_s = k_ms * 1e-3
+            msg_launch = float(args.instances) * (kec_bytes + sha_bytes) * batches_per_launch
+            ach = 2.5 * msg_launch / per_launch_s / 1e9
+            out["metric"] = "precompile message bytes/sec (keccak256 + sha256 round functions over calldata, BASELINE configs[3])"
+            out["cycles_per_s"] = value
+            out["value"] = msg_step * args.steps / elapsed
+            out["unit"] = "message bytes/s"
+            out["dtype"] = "u64 lanes (keccak-f[1600]) / u32 (sha256), as 32-bit integer ALU"
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                               "bytes_per_message_byte": 2.5, "message_bytes_per_launch": msg_launch,
+                               "message_GBps_in_kernel": msg_launch / per_launch_s / 1e9,
+                               "keccak_f_per_s": float(args.instances) * kec_f * batches_per_launch / per_launch_s,
+                               "sha256_compressions_per_s": float(args.instances) * sha_c * batches_per_launch / per_launch_s,
+                               "lone_launch_ms": k_ms_alone, "batches_in_lone_launch": len(groups[0]),
+                               "note": "integer-ALU bound (hash rounds), not HBM: see DESIGN.md 4.3"}
+            if "cpu_baseline" in out:  # the same workload on the host cores: cycles/s -> message bytes/s
+                cb = out["cpu_baseline"]
+                scale = (kec_bytes + sha_bytes) / float(args.cycles_executed)
+                for k_ in ("value", "whole_box_value", "single_core_value", "single_socket_value"):
+                    cb[k_ + "_cycles_per_s"] = cb[k_]
+                    cb[k_] = cb[k_] * scale
+                cb["unit"] = "message bytes/s"
     if os.environ.get("ZKW_BENCH_MEMINFO"):
         free_b, total_b = torch.cuda.mem_get_info(local_rank)
         print("rank %d: device memory in use %.1f GB of %.1f GB" % (rank, (total_b - free_b) / 2**30, total_b / 2**30), file=sys.stderr)

@@ -61,7 +61,7 @@ ISA_CONSTS = _dt([("nop_encoding", "<u8", 0), ("exception_revert_encoding", "<u8
                   ("initial_storage_write_pubdata_bytes", "<u4", 56), ("l1_message_pubdata_bytes", "<u4", 60), ("max_offset_to_deref_low", "<u4", 64),
                   ("deployer_address_low", "<u4", 68), ("keccak_precompile_address", "<u4", 72), ("sha256_precompile_address", "<u4", 76),
                   ("ecrecover_precompile_address", "<u4", 80), ("storage_aux_byte", "u1", 84), ("event_aux_byte", "u1", 85),
-                  ("l1_message_aux_byte", "u1", 86), ("precompile_aux_byte", "u1", 87), ("ecrecover_input_layout", "<u4", 88), ("reserved", ("<u4", 7), 92)], 120)
+                  ("l1_message_aux_byte", "u1", 86), ("precompile_aux_byte", "u1", 87), ("ecrecover_input_layout", "<u4", 88), ("bootloader_calldata_page", "<u4", 92), ("reserved", ("<u4", 6), 96)], 120)
 ISA_TABLE = _dt([("entries", (ISA_ENTRY, ISA_TABLE_SIZE), 0), ("consts", ISA_CONSTS, 12 * ISA_TABLE_SIZE)], 12 * ISA_TABLE_SIZE + 120)
 
 CALLSTACK_ENTRY = _dt([("this_address", ("u1", 20), 0), ("msg_sender", ("u1", 20), 20), ("code_address", ("u1", 20), 40), ("base_memory_page", "<u4", 60),
@@ -418,6 +418,10 @@ class Batch:
             heaps = np.ascontiguousarray(wl.heaps, dtype="<u8")  # [n, words, 4]
             for i in range(wl.n_instances):
                 be.call("batch_set_heap", self.h, C.c_uint32(i), _ptr(heaps[i]), C.c_uint32(heaps.shape[1]))
+        if getattr(wl, "bootloader_calldata", None) is not None:
+            cd = np.ascontiguousarray(wl.bootloader_calldata, dtype="<u8")  # [n, words, 4]
+            for i in range(wl.n_instances):
+                be.call("batch_set_bootloader_calldata", self.h, C.c_uint32(i), _ptr(cd[i]), C.c_uint32(cd.shape[1]))
         if wl.storage is not None:
             for i in range(wl.n_instances):
                 s = np.ascontiguousarray(wl.storage[i])
@@ -460,6 +464,13 @@ class Batch:
             "aux_off": _from_ptr(t.aux_off, n + 1, np.dtype("<u4")),
             "final_state": np.frombuffer(bytes(t.final_state), dtype=VM_LOCAL_STATE, count=1).copy()[0],
         }
+
+    def page(self, i, page, first_word, n_words):
+        """`vm.memory.dump_page_content_as_u256_words(page, first..first + n)` of instance i after the run
+        (reference_impls/memory.rs:316-396): [n_words, 4] little-endian u64 limbs."""
+        out = np.zeros((max(n_words, 1), 4), dtype="<u8")
+        self.be.call("batch_get_page", self.h, C.c_uint32(i), C.c_uint32(page), C.c_uint32(first_word), C.c_uint32(n_words), _ptr(out))
+        return out[:n_words]
 
     def net_state(self, i):
         """get_final_net_states (testing/mod.rs:42-71) of instance i: storage / event histories, net events and L1

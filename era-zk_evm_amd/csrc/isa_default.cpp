@@ -143,6 +143,7 @@ int zkw_isa_default(zkw_isa_table* out) {
   c.event_aux_byte = 1;
   c.l1_message_aux_byte = 2;
   c.precompile_aux_byte = 3;
+  c.bootloader_calldata_page = 3;  // recalled from zkevm_opcode_defs (UNVERIFIED; SURVEY App. B lists it as unknown): a table constant for that reason
   return ZKW_OK;
 }
 

@@ -29,6 +29,13 @@ typedef uint64_t u64;
 
 #include "zkw_goldilocks.hip.h"
 
+// Register bound of the permutation kernels.  The field multiplication (gl_mulred) names v112..v118 in its asm, so these
+// kernels are allocated 128 registers = 4 waves per SIMD whatever the bound says; a tighter bound (it was 6) only made
+// the compiler squeeze everything else into 80 registers and spill 82 of them (332 B of scratch per lane).
+#ifndef ZKW_CHAIN_MIN_WAVES
+#define ZKW_CHAIN_MIN_WAVES 4
+#endif
+
 // orders one wavefront's LDS stores before its later cross-lane LDS reads
 ZD void zkw_commit_wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -43,7 +50,7 @@ ZD void zkw_commit_wave_fence() {
 // Leaves exist only for the code words of the blobs (Q = ZKW_QUEUE_CODE_WORDS, at upload): the records of the memory and
 // log queues are the inputs of their chain permutations, the decommit leaves are cached per preimage.
 template <int Q>
-__global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) zkw_leaf_kernel(zkw_fused_table T) {
+__global__ void __attribute__((amdgpu_waves_per_eu(ZKW_CHAIN_MIN_WAVES, 8))) zkw_leaf_kernel(zkw_fused_table T) {
   const zkw_commit_params ZKW_CONST_AS& C = *(const zkw_commit_params ZKW_CONST_AS*)T.p[blockIdx.z];
   if (blockIdx.y >= C.n_waves) return;
   const u32 wave = blockIdx.y;
@@ -138,7 +145,7 @@ __global__ void zkw_bucket_kernel(zkw_fused_table T) {
 }
 
 // one instance per lane: sequential chain over its leaves
-__global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) zkw_chain_kernel(zkw_fused_table T) {
+__global__ void __attribute__((amdgpu_waves_per_eu(ZKW_CHAIN_MIN_WAVES, 8))) zkw_chain_kernel(zkw_fused_table T) {
   const zkw_commit_params ZKW_CONST_AS& C = zkw_commit_block(T, blockIdx.y, blockIdx.z);
   const u32 wave = blockIdx.x;
   const u32 lane = threadIdx.x;

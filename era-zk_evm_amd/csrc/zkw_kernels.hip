@@ -97,6 +97,20 @@ enum {
 #endif
 #define lane_inst(sh, s) ((sh).wave * (sh).L + (s).lane)
 
+// The four cold fields that almost every cycle reads — the heap / aux-heap bounds go into every record tail, the arena
+// slot and the heap mark into every UMA — live in registers of the reserved range instead of LDS (v129, v130, v134, v135:
+// never touched by compiled code, see RegFile): a read is one v_mov instead of an LDS round trip with its s_waitcnt.
+// The out-of-line opcode bodies reach them the same way (they are registers of the wave, not of a function).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZKW_CFV(name, reg)                                                        \
+  ZD u32 cfv_##name(const Shared&, const Lane&) {                                  \
+    u32 x;                                                                         \
+    asm volatile("v_mov_b32 %0, " reg : "=v"(x));                                  \
+    return x;                                                                      \
+  }                                                                                \
+  ZD void cfv_set_##name(const Shared&, const Lane&, u32 v) { asm volatile("v_mov_b32 " reg ", %0" : : "v"(v) : reg); }
+#endif
+
 #define FLAG_LT 1u
 #define FLAG_EQ 2u
 #define FLAG_GT 4u
@@ -419,6 +433,20 @@ struct Shared {
   uint8_t* stack_ptrs;
   const uint4* blob_words;
 };
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZKW_CFV_IN_LDS) /* (-DZKW_CFV_IN_LDS: the A/B partner) */
+ZKW_CFV(heap_bound, "v129")
+ZKW_CFV(aux_bound, "v130")
+ZKW_CFV(slot, "v134")
+ZKW_CFV(heap_hwm, "v135")
+#else  // single-lane emulation build (and the A/B partner): the LDS rows
+#define ZKW_CFV_EMU(name, field)                                                      \
+  ZD u32 cfv_##name(const Shared& sh, const Lane& s) { return CF(sh, s, field); }     \
+  ZD void cfv_set_##name(const Shared& sh, const Lane& s, u32 v) { CF(sh, s, field) = v; }
+ZKW_CFV_EMU(heap_bound, CF_HEAP_BOUND)
+ZKW_CFV_EMU(aux_bound, CF_AUX_BOUND)
+ZKW_CFV_EMU(slot, CF_SLOT)
+ZKW_CFV_EMU(heap_hwm, CF_HEAP_HWM)
+#endif
 #ifdef __HIP_DEVICE_COMPILE__
 #define ZKW_PIN_SGPR(x) asm volatile("" : "+s"(x))
 #else
@@ -649,7 +677,7 @@ ZD u256 stack_read(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, u32& is_ptr) {
   // a word that was never written reads as zero in the reference (the stack page is a zero-filled Vec); only WRITES
   // need capacity, and stack_hwm <= S
   if (idx >= CF(sh, s, CF_STACK_HWM)) return u256_zero();
-  const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), sh.S, idx);
+  const u32 w = page_word_index(sh, s, cfv_slot(sh, s), sh.S, idx);
   // (the tag byte last: loads return in order, so a use of the tag scheduled early cannot split the three into two round trips)
   const uint4 lo = zkw_gload4(sh.stack_vals + (2 * w - s.lane)), hi = zkw_gload4(sh.stack_vals + (2 * w - s.lane + sh.L));
 #ifdef __HIP_DEVICE_COMPILE__
@@ -668,12 +696,12 @@ ZD void stack_write(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, const u256& v,
     return;
   }
   for (u32 g = CF(sh, s, CF_STACK_HWM); g < idx; g++) {  // lazily zero the gap
-    const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), sh.S, g);
+    const u32 w = page_word_index(sh, s, cfv_slot(sh, s), sh.S, g);
     zkw_gstore4(sh.stack_vals + (2 * w - s.lane), make_uint4(0, 0, 0, 0));
     zkw_gstore4(sh.stack_vals + (2 * w - s.lane + sh.L), make_uint4(0, 0, 0, 0));
     zkw_gstore1(sh.stack_ptrs + w, 0);
   }
-  const u32 w = page_word_index(sh, s, CF(sh, s, CF_SLOT), sh.S, idx);
+  const u32 w = page_word_index(sh, s, cfv_slot(sh, s), sh.S, idx);
   if (!(sh.debug_flags & 128u)) {  // (128: traffic ablation — the run is then wrong)
     zkw_gstore4(sh.stack_vals + (2 * w - s.lane), u256_lo4(v));
     zkw_gstore4(sh.stack_vals + (2 * w - s.lane + sh.L), u256_hi4(v));
@@ -694,7 +722,7 @@ ZD u256 heap_read_at(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 slot,
 // MemoryType::Heap / AuxHeap of the current frame (memory.rs:439-473; the page number of the query
 // is only debug_assert'ed there, i.e. ignored in release builds)
 ZD u256 heap_read_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx) {
-  return heap_read_at(P, sh, s, is_aux, CF(sh, s, CF_SLOT), is_aux ? CF(sh, s, CF_AUX_HWM) : CF(sh, s, CF_HEAP_HWM), idx);
+  return heap_read_at(P, sh, s, is_aux, cfv_slot(sh, s), is_aux ? CF(sh, s, CF_AUX_HWM) : cfv_heap_hwm(sh, s), idx);
 }
 // write into page `slot` whose high-water mark is `hwm` (updated; the caller stores it back): the frame fields come in
 // as values so that a caller with several accesses reads them from LDS once, together
@@ -724,49 +752,70 @@ ZD void heap_write_at(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 slot
   if (idx >= hwm) hwm = idx + 1;
 }
 ZD void heap_write_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx, const u256& v) {
-  u32 hwm = is_aux ? CF(sh, s, CF_AUX_HWM) : CF(sh, s, CF_HEAP_HWM);
-  heap_write_at(P, sh, s, is_aux, CF(sh, s, CF_SLOT), hwm, idx, v);
-  if (is_aux) CF(sh, s, CF_AUX_HWM) = hwm; else CF(sh, s, CF_HEAP_HWM) = hwm;
+  u32 hwm = is_aux ? CF(sh, s, CF_AUX_HWM) : cfv_heap_hwm(sh, s);
+  heap_write_at(P, sh, s, is_aux, cfv_slot(sh, s), hwm, idx, v);
+  if (is_aux) CF(sh, s, CF_AUX_HWM) = hwm; else cfv_set_heap_hwm(sh, s, hwm);
 }
 
+// Arena slots and page lifetimes (memory.rs:573-758).  A far frame owns one arena slot (stack, heap, aux heap pages
+// base + 1 .. 3).  What the reference does with those pages when the frame returns (finish_global_frame, :660-758):
+//   * the stack page always goes back to its pool;
+//   * the heap / aux page the returndata pointer names moves to `pages_with_extended_lifetime` and stays reachable
+//     (Indirection::ReturndataExtendedLifetime) until the frame that RECEIVED it returns — unless that frame forwards
+//     the same page as its own returndata, which hands it to the next frame up (:725-742);
+//   * every other page of the frame goes back to the pool.
+// The state of a slot lives in the `stack_hwm` word of its frame meta (the stack page is dead in every state but LIVE):
+//   <= 2^16           LIVE: the stack page's high-water mark
+//   ZKW_SLOT_KEPT     | kind << 16 | owner: the heap (kind 2) / aux (kind 3) page is returndata owned by the far frame in
+//                     slot `owner`; the slot's other pages read as zero
+//   ZKW_SLOT_DEAD     | kind << 16: its owner returned — unreachable for the VM (the reference removes the indirection
+//                     and leaks the page: `dump_page_content` still finds it), recycled when no fresh or free slot is left
+//   ZKW_SLOT_FREE     returned to the pool: reused by the next far call once the fresh slots are used up
+// so that limits.max_far_frames bounds the frames that are live or reachable at one time, not the far calls of a run.
+#define ZKW_SLOT_FREE 0xffffffffu
+#define ZKW_SLOT_KEPT 0x80000000u
+#define ZKW_SLOT_DEAD 0xc0000000u
+#define ZKW_SLOT_STATE(st) ((st) & 0xc0000000u)
+ZD zkw_dev_frame_meta* frame_metas(ZKW_KP P, const Shared& sh, const Lane& s) { return P.frames + (u64)lane_inst(sh, s) * P.F; }
+
 // MemoryType::FatPointer read (memory.rs:475-521): resolve the page to an arena slot.
-// Page 0 is Indirection::Empty; pages that never were a heap/aux page of a frame of this
+// Page 0 is Indirection::Empty; pages that are no heap / aux page of a live or kept frame of this
 // instance are "unreachable memory" (the reference's expect() at :478-481).
 ZD u256 fat_ptr_read(ZKW_KP P, const Shared& sh, Lane& s, u32 page, u32 idx) {
   s.lane = zkw_lane_id();  // fresh, short-lived lane index (see struct Lane)
   if (page == 0) return u256_zero();
-  u32 slot, kind;
+  u32 slot = 0, kind = 0, hwm = 0;
   bool found = false;
-  if (page >= CF(sh, s, CF_FIRST_DYN)) {
-    const u32 rel = page - CF(sh, s, CF_FIRST_DYN);
-    const u32 stride = P.consts.new_memory_pages_per_far_call;
-    slot = CF(sh, s, CF_N_INITIAL_SLOTS) + rel / stride;
-    kind = rel % stride;
-    found = slot < CF(sh, s, CF_NEXT_SLOT);
-  } else {
-    slot = 0;
-    kind = 0;
-    for (u32 i = 0; i < CF(sh, s, CF_N_INITIAL_SLOTS); i++) {
-      const u32 bp = P.frames[(u64)lane_inst(sh, s) * P.F + i].base_page;
-      if (page >= bp && page < bp + 4) {
+  {
+    const u32 cur_slot = cfv_slot(sh, s);
+    const u32 rel = page - CF(sh, s, CF_BASE_PAGE);
+    if (rel == 2u || rel == 3u) {  // the current frame's own pages: their marks are in LDS
+      slot = cur_slot;
+      kind = rel;
+      hwm = rel == 3u ? CF(sh, s, CF_AUX_HWM) : cfv_heap_hwm(sh, s);
+      found = true;
+    } else {
+      const uint4* fms = (const uint4*)frame_metas(P, sh, s);
+      const u32 n = CF(sh, s, CF_NEXT_SLOT);
+      for (u32 i = 0; i < n; i++) {
+        const uint4 m = fms[i];  // base page, state | stack mark, heap mark, aux mark
+        const u32 r = page - m.x;
+        if (i == cur_slot || m.x == 0 || m.y == ZKW_SLOT_FREE || (r != 2u && r != 3u)) continue;
+        const u32 state = ZKW_SLOT_STATE(m.y);
+        if (state == ZKW_SLOT_DEAD) continue;                                   // indirection removed (:752-756)
+        if (state == ZKW_SLOT_KEPT && ((m.y >> 16) & 3u) != r) continue;        // the frame's other page went back to the pool
         slot = i;
-        kind = page - bp;
+        kind = r;
+        hwm = r == 3u ? m.w : m.z;
         found = true;
       }
     }
   }
-  if (!found || (kind != 2 && kind != 3)) {
+  if (!found) {
     lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
     return u256_zero();
   }
   const bool is_aux = kind == 3;
-  u32 hwm;
-  if (slot == CF(sh, s, CF_SLOT)) {
-    hwm = is_aux ? CF(sh, s, CF_AUX_HWM) : CF(sh, s, CF_HEAP_HWM);
-  } else {
-    const zkw_dev_frame_meta fm = P.frames[(u64)lane_inst(sh, s) * P.F + slot];
-    hwm = is_aux ? fm.aux_hwm : fm.heap_hwm;
-  }
   const u32 words = is_aux ? sh.A : sh.H;
   if (idx >= hwm || idx >= words) return u256_zero();  // `.get(index).unwrap_or(zero)` (:490-495)
   const uint4* base = is_aux ? sh.aux_heap : sh.heap;
@@ -817,13 +866,13 @@ ZD void frame_writeback(ZKW_KP P, const Shared& sh, const Lane& s) {
   u32* e = (u32*)entry_ptr(P, sh, s, s.depth);
   e[E_SP_PC] = (s.sp & 0xffffu) | (s.pc << 16);
   e[E_ERGS] = s.ergs;
-  e[E_HEAP_BOUND] = CF(sh, s, CF_HEAP_BOUND);
-  e[E_AUX_BOUND] = CF(sh, s, CF_AUX_BOUND);
+  e[E_HEAP_BOUND] = cfv_heap_bound(sh, s);
+  e[E_AUX_BOUND] = cfv_aux_bound(sh, s);
 }
 ZD void hwm_writeback(ZKW_KP P, const Shared& sh, const Lane& s) {
-  zkw_dev_frame_meta* fm = P.frames + (u64)lane_inst(sh, s) * P.F + CF(sh, s, CF_SLOT);
+  zkw_dev_frame_meta* fm = P.frames + (u64)lane_inst(sh, s) * P.F + cfv_slot(sh, s);
   fm->stack_hwm = CF(sh, s, CF_STACK_HWM);
-  fm->heap_hwm = CF(sh, s, CF_HEAP_HWM);
+  fm->heap_hwm = cfv_heap_hwm(sh, s);
   fm->aux_hwm = CF(sh, s, CF_AUX_HWM);
 }
 // load the hot fields of entry `s.depth` into the lane
@@ -846,17 +895,17 @@ ZD void frame_load(ZKW_KP P, const Shared& sh, Lane& s) {
   if ((ehf >> 16) & 0xffu) s.kflags |= KF_STATIC;
   if ((ehf >> 24) & 0xffu) s.kflags |= KF_LOCAL;
   s.ergs = e[E_ERGS];
-  CF(sh, s, CF_HEAP_BOUND) = e[E_HEAP_BOUND];
-  CF(sh, s, CF_AUX_BOUND) = e[E_AUX_BOUND];
+  cfv_set_heap_bound(sh, s, e[E_HEAP_BOUND]);
+  cfv_set_aux_bound(sh, s, e[E_AUX_BOUND]);
   if (e[E_THIS] < 0x10000u && (e[E_THIS + 1] | e[E_THIS + 2] | e[E_THIS + 3] | e[E_THIS + 4]) == 0) s.kflags |= KF_KERNEL;  // execution_stack.rs:83-87
   const u32 new_slot = e[E_SLOT];
   const uint2 bd = P.blob_dir[e[E_CODE_BLOB]];
   CF(sh, s, CF_CODE_OFF) = bd.x;
   CF(sh, s, CF_CODE_LEN) = bd.y;
-  CF(sh, s, CF_SLOT) = new_slot;
+  cfv_set_slot(sh, s, new_slot);
   const zkw_dev_frame_meta fm = P.frames[(u64)lane_inst(sh, s) * P.F + new_slot];
   CF(sh, s, CF_STACK_HWM) = fm.stack_hwm;
-  CF(sh, s, CF_HEAP_HWM) = fm.heap_hwm;
+  cfv_set_heap_hwm(sh, s, fm.heap_hwm);
   CF(sh, s, CF_AUX_HWM) = fm.aux_hwm;
 }
 
@@ -1045,8 +1094,8 @@ ZD void entry_image_current(ZKW_KP P, const Shared& sh, const Lane& s, u32 img[3
   }
   img[E_SP_PC] = (s.sp & 0xffffu) | (s.pc << 16);
   img[E_ERGS] = s.ergs;
-  img[E_HEAP_BOUND] = CF(sh, s, CF_HEAP_BOUND);
-  img[E_AUX_BOUND] = CF(sh, s, CF_AUX_BOUND);
+  img[E_HEAP_BOUND] = cfv_heap_bound(sh, s);
+  img[E_AUX_BOUND] = cfv_aux_bound(sh, s);
 }
 
 // VmState::start_frame (helpers.rs:225-246): Storage/EventSink::start_frame are a journal mark here
@@ -1167,8 +1216,8 @@ ZD void op_context(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, cons
   } else if (v == ZKW_CTX_META) {  // VmMetaParameters::to_u256 (Appendix B layout)
     const u32 sh3 = e[E_SHARDS];
     value.w[0] = CF(sh, s, CF_ERGS_PP);
-    value.w[2] = CF(sh, s, CF_HEAP_BOUND);
-    value.w[3] = CF(sh, s, CF_AUX_BOUND);
+    value.w[2] = cfv_heap_bound(sh, s);
+    value.w[3] = cfv_aux_bound(sh, s);
     value.w[7] = (sh3 & 0xffu) | (((sh3 >> 8) & 0xffu) << 8) | (((sh3 >> 16) & 0xffu) << 16);
   } else if (v == ZKW_CTX_ERGS_LEFT) {
     value.w[0] = s.ergs;
@@ -1248,9 +1297,9 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
   u32 f_base_page = 0, f_slot = 0, f_hwm = 0, f_bound = 0;
   if (!is_ptr_read) {
     f_base_page = CF(sh, s, CF_BASE_PAGE);
-    f_slot = CF(sh, s, CF_SLOT);
-    f_hwm = is_heap ? CF(sh, s, CF_HEAP_HWM) : CF(sh, s, CF_AUX_HWM);
-    f_bound = is_heap ? CF(sh, s, CF_HEAP_BOUND) : CF(sh, s, CF_AUX_BOUND);
+    f_slot = cfv_slot(sh, s);
+    f_hwm = is_heap ? cfv_heap_hwm(sh, s) : CF(sh, s, CF_AUX_HWM);
+    f_bound = is_heap ? cfv_heap_bound(sh, s) : cfv_aux_bound(sh, s);
     ZKW_LGKM_PROBE(7 /* UMA frame fields */)
   }
   const u32 f_hwm_in = f_hwm;
@@ -1287,7 +1336,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
     const u32 bound = f_bound;
     if (incremented >= bound) {
       growth = incremented - bound;
-      if (is_heap) CF(sh, s, CF_HEAP_BOUND) = incremented; else CF(sh, s, CF_AUX_BOUND) = incremented;
+      if (is_heap) cfv_set_heap_bound(sh, s, incremented); else cfv_set_aux_bound(sh, s, incremented);
     }
   }
   u32 cost = growth * sh.growth_per_byte;  // :196-197
@@ -1361,7 +1410,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
       }
     }
     if (f_hwm != f_hwm_in) {
-      if (is_heap) CF(sh, s, CF_HEAP_HWM) = f_hwm; else CF(sh, s, CF_AUX_HWM) = f_hwm;
+      if (is_heap) cfv_set_heap_hwm(sh, s, f_hwm); else CF(sh, s, CF_AUX_HWM) = f_hwm;
     }
     ZKW_SUB(46)  // write: heap writes + write queries
     if (!set_panic) {
@@ -1615,10 +1664,10 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
   if (fwd != 1u) {
     u32 upper = abi.start + abi.length;
     if (pve & FPV_DEREF_BEYOND) upper = 0xffffffffu;
-    const u32 bound = fwd == 0u ? CF(sh, s, CF_HEAP_BOUND) : CF(sh, s, CF_AUX_BOUND);
+    const u32 bound = fwd == 0u ? cfv_heap_bound(sh, s) : cfv_aux_bound(sh, s);
     if (upper >= bound) {
       growth = upper - bound;
-      if (fwd == 0u) CF(sh, s, CF_HEAP_BOUND) = upper; else CF(sh, s, CF_AUX_BOUND) = upper;
+      if (fwd == 0u) cfv_set_heap_bound(sh, s, upper); else cfv_set_aux_bound(sh, s, upper);
     }
   }
   const u32 growth_cost = growth * K.memory_growth_ergs_per_byte;
@@ -1723,8 +1772,8 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
   s.pc = ps.new_pc;
   prev[E_SP_PC] = (s.sp & 0xffffu) | (s.pc << 16);
   prev[E_ERGS] = s.ergs;
-  prev[E_HEAP_BOUND] = CF(sh, s, CF_HEAP_BOUND);
-  prev[E_AUX_BOUND] = CF(sh, s, CF_AUX_BOUND);
+  prev[E_HEAP_BOUND] = cfv_heap_bound(sh, s);
+  prev[E_AUX_BOUND] = cfv_aux_bound(sh, s);
   const u32 new_static = ((s.kflags & KF_STATIC) != 0 || is_static_call) ? 1u : 0u;
   CF(sh, s, CF_MPC) += K.new_memory_pages_per_far_call;  // :503
   s.kflags |= KF_COLD_DIRTY;
@@ -1762,15 +1811,30 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
   next[E_CODE_BLOB] = mapped_blob;
   CF(sh, s, CF_CTX0 + 0) = CF(sh, s, CF_CTX0 + 1) = CF(sh, s, CF_CTX0 + 2) = CF(sh, s, CF_CTX0 + 3) = 0;  // :558
   // memory.start_global_frame (memory.rs:573-657): a fresh arena slot, pages lazily zero
-  const u32 new_slot = CF(sh, s, CF_NEXT_SLOT);
-  if (new_slot >= P.F) {
-    lane_fail(s, ZKW_STATUS_LIMIT);
-    return;
+  u32 new_slot = CF(sh, s, CF_NEXT_SLOT);
+  if (new_slot < P.F) {
+    CF(sh, s, CF_NEXT_SLOT)++;  // a fresh slot
+  } else {  // reuse: a slot whose frame returned (the reference's page pools, memory.rs:15-148), else one that only `dump_page_content` still sees
+    const zkw_dev_frame_meta* fms = frame_metas(P, sh, s);
+    u32 dead = 0xffffffffu;
+    new_slot = 0xffffffffu;
+    for (u32 i = 0; i < P.F; i++) {
+      const u32 st = fms[i].stack_hwm;
+      if (st == ZKW_SLOT_FREE) {
+        if (new_slot == 0xffffffffu) new_slot = i;
+      } else if (ZKW_SLOT_STATE(st) == ZKW_SLOT_DEAD && dead == 0xffffffffu) {
+        dead = i;
+      }
+    }
+    if (new_slot == 0xffffffffu) new_slot = dead;
+    if (new_slot == 0xffffffffu) {
+      lane_fail(s, ZKW_STATUS_LIMIT);
+      return;
+    }
   }
-  CF(sh, s, CF_NEXT_SLOT)++;
   next[E_SLOT] = new_slot;
   {
-    zkw_dev_frame_meta* fm = P.frames + (u64)lane_inst(sh, s) * P.F + new_slot;
+    zkw_dev_frame_meta* fm = frame_metas(P, sh, s) + new_slot;
     fm->base_page = new_base;
     fm->stack_hwm = 0;
     fm->heap_hwm = 0;
@@ -1831,7 +1895,7 @@ ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, H
     if (fwd != 1u) {
       u32 upper = ptr.start + ptr.length;
       if (pve & FPV_DEREF_BEYOND) upper = 0xffffffffu;
-      const u32 bound = fwd == 0u ? CF(sh, s, CF_HEAP_BOUND) : CF(sh, s, CF_AUX_BOUND);
+      const u32 bound = fwd == 0u ? cfv_heap_bound(sh, s) : cfv_aux_bound(sh, s);
       growth = upper < bound ? 0u : upper - bound;
     }
     const u32 cost = growth * K.memory_growth_ergs_per_byte;
@@ -1848,7 +1912,7 @@ ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, H
   const u32* fin = (const u32*)entry_ptr(P, sh, s, s.depth);
   const u32 fin_eh = fin[E_EH_FLAGS] & 0xffffu;
   const u32 fin_mark = fin[E_JOURNAL_MARK];
-  const u32 fin_heap_bound = CF(sh, s, CF_HEAP_BOUND), fin_aux_bound = CF(sh, s, CF_AUX_BOUND);
+  const u32 fin_heap_bound = cfv_heap_bound(sh, s), fin_aux_bound = cfv_aux_bound(sh, s);
   storage_finish_frame(P, sh, s, fin_mark, panicked);
   {
     uint4* a = aux_alloc(P, sh, s, ZKW_AUX_FRAME_FINISH, panicked ? 1u : 0u, 0, 0, 0);
@@ -1860,10 +1924,29 @@ ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, H
   }
   ZKW_STAMP(62)  // ret: validation, finish_frame
   hwm_writeback(P, sh, s);
+  const u32 fin_slot = cfv_slot(sh, s), fin_base = CF(sh, s, CF_BASE_PAGE);
   s.depth--;
   frame_load(P, sh, s);
   to_label = to_label && local;  // :202
-  if (!local) {  // :204-236; memory.finish_global_frame (memory.rs:660-758) is pure bookkeeping here: arena slots are never recycled
+  if (!local) {  // memory.finish_global_frame (memory.rs:660-758): see "Arena slots and page lifetimes" above
+    zkw_dev_frame_meta* fms = frame_metas(P, sh, s);
+    const u32 parent = cfv_slot(sh, s), rp = ptr.page, n_slots = CF(sh, s, CF_NEXT_SLOT);
+    for (u32 k2 = 0; k2 < n_slots; k2++) {  // returndata pages this frame had received: forwarded upwards or out of reach (:725-756)
+      const u32 st = fms[k2].stack_hwm;
+      if (ZKW_SLOT_STATE(st) != ZKW_SLOT_KEPT || st == ZKW_SLOT_FREE || (st & 0xffffu) != fin_slot) continue;
+      const u32 kind = (st >> 16) & 3u;
+      fms[k2].stack_hwm = (rp != 0 && rp == fms[k2].base_page + kind) ? (ZKW_SLOT_KEPT | (kind << 16) | parent) : (ZKW_SLOT_DEAD | (kind << 16));
+    }
+    if (rp != 0 && rp == fin_base + 2u) {         // the heap is the returndata (:702-715)
+      fms[fin_slot].stack_hwm = ZKW_SLOT_KEPT | (2u << 16) | parent;
+      fms[fin_slot].aux_hwm = 0;
+    } else if (rp != 0 && rp == fin_base + 3u) {  // the aux heap is (:716-731)
+      fms[fin_slot].stack_hwm = ZKW_SLOT_KEPT | (3u << 16) | parent;
+      fms[fin_slot].heap_hwm = 0;
+    } else {                                      // forwarding or a panic: every page of the frame goes back to the pool (:732-750)
+      fms[fin_slot].stack_hwm = ZKW_SLOT_FREE;
+      fms[fin_slot].base_page = 0;
+    }
     out.v1 = fat_ptr_to_u256(ptr);
     out.action = ZKW_ACT_RET;
     if (CF(sh, s, CF_CTX0 + 0) | CF(sh, s, CF_CTX0 + 1) | CF(sh, s, CF_CTX0 + 2) | CF(sh, s, CF_CTX0 + 3)) s.kflags |= KF_COLD_DIRTY;
@@ -1873,12 +1956,12 @@ ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, H
   if (to_label) s.pc = label_pc;
   else if (panicked) s.pc = fin_eh;
   if (local) {  // :254-260
-    if (fin_heap_bound < CF(sh, s, CF_HEAP_BOUND) || fin_aux_bound < CF(sh, s, CF_AUX_BOUND)) {
+    if (fin_heap_bound < cfv_heap_bound(sh, s) || fin_aux_bound < cfv_aux_bound(sh, s)) {
       lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
       return;
     }
-    CF(sh, s, CF_HEAP_BOUND) = fin_heap_bound;
-    CF(sh, s, CF_AUX_BOUND) = fin_aux_bound;
+    cfv_set_heap_bound(sh, s, fin_heap_bound);
+    cfv_set_aux_bound(sh, s, fin_aux_bound);
   }
   if (variant == ZKW_RET_PANIC) s.flags |= FLAG_LT;  // :262-264
 }
@@ -2680,7 +2763,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
           uint4* const tail_ptr = tails_wave + (u64)k * tail_step + s.lane;
           zkw_stream_store(tail_ptr, make_uint4((s.ptr_bitmap & 0xffffu) | ((s.flags & 0xfu) << 16) | ((s.reg_dirty & 0xffu) << 24),
                                                 (s.pc & 0xffffu) | (s.sp << 16), s.ergs, s.timestamp));
-          zkw_stream_store(tail_ptr + sh.L, make_uint4(CF(sh, s, CF_HEAP_BOUND), CF(sh, s, CF_AUX_BOUND), (s.depth & 0xffffu) | (s.prev_super_pc << 16), cnt | ((s.reg_dirty >> 8) << 24)));
+          zkw_stream_store(tail_ptr + sh.L, make_uint4(cfv_heap_bound(sh, s), cfv_aux_bound(sh, s), (s.depth & 0xffffu) | (s.prev_super_pc << 16), cnt | ((s.reg_dirty >> 8) << 24)));
         }
         if (fits && total) {
           // `total` is the same for every lane still in the loop (ballots over exactly those lanes); the LDS copy is

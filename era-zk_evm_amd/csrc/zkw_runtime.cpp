@@ -75,6 +75,7 @@ struct StagedInstance {
   std::vector<zkw_callstack_entry> inner;
   std::vector<std::pair<uint32_t, uint32_t>> code_pages;  // page -> blob
   std::vector<zkw_u256> heap;
+  std::vector<zkw_u256> bootloader_calldata;  // BOOTLOADER_CALLDATA_PAGE (host only: the VM cannot reach it, zkw.h)
   std::vector<zkw_storage_slot> storage;
   bool has_state = false;
 };
@@ -494,6 +495,12 @@ int zkw_batch_set_heap(zkw_batch* b, uint32_t instance, const zkw_u256* words, u
   return ZKW_OK;
 }
 
+int zkw_batch_set_bootloader_calldata(zkw_batch* b, uint32_t instance, const zkw_u256* words, uint32_t n_words) {
+  if (!b || instance >= b->n || (n_words && !words)) return ZKW_ERR_INVALID;
+  b->staged[instance].bootloader_calldata.assign(words, words + n_words);  // nothing on the device depends on it
+  return ZKW_OK;
+}
+
 int zkw_batch_set_storage(zkw_batch* b, uint32_t instance, const zkw_storage_slot* slots, uint32_t n_slots) {
   if (!b || instance >= b->n || (n_slots && !slots)) return ZKW_ERR_INVALID;
   if (n_slots * 2 > b->lim.storage_slots) {
@@ -745,6 +752,7 @@ int zkw_batch_upload(zkw_batch* b) {
     if (next_slot == 0) next_slot = 1;  // slot 0 is reserved even for an already-ended VM
     sc.n_initial_slots = next_slot;
     sc.next_slot = next_slot;
+    for (uint32_t k = next_slot; k < F; k++) frames[(size_t)i * F + k].stack_hwm = 0xffffffffu;  // ZKW_SLOT_FREE (zkw_kernels.hip)
     // heap image of the current frame
     if (!s.heap.empty()) {
       const uint32_t cur_slot = stack[(size_t)i * (D + 1) + depth].frame_slot;
@@ -1480,6 +1488,70 @@ int zkw_batch_net_states(zkw_batch* b, void* hip_stream) {
   b->ns_done = true;
   b->ns_cached_wave = 0xffffffffu;
   return ZKW_OK;
+}
+
+// SimpleMemory::dump_page_content_as_u256_words (memory.rs:316-396)
+int zkw_batch_get_page(zkw_batch* b, uint32_t instance, uint32_t page, uint32_t first_word, uint32_t n_words, zkw_u256* out) {
+  if (!b || instance >= b->n || (n_words && !out)) return ZKW_ERR_INVALID;
+  zkw_ctx* c = b->ctx;
+  if (!b->uploaded) {
+    c->last_error = "zkw_batch_get_page: batch not uploaded";
+    return ZKW_ERR_INVALID;
+  }
+  int rc = zkw_batch_sync(b);
+  if (rc != ZKW_OK) return rc;
+  if (!n_words) return ZKW_OK;
+  std::memset(out, 0, (size_t)n_words * sizeof(zkw_u256));
+  const StagedInstance& si = b->staged[instance];
+  const uint32_t F = b->lim.max_far_frames, L = b->L, w = instance / L, l = instance % L;
+  auto from_vector = [&](const std::vector<zkw_u256>& v) {
+    for (uint32_t k = 0; k < n_words; k++)
+      if ((uint64_t)first_word + k < v.size()) out[k] = v[(size_t)first_word + k];
+  };
+  // 1. code pages (:321-332): page 0 (always present, all zero), the populated ones, the ones the run decommitted
+  if (page == 0) return ZKW_OK;
+  for (auto it = si.code_pages.rbegin(); it != si.code_pages.rend(); ++it)
+    if (it->first == page) {
+      from_vector(b->blobs[it->second]);
+      return ZKW_OK;
+    }
+  {
+    const zkw_dev_scalars& sc = b->h_scalars[instance];  // (zkw_batch_sync has refreshed them)
+    const uint32_t nh = std::min(sc.n_history, F);
+    std::vector<zkw_dev_history> hist(nh);
+    if (nh) HIP_TRY(c, hipMemcpy(hist.data(), b->d_history.p + (size_t)instance * F, (size_t)nh * sizeof(zkw_dev_history), hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < nh; k++)
+      if (hist[k].page == page && hist[k].preimage < b->preimages.size()) {
+        from_vector(b->blobs[b->preimages[hist[k].preimage].second]);
+        return ZKW_OK;
+      }
+  }
+  // 2. pages with extended lifetime that are no arena pages: the bootloader's calldata (:229-231, 293-298)
+  if (page == c->isa.consts.bootloader_calldata_page) {
+    from_vector(si.bootloader_calldata);
+    return ZKW_OK;
+  }
+  // 3. arena pages: returndata pages (extended lifetime), then the stack / heap / aux heap pages of live frames (:333-392)
+  std::vector<zkw_dev_frame_meta> fm(F);
+  HIP_TRY(c, hipMemcpy(fm.data(), b->d_frames.p + (size_t)instance * F, (size_t)F * sizeof(zkw_dev_frame_meta), hipMemcpyDeviceToHost));
+  for (uint32_t slot = 0; slot < F; slot++) {
+    const uint32_t st = fm[slot].stack_hwm, kind = page - fm[slot].base_page;
+    if (st == 0xffffffffu || fm[slot].base_page == 0 || kind < 1 || kind > 3) continue;
+    const bool live = (st & 0xc0000000u) == 0;                  // else kept / dead returndata: only that page has content
+    if (!live && ((st >> 16) & 3u) != kind) return ZKW_OK;     // the frame's other pages went back to the pool: zeros
+    const uint32_t hwm = kind == 1 ? st : (kind == 2 ? fm[slot].heap_hwm : fm[slot].aux_hwm);
+    const uint32_t words = kind == 1 ? b->lim.stack_words : (kind == 2 ? b->lim.heap_words : b->lim.aux_heap_words);
+    const uint4* arena = kind == 1 ? b->d_stack_vals.p : (kind == 2 ? b->d_heap.p : b->d_aux.p);
+    const uint32_t end = std::min(std::min(hwm, words), first_word + n_words);
+    if (first_word < end) {
+      // a word is two 16-byte halves in two lane-minor planes of its row ([word][2][L]): rows of 16 bytes, pitch 16 L
+      const uint4* src = arena + (((size_t)w * F + slot) * words + first_word) * 2 * L + l;
+      HIP_TRY(c, hipMemcpy2DAsync(out, 16, src, (size_t)L * 16, 16, (size_t)(end - first_word) * 2, hipMemcpyDeviceToHost, b->run_stream));
+      HIP_TRY(c, hipStreamSynchronize(b->run_stream));
+    }
+    return ZKW_OK;
+  }
+  return ZKW_OK;  // anything else: zeros (:395)
 }
 
 int zkw_batch_get_net_state(zkw_batch* b, uint32_t instance, zkw_net_state* out) {

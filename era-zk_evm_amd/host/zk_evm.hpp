@@ -7,13 +7,16 @@
 //   MemoryQuery / LogQuery / DecommittmentQuery               field sets pinned by helpers.rs:26-32, log.rs:85-97, helpers.rs:171-177
 //   VmWitnessTracer (10 callbacks)                             src/witness_trace/mod.rs:11-72
 //   EventSink {add_partial_query, start_frame, finish_frame}   src/reference_impls/event_sink.rs:134-176
-//   BatchedVmState::cycle() / execution_has_ended()            src/vm_state/cycle.rs:257, mod.rs:214-216
+//   BatchedVmState::cycle(tracer) / execution_has_ended()      src/vm_state/cycle.rs:257-260, mod.rs:214-216
+//   Tracer (debug hooks; accepted, const-gated off) / GenericNoopTracer   src/tracing.rs:40-72, utils.rs:51-92
+//   SimpleMemory::dump_page_content_as_u256_words / dump_page_content     src/reference_impls/memory.rs:300-396
 // `cycle()` is served from a finished GPU run: it replays one cycle's records of a
 // zkw_instance_trace into the tracer and the event sink in the exact order the reference calls
 // them and rebuilds the full VmLocalState the reference would pass to
 // start_new_execution_cycle / end_execution_cycle.  Header-only, no GPU or HIP dependency.
 #pragma once
 #include <cstdint>
+#include <array>
 #include <cstring>
 #include <functional>
 #include <stdexcept>
@@ -230,6 +233,38 @@ inline U256 to_u256(const zkw_u256& v) {
   return r;
 }
 
+// The debug tracer of `cycle<DT: Tracer>(&mut self, tracer: &mut DT)` (cycle.rs:257-260).  Its four hooks are compiled
+// out unless the implementation's CALL_* constants say otherwise (tracing.rs:43-46); the replay has no decode internals
+// to hand to them, so a tracer that enables one is refused at compile time.
+struct GenericNoopTracer {  // utils.rs:51-92
+  static constexpr bool CALL_BEFORE_DECODING = false, CALL_AFTER_DECODING = false, CALL_BEFORE_EXECUTION = false, CALL_AFTER_EXECUTION = false;
+};
+
+// `vm.memory` after the run, as far as callers read it (memory.rs:300-401).  `get_page` is the C-ABI entry of the
+// library that ran the batch (zkw_batch_get_page of include/zkw.h).
+struct SimpleMemory {
+  typedef int (*get_page_fn)(zkw_batch*, uint32_t, uint32_t, uint32_t, uint32_t, zkw_u256*);
+  get_page_fn get_page;
+  zkw_batch* batch;
+  uint32_t instance;
+  // range = [begin, end) as in `std::ops::Range<u32>`
+  std::vector<U256> dump_page_content_as_u256_words(uint32_t page_number, uint32_t begin, uint32_t end) const {  // :316-396
+    std::vector<zkw_u256> raw(end > begin ? end - begin : 0);
+    if (!raw.empty() && get_page(batch, instance, page_number, begin, (uint32_t)raw.size(), raw.data()) != ZKW_OK) throw std::runtime_error("zkw_batch_get_page failed");
+    std::vector<U256> out(raw.size());
+    for (size_t i = 0; i < raw.size(); i++) std::memcpy(out[i].l, raw[i].l, 32);
+    return out;
+  }
+  std::vector<std::array<uint8_t, 32>> dump_page_content(uint32_t page_number, uint32_t begin, uint32_t end) const {  // :300-314: big-endian bytes
+    const std::vector<U256> w = dump_page_content_as_u256_words(page_number, begin, end);
+    std::vector<std::array<uint8_t, 32>> out(w.size());
+    for (size_t i = 0; i < w.size(); i++)
+      for (int b = 0; b < 32; b++) out[i][b] = (uint8_t)(w[i].l[3 - b / 8] >> (8 * (7 - b % 8)));
+    return out;
+  }
+  std::vector<std::array<uint8_t, 32>> dump_full_page(uint32_t page_number) const { return dump_page_content(page_number, 0, 1u << 10); }  // :397-400
+};
+
 class BatchedVmState {
  public:
   VmLocalState local_state;
@@ -269,6 +304,12 @@ class BatchedVmState {
 
   // VmState::cycle (cycle.rs:257-429). Returns 0 on success; ZKW_STATUS_* (>= 2) when the GPU run
   // stopped at this cycle with an error (the reference's Err / panic); -1 when the trace is exhausted.
+  template <class DT>
+  int cycle(DT& /*tracer*/) {
+    static_assert(!(DT::CALL_BEFORE_DECODING || DT::CALL_AFTER_DECODING || DT::CALL_BEFORE_EXECUTION || DT::CALL_AFTER_EXECUTION),
+                  "the replay serves finished cycles: the debug Tracer hooks (tracing.rs:40-72) are not available");
+    return cycle();
+  }
   int cycle() {
     if (k_ >= trace_.n_cycles) return trace_.status >= ZKW_STATUS_UNKNOWN_CODE_HASH ? (int)trace_.status : -1;
     VmLocalState& s = local_state;

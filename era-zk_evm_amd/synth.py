@@ -876,6 +876,112 @@ def nested_frames(isa, outer=K.RET_OK, inner=K.RET_OK, main_panics=False, n_inst
     return wl
 
 
+# ----------------------------------------------------------------------------------------
+# many sequential far calls under a small max_far_frames: the arena slot of a frame that has returned is reused unless
+# its heap / aux heap became returndata (memory.rs:660-758).  Callees:
+#   K  (kept)    writes its heap and returns a heap slice: the slot stays reachable from the caller (returndata)
+#   P  (panics)  reads words of its fresh pages that the previous tenant of the slot had written (they must read zero),
+#                writes heap + stack, then `ret.panic`: every page goes back to the pool
+#   N  (nested)  far-calls K itself and return-forwards K's returndata pointer: K's page is handed to N's caller, N's own
+#                slot goes back to the pool
+# ----------------------------------------------------------------------------------------
+def many_far_calls(isa, n_calls=64, n_instances=8, seed=0x5EED00F7, plan=None, max_far_frames=4):
+    e = isa.enc
+    ADDR_K, ADDR_P, ADDR_N = 0x10011, 0x10012, 0x10013
+    local = CALLEE_CODE_WORDS - 8  # page-local constant pool of the callees
+
+    def callee_k():
+        return [e(K.OP_UMA, variant=K.UMA_FAT_PTR_READ, flags=1, src0=1, dst0=3, dst1=1),
+                e(K.OP_UMA, variant=K.UMA_HEAP_READ, src0_mode=K.MODE_IMM, imm0=96, dst0=4),          # fresh heap: zero
+                e(K.OP_ADD, src0_mode=K.MODE_STACK_ABS, imm0=7, src1=0, dst0=5),                      # fresh stack: zero
+                e(K.OP_ADD, flags=0, src0=3, src1=4, dst0=6),
+                e(K.OP_UMA, variant=K.UMA_HEAP_WRITE, src0_mode=K.MODE_IMM, imm0=0, src1=6),
+                e(K.OP_UMA, variant=K.UMA_HEAP_WRITE, src0_mode=K.MODE_IMM, imm0=96, src1=3),
+                e(K.OP_ADD, dst0_mode=K.MODE_STACK_ABS, src0=3, src1=5, dst0=0, imm1=7),             # stack[7] := ...
+                e(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=local, src1=0, dst0=13),
+                e(K.OP_RET, variant=K.RET_OK, flags=0, src0=13)]
+
+    def callee_p():
+        return [e(K.OP_UMA, variant=K.UMA_HEAP_READ, src0_mode=K.MODE_IMM, imm0=0, dst0=3),
+                e(K.OP_UMA, variant=K.UMA_HEAP_READ, src0_mode=K.MODE_IMM, imm0=96, dst0=4),
+                e(K.OP_UMA, variant=K.UMA_AUX_READ, src0_mode=K.MODE_IMM, imm0=32, dst0=5),
+                e(K.OP_ADD, src0_mode=K.MODE_STACK_ABS, imm0=7, src1=0, dst0=6),
+                e(K.OP_UMA, variant=K.UMA_FAT_PTR_READ, flags=0, src0=1, dst0=7),
+                e(K.OP_UMA, variant=K.UMA_HEAP_WRITE, src0_mode=K.MODE_IMM, imm0=0, src1=7),
+                e(K.OP_UMA, variant=K.UMA_HEAP_WRITE, src0_mode=K.MODE_IMM, imm0=100, src1=7),
+                e(K.OP_ADD, dst0_mode=K.MODE_STACK_ABS, src0=7, src1=3, dst0=0, imm1=7),
+                e(K.OP_RET, variant=K.RET_PANIC, flags=0, src0=0)]
+
+    def callee_n():
+        return [e(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=local + 1, src1=0, dst0=13),   # far-call ABI
+                e(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=local + 2, src1=0, dst0=14),   # callee K
+                e(K.OP_UMA, variant=K.UMA_HEAP_WRITE, src0_mode=K.MODE_IMM, imm0=32, src1=13),
+                e(K.OP_FAR_CALL, variant=K.FAR_NORMAL, src0=13, src1=14, imm0=4),
+                e(K.OP_UMA, variant=K.UMA_FAT_PTR_READ, flags=0, src0=1, dst0=5),      # K's returndata
+                e(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=local + 3, src1=0, dst0=12),
+                e(K.OP_PTR, variant=K.PTR_PACK, src0=1, src1=12, dst0=13),            # returndata pointer | forwarding mode 1 in the top bits
+                e(K.OP_RET, variant=K.RET_OK, flags=0, src0=13)]
+
+    programs = {"K": (ADDR_K, callee_k()), "P": (ADDR_P, callee_p()), "N": (ADDR_N, callee_n())}
+    if plan is None:
+        plan = "K" + "P" * 5 + "N" + "P" * (n_calls - 7)  # two live returndata pages + the bootloader: one slot left to reuse
+    assert len(plan) == n_calls
+    n_cycles = 4
+    for c in plan:
+        n_cycles += 1 + len(programs[c][1]) + (len(programs["K"][1]) if c == "N" else 0) + RELOAD_CYCLES
+    wl = Workload("many_far_calls_%s" % plan[:12], n_instances, n_cycles)
+    rng = ScalarRng(seed)
+    tb = TapeBuilder(isa, rng)
+    order = ["K", "P", "N"]
+    consts = []
+    for c in order:
+        consts += [far_call_abi(64, 128, 200000), K.u256_from_int(programs[c][0])]
+    for j, c in enumerate(plan):  # r13 / r14 hold the ABI / address of callee j: preset for the first, reloaded after every return
+        tb.far_call()
+        k = order.index(plan[min(j + 1, n_calls - 1)])
+        tb.reload(2 * k, 2 * k + 1)   # (also reads the first returndata word through r1)
+    for _ in range(4):
+        tb.emit(e(K.OP_ADD, flags=1, src0=12, src1=2, dst0=3))
+    boot_words = np.zeros((CONST_BASE + len(consts), 4), dtype="<u8")
+    code = K.pack_code(tb.ops)
+    assert len(code) < CONST_BASE
+    boot_words[: len(code)] = code
+    for i, c in enumerate(consts):
+        boot_words[CONST_BASE + i] = c
+    wl.blobs.append(boot_words)
+    wl.code_pages.append((0, n_instances, BOOTLOADER_CODE_PAGE, 0))
+    slots = np.zeros(len(order), dtype=K.STORAGE_SLOT)
+    for which, c in enumerate(order):
+        addr, ops = programs[c]
+        words = np.zeros((CALLEE_CODE_WORDS, 4), dtype="<u8")
+        code = K.pack_code(ops)
+        words[: len(code)] = code
+        fill = Xoshiro(seed ^ (0x2000 + which), 1).words(64)[0]
+        words[64:128] = fill
+        words[local] = ret_abi(0, 128)
+        words[local + 1] = far_call_abi(0, 64, 50000)
+        words[local + 2] = K.u256_from_int(ADDR_K)
+        words[local + 3] = K.u256_from_int(1 << 224)  # RetABI forwarding_mode = ForwardFatPointer, in the half ptr.pack takes from src1
+        wl.blobs.append(words)
+        h = versioned_code_hash(words)
+        wl.preimages.append((h, 1 + which))
+        slots[which]["key"] = K.u256_from_int(addr)
+        slots[which]["value"] = h
+        slots[which]["address"] = K.address_bytes(0x8002)
+    wl.storage = [slots] * n_instances
+    regs = Xoshiro(seed ^ 0xABCDEF, n_instances).words(15)
+    regs[:, 11] = 0
+    regs[:, 12] = consts[2 * order.index(plan[0])]
+    regs[:, 13] = consts[2 * order.index(plan[0]) + 1]
+    regs[:, 14] = 0
+    wl.states, wl.inner = initial_states(n_instances, regs)
+    wl.heaps = Xoshiro(seed ^ 0x4EA9, n_instances).words(HEAP_BYTES // 32)
+    wl.limits.update(max_far_frames=max_far_frames, heap_words=320, stack_words=16, aux_heap_words=8, storage_slots=8, storage_journal=4,
+                     max_aux_events=8 * n_calls + 32, max_reg_deltas=2 * n_cycles + 40 * n_calls)
+    return wl
+
+
+
 def make(cfg, isa, **kw):  # noqa: F811
     return {0: config0, 1: config1, 2: config2, 3: config3, 4: config4}[cfg](isa, **kw)
 

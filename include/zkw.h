@@ -145,7 +145,10 @@ typedef struct zkw_isa_consts {
   uint8_t storage_aux_byte, event_aux_byte, l1_message_aux_byte, precompile_aux_byte; /* log.rs:6-8 */
   uint32_t ecrecover_input_layout;    /* words at input_memory_offset: 0 = (hash, r, s, v) as the reference's own test fills
                                          memory (testing/tests/precompiles/ecrecover.rs:3-49); 1 = (hash, v, r, s) */
-  uint32_t reserved[7];
+  uint32_t bootloader_calldata_page;  /* zkevm_opcode_defs::BOOTLOADER_CALLDATA_PAGE (memory.rs:11,229-231): the page that
+                                         SimpleMemory keeps in `pages_with_extended_lifetime` from the start.  Value recalled,
+                                         UNVERIFIED (the crate is not on disk) — hence a table constant, not code */
+  uint32_t reserved[6];
 } zkw_isa_consts;
 
 typedef struct zkw_isa_table {
@@ -222,7 +225,9 @@ typedef struct zkw_storage_slot {
  * written is not an overrun — it reads zero, as in the reference's zero-filled pages (memory.rs:427-473). */
 typedef struct zkw_limits {
   uint32_t max_cycles;            /* cycles recorded per instance and per run                      */
-  uint32_t max_far_frames;        /* far-call frames (incl. the bootloader frame) opened per run   */
+  uint32_t max_far_frames;        /* far-call frames (incl. the bootloader frame) that are live or reachable at one time: a
+                                     frame's arena slot is reused once it has returned and its heap / aux heap is no
+                                     returndata any more (the reference's page pools, memory.rs:660-758)              */
   uint32_t max_callstack_depth;   /* near + far frames alive at once                                */
   uint32_t stack_words;           /* words per stack page   (reference: 65536, memory.rs:177-179)  */
   uint32_t heap_words;            /* words per heap page    (reference: grows on demand)            */
@@ -438,6 +443,11 @@ int zkw_batch_set_state(zkw_batch* batch, uint32_t first, uint32_t count, const 
                         const zkw_callstack_entry* inner, uint32_t inner_depth);
 /* heap of the current (bootloader) frame (memory.rs:287-291 populate_heap) */
 int zkw_batch_set_heap(zkw_batch* batch, uint32_t instance, const zkw_u256* words, uint32_t n_words);
+/* SimpleMemory::polulate_bootloaders_calldata (memory.rs:293-298): the content of BOOTLOADER_CALLDATA_PAGE
+ * (consts.bootloader_calldata_page).  The crate registers no indirection for that page (memory.rs:229-233, 257-261: only
+ * page 0 gets one), so the VM itself cannot read it — the words come back through zkw_batch_get_page, as they do through
+ * `dump_page_content` in the reference. */
+int zkw_batch_set_bootloader_calldata(zkw_batch* batch, uint32_t instance, const zkw_u256* words, uint32_t n_words);
 /* storage snapshot (testing/storage.rs:25-31) */
 int zkw_batch_set_storage(zkw_batch* batch, uint32_t instance, const zkw_storage_slot* slots, uint32_t n_slots);
 int zkw_batch_set_block_properties(zkw_batch* batch, const zkw_block_properties* props);
@@ -476,6 +486,15 @@ int zkw_batch_kernel_time(zkw_batch* batch, double* mean_ms, uint32_t* n_launche
 int zkw_batch_sync(zkw_batch* batch);
 int zkw_batch_get_stats(zkw_batch* batch, zkw_run_stats* out);
 int zkw_batch_get_instance_trace(zkw_batch* batch, uint32_t instance, zkw_instance_trace* out);
+/* SimpleMemory::dump_page_content_as_u256_words (memory.rs:316-396) on `vm.memory` after the run (VmState.memory is a
+ * public field, vm_state/mod.rs:170): words [first_word, first_word + n_words) of `page` of one instance, in the
+ * reference's lookup order — code pages (populated ones and those decommitted by the run), pages with extended lifetime
+ * (the bootloader calldata page; heap / aux heap pages that were returned as returndata), the stack pages and the heap /
+ * aux heap pages of the frames that are live; anything else, and every word a page was never grown to, reads as zero.
+ * A stack word comes back as its value (the pointer tag is dropped, :347).  One limit of the device's arena: a returndata
+ * page whose receiver has returned as well (the reference never frees those) stays readable only until its arena slot is
+ * reused, i.e. while the run has opened no more than limits.max_far_frames far frames.  Synchronises the batch. */
+int zkw_batch_get_page(zkw_batch* batch, uint32_t instance, uint32_t page, uint32_t first_word, uint32_t n_words, zkw_u256* out);
 
 /* --- queue commitments (the build's own sponge spec) --- */
 #define ZKW_QUEUE_MEMORY 0

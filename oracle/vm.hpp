@@ -417,6 +417,38 @@ struct SimpleMemory {
   }
   // :287-291
   void populate_heap(const std::vector<U256>& values) { heaps.back().heap = values; }
+  // BOOTLOADER_CALLDATA_PAGE lives in `pages_with_extended_lifetime` from the start (:229-231, 257-259; the constant is an
+  // ISA-table input here) and polulate_bootloaders_calldata replaces its content (:293-298).  No indirection is
+  // registered for it (:233, 261 insert page 0 only): the VM cannot read it, `dump_page_content` can.
+  void register_bootloader_calldata_page(uint32_t page) { pages_with_extended_lifetime[page]; }
+  void polulate_bootloaders_calldata(uint32_t page, const std::vector<U256>& values) {
+    REF_ASSERT(pages_with_extended_lifetime.find(page) != pages_with_extended_lifetime.end(), "bootloader calldata page missing");  // :296 unwrap
+    pages_with_extended_lifetime[page] = values;
+  }
+  // dump_page_content_as_u256_words (:316-396): code pages, pages with extended lifetime, live stack pages (values only),
+  // live heaps — in that order; anything else reads as zero
+  std::vector<U256> dump_page_content_as_u256_words(uint32_t page_number, uint32_t first, uint32_t n) const {
+    std::vector<U256> result(n, U256::zero());
+    auto take = [&](const std::vector<U256>& content) {
+      for (uint32_t k = 0; k < n; k++) result[k] = get_or_zero(content, (size_t)first + k);
+      return result;
+    };
+    auto cp = code_pages.find(page_number);
+    if (cp != code_pages.end()) return take(cp->second);  // :321-332
+    auto ext = pages_with_extended_lifetime.find(page_number);
+    if (ext != pages_with_extended_lifetime.end()) return take(ext->second);  // :334-345
+    for (auto it = stack_pages.rbegin(); it != stack_pages.rend(); ++it) {  // :347-362
+      if (it->first != page_number) continue;
+      for (uint32_t k = 0; k < n; k++)
+        if ((size_t)first + k < it->second.size()) result[k] = it->second[(size_t)first + k].value;
+      return result;
+    }
+    for (auto it = heaps.rbegin(); it != heaps.rend(); ++it) {  // :364-392
+      if (it->heap_page == page_number) return take(it->heap);
+      if (it->aux_page == page_number) return take(it->aux);
+    }
+    return result;  // :395
+  }
 
   static void resize_to_fit(std::vector<U256>& el, size_t idx) {  // :194-200
     if (el.size() >= idx + 1) return;

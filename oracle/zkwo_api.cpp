@@ -30,6 +30,7 @@ struct StagedInstance {
   std::vector<zkw_callstack_entry> inner;
   std::vector<std::pair<uint32_t, uint32_t>> code_pages;  // page -> blob
   std::vector<U256> heap;
+  std::vector<U256> bootloader_calldata;
   std::vector<zkw_storage_slot> storage;
 };
 
@@ -195,6 +196,12 @@ int zkwo_batch_set_heap(zkwo_batch* b, uint32_t instance, const zkw_u256* words,
   if (n_words) std::memcpy(b->staged[instance].heap.data(), words, (size_t)n_words * 32);
   return ZKW_OK;
 }
+int zkwo_batch_set_bootloader_calldata(zkwo_batch* b, uint32_t instance, const zkw_u256* words, uint32_t n_words) {
+  if (instance >= b->n) return ZKW_ERR_INVALID;
+  b->staged[instance].bootloader_calldata.resize(n_words);
+  if (n_words) std::memcpy(b->staged[instance].bootloader_calldata.data(), words, (size_t)n_words * 32);
+  return ZKW_OK;
+}
 int zkwo_batch_set_storage(zkwo_batch* b, uint32_t instance, const zkw_storage_slot* slots, uint32_t n_slots) {
   if (instance >= b->n) return ZKW_ERR_INVALID;
   b->staged[instance].storage.assign(slots, slots + n_slots);
@@ -253,6 +260,8 @@ static void build_vm(zkwo_batch* b, uint32_t i) {
     for (auto& pb : last) vm->memory.populate_code(pb.first, *b->blobs[pb.second]);
   }
   if (!s.heap.empty()) vm->memory.populate_heap(s.heap);
+  vm->memory.register_bootloader_calldata_page(b->ctx->isa.consts.bootloader_calldata_page);
+  if (!s.bootloader_calldata.empty()) vm->memory.polulate_bootloaders_calldata(b->ctx->isa.consts.bootloader_calldata_page, s.bootloader_calldata);
   for (const zkw_storage_slot& sl : s.storage) {
     Address a;
     std::memcpy(a.b, sl.address, 20);
@@ -373,6 +382,15 @@ int zkwo_batch_get_stats(zkwo_batch* b, zkw_run_stats* out) {
     if (r.status >= ZKW_STATUS_UNKNOWN_CODE_HASH) out->instances_failed++;
   }
   out->kernel_ms = b->last_ms;
+  return ZKW_OK;
+}
+
+// `vm.memory.dump_page_content_as_u256_words(page, first..first + n)` after the run (memory.rs:316-396)
+int zkwo_batch_get_page(zkwo_batch* b, uint32_t instance, uint32_t page, uint32_t first_word, uint32_t n_words, zkw_u256* out) {
+  if (!b->ran) return ZKW_ERR_NOT_RUN;
+  if (instance >= b->n || b->vms.size() != b->n || !b->vms[instance]) return ZKW_ERR_INVALID;
+  const std::vector<U256> v = b->vms[instance]->memory.dump_page_content_as_u256_words(page, first_word, n_words);
+  for (uint32_t k = 0; k < n_words; k++) std::memcpy(out[k].l, v[k].l, 32);
   return ZKW_OK;
 }
 

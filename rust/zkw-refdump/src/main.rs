@@ -230,6 +230,7 @@ fn dump_isa(out: &str) -> anyhow::Result<()> {
     c[85] = defs::system_params::EVENT_AUX_BYTE;
     c[86] = defs::system_params::L1_MESSAGE_AUX_BYTE;
     c[87] = defs::system_params::PRECOMPILE_AUX_BYTE;
+    put(c, 92, defs::BOOTLOADER_CALLDATA_PAGE); // memory.rs:11 imports it from the crate root
     put(c, 88, 0); // ecrecover_input_layout: (hash, v, r, s) vs (hash, r, s, v) is settled by the ecrecover fixture itself
     let mut w = Writer::new();
     w.section("isa", &table);

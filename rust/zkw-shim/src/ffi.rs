@@ -48,7 +48,8 @@ pub struct zkw_isa_consts {
     pub l1_message_aux_byte: u8,
     pub precompile_aux_byte: u8,
     pub ecrecover_input_layout: u32,
-    pub reserved: [u32; 7],
+    pub bootloader_calldata_page: u32,
+    pub reserved: [u32; 6],
 }
 
 #[repr(C)]
@@ -294,6 +295,8 @@ extern "C" {
     pub fn zkw_batch_sync(batch: *mut zkw_batch) -> c_int;
     pub fn zkw_batch_get_stats(batch: *mut zkw_batch, out: *mut zkw_run_stats) -> c_int;
     pub fn zkw_batch_get_instance_trace(batch: *mut zkw_batch, instance: u32, out: *mut zkw_instance_trace) -> c_int;
+    pub fn zkw_batch_get_page(batch: *mut zkw_batch, instance: u32, page: u32, first_word: u32, n_words: u32, out: *mut zkw_u256) -> c_int;
+    pub fn zkw_batch_set_bootloader_calldata(batch: *mut zkw_batch, instance: u32, words: *const zkw_u256, n_words: u32) -> c_int;
     pub fn zkw_batch_get_commitments(batch: *mut zkw_batch, out: *mut u64) -> c_int;
     pub fn zkw_comm_get_unique_id(out: *mut zkw_comm_id) -> c_int;
     pub fn zkw_comm_create_rccl(ctx: *mut zkw_ctx, rank: c_int, world: c_int, id: *const zkw_comm_id, out: *mut *mut zkw_comm) -> c_int;

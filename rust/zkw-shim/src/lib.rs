@@ -241,6 +241,7 @@ pub fn isa_from_opcode_defs() -> Box<zkw_isa_table> {
     c.event_aux_byte = defs::system_params::EVENT_AUX_BYTE;
     c.l1_message_aux_byte = defs::system_params::L1_MESSAGE_AUX_BYTE;
     c.precompile_aux_byte = defs::system_params::PRECOMPILE_AUX_BYTE;
+    c.bootloader_calldata_page = defs::BOOTLOADER_CALLDATA_PAGE; // memory.rs:11
     t
 }
 
@@ -335,6 +336,31 @@ impl<'a> Batch<'a> {
     pub fn set_heap(&mut self, instance: u32, words: &[U256]) -> anyhow::Result<()> {
         let c: Vec<zkw_u256> = words.iter().map(u256_to_c).collect();
         self.ctx.check(unsafe { zkw_batch_set_heap(self.raw, instance, c.as_ptr(), c.len() as u32) }, "zkw_batch_set_heap")
+    }
+    /// `SimpleMemory::polulate_bootloaders_calldata` (memory.rs:293-298)
+    pub fn set_bootloader_calldata(&mut self, instance: u32, words: &[U256]) -> anyhow::Result<()> {
+        let c: Vec<zkw_u256> = words.iter().map(u256_to_c).collect();
+        self.ctx.check(unsafe { zkw_batch_set_bootloader_calldata(self.raw, instance, c.as_ptr(), c.len() as u32) }, "zkw_batch_set_bootloader_calldata")
+    }
+    /// `vm.memory.dump_page_content_as_u256_words(page, range)` after the run (memory.rs:316-396; `VmState.memory` is a
+    /// public field, vm_state/mod.rs:170)
+    pub fn dump_page_content_as_u256_words(&self, instance: u32, page_number: u32, range: std::ops::Range<u32>) -> anyhow::Result<Vec<U256>> {
+        let n = range.end.saturating_sub(range.start);
+        let mut raw = vec![zkw_u256::default(); n as usize];
+        self.ctx.check(unsafe { zkw_batch_get_page(self.raw, instance, page_number, range.start, n, raw.as_mut_ptr()) }, "zkw_batch_get_page")?;
+        Ok(raw.iter().map(u256_from_c).collect())
+    }
+    /// `vm.memory.dump_page_content(page, range)` (memory.rs:300-314): big-endian words
+    pub fn dump_page_content(&self, instance: u32, page_number: u32, range: std::ops::Range<u32>) -> anyhow::Result<Vec<[u8; 32]>> {
+        Ok(self
+            .dump_page_content_as_u256_words(instance, page_number, range)?
+            .iter()
+            .map(|w| {
+                let mut b = [0u8; 32];
+                w.to_big_endian(&mut b);
+                b
+            })
+            .collect())
     }
     /// `InMemoryStorage::populate` (testing/storage.rs:26-31)
     pub fn set_storage(&mut self, instance: u32, elements: &[(u8, Address, U256, U256)]) -> anyhow::Result<()> {

@@ -97,7 +97,8 @@ extern "C" int zkw_host_replay_callback_log(const zkw_vm_local_state* initial, c
       return w;
     };
     int rc = 0;
-    while (!vm.execution_has_ended() && (rc = vm.cycle()) == 0) {
+    GenericNoopTracer debug_tracer;  // the caller's loop of cycle.rs:257-260: `vm.cycle(&mut tracer)?`
+    while (!vm.execution_has_ended() && (rc = vm.cycle(debug_tracer)) == 0) {
     }
     *last_rc = rc;
     *n_out = (uint32_t)log.entries.size();
@@ -121,7 +122,8 @@ extern "C" int zkw_host_replay_event_sink(const zkw_vm_local_state* initial, con
     for (uint32_t d = 0; d < initial_depth; d++) ev.start_frame(0);  // push_bootloader_context (helpers.rs:289-316)
     BatchedVmState vm(*initial, inner, *trace, &wt, &ev);
     int rc = 0;
-    while (!vm.execution_has_ended() && (rc = vm.cycle()) == 0) {
+    GenericNoopTracer debug_tracer;  // the caller's loop of cycle.rs:257-260: `vm.cycle(&mut tracer)?`
+    while (!vm.execution_has_ended() && (rc = vm.cycle(debug_tracer)) == 0) {
     }
     std::vector<LogQuery> h;
     std::vector<EventMessage> e, m;
@@ -146,6 +148,19 @@ extern "C" int zkw_host_replay_event_sink(const zkw_vm_local_state* initial, con
     for (uint32_t i = 0; i < e.size() && i < cap_events; i++) put(e[i], &events[i]);
     for (uint32_t i = 0; i < m.size() && i < cap_l1; i++) put(m[i], &l1[i]);
     return rc == -1 || rc == 0 ? 0 : rc;  // -1 = the recorded cycles are exhausted (a run that was stopped while still running)
+  } catch (const std::exception&) {
+    return -1;
+  }
+}
+
+// `vm.memory.dump_page_content(page, begin..end)` through the mirror (zk_evm::SimpleMemory over the C ABI's get_page of
+// whichever library ran the batch): big-endian 32-byte words into `out`.
+extern "C" int zkw_host_dump_page(void* get_page_fn, void* batch, uint32_t instance, uint32_t page, uint32_t begin, uint32_t end, uint8_t* out) {
+  try {
+    SimpleMemory m{(SimpleMemory::get_page_fn)get_page_fn, (zkw_batch*)batch, instance};
+    const auto v = m.dump_page_content(page, begin, end);
+    for (size_t i = 0; i < v.size(); i++) std::memcpy(out + 32 * i, v[i].data(), 32);
+    return 0;
   } catch (const std::exception&) {
     return -1;
   }

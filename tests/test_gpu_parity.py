@@ -528,3 +528,44 @@ def test_reference_ecrecover_vectors_through_the_gpu_precompile(product, isa):
             assert K.u256_to_int(marker["value"]) == 1
             w = K.u256_to_int(word["value"]).to_bytes(32, "big")
             assert w[:12] == bytes(12) and w[12:].hex() == address
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# memory after the run (zkw_batch_get_page = SimpleMemory::dump_page_content_as_u256_words, memory.rs:316-396) and
+# reuse of arena slots (memory.rs:660-758) — the 64-lane counterpart of the cases in tests/test_emu_parity.py
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg,kw", [(2, dict(n_instances=200)), (4, dict(n_instances=130, n_cycles=1024))])
+def test_pages_after_the_run(oracle, product, isa, cfg, kw):
+    from test_emu_parity import compare_pages
+    wl = synth.make(cfg, isa, **kw)
+    wl.bootloader_calldata = synth.Xoshiro(0xCA11DA7A, wl.n_instances).words(5)
+    bo, bp = _run(oracle, wl), _run(product, wl)
+    assert compare_pages(bo, bp, wl, list(range(0, wl.n_instances, 13)) + [wl.n_instances - 1]) > 50
+    page = int(isa.consts["bootloader_calldata_page"])
+    assert np.array_equal(bp.page(7, page, 0, 5), wl.bootloader_calldata[7])
+    bo.destroy()
+    bp.destroy()
+
+
+@pytest.mark.parametrize("lanes", [0, 64, 8])
+def test_arena_slots_are_reused(oracle, product, isa, lanes):
+    """64 sequential far calls under max_far_frames = 4 (two live returndata pages + the bootloader frame: one slot is
+    reused some sixty times), bit-exact, and every page the run touched reads back like the reference's"""
+    from test_emu_parity import compare_pages
+    wl = synth.many_far_calls(isa, n_calls=64, n_instances=150)
+    bo, bp = _run(oracle, wl), _run(product, wl, lanes)
+    for i in range(wl.n_instances):
+        tp = bp.trace(i)
+        assert tp["status"] == K.STATUS_RUNNING and int(np.sum(tp["aux"]["type"] == K.AUX_FRAME_START)) == 65
+        ok, why = K.traces_equal(bo.trace(i), tp)
+        assert ok, "instance %d: %s" % (i, why)
+    assert compare_pages(bo, bp, wl, [0, 63, 64, 149]) > 50
+    bo.destroy()
+    bp.destroy()
+
+
+def test_arena_limit_is_a_status(product, isa):
+    wl = synth.many_far_calls(isa, n_calls=6, plan="KKKKKK", n_instances=70, max_far_frames=4)
+    bp = _run(product, wl)
+    assert all(bp.trace(i)["status"] == K.STATUS_LIMIT for i in range(wl.n_instances))
+    bp.destroy()

@@ -143,3 +143,21 @@ def test_host_event_sink_mirror_flattens_to_the_device_net_state(oracle, emu, re
             assert ns["event_history"].tobytes() == hist[: nh.value].tobytes()
             assert ns["events"].tobytes() == ev[: ne.value].tobytes()
             assert ns["l1_messages"].tobytes() == l1[: nl.value].tobytes()
+
+
+def test_mirror_dumps_pages_through_the_c_abi(oracle, isa):
+    """`vm.memory.dump_page_content(page, range)` of the mirror (zk_evm::SimpleMemory over the library's get_page entry)
+    = the big-endian bytes of the words the C ABI returns (memory.rs:300-314)."""
+    lib = build_replay_lib()
+    wl = synth.make(2, isa, n_instances=3)
+    b = oracle.create_batch(wl)
+    b.reset()
+    b.run(wl.n_cycles)
+    fn = C.cast(getattr(oracle.lib, oracle.prefix + "batch_get_page"), C.c_void_p)
+    page = synth.BOOTLOADER_BASE_PAGE + 2  # the bootloader's heap
+    out = np.zeros((40, 32), dtype=np.uint8)
+    assert lib.zkw_host_dump_page(fn, b.h, C.c_uint32(1), C.c_uint32(page), C.c_uint32(3), C.c_uint32(43), K._ptr(out)) == 0
+    words = b.page(1, page, 3, 40)
+    assert words.any()
+    for k in range(40):
+        assert int.from_bytes(out[k].tobytes(), "big") == K.u256_to_int(words[k])
