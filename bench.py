@@ -353,17 +353,28 @@ def main():
         print(json.dumps(out), flush=True)
 
 
+def kernel_source_hash():
+    """sha256 over the device sources of the cycle kernel: ties a committed PMC measurement to the code it was taken on"""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "era-zk_evm_amd", "csrc")
+    for name in ("zkw_kernels.hip", "zkw_device.h", "zkw_u256.hip.h", "zkw_goldilocks.hip.h", "zkw_precompiles.hip.h", "zkw_secp256k1.hip.h"):
+        h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()
+
+
 def measured_traffic(args, batches_per_launch):
-    """HBM bytes per launch of the cycle kernel from the rocprofv3 PMC passes committed under profiles/
-    (FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM): measured per
-    launch with `fused_batches` batches in it, scaled to this run's batches per launch.  Only valid for the
-    default workload the profile was taken on; null otherwise."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    """HBM bytes per launch of the cycle kernel from the rocprofv3 PMC passes of the last collection (profiles/collect.sh
+    writes profiles/traffic.json: FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md
+    §HBM), per launch with `fused_batches` batches in it, scaled to this run's batches per launch.  Only for the workload
+    the counters were taken on AND only while the kernel sources are the ones they were taken on (`kernel_source_sha256`):
+    null otherwise — the figure cannot silently outlive the kernel."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
     if args.cfg != 2 or args.instances != 4096 or args.cycles != 256 or not os.path.exists(path):
         return None
     j = json.load(open(path))
     per_launch = j.get("hbm_bytes_per_launch")
-    if per_launch is None:
+    if per_launch is None or j.get("kernel_source_sha256") != kernel_source_hash():
         return None
     return per_launch * batches_per_launch / float(j.get("fused_batches", 1))
 
@@ -468,4 +479,7 @@ def cpu_baseline(isa, args, prod=None):
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 2 and sys.argv[1] == "--kernel-source-hash":
+        print(kernel_source_hash())
+    else:
+        main()

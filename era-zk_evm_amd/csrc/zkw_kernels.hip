@@ -781,46 +781,54 @@ ZD zkw_dev_frame_meta* frame_metas(ZKW_KP P, const Shared& sh, const Lane& s) { 
 // MemoryType::FatPointer read (memory.rs:475-521): resolve the page to an arena slot.
 // Page 0 is Indirection::Empty; pages that are no heap / aux page of a live or kept frame of this
 // instance are "unreachable memory" (the reference's expect() at :478-481).
-ZD u256 fat_ptr_read(ZKW_KP P, const Shared& sh, Lane& s, u32 page, u32 idx) {
+struct FatPage {  // a resolved page: which arena, which slot, how far it was ever written
+  u32 slot, hwm;
+  bool found, is_aux, empty;
+};
+ZD FatPage fat_ptr_resolve(ZKW_KP P, const Shared& sh, Lane& s, u32 page) {
   s.lane = zkw_lane_id();  // fresh, short-lived lane index (see struct Lane)
-  if (page == 0) return u256_zero();
-  u32 slot = 0, kind = 0, hwm = 0;
-  bool found = false;
-  {
-    const u32 cur_slot = cfv_slot(sh, s);
-    const u32 rel = page - CF(sh, s, CF_BASE_PAGE);
-    if (rel == 2u || rel == 3u) {  // the current frame's own pages: their marks are in LDS
-      slot = cur_slot;
-      kind = rel;
-      hwm = rel == 3u ? CF(sh, s, CF_AUX_HWM) : cfv_heap_hwm(sh, s);
-      found = true;
-    } else {
-      const uint4* fms = (const uint4*)frame_metas(P, sh, s);
-      const u32 n = CF(sh, s, CF_NEXT_SLOT);
-      for (u32 i = 0; i < n; i++) {
-        const uint4 m = fms[i];  // base page, state | stack mark, heap mark, aux mark
-        const u32 r = page - m.x;
-        if (i == cur_slot || m.x == 0 || m.y == ZKW_SLOT_FREE || (r != 2u && r != 3u)) continue;
-        const u32 state = ZKW_SLOT_STATE(m.y);
-        if (state == ZKW_SLOT_DEAD) continue;                                   // indirection removed (:752-756)
-        if (state == ZKW_SLOT_KEPT && ((m.y >> 16) & 3u) != r) continue;        // the frame's other page went back to the pool
-        slot = i;
-        kind = r;
-        hwm = r == 3u ? m.w : m.z;
-        found = true;
-      }
+  FatPage fp;
+  fp.slot = 0; fp.hwm = 0; fp.found = false; fp.is_aux = false;
+  fp.empty = page == 0;
+  if (fp.empty) return fp;
+  const u32 cur_slot = cfv_slot(sh, s);
+  const u32 rel = page - CF(sh, s, CF_BASE_PAGE);
+  if (rel == 2u || rel == 3u) {  // the current frame's own pages: their marks are in registers / LDS
+    fp.slot = cur_slot;
+    fp.is_aux = rel == 3u;
+    fp.hwm = rel == 3u ? CF(sh, s, CF_AUX_HWM) : cfv_heap_hwm(sh, s);
+    fp.found = true;
+  } else {
+    const uint4* fms = (const uint4*)frame_metas(P, sh, s);
+    const u32 n = CF(sh, s, CF_NEXT_SLOT);
+    for (u32 i = 0; i < n; i++) {
+      const uint4 m = fms[i];  // base page, state | stack mark, heap mark, aux mark
+      const u32 r = page - m.x;
+      if (i == cur_slot || m.x == 0 || m.y == ZKW_SLOT_FREE || (r != 2u && r != 3u)) continue;
+      const u32 state = ZKW_SLOT_STATE(m.y);
+      if (state == ZKW_SLOT_DEAD) continue;                                   // indirection removed (:752-756)
+      if (state == ZKW_SLOT_KEPT && ((m.y >> 16) & 3u) != r) continue;        // the frame's other page went back to the pool
+      fp.slot = i;
+      fp.is_aux = r == 3u;
+      fp.hwm = r == 3u ? m.w : m.z;
+      fp.found = true;
     }
   }
-  if (!found) {
-    lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
-    return u256_zero();
-  }
-  const bool is_aux = kind == 3;
-  const u32 words = is_aux ? sh.A : sh.H;
-  if (idx >= hwm || idx >= words) return u256_zero();  // `.get(index).unwrap_or(zero)` (:490-495)
-  const uint4* base = is_aux ? sh.aux_heap : sh.heap;
-  const u32 w = page_word_index(sh, s, slot, words, idx);
+  if (!fp.found) lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
+  return fp;
+}
+ZD u256 fat_page_read(const Shared& sh, Lane& s, const FatPage& fp, u32 idx) {
+  s.lane = zkw_lane_id();
+  if (fp.empty || !fp.found) return u256_zero();
+  const u32 words = fp.is_aux ? sh.A : sh.H;
+  if (idx >= fp.hwm || idx >= words) return u256_zero();  // `.get(index).unwrap_or(zero)` (:490-495)
+  const uint4* base = fp.is_aux ? sh.aux_heap : sh.heap;
+  const u32 w = page_word_index(sh, s, fp.slot, words, idx);
   return u256_from_uint4(zkw_gload4(base + (2 * w - s.lane)), zkw_gload4(base + (2 * w - s.lane + sh.L)));
+}
+ZD u256 fat_ptr_read(ZKW_KP P, const Shared& sh, Lane& s, u32 page, u32 idx) {
+  const FatPage fp = fat_ptr_resolve(P, sh, s, page);
+  return fat_page_read(sh, s, fp, idx);
 }
 
 // read_code_query (memory.rs:556-569) against the blob backing the current code page
@@ -1969,10 +1977,11 @@ ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, H
 // ---------------------------------------------------------------------------------------------
 // precompiles: see zkw_precompiles.hip.h (keccak256 / sha256 round functions over the lane's memory)
 // ---------------------------------------------------------------------------------------------
-#include "zkw_precompiles.hip.h"
-
 // wave-uniform value that reached a function through a (vector) argument register: back into a scalar register
 ZD u32 zkw_uniform(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
+
+#include "zkw_precompiles.hip.h"
+
 
 // The precompile bodies (Keccak-f state of 50 VGPRs, SHA-256 schedule, secp256k1) are compiled as ONE out-of-line
 // function that takes and returns the lane state by value (the wave's Shared view is rebuilt from the uniform wave

@@ -24,7 +24,24 @@ __device__ const u32 ZKW_SHA256_K[64] = {
     0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
     0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
 
-ZD u64 zk_rotl64(u64 x, int n) { return (x << n) | (x >> (64 - n)); }
+// rotation of a 64-bit lane by a constant: two funnel shifts of its halves (v_alignbit_b32) — left to itself the compiler
+// builds it from 64-bit shifts and an or (four to five instructions, the 64-bit shifts at a fraction of the rate)
+ZD u64 zk_rotl64(u64 x, int n) {
+#ifdef __HIP_DEVICE_COMPILE__
+  u32 lo = (u32)x, hi = (u32)(x >> 32);
+  if (n >= 32) {
+    const u32 t = lo;
+    lo = hi;
+    hi = t;
+    n -= 32;
+  }
+  if (n == 0) return ((u64)hi << 32) | lo;
+  // {a, b} >> s, low word: alignbit(hi, lo, 32 - n) = hi << n | lo >> (32 - n)
+  return ((u64)__builtin_amdgcn_alignbit(hi, lo, (u32)(32 - n)) << 32) | (u64)__builtin_amdgcn_alignbit(lo, hi, (u32)(32 - n));
+#else
+  return (x << n) | (x >> (64 - n));
+#endif
+}
 
 // Keccak-f[1600], state in 25 statically indexed u64
 ZD void zk_keccak_f1600(u64 a[25]) {
@@ -84,6 +101,53 @@ ZD u32 word_be_dword(const u256& w, u32 k) {
 // (the byte misalignment of the input is constant over the message); the rate block is staged as 34 dwords per lane in
 // the wave's row buffer ([dword][lane], one coalesced store per dword) and absorbed with static indices.  Every memory
 // word that holds message bytes is read exactly once, in order, as in the reference.
+// The share of memory word J (of the up to six that a full 136-byte block reaches into: 35 dwords from dword 7 of a word) in the block whose first stream
+// dword sits at dword PHI of word 0: stream dword p = 8 J + k of the word run is block dword p - PHI, and — when the
+// message is not dword-aligned (`sh8` = misalignment in bits, wave-uniform) — its low bits also are the tail of block
+// dword p - 1 - PHI.  The two parts of a funnelled dword occupy disjoint bytes, so each memory dword is XORed into the
+// state on its own (byte-swapped into the little-endian lanes): no word has to wait for its neighbour, one word is live
+// at a time.  PHI and J are template parameters: every index is static, the state stays in registers.
+template <int PHI, int J>
+ZD void keccak_xor_word(u64 st[25], const u256& w, u32 sh8) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const u32 d = w.w[7 - k];
+    const int i = 8 * J + k - PHI;  // block dword that starts in this memory dword
+    if (i >= 0 && i < 34) {
+      const u64 le = (u64)__builtin_bswap32(sh8 ? d << sh8 : d);
+      st[i >> 1] ^= (i & 1) ? le << 32 : le;
+    }
+    if (i - 1 >= 0 && i - 1 < 34 && sh8) {  // (wave-uniform)
+      const u64 le = (u64)__builtin_bswap32(d >> (32u - sh8));
+      st[(i - 1) >> 1] ^= ((i - 1) & 1) ? le << 32 : le;
+    }
+  }
+}
+// the lane's 256-bit LDS transfer slot (ZKW_XFER)
+ZD u256 xfer_load(const Shared& sh, const Lane& s) {
+  u256 v;
+  v.w[0] = ZKW_XFER(sh, s, 0); v.w[1] = ZKW_XFER(sh, s, 1); v.w[2] = ZKW_XFER(sh, s, 2); v.w[3] = ZKW_XFER(sh, s, 3);
+  v.w[4] = ZKW_XFER(sh, s, 4); v.w[5] = ZKW_XFER(sh, s, 5); v.w[6] = ZKW_XFER(sh, s, 6); v.w[7] = ZKW_XFER(sh, s, 7);
+  return v;
+}
+ZD void xfer_store(const Shared& sh, const Lane& s, const u256& v) {
+  ZKW_XFER(sh, s, 0) = v.w[0]; ZKW_XFER(sh, s, 1) = v.w[1]; ZKW_XFER(sh, s, 2) = v.w[2]; ZKW_XFER(sh, s, 3) = v.w[3];
+  ZKW_XFER(sh, s, 4) = v.w[4]; ZKW_XFER(sh, s, 5) = v.w[5]; ZKW_XFER(sh, s, 6) = v.w[6]; ZKW_XFER(sh, s, 7) = v.w[7];
+}
+template <int J>
+ZD void keccak_xor_word_phase(u64 st[25], const u256& w, u32 phase, u32 sh8) {
+  switch (phase) {  // wave-uniform
+    case 0: keccak_xor_word<0, J>(st, w, sh8); break;
+    case 1: keccak_xor_word<1, J>(st, w, sh8); break;
+    case 2: keccak_xor_word<2, J>(st, w, sh8); break;
+    case 3: keccak_xor_word<3, J>(st, w, sh8); break;
+    case 4: keccak_xor_word<4, J>(st, w, sh8); break;
+    case 5: keccak_xor_word<5, J>(st, w, sh8); break;
+    case 6: keccak_xor_word<6, J>(st, w, sh8); break;
+    default: keccak_xor_word<7, J>(st, w, sh8); break;
+  }
+}
+
 ZD void precompile_keccak256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   const u32 in_off = q.key.w[0], in_len = q.key.w[1], out_off = q.key.w[2];
   const u32 page_r = q.key.w[4], page_w = q.key.w[5];
@@ -95,7 +159,55 @@ ZD void precompile_keccak256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   u32 cur_idx = 0xffffffffu, next_idx = 0xffffffffu;  // word indices held in w_cur / w_next
   const u32 n_dwords = (in_len + 3u) >> 2;
   u32 slot = 0;  // dword position inside the rate block
-  for (u32 d = 0; d < n_dwords && lane_ok(s); d++) {
+  u32 d_start = 0;
+  // Full blocks of a wave whose calls share the byte phase of the input inside its memory word and the length — a
+  // shared tape: the walk over the message is then the same for every lane, so its control flow is scalar and a block
+  // is absorbed straight from the (up to five) words that hold it, with static indices.  The general loop below — one
+  // stream dword at a time, word index and dword-in-word per lane, the rate block staged through a row in HBM — costs
+  // four times the permutation it feeds; it keeps the last, partial block and every wave whose lanes differ.
+  {
+    const u32 u_phase = zkw_uniform(in_off & 31u), u_len = zkw_uniform(in_len);
+    if (__ballot((in_off & 31u) != u_phase || in_len != u_len) == 0 && u_len >= ZKW_KECCAK_RATE) {
+      const u32 u_sh8 = (u_phase & 3u) * 8u;
+      const u32 n_full = u_len / ZKW_KECCAK_RATE;
+      const u32 w0 = in_off >> 5;  // per lane
+      const FatPage fpage = fat_ptr_resolve(P, sh, s, page_r);  // the page is resolved once: the call writes nothing before its reads are done
+      u32 have = 0;                // words w0 .. w0 + have - 1 have been read (and witnessed), wave-uniform
+      for (u32 b = 0; b < n_full; b++) {
+        const u32 p0 = (u_phase >> 2) + 34u * b;                    // first stream dword of the block, in dwords from word w0
+        const u32 r0 = p0 >> 3, r1 = (p0 + 33u + (u_sh8 ? 1u : 0u)) >> 3;  // words the block reaches into
+        // (the word a block ends in is parked in the lane's LDS transfer slot across the permutation — 8 dwords fewer to keep
+        // in registers next to the 50 of the state — and taken back when the next block starts inside it)
+        u256 wv = u256_zero();
+#define ZKW_KECCAK_WORD(J)                                                                                       \
+  {                                                                                                              \
+    const u32 r = r0 + (u32)(J); /* wave-uniform */                                                              \
+    if (r <= r1) {                                                                                               \
+      if (r >= have) {                                                                                           \
+        if (lane_ok(s)) {                                                                                        \
+          wv = fat_page_read(sh, s, fpage, w0 + r);                                                              \
+          emit_mem(P, sh, s, q.timestamp, ZKW_MEM_FAT_PTR, page_r, w0 + r, wv, false, false, 1);                 \
+        }                                                                                                        \
+        have = r + 1u;                                                                                           \
+      } else { /* the previous block ended inside this word (only J = 0) */                                      \
+        wv = xfer_load(sh, s);                                                                                   \
+      }                                                                                                          \
+      keccak_xor_word_phase<J>(st, wv, p0 & 7u, u_sh8);                                                          \
+    }                                                                                                            \
+  }
+        ZKW_KECCAK_WORD(0) ZKW_KECCAK_WORD(1) ZKW_KECCAK_WORD(2) ZKW_KECCAK_WORD(3) ZKW_KECCAK_WORD(4) ZKW_KECCAK_WORD(5)
+#undef ZKW_KECCAK_WORD
+        xfer_store(sh, s, wv);
+        zk_keccak_f1600(st);
+      }
+      d_start = 34u * n_full;
+      if (have) {  // the general loop continues behind the last word read
+        w_cur = xfer_load(sh, s);
+        cur_idx = w0 + have - 1u;
+      }
+    }
+  }
+  for (u32 d = d_start; d < n_dwords && lane_ok(s); d++) {
     const u32 need = in_len - 4u * d < 4u ? in_len - 4u * d : 4u;  // message bytes in this stream dword
     const u32 m0 = (in_off >> 2) + d;                               // memory dword holding its first byte
     const bool two = (in_off & 3u) + need > 4u;                     // the dword straddles two memory dwords

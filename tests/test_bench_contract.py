@@ -52,6 +52,44 @@ def test_traffic_file_matches_the_profile_summary():
     assert abs(t["fetch_bytes_corrected_x2"] - 2 * 1024 * t["FETCH_SIZE_KB"]) < 1
 
 
+def test_roofline_traffic_is_tied_to_the_kernel_it_was_measured_on():
+    """bench.py reports `roofline.traffic` from profiles/traffic.json only while the device sources hash to the value the
+    PMC passes were taken on; after any edit of the kernel the line carries null until the collection is repeated."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class A:
+        cfg, instances, cycles = 2, 4096, 256
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    got = bench.measured_traffic(A, 20)
+    if not os.path.exists(path):
+        assert got is None
+        return
+    t = json.load(open(path))
+    assert abs(t["hbm_bytes_per_launch"] - (t["fetch_bytes_corrected_x2"] + t["write_bytes"])) < 1
+    if t["kernel_source_sha256"] == bench.kernel_source_hash():
+        assert abs(got - t["hbm_bytes_per_launch"] * 20 / t["fused_batches"]) < 1
+    else:
+        assert got is None
+
+
+def test_cfg3_line_has_roofline_and_cpu_baseline():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cfg3_line.json")))
+    if not files:
+        import pytest
+        pytest.skip("no cfg-3 line collected yet")
+    j = json.load(open(files[-1]))
+    assert j["unit"] == "message bytes/s" and "configs[3]" in j["metric"]
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "keccak_f_per_s", "sha256_compressions_per_s"):
+        assert k in r, k
+    assert abs(r["achieved"] - 2.5 * r["message_bytes_per_launch"] / (j["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
+    c = j["cpu_baseline"]
+    assert c["unit"] == j["unit"] and c["kind"] == "port" and c["cores"] >= 1
+
+
 def test_rocprof_kernel_duration_agrees_with_the_bench_line():
     """The committed rocprofv3 --kernel-trace --stats summary of a command and the HIP-event duration its bench line
     carries describe the same launches of zkw_cycle_kernel: they must agree (within 5 %).  Checked on the newest line
