@@ -119,7 +119,7 @@ typedef struct zkw_kparams {
   uint32_t reserved3;
   uint32_t n_blobs, n_preimages;
   uint32_t wave_threads; /* hardware wave width (64 on gfx950; 1 in the CPU emulation build of tests/emu) */
-  uint32_t waves_per_group; /* waves per workgroup (ZKW_WAVES_PER_GROUP; 1 in the emulation build) */
+  uint32_t waves_per_group; /* unused: the waves per workgroup are a property of the launch (zkw_launch_args) */
   uint32_t reserved0;
   uint32_t reserved2;
   zkw_isa_consts consts;
@@ -168,8 +168,15 @@ typedef struct zkw_kparams {
 #define ZKW_KP const zkw_kparams ZKW_CONST_AS&
 
 /* by-value arguments of one (possibly fused) launch of the cycle kernel: grid.y = batch */
+#define ZKW_MAX_WAVES_PER_GROUP 8 /* a CU holds 8 waves of the cycle kernel (256 registers: two per SIMD) */
 typedef struct zkw_launch_args {
   const zkw_kparams* kp[ZKW_MAX_FUSED]; /* device copies of the parameter blocks */
+  /* The waves of all batches of the launch are numbered through (batch 0's first): workgroup j runs waves
+   * j * waves_per_group ..., so that the number of waves per workgroup can be chosen for the launch as a whole (1280 waves
+   * = 256 workgroups of 5: one per CU) and not per batch.  wave_base[b] = first wave of batch b, wave_base[n_batches] = all;
+   * uniform_waves != 0: every batch has that many waves (batch = wave / uniform_waves, no search). */
+  uint32_t wave_base[ZKW_MAX_FUSED + 1];
+  uint32_t uniform_waves;
   uint32_t n_batches;
   uint32_t run_cycles;
   uint32_t debug_flags; /* profiling ablations / test hooks only (ZKW_DEBUG_FLAGS): 1 = no CycleRecord stores, 2 = no stream stores, 4 = one lane per group */

@@ -171,7 +171,7 @@ ZD void zkw_lds_write4(uint4* p, const uint4 v) { *p = v; }
 // Phase timing of a VM cycle (profiling build only: -DZKW_PROFILE, profiles/tools/r02_phase.sh): shader clocks between
 // marks, accumulated per workgroup wave in LDS by the first active lane; printed by one workgroup at the end.
 #ifdef ZKW_PROFILE
-__shared__ unsigned long long zp_acc[ZKW_WAVES_PER_GROUP][80];  // 0-3 phases, 8-23 / 24-39 opcode clocks / counts, 40-63 sub-phases
+__shared__ unsigned long long zp_acc[ZKW_MAX_WAVES_PER_GROUP][80];  // 0-3 phases, 8-23 / 24-39 opcode clocks / counts, 40-63 sub-phases
 #define ZKW_SUB_DECL unsigned long long zs_last = __builtin_readcyclecounter();
 #define ZKW_SUB(i)                                                                       \
   {                                                                                      \
@@ -365,7 +365,7 @@ ZD void zkw_gstore1(uint8_t* p, uint8_t v) { *p = v; }
 // in-order counter for loads and stores, it waits for the acknowledgement of every stream store the body has just issued
 // (the cycle kernel spent 54 % of its wave-cycles in s_waitcnt, SQ_WAIT_ANY; the loads account for a third of that).
 #ifdef ZKW_WAITPROF  /* profiling build (profiles/tools/r03_waitprof.sh): clocks a wave spends in each of these waits */
-__shared__ unsigned long long zw_acc[ZKW_WAVES_PER_GROUP][32];  // [site] clocks, [16 + site] count
+__shared__ unsigned long long zw_acc[ZKW_MAX_WAVES_PER_GROUP][32];  // [site] clocks, [16 + site] count
 #endif
 #ifdef __HIP_DEVICE_COMPILE__
 #ifdef ZKW_WAITPROF
@@ -883,9 +883,12 @@ ZD void hwm_writeback(ZKW_KP P, const Shared& sh, const Lane& s) {
   fm->heap_hwm = cfv_heap_hwm(sh, s);
   fm->aux_hwm = CF(sh, s, CF_AUX_HWM);
 }
-// load the hot fields of entry `s.depth` into the lane
-ZD void frame_load(ZKW_KP P, const Shared& sh, Lane& s) {
-  const u32* e = (const u32*)entry_ptr(P, sh, s, s.depth);
+// The hot fields of a callstack entry into the lane.  `e` is the entry image: its row in HBM (a frame the lane returns
+// to) or the 32 dwords start_frame has just built in registers (a frame it enters: no reload of what was stored a moment
+// ago, which would wait for those stores).  `same_slot`: a near-call frame shares the arena slot, the code blob and the
+// page marks of the frame around it — nothing of that is touched.  `fresh_slot`: a far frame that starts now owns empty pages.
+template <class E>
+ZD void frame_apply(ZKW_KP P, const Shared& sh, Lane& s, const E& e, bool same_slot, bool fresh_slot) {
   CF(sh, s, CF_BASE_PAGE) = e[E_BASE_PAGE];
   {
     // previous_code_memory_page := the code page of the cycle that is executing (cycle.rs:49 ran before the opcode), so
@@ -906,15 +909,27 @@ ZD void frame_load(ZKW_KP P, const Shared& sh, Lane& s) {
   cfv_set_heap_bound(sh, s, e[E_HEAP_BOUND]);
   cfv_set_aux_bound(sh, s, e[E_AUX_BOUND]);
   if (e[E_THIS] < 0x10000u && (e[E_THIS + 1] | e[E_THIS + 2] | e[E_THIS + 3] | e[E_THIS + 4]) == 0) s.kflags |= KF_KERNEL;  // execution_stack.rs:83-87
+  if (same_slot) return;
   const u32 new_slot = e[E_SLOT];
   const uint2 bd = P.blob_dir[e[E_CODE_BLOB]];
   CF(sh, s, CF_CODE_OFF) = bd.x;
   CF(sh, s, CF_CODE_LEN) = bd.y;
   cfv_set_slot(sh, s, new_slot);
-  const zkw_dev_frame_meta fm = P.frames[(u64)lane_inst(sh, s) * P.F + new_slot];
-  CF(sh, s, CF_STACK_HWM) = fm.stack_hwm;
-  cfv_set_heap_hwm(sh, s, fm.heap_hwm);
-  CF(sh, s, CF_AUX_HWM) = fm.aux_hwm;
+  if (fresh_slot) {
+    CF(sh, s, CF_STACK_HWM) = 0;
+    cfv_set_heap_hwm(sh, s, 0);
+    CF(sh, s, CF_AUX_HWM) = 0;
+  } else {
+    const zkw_dev_frame_meta fm = P.frames[(u64)lane_inst(sh, s) * P.F + new_slot];
+    CF(sh, s, CF_STACK_HWM) = fm.stack_hwm;
+    cfv_set_heap_hwm(sh, s, fm.heap_hwm);
+    CF(sh, s, CF_AUX_HWM) = fm.aux_hwm;
+  }
+}
+// load the hot fields of entry `s.depth` into the lane
+ZD void frame_load(ZKW_KP P, const Shared& sh, Lane& s, bool same_slot = false) {
+  const u32* e = (const u32*)entry_ptr(P, sh, s, s.depth);
+  frame_apply(P, sh, s, e, same_slot, false);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1131,9 +1146,9 @@ ZD void start_frame(ZKW_KP P, Shared& sh, Lane& s, const u32 prev[32], u32 next[
     cur[i] = make_uint4(prev[4 * i], prev[4 * i + 1], prev[4 * i + 2], prev[4 * i + 3]);
     nxt[i] = make_uint4(next[4 * i], next[4 * i + 1], next[4 * i + 2], next[4 * i + 3]);
   }
-  hwm_writeback(P, sh, s);
+  if (far) hwm_writeback(P, sh, s);  // (a near-call frame keeps the slot and its marks)
   s.depth++;
-  frame_load(P, sh, s);
+  frame_apply(P, sh, s, next, !far, far);
 }
 
 // =============================================================================================
@@ -1931,10 +1946,10 @@ ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, H
     return;
   }
   ZKW_STAMP(62)  // ret: validation, finish_frame
-  hwm_writeback(P, sh, s);
+  if (!local) hwm_writeback(P, sh, s);  // (a near-call frame shares the slot and the marks of the frame it returns to)
   const u32 fin_slot = cfv_slot(sh, s), fin_base = CF(sh, s, CF_BASE_PAGE);
   s.depth--;
-  frame_load(P, sh, s);
+  frame_load(P, sh, s, local);
   to_label = to_label && local;  // :202
   if (!local) {  // memory.finish_global_frame (memory.rs:660-758): see "Arena slots and page lifetimes" above
     zkw_dev_frame_meta* fms = frame_metas(P, sh, s);
@@ -2051,7 +2066,7 @@ ZD zkw_v16 zkw_heavy_body(zkw_v16 a, zkw_v16 b) {
   const zkw_kparams ZKW_CONST_AS* Pp = (const zkw_kparams ZKW_CONST_AS*)(((u64)zkw_uniform(hdr.y) << 32) | zkw_uniform(hdr.x));
   ZKW_KP P = *Pp;
   Shared sh;
-  shared_setup(sh, P, zkw_uniform(hdr.z), wib, blockIdx.x * P.waves_per_group + wib, false);
+  shared_setup(sh, P, zkw_uniform(hdr.z), wib, zkw_uniform(hdr.w), false);
   ZKW_STAMP(48)  // marshalling, call, prologue, parameter block
   Lane s;
   s.lane = zkw_lane_id();
@@ -2123,7 +2138,7 @@ static __device__ __noinline__ zkw_v16 zkw_vec_exec(zkw_v16 a, zkw_v16 b) {
   const zkw_kparams ZKW_CONST_AS* Pp = (const zkw_kparams ZKW_CONST_AS*)(((u64)zkw_uniform(hdr.y) << 32) | zkw_uniform(hdr.x));
   ZKW_KP P = *Pp;
   Shared sh;
-  shared_setup(sh, P, zkw_uniform(hdr.z), wib, blockIdx.x * P.waves_per_group + wib, false);
+  shared_setup(sh, P, zkw_uniform(hdr.z), wib, zkw_uniform(hdr.w), false);
   Lane s;
   s.lane = zkw_lane_id();
   lane_unpack(s, a);
@@ -2452,12 +2467,31 @@ ZD void lane_writeback(ZKW_KP P, Shared& sh, const RegFile& rf, Lane& s, u32 com
 #ifndef ZKW_MIN_WAVES_PER_SIMD
 #define ZKW_MIN_WAVES_PER_SIMD 4
 #endif
-__global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_PER_SIMD) zkw_cycle_kernel(zkw_launch_args A) {
-  ZKW_KP P = *(const zkw_kparams ZKW_CONST_AS*)A.kp[blockIdx.y];
-  // one wave = one independent group of L VM instances; ZKW_WAVES_PER_GROUP waves per workgroup share the ISA table
-  const u32 tid = threadIdx.x % P.wave_threads;
-  const u32 wib = zkw_uniform(threadIdx.x / P.wave_threads);  // a scalar: the per-wave bases below then live in SGPRs
-  const u32 wave = blockIdx.x * P.waves_per_group + wib;
+__global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WAVES_PER_SIMD) zkw_cycle_kernel(zkw_launch_args A) {
+  // one wave = one independent group of L VM instances; the waves of a workgroup share the ISA table.  The waves of the
+  // launch are numbered through all its batches (zkw_launch_args.wave_base): a workgroup may hold waves of two batches.
+  const u32 tid = threadIdx.x % A.wave_threads;
+  const u32 wib = zkw_uniform(threadIdx.x / A.wave_threads);  // a scalar: the per-wave bases below then live in SGPRs
+  const u32 gw = blockIdx.x * A.waves_per_group + wib;         // wave of the launch
+  u32 batch_idx, wave;
+  if (A.uniform_waves) {
+    batch_idx = gw / A.uniform_waves;
+    wave = gw - batch_idx * A.uniform_waves;
+  } else {  // largest b with wave_base[b] <= gw
+    u32 lo = 0, hi = A.n_batches;
+    while (hi - lo > 1) {
+      const u32 mid = (lo + hi) >> 1;
+      if (A.wave_base[mid] <= gw) lo = mid; else hi = mid;
+    }
+    batch_idx = lo;
+    wave = gw - A.wave_base[lo];
+  }
+  const bool beyond = gw >= A.wave_base[A.n_batches];  // tail of the last workgroup
+  if (beyond) {
+    batch_idx = 0;  // (a valid parameter block for the table staging below; the wave leaves after the barrier)
+    wave = 0;
+  }
+  ZKW_KP P = *(const zkw_kparams ZKW_CONST_AS*)A.kp[batch_idx];
   Shared sh;
   shared_setup(sh, P, A.debug_flags, wib, wave, true);
 #ifdef __HIP_DEVICE_COMPILE__
@@ -2472,16 +2506,16 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
     for (u32 i = threadIdx.x; i < ZKW_ISA_TABLE_SIZE / 2; i += blockDim.x) dst[i] = src[i];
   }
 #ifdef ZKW_PROFILE
-  for (u32 i = threadIdx.x; i < ZKW_WAVES_PER_GROUP * 80; i += blockDim.x) (&zp_acc[0][0])[i] = 0;
+  for (u32 i = threadIdx.x; i < ZKW_MAX_WAVES_PER_GROUP * 80; i += blockDim.x) (&zp_acc[0][0])[i] = 0;
 #endif
 #ifdef ZKW_WAITPROF
-  for (u32 i = threadIdx.x; i < ZKW_WAVES_PER_GROUP * 32; i += blockDim.x) (&zw_acc[0][0])[i] = 0;
+  for (u32 i = threadIdx.x; i < ZKW_MAX_WAVES_PER_GROUP * 32; i += blockDim.x) (&zw_acc[0][0])[i] = 0;
 #endif
   __syncthreads();
-  if (wave >= P.n_waves) return;  // tail workgroup: no further workgroup-level barrier below
+  if (beyond || wave >= P.n_waves) return;  // tail workgroup: no further workgroup-level barrier below
   if (tid == 0) {  // what zkw_heavy_entry needs and cannot take through its argument registers
-    const u64 kp = (u64)A.kp[blockIdx.y];
-    zkw_lds[ZKW_ISA_TABLE_SIZE / 2 + wib * zkw_wave_lds_units() + 1] = make_uint4((u32)kp, (u32)(kp >> 32), A.debug_flags, 0);
+    const u64 kp = (u64)A.kp[batch_idx];
+    zkw_lds[ZKW_ISA_TABLE_SIZE / 2 + wib * zkw_wave_lds_units() + 1] = make_uint4((u32)kp, (u32)(kp >> 32), A.debug_flags, wave);
   }
 #ifdef __HIP_DEVICE_COMPILE__
   {  // the wave's stream cursors -> lanes 0..3 of v128 (see stream_alloc); uniform loads
@@ -2539,7 +2573,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
   }
 
 #ifdef ZKW_DEBUG_PRINT
-  if (tid == 0 && wave == 0 && blockIdx.y == 0)
+  if (tid == 0 && gw == 0)
     printf("ZKWDBG exists %d depth %u status %u ergs %u pc %u code_page %u prev %u base %u code_len %u code_off %u kflags %x L %u wave %u wib %u inst %u\n", (int)exists, s.depth, s.status, s.ergs,
            s.pc, CF(sh, s, CF_CODE_PAGE), CF(sh, s, CF_PREV_CODE_PAGE), CF(sh, s, CF_BASE_PAGE), CF(sh, s, CF_CODE_LEN), CF(sh, s, CF_CODE_OFF), s.kflags, sh.L, sh.wave, sh.wib, inst);
 #endif
@@ -2798,7 +2832,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
   }
 #ifdef ZKW_PROFILE
   __syncthreads();
-  if (blockIdx.x == 5 && blockIdx.y == 0 && threadIdx.x == 0) {
+  if (blockIdx.x == 1 && threadIdx.x == 0) {
     printf("ZKWPROF cycles %u: fetch %llu select %llu eoc %llu record %llu\n", k, zp_acc[0][0], zp_acc[0][1], zp_acc[0][2], zp_acc[0][3]);
     for (int o = 0; o < 16; o++)
       if (zp_acc[0][24 + o]) printf("ZKWPROF opcode %d: %llu iterations, %llu clocks each\n", o, zp_acc[0][24 + o], zp_acc[0][8 + o] / zp_acc[0][24 + o]);
@@ -2808,7 +2842,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_WAVES_PER_GROUP, ZKW_MIN_WAVES_
 #endif
 #ifdef ZKW_WAITPROF
   __syncthreads();
-  if (blockIdx.x == 5 && blockIdx.y == 0 && threadIdx.x == 0) {
+  if (blockIdx.x == 1 && threadIdx.x == 0) {
     for (int o = 0; o < 16; o++)
       if (zw_acc[0][16 + o]) printf("ZKWWAIT site %d: %llu waits, %llu clocks in total\n", o, zw_acc[0][16 + o], zw_acc[0][o]);
   }
@@ -3014,6 +3048,6 @@ extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_launch_args* A, hipStrea
       if (dev >= 0 && dev < 64) opted[dev] = lds;
     }
   }
-  hipLaunchKernelGGL(zkw_cycle_kernel, dim3((A->max_waves + g - 1) / g, A->n_batches), dim3(A->wave_threads * g), lds, stream, *A);
+  hipLaunchKernelGGL(zkw_cycle_kernel, dim3((A->wave_base[A->n_batches] + g - 1) / g), dim3(A->wave_threads * g), lds, stream, *A);
   return hipGetLastError();
 }

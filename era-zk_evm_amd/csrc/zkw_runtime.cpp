@@ -239,8 +239,8 @@ int zkw_ctx_set_option(zkw_ctx* c, uint32_t option, uint64_t value) {
     case ZKW_OPT_DEBUG_SYNC: c->opt_debug_sync = value != 0; break;
     case ZKW_OPT_NO_GRAPH: c->opt_no_graph = value != 0; break;
     case ZKW_OPT_WAVES_PER_GROUP:
-      if (value != 0 && value != 1 && value != 2 && value != 4) {
-        c->last_error = "ZKW_OPT_WAVES_PER_GROUP: 0 (default), 1, 2 or 4";
+      if (value > ZKW_MAX_WAVES_PER_GROUP) {
+        c->last_error = "ZKW_OPT_WAVES_PER_GROUP: 0 (chosen per launch) or 1 .. 8";
         return ZKW_ERR_INVALID;
       }
       c->opt_waves_per_group = (uint32_t)value;
@@ -848,8 +848,7 @@ int zkw_batch_upload(zkw_batch* b) {
   P.n_blobs = (uint32_t)b->blobs.size(); P.n_preimages = (uint32_t)b->preimages.size();
   P.consts = c->isa.consts;
   P.wave_threads = (uint32_t)c->wave_width;
-  P.waves_per_group = c->wave_width > 1 ? ZKW_WAVES_PER_GROUP : 1;
-  if (c->wave_width > 1 && c->opt_waves_per_group) P.waves_per_group = c->opt_waves_per_group;  // experiments: 1, 2 or 4
+  P.waves_per_group = 0;  // (chosen per launch: zkw_launch_args.waves_per_group, pick_waves_per_group)
   P.isa = c->d_isa;
   P.krow = b->d_krow.p;
   P.regs = b->d_regs.p; P.scalars = b->d_scalars.p; P.callstack = b->d_callstack.p; P.frames = b->d_frames.p;
@@ -972,6 +971,34 @@ static int enqueue_reset(zkw_batch* const* bs, uint32_t n, hipStream_t st) {
   return ZKW_OK;
 }
 
+// Waves per workgroup of one launch of the cycle kernel.  A CU holds 8 waves of it (256 registers: two per SIMD) and
+// 160 KB of LDS (16 KB of ISA table per workgroup + 14 KB per wave); the waves of all batches of the launch are numbered
+// through, so the choice is free per launch: the fewest rounds of workgroups, then the fewest waves on the busiest CU —
+// the kernel runs at the pace of its busiest CU (its waves queue for the CU's memory path).  The driver's 20 batches are
+// 1280 waves: as workgroups of 4 they were 320 on 256 CUs (64 CUs with 8 waves, 192 with 4); as 256 workgroups of 5
+// every CU has 5.
+static uint32_t pick_waves_per_group(const zkw_ctx* c, uint32_t total_waves) {
+  if (c->wave_width <= 1) return 1;  // emulation build: one thread is one "wave"
+  if (c->opt_waves_per_group) return c->opt_waves_per_group;
+  const uint32_t cus = (uint32_t)c->n_cus;
+  uint32_t best = ZKW_WAVES_PER_GROUP;
+  uint64_t best_key = ~0ull;
+  for (uint32_t g = ZKW_WAVES_PER_GROUP; g <= ZKW_MAX_WAVES_PER_GROUP; g++) {
+    const uint32_t lds = zkw_cycle_kernel_lds_bytes(ZKW_WAVE, g);
+    const uint32_t per_cu = std::max(1u, std::min(ZKW_MAX_WAVES_PER_GROUP / g, (160u * 1024u) / lds));
+    const uint32_t n_wg = (total_waves + g - 1) / g;
+    const uint32_t rounds = (n_wg + cus * per_cu - 1) / (cus * per_cu);
+    const uint32_t wg_last = n_wg - (rounds - 1) * cus * per_cu;
+    const uint32_t busiest = ((wg_last + cus - 1) / cus) * g;
+    const uint64_t key = ((uint64_t)rounds << 32) | ((uint64_t)busiest << 8) | g;  // ties: the smaller workgroup
+    if (key < best_key) {
+      best_key = key;
+      best = g;
+    }
+  }
+  return best;
+}
+
 // `inline_decommit`: the cycle kernel chains the decommit-queue commitment itself (a step that runs and commits in one
 // call has nothing to overlap the commitment kernels with); otherwise zkw_batch_commit computes it from the aux stream
 static int enqueue_run(zkw_batch* const* bs, uint32_t n, uint32_t max_cycles, hipStream_t st, bool inline_decommit = false) {
@@ -998,12 +1025,16 @@ static int enqueue_run(zkw_batch* const* bs, uint32_t n, uint32_t max_cycles, hi
   A.n_batches = n;
   A.run_cycles = max_cycles;
   A.wave_threads = bs[0]->kp.wave_threads;
-  A.waves_per_group = bs[0]->kp.waves_per_group;
+  bool uniform = true;
   for (uint32_t i = 0; i < n; i++) {
     A.kp[i] = bs[i]->d_kp.p;
+    A.wave_base[i + 1] = A.wave_base[i] + bs[i]->n_waves;
+    uniform = uniform && bs[i]->n_waves == bs[0]->n_waves;
     A.max_waves = std::max(A.max_waves, bs[i]->n_waves);
     A.max_L = std::max(A.max_L, bs[i]->L);
   }
+  A.uniform_waves = uniform ? bs[0]->n_waves : 0;
+  A.waves_per_group = pick_waves_per_group(c, A.wave_base[n]);
   A.debug_flags = c->opt_debug_flags;  // profiling ablations / test hooks only
   if (inline_decommit) A.debug_flags |= 16u;
   // HIP events around the launch: on the first batch of the group (its kernel_ms is the launch's duration)

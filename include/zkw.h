@@ -419,7 +419,7 @@ int zkw_ctx_set_isa(zkw_ctx* ctx, const zkw_isa_table* table); /* copies */
 #define ZKW_OPT_NO_INLINE_DECOMMIT 3u  /* 1 = the decommit queue is never chained inside the cycle kernel */
 #define ZKW_OPT_DEBUG_SYNC 5u          /* 1 = synchronise after every cycle-kernel launch (diagnostics) */
 #define ZKW_OPT_NO_GRAPH 6u            /* 1 = zkw_batch_step never captures / replays a hipGraph */
-#define ZKW_OPT_WAVES_PER_GROUP 7u     /* 1, 2 or 4 waves per workgroup of the cycle kernel (batches uploaded afterwards) */
+#define ZKW_OPT_WAVES_PER_GROUP 7u     /* 1 .. 8 waves per workgroup of the cycle kernel instead of the choice made per launch (0) */
 #define ZKW_OPT_LANES_PER_WAVE 8u      /* overrides zkw_limits.lanes_per_wave (batches created afterwards) */
 int zkw_ctx_set_option(zkw_ctx* ctx, uint32_t option, uint64_t value);
 
