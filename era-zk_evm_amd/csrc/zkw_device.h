@@ -168,6 +168,9 @@ typedef struct zkw_kparams {
 #define ZKW_KP const zkw_kparams ZKW_CONST_AS&
 
 /* by-value arguments of one (possibly fused) launch of the cycle kernel: grid.y = batch */
+#define ZKW_DQ_HELPER (1u << 27)     /* zkw_launch_args.debug_flags: decommits are posted to the workgroup's helper wave */
+#define ZKW_NO_DQ_HELPER (1u << 28)  /* ZKW_OPT_DEBUG_FLAGS: never launch helper waves (A/B) */
+#define ZKW_DQ_HELPER_BYTES 1552u    /* LDS per cycle wave: 16 B of counters + a ring of 2 x [3][64] dwords */
 #define ZKW_MAX_WAVES_PER_GROUP 8 /* a CU holds 8 waves of the cycle kernel (256 registers: two per SIMD) */
 typedef struct zkw_launch_args {
   const zkw_kparams* kp[ZKW_MAX_FUSED]; /* device copies of the parameter blocks */
@@ -177,6 +180,8 @@ typedef struct zkw_launch_args {
    * uniform_waves != 0: every batch has that many waves (batch = wave / uniform_waves, no search). */
   uint32_t wave_base[ZKW_MAX_FUSED + 1];
   uint32_t uniform_waves;
+  uint32_t helpers;   /* 1: every workgroup carries one more wave that chains the decommit-queue commitment for its cycle waves
+                         (ZKW_DQ_HELPER in debug_flags; only when the CUs have a wave slot to spare) */
   uint32_t n_batches;
   uint32_t run_cycles;
   uint32_t debug_flags; /* profiling ablations / test hooks only (ZKW_DEBUG_FLAGS): 1 = no CycleRecord stores, 2 = no stream stores, 4 = one lane per group */

@@ -1554,8 +1554,14 @@ ZD void versioned_hash(const u256& h, bool& ok, u32& marker, u32& len_words, u25
 }
 
 // takes back the decommit this cycle chained into the running commitment (the cycle failed behind it: see op_far_call)
+#ifdef __HIP_DEVICE_COMPILE__
+// LDS byte address of this wave's hand-over area to the helper wave (0: no helper in this launch); kept in the first
+// dword of the wave's LDS header, which the device build does not use otherwise (the stream cursors live in v128)
+ZD u32 dq_helper_area(const Shared& sh) { return *ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor); }
+#endif
 ZD void dq_undo(ZKW_KP P, const Shared& sh, Lane& s) {
   if (!(s.kflags & KF_DQ_CHAINED)) return;
+  if (sh.debug_flags & ZKW_DQ_HELPER) return;  // handed to the helper wave only when the cycle completes: nothing to take back
   s.kflags &= ~KF_DQ_CHAINED;
   const u32 inst = lane_inst(sh, s);
   u64* tail_p = P.commit_out + ((u64)inst * ZKW_QUEUE_COUNT + ZKW_QUEUE_DECOMMIT) * 4;
@@ -1754,6 +1760,21 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
       a[2] = u256_hi4(code_hash);
       a[3] = make_uint4(pre, 0, 0, 0);  // preimage index: selects the cached sponge midstate of this code hash (zkw_commit.hip)
     }
+#ifdef __HIP_DEVICE_COMPILE__
+    if (a && P.commit_out && (sh.debug_flags & 16u) && (sh.debug_flags & ZKW_DQ_HELPER)) {
+      // The workgroup has a helper wave (zkw_dq_helper): the decommit is handed over through LDS instead of being
+      // chained here, where its permutation (~80k clocks for a lone wave) sits on this wave's critical path.  The record
+      // goes into the slot the wave posts next; it becomes valid at the end of the cycle, if the cycle completes.
+      const u32 area = dq_helper_area(sh);
+      u32 posted = *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)area);
+      while (posted - *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(area + 4u)) >= 2u) __builtin_amdgcn_s_sleep(8);  // both slots still with the helper
+      const u32 row = area + 16u + (posted & 1u) * 768u + zkw_lane_id() * 4u;
+      *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)row) = pre | ((fresh ? 1u : 0u) << 30);  // (bit 31 = valid: set at the end of the cycle)
+      *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(row + 256u)) = s.timestamp + 1;
+      *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(row + 512u)) = page;
+      s.kflags |= KF_DQ_CHAINED;
+    } else
+#endif
     if (a && P.commit_out && (sh.debug_flags & 16u)) {  // requested per launch (zkw_batches_step with the decommit queue in its mask)
       // decommit-queue commitment, chained here (zkw_commit.hip spec: leaf = sponge(code hash | length | blob digest),
       // cached per preimage at upload; tail' = P(leaf | tail | index | queue | timestamp, fresh | page)): one permutation
@@ -2463,6 +2484,76 @@ ZD void lane_writeback(ZKW_KP P, Shared& sh, const RegFile& rf, Lane& s, u32 com
   }
 }
 
+#ifdef __HIP_DEVICE_COMPILE__
+// The helper wave of a workgroup (zkw_launch_args.helpers): chains the decommit-queue commitment for the cycle waves of
+// its workgroup.  A far call that decommits posts (preimage, timestamp | fresh, page) per lane into a two-slot ring in
+// LDS (op_far_call, end of cycle); this wave takes the slots in order — lane l serves lane l of the posting wave: one
+// permutation per record, exactly the step the far call would have run itself (gl_chain_step on the instance's running
+// tail) — and leaves when every cycle wave has said it is done and every slot is consumed.  The permutation is ~80k
+// clocks for a lone wave, twice per 256 cycles of cfg 2: off the critical path of the cycle waves when a CU has a wave
+// slot to spare (the driver's 1280 waves = 5 per CU), which is the only case the runtime launches helpers for.
+ZD void zkw_dq_helper(const zkw_launch_args& A, u32 tid) {
+  const u32 g = A.waves_per_group;
+  const u32 area0 = (u32)(size_t)(ZKW_LDS_AS uint4*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + g * zkw_wave_lds_units());
+  u32 consumed[ZKW_MAX_WAVES_PER_GROUP];
+#pragma unroll
+  for (int h = 0; h < ZKW_MAX_WAVES_PER_GROUP; h++) consumed[h] = 0;
+  for (;;) {
+    bool all_done = true;
+#pragma unroll
+    for (int h = 0; h < ZKW_MAX_WAVES_PER_GROUP; h++) {
+      if ((u32)h >= g) continue;
+      const u32 gw = blockIdx.x * g + (u32)h;
+      if (gw >= A.wave_base[A.n_batches]) continue;  // no such wave
+      u32 b, wave;
+      if (A.uniform_waves) {
+        b = gw / A.uniform_waves;
+        wave = gw - b * A.uniform_waves;
+      } else {
+        u32 lo = 0, hi = A.n_batches;
+        while (hi - lo > 1) {
+          const u32 mid = (lo + hi) >> 1;
+          if (A.wave_base[mid] <= gw) lo = mid; else hi = mid;
+        }
+        b = lo;
+        wave = gw - A.wave_base[lo];
+      }
+      ZKW_KP P = *(const zkw_kparams ZKW_CONST_AS*)A.kp[b];
+      if (wave >= P.n_waves) continue;
+      const u32 area = area0 + (u32)h * ZKW_DQ_HELPER_BYTES;
+      const u32 posted = *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)area);
+      if (consumed[h] == posted) {
+        if (!*ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(area + 8u))) all_done = false;  // still cycling
+        else if (*ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)area) != posted) all_done = false;  // posted between the two reads
+        continue;
+      }
+      all_done = false;
+      const u32 row = area + 16u + (consumed[h] & 1u) * 768u + tid * 4u;
+      const u32 w0 = *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)row);
+      const u32 ts = *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(row + 256u));
+      const u32 page = *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(row + 512u));
+      const u32 inst = wave * P.L + tid;
+      if ((w0 >> 31) && tid < P.L && inst < P.n_instances) {
+        const u32 pre = w0 & 0x3fffffffu, fresh = (w0 >> 30) & 1u;
+        u64* tail_p = P.commit_out + ((u64)inst * ZKW_QUEUE_COUNT + ZKW_QUEUE_DECOMMIT) * 4;
+        const u32 j = P.dq_count[inst];
+        const u64* ms = P.midstates + (u64)pre * 12;
+        const u64 leaf[4] = {ms[0], ms[1], ms[2], ms[3]};
+        u64 tail[4] = {tail_p[0], tail_p[1], tail_p[2], tail_p[3]};
+        gl_chain_step(P.commit_rc, leaf, tail, (u64)j + 1, ZKW_QUEUE_DECOMMIT, (u64)ts | ((u64)fresh << 32), (u64)page);
+        tail_p[0] = tail[0]; tail_p[1] = tail[1]; tail_p[2] = tail[2]; tail_p[3] = tail[3];
+        P.dq_count[inst] = j + 1;
+      }
+      *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)row) = 0;  // the entry is empty again (a lane that has left its loop never rewrites it)
+      consumed[h]++;
+      if (tid == 0) *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(area + 4u)) = consumed[h];  // the slot is free
+    }
+    if (all_done) break;
+    __builtin_amdgcn_s_sleep(32);
+  }
+}
+#endif
+
 // compiled for 128 vector registers (v0..v127); v128..v255 hold the register file (see RegFile): 256 in all = two waves per SIMD
 #ifndef ZKW_MIN_WAVES_PER_SIMD
 #define ZKW_MIN_WAVES_PER_SIMD 4
@@ -2486,7 +2577,8 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
     batch_idx = lo;
     wave = gw - A.wave_base[lo];
   }
-  const bool beyond = gw >= A.wave_base[A.n_batches];  // tail of the last workgroup
+  const bool is_helper = A.helpers && wib == A.waves_per_group;  // the extra wave of the workgroup (zkw_dq_helper)
+  const bool beyond = is_helper || gw >= A.wave_base[A.n_batches];  // tail of the last workgroup
   if (beyond) {
     batch_idx = 0;  // (a valid parameter block for the table staging below; the wave leaves after the barrier)
     wave = 0;
@@ -2511,11 +2603,27 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
 #ifdef ZKW_WAITPROF
   for (u32 i = threadIdx.x; i < ZKW_MAX_WAVES_PER_GROUP * 32; i += blockDim.x) (&zw_acc[0][0])[i] = 0;
 #endif
+#ifdef __HIP_DEVICE_COMPILE__
+  if (is_helper) {  // counters and entries of every hand-over area start empty (before the barrier: the cycle waves post after it)
+    u32* area = (u32*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + A.waves_per_group * zkw_wave_lds_units());
+    for (u32 i = tid; i < A.waves_per_group * (ZKW_DQ_HELPER_BYTES / 4u); i += A.wave_threads) area[i] = 0;
+  }
+#endif
   __syncthreads();
+#ifdef __HIP_DEVICE_COMPILE__
+  if (is_helper) {
+    zkw_dq_helper(A, tid);
+    return;
+  }
+#endif
   if (beyond || wave >= P.n_waves) return;  // tail workgroup: no further workgroup-level barrier below
   if (tid == 0) {  // what zkw_heavy_entry needs and cannot take through its argument registers
     const u64 kp = (u64)A.kp[batch_idx];
     zkw_lds[ZKW_ISA_TABLE_SIZE / 2 + wib * zkw_wave_lds_units() + 1] = make_uint4((u32)kp, (u32)(kp >> 32), A.debug_flags, wave);
+#ifdef __HIP_DEVICE_COMPILE__
+    const u32 area0 = (u32)(size_t)(ZKW_LDS_AS uint4*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + A.waves_per_group * zkw_wave_lds_units());
+    *ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor) = A.helpers ? area0 + wib * ZKW_DQ_HELPER_BYTES : 0u;  // dq_helper_area
+#endif
   }
 #ifdef __HIP_DEVICE_COMPILE__
   {  // the wave's stream cursors -> lanes 0..3 of v128 (see stream_alloc); uniform loads
@@ -2820,6 +2928,20 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
         }
       }
       ZKW_PROF(3)  // CycleRecord: delta ranks, delta + tail stores
+#ifdef __HIP_DEVICE_COMPILE__
+      if ((A.debug_flags & ZKW_DQ_HELPER) && __ballot((s.kflags & KF_DQ_CHAINED) != 0)) {  // (wave-uniform; rare: a far call with a decommit)
+        // hand this cycle's decommits to the helper wave: every lane still in the loop marks its entry of the slot valid
+        // (its cycle completed with a decommit) or empty, then the slot is posted — a wave's LDS operations complete in
+        // order, so the helper that sees the new count sees the entries
+        const u32 area = dq_helper_area(sh);
+        const u32 posted = *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)area);
+        const u32 row = area + 16u + (posted & 1u) * 768u + zkw_lane_id() * 4u;
+        const bool valid = (s.kflags & KF_DQ_CHAINED) && lane_ok(s);
+        const u32 w0 = *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)row);
+        *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)row) = valid ? (w0 | 0x80000000u) : 0u;
+        if (zkw_rank_below(__ballot(1)) == 0) *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)area) = posted + 1u;
+      }
+#endif
       k++;
       dir_ptr += 4;
       // leave: failed / out of cycles / execution_has_ended() (mod.rs:96-98: callers stop cycling at depth 0)
@@ -2846,6 +2968,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
     for (int o = 0; o < 16; o++)
       if (zw_acc[0][16 + o]) printf("ZKWWAIT site %d: %llu waits, %llu clocks in total\n", o, zw_acc[0][16 + o], zw_acc[0][o]);
   }
+#endif
+#ifdef __HIP_DEVICE_COMPILE__
+  if ((A.debug_flags & ZKW_DQ_HELPER) && tid == 0) *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(dq_helper_area(sh) + 8u)) = 1u;  // every lane has left the loop: nothing more will be posted
 #endif
   // wave-cycles executed = the maximum over the lanes (lanes leave the loop at different iterations)
 #pragma unroll
@@ -3031,7 +3156,7 @@ extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_gr
 // host-callable launcher (keeps <<<>>> out of the runtime)
 extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_launch_args* A, hipStream_t stream) {
   const u32 g = A->waves_per_group;
-  const uint32_t lds = zkw_cycle_kernel_lds_bytes(A->max_L, g);
+  const uint32_t lds = zkw_cycle_kernel_lds_bytes(A->max_L, g) + (A->helpers ? g * ZKW_DQ_HELPER_BYTES : 0u);
   if (lds > 64u * 1024u) {
     // dynamic LDS above the 64 KB default needs an explicit opt-in (not reached by the current layout: 41 KB per workgroup).  The
     // attribute is per device: remember the opted-in size per device, under a lock (contexts on several devices and
@@ -3048,6 +3173,6 @@ extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_launch_args* A, hipStrea
       if (dev >= 0 && dev < 64) opted[dev] = lds;
     }
   }
-  hipLaunchKernelGGL(zkw_cycle_kernel, dim3((A->wave_base[A->n_batches] + g - 1) / g), dim3(A->wave_threads * g), lds, stream, *A);
+  hipLaunchKernelGGL(zkw_cycle_kernel, dim3((A->wave_base[A->n_batches] + g - 1) / g), dim3(A->wave_threads * (g + (A->helpers ? 1u : 0u))), lds, stream, *A);
   return hipGetLastError();
 }

@@ -1037,6 +1037,17 @@ static int enqueue_run(zkw_batch* const* bs, uint32_t n, uint32_t max_cycles, hi
   A.waves_per_group = pick_waves_per_group(c, A.wave_base[n]);
   A.debug_flags = c->opt_debug_flags;  // profiling ablations / test hooks only
   if (inline_decommit) A.debug_flags |= 16u;
+  {
+    // A helper wave per workgroup takes the decommit chain off the cycle waves (zkw_dq_helper) when the CUs have a wave
+    // slot to spare: one more wave per workgroup must not cost a round of workgroups (8 waves of this kernel per CU)
+    const uint32_t g = A.waves_per_group, n_wg = (A.wave_base[n] + g - 1) / g;
+    const uint32_t lds = zkw_cycle_kernel_lds_bytes(ZKW_WAVE, g) + g * ZKW_DQ_HELPER_BYTES;
+    const uint32_t per_cu = g + 1 <= ZKW_MAX_WAVES_PER_GROUP ? std::min(ZKW_MAX_WAVES_PER_GROUP / (g + 1), (160u * 1024u) / lds) : 0u;
+    if (inline_decommit && c->wave_width > 1 && !(c->opt_debug_flags & ZKW_NO_DQ_HELPER) && per_cu && n_wg <= (uint32_t)c->n_cus * per_cu) {
+      A.helpers = 1;
+      A.debug_flags |= ZKW_DQ_HELPER;
+    }
+  }
   // HIP events around the launch: on the first batch of the group (its kernel_ms is the launch's duration)
   zkw_batch* lead = bs[0];
   const uint32_t slot = lead->pending_runs % zkw_batch::EV_RING;
