@@ -280,8 +280,9 @@ def main():
         heap_words = hw / max(1, cy)
         n_delta = float(st["reg_deltas"]) / max(1, cycles_per_step)
         # bytes the kernel has to move per VM cycle: code word + record tail + register deltas + queries + heap words
-        # (the 512-B snapshot of SURVEY §8d is stored losslessly as 32-B tail + 32 B per written register)
-        b_cycle = 8 + 32 + 32 * n_delta + 48 * n_mem + 128 * n_log + 32 * heap_words
+        # (the 512-B snapshot of SURVEY §8d is stored losslessly as a 16-B tail + 32 B per written register / per change of
+        # the tail's slow half (memory bounds, depth): `n_delta` counts both; timestamp and previous_super_pc are derived)
+        b_cycle = 8 + 16 + 32 * n_delta + 48 * n_mem + 128 * n_log + 32 * heap_words
         b_cycle_snapshot = 8 + 512 + 48 * n_mem + 128 * n_log + 32 * heap_words
         # mean duration of one cycle-kernel launch (HIP events on its stream) and the cycles that launch processed
         k_ms = sum(k_ms_list) / len(k_ms_list)

@@ -58,7 +58,7 @@ typedef struct zkw_netstate_params {
   uint32_t mark_cap;              /* frame-mark capacity per instance */
   uint32_t storage_aux_byte, event_aux_byte, l1_aux_byte;
   uint32_t reserved0;
-  const uint4* tails;             /* [n_waves][max_cycles][2][L] record tails: the per-cycle event counts */
+  const uint4* tails;             /* [n_waves][max_cycles][L] record tails: the per-cycle event counts (.w, low 24 bits) */
   const uint4* log_stream;
   const uint4* aux_stream;
   const zkw_dev_scalars* scalars;   /* status, n_cycles */

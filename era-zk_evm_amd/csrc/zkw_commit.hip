@@ -293,7 +293,7 @@ __global__ void zkw_netstate_kernel(zkw_fused_table T) {
   const uint4* lbase = N.log_stream + (u64)wave * N.cap_log * 8;
   const uint4* abase = N.aux_stream + (u64)wave * N.cap_aux * 16;
   for (u32 c = 0; c < n_cyc && !flags; c++) {
-    const u32 cnt = N.tails[(((u64)wave * N.max_cycles + c) * 2 + 1) * N.L + lane].w;
+    const u32 cnt = N.tails[((u64)wave * N.max_cycles + c) * N.L + lane].w;
     u32 nl = (cnt >> 8) & 0xffu, na = (cnt >> 16) & 0xffu;
     while ((nl || na) && !flags) {
       // next record of this cycle by in-cycle sequence number (SURVEY Appendix A order)

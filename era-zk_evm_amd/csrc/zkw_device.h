@@ -143,8 +143,8 @@ typedef struct zkw_kparams {
   const uint2* blob_dir;       /* [n_blobs] (first word, n_words)        */
   const zkw_dev_preimage* preimages; /* [n_preimages]                    */
   /* outputs */
-  uint4* tails;                /* [n_waves][max_cycles][2][L]: the 32-B record tail of every executed cycle (+ dirty-register mask) */
-  uint4* deltas;               /* [n_waves][2][cap_delta]: 32-B values of the registers a cycle wrote, dense per wave, as two planes (low / high 16 B) */
+  uint4* tails;                /* [n_waves][max_cycles][L]: 16 B per executed cycle: pointer bitmap, flags, pc, sp, ergs, event counts + the 16-bit delta mask */
+  uint4* deltas;               /* [n_waves][2][cap_delta]: 32-B values of the registers a cycle wrote (mask bits 0..14) and of the tail's slow half (bit 15: heap bound, aux bound, depth), dense per wave, as two planes (low / high 16 B) */
   uint32_t* wave_cycles;       /* [n_waves] wave-cycles run since the reset */
   uint32_t* heap_dirty;        /* [n_waves][ceil(heap_image_words / 32)][L]: words of the heap image overwritten since the reset */
   const uint4* regs0;          /* pristine register files / scalars: what a wave starts from in its first launch after a  */

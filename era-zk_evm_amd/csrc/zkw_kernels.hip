@@ -59,6 +59,7 @@ struct Lane {
 #define KF_CHARGED 32u     /* this cycle's price is taken and its exceptions / condition are resolved (group loop) */
 #define KF_MASKED 64u      /* the instruction of this cycle is the one in sh.enc (pending exception, masked into nop / panic), not the slot of the code word */
 #define KF_CODE_PAGE_CHANGED 16u /* previous_code_memory_page != callstack.current.code_page (cycle.rs:49,59) */
+#define KF_TAIL2 256u     /* heap bound / aux-heap bound / callstack depth changed since the last record that carried them (CycleRecord, delta form) */
 #define KF_DQ_CHAINED 128u /* this cycle chained a decommit into the running commitment (op_far_call): undone if the cycle fails afterwards */
 // The rest of the per-lane state lives in LDS, [field][lane] (conflict-free dword accesses); CF(sh, s, field) is an
 // lvalue.  Rare opcodes touch the first block, memory operands / frame changes the second.
@@ -889,6 +890,7 @@ ZD void hwm_writeback(ZKW_KP P, const Shared& sh, const Lane& s) {
 // page marks of the frame around it — nothing of that is touched.  `fresh_slot`: a far frame that starts now owns empty pages.
 template <class E>
 ZD void frame_apply(ZKW_KP P, const Shared& sh, Lane& s, const E& e, bool same_slot, bool fresh_slot) {
+  s.kflags |= KF_TAIL2;  // depth and memory bounds are those of another frame
   CF(sh, s, CF_BASE_PAGE) = e[E_BASE_PAGE];
   {
     // previous_code_memory_page := the code page of the cycle that is executing (cycle.rs:49 ran before the opcode), so
@@ -1360,6 +1362,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
     if (incremented >= bound) {
       growth = incremented - bound;
       if (is_heap) cfv_set_heap_bound(sh, s, incremented); else cfv_set_aux_bound(sh, s, incremented);
+      s.kflags |= KF_TAIL2;
     }
   }
   u32 cost = growth * sh.growth_per_byte;  // :196-197
@@ -2687,9 +2690,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
 #endif
   // running output pointers of this wave (advanced once per cycle instead of re-derived from the parameter block)
   u32* dir_ptr = P.dir + ((u64)wave * (P.max_cycles + 1) + cycle_base) * 4;
-  uint4* const tails_wave = P.tails + ((u64)wave * P.max_cycles + cycle_base) * 2 * sh.L;  // wave-uniform
+  uint4* const tails_wave = P.tails + ((u64)wave * P.max_cycles + cycle_base) * sh.L;  // wave-uniform
   uint4* const delta_base = P.deltas + (u64)wave * P.cap_delta * 2;
-  const u32 tail_step = 2 * sh.L;
+  const u32 tail_step = sh.L;
   // The cycle loop is entered once by the lanes that are running and left per lane (divergent exit) when the lane ends,
   // fails or has used its cycles: the lane state is then modified unconditionally inside the loop body instead of inside
   // an `if (active)` region of every iteration (whose merge points cost ~75 register copies per VM cycle).
@@ -2871,7 +2874,11 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
         ZKW_PROF(2)  // end-of-cycle bookkeeping
         s.lane = zkw_lane_id();
         const bool ok = lane_ok(s);
-        const u32 dm = ok ? s.reg_dirty : 0u;
+        // (bit 15 of the mask: the "register" that carries heap bound, aux-heap bound and callstack depth — the half of the
+        // record tail that changes a few times per hundred cycles travels as a delta like a register, 32 B when it changes
+        // instead of 16 B in every tail; timestamp and previous_super_pc are not stored at all: the one advances by a
+        // constant per cycle, the other is the pc the cycle started from — the host rebuilds both, zkw_runtime.cpp)
+        const u32 dm = ok ? (s.reg_dirty | ((s.kflags & KF_TAIL2) ? 0x8000u : 0u)) : 0u;
         // union of the lanes' dirty masks and the number of deltas of this wave-cycle; a shared tape makes all masks equal
         const u32 dm0 = (u32)__builtin_amdgcn_readfirstlane((int)dm);
         u32 any, total;
@@ -2882,7 +2889,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
           any = 0;
           total = 0;
 #pragma unroll
-          for (u32 r = 0; r < ZKW_REGISTERS_COUNT; r++) {
+          for (u32 r = 0; r < ZKW_REGISTERS_COUNT + 1; r++) {
             const u32 c = (u32)__popcll(__ballot((dm >> r) & 1u));
             total += c;
             any |= c ? 1u << r : 0u;
@@ -2899,7 +2906,13 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
             const bool has = (dm >> r) & 1u;
             const u64 part = __ballot(has);
             if (has) {
-              const u256 v = rf_get(rf, r + 1u);
+              u256 v;
+              if (r == ZKW_REGISTERS_COUNT) {  // (wave-uniform)
+                v = u256_zero();
+                v.w[0] = cfv_heap_bound(sh, s); v.w[1] = cfv_aux_bound(sh, s); v.w[2] = s.depth;
+              } else {
+                v = rf_get(rf, r + 1u);
+              }
               const u32 at = pos + zkw_rank_below(part);
               // two planes (low / high 16 bytes) so that each store instruction covers whole 64-byte lines
               zkw_stream_store(dl + (u64)at, u256_lo4(v));
@@ -2912,9 +2925,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
           const u32 cnt = s.counts >> 8;  // memory queries | log queries << 8 | aux events << 16 (saturating bytes)
           // dirty mask: bits 0-7 in the tail's reserved byte, bits 8-14 in the top byte of the event counts
           uint4* const tail_ptr = tails_wave + (u64)k * tail_step + s.lane;
-          zkw_stream_store(tail_ptr, make_uint4((s.ptr_bitmap & 0xffffu) | ((s.flags & 0xfu) << 16) | ((s.reg_dirty & 0xffu) << 24),
-                                                (s.pc & 0xffffu) | (s.sp << 16), s.ergs, s.timestamp));
-          zkw_stream_store(tail_ptr + sh.L, make_uint4(cfv_heap_bound(sh, s), cfv_aux_bound(sh, s), (s.depth & 0xffffu) | (s.prev_super_pc << 16), cnt | ((s.reg_dirty >> 8) << 24)));
+          zkw_stream_store(tail_ptr, make_uint4((s.ptr_bitmap & 0xffffu) | ((s.flags & 0xfu) << 16) | ((dm & 0xffu) << 24),
+                                                (s.pc & 0xffffu) | (s.sp << 16), s.ergs, cnt | ((dm >> 8) << 24)));
+          s.kflags &= ~KF_TAIL2;
         }
         if (fits && total) {
           // `total` is the same for every lane still in the loop (ballots over exactly those lanes); the LDS copy is

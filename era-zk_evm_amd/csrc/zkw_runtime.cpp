@@ -819,7 +819,7 @@ int zkw_batch_upload(zkw_batch* b) {
   HIP_TRY(c, ensure(b->d_stack_ptrs, (size_t)W * F * lim.stack_words * L));
   HIP_TRY(c, ensure(b->d_heap, (size_t)W * F * lim.heap_words * L * 2));
   HIP_TRY(c, ensure(b->d_aux, (size_t)W * F * lim.aux_heap_words * L * 2));
-  HIP_TRY(c, ensure(b->d_tails, (size_t)W * lim.max_cycles * 2 * L));
+  HIP_TRY(c, ensure(b->d_tails, (size_t)W * lim.max_cycles * L));
   HIP_TRY(c, ensure(b->d_deltas, (size_t)W * b->cap_delta * 2));
   HIP_TRY(c, ensure(b->d_wave_cycles, (size_t)W));
   HIP_TRY(c, ensure(b->d_heap_dirty, std::max<size_t>(1, (size_t)W * ((b->heap_image_words + 31) / 32) * L)));
@@ -1221,7 +1221,7 @@ int zkw_batch_download_all(zkw_batch* b, uint64_t* n_bytes, double* ms) {
   size_t total = 0;
   for (uint32_t w = 0; w < W; w++) {
     const uint32_t* cur = &b->h_cursors[(size_t)w * 4];
-    pieces.push_back({b->d_tails.p + (size_t)w * MC * 2 * L, 0, (size_t)max_cyc * 2 * L * 16});
+    pieces.push_back({b->d_tails.p + (size_t)w * MC * L, 0, (size_t)max_cyc * L * 16});
     pieces.push_back({b->d_deltas.p + (size_t)w * b->cap_delta * 2, 0, (size_t)std::min(cur[3], b->cap_delta) * 16});                   // low plane
     pieces.push_back({b->d_deltas.p + (size_t)w * b->cap_delta * 2 + b->cap_delta, 0, (size_t)std::min(cur[3], b->cap_delta) * 16});  // high plane
     for (int pl = 0; pl < 3; pl++)  // three planes
@@ -1315,11 +1315,16 @@ static int build_wave(zkw_batch* b, uint32_t w) {
     const uint32_t used = aux[i].type == ZKW_AUX_FRAME_START ? 240u : aux[i].type == ZKW_AUX_DECOMMIT ? 64u : aux[i].type == ZKW_AUX_COLD_STATE ? 48u : 16u;
     std::memset((uint8_t*)&aux[i] + used, 0, 256 - used);
   }
-  // records: tails [cycle][2][L] + register deltas of the wave; the 512-byte snapshots are rebuilt from the initial
-  // register file by replaying every lane's deltas (positions from the dirty masks, see zkw_cycle_kernel)
-  std::vector<uint4> tails((size_t)max_cycles_lane * 2 * L);
+  // records: tails [cycle][L] (16 B) + the deltas of the wave; the 512-byte snapshots are rebuilt from the initial state
+  // by replaying every lane's deltas (positions from the 16-bit masks in the tails, see zkw_cycle_kernel): bits 0..14 the
+  // registers the cycle wrote, bit 15 the slow half of the tail (heap bound, aux-heap bound, callstack depth).  Two tail
+  // fields are not stored at all: the timestamp advances by time_delta_per_cycle with every completed cycle
+  // (cycle.rs:408-411), and previous_super_pc after a cycle is the super-pc that cycle started from — the pc of the record
+  // before it (cycle.rs:84,113: set on every fetch and on every pending exception, and left alone only when it already
+  // equals it).
+  std::vector<uint4> tails((size_t)max_cycles_lane * L);
   if (max_cycles_lane)
-    HIP_TRY(c, hipMemcpy(tails.data(), b->d_tails.p + (size_t)w * MC * 2 * L, tails.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(tails.data(), b->d_tails.p + (size_t)w * MC * L, tails.size() * sizeof(uint4), hipMemcpyDeviceToHost));
   const uint32_t n_delta = std::min(b->h_cursors[(size_t)w * 4 + 3], b->cap_delta);
   std::vector<uint4> deltas((size_t)n_delta * 2);  // [2][n_delta]: the used extents of the two planes
   if (n_delta) {
@@ -1329,9 +1334,17 @@ static int build_wave(zkw_batch* b, uint32_t w) {
   std::vector<uint4> regs0((size_t)ZKW_REG_CHUNKS * L);
   HIP_TRY(c, hipMemcpy(regs0.data(), b->d_regs0.p + (size_t)w * ZKW_REG_CHUNKS * L, regs0.size() * sizeof(uint4), hipMemcpyDeviceToHost));
   std::vector<std::array<uint4, ZKW_REG_CHUNKS>> cur(L);
+  struct Slow { uint32_t heap_bound, aux_bound, depth, timestamp, pc; };
+  std::vector<Slow> slow(L);
+  const uint32_t time_delta = c->isa.consts.time_delta_per_cycle;
   for (uint32_t l = 0; l < L; l++) {
     wt->records[l].resize(ncyc[l]);
     for (uint32_t ch = 0; ch < ZKW_REG_CHUNKS; ch++) cur[l][ch] = regs0[(size_t)ch * L + l];
+    const uint32_t inst = w * L + l;
+    if (inst < b->n) {
+      const zkw_vm_local_state& st0 = b->staged[inst].state;
+      slow[l] = Slow{st0.current.heap_bound, st0.current.aux_heap_bound, st0.callstack_depth, st0.timestamp, st0.current.pc};
+    }
   }
   {
     std::vector<uint32_t> mask(L), cnt(L);
@@ -1341,19 +1354,24 @@ static int build_wave(zkw_batch* b, uint32_t w) {
       for (uint32_t l = 0; l < L; l++) {
         mask[l] = 0; cnt[l] = 0;
         if (k >= ncyc[l]) continue;
-        const uint4 t0 = tails[((size_t)k * 2) * L + l], t1 = tails[((size_t)k * 2 + 1) * L + l];
-        mask[l] = (t0.x >> 24) | ((t1.w >> 24) << 8);
+        const uint4 t0 = tails[(size_t)k * L + l];
+        mask[l] = (t0.x >> 24) | ((t0.w >> 24) << 8);
         cnt[l] = (uint32_t)__builtin_popcount(mask[l]);
         max_cnt = std::max(max_cnt, cnt[l]);
       }
-      // order inside a wave-cycle: by register (ascending), lanes in lane order within a register (zkw_cycle_kernel)
+      // order inside a wave-cycle: by mask bit (ascending), lanes in lane order within a bit (zkw_cycle_kernel)
       uint32_t pos = base;
-      for (uint32_t r = 0; r < ZKW_REGISTERS_COUNT && max_cnt; r++) {
+      for (uint32_t r = 0; r < ZKW_REGISTERS_COUNT + 1 && max_cnt; r++) {
         for (uint32_t l = 0; l < L; l++) {
           if (!((mask[l] >> r) & 1u)) continue;
           if (pos < n_delta) {
-            cur[l][2 * r] = deltas[(size_t)pos];
-            cur[l][2 * r + 1] = deltas[(size_t)n_delta + pos];
+            if (r < ZKW_REGISTERS_COUNT) {
+              cur[l][2 * r] = deltas[(size_t)pos];
+              cur[l][2 * r + 1] = deltas[(size_t)n_delta + pos];
+            } else {
+              const uint4 v = deltas[(size_t)pos];
+              slow[l].heap_bound = v.x; slow[l].aux_bound = v.y; slow[l].depth = v.z;
+            }
           }
           pos++;
         }
@@ -1362,11 +1380,13 @@ static int build_wave(zkw_batch* b, uint32_t w) {
         if (k >= ncyc[l]) continue;
         uint4* dst = (uint4*)&wt->records[l][k];
         for (uint32_t ch = 0; ch < ZKW_REG_CHUNKS; ch++) dst[ch] = cur[l][ch];
-        uint4 t0 = tails[((size_t)k * 2) * L + l], t1 = tails[((size_t)k * 2 + 1) * L + l];
-        t0.x &= 0x00ffffffu;  // the dirty mask is device bookkeeping: reserved byte and top byte of the counts are zero in the ABI
-        t1.w &= 0x00ffffffu;
-        dst[30] = t0;
-        dst[31] = t1;
+        const uint4 t0 = tails[(size_t)k * L + l];
+        const uint32_t super_pc = (slow[l].pc & 0xffffu) >> 2;  // of the pc this cycle started from
+        slow[l].timestamp += time_delta;
+        slow[l].pc = t0.y & 0xffffu;
+        // (the delta mask is device bookkeeping: reserved byte and top byte of the counts are zero in the ABI)
+        dst[30] = make_uint4(t0.x & 0x00ffffffu, t0.y, t0.z, slow[l].timestamp);
+        dst[31] = make_uint4(slow[l].heap_bound, slow[l].aux_bound, (slow[l].depth & 0xffffu) | (super_pc << 16), t0.w & 0x00ffffffu);
       }
     }
   }
