@@ -1001,7 +1001,7 @@ static uint32_t pick_waves_per_group(const zkw_ctx* c, uint32_t total_waves) {
 
 // `inline_decommit`: the cycle kernel chains the decommit-queue commitment itself (a step that runs and commits in one
 // call has nothing to overlap the commitment kernels with); otherwise zkw_batch_commit computes it from the aux stream
-static int enqueue_run(zkw_batch* const* bs, uint32_t n, uint32_t max_cycles, hipStream_t st, bool inline_decommit = false) {
+static int enqueue_run(zkw_batch* const* bs, uint32_t n, uint32_t max_cycles, hipStream_t st, bool inline_decommit = false, bool whole_step = false) {
   zkw_ctx* c = bs[0]->ctx;
   if (c->opt_no_inline_decommit) inline_decommit = false;  // A/B switch
   for (uint32_t i = 0; i < n; i++) {
@@ -1043,7 +1043,11 @@ static int enqueue_run(zkw_batch* const* bs, uint32_t n, uint32_t max_cycles, hi
     const uint32_t g = A.waves_per_group, n_wg = (A.wave_base[n] + g - 1) / g;
     const uint32_t lds = zkw_cycle_kernel_lds_bytes(ZKW_WAVE, g) + g * ZKW_DQ_HELPER_BYTES;
     const uint32_t per_cu = g + 1 <= ZKW_MAX_WAVES_PER_GROUP ? std::min(ZKW_MAX_WAVES_PER_GROUP / (g + 1), (160u * 1024u) / lds) : 0u;
-    if (inline_decommit && c->wave_width > 1 && !(c->opt_debug_flags & ZKW_NO_DQ_HELPER) && per_cu && n_wg <= (uint32_t)c->n_cus * per_cu) {
+    // ... and only inside a whole step (zkw_batches_step: reset, run and commitments of one group on one stream).  A caller
+    // that runs and commits separately does so to overlap the commitment kernels of one group with the cycle kernel of
+    // another (bench.py's default command): there the "spare" slots are what those kernels run in — with helper waves
+    // cfg 4 with all three commitments fell from 1.77 to 1.28 G cycles/s (profiles/r04_ab_settle.txt).
+    if (whole_step && inline_decommit && c->wave_width > 1 && !(c->opt_debug_flags & ZKW_NO_DQ_HELPER) && per_cu && n_wg <= (uint32_t)c->n_cus * per_cu) {
       A.helpers = 1;
       A.debug_flags |= ZKW_DQ_HELPER;
     }
@@ -1147,7 +1151,7 @@ int zkw_batches_step(zkw_batch* const* batches, uint32_t n_batches, uint32_t max
   if (rc != ZKW_OK) return rc;
   hipStream_t st = (hipStream_t)hip_stream;
   rc = enqueue_reset(batches, n_batches, st);
-  if (rc == ZKW_OK) rc = enqueue_run(batches, n_batches, max_cycles, st, (queue_mask >> ZKW_QUEUE_DECOMMIT) & 1u);
+  if (rc == ZKW_OK) rc = enqueue_run(batches, n_batches, max_cycles, st, (queue_mask >> ZKW_QUEUE_DECOMMIT) & 1u, true);
   if (rc == ZKW_OK && queue_mask) rc = enqueue_commit(batches, n_batches, queue_mask, st);
   return rc;
 }
