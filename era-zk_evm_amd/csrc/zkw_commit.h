@@ -29,7 +29,9 @@ typedef struct zkw_commit_params {
   uint32_t n_blobs;
   uint32_t n_override;       /* != 0: number of records instead of cursors[] (code-word leaves) */
   uint32_t aux_type_mask;    /* bucket pass over the aux stream: bit t keeps events of type t (0 = DECOMMIT only) */
-  uint32_t reserved0;
+  uint32_t pooled;           /* bucket / chain: 1 = the index lists of a wave share its `cap` entries (offs[]): an instance may hold more
+                                than per_instance_cap records as long as its wave's stream held them (the commitments); 0 = fixed
+                                per-instance lists, counts clamped to per_instance_cap (the netting pass reports the overflow) */
   const uint64_t* rc;        /* [ZKW_GL_RC_COUNT] round constants */
   const uint4* stream;
   const uint32_t* cursors;   /* [n_waves][4] */
@@ -43,8 +45,9 @@ typedef struct zkw_commit_params {
   uint32_t n_preimages;
   uint32_t reserved1;
   uint64_t* leaves;          /* [n_waves][cap][4] */
-  uint32_t* idx;             /* [n_instances][per_instance_cap] */
+  uint32_t* idx;             /* [n_instances][per_instance_cap]; pooled: [n_waves][cap] */
   uint32_t* counts;          /* [n_instances] */
+  uint32_t* offs;            /* pooled: [n_instances] first entry of the instance's list in idx[] */
   uint64_t* out;             /* chain: [n_instances][ZKW_QUEUE_COUNT][4]; blob chain: [n_blobs][4] */
 } zkw_commit_params;
 

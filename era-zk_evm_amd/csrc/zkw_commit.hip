@@ -89,6 +89,7 @@ __global__ void zkw_bucket_kernel(zkw_fused_table T) {
   const zkw_commit_params ZKW_CONST_AS& C = zkw_commit_block(T, blockIdx.y, blockIdx.z);
   __shared__ u32 s_count[ZKW_WAVE];
   __shared__ u32 s_limit[ZKW_WAVE];
+  __shared__ u32 s_off[ZKW_WAVE];
   const u32 wave = blockIdx.x;
   const u32 tid = threadIdx.x;
   if (wave >= C.n_waves) return;  // uniform per workgroup
@@ -105,42 +106,66 @@ __global__ void zkw_bucket_kernel(zkw_fused_table T) {
     s_count[l] = 0;
   }
   __syncthreads();
-  for (u32 tile = 0; tile < n; tile += blockDim.x) {
-    const u32 p = tile + tid;
-    u32 tag = 0;
-    bool keep = false;
-    if (p < n) {
-      u32 type = ZKW_AUX_DECOMMIT;
-      if (C.queue == ZKW_QUEUE_MEMORY) {
-        tag = base[(u64)p * 16 + 12];  // plane 0 (headers) of the wave's memory stream
-      } else if (C.queue == ZKW_QUEUE_LOG) {
-        tag = base[(u64)p * 128 + 126];
-      } else {
-        tag = base[(u64)p * 256 + 1];
-        type = base[(u64)p * 256];
+  // pooled lists: a counting pass first (the same walk, nothing placed), then every lane's list starts where the previous
+  // lane's ends inside the wave's `cap` entries
+  for (u32 pass = C.pooled ? 0u : 1u; pass < 2u; pass++) {
+    for (u32 tile = 0; tile < n; tile += blockDim.x) {
+      const u32 p = tile + tid;
+      u32 tag = 0;
+      bool keep = false;
+      if (p < n) {
+        u32 type = ZKW_AUX_DECOMMIT;
+        if (C.queue == ZKW_QUEUE_MEMORY) {
+          tag = base[(u64)p * 16 + 12];  // plane 0 (headers) of the wave's memory stream
+        } else if (C.queue == ZKW_QUEUE_LOG) {
+          tag = base[(u64)p * 128 + 126];
+        } else {
+          tag = base[(u64)p * 256 + 1];
+          type = base[(u64)p * 256];
+        }
+        keep = tag < ZKW_WAVE && p < s_limit[tag & (ZKW_WAVE - 1)] && ((type_mask >> (type & 31u)) & 1u);
       }
-      keep = tag < ZKW_WAVE && p < s_limit[tag & (ZKW_WAVE - 1)] && ((type_mask >> (type & 31u)) & 1u);
-    }
-    tag &= ZKW_WAVE - 1;
-    u64 same = __ballot(keep);
+      tag &= ZKW_WAVE - 1;
+      u64 same = __ballot(keep);
 #pragma unroll
-    for (int bit = 0; bit < 6; bit++) {
-      const bool b = (tag >> bit) & 1u;
-      const u64 m = __ballot(keep && b);
-      same &= b ? m : ~m;
+      for (int bit = 0; bit < 6; bit++) {
+        const bool b = (tag >> bit) & 1u;
+        const u64 m = __ballot(keep && b);
+        same &= b ? m : ~m;
+      }
+      if (keep) {
+        const u32 rank = (u32)__popcll(same & ((1ull << (tid & 63u)) - 1ull));
+        const u32 before = s_count[tag];
+        const u32 inst = wave * C.L + tag;
+        if (pass == 1u) {
+          if (C.pooled) C.idx[(u64)wave * C.cap + s_off[tag] + before + rank] = p;
+          else if (before + rank < C.per_instance_cap) C.idx[(u64)inst * C.per_instance_cap + before + rank] = p;
+        }
+        if (rank == 0) s_count[tag] = before + (u32)__popcll(same);
+      }
+      __syncthreads();
     }
-    if (keep) {
-      const u32 rank = (u32)__popcll(same & ((1ull << (tid & 63u)) - 1ull));
-      const u32 before = s_count[tag];
-      const u32 inst = wave * C.L + tag;
-      if (before + rank < C.per_instance_cap) C.idx[(u64)inst * C.per_instance_cap + before + rank] = p;
-      if (rank == 0) s_count[tag] = before + (u32)__popcll(same);
+    if (pass == 0u) {
+      if (tid == 0) {
+        u32 run = 0;
+        for (u32 l = 0; l < ZKW_WAVE; l++) {
+          s_off[l] = run;
+          run += s_count[l];
+          s_count[l] = 0;
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   for (u32 l = tid; l < C.L; l += blockDim.x) {
     const u32 inst = wave * C.L + l;
-    if (inst < C.n_instances) C.counts[inst] = s_count[l] < C.per_instance_cap ? s_count[l] : C.per_instance_cap;
+    if (inst >= C.n_instances) continue;
+    if (C.pooled) {
+      C.counts[inst] = s_count[l];
+      C.offs[inst] = wave * C.cap + s_off[l];
+    } else {
+      C.counts[inst] = s_count[l] < C.per_instance_cap ? s_count[l] : C.per_instance_cap;
+    }
   }
 }
 
@@ -152,7 +177,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(ZKW_CHAIN_MIN_WAVES, 8))) zkw
   const u32 inst = wave * C.L + lane;
   if (wave >= C.n_waves || lane >= C.L || inst >= C.n_instances) return;
   const u32 cnt = C.counts[inst];
-  const u32* idx = C.idx + (u64)inst * C.per_instance_cap;
+  const u32* idx = C.pooled ? C.idx + C.offs[inst] : C.idx + (u64)inst * C.per_instance_cap;
   u64 tail[4] = {0, 0, 0, 0};
   if (C.queue == ZKW_QUEUE_DECOMMIT) {
     // one permutation per decommit: the leaf depends only on the code (hash, length, blob digest) and was computed per

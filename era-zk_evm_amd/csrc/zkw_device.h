@@ -171,6 +171,10 @@ typedef struct zkw_kparams {
 #define ZKW_DQ_HELPER (1u << 27)     /* zkw_launch_args.debug_flags: decommits are posted to the workgroup's helper wave */
 #define ZKW_NO_DQ_HELPER (1u << 28)  /* ZKW_OPT_DEBUG_FLAGS: never launch helper waves (A/B) */
 #define ZKW_DQ_HELPER_BYTES 1552u    /* LDS per cycle wave: 16 B of counters + a ring of 2 x [3][64] dwords */
+#define ZKW_KECCAK_HELPER (1u << 29) /* zkw_launch_args.debug_flags: every cycle wave has a helper wave of its own that serves its keccak256
+                                        calls lane-parallel (25 lanes per message: zkw_kh_helper) — batches of thin waves (<= 8 lanes) only */
+#define ZKW_KH_MAX_LANES 8u          /* ... which is the number of request rows in the mailbox of a cycle wave */
+#define ZKW_KH_BYTES (ZKW_KH_MAX_LANES * 64u) /* LDS per cycle wave: one 16-dword row per lane (request in, digest out) */
 #define ZKW_MAX_WAVES_PER_GROUP 8 /* a CU holds 8 waves of the cycle kernel (256 registers: two per SIMD) */
 typedef struct zkw_launch_args {
   const zkw_kparams* kp[ZKW_MAX_FUSED]; /* device copies of the parameter blocks */
@@ -180,8 +184,9 @@ typedef struct zkw_launch_args {
    * uniform_waves != 0: every batch has that many waves (batch = wave / uniform_waves, no search). */
   uint32_t wave_base[ZKW_MAX_FUSED + 1];
   uint32_t uniform_waves;
-  uint32_t helpers;   /* 1: every workgroup carries one more wave that chains the decommit-queue commitment for its cycle waves
-                         (ZKW_DQ_HELPER in debug_flags; only when the CUs have a wave slot to spare) */
+  uint32_t helpers;   /* helper waves per workgroup.  1: one more wave that chains the decommit-queue commitment for the cycle waves
+                         (ZKW_DQ_HELPER in debug_flags; only when the CUs have a wave slot to spare); waves_per_group with
+                         ZKW_KECCAK_HELPER: helper h serves cycle wave h (keccak256 calls, and its decommits under ZKW_DQ_HELPER) */
   uint32_t n_batches;
   uint32_t run_cycles;
   uint32_t debug_flags; /* profiling ablations / test hooks only (ZKW_DEBUG_FLAGS): 1 = no CycleRecord stores, 2 = no stream stores, 4 = one lane per group */

@@ -1561,6 +1561,7 @@ ZD void versioned_hash(const u256& h, bool& ok, u32& marker, u32& len_words, u25
 // LDS byte address of this wave's hand-over area to the helper wave (0: no helper in this launch); kept in the first
 // dword of the wave's LDS header, which the device build does not use otherwise (the stream cursors live in v128)
 ZD u32 dq_helper_area(const Shared& sh) { return *ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor); }
+ZD u32 kh_box(const Shared& sh) { return *ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor + 1); }
 #endif
 ZD void dq_undo(ZKW_KP P, const Shared& sh, Lane& s) {
   if (!(s.kflags & KF_DQ_CHAINED)) return;
@@ -2036,6 +2037,65 @@ static __device__ __noinline__ Lane zkw_precompile_entry(const zkw_kparams ZKW_C
   return s;
 }
 
+#ifdef __HIP_DEVICE_COMPILE__
+// `count` consecutive positions of the memory-query stream for every active lane (stream_alloc: one).  A lane whose
+// positions would not fit below `cap` takes none and gets ~0.
+ZD u32 stream_alloc_counted(u32 count, u32 cap) {
+  const u32 base = zkw_cursor_get<0>();
+  u32 total = 0, my = 0xffffffffu;
+  for (u64 m = __ballot(1); m; m &= m - 1) {
+    const u32 l = (u32)__builtin_ctzll(m);
+    const u32 c = (u32)__builtin_amdgcn_readlane((int)count, (int)l);
+    const bool fits = c <= cap && base + total <= cap - c;
+    if (zkw_lane_id() == l && fits) my = base + total;
+    if (fits) total += c;
+  }
+  zkw_cursor_set<0>(base + total);
+  return my;
+}
+
+// keccak256 of a wave that has a helper (ZKW_KECCAK_HELPER, zkw_kh_helper): what precompile_keccak256 does, with the
+// reads, their witness and the sponge handed over.  The requester resolves the page (the unreachable-page status is its
+// own), allocates the stream positions and the sequence numbers of the input reads — its later records then follow
+// them, in the order the reference emits — posts the request in its row of the mailbox and waits for the digest.
+ZD void keccak_request(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
+  const u32 in_off = q.key.w[0], in_len = q.key.w[1], out_off = q.key.w[2];
+  const u32 page_r = q.key.w[4], page_w = q.key.w[5];
+  const u32 n_words = in_len ? ((in_off & 31u) + in_len + 31u) >> 5 : 0u;
+  FatPage fp;
+  fp.slot = 0; fp.hwm = 0; fp.found = true; fp.is_aux = false; fp.empty = true;
+  if (n_words) fp = fat_ptr_resolve(P, sh, s, page_r);
+  const u32 pos = stream_alloc_counted(lane_ok(s) ? n_words : 0u, sh.cap_mem);
+  if (!lane_ok(s)) return;
+  const u32 seq0 = s.counts & 255u, mem0 = (s.counts >> 8) & 255u;
+  const u32 seq1 = n_words < 255u - seq0 ? seq0 + n_words : 255u, mem1 = n_words < 255u - mem0 ? mem0 + n_words : 255u;
+  s.counts = (s.counts & 0xffff0000u) | seq1 | (mem1 << 8);
+  if (pos == 0xffffffffu) {
+    lane_fail(s, ZKW_STATUS_LIMIT);
+    return;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the heap words this wave has stored are what the helper reads
+  const u32 row = kh_box(sh) + zkw_lane_id() * 64u;
+  ZKW_LDS_AS u32* rw = (ZKW_LDS_AS u32*)(size_t)row;
+  *ZKW_LDS_WORD(rw + 1) = in_off;
+  *ZKW_LDS_WORD(rw + 2) = in_len;
+  *ZKW_LDS_WORD(rw + 3) = fp.hwm;
+  *ZKW_LDS_WORD(rw + 4) = pos;
+  *ZKW_LDS_WORD(rw + 5) = seq0;
+  *ZKW_LDS_WORD(rw + 6) = q.timestamp;
+  *ZKW_LDS_WORD(rw + 7) = page_r;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  *ZKW_LDS_WORD(rw) = 0x80000000u | fp.slot | (fp.is_aux ? 1u << 16 : 0u) | (fp.empty ? 1u << 17 : 0u);
+  while (*ZKW_LDS_WORD(rw) >> 31) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  u256 digest;
+#pragma unroll
+  for (int i = 0; i < 8; i++) digest.w[i] = *ZKW_LDS_WORD(rw + 8 + i);
+  heap_write_cur(P, sh, s, false, out_off, digest);
+  emit_mem(P, sh, s, q.timestamp + 1, ZKW_MEM_HEAP, page_w, out_off, digest, false, true, 2);
+}
+#endif
+
 // helpers.rs:196-223 + DefaultPrecompilesProcessor dispatch on the low 16 address bits
 ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   emit_log(P, sh, s, q, ZKW_LQ_LOG);
@@ -2044,6 +2104,12 @@ ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   if (addr_low == P.consts.keccak_precompile_address) which = 0;
   else if (addr_low == P.consts.sha256_precompile_address) which = 1;
   else if (addr_low == P.consts.ecrecover_precompile_address) which = 2;
+#ifdef __HIP_DEVICE_COMPILE__
+  if (which == 0 && (sh.debug_flags & ZKW_KECCAK_HELPER)) {
+    keccak_request(P, sh, s, q);
+    which = 3;
+  }
+#endif
   // anything else behaves as an unknown precompile: no memory traffic.  The lanes of a group may call different
   // precompiles (the address is per lane): one call per kind present.
   for (u32 k = 0; k < 3; k++) {
@@ -2495,6 +2561,54 @@ ZD void lane_writeback(ZKW_KP P, Shared& sh, const RegFile& rf, Lane& s, u32 com
 // tail) — and leaves when every cycle wave has said it is done and every slot is consumed.  The permutation is ~80k
 // clocks for a lone wave, twice per 256 cycles of cfg 2: off the critical path of the cycle waves when a CU has a wave
 // slot to spare (the driver's 1280 waves = 5 per CU), which is the only case the runtime launches helpers for.
+// (the wave `gw` of the launch -> its batch and its wave of that batch; false: no such wave)
+ZD bool zkw_find_wave(const zkw_launch_args& A, u32 gw, u32& b, u32& wave) {
+  if (gw >= A.wave_base[A.n_batches]) return false;
+  if (A.uniform_waves) {
+    b = gw / A.uniform_waves;
+    wave = gw - b * A.uniform_waves;
+  } else {
+    u32 lo = 0, hi = A.n_batches;
+    while (hi - lo > 1) {
+      const u32 mid = (lo + hi) >> 1;
+      if (A.wave_base[mid] <= gw) lo = mid; else hi = mid;
+    }
+    b = lo;
+    wave = gw - A.wave_base[lo];
+  }
+  return true;
+}
+ZD u32 zkw_lds_get(u32 addr) { return *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)addr); }
+ZD void zkw_lds_put(u32 addr, u32 v) { *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)addr) = v; }
+
+// one look at the hand-over area of a cycle wave: 0 = nothing posted and the wave still cycles, 1 = one slot served,
+// 2 = nothing posted and the wave has left its loop
+ZD u32 zkw_dq_serve(ZKW_KP P, u32 wave, u32 area, u32& consumed, u32 tid) {
+  const u32 posted = zkw_lds_get(area);
+  if (consumed == posted) {
+    if (!zkw_lds_get(area + 8u)) return 0;               // still cycling
+    return zkw_lds_get(area) != posted ? 0u : 2u;        // (posted between the two reads)
+  }
+  const u32 row = area + 16u + (consumed & 1u) * 768u + tid * 4u;
+  const u32 w0 = zkw_lds_get(row), ts = zkw_lds_get(row + 256u), page = zkw_lds_get(row + 512u);
+  const u32 inst = wave * P.L + tid;
+  if ((w0 >> 31) && tid < P.L && inst < P.n_instances) {
+    const u32 pre = w0 & 0x3fffffffu, fresh = (w0 >> 30) & 1u;
+    u64* tail_p = P.commit_out + ((u64)inst * ZKW_QUEUE_COUNT + ZKW_QUEUE_DECOMMIT) * 4;
+    const u32 j = P.dq_count[inst];
+    const u64* ms = P.midstates + (u64)pre * 12;
+    const u64 leaf[4] = {ms[0], ms[1], ms[2], ms[3]};
+    u64 tail[4] = {tail_p[0], tail_p[1], tail_p[2], tail_p[3]};
+    gl_chain_step(P.commit_rc, leaf, tail, (u64)j + 1, ZKW_QUEUE_DECOMMIT, (u64)ts | ((u64)fresh << 32), (u64)page);
+    tail_p[0] = tail[0]; tail_p[1] = tail[1]; tail_p[2] = tail[2]; tail_p[3] = tail[3];
+    P.dq_count[inst] = j + 1;
+  }
+  zkw_lds_put(row, 0);  // the entry is empty again (a lane that has left its loop never rewrites it)
+  consumed++;
+  if (tid == 0) zkw_lds_put(area + 4u, consumed);  // the slot is free
+  return 1;
+}
+
 ZD void zkw_dq_helper(const zkw_launch_args& A, u32 tid) {
   const u32 g = A.waves_per_group;
   const u32 area0 = (u32)(size_t)(ZKW_LDS_AS uint4*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + g * zkw_wave_lds_units());
@@ -2506,53 +2620,163 @@ ZD void zkw_dq_helper(const zkw_launch_args& A, u32 tid) {
 #pragma unroll
     for (int h = 0; h < ZKW_MAX_WAVES_PER_GROUP; h++) {
       if ((u32)h >= g) continue;
-      const u32 gw = blockIdx.x * g + (u32)h;
-      if (gw >= A.wave_base[A.n_batches]) continue;  // no such wave
       u32 b, wave;
-      if (A.uniform_waves) {
-        b = gw / A.uniform_waves;
-        wave = gw - b * A.uniform_waves;
-      } else {
-        u32 lo = 0, hi = A.n_batches;
-        while (hi - lo > 1) {
-          const u32 mid = (lo + hi) >> 1;
-          if (A.wave_base[mid] <= gw) lo = mid; else hi = mid;
-        }
-        b = lo;
-        wave = gw - A.wave_base[lo];
-      }
+      if (!zkw_find_wave(A, blockIdx.x * g + (u32)h, b, wave)) continue;
       ZKW_KP P = *(const zkw_kparams ZKW_CONST_AS*)A.kp[b];
       if (wave >= P.n_waves) continue;
-      const u32 area = area0 + (u32)h * ZKW_DQ_HELPER_BYTES;
-      const u32 posted = *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)area);
-      if (consumed[h] == posted) {
-        if (!*ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(area + 8u))) all_done = false;  // still cycling
-        else if (*ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)area) != posted) all_done = false;  // posted between the two reads
-        continue;
-      }
-      all_done = false;
-      const u32 row = area + 16u + (consumed[h] & 1u) * 768u + tid * 4u;
-      const u32 w0 = *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)row);
-      const u32 ts = *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(row + 256u));
-      const u32 page = *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(row + 512u));
-      const u32 inst = wave * P.L + tid;
-      if ((w0 >> 31) && tid < P.L && inst < P.n_instances) {
-        const u32 pre = w0 & 0x3fffffffu, fresh = (w0 >> 30) & 1u;
-        u64* tail_p = P.commit_out + ((u64)inst * ZKW_QUEUE_COUNT + ZKW_QUEUE_DECOMMIT) * 4;
-        const u32 j = P.dq_count[inst];
-        const u64* ms = P.midstates + (u64)pre * 12;
-        const u64 leaf[4] = {ms[0], ms[1], ms[2], ms[3]};
-        u64 tail[4] = {tail_p[0], tail_p[1], tail_p[2], tail_p[3]};
-        gl_chain_step(P.commit_rc, leaf, tail, (u64)j + 1, ZKW_QUEUE_DECOMMIT, (u64)ts | ((u64)fresh << 32), (u64)page);
-        tail_p[0] = tail[0]; tail_p[1] = tail[1]; tail_p[2] = tail[2]; tail_p[3] = tail[3];
-        P.dq_count[inst] = j + 1;
-      }
-      *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)row) = 0;  // the entry is empty again (a lane that has left its loop never rewrites it)
-      consumed[h]++;
-      if (tid == 0) *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(area + 4u)) = consumed[h];  // the slot is free
+      if (zkw_dq_serve(P, wave, area0 + (u32)h * ZKW_DQ_HELPER_BYTES, consumed[h], tid) != 2u) all_done = false;
     }
     if (all_done) break;
     __builtin_amdgcn_s_sleep(32);
+  }
+}
+
+// ---- keccak256 served by a helper wave, 25 lanes per message --------------------------------------------------------
+// A batch of thin waves (a few instances per wave: the shape of a latency-bound caller, BASELINE cfg 3's 512 instances)
+// leaves most lanes of the chip idle while every instance walks its message one permutation after the other: ~15 us per
+// Keccak-f[1600] with the 25-word state in the registers of one lane.  With ZKW_KECCAK_HELPER every cycle wave has a
+// helper wave in its workgroup, and a keccak256 call is a request in the cycle wave's mailbox in LDS (one 16-dword row
+// per lane: call_precompile -> keccak_request).  The helper serves two requests at a time, one per half wave: state
+// word x + 5y in lane x + 5y, the cross-lane terms of a round fetched with ds_bpermute in three dependent steps —
+//   C[i]  = A[i] ^ A[i+5] ^ A[i+10] ^ A[i+15] ^ A[i+20]          (indices mod 25: the column of lane i)
+//   E[i]  = A[i] ^ C[x-1] ^ rotl(C[x+1], 1)                      (theta)
+//   T[i]  = rotl(E[i], rho[i])                                   (rho, in the lane that holds the word)
+//   A'[d] = T[src d] ^ (~T[src(x+1)] & T[src(x+2)]),  src(X, Y) = ((X + 3Y) % 5, X)   (pi and chi in one step) — and the
+// message bytes, the witnessed input words (precompile read queries: positions and sequence numbers handed over by the
+// requester, which has allocated them) straight from the arena of the instance.  The digest goes back through the row.
+__device__ const unsigned char ZKW_KH_RHO[32] = {0,  1,  62, 28, 27, 36, 44, 6,  55, 20, 3, 10, 43, 25, 39, 41,
+                                                 45, 15, 21, 8,  18, 2,  61, 56, 14, 0,  0, 0,  0,  0,  0,  0};
+// rotl of a 64-bit lane word by a per-lane amount: `swap` exchanges the halves (amounts >= 32), `s` = 32 - (amount % 32)
+// is the funnel shift.  Amount 0 — lane 0 only, no other rho offset is a multiple of 32 — is taken as 64: halves
+// exchanged twice (swap and s = 0, where the funnel returns its low operand).
+struct KhRot { bool swap; u32 s; };
+ZD KhRot kh_rot(u32 amount) { KhRot r; r.swap = amount >= 32u || amount == 0u; r.s = (32u - (amount & 31u)) & 31u; return r; }
+ZD void kh_rotl(u32& lo, u32& hi, const KhRot& r) {
+  const u32 a = r.swap ? hi : lo, b = r.swap ? lo : hi;  // (b:a) rotated left by amount % 32
+  lo = __builtin_amdgcn_alignbit(a, b, r.s);
+  hi = __builtin_amdgcn_alignbit(b, a, r.s);
+}
+ZD u32 kh_bp(u32 byte_addr, u32 v) { return (u32)__builtin_amdgcn_ds_bpermute((int)byte_addr, (int)v); }
+
+ZD void zkw_kh_serve(ZKW_KP P, u32 wave, u32 box, u32 r0, u32 r1, u32 tid) {
+  const u32 half = tid >> 5, idx = tid & 31u;
+  const u32 r = half ? r1 : r0;  // the request of this half wave (r1 = ~0: none)
+  const bool have = r != 0xffffffffu;
+  const u32 row = box + (have ? r : r0) * 64u;
+  const u32 f = zkw_lds_get(row), in_off = zkw_lds_get(row + 4u), in_len = have ? zkw_lds_get(row + 8u) : 0u;
+  const u32 hwm = zkw_lds_get(row + 12u), pos = zkw_lds_get(row + 16u), seq0 = zkw_lds_get(row + 20u), ts = zkw_lds_get(row + 24u), page = zkw_lds_get(row + 28u);
+  const u32 slot = f & 0xffffu;
+  const bool is_aux = (f >> 16) & 1u, empty = (f >> 17) & 1u;
+  const u32 L = P.L, words = is_aux ? P.A : P.H;
+  const uint4* arena = is_aux ? P.aux_heap + (u64)wave * P.F * P.A * 2u * L : P.heap + (u64)wave * P.F * P.H * 2u * L;
+  const u32 lim = empty ? 0u : (hwm < words ? hwm : words);  // words at and beyond read as zero (memory.rs:490-495)
+  const u32 w0 = in_off >> 5;
+  const u32 n_words = in_len ? ((in_off & 31u) + in_len + 31u) >> 5 : 0u;
+  // the witnessed reads: one word per lane and step
+  {
+    uint4* mem = P.mem_stream + (u64)wave * P.cap_mem * 3 + pos;
+    const u32 meta = (ZKW_MEM_FAT_PTR & ZKW_MQ_TYPE_MASK) | (1u << ZKW_MQ_KIND_SHIFT);
+    for (u32 i = idx; i < n_words; i += 32u) {
+      const u32 wi = w0 + i;
+      uint4 lo = make_uint4(0, 0, 0, 0), hi = make_uint4(0, 0, 0, 0);
+      if (wi < lim) {
+        const uint4* e = arena + (2u * (slot * words + wi) * L + r);
+        lo = zkw_gload4(e);
+        hi = zkw_gload4(e + L);
+      }
+      const u32 seq = seq0 + i < 255u ? seq0 + i : 255u;
+      zkw_stream_store(mem + i, make_uint4(ts, page, wi, r | (seq << 8) | (meta << 16)));
+      zkw_stream_store(mem + i + P.cap_mem, lo);
+      zkw_stream_store(mem + i + 2u * (u64)P.cap_mem, hi);
+    }
+  }
+  // the sponge
+  const u32 nb = have ? in_len / ZKW_KECCAK_RATE + 1u : 0u;
+  const u32 nb_max = max((u32)__builtin_amdgcn_readlane((int)nb, 0), (u32)__builtin_amdgcn_readlane((int)nb, 32));
+  const u32 lane0 = half * 32u;
+  const bool in_state = idx < 25u;
+  const u32 X = idx % 5u, Y = idx / 5u;
+#define ZKW_KH_LANE(i) ((in_state ? lane0 + (i) : tid) * 4u)
+  const u32 a_c1 = ZKW_KH_LANE((idx + 5u) % 25u), a_c2 = ZKW_KH_LANE((idx + 10u) % 25u), a_c3 = ZKW_KH_LANE((idx + 15u) % 25u), a_c4 = ZKW_KH_LANE((idx + 20u) % 25u);
+  const u32 xm1 = Y * 5u + (X + 4u) % 5u, xp1 = Y * 5u + (X + 1u) % 5u, xp2 = Y * 5u + (X + 2u) % 5u;
+  const u32 a_xm1 = ZKW_KH_LANE(xm1), a_xp1 = ZKW_KH_LANE(xp1);
+  // pi: destination (X, Y) takes the word of source x = (X + 3Y) % 5, y = X
+  const u32 s0 = in_state ? (X + 3u * Y) % 5u + 5u * X : 0u;
+  const u32 s1 = in_state ? ((xp1 % 5u) + 3u * Y) % 5u + 5u * (xp1 % 5u) : 0u;
+  const u32 s2 = in_state ? ((xp2 % 5u) + 3u * Y) % 5u + 5u * (xp2 % 5u) : 0u;
+  const u32 a_s0 = ZKW_KH_LANE(s0), a_s1 = ZKW_KH_LANE(s1), a_s2 = ZKW_KH_LANE(s2);
+#undef ZKW_KH_LANE
+  const KhRot rho = kh_rot(ZKW_KH_RHO[in_state ? idx : 0u]);
+  const u32 iota_lane = idx == 0 ? 0xffffffffu : 0u;
+  u32 lo = 0, hi = 0, dg_lo = 0, dg_hi = 0;
+  const unsigned char* bytes = (const unsigned char*)arena;
+  // this lane's eight bytes of block b of the padded message, little-endian (lanes 0..16 of a half wave)
+  auto block_word = [&](u32 b, u32& m0, u32& m1) {
+    m0 = 0; m1 = 0;
+    if (b >= nb || idx >= 17u) return;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const u32 rel = b * ZKW_KECCAK_RATE + 8u * idx + (u32)i;  // byte of the padded message
+      u32 v = 0;
+      if (rel < in_len) {
+        const u32 p = in_off + rel, wi = p >> 5, back = 31u - (p & 31u);  // words are big-endian: byte `back` of the little-endian value
+        if (wi < lim) v = bytes[((u64)(2u * (slot * words + wi) * L + r + (back >> 4) * L)) * 16u + (back & 15u)];
+      } else if (rel == in_len) {
+        v = 0x01u;  // pad10*1 with the legacy domain byte
+      }
+      if (rel == nb * ZKW_KECCAK_RATE - 1u) v |= 0x80u;
+      if (i < 4) m0 |= v << (8 * i); else m1 |= v << (8 * (i - 4));
+    }
+  };
+  u32 m0, m1;
+  block_word(0, m0, m1);
+  for (u32 b = 0; b < nb_max; b++) {
+    lo ^= m0;
+    hi ^= m1;
+    block_word(b + 1u, m0, m1);  // (in flight during the permutation)
+#pragma unroll
+    for (int round = 0; round < 24; round++) {
+      const u32 c_lo = lo ^ kh_bp(a_c1, lo) ^ kh_bp(a_c2, lo) ^ kh_bp(a_c3, lo) ^ kh_bp(a_c4, lo);
+      const u32 c_hi = hi ^ kh_bp(a_c1, hi) ^ kh_bp(a_c2, hi) ^ kh_bp(a_c3, hi) ^ kh_bp(a_c4, hi);
+      const u32 m_lo = kh_bp(a_xm1, c_lo), m_hi = kh_bp(a_xm1, c_hi), p_lo = kh_bp(a_xp1, c_lo), p_hi = kh_bp(a_xp1, c_hi);
+      u32 e_lo = lo ^ m_lo ^ __builtin_amdgcn_alignbit(p_lo, p_hi, 31), e_hi = hi ^ m_hi ^ __builtin_amdgcn_alignbit(p_hi, p_lo, 31);
+      kh_rotl(e_lo, e_hi, rho);  // rho at the source, pi and chi at the destination
+      const u32 b0_lo = kh_bp(a_s0, e_lo), b0_hi = kh_bp(a_s0, e_hi), b1_lo = kh_bp(a_s1, e_lo), b1_hi = kh_bp(a_s1, e_hi), b2_lo = kh_bp(a_s2, e_lo), b2_hi = kh_bp(a_s2, e_hi);
+      lo = b0_lo ^ (~b1_lo & b2_lo) ^ (iota_lane & (u32)ZKW_KECCAK_RC[round]);
+      hi = b0_hi ^ (~b1_hi & b2_hi) ^ (iota_lane & (u32)(ZKW_KECCAK_RC[round] >> 32));
+    }
+    if (b + 1u == nb) { dg_lo = lo; dg_hi = hi; }
+  }
+  if (have && idx < 4u) {  // digest word = state words 0..3, big-endian (as precompile_keccak256 writes it)
+    zkw_lds_put(row + 32u + (7u - 2u * idx) * 4u, __builtin_bswap32(dg_lo));
+    zkw_lds_put(row + 32u + (6u - 2u * idx) * 4u, __builtin_bswap32(dg_hi));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (have && idx == 0) zkw_lds_put(row, 0);  // served
+}
+
+ZD void zkw_kh_helper(const zkw_launch_args& A, u32 tid, u32 h) {
+  const u32 g = A.waves_per_group;
+  u32 b, wave;
+  if (!zkw_find_wave(A, blockIdx.x * g + h, b, wave)) return;
+  ZKW_KP P = *(const zkw_kparams ZKW_CONST_AS*)A.kp[b];
+  if (wave >= P.n_waves) return;
+  const u32 area0 = (u32)(size_t)(ZKW_LDS_AS uint4*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + g * zkw_wave_lds_units());
+  const u32 area = area0 + h * ZKW_DQ_HELPER_BYTES, box = area0 + g * ZKW_DQ_HELPER_BYTES + h * ZKW_KH_BYTES;
+  u32 consumed = 0;
+  for (;;) {
+    const u64 req = __ballot(tid < ZKW_KH_MAX_LANES && (zkw_lds_get(box + tid * 64u) >> 31));
+    if (req) {
+      const u32 r0 = (u32)__builtin_ctzll(req);
+      const u64 rest = req & (req - 1);
+      const u32 r1 = rest ? (u32)__builtin_ctzll(rest) : 0xffffffffu;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the heap words the requesters stored
+      zkw_kh_serve(P, wave, box, r0, r1, tid);
+      continue;
+    }
+    const u32 st = zkw_dq_serve(P, wave, area, consumed, tid);
+    if (st == 2u) break;  // (a wave that has left its loop has no request pending: the requester waits for its digest)
+    if (st == 0u) __builtin_amdgcn_s_sleep(2);
   }
 }
 #endif
@@ -2580,7 +2804,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
     batch_idx = lo;
     wave = gw - A.wave_base[lo];
   }
-  const bool is_helper = A.helpers && wib == A.waves_per_group;  // the extra wave of the workgroup (zkw_dq_helper)
+  const bool is_helper = A.helpers && wib >= A.waves_per_group;  // the extra wave(s) of the workgroup (zkw_dq_helper / zkw_kh_helper)
   const bool beyond = is_helper || gw >= A.wave_base[A.n_batches];  // tail of the last workgroup
   if (beyond) {
     batch_idx = 0;  // (a valid parameter block for the table staging below; the wave leaves after the barrier)
@@ -2609,13 +2833,15 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
 #ifdef __HIP_DEVICE_COMPILE__
   if (is_helper) {  // counters and entries of every hand-over area start empty (before the barrier: the cycle waves post after it)
     u32* area = (u32*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + A.waves_per_group * zkw_wave_lds_units());
-    for (u32 i = tid; i < A.waves_per_group * (ZKW_DQ_HELPER_BYTES / 4u); i += A.wave_threads) area[i] = 0;
+    const u32 per_wave = (ZKW_DQ_HELPER_BYTES + ((A.debug_flags & ZKW_KECCAK_HELPER) ? ZKW_KH_BYTES : 0u)) / 4u;
+    for (u32 i = tid + (wib - A.waves_per_group) * A.wave_threads; i < A.waves_per_group * per_wave; i += A.helpers * A.wave_threads) area[i] = 0;
   }
 #endif
   __syncthreads();
 #ifdef __HIP_DEVICE_COMPILE__
   if (is_helper) {
-    zkw_dq_helper(A, tid);
+    if (A.debug_flags & ZKW_KECCAK_HELPER) zkw_kh_helper(A, tid, wib - A.waves_per_group);
+    else zkw_dq_helper(A, tid);
     return;
   }
 #endif
@@ -2626,6 +2852,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
 #ifdef __HIP_DEVICE_COMPILE__
     const u32 area0 = (u32)(size_t)(ZKW_LDS_AS uint4*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + A.waves_per_group * zkw_wave_lds_units());
     *ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor) = A.helpers ? area0 + wib * ZKW_DQ_HELPER_BYTES : 0u;  // dq_helper_area
+    *ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor + 1) = area0 + A.waves_per_group * ZKW_DQ_HELPER_BYTES + wib * ZKW_KH_BYTES;  // kh_box (ZKW_KECCAK_HELPER)
 #endif
   }
 #ifdef __HIP_DEVICE_COMPILE__
@@ -2983,7 +3210,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
   }
 #endif
 #ifdef __HIP_DEVICE_COMPILE__
-  if ((A.debug_flags & ZKW_DQ_HELPER) && tid == 0) *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(dq_helper_area(sh) + 8u)) = 1u;  // every lane has left the loop: nothing more will be posted
+  if (A.helpers && tid == 0) *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(dq_helper_area(sh) + 8u)) = 1u;  // every lane has left the loop: nothing more will be posted
 #endif
   // wave-cycles executed = the maximum over the lanes (lanes leave the loop at different iterations)
 #pragma unroll
@@ -3169,7 +3396,7 @@ extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_gr
 // host-callable launcher (keeps <<<>>> out of the runtime)
 extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_launch_args* A, hipStream_t stream) {
   const u32 g = A->waves_per_group;
-  const uint32_t lds = zkw_cycle_kernel_lds_bytes(A->max_L, g) + (A->helpers ? g * ZKW_DQ_HELPER_BYTES : 0u);
+  const uint32_t lds = zkw_cycle_kernel_lds_bytes(A->max_L, g) + (A->helpers ? g * (ZKW_DQ_HELPER_BYTES + ((A->debug_flags & ZKW_KECCAK_HELPER) ? ZKW_KH_BYTES : 0u)) : 0u);
   if (lds > 64u * 1024u) {
     // dynamic LDS above the 64 KB default needs an explicit opt-in (not reached by the current layout: 41 KB per workgroup).  The
     // attribute is per device: remember the opted-in size per device, under a lock (contexts on several devices and
@@ -3186,6 +3413,6 @@ extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_launch_args* A, hipStrea
       if (dev >= 0 && dev < 64) opted[dev] = lds;
     }
   }
-  hipLaunchKernelGGL(zkw_cycle_kernel, dim3((A->wave_base[A->n_batches] + g - 1) / g), dim3(A->wave_threads * (g + (A->helpers ? 1u : 0u))), lds, stream, *A);
+  hipLaunchKernelGGL(zkw_cycle_kernel, dim3((A->wave_base[A->n_batches] + g - 1) / g), dim3(A->wave_threads * (g + A->helpers)), lds, stream, *A);
   return hipGetLastError();
 }

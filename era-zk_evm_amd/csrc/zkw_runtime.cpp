@@ -891,8 +891,11 @@ int zkw_batch_upload(zkw_batch* b) {
     const uint32_t max_per = std::max(per_inst[0], std::max(per_inst[1], per_inst[2]));
     (void)max_cap; (void)max_per;
     // per-instance index lists and counts of every queue side by side: the queues of a step are chained in ONE launch
-    HIP_TRY(c, ensure(b->d_idx, (size_t)b->n * ((size_t)per_inst[0] + per_inst[1] + per_inst[2])));
-    HIP_TRY(c, ensure(b->d_counts, (size_t)b->n * ZKW_QUEUE_COUNT));
+    // (the lists of a wave share its stream capacity — zkw_commit_params.pooled: an instance that logged more than its nominal
+    // share without overflowing the wave's stream is committed in full, as its trace is returned in full)
+    const size_t n_padded = (size_t)b->n_waves * b->L;
+    HIP_TRY(c, ensure(b->d_idx, n_padded * ((size_t)per_inst[0] + per_inst[1] + per_inst[2])));
+    HIP_TRY(c, ensure(b->d_counts, (size_t)b->n * ZKW_QUEUE_COUNT * 2));
     const uint4* streams[3] = {b->d_mem.p, b->d_log.p, b->d_auxs.p};
     zkw_commit_params CP[ZKW_QUEUE_COUNT];
     std::memset(CP, 0, sizeof CP);
@@ -902,7 +905,8 @@ int zkw_batch_upload(zkw_batch* b) {
       C.queue = q; C.cap = caps[q]; C.per_instance_cap = per_inst[q]; C.n_blobs = (uint32_t)b->blobs.size();
       C.rc = b->d_rc.p; C.stream = streams[q]; C.cursors = b->d_cursors.p; C.dir = b->d_dir.p; C.scalars = b->d_scalars.p;
       C.blob_digests = b->d_blob_digests.p; C.blob_dir = b->d_blob_dir.p; C.leaves = nullptr;
-      C.idx = b->d_idx.p + (size_t)b->n * (q == 0 ? 0 : (q == 1 ? per_inst[0] : (size_t)per_inst[0] + per_inst[1])); C.counts = b->d_counts.p + (size_t)b->n * q;
+      C.idx = b->d_idx.p + n_padded * (q == 0 ? 0 : (q == 1 ? per_inst[0] : (size_t)per_inst[0] + per_inst[1])); C.counts = b->d_counts.p + (size_t)b->n * q;
+      C.pooled = 1; C.offs = b->d_counts.p + (size_t)b->n * (ZKW_QUEUE_COUNT + q);
       C.out = b->d_commit.p; C.midstates = b->d_midstates.p; C.preimages = b->d_preimages.p; C.n_preimages = (uint32_t)b->preimages.size();
     }
     HIP_TRY(c, ensure(b->d_commit_params, ZKW_QUEUE_COUNT + 1));
@@ -1050,6 +1054,22 @@ static int enqueue_run(zkw_batch* const* bs, uint32_t n, uint32_t max_cycles, hi
     if (whole_step && inline_decommit && c->wave_width > 1 && !(c->opt_debug_flags & ZKW_NO_DQ_HELPER) && per_cu && n_wg <= (uint32_t)c->n_cus * per_cu) {
       A.helpers = 1;
       A.debug_flags |= ZKW_DQ_HELPER;
+    }
+  }
+  // Batches of thin waves (<= 8 instances per wave: a caller after latency, not throughput): every cycle wave gets a helper
+  // wave of its own that runs its keccak256 calls lane-parallel (zkw_kh_helper) and, inside a whole step, chains its
+  // decommits.  Workgroups of g cycle + g helper waves, the smallest g that fits the launch in one round of workgroups.
+  if (c->wave_width > 1 && A.max_L <= ZKW_KH_MAX_LANES && !c->opt_waves_per_group && !(c->opt_debug_flags & ZKW_NO_DQ_HELPER)) {
+    for (uint32_t g = 1; 2 * g <= ZKW_MAX_WAVES_PER_GROUP; g++) {
+      const uint32_t lds = zkw_cycle_kernel_lds_bytes(ZKW_WAVE, g) + g * (ZKW_DQ_HELPER_BYTES + ZKW_KH_BYTES);
+      const uint32_t per_cu = std::min(ZKW_MAX_WAVES_PER_GROUP / (2 * g), (160u * 1024u) / lds);
+      const uint32_t n_wg = (A.wave_base[n] + g - 1) / g;
+      if (!per_cu || n_wg > (uint32_t)c->n_cus * per_cu) continue;
+      A.waves_per_group = g;
+      A.helpers = g;
+      A.debug_flags |= ZKW_KECCAK_HELPER;
+      if (whole_step && inline_decommit) A.debug_flags |= ZKW_DQ_HELPER; else A.debug_flags &= ~ZKW_DQ_HELPER;
+      break;
     }
   }
   // HIP events around the launch: on the first batch of the group (its kernel_ms is the launch's duration)

@@ -427,6 +427,72 @@ def test_keccak_precompile_odd_lengths_and_alignments(oracle, product, isa, lens
         assert ok, (i, why)
 
 
+def test_commitments_of_an_instance_beyond_its_nominal_share(oracle, product, isa):
+    """The streams of a wave are one pool (limits.max_*_queries x lanes): an instance may log more than its nominal share as
+    long as the wave's stream holds it — its trace comes back in full, and so must its queue commitments (fuzz seed 0x400c
+    of the round-3 campaign: instance 386 logs past max_log_queries next to lanes that hit the capacity; the per-instance
+    index lists of the commitment pass once cut its log queue short).  Instances with ZKW_STATUS_LIMIT are excluded."""
+    wl = synth.fuzz_workload(isa, n_instances=512, n_ops=96, seed=0x400C)
+    bo = _run(oracle, wl)
+    bp = _run(product, wl, 64)
+    co, cp = bo.commitments(), bp.commitments()
+    keep = np.array([int(bp.trace(i)["status"]) != K.STATUS_LIMIT for i in range(wl.n_instances)])
+    per = int(bp.limits["max_log_queries"][0]) or None  # (the library writes the resolved limits back)
+    beyond = [i for i in np.nonzero(keep)[0] if per is not None and len(bp.trace(int(i))["log"]) > per]
+    assert keep.sum() > 400
+    assert np.array_equal(co[keep], cp[keep]), np.argwhere((co != cp).any(axis=-1) & keep[:, None]).tolist()
+    if per is not None:
+        assert beyond, "the seed no longer drives an instance past its nominal share"
+    bo.destroy(); bp.destroy()
+
+
+@pytest.mark.parametrize("lanes", [2, 8, 5])
+@pytest.mark.parametrize("lens,unal", [((0, 1, 3, 50), (0, 1, 2, 3)), ((135, 136, 137, 200), (31, 5, 30, 7)), ((272, 7, 131, 408), (1, 2, 3, 4)), ((1088, 271, 690, 32), (9, 31, 0, 16))])
+def test_keccak_served_by_helper_waves(oracle, product, isa, lanes, lens, unal):
+    """Batches of thin waves (<= 8 lanes): every cycle wave has a helper wave that runs its keccak256 calls 25 lanes per
+    message (zkw_kh_helper) — reads witnessed by the helper at positions the requester allocated, digest back through LDS.
+    Same traces as the oracle, run() and the whole step (helper also chains the decommits) alike, commitments included."""
+    wl = synth.make(3, isa, n_instances=37, keccak_bytes=lens, keccak_unalign=unal, sha_rounds=(1, 2, 1, 1))
+    bo = _run(oracle, wl)
+    bp = _run(product, wl, lanes)
+    for i in range(wl.n_instances):
+        ok, why = K.traces_equal(bo.trace(i), bp.trace(i))
+        assert ok, (i, why)
+    assert np.array_equal(bo.commitments(), bp.commitments())
+    bs = product.create_batch(wl)
+    product.step_many([bs], wl.n_cycles, 7)
+    bs.sync()
+    for i in range(0, wl.n_instances, 5):
+        ok, why = K.traces_equal(bo.trace(i), bs.trace(i))
+        assert ok, (i, why)
+    assert np.array_equal(bo.commitments(), bs.commitments())
+    for b in (bo, bp, bs):
+        b.destroy()
+
+
+@pytest.mark.parametrize("lanes", [2, 8])
+def test_reference_keccak_kats_through_the_helper_waves(product, isa, lanes):
+    """The reference's keccak256 cases (src/testing/tests/precompiles/keccak256.rs:144-196) through the lane-parallel
+    sponge of the helper waves: digests against the literal SURVEY Appendix C values, no oracle in between."""
+    from test_oracle_precompiles import KECCAK_KATS
+    lens = (0, 50, 136, 200)
+    for unalignment in (0, 31):
+        wl = synth.make(3, isa, n_instances=19, keccak_bytes=lens, keccak_unalign=(unalignment,) * 4, sha_rounds=(1, 1, 1, 1))
+        by = wl.heap_bytes
+        for (start, length, _) in wl.keccak_messages:
+            by[:, start - unalignment:start] = 0xFF
+            by[:, start:start + length] = 123
+        n, hw = by.shape[0], by.shape[1] // 32
+        wl.heaps = np.ascontiguousarray(by.reshape(n, hw, 4, 8).view(">u8").reshape(n, hw, 4)[:, :, ::-1].astype("<u8"))
+        bp = _run(product, wl, lanes)
+        for i in range(wl.n_instances):
+            t = bp.trace(i)
+            writes = [q for q in t["mem"] if (q["meta"] >> K.MQ_KIND_SHIFT) == 2]
+            for length, q in zip(lens, writes[4:8]):
+                assert K.u256_to_int(q["value"]).to_bytes(32, "big").hex() == KECCAK_KATS[length], (i, length, unalignment)
+        bp.destroy()
+
+
 @pytest.mark.parametrize("seed,lanes", [(0xF001, 64), (0xF002, 64), (0xF003, 16), (0xF004, 0)])
 def test_fuzz_tapes(oracle, product, isa, seed, lanes):
     """Every instance runs its own tape of random valid encodings (synth.fuzz_workload): all 64 lanes of a wave diverge
