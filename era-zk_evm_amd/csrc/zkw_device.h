@@ -171,8 +171,8 @@ typedef struct zkw_kparams {
 #define ZKW_DQ_HELPER (1u << 27)     /* zkw_launch_args.debug_flags: decommits are posted to the workgroup's helper wave */
 #define ZKW_NO_DQ_HELPER (1u << 28)  /* ZKW_OPT_DEBUG_FLAGS: never launch helper waves (A/B) */
 #define ZKW_DQ_HELPER_BYTES 1552u    /* LDS per cycle wave: 16 B of counters + a ring of 2 x [3][64] dwords */
-#define ZKW_KECCAK_HELPER (1u << 29) /* zkw_launch_args.debug_flags: every cycle wave has a helper wave of its own that serves its keccak256
-                                        calls lane-parallel (25 lanes per message: zkw_kh_helper) — batches of thin waves (<= 8 lanes) only */
+#define ZKW_KECCAK_HELPER (1u << 29) /* zkw_launch_args.debug_flags: every cycle wave has helper waves of its own that serve its keccak256
+                                        calls lane-parallel (one lane per half state word: zkw_kh_helper) — batches of thin waves (<= 8 lanes) only */
 #define ZKW_KH_MAX_LANES 8u          /* ... which is the number of request rows in the mailbox of a cycle wave */
 #define ZKW_KH_BYTES (ZKW_KH_MAX_LANES * 64u) /* LDS per cycle wave: one 16-dword row per lane (request in, digest out) */
 #define ZKW_MAX_WAVES_PER_GROUP 8 /* a CU holds 8 waves of the cycle kernel (256 registers: two per SIMD) */
@@ -185,8 +185,9 @@ typedef struct zkw_launch_args {
   uint32_t wave_base[ZKW_MAX_FUSED + 1];
   uint32_t uniform_waves;
   uint32_t helpers;   /* helper waves per workgroup.  1: one more wave that chains the decommit-queue commitment for the cycle waves
-                         (ZKW_DQ_HELPER in debug_flags; only when the CUs have a wave slot to spare); waves_per_group with
-                         ZKW_KECCAK_HELPER: helper h serves cycle wave h (keccak256 calls, and its decommits under ZKW_DQ_HELPER) */
+                         (ZKW_DQ_HELPER in debug_flags; only when the CUs have a wave slot to spare); a multiple k of waves_per_group with
+                         ZKW_KECCAK_HELPER: helpers h * k .. h * k + k - 1 serve cycle wave h (keccak256 calls of its lanes r with r % k = the
+                         helper's index; the first also its decommits under ZKW_DQ_HELPER) */
   uint32_t n_batches;
   uint32_t run_cycles;
   uint32_t debug_flags; /* profiling ablations / test hooks only (ZKW_DEBUG_FLAGS): 1 = no CycleRecord stores, 2 = no stream stores, 4 = one lane per group */

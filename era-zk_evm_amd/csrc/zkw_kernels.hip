@@ -2631,92 +2631,72 @@ ZD void zkw_dq_helper(const zkw_launch_args& A, u32 tid) {
   }
 }
 
-// ---- keccak256 served by a helper wave, 25 lanes per message --------------------------------------------------------
+// ---- keccak256 served by helper waves, one lane per 32-bit half of a state word -------------------------------------
 // A batch of thin waves (a few instances per wave: the shape of a latency-bound caller, BASELINE cfg 3's 512 instances)
 // leaves most lanes of the chip idle while every instance walks its message one permutation after the other: ~15 us per
-// Keccak-f[1600] with the 25-word state in the registers of one lane.  With ZKW_KECCAK_HELPER every cycle wave has a
-// helper wave in its workgroup, and a keccak256 call is a request in the cycle wave's mailbox in LDS (one 16-dword row
-// per lane: call_precompile -> keccak_request).  The helper serves two requests at a time, one per half wave: state
-// word x + 5y in lane x + 5y, the cross-lane terms of a round fetched with ds_bpermute in three dependent steps —
+// Keccak-f[1600] with the 25-word state in the registers of one lane.  With ZKW_KECCAK_HELPER every cycle wave has helper
+// waves in its workgroup, and a keccak256 call is a request in the cycle wave's mailbox in LDS (one 16-dword row per
+// lane: call_precompile -> keccak_request).  A helper serves one request at a time: the low half of state word i = x + 5y
+// in lane i, the high half in lane 32 + i, so that one ds_bpermute moves both halves of a word.  The cross-lane terms of
+// a round take three dependent fetch steps (13 ds_bpermute, 13 ALU operations per lane; measured on the cfg-3 lone batch:
+// a ds_bpermute costs ~13 clocks of issue, so that summing the neighbour columns in the lane itself — two steps, 21
+// fetches — is slower, and so are DPP row shifts + v_permlane32_swap in place of the three fetches of theta) —
 //   C[i]  = A[i] ^ A[i+5] ^ A[i+10] ^ A[i+15] ^ A[i+20]          (indices mod 25: the column of lane i)
-//   E[i]  = A[i] ^ C[x-1] ^ rotl(C[x+1], 1)                      (theta)
-//   T[i]  = rotl(E[i], rho[i])                                   (rho, in the lane that holds the word)
-//   A'[d] = T[src d] ^ (~T[src(x+1)] & T[src(x+2)]),  src(X, Y) = ((X + 3Y) % 5, X)   (pi and chi in one step) — and the
-// message bytes, the witnessed input words (precompile read queries: positions and sequence numbers handed over by the
-// requester, which has allocated them) straight from the arena of the instance.  The digest goes back through the row.
+//   E[i]  = A[i] ^ C[x-1] ^ rotl(C[x+1], 1)                      (theta; the rotation funnels the two halves of C[x+1])
+//   A'[d] = T[src d] ^ (~T[src(x+1)] & T[src(x+2)]),  T[s] = rotl(E[s], rho[s]),  src(X, Y) = ((X + 3Y) % 5, X)
+// (rho, pi, chi: the destination fetches both halves of the three words it needs and funnels them; which half is the
+// high operand — rotations by 32 and more exchange them — is folded into the fetch addresses).  The message bytes of
+// the next block are loaded while the current one is permuted, and the lanes that hold no state (25..31) read and
+// witness the input words of the block (precompile read queries at the stream positions and with the sequence numbers
+// the requester has allocated).  The digest goes back through the row.
 __device__ const unsigned char ZKW_KH_RHO[32] = {0,  1,  62, 28, 27, 36, 44, 6,  55, 20, 3, 10, 43, 25, 39, 41,
                                                  45, 15, 21, 8,  18, 2,  61, 56, 14, 0,  0, 0,  0,  0,  0,  0};
-// rotl of a 64-bit lane word by a per-lane amount: `swap` exchanges the halves (amounts >= 32), `s` = 32 - (amount % 32)
-// is the funnel shift.  Amount 0 — lane 0 only, no other rho offset is a multiple of 32 — is taken as 64: halves
-// exchanged twice (swap and s = 0, where the funnel returns its low operand).
-struct KhRot { bool swap; u32 s; };
-ZD KhRot kh_rot(u32 amount) { KhRot r; r.swap = amount >= 32u || amount == 0u; r.s = (32u - (amount & 31u)) & 31u; return r; }
-ZD void kh_rotl(u32& lo, u32& hi, const KhRot& r) {
-  const u32 a = r.swap ? hi : lo, b = r.swap ? lo : hi;  // (b:a) rotated left by amount % 32
-  lo = __builtin_amdgcn_alignbit(a, b, r.s);
-  hi = __builtin_amdgcn_alignbit(b, a, r.s);
-}
 ZD u32 kh_bp(u32 byte_addr, u32 v) { return (u32)__builtin_amdgcn_ds_bpermute((int)byte_addr, (int)v); }
 
-ZD void zkw_kh_serve(ZKW_KP P, u32 wave, u32 box, u32 r0, u32 r1, u32 tid) {
-  const u32 half = tid >> 5, idx = tid & 31u;
-  const u32 r = half ? r1 : r0;  // the request of this half wave (r1 = ~0: none)
-  const bool have = r != 0xffffffffu;
-  const u32 row = box + (have ? r : r0) * 64u;
-  const u32 f = zkw_lds_get(row), in_off = zkw_lds_get(row + 4u), in_len = have ? zkw_lds_get(row + 8u) : 0u;
+ZD void zkw_kh_serve(ZKW_KP P, u32 wave, u32 box, u32 r, u32 tid) {
+  const u32 h = tid >> 5, idx = tid & 31u;  // half of the word (0 = low), state index
+  const bool in_state = idx < 25u;
+  const u32 X = idx % 5u, Y = idx / 5u;
+  const u32 row = box + r * 64u;
+  const u32 f = zkw_lds_get(row), in_off = zkw_lds_get(row + 4u), in_len = zkw_lds_get(row + 8u);
   const u32 hwm = zkw_lds_get(row + 12u), pos = zkw_lds_get(row + 16u), seq0 = zkw_lds_get(row + 20u), ts = zkw_lds_get(row + 24u), page = zkw_lds_get(row + 28u);
   const u32 slot = f & 0xffffu;
   const bool is_aux = (f >> 16) & 1u, empty = (f >> 17) & 1u;
   const u32 L = P.L, words = is_aux ? P.A : P.H;
   const uint4* arena = is_aux ? P.aux_heap + (u64)wave * P.F * P.A * 2u * L : P.heap + (u64)wave * P.F * P.H * 2u * L;
   const u32 lim = empty ? 0u : (hwm < words ? hwm : words);  // words at and beyond read as zero (memory.rs:490-495)
-  const u32 w0 = in_off >> 5;
-  const u32 n_words = in_len ? ((in_off & 31u) + in_len + 31u) >> 5 : 0u;
-  // the witnessed reads: one word per lane and step
-  {
-    uint4* mem = P.mem_stream + (u64)wave * P.cap_mem * 3 + pos;
-    const u32 meta = (ZKW_MEM_FAT_PTR & ZKW_MQ_TYPE_MASK) | (1u << ZKW_MQ_KIND_SHIFT);
-    for (u32 i = idx; i < n_words; i += 32u) {
-      const u32 wi = w0 + i;
-      uint4 lo = make_uint4(0, 0, 0, 0), hi = make_uint4(0, 0, 0, 0);
-      if (wi < lim) {
-        const uint4* e = arena + (2u * (slot * words + wi) * L + r);
-        lo = zkw_gload4(e);
-        hi = zkw_gload4(e + L);
-      }
-      const u32 seq = seq0 + i < 255u ? seq0 + i : 255u;
-      zkw_stream_store(mem + i, make_uint4(ts, page, wi, r | (seq << 8) | (meta << 16)));
-      zkw_stream_store(mem + i + P.cap_mem, lo);
-      zkw_stream_store(mem + i + 2u * (u64)P.cap_mem, hi);
-    }
-  }
-  // the sponge
-  const u32 nb = have ? in_len / ZKW_KECCAK_RATE + 1u : 0u;
-  const u32 nb_max = max((u32)__builtin_amdgcn_readlane((int)nb, 0), (u32)__builtin_amdgcn_readlane((int)nb, 32));
-  const u32 lane0 = half * 32u;
-  const bool in_state = idx < 25u;
-  const u32 X = idx % 5u, Y = idx / 5u;
-#define ZKW_KH_LANE(i) ((in_state ? lane0 + (i) : tid) * 4u)
-  const u32 a_c1 = ZKW_KH_LANE((idx + 5u) % 25u), a_c2 = ZKW_KH_LANE((idx + 10u) % 25u), a_c3 = ZKW_KH_LANE((idx + 15u) % 25u), a_c4 = ZKW_KH_LANE((idx + 20u) % 25u);
-  const u32 xm1 = Y * 5u + (X + 4u) % 5u, xp1 = Y * 5u + (X + 1u) % 5u, xp2 = Y * 5u + (X + 2u) % 5u;
-  const u32 a_xm1 = ZKW_KH_LANE(xm1), a_xp1 = ZKW_KH_LANE(xp1);
+  const u32 w0 = in_off >> 5, phase = in_off & 31u;
+  const u32 n_words = in_len ? (phase + in_len + 31u) >> 5 : 0u;
+  const u32 nb = in_len / ZKW_KECCAK_RATE + 1u;
+  uint4* mem = P.mem_stream + (u64)wave * P.cap_mem * 3 + pos;
+  const u32 meta = (ZKW_MEM_FAT_PTR & ZKW_MQ_TYPE_MASK) | (1u << ZKW_MQ_KIND_SHIFT);
+  // fetch addresses (bytes: lane * 4); lanes outside the state fetch themselves
+#define ZKW_KH_LANE(hh, i) ((in_state ? (hh) * 32u + (i) : tid) * 4u)
+  const u32 a_c1 = ZKW_KH_LANE(h, (idx + 5u) % 25u), a_c2 = ZKW_KH_LANE(h, (idx + 10u) % 25u), a_c3 = ZKW_KH_LANE(h, (idx + 15u) % 25u), a_c4 = ZKW_KH_LANE(h, (idx + 20u) % 25u);
+  const u32 xm1 = Y * 5u + (X + 4u) % 5u, xp1 = Y * 5u + (X + 1u) % 5u;
+  const u32 a_xm1 = ZKW_KH_LANE(h, xm1), a_xp1_own = ZKW_KH_LANE(h, xp1), a_xp1_other = ZKW_KH_LANE(1u - h, xp1);
   // pi: destination (X, Y) takes the word of source x = (X + 3Y) % 5, y = X
-  const u32 s0 = in_state ? (X + 3u * Y) % 5u + 5u * X : 0u;
-  const u32 s1 = in_state ? ((xp1 % 5u) + 3u * Y) % 5u + 5u * (xp1 % 5u) : 0u;
-  const u32 s2 = in_state ? ((xp2 % 5u) + 3u * Y) % 5u + 5u * (xp2 % 5u) : 0u;
-  const u32 a_s0 = ZKW_KH_LANE(s0), a_s1 = ZKW_KH_LANE(s1), a_s2 = ZKW_KH_LANE(s2);
-#undef ZKW_KH_LANE
-  const KhRot rho = kh_rot(ZKW_KH_RHO[in_state ? idx : 0u]);
-  const u32 iota_lane = idx == 0 ? 0xffffffffu : 0u;
-  u32 lo = 0, hi = 0, dg_lo = 0, dg_hi = 0;
-  const unsigned char* bytes = (const unsigned char*)arena;
-  // this lane's eight bytes of block b of the padded message, little-endian (lanes 0..16 of a half wave)
-  auto block_word = [&](u32 b, u32& m0, u32& m1) {
-    m0 = 0; m1 = 0;
-    if (b >= nb || idx >= 17u) return;
+  u32 a_first[3], a_second[3], shift[3];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const u32 rel = b * ZKW_KECCAK_RATE + 8u * idx + (u32)i;  // byte of the padded message
+  for (int k = 0; k < 3; k++) {
+    const u32 xs = (X + (u32)k) % 5u;                       // the column of the destination this term stands for
+    const u32 sidx = in_state ? (xs + 3u * Y) % 5u + 5u * xs : 0u;
+    const u32 amount = ZKW_KH_RHO[sidx];
+    const bool swap = amount >= 32u || amount == 0u;        // (0 is taken as 64: both halves exchanged, funnel shift 0)
+    a_first[k] = ZKW_KH_LANE(swap ? 1u - h : h, sidx);      // high operand of the funnel
+    a_second[k] = ZKW_KH_LANE(swap ? h : 1u - h, sidx);
+    shift[k] = (32u - (amount & 31u)) & 31u;
+  }
+#undef ZKW_KH_LANE
+  const u32 iota_lane = idx == 0 ? 0xffffffffu : 0u;
+  const unsigned char* bytes = (const unsigned char*)arena;
+  // this lane's four bytes of block b of the padded message, little-endian (lanes 0..16 of either half)
+  auto block_dword = [&](u32 b) -> u32 {
+    u32 m = 0;
+    if (b >= nb || idx >= 17u) return m;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const u32 rel = b * ZKW_KECCAK_RATE + 8u * idx + 4u * h + (u32)i;  // byte of the padded message
       u32 v = 0;
       if (rel < in_len) {
         const u32 p = in_off + rel, wi = p >> 5, back = 31u - (p & 31u);  // words are big-endian: byte `back` of the little-endian value
@@ -2725,37 +2705,54 @@ ZD void zkw_kh_serve(ZKW_KP P, u32 wave, u32 box, u32 r0, u32 r1, u32 tid) {
         v = 0x01u;  // pad10*1 with the legacy domain byte
       }
       if (rel == nb * ZKW_KECCAK_RATE - 1u) v |= 0x80u;
-      if (i < 4) m0 |= v << (8 * i); else m1 |= v << (8 * (i - 4));
+      m |= v << (8 * i);
     }
+    return m;
   };
-  u32 m0, m1;
-  block_word(0, m0, m1);
-  for (u32 b = 0; b < nb_max; b++) {
-    lo ^= m0;
-    hi ^= m1;
-    block_word(b + 1u, m0, m1);  // (in flight during the permutation)
+  u32 st = 0;
+  u32 m = block_dword(0);
+  u32 witnessed = 0;  // input words read and witnessed so far
+  for (u32 b = 0; b < nb; b++) {
+    st ^= m;
+    m = block_dword(b + 1u);  // (in flight during the permutation)
+    {  // the words this block reaches into for the first time: one per spare lane
+      const u32 end = (b + 1u) * ZKW_KECCAK_RATE < in_len ? (b + 1u) * ZKW_KECCAK_RATE : in_len;
+      const u32 upto = in_len ? (phase + end + 31u) >> 5 : 0u;
+      const u32 i = witnessed + (idx - 25u);
+      if (h == 0 && idx >= 25u && i < upto) {
+        const u32 wi = w0 + i;
+        uint4 lo = make_uint4(0, 0, 0, 0), hi = make_uint4(0, 0, 0, 0);
+        if (wi < lim) {
+          const uint4* e = arena + (2u * (slot * words + wi) * L + r);
+          lo = zkw_gload4(e);
+          hi = zkw_gload4(e + L);
+        }
+        const u32 seq = seq0 + i < 255u ? seq0 + i : 255u;
+        zkw_stream_store(mem + i, make_uint4(ts, page, wi, r | (seq << 8) | (meta << 16)));
+        zkw_stream_store(mem + i + P.cap_mem, lo);
+        zkw_stream_store(mem + i + 2u * (u64)P.cap_mem, hi);
+      }
+      witnessed = upto;
+    }
 #pragma unroll
     for (int round = 0; round < 24; round++) {
-      const u32 c_lo = lo ^ kh_bp(a_c1, lo) ^ kh_bp(a_c2, lo) ^ kh_bp(a_c3, lo) ^ kh_bp(a_c4, lo);
-      const u32 c_hi = hi ^ kh_bp(a_c1, hi) ^ kh_bp(a_c2, hi) ^ kh_bp(a_c3, hi) ^ kh_bp(a_c4, hi);
-      const u32 m_lo = kh_bp(a_xm1, c_lo), m_hi = kh_bp(a_xm1, c_hi), p_lo = kh_bp(a_xp1, c_lo), p_hi = kh_bp(a_xp1, c_hi);
-      u32 e_lo = lo ^ m_lo ^ __builtin_amdgcn_alignbit(p_lo, p_hi, 31), e_hi = hi ^ m_hi ^ __builtin_amdgcn_alignbit(p_hi, p_lo, 31);
-      kh_rotl(e_lo, e_hi, rho);  // rho at the source, pi and chi at the destination
-      const u32 b0_lo = kh_bp(a_s0, e_lo), b0_hi = kh_bp(a_s0, e_hi), b1_lo = kh_bp(a_s1, e_lo), b1_hi = kh_bp(a_s1, e_hi), b2_lo = kh_bp(a_s2, e_lo), b2_hi = kh_bp(a_s2, e_hi);
-      lo = b0_lo ^ (~b1_lo & b2_lo) ^ (iota_lane & (u32)ZKW_KECCAK_RC[round]);
-      hi = b0_hi ^ (~b1_hi & b2_hi) ^ (iota_lane & (u32)(ZKW_KECCAK_RC[round] >> 32));
+      const u32 c = st ^ kh_bp(a_c1, st) ^ kh_bp(a_c2, st) ^ kh_bp(a_c3, st) ^ kh_bp(a_c4, st);
+      const u32 e = st ^ kh_bp(a_xm1, c) ^ __builtin_amdgcn_alignbit(kh_bp(a_xp1_own, c), kh_bp(a_xp1_other, c), 31);
+      const u32 t0 = __builtin_amdgcn_alignbit(kh_bp(a_first[0], e), kh_bp(a_second[0], e), shift[0]);
+      const u32 t1 = __builtin_amdgcn_alignbit(kh_bp(a_first[1], e), kh_bp(a_second[1], e), shift[1]);
+      const u32 t2 = __builtin_amdgcn_alignbit(kh_bp(a_first[2], e), kh_bp(a_second[2], e), shift[2]);
+      const u32 rc = h ? (u32)(ZKW_KECCAK_RC[round] >> 32) : (u32)ZKW_KECCAK_RC[round];
+      st = t0 ^ (~t1 & t2) ^ (iota_lane & rc);
     }
-    if (b + 1u == nb) { dg_lo = lo; dg_hi = hi; }
   }
-  if (have && idx < 4u) {  // digest word = state words 0..3, big-endian (as precompile_keccak256 writes it)
-    zkw_lds_put(row + 32u + (7u - 2u * idx) * 4u, __builtin_bswap32(dg_lo));
-    zkw_lds_put(row + 32u + (6u - 2u * idx) * 4u, __builtin_bswap32(dg_hi));
-  }
+  if (idx < 4u) zkw_lds_put(row + 32u + (7u - 2u * idx - h) * 4u, __builtin_bswap32(st));  // digest = state words 0..3, big-endian (as precompile_keccak256 writes it)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if (have && idx == 0) zkw_lds_put(row, 0);  // served
+  if (tid == 0) zkw_lds_put(row, 0);  // served
 }
 
-ZD void zkw_kh_helper(const zkw_launch_args& A, u32 tid, u32 h) {
+// helper `sub` of the `n_sub` helpers of cycle wave h: requests of the rows r with r % n_sub == sub; the first also chains
+// the wave's decommits (ZKW_DQ_HELPER)
+ZD void zkw_kh_helper(const zkw_launch_args& A, u32 tid, u32 h, u32 sub, u32 n_sub) {
   const u32 g = A.waves_per_group;
   u32 b, wave;
   if (!zkw_find_wave(A, blockIdx.x * g + h, b, wave)) return;
@@ -2765,18 +2762,20 @@ ZD void zkw_kh_helper(const zkw_launch_args& A, u32 tid, u32 h) {
   const u32 area = area0 + h * ZKW_DQ_HELPER_BYTES, box = area0 + g * ZKW_DQ_HELPER_BYTES + h * ZKW_KH_BYTES;
   u32 consumed = 0;
   for (;;) {
-    const u64 req = __ballot(tid < ZKW_KH_MAX_LANES && (zkw_lds_get(box + tid * 64u) >> 31));
+    const u64 req = __ballot(tid < ZKW_KH_MAX_LANES && tid % n_sub == sub && (zkw_lds_get(box + tid * 64u) >> 31));
     if (req) {
-      const u32 r0 = (u32)__builtin_ctzll(req);
-      const u64 rest = req & (req - 1);
-      const u32 r1 = rest ? (u32)__builtin_ctzll(rest) : 0xffffffffu;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the heap words the requesters stored
-      zkw_kh_serve(P, wave, box, r0, r1, tid);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the heap words the requester stored
+      zkw_kh_serve(P, wave, box, (u32)__builtin_ctzll(req), tid);
       continue;
     }
-    const u32 st = zkw_dq_serve(P, wave, area, consumed, tid);
-    if (st == 2u) break;  // (a wave that has left its loop has no request pending: the requester waits for its digest)
-    if (st == 0u) __builtin_amdgcn_s_sleep(2);
+    if (sub == 0) {
+      const u32 st = zkw_dq_serve(P, wave, area, consumed, tid);
+      if (st == 2u) break;  // (a wave that has left its loop has no request pending: the requester waits for its digest)
+      if (st == 0u) __builtin_amdgcn_s_sleep(2);
+    } else {
+      if (zkw_lds_get(area + 8u)) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
   }
 }
 #endif
@@ -2840,7 +2839,10 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
   __syncthreads();
 #ifdef __HIP_DEVICE_COMPILE__
   if (is_helper) {
-    if (A.debug_flags & ZKW_KECCAK_HELPER) zkw_kh_helper(A, tid, wib - A.waves_per_group);
+    if (A.debug_flags & ZKW_KECCAK_HELPER) {
+      const u32 n_sub = A.helpers / A.waves_per_group, hx = wib - A.waves_per_group;
+      zkw_kh_helper(A, tid, hx / n_sub, hx % n_sub, n_sub);
+    }
     else zkw_dq_helper(A, tid);
     return;
   }

@@ -1056,20 +1056,24 @@ static int enqueue_run(zkw_batch* const* bs, uint32_t n, uint32_t max_cycles, hi
       A.debug_flags |= ZKW_DQ_HELPER;
     }
   }
-  // Batches of thin waves (<= 8 instances per wave: a caller after latency, not throughput): every cycle wave gets a helper
-  // wave of its own that runs its keccak256 calls lane-parallel (zkw_kh_helper) and, inside a whole step, chains its
-  // decommits.  Workgroups of g cycle + g helper waves, the smallest g that fits the launch in one round of workgroups.
+  // Batches of thin waves (<= 8 instances per wave: a caller after latency, not throughput): every cycle wave gets helper
+  // waves of its own that run its keccak256 calls lane-parallel, one call per helper at a time (zkw_kh_helper) and, inside a
+  // whole step, chain its decommits.  Workgroups of g cycle + g * n_sub helper waves: as many helpers per cycle wave as it
+  // has lanes (up to 4), the smallest g, as long as the launch stays one round of workgroups.
   if (c->wave_width > 1 && A.max_L <= ZKW_KH_MAX_LANES && !c->opt_waves_per_group && !(c->opt_debug_flags & ZKW_NO_DQ_HELPER)) {
-    for (uint32_t g = 1; 2 * g <= ZKW_MAX_WAVES_PER_GROUP; g++) {
-      const uint32_t lds = zkw_cycle_kernel_lds_bytes(ZKW_WAVE, g) + g * (ZKW_DQ_HELPER_BYTES + ZKW_KH_BYTES);
-      const uint32_t per_cu = std::min(ZKW_MAX_WAVES_PER_GROUP / (2 * g), (160u * 1024u) / lds);
-      const uint32_t n_wg = (A.wave_base[n] + g - 1) / g;
-      if (!per_cu || n_wg > (uint32_t)c->n_cus * per_cu) continue;
-      A.waves_per_group = g;
-      A.helpers = g;
-      A.debug_flags |= ZKW_KECCAK_HELPER;
-      if (whole_step && inline_decommit) A.debug_flags |= ZKW_DQ_HELPER; else A.debug_flags &= ~ZKW_DQ_HELPER;
-      break;
+    bool done = false;
+    for (uint32_t n_sub = std::min(A.max_L, 4u) >= 4 ? 4 : (A.max_L >= 2 ? 2 : 1); n_sub && !done; n_sub >>= 1) {
+      for (uint32_t g = 1; g * (1 + n_sub) <= ZKW_MAX_WAVES_PER_GROUP && !done; g++) {
+        const uint32_t lds = zkw_cycle_kernel_lds_bytes(ZKW_WAVE, g) + g * (ZKW_DQ_HELPER_BYTES + ZKW_KH_BYTES);
+        const uint32_t per_cu = std::min(ZKW_MAX_WAVES_PER_GROUP / (g * (1 + n_sub)), (160u * 1024u) / lds);
+        const uint32_t n_wg = (A.wave_base[n] + g - 1) / g;
+        if (!per_cu || n_wg > (uint32_t)c->n_cus * per_cu) continue;
+        A.waves_per_group = g;
+        A.helpers = g * n_sub;
+        A.debug_flags |= ZKW_KECCAK_HELPER;
+        if (whole_step && inline_decommit) A.debug_flags |= ZKW_DQ_HELPER; else A.debug_flags &= ~ZKW_DQ_HELPER;
+        done = true;
+      }
     }
   }
   // HIP events around the launch: on the first batch of the group (its kernel_ms is the launch's duration)

@@ -23,7 +23,7 @@ for k in range(count):
     kb = tuple(rng.choice([0, 1, 31, 32, 33, 135, 136, 137, 200, 271, 272, 273, rng.randrange(0, 700)]) for _ in range(4))
     ku = tuple(rng.randrange(0, 32) for _ in range(4))
     sr = tuple(rng.choice([1, 2, 3, 5, 8, rng.randrange(1, 20)]) for _ in range(4))
-    lanes = (0, 64, 16, 4)[k % 4]
+    lanes = (0, 64, 16, 4, 2, 8, 1)[k % 7]  # (<= 8: keccak256 served by helper waves)
     wl = synth.make(3, isa, n_instances=96, seed=seed, keccak_bytes=kb, keccak_unalign=ku, sha_rounds=sr)
     bo = orc.create_batch(wl); bo.reset(); bo.run(wl.n_cycles); bo.sync()
     wl.limits["lanes_per_wave"] = lanes
