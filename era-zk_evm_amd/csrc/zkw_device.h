@@ -171,6 +171,7 @@ typedef struct zkw_kparams {
 #define ZKW_DQ_HELPER (1u << 27)     /* zkw_launch_args.debug_flags: decommits are posted to the workgroup's helper wave */
 #define ZKW_NO_DQ_HELPER (1u << 28)  /* ZKW_OPT_DEBUG_FLAGS: never launch helper waves (A/B) */
 #define ZKW_DQ_HELPER_BYTES 1552u    /* LDS per cycle wave: 16 B of counters + a ring of 2 x [3][64] dwords */
+#define ZKW_NO_PREFETCH (1u << 30)   /* ZKW_OPT_DEBUG_FLAGS: no heap prefetch for the next instruction (A/B) */
 #define ZKW_KECCAK_HELPER (1u << 29) /* zkw_launch_args.debug_flags: every cycle wave has helper waves of its own that serve its keccak256
                                         calls lane-parallel (one lane per half state word: zkw_kh_helper) — batches of thin waves (<= 8 lanes) only */
 #define ZKW_KH_MAX_LANES 8u          /* ... which is the number of request rows in the mailbox of a cycle wave */
@@ -188,6 +189,7 @@ typedef struct zkw_launch_args {
                          (ZKW_DQ_HELPER in debug_flags; only when the CUs have a wave slot to spare); a multiple k of waves_per_group with
                          ZKW_KECCAK_HELPER: helpers h * k .. h * k + k - 1 serve cycle wave h (keccak256 calls of its lanes r with r % k = the
                          helper's index; the first also its decommits under ZKW_DQ_HELPER) */
+  uint32_t lds_sink;  /* byte offset, in the dynamic LDS of a workgroup, of the 256 bytes the prefetches of the cycle kernel land in (set by the launcher) */
   uint32_t n_batches;
   uint32_t run_cycles;
   uint32_t debug_flags; /* profiling ablations / test hooks only (ZKW_DEBUG_FLAGS): 1 = no CycleRecord stores, 2 = no stream stores, 4 = one lane per group */

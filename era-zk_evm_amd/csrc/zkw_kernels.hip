@@ -1302,6 +1302,44 @@ ZD void op_ptr(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
   dst0_update(P, sh, rf, s, ps.dst0, d.dst0, result, true);
 }
 
+#ifdef __HIP_DEVICE_COMPILE__
+// Heap prefetch for the instructions behind the current one.  A heap word comes from HBM (the arenas of a launch are
+// hundreds of MB): ~2000 clocks between the issue of a UMA's word loads and their return, a wave per SIMD and nothing to
+// overlap them with — the largest single wait of a UMA cycle.  When a code word is fetched its four
+// opcodes are decoded at once, so the instructions behind the current one are known up to three cycles ahead, and when
+// one of them is a heap access with an immediate address (src0 = UseImm16Only: the offset is in the instruction, no
+// register involved) its words can be requested now: two `global_load_lds_dword` per word (one per 16-byte plane: each
+// lane touches its own 64-byte segment), results written to a 256-byte sink in LDS that nobody reads — a load without a
+// destination register, so nothing to keep alive and nothing to wait for: the lines are in L2 when the access itself
+// comes.  A hint only: a jump in between, a frame change or a word beyond the written part of the heap make it useless
+// or skip it, never wrong.  (Not for register-addressed accesses — the register may be written by an instruction in
+// between — nor across code words: op_uma requests those itself, early in their own cycle.)  Same-box A/B on the
+// driver's command: +3 % (profiles/r05_prefetch_ab.txt); checking the next opcode every cycle instead (an LDS read of its
+// slot) gave the same.
+// the words an access at byte offset `off` of a heap / aux-heap page touches (page in arena slot `slot`, written up to `hwm`)
+ZD void prefetch_page_words(const uint4* arena, u32 words_per_page, u32 L, u32 lds_sink, u32 slot, u32 hwm, u32 off) {
+  const u32 lane = zkw_lane_id();
+  const u32 w0 = off >> 5;
+  const u32 last = (off & 31u) ? w0 + 1u : w0;
+  for (u32 w = w0; w <= last; w++) {
+    if (w >= hwm) continue;  // words at and beyond the mark (<= the page size) read as zero without a memory access
+    // (slot * words + w) * L with the scalars spelled out as scalar operands: left to itself the optimiser hoists vector
+    // copies of them out of the cycle loop and reloads them from scratch memory here — behind an s_waitcnt vmcnt(0), i.e.
+    // behind the stores of the previous cycle
+    u32 row, first;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row) : "v"(slot), "s"(words_per_page), "v"(w));
+    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(first) : "v"(row), "s"(L));
+    const uint4* p = arena + ((u64)2u * first + lane);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, off\n\tglobal_load_lds_dword %1, off" : : "v"(p), "v"(p + L), "s"(lds_sink) : "m0");
+  }
+}
+ZD void prefetch_uma_words(ZKW_KP P, const Shared& sh, Lane& s, u32 lds_sink, u32 attr, u32 word_hi) {
+  const u32 v = ZKW_ATTR_VARIANT(attr);
+  if (ZKW_ATTR_OPCODE(attr) != ZKW_OP_UMA || ZKW_ATTR_SRC0(attr) != ZKW_MODE_IMM || (v != ZKW_UMA_HEAP_READ && v != ZKW_UMA_HEAP_WRITE)) return;
+  prefetch_page_words(sh.heap, P.H, P.L, lds_sink, cfv_slot(sh, s), cfv_heap_hwm(sh, s), word_hi & 0xffffu);
+}
+#endif
+
 // uma.rs:26-425
 template <class RF>
 ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pre& ps) {
@@ -1328,6 +1366,14 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
     ZKW_LGKM_PROBE(7 /* UMA frame fields */)
   }
   const u32 f_hwm_in = f_hwm;
+#ifdef __HIP_DEVICE_COMPILE__
+  // the accesses the code-word prefetch did not see — a register-held address, the first opcode of a code word, the aux
+  // heap — are requested here, ~1500 clocks (exceptions, growth, query bookkeeping) before their loads are issued for
+  // real (same-box A/B: +1.5 % on top of the code-word prefetch)
+  if (!is_ptr_read && !(sh.debug_flags & ZKW_NO_PREFETCH) && (!is_heap || ZKW_ATTR_SRC0(d.attr) != ZKW_MODE_IMM || ((ps.new_pc - 1u) & 3u) == 0) &&
+      !(ps.src0.w[1] | ps.src0.w[2] | ps.src0.w[3] | ps.src0.w[4] | ps.src0.w[5] | ps.src0.w[6] | ps.src0.w[7]))
+    prefetch_page_words(is_heap ? sh.heap : sh.aux_heap, is_heap ? P.H : P.A, P.L, (u32)__builtin_amdgcn_readfirstlane((int)*ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor + 2)), f_slot, f_hwm, ps.src0.w[0]);
+#endif
   u32 mem_type;
   if (is_ptr_read) {
     mem_type = ZKW_MEM_FAT_PTR;
@@ -2855,6 +2901,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
     const u32 area0 = (u32)(size_t)(ZKW_LDS_AS uint4*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + A.waves_per_group * zkw_wave_lds_units());
     *ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor) = A.helpers ? area0 + wib * ZKW_DQ_HELPER_BYTES : 0u;  // dq_helper_area
     *ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor + 1) = area0 + A.waves_per_group * ZKW_DQ_HELPER_BYTES + wib * ZKW_KH_BYTES;  // kh_box (ZKW_KECCAK_HELPER)
+    *ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor + 2) = (u32)(size_t)(ZKW_LDS_AS char*)((char*)zkw_lds + A.lds_sink);  // the prefetch sink (op_uma)
 #endif
   }
 #ifdef __HIP_DEVICE_COMPILE__
@@ -2865,6 +2912,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
 #else
   for (u32 i = tid; i < 4; i += P.wave_threads) sh.cursor[i] = P.cursors[wave * 4 + i];
   zkw_wave_lds_fence();
+#endif
+#ifdef __HIP_DEVICE_COMPILE__
+  const u32 lds_sink = zkw_uniform((u32)(size_t)(ZKW_LDS_AS char*)((char*)zkw_lds + A.lds_sink));
 #endif
   const u32 cycle_base = P.wave_cycles[wave];  // wave-cycles run since the reset (records / directory index)
   // first launch after a reset: the lanes start from the pristine images (the reset does not copy them — 2.5 MB per 4096
@@ -2965,6 +3015,13 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
 #pragma unroll
           for (int i = 0; i < 4; i++) ZKW_SLOT_WRITE(sh, s.lane, i, make_uint4(word.w[2 * i], word.w[2 * i + 1], e4[i].x, e4[i].y));
           s.prev_super_pc = super_pc;
+#ifdef __HIP_DEVICE_COMPILE__
+          if (!(A.debug_flags & ZKW_NO_PREFETCH)) {  // the opcodes behind this one (opcode k of the word = slot 3 - k): prefetch_uma_words
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+              if (3u - (u32)i > sub_pc) prefetch_uma_words(P, sh, s, lds_sink, e4[i].x, word.w[2 * i + 1]);
+          }
+#endif
         }
       } else {  // :104-115
         s.flags &= ~FLAG_PENDING;
@@ -3398,7 +3455,11 @@ extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_gr
 // host-callable launcher (keeps <<<>>> out of the runtime)
 extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_launch_args* A, hipStream_t stream) {
   const u32 g = A->waves_per_group;
-  const uint32_t lds = zkw_cycle_kernel_lds_bytes(A->max_L, g) + (A->helpers ? g * (ZKW_DQ_HELPER_BYTES + ((A->debug_flags & ZKW_KECCAK_HELPER) ? ZKW_KH_BYTES : 0u)) : 0u);
+  const uint32_t lds_used = zkw_cycle_kernel_lds_bytes(A->max_L, g) + (A->helpers ? g * (ZKW_DQ_HELPER_BYTES + ((A->debug_flags & ZKW_KECCAK_HELPER) ? ZKW_KH_BYTES : 0u)) : 0u);
+  const uint32_t lds = lds_used + 256u;  // + the sink of the prefetches (prefetch_next_uma)
+  zkw_launch_args args = *A;
+  args.lds_sink = lds_used;
+  A = &args;
   if (lds > 64u * 1024u) {
     // dynamic LDS above the 64 KB default needs an explicit opt-in (not reached by the current layout: 41 KB per workgroup).  The
     // attribute is per device: remember the opted-in size per device, under a lock (contexts on several devices and
