@@ -2151,7 +2151,9 @@ ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   else if (addr_low == P.consts.sha256_precompile_address) which = 1;
   else if (addr_low == P.consts.ecrecover_precompile_address) which = 2;
 #ifdef __HIP_DEVICE_COMPILE__
-  if (which == 0 && (sh.debug_flags & ZKW_KECCAK_HELPER)) {
+  // (lengths near 2^32 — no real call: the stream capacity ends it — keep the one path whose arithmetic on them the oracle
+  // is checked against; the helper's block count must stay bounded by the positions the requester could allocate)
+  if (which == 0 && (sh.debug_flags & ZKW_KECCAK_HELPER) && q.key.w[1] < 0x40000000u) {
     keccak_request(P, sh, s, q);
     which = 3;
   }
