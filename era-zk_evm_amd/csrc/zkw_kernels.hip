@@ -454,6 +454,10 @@ ZKW_CFV_EMU(heap_hwm, CF_HEAP_HWM)
 #define ZKW_PIN_SGPR(x) ((void)0)
 #endif
 extern __shared__ uint4 zkw_lds[];
+// dynamic LDS of a workgroup, in 16-byte units: ISA table | 256-byte sink of the prefetches (prefetch_page_words; kept below
+// 64 KB whatever the workgroup size) | one area per cycle wave | the hand-over areas of the helper waves
+#define ZKW_LDS_SINK_UNITS 16u
+#define ZKW_LDS_WAVES0 (ZKW_ISA_TABLE_SIZE / 2 + ZKW_LDS_SINK_UNITS)
 // 16-byte units of LDS per wave: cursors | parameter-block pointer, debug flags | cold | previous_code_word | pending instruction | transfer value
 ZD u32 zkw_wave_lds_units() { return 2u + (ZKW_COLD_FIELDS / 4u) * ZKW_LDS_STRIDE + 4u * ZKW_LDS_STRIDE + ZKW_LDS_STRIDE + 2u * ZKW_LDS_STRIDE; }
 // `wib` (wave in workgroup), `wave` and `dbg` must be wave-uniform
@@ -473,7 +477,7 @@ ZD void shared_setup(Shared& sh, ZKW_KP P, u32 dbg, u32 wib, u32 wave, bool pin)
     ZKW_PIN_SGPR(sh.L); ZKW_PIN_SGPR(sh.F); ZKW_PIN_SGPR(sh.S); ZKW_PIN_SGPR(sh.H); ZKW_PIN_SGPR(sh.A); ZKW_PIN_SGPR(sh.cap_mem);
     ZKW_PIN_SGPR(sh.stack_vals); ZKW_PIN_SGPR(sh.stack_ptrs); ZKW_PIN_SGPR(sh.heap); ZKW_PIN_SGPR(sh.aux_heap); ZKW_PIN_SGPR(sh.blob_words);
   }
-  uint4* wl = zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + wib * zkw_wave_lds_units();
+  uint4* wl = zkw_lds + ZKW_LDS_WAVES0 + wib * zkw_wave_lds_units();
   sh.isa = (uint2*)zkw_lds;                                  // 16 KB
   sh.cursor = (u32*)wl;                                      // 16 B
   sh.cold = (u32*)(wl + 2);                                  // ZKW_COLD_FIELDS * stride * 4 B   (wl[1]: see zkw_heavy_entry)
@@ -1369,7 +1373,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
 #ifdef __HIP_DEVICE_COMPILE__
   // the accesses the code-word prefetch did not see — a register-held address, the first opcode of a code word, the aux
   // heap — are requested here, ~1500 clocks (exceptions, growth, query bookkeeping) before their loads are issued for
-  // real (same-box A/B: +1.5 % on top of the code-word prefetch)
+  // real (same-box A/B: +1.5 % on top of the code-word prefetch; requesting the covered ones here again changes nothing)
   if (!is_ptr_read && !(sh.debug_flags & ZKW_NO_PREFETCH) && (!is_heap || ZKW_ATTR_SRC0(d.attr) != ZKW_MODE_IMM || ((ps.new_pc - 1u) & 3u) == 0) &&
       !(ps.src0.w[1] | ps.src0.w[2] | ps.src0.w[3] | ps.src0.w[4] | ps.src0.w[5] | ps.src0.w[6] | ps.src0.w[7]))
     prefetch_page_words(is_heap ? sh.heap : sh.aux_heap, is_heap ? P.H : P.A, P.L, (u32)__builtin_amdgcn_readfirstlane((int)*ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor + 2)), f_slot, f_hwm, ps.src0.w[0]);
@@ -2200,7 +2204,7 @@ ZD void lane_unpack(Lane& s, const zkw_v16& a) {
 template <u32 OPCODE, int KIND>
 ZD zkw_v16 zkw_heavy_body(zkw_v16 a, zkw_v16 b) {
   const u32 wib = zkw_uniform(threadIdx.x / ZKW_WAVE);
-  const uint4 hdr = *(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + wib * zkw_wave_lds_units() + 1);  // written by the kernel prologue
+  const uint4 hdr = *(zkw_lds + ZKW_LDS_WAVES0 + wib * zkw_wave_lds_units() + 1);  // written by the kernel prologue
   const zkw_kparams ZKW_CONST_AS* Pp = (const zkw_kparams ZKW_CONST_AS*)(((u64)zkw_uniform(hdr.y) << 32) | zkw_uniform(hdr.x));
   ZKW_KP P = *Pp;
   Shared sh;
@@ -2272,7 +2276,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
 static __device__ __noinline__ zkw_v16 zkw_vec_exec(zkw_v16 a, zkw_v16 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const u32 wib = zkw_uniform(threadIdx.x / ZKW_WAVE);
-  const uint4 hdr = *(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + wib * zkw_wave_lds_units() + 1);  // written by the kernel prologue
+  const uint4 hdr = *(zkw_lds + ZKW_LDS_WAVES0 + wib * zkw_wave_lds_units() + 1);  // written by the kernel prologue
   const zkw_kparams ZKW_CONST_AS* Pp = (const zkw_kparams ZKW_CONST_AS*)(((u64)zkw_uniform(hdr.y) << 32) | zkw_uniform(hdr.x));
   ZKW_KP P = *Pp;
   Shared sh;
@@ -2659,7 +2663,7 @@ ZD u32 zkw_dq_serve(ZKW_KP P, u32 wave, u32 area, u32& consumed, u32 tid) {
 
 ZD void zkw_dq_helper(const zkw_launch_args& A, u32 tid) {
   const u32 g = A.waves_per_group;
-  const u32 area0 = (u32)(size_t)(ZKW_LDS_AS uint4*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + g * zkw_wave_lds_units());
+  const u32 area0 = (u32)(size_t)(ZKW_LDS_AS uint4*)(zkw_lds + ZKW_LDS_WAVES0 + g * zkw_wave_lds_units());
   u32 consumed[ZKW_MAX_WAVES_PER_GROUP];
 #pragma unroll
   for (int h = 0; h < ZKW_MAX_WAVES_PER_GROUP; h++) consumed[h] = 0;
@@ -2806,7 +2810,7 @@ ZD void zkw_kh_helper(const zkw_launch_args& A, u32 tid, u32 h, u32 sub, u32 n_s
   if (!zkw_find_wave(A, blockIdx.x * g + h, b, wave)) return;
   ZKW_KP P = *(const zkw_kparams ZKW_CONST_AS*)A.kp[b];
   if (wave >= P.n_waves) return;
-  const u32 area0 = (u32)(size_t)(ZKW_LDS_AS uint4*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + g * zkw_wave_lds_units());
+  const u32 area0 = (u32)(size_t)(ZKW_LDS_AS uint4*)(zkw_lds + ZKW_LDS_WAVES0 + g * zkw_wave_lds_units());
   const u32 area = area0 + h * ZKW_DQ_HELPER_BYTES, box = area0 + g * ZKW_DQ_HELPER_BYTES + h * ZKW_KH_BYTES;
   u32 consumed = 0;
   for (;;) {
@@ -2879,7 +2883,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
 #endif
 #ifdef __HIP_DEVICE_COMPILE__
   if (is_helper) {  // counters and entries of every hand-over area start empty (before the barrier: the cycle waves post after it)
-    u32* area = (u32*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + A.waves_per_group * zkw_wave_lds_units());
+    u32* area = (u32*)(zkw_lds + ZKW_LDS_WAVES0 + A.waves_per_group * zkw_wave_lds_units());
     const u32 per_wave = (ZKW_DQ_HELPER_BYTES + ((A.debug_flags & ZKW_KECCAK_HELPER) ? ZKW_KH_BYTES : 0u)) / 4u;
     for (u32 i = tid + (wib - A.waves_per_group) * A.wave_threads; i < A.waves_per_group * per_wave; i += A.helpers * A.wave_threads) area[i] = 0;
   }
@@ -2898,9 +2902,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
   if (beyond || wave >= P.n_waves) return;  // tail workgroup: no further workgroup-level barrier below
   if (tid == 0) {  // what zkw_heavy_entry needs and cannot take through its argument registers
     const u64 kp = (u64)A.kp[batch_idx];
-    zkw_lds[ZKW_ISA_TABLE_SIZE / 2 + wib * zkw_wave_lds_units() + 1] = make_uint4((u32)kp, (u32)(kp >> 32), A.debug_flags, wave);
+    zkw_lds[ZKW_LDS_WAVES0 + wib * zkw_wave_lds_units() + 1] = make_uint4((u32)kp, (u32)(kp >> 32), A.debug_flags, wave);
 #ifdef __HIP_DEVICE_COMPILE__
-    const u32 area0 = (u32)(size_t)(ZKW_LDS_AS uint4*)(zkw_lds + ZKW_ISA_TABLE_SIZE / 2 + A.waves_per_group * zkw_wave_lds_units());
+    const u32 area0 = (u32)(size_t)(ZKW_LDS_AS uint4*)(zkw_lds + ZKW_LDS_WAVES0 + A.waves_per_group * zkw_wave_lds_units());
     *ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor) = A.helpers ? area0 + wib * ZKW_DQ_HELPER_BYTES : 0u;  // dq_helper_area
     *ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor + 1) = area0 + A.waves_per_group * ZKW_DQ_HELPER_BYTES + wib * ZKW_KH_BYTES;  // kh_box (ZKW_KECCAK_HELPER)
     *ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor + 2) = (u32)(size_t)(ZKW_LDS_AS char*)((char*)zkw_lds + A.lds_sink);  // the prefetch sink (op_uma)
@@ -3253,6 +3257,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
       }
     }
   }
+#ifdef __HIP_DEVICE_COMPILE__
+  if (A.helpers && tid == 0) *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(dq_helper_area(sh) + 8u)) = 1u;  // every lane has left the loop: nothing more will be posted (before the barriers of the profiling builds below: the helper waves leave on it)
+#endif
 #ifdef ZKW_PROFILE
   __syncthreads();
   if (blockIdx.x == 1 && threadIdx.x == 0) {
@@ -3269,9 +3276,6 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
     for (int o = 0; o < 16; o++)
       if (zw_acc[0][16 + o]) printf("ZKWWAIT site %d: %llu waits, %llu clocks in total\n", o, zw_acc[0][16 + o], zw_acc[0][o]);
   }
-#endif
-#ifdef __HIP_DEVICE_COMPILE__
-  if (A.helpers && tid == 0) *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(dq_helper_area(sh) + 8u)) = 1u;  // every lane has left the loop: nothing more will be posted
 #endif
   // wave-cycles executed = the maximum over the lanes (lanes leave the loop at different iterations)
 #pragma unroll
@@ -3451,16 +3455,15 @@ extern "C" hipError_t zkw_launch_reset_kernel(const zkw_fused_table* T, hipStrea
 // dynamic LDS per workgroup: ISA table + per wave (cursors + per-lane cold state and previous_code_word)
 extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_group) {
   (void)L;  // rows have a fixed lane stride
-  return ZKW_ISA_TABLE_SIZE * 8 + waves_per_group * (32 + ZKW_LDS_STRIDE * (ZKW_COLD_FIELDS * 4 + 64 + 16 + 32));
+  return ZKW_ISA_TABLE_SIZE * 8 + ZKW_LDS_SINK_UNITS * 16 + waves_per_group * (32 + ZKW_LDS_STRIDE * (ZKW_COLD_FIELDS * 4 + 64 + 16 + 32));
 }
 
 // host-callable launcher (keeps <<<>>> out of the runtime)
 extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_launch_args* A, hipStream_t stream) {
   const u32 g = A->waves_per_group;
-  const uint32_t lds_used = zkw_cycle_kernel_lds_bytes(A->max_L, g) + (A->helpers ? g * (ZKW_DQ_HELPER_BYTES + ((A->debug_flags & ZKW_KECCAK_HELPER) ? ZKW_KH_BYTES : 0u)) : 0u);
-  const uint32_t lds = lds_used + 256u;  // + the sink of the prefetches (prefetch_next_uma)
+  const uint32_t lds = zkw_cycle_kernel_lds_bytes(A->max_L, g) + (A->helpers ? g * (ZKW_DQ_HELPER_BYTES + ((A->debug_flags & ZKW_KECCAK_HELPER) ? ZKW_KH_BYTES : 0u)) : 0u);
   zkw_launch_args args = *A;
-  args.lds_sink = lds_used;
+  args.lds_sink = ZKW_ISA_TABLE_SIZE * 8;  // right behind the ISA table
   A = &args;
   if (lds > 64u * 1024u) {
     // dynamic LDS above the 64 KB default needs an explicit opt-in (not reached by the current layout: 41 KB per workgroup).  The
