@@ -470,6 +470,19 @@ def test_keccak_served_by_helper_waves(oracle, product, isa, lanes, lens, unal):
         b.destroy()
 
 
+def test_thin_waves_without_room_for_helpers_keep_the_lane_path(oracle, product, isa):
+    """More thin waves than a round of workgroups with helpers holds (2100 instances at 2 lanes per wave = 1050 cycle
+    waves): the launch falls back to the ordinary geometry and every lane runs its own keccak256 — same traces."""
+    wl = synth.make(3, isa, n_instances=2100, keccak_k=(1, 2, 1, 1), sha_rounds=(1, 1, 2, 1))
+    bo = _run(oracle, wl)
+    bp = _run(product, wl, 2)
+    for i in list(range(0, 2100, 97)) + [2099]:
+        ok, why = K.traces_equal(bo.trace(i), bp.trace(i))
+        assert ok, (i, why)
+    assert int(bp.stats()["cycles"]) == int(bo.stats()["cycles"])
+    bo.destroy(); bp.destroy()
+
+
 @pytest.mark.parametrize("lanes", [2, 8])
 def test_reference_keccak_kats_through_the_helper_waves(product, isa, lanes):
     """The reference's keccak256 cases (src/testing/tests/precompiles/keccak256.rs:144-196) through the lane-parallel
