@@ -279,6 +279,42 @@ def test_fused_step_of_several_batches(oracle, product, isa):
         assert np.array_equal(bo.commitments(), bp.commitments()), w.name
 
 
+@pytest.mark.parametrize("lanes", [64, 16])
+def test_every_record_of_whole_steps(oracle, product, isa, lanes):
+    """Whole steps with room for helper waves (zkw_batches_step: the geometry of the driver's command), repeated so that the
+    restore between them is part of it.  Every record of every instance against the oracle: divergent fuzz tapes (lanes
+    that fail or end early beside the others), then cfg 2 (far calls, decommits chained by the helper wave)."""
+    wl = synth.fuzz_workload(isa, n_instances=320, n_ops=96, seed=0xF0A1)
+    bo = _run(oracle, wl)
+    wl.limits["lanes_per_wave"] = lanes
+    bp = product.create_batch(wl)
+    for _ in range(2):
+        product.step_many([bp], wl.n_cycles, 4)
+    bp.sync()
+    compared = 0
+    for i in range(wl.n_instances):
+        tp = bp.trace(i)
+        if int(tp["status"]) == K.STATUS_LIMIT:
+            continue
+        ok, why = K.traces_equal(bo.trace(i), tp)
+        assert ok, (i, why)
+        compared += 1
+    assert compared > 250
+    bo.destroy(); bp.destroy()
+    wl = synth.make(2, isa, n_instances=700)
+    bo = _run(oracle, wl)
+    wl.limits["lanes_per_wave"] = lanes
+    bp = product.create_batch(wl)
+    for _ in range(3):
+        product.step_many([bp], wl.n_cycles, 7)
+    bp.sync()
+    for i in range(wl.n_instances):
+        ok, why = K.traces_equal(bo.trace(i), bp.trace(i))
+        assert ok, (i, why)
+    assert np.array_equal(bo.commitments(), bp.commitments())
+    bo.destroy(); bp.destroy()
+
+
 def test_full_steps_after_partial_ones(oracle, product, isa):
     """zkw_batches_step: full steps after partial ones (which dirty other heap words and storage slots than a full run) and
     after plain reset + run calls must reproduce the oracle — the reset restores exactly what the previous run marked."""
