@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--instances", type=int, default=0, help="VM instances per GPU (weak scaling); default 4096, cfg 3: 512 = one GPU's share of BASELINE configs[3]'s 4096 instances over 8 GPUs")
     ap.add_argument("--cycles", type=int, default=256)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per wave (0 = library default: full waves)")
-    ap.add_argument("--fuse", type=int, default=64, help="batches (steps) per fused launch (zkw_batches_step), <= 256 (ZKW_MAX_FUSED)")
+    ap.add_argument("--fuse", type=int, default=0, help="batches (steps) per fused launch (zkw_batches_step), <= 256 (ZKW_MAX_FUSED); default 64, cfg 3: 128 (its batches are 8 waves each)")
     ap.add_argument("--streams", type=int, default=0, help="fused groups in flight (1 = everything on one stream; >= 2 = restore + cycle kernels on the main stream, commitments and the digest exchange on side streams; 0 = 2)")
     ap.add_argument("--side", choices=["commit", "commit+reset"], default="commit+reset", help="what the side streams carry when --streams >= 2")
     ap.add_argument("--no-rccl", action="store_true", help="skip libzkw.so's own RCCL communicator: the final exchange runs over the torch process group (the fallback of shard.make_comm)")
@@ -39,10 +39,16 @@ def main():
     ap.add_argument("--min-warmup-s", type=float, default=0.6, help="untimed warm-up is extended to at least this long (clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nop-only", action="store_true", help="with --cfg 0: a tape of NOPs only instead of alternating NOP / ADD")
-    ap.add_argument("--commit-mask", type=int, default=4, help="queue commitments computed inside every step: bit0 memory, bit1 log, bit2 decommit (BASELINE configs[2]: decommit queue)")
+    ap.add_argument("--commit-mask", type=int, default=-1, help="queue commitments computed inside every step: bit0 memory, bit1 log, bit2 decommit; default 4 (BASELINE configs[2]: decommit queue), cfg 3: 0 (its metric is the precompile path)")
     args = ap.parse_args()
     if args.instances <= 0:
         args.instances = 512 if args.cfg == 3 else 4096
+    if args.fuse <= 0:
+        args.fuse = 128 if args.cfg == 3 else 64
+    if args.commit_mask < 0:
+        args.commit_mask = 0 if args.cfg == 3 else 4
+    if args.cfg == 3 and args.streams <= 0:
+        args.streams = 1  # (128 batches of 8 waves fill the chip in one launch; nothing to pipeline beside it)
 
     # `--gpus N` must mean N ranks.  Under torchrun (the driver's launch for N > 1) WORLD_SIZE says so; started plainly
     # with N > 1 this process re-executes itself under torch.distributed.run, one rank per GPU — it never runs one
@@ -335,6 +341,22 @@ def main():
                                "sha256_compressions_per_s": float(args.instances) * sha_c * batches_per_launch / per_launch_s,
                                "lone_launch_ms": k_ms_alone, "batches_in_lone_launch": len(groups[0]),
                                "note": "integer-ALU bound (hash rounds), not HBM: see DESIGN.md 4.3"}
+            # the latency of ONE batch (a caller that has only this GPU's 512 instances in hand): kernel time of a lone launch,
+            # with full waves and with 2 lanes per wave (keccak256 then runs across the lanes of helper waves)
+            lone = {}
+            for label, lanes in (("full_waves", 0), ("two_lanes_per_wave", 2)):
+                w2 = synth.make(3, isa, n_instances=args.instances)
+                w2.limits.update(wl.limits)
+                w2.limits["lanes_per_wave"] = lanes
+                b2 = prod.create_batch(w2)
+                best = None
+                for _ in range(4):
+                    b2.reset(); b2.run(w2.n_cycles); b2.sync()
+                    ms = float(b2.stats()["kernel_ms"])
+                    best = ms if best is None else min(best, ms)
+                lone[label] = best
+                b2.destroy()
+            out["roofline"]["lone_batch_kernel_ms"] = lone
             if "cpu_baseline" in out:  # the same workload on the host cores: cycles/s -> message bytes/s
                 cb = out["cpu_baseline"]
                 scale = (kec_bytes + sha_bytes) / float(args.cycles_executed)
