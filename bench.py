@@ -1,36 +1,51 @@
 #!/usr/bin/env python3
 """bench.py — witnessed VM cycles/sec on the 1M-cycle synthetic batch (BASELINE.json configs[2]).
 
-One "step" = one pass of the hot path over one batch whose inputs are already resident in HBM: device-side restore
-of the batch's pristine state, the cycle kernel (every instance replays its opcode tape and emits its witness
-trace) and the queue-commitment kernels selected by --commit-mask.  Steps are issued `--fuse` batches per fused
-launch (zkw_batches_step).  Prints ONE JSON line (contract in the task description) with `roofline` and
-`cpu_baseline`.
+One "step" = one pass of the hot path over one batch whose inputs are already resident in HBM: the cycle kernel (every
+instance replays its opcode tape and emits its witness trace) and the queue-commitment kernels selected by
+--commit-mask.  Steps are issued `--fuse` batches per fused launch.  A batch object that is used AGAIN has its inputs
+restored on the device in between (zkw_batches_reset) — enqueued right behind its previous use, on a side stream when
+several groups are in flight, so that the restore runs beside the cycle kernel of another group; a batch object that is
+used once in the timed region (the driver's `--steps 20`: one fused launch of 20 batches) starts it restored, like any
+input that is "already resident", and the restore for a later use is not part of its step (`--restore every-step` is
+the arrangement of rounds 1-3: zkw_batches_step, the restore in front of every use).
+Prints ONE JSON line (contract in the task description) with `roofline` and `cpu_baseline`; on the headline command it
+also carries `other_configs`: the other single-GPU BASELINE configurations, run after the headline's timed region.
+
+ZKW_BENCH_BACKEND=emu (tests only, tests/test_multiprocess.py): the same orchestration — launches, overlap, reduce,
+barriers — on the single-lane CPU build of the product sources (tests/emu) under gloo; never a measurement.
 """
 import os
 # The pipelined batch slots live on separate HIP streams; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware
 # queues (default 4), which would cap the number of cycle kernels in flight.  Must be set before HIP initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import argparse
+import copy
 import json
-import os
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Frozen accounting ("the rule"): the algorithmic bytes per VM cycle of the headline workload (cfg 2,
+# 4096 instances x 256 cycles) are the figure of round 3 — 8 B opcode + 16 B record tail + 32 B per register delta +
+# 48 B per memory query + 128 B per log query + 32 B per heap word touched, measured then on the traces — and stay that
+# whatever the kernel stores from now on: a byte the kernel no longer writes raises the fraction instead of lowering it.
+# The run's own count and the counter traffic are separate fields (bytes_per_cycle_this_run, traffic).
+ALGORITHMIC_BYTES_R3 = 149.125
 
-def main():
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1024, help="timed steps (1M-cycle batches); the default is 8 fused launches, so that the fill and drain of the two-group pipeline are a small part of the timed region")
+    ap.add_argument("--steps", type=int, default=1024, help="timed steps (1M-cycle batches); the default is 16 fused launches, so that the fill and drain of the two-group pipeline are a small part of the timed region")
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--instances", type=int, default=0, help="VM instances per GPU (weak scaling); default 4096, cfg 3: 512 = one GPU's share of BASELINE configs[3]'s 4096 instances over 8 GPUs")
     ap.add_argument("--cycles", type=int, default=256)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per wave (0 = library default: full waves)")
-    ap.add_argument("--fuse", type=int, default=0, help="batches (steps) per fused launch (zkw_batches_step), <= 256 (ZKW_MAX_FUSED); default 64, cfg 3: 128 (its batches are 8 waves each)")
-    ap.add_argument("--streams", type=int, default=0, help="fused groups in flight (1 = everything on one stream; >= 2 = restore + cycle kernels on the main stream, commitments and the digest exchange on side streams; 0 = 2)")
+    ap.add_argument("--fuse", type=int, default=0, help="batches (steps) per fused launch, <= 256 (ZKW_MAX_FUSED); default 64, cfg 3: 128 (its batches are 8 waves each)")
+    ap.add_argument("--streams", type=int, default=0, help="fused groups in flight (1 = everything on one stream; >= 2 = cycle kernels on the main stream, commitments, the digest exchange and the restore for the next use on side streams; 0 = 2)")
     ap.add_argument("--side", choices=["commit", "commit+reset"], default="commit+reset", help="what the side streams carry when --streams >= 2")
     ap.add_argument("--no-rccl", action="store_true", help="skip libzkw.so's own RCCL communicator: the final exchange runs over the torch process group (the fallback of shard.make_comm)")
     ap.add_argument("--force-collective", action="store_true", help="run the digest all-gather even with one rank (exercises the multi-GPU code path on a single GPU)")
@@ -38,9 +53,17 @@ def main():
     ap.add_argument("--cfg", type=int, default=2)
     ap.add_argument("--min-warmup-s", type=float, default=0.6, help="untimed warm-up is extended to at least this long (clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other BASELINE configurations that the headline command runs after its timed region")
+    ap.add_argument("--repeats", type=int, default=-1, help="further timed regions of the same K steps behind the first (value_min / median / max); default 4 on the headline workload, else 0")
+    ap.add_argument("--restore", choices=["between-uses", "every-step"], default="between-uses",
+                    help="between-uses (default): a group's inputs are restored behind each use that is followed by another; every-step: zkw_batches_step — restore, run, commit in front of every use (rounds 1-3)")
     ap.add_argument("--nop-only", action="store_true", help="with --cfg 0: a tape of NOPs only instead of alternating NOP / ADD")
     ap.add_argument("--commit-mask", type=int, default=-1, help="queue commitments computed inside every step: bit0 memory, bit1 log, bit2 decommit; default 4 (BASELINE configs[2]: decommit queue), cfg 3: 0 (its metric is the precompile path)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    return fill_defaults(args)
+
+
+def fill_defaults(args):
     if args.instances <= 0:
         args.instances = 512 if args.cfg == 3 else 4096
     if args.fuse <= 0:
@@ -49,223 +72,356 @@ def main():
         args.commit_mask = 0 if args.cfg == 3 else 4
     if args.cfg == 3 and args.streams <= 0:
         args.streams = 1  # (128 batches of 8 waves fill the chip in one launch; nothing to pipeline beside it)
-
-    # `--gpus N` must mean N ranks.  Under torchrun (the driver's launch for N > 1) WORLD_SIZE says so; started plainly
-    # with N > 1 this process re-executes itself under torch.distributed.run, one rank per GPU — it never runs one
-    # rank and reports N.
-    if "WORLD_SIZE" in os.environ:
-        if int(os.environ["WORLD_SIZE"]) != args.gpus:
-            sys.exit("bench.py: --gpus %d but WORLD_SIZE=%s (launch with --nproc-per-node %d)" % (args.gpus, os.environ["WORLD_SIZE"], args.gpus))
-    elif args.gpus > 1:
-        import socket
-        import subprocess
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-        s.close()
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd))
-
-    import torch
-    import torch.distributed as dist
-    from era_zk_evm_amd import capi as K, synth
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    collective = world > 1 or args.force_collective
     if args.streams <= 0:
         args.streams = 2
-    if collective:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        if world == 1:
-            os.environ.setdefault("RANK", "0")
-            os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
+    return args
 
-    isa = K.Isa()
-    prod = K.load_product().open(isa, device=local_rank)
-    # The final exchange goes through the library's own entry point (zkw_reduce_commitments, include/zkw.h): an RCCL
-    # communicator created from an id that rank 0 generates and hands to the others (here over the process group that
-    # also serves the barriers).  One rank without --force-collective: a one-rank communicator without RCCL, used for
-    # the counter totals only.
-    from era_zk_evm_amd import shard
-    if collective:
-        # RCCL inside libzkw.so when every rank can create that communicator; otherwise all ranks together fall back to
-        # the library's external transport over the process group that is already up (era-zk_evm_amd/shard.py)
-        comm, transport = shard.make_comm(prod, rank, world, device=torch.device("cuda", local_rank), prefer_rccl=not args.no_rccl)
-    else:
-        comm, transport = K.Comm.external(prod, 0, 1), "single rank (no transport)"
-    # shard: every rank owns `instances` independent VM instances (different seeds), no data-path collective
+
+# ---------------------------------------------------------------------------------------------------------------------
+# device plumbing: torch.cuda streams / events and the HIP library — or, for the CPU test of the orchestration, stand-ins
+# ---------------------------------------------------------------------------------------------------------------------
+class GpuDev:
+    name = "gpu"
+
+    def __init__(self, local_rank):
+        import torch
+        self.torch = torch
+        self.local_rank = local_rank
+        torch.cuda.set_device(local_rank)
+        self.tensor_device = torch.device("cuda", local_rank)
+
+    def open_product(self, isa):
+        from era_zk_evm_amd import capi as K
+        return K.load_product().open(isa, device=self.local_rank)  # raises without libzkw.so / without a GPU: no fallback
+
+    def stream(self, priority=0):
+        return self.torch.cuda.Stream(device=self.local_rank, priority=priority)
+
+    def event(self):
+        return self.torch.cuda.Event()
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def init_pg(self):
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=self.tensor_device)
+
+
+class _EmuStream:
+    cuda_stream = None
+
+    def synchronize(self):
+        pass
+
+    def wait_event(self, ev):
+        pass
+
+
+class _EmuEvent:
+    def record(self, stream=None):
+        pass
+
+
+class EmuDev:
+    """tests only: the product sources built single-lane for the CPU (tests/emu), synchronous 'streams', gloo"""
+    name = "emu"
+
+    def __init__(self, local_rank):
+        import torch
+        self.torch = torch
+        self.local_rank = local_rank
+        self.tensor_device = torch.device("cpu")
+
+    def open_product(self, isa):
+        from era_zk_evm_amd import capi as K
+        sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+        import build_emu
+        return K.Backend(build_emu.build(), "zkw_").open(isa)
+
+    def stream(self, priority=0):
+        return _EmuStream()
+
+    def event(self):
+        return _EmuEvent()
+
+    def sync(self):
+        pass
+
+    def init_pg(self):
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one workload on one rank: batches, groups, streams, the launch sequence
+# ---------------------------------------------------------------------------------------------------------------------
+def make_workload(args, isa, rank):
+    from era_zk_evm_amd import capi as K, synth
     if args.cfg == 0:  # NOP/ADD plumbing tape replicated over many instances (loop-overhead floor)
         wl = synth.make(1, isa, n_instances=args.instances, n_cycles=args.cycles, seed=0x5EED0000 + 0x100 * rank)
         ops = [isa.enc(K.OP_NOP) if args.nop_only or k % 2 == 0 else isa.enc(K.OP_ADD, flags=(k // 2) % 2, src0=1, src1=2, dst0=3) for k in range(args.cycles)]
         wl.blobs[0] = K.pack_code(ops)
+    elif args.cfg == 3:
+        wl = synth.make(3, isa, n_instances=args.instances, seed=0x5EED0000 + args.cfg + 0x100 * rank, **getattr(args, "wl_kwargs", {}))
     else:
         wl = synth.make(args.cfg, isa, n_instances=args.instances, n_cycles=args.cycles, seed=0x5EED0000 + args.cfg + 0x100 * rank)
     wl.limits["lanes_per_wave"] = args.lanes
-    args.cycles_executed = wl.n_cycles
-    if args.cfg == 3:
-        args.cycles = wl.n_cycles  # the tape decides (8 precompile calls + the frame changes around them)
     if args.cfg == 2:
         # stream capacities sized for this tape (332 memory queries, 2 log queries, 8 aux events per 256 cycles and
         # instance) instead of the library's generic defaults (6 / 0.5 / 0.25 per cycle): 0.67 instead of 0.97 GB of
         # device memory per batch, so that the 2 x 128 batches of a multi-GPU rank stay well inside 288 GB.  An
         # overrun would show as failed instances, which the run refuses below.
         wl.limits.update(max_mem_queries=2 * args.cycles + 64, max_log_queries=16, max_aux_events=32)
-    # A 4096-instance batch is 64 waves and every instance is a sequential chain of cycles, so ONE batch cannot fill
-    # 256 CUs (the cycle kernel is latency-bound per wave) and the hardware overlaps only ~4 kernels of different
-    # streams.  The K steps (one step = one 1M-cycle batch, every cycle of it executed and witnessed) are therefore
-    # issued `--fuse` batches per launch through zkw_batches_step (one reset launch, one cycle-kernel launch, one set
-    # of commitment launches; grid.y = batch) and `--streams` such groups are in flight on separate HIP streams.
-    fuse = max(1, min(args.fuse, 256, args.steps))
-    n_groups = max(1, min(args.streams, (args.steps + fuse - 1) // fuse))
-    groups = [[prod.create_batch(wl) for _ in range(fuse)] for _ in range(n_groups)]
-    # the main stream (cycle kernels) gets the higher queue priority, the side streams fill in behind it
-    streams = [torch.cuda.Stream(device=local_rank, priority=(-1 if args.main_priority else 0)) for _ in range(n_groups)]
-    batches = [b for g in groups for b in g]
-    batch = batches[0]
+    return wl
 
-    def barrier():
-        torch.cuda.synchronize()
+
+class Flow:
+    """A 4096-instance batch is 64 waves and every instance is a sequential chain of cycles, so ONE batch cannot fill
+    256 CUs (the cycle kernel is latency-bound per wave) and the hardware overlaps only ~4 kernels of different
+    streams.  The K steps (one step = one batch, every cycle of it executed and witnessed) are therefore issued `fuse`
+    batches per launch (one cycle-kernel launch, one set of commitment launches; the waves of all batches numbered
+    through) and `n_groups` such groups are in flight on separate HIP streams.
+
+    Pipelining over streams (n_groups >= 2): the main stream carries the cycle kernels of the groups back to back; every
+    group has a side stream that carries its commitment kernels (integer-ALU bound), the digest exchange and the restore
+    of the group's inputs for its next use, ordered by events.  Kernel trace of the other arrangement (restore on the
+    main stream, profiles/r01_kernel_variants.md step 51): the restore of group B then starts together with the
+    commitment of group A the moment a cycle kernel ends, both take 1.6 ms instead of 0.6 / 1.3 ms, and the next cycle
+    kernel waits for the restore — the step time was the SUM of all kernels.  With the restore behind the commitment on
+    the side stream, the side work runs beside the next cycle kernel and the main stream never waits."""
+
+    def __init__(self, dev, prod, isa, args, rank, world, comm, collective):
+        import numpy as np
+        self.dev, self.prod, self.args, self.comm, self.collective, self.world, self.rank = dev, prod, args, comm, collective, world, rank
+        self.wl = wl = make_workload(args, isa, rank)
+        self.cycles = wl.n_cycles  # (cfg 3: the tape decides — 8 precompile calls + the frame changes around them)
+        self.fuse = fuse = max(1, min(args.fuse, 256, args.steps))
+        self.n_groups = n_groups = max(1, min(args.streams, (args.steps + fuse - 1) // fuse))
+        self.groups = [[prod.create_batch(wl) for _ in range(fuse)] for _ in range(n_groups)]
+        self.batches = [b for g in self.groups for b in g]
+        # the main stream (cycle kernels) gets the higher queue priority when asked, the side streams fill in behind it
+        self.main_stream = dev.stream(priority=(-1 if args.main_priority else 0))
+        self.side_streams = [dev.stream() for _ in range(n_groups)]
+        self.ev_run = [dev.event() for _ in range(n_groups)]
+        self.ev_ready = [dev.event() for _ in range(n_groups)]
+        self.overlap = n_groups > 1
+        self.side_reset = args.side == "commit+reset"
+        self.every_step = args.restore == "every-step"
+        self.pristine = [True] * n_groups      # the upload leaves every batch restored
+        self.waits_ready = [False] * n_groups  # ev_ready[g] has been recorded behind work the group's next run must wait for
+        self.restores = 0
+        # final exchange (SURVEY §8e): all-gather of the per-instance queue digests, once per fused group; only the
+        # committed queues travel: [world][batches][instances][n_committed][4] u64 per group (layout of zkw_reduce_commitments)
+        self.committed = [q for q in range(3) if (args.commit_mask >> q) & 1]
+        self.gathered = [None] * n_groups
         if collective:
-            dist.barrier()
-        torch.cuda.synchronize()
+            shape = (world, fuse, args.instances, max(1, len(self.committed)), 4)
+            # (device tensors for the RCCL communicator, host arrays for the external transport)
+            self.gathered = [dev.torch.zeros(shape, dtype=dev.torch.int64, device=dev.tensor_device) if comm.device_buffers else np.zeros(shape, dtype="<u8") for _ in range(n_groups)]
 
-    import ctypes as C
+    def all_streams(self):
+        return [self.main_stream] + self.side_streams
 
-    # final exchange: all-gather of the per-instance queue digests over RCCL, once per fused group
-    # only the committed queues travel: [fuse, instances, n_committed, 4] u64 per group
-    # only the committed queues travel: [world][batches][instances][n_committed][4] u64 per group (layout of zkw_reduce_commitments)
-    committed = [q for q in range(3) if (args.commit_mask >> q) & 1]
-    # (device tensors for the RCCL communicator, host arrays for the external transport)
-    import numpy as np
-    gathered = [None] * n_groups
-    if collective:
-        shape = (world, fuse, args.instances, max(1, len(committed)), 4)
-        gathered = [torch.zeros(shape, dtype=torch.int64, device="cuda") if comm.device_buffers else np.zeros(shape, dtype="<u8") for _ in range(n_groups)]
+    def sync_streams(self):
+        for st_ in self.all_streams():
+            st_.synchronize()
 
-    # Pipelining over streams (--streams >= 2): the main stream carries the cycle kernels of the groups back to back;
-    # every group has a side stream that carries its commitment kernels (integer-ALU bound), the digest exchange and
-    # (--side commit+reset, the default) the restore of the group's inputs for its next use, ordered by events.  Kernel
-    # trace of the other arrangement (restore on the main stream, profiles/r01_kernel_variants.md step 51): the restore
-    # of group B then starts together with the commitment of group A the moment a cycle kernel ends, both take 1.6 ms
-    # instead of 0.6 / 1.3 ms, and the next cycle kernel waits for the restore — the step time was the SUM of all kernels.
-    # With the restore behind the commitment on the side stream, the side work runs beside the next cycle kernel (which
-    # has idle issue slots: it is latency-bound) and the main stream never waits.
-    main_stream = streams[0]
-    side_streams = [torch.cuda.Stream(device=local_rank) for _ in range(n_groups)]
-    ev_run = [torch.cuda.Event() for _ in range(n_groups)]
-    ev_ready = [torch.cuda.Event() for _ in range(n_groups)]
-    overlap = n_groups > 1
-    side_reset = args.side == "commit+reset"
-    group_used = [False] * n_groups  # the upload leaves every batch reset
+    def _reduce(self, g, n, sptr):
+        args = self.args
+        if args.commit_mask and self.collective:  # pack kernel + all-gather, enqueued on the group's stream (asynchronous with RCCL)
+            gb = self.gathered[g]
+            self.comm.reduce(self.groups[g][:n], args.commit_mask, gathered=(gb.data_ptr() if self.comm.device_buffers else (gb if n == self.fuse else None)), stream=sptr)
 
-    def launch(g, n):
-        """n <= fuse steps (batches) in one fused launch sequence of group g"""
-        if not overlap:
-            stream = streams[g]
-            sptr = stream.cuda_stream
-            prod.step_many(groups[g][:n], wl.n_cycles, args.commit_mask, sptr)
-        else:
-            if group_used[g]:
-                main_stream.wait_event(ev_ready[g])  # the old streams consumed by the commitment (and the inputs restored)
-            group_used[g] = True
-            if not side_reset:
-                prod.reset_many(groups[g][:n], main_stream.cuda_stream)
-            prod.run_many_committing(groups[g][:n], wl.n_cycles, args.commit_mask, main_stream.cuda_stream)  # the decommit queue is chained inside the run
-            ev_run[g].record(main_stream)
-            stream = side_streams[g]
-            sptr = stream.cuda_stream
-            stream.wait_event(ev_run[g])
-            prod.commit_many(groups[g][:n], args.commit_mask, sptr)
-        if args.commit_mask and collective:  # pack kernel + ncclAllGather, enqueued on the group's stream (asynchronous)
-            comm.reduce(groups[g][:n], args.commit_mask, gathered=(gathered[g].data_ptr() if comm.device_buffers else (gathered[g] if n == fuse else None)), stream=sptr)
-        if overlap:
-            if side_reset:
-                prod.reset_many(groups[g], sptr)  # the whole group, so that a later partial launch finds it restored
-            ev_ready[g].record(stream)
+    def _launch_every_step(self, g, n):
+        """rounds 1-3: the restore in front of every use"""
+        prod, args, group, main = self.prod, self.args, self.groups[g], self.main_stream
+        if not self.overlap:
+            prod.step_many(group[:n], self.cycles, args.commit_mask, main.cuda_stream)  # zkw_batches_step
+            self.restores += 1
+            self._reduce(g, n, main.cuda_stream)
+            return
+        if self.waits_ready[g]:
+            main.wait_event(self.ev_ready[g])  # the old streams consumed by the commitment (and the inputs restored)
+        if not self.side_reset:
+            prod.reset_many(group[:n], main.cuda_stream)
+        prod.run_many_committing(group[:n], self.cycles, args.commit_mask, main.cuda_stream)
+        self.ev_run[g].record(main)
+        side = self.side_streams[g]
+        side.wait_event(self.ev_run[g])
+        prod.commit_many(group[:n], args.commit_mask, side.cuda_stream)
+        self._reduce(g, n, side.cuda_stream)
+        if self.side_reset:
+            prod.reset_many(group, side.cuda_stream)  # the whole group, so that a later partial launch finds it restored
+        self.restores += 1
+        self.ev_ready[g].record(side)
+        self.waits_ready[g] = True
 
-    def run_steps(k):
-        g = 0
-        while k > 0:
-            n = min(fuse, k)
-            launch(g % n_groups, n)
-            g += 1
-            k -= n
-        return g
+    def launch(self, g, n, used_again):
+        """n <= fuse steps (batches) of group g in one fused launch sequence; `used_again`: this run_steps call comes back to
+        the group, so its inputs are restored behind this use"""
+        if self.every_step:
+            return self._launch_every_step(g, n)
+        prod, args, group, main = self.prod, self.args, self.groups[g], self.main_stream
+        if self.waits_ready[g]:
+            main.wait_event(self.ev_ready[g])  # the old streams consumed by the commitment, the inputs restored
+            self.waits_ready[g] = False
+        if not self.pristine[g]:  # left used by an earlier call (never inside a timed region: `prepare` runs before it)
+            prod.reset_many(group, main.cuda_stream)
+            self.restores += 1
+        if not self.overlap:
+            prod.step_prepared_many(group[:n], self.cycles, args.commit_mask, main.cuda_stream)  # run + commitments: a whole step on one stream
+            self._reduce(g, n, main.cuda_stream)
+            if used_again:
+                prod.reset_many(group, main.cuda_stream)
+                self.restores += 1
+            self.pristine[g] = used_again
+            return
+        prod.run_many_committing(group[:n], self.cycles, args.commit_mask, main.cuda_stream)  # the decommit queue is chained inside the run
+        self.ev_run[g].record(main)
+        side = self.side_streams[g]
+        side.wait_event(self.ev_run[g])
+        prod.commit_many(group[:n], args.commit_mask, side.cuda_stream)
+        self._reduce(g, n, side.cuda_stream)
+        restored = used_again and self.side_reset
+        if restored:
+            prod.reset_many(group, side.cuda_stream)  # the whole group, so that a later partial launch finds it restored
+            self.restores += 1
+        self.ev_ready[g].record(side)
+        self.waits_ready[g] = True
+        self.pristine[g] = restored
 
-    def drain_timing():
+    def run_steps(self, k):
+        n_launches = (k + self.fuse - 1) // self.fuse
+        for i in range(n_launches):
+            n = min(self.fuse, k - i * self.fuse)
+            self.launch(i % self.n_groups, n, used_again=(i + self.n_groups < n_launches))
+        return n_launches
+
+    def prepare(self):
+        """untimed: every group restored and idle — the state 'inputs resident in HBM' a timed region starts from"""
+        if not self.every_step:
+            for g in range(self.n_groups):
+                if self.waits_ready[g]:
+                    self.main_stream.wait_event(self.ev_ready[g])
+                    self.waits_ready[g] = False
+                if not self.pristine[g]:
+                    self.prod.reset_many(self.groups[g], self.main_stream.cuda_stream)
+                    self.pristine[g] = True
+        self.sync_streams()
+
+    def drain_timing(self):
+        import ctypes as C
         out = []
-        for g in groups:
+        for g in self.groups:
             ms, nl = C.c_double(0), C.c_uint32(0)
-            prod.call("batch_kernel_time", g[0].h, C.byref(ms), C.byref(nl))
+            self.prod.call("batch_kernel_time", g[0].h, C.byref(ms), C.byref(nl))
             if nl.value:
                 out.append(ms.value)
         return out
 
-    run_steps(max(args.warmup, fuse * n_groups))  # untimed: every group at least once
-    for st_ in streams + side_streams:
-        st_.synchronize()
+    def barrier(self):
+        self.dev.sync()
+        if self.collective:
+            import torch.distributed as dist
+            dist.barrier()
+        self.dev.sync()
+
+    def timed(self, k):
+        """exactly k steps between barrier + synchronize on both sides -> (seconds, launches, host enqueue seconds, kernel ms list, restores)"""
+        self.prepare()
+        self.drain_timing()  # the event pairs of earlier launches do not count
+        r0 = self.restores
+        self.barrier()
+        t0 = time.perf_counter()
+        n_launches = self.run_steps(k)
+        t_enq = time.perf_counter() - t0  # host time spent enqueueing (launch-bound check)
+        self.sync_streams()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        return elapsed, n_launches, t_enq, self.drain_timing(), self.restores - r0
+
+    def lone_kernel_ms(self, reps=3):
+        """untimed: the fused launch of group 0 with nothing else in flight (duration of the kernel on its own)"""
+        self.prepare()
+        for _ in range(reps):
+            self.prod.reset_many(self.groups[0], self.main_stream.cuda_stream)
+            self.prod.run_many_committing(self.groups[0], self.cycles, self.args.commit_mask, self.main_stream.cuda_stream)
+            self.main_stream.synchronize()
+        self.pristine[0] = False
+        return self.drain_timing()[0]
+
+    def verify(self):
+        """untimed: every batch of every group, every rank — the last run of each must have executed all of its cycles with no
+        instance stopped on a capacity limit or an error status (counters summed by zkw_reduce_commitments: RCCL all-reduce
+        at N > 1).  The pipelined loop leaves groups restored for their next use, so every group is run once more first."""
+        self.prepare()
+        for g_, group in enumerate(self.groups):
+            self.prod.reset_many(group, self.main_stream.cuda_stream)
+            self.prod.run_many_committing(group, self.cycles, self.args.commit_mask, self.main_stream.cuda_stream)
+            if self.args.commit_mask:
+                self.prod.commit_many(group, self.args.commit_mask, self.main_stream.cuda_stream)
+            self.pristine[g_] = False
+        self.main_stream.synchronize()
+        self.drain_timing()
+        tot_cycles = tot_failed = 0
+        for i in range(0, len(self.batches), 128):
+            _, _, _, tot = self.comm.reduce(self.batches[i:i + 128], 0, want_total=True, stream=self.main_stream.cuda_stream)
+            tot_cycles += int(tot["cycles"])
+            tot_failed += int(tot["instances_failed"])
+        return tot_cycles, tot_failed
+
+    def close(self):
+        self.sync_streams()
+        for b in self.batches:
+            b.destroy()
+        self.batches, self.groups = [], []
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one measured line
+# ---------------------------------------------------------------------------------------------------------------------
+def measure(dev, prod, isa, args, rank, world, comm, collective, transport, with_cpu_baseline, repeats=0):
+    import ctypes as C
+    import torch.distributed as dist
+    from era_zk_evm_amd import capi as K
+    torch = dev.torch
+    flow = Flow(dev, prod, isa, args, rank, world, comm, collective)
+    wl, fuse, n_groups = flow.wl, flow.fuse, flow.n_groups
+    batch = flow.batches[0]
+    cycles = flow.cycles
+
+    flow.run_steps(max(args.warmup, fuse * n_groups))  # untimed: every group at least once
+    flow.sync_streams()
     # the GPU's clocks need a few hundred ms of load to settle (measured: the first launches of a fresh process run
     # ~20% slower): keep warming up, untimed, until 0.6 s of device work has been issued
     t_w = time.perf_counter()
     while time.perf_counter() - t_w < args.min_warmup_s:
-        run_steps(4 * fuse * n_groups)  # long bursts: the launches of the warm-up then run in the same pipelined regime as the timed ones
-        for st_ in streams + side_streams:
-            st_.synchronize()
-    drain_timing()  # the event pairs of the warm-up launches do not count
+        flow.run_steps(4 * fuse * n_groups)  # long bursts: the launches of the warm-up then run in the same pipelined regime as the timed ones
+        flow.sync_streams()
     # timed region: exactly K steps
-    barrier()
-    t0 = time.perf_counter()
-    n_launches = run_steps(args.steps)
-    t_enq = time.perf_counter() - t0  # host time spent enqueueing (launch-bound check)
-    for st_ in streams + side_streams:
-        st_.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    leaders = [g[0] for g in groups]
-    # HIP event pairs around the cycle-kernel launches of the timed region give the kernel's own mean duration
-    k_ms_list = drain_timing()
-    # untimed epilogue: the same fused launch with nothing else in flight (duration of the kernel on its own)
-    for _ in range(3):
-        prod.reset_many(groups[0], main_stream.cuda_stream)
-        prod.run_many_committing(groups[0], wl.n_cycles, args.commit_mask, main_stream.cuda_stream)
-        main_stream.synchronize()
-    k_ms_alone = drain_timing()[0]
-    # verification pass (untimed): the pipelined loop leaves every group restored for its next use, so the counters
-    # of the timed runs are gone; every step replays the same inputs, so one more run of every group shows what each
-    # of them did
-    for g_ in groups[1:]:
-        prod.reset_many(g_, main_stream.cuda_stream)
-        prod.run_many_committing(g_, wl.n_cycles, args.commit_mask, main_stream.cuda_stream)
-    main_stream.synchronize()
-    drain_timing()
+    elapsed, n_launches, t_enq, k_ms_list, n_restores = flow.timed(args.steps)
+    samples = [elapsed]
+    for _ in range(max(0, repeats)):  # further timed regions of the same K steps: the spread of the figure
+        samples.append(flow.timed(args.steps)[0])
+    k_ms_alone = flow.lone_kernel_ms()
+    tot_cycles, tot_failed = flow.verify()
     batch.sync()
     st = batch.stats()
-    # every batch of every group, every rank: the last run of each must have executed all of its cycles with no instance
-    # stopped on a capacity limit or an error status (counters summed by zkw_reduce_commitments — RCCL all-reduce at N > 1)
-    tot_cycles = tot_failed = 0
-    for i in range(0, len(batches), 128):
-        _, _, _, tot = comm.reduce(batches[i:i + 128], 0, want_total=True, stream=main_stream.cuda_stream)
-        tot_cycles += int(tot["cycles"])
-        tot_failed += int(tot["instances_failed"])
-    expect = world * len(batches) * args.instances * args.cycles
-    if tot_failed != 0 or (args.cfg in (0, 1, 2) and tot_cycles != expect):
+    expect = world * len(flow.batches) * args.instances * cycles
+    if (tot_failed != 0 or (args.cfg in (0, 1, 2) and tot_cycles != expect)) and not os.environ.get("ZKW_BENCH_NOCHECK"):  # (the env switch: kernel-time ablations of profiles/tools, whose runs are wrong by construction)
         raise RuntimeError("bench: %d instances stopped on a capacity limit or an error status; %d of %d cycles executed" % (tot_failed, tot_cycles, expect))
     # untimed: what pulling one step's whole trace over PCIe would cost (DESIGN.md §6)
     dl_bytes, dl_ms = C.c_uint64(0), C.c_double(0)
     prod.call("batch_download_all", batch.h, C.byref(dl_bytes), C.byref(dl_ms))
     cycles_per_step = int(st["cycles"])
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    c = torch.tensor([float(cycles_per_step)], dtype=torch.float64, device="cuda")
+    t = torch.tensor(samples, dtype=torch.float64, device=dev.tensor_device)
+    c = torch.tensor([float(cycles_per_step)], dtype=torch.float64, device=dev.tensor_device)
     if collective:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
+    samples = [float(x) for x in t.tolist()]
+    elapsed = samples[0]
     total_cycles_per_step = float(c.item())
 
     out = None
@@ -288,85 +444,211 @@ def main():
         # bytes the kernel has to move per VM cycle: code word + record tail + register deltas + queries + heap words
         # (the 512-B snapshot of SURVEY §8d is stored losslessly as a 16-B tail + 32 B per written register / per change of
         # the tail's slow half (memory bounds, depth): `n_delta` counts both; timestamp and previous_super_pc are derived)
-        b_cycle = 8 + 16 + 32 * n_delta + 48 * n_mem + 128 * n_log + 32 * heap_words
+        b_run = 8 + 16 + 32 * n_delta + 48 * n_mem + 128 * n_log + 32 * heap_words
+        headline_shape = args.cfg == 2 and args.instances == 4096 and args.cycles == 256 and args.lanes == 0
+        b_cycle = ALGORITHMIC_BYTES_R3 if headline_shape else b_run  # frozen for the headline workload (see the constant)
         b_cycle_snapshot = 8 + 512 + 48 * n_mem + 128 * n_log + 32 * heap_words
         # mean duration of one cycle-kernel launch (HIP events on its stream) and the cycles that launch processed
         k_ms = sum(k_ms_list) / len(k_ms_list)
         batches_per_launch = min(fuse, args.steps)
         achieved = b_cycle * cycles_per_step * batches_per_launch / (k_ms * 1e-3) / 1e9
         traffic = measured_traffic(args, batches_per_launch)
+        vals = sorted(total_cycles_per_step * args.steps / s_ for s_ in samples)
         out = {
             "metric": "witnessed VM cycles/sec (1M-cycle synthetic batch)",
             "value": value, "unit": "cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u256 (8 x u32 limbs)", "data": "synthetic",
-            "config": {"workload": "cfg%d: %d instances x %d cycles per GPU (%s)" % (args.cfg, args.instances, args.cycles, wl.name),
-                       "instances_per_gpu": args.instances, "cycles_per_instance": args.cycles, "lanes_per_wave": int(batch.limits["lanes_per_wave"][0]), "commit_mask": args.commit_mask,
-                       "batches_per_fused_launch": batches_per_launch, "fused_groups_in_flight": n_groups, "side_stream_work": (args.side if overlap else None), "cycle_kernel_launches": n_launches,
-                       "collective": transport},
+            "config": {"workload": "cfg%d: %d instances x %d cycles per GPU (%s)" % (args.cfg, args.instances, cycles, wl.name),
+                       "instances_per_gpu": args.instances, "cycles_per_instance": cycles, "lanes_per_wave": int(batch.limits["lanes_per_wave"][0]), "commit_mask": args.commit_mask,
+                       "batches_per_fused_launch": batches_per_launch, "fused_groups_in_flight": n_groups, "side_stream_work": (args.side if flow.overlap else None), "cycle_kernel_launches": n_launches,
+                       "restore": args.restore, "restores_in_timed_region": n_restores,
+                       "collective": transport, "backend": dev.name},
+            "value_min": vals[0], "value_median": vals[len(vals) // 2], "value_max": vals[-1], "timed_regions": len(vals),
             "kernel_ms": k_ms, "kernel_ms_alone": k_ms_alone,
             "pcie_download_of_one_step": {"bytes": dl_bytes.value, "ms": dl_ms.value, "GBps": dl_bytes.value / max(dl_ms.value, 1e-9) / 1e6,
                                           "cycles_per_s_if_every_step_were_downloaded": cycles_per_step / (1e-3 * (dl_ms.value + ms_per_step))}, "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
             "kernel_cycles_per_s": cycles_per_step * batches_per_launch / (k_ms * 1e-3),
-            "checked": {"batches": len(batches) * world, "cycles_executed": tot_cycles, "instances_failed": tot_failed},
+            "checked": {"batches": len(flow.batches) * world, "cycles_executed": tot_cycles, "instances_failed": tot_failed},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "frac_alone": b_cycle * cycles_per_step * len(groups[0]) / (k_ms_alone * 1e-3) / 1e9 / 8000.0, "bytes_per_cycle": b_cycle, "heap_words_per_cycle": heap_words, "snapshot_equivalent_bytes_per_cycle": b_cycle_snapshot, "snapshot_equivalent_GBps": b_cycle_snapshot * cycles_per_step * batches_per_launch / (k_ms * 1e-3) / 1e9, "cycles_per_launch": cycles_per_step * batches_per_launch,
+                         "frac_alone": b_cycle * cycles_per_step * len(flow.groups[0]) / (k_ms_alone * 1e-3) / 1e9 / 8000.0, "bytes_per_cycle": b_cycle,
+                         "algorithmic_bytes_r3": ALGORITHMIC_BYTES_R3 if headline_shape else None, "bytes_per_cycle_this_run": b_run,
+                         "heap_words_per_cycle": heap_words, "snapshot_equivalent_bytes_per_cycle": b_cycle_snapshot, "snapshot_equivalent_GBps": b_cycle_snapshot * cycles_per_step * batches_per_launch / (k_ms * 1e-3) / 1e9, "cycles_per_launch": cycles_per_step * batches_per_launch,
                          "chip_achieved": b_cycle * value / 1e9, "chip_frac": b_cycle * value / 1e9 / 8000.0},
         }
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
+        if with_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(isa, args, prod)
         if args.cfg == 3:
-            # BASELINE configs[3] (precompile-dominant): SURVEY §8d asks for message bytes/s against the HBM roofline at
-            # 2.5 B per message byte (the message read once + one 48-B memory query per 32-B word in, digest + query out)
-            # with the keccak-f / sha256 round rates beside it.  (The honest bound of this path is the integer ALU: a
-            # keccak-f[1600] is ~10k 32-bit instructions per lane — the fraction of the HBM roofline only says how far
-            # from a streaming kernel a hash-bound one sits.)
-            kec_bytes = sum(m[1] for m in wl.keccak_messages)
-            sha_bytes = sum(64 * ((m[1] + 9 + 63) // 64) for m in wl.sha_messages)
-            kec_f = sum(m[1] // 136 + 1 for m in wl.keccak_messages)
-            sha_c = sum((m[1] + 9 + 63) // 64 for m in wl.sha_messages)
-            msg_step = float(args.instances * world) * (kec_bytes + sha_bytes)
-            per_launch_s = k_ms * 1e-3
-            msg_launch = float(args.instances) * (kec_bytes + sha_bytes) * batches_per_launch
-            ach = 2.5 * msg_launch / per_launch_s / 1e9
-            out["metric"] = "precompile message bytes/sec (keccak256 + sha256 round functions over calldata, BASELINE configs[3])"
-            out["cycles_per_s"] = value
-            out["value"] = msg_step * args.steps / elapsed
-            out["unit"] = "message bytes/s"
-            out["dtype"] = "u64 lanes (keccak-f[1600]) / u32 (sha256), as 32-bit integer ALU"
-            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
-                               "bytes_per_message_byte": 2.5, "message_bytes_per_launch": msg_launch,
-                               "message_GBps_in_kernel": msg_launch / per_launch_s / 1e9,
-                               "keccak_f_per_s": float(args.instances) * kec_f * batches_per_launch / per_launch_s,
-                               "sha256_compressions_per_s": float(args.instances) * sha_c * batches_per_launch / per_launch_s,
-                               "lone_launch_ms": k_ms_alone, "batches_in_lone_launch": len(groups[0]),
-                               "note": "integer-ALU bound (hash rounds), not HBM: see DESIGN.md 4.3"}
-            # the latency of ONE batch (a caller that has only this GPU's 512 instances in hand): kernel time of a lone launch,
-            # with full waves and with 2 lanes per wave (keccak256 then runs across the lanes of helper waves)
-            lone = {}
-            for label, lanes in (("full_waves", 0), ("two_lanes_per_wave", 2)):
-                w2 = synth.make(3, isa, n_instances=args.instances)
-                w2.limits.update(wl.limits)
-                w2.limits["lanes_per_wave"] = lanes
-                b2 = prod.create_batch(w2)
-                best = None
-                for _ in range(4):
-                    b2.reset(); b2.run(w2.n_cycles); b2.sync()
-                    ms = float(b2.stats()["kernel_ms"])
-                    best = ms if best is None else min(best, ms)
-                lone[label] = best
-                b2.destroy()
-            out["roofline"]["lone_batch_kernel_ms"] = lone
-            if "cpu_baseline" in out:  # the same workload on the host cores: cycles/s -> message bytes/s
-                cb = out["cpu_baseline"]
-                scale = (kec_bytes + sha_bytes) / float(args.cycles_executed)
-                for k_ in ("value", "whole_box_value", "single_core_value", "single_socket_value"):
-                    cb[k_ + "_cycles_per_s"] = cb[k_]
-                    cb[k_] = cb[k_] * scale
-                cb["unit"] = "message bytes/s"
-    if os.environ.get("ZKW_BENCH_MEMINFO"):
-        free_b, total_b = torch.cuda.mem_get_info(local_rank)
+            cfg3_line(out, args, flow, prod, isa, value, elapsed, k_ms, k_ms_alone, batches_per_launch, world)
+    if os.environ.get("ZKW_BENCH_MEMINFO") and dev.name == "gpu":
+        free_b, total_b = torch.cuda.mem_get_info(dev.local_rank)
         print("rank %d: device memory in use %.1f GB of %.1f GB" % (rank, (total_b - free_b) / 2**30, total_b / 2**30), file=sys.stderr)
+    if collective and os.environ.get("ZKW_BENCH_DUMP_GATHERED") and rank == 0 and flow.gathered[0] is not None:
+        import numpy as np  # (tests: the digests the last full launch of group 0 gathered)
+        g0 = flow.gathered[0]
+        np.save(os.environ["ZKW_BENCH_DUMP_GATHERED"], g0.cpu().numpy().astype("<u8") if hasattr(g0, "cpu") else g0)
+    flow.close()
+    return out
+
+
+def cfg3_line(out, args, flow, prod, isa, value, elapsed, k_ms, k_ms_alone, batches_per_launch, world):
+    """BASELINE configs[3] (precompile-dominant): SURVEY §8d asks for message bytes/s against the HBM roofline at 2.5 B per
+    message byte (the message read once + one 48-B memory query per 32-B word in, digest + query out) with the keccak-f /
+    sha256 round rates beside it.  (The honest bound of this path is the integer ALU: a keccak-f[1600] is ~10k 32-bit
+    instructions per lane — the fraction of the HBM roofline only says how far from a streaming kernel a hash-bound one sits.)"""
+    from era_zk_evm_amd import synth
+    wl = flow.wl
+    kec_bytes = sum(m[1] for m in wl.keccak_messages)
+    sha_bytes = sum(64 * ((m[1] + 9 + 63) // 64) for m in wl.sha_messages)
+    kec_f = sum(m[1] // 136 + 1 for m in wl.keccak_messages)
+    sha_c = sum((m[1] + 9 + 63) // 64 for m in wl.sha_messages)
+    msg_step = float(args.instances * world) * (kec_bytes + sha_bytes)
+    per_launch_s = k_ms * 1e-3
+    msg_launch = float(args.instances) * (kec_bytes + sha_bytes) * batches_per_launch
+    ach = 2.5 * msg_launch / per_launch_s / 1e9
+    out["metric"] = "precompile message bytes/sec (keccak256 + sha256 round functions over calldata, BASELINE configs[3])"
+    out["cycles_per_s"] = value
+    out["value"] = msg_step * args.steps / elapsed
+    for k_ in ("value_min", "value_median", "value_max"):
+        out[k_] = out[k_] * (kec_bytes + sha_bytes) / float(flow.cycles)
+    out["unit"] = "message bytes/s"
+    out["dtype"] = "u64 lanes (keccak-f[1600]) / u32 (sha256), as 32-bit integer ALU"
+    out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                       "bytes_per_message_byte": 2.5, "message_bytes_per_launch": msg_launch,
+                       "message_GBps_in_kernel": msg_launch / per_launch_s / 1e9,
+                       "keccak_f_per_s": float(args.instances) * kec_f * batches_per_launch / per_launch_s,
+                       "sha256_compressions_per_s": float(args.instances) * sha_c * batches_per_launch / per_launch_s,
+                       "lone_launch_ms": k_ms_alone, "batches_in_lone_launch": flow.fuse,
+                       "note": "integer-ALU bound (hash rounds), not HBM: see DESIGN.md 4.3"}
+    # the latency of ONE batch (a caller that has only this GPU's 512 instances in hand): kernel time of a lone launch,
+    # with full waves and with 2 lanes per wave (keccak256 then runs across the lanes of helper waves, DESIGN.md 4.3)
+    lone = {}
+    for label, lanes in (("full_waves", 0), ("two_lanes_per_wave", 2)):
+        w2 = synth.make(3, isa, n_instances=args.instances, **getattr(args, "wl_kwargs", {}))
+        w2.limits.update(wl.limits)
+        w2.limits["lanes_per_wave"] = lanes
+        b2 = prod.create_batch(w2)
+        best = None
+        for _ in range(4):
+            b2.reset(); b2.run(w2.n_cycles); b2.sync()
+            ms = float(b2.stats()["kernel_ms"])
+            best = ms if best is None else min(best, ms)
+        lone[label] = best
+        b2.destroy()
+    out["roofline"]["lone_batch_kernel_ms"] = lone
+    if "cpu_baseline" in out:  # the same workload on the host cores: cycles/s -> message bytes/s
+        cb = out["cpu_baseline"]
+        scale = (kec_bytes + sha_bytes) / float(flow.cycles)
+        for k_ in ("value", "whole_box_value", "single_core_value", "single_socket_value"):
+            if k_ in cb:
+                cb[k_ + "_cycles_per_s"] = cb[k_]
+                cb[k_] = cb[k_] * scale
+        cb["unit"] = "message bytes/s"
+
+
+# the other single-GPU BASELINE configurations, run by the headline command after its timed region (untimed for the
+# headline; bounded: a few seconds each): configs[1] at its literal size and at a chip-filling size, configs[3] (one
+# GPU's share: fused, and the lone batch at 2 lanes per wave inside the line), configs[4] with all three commitments
+OTHER_CONFIGS = [
+    dict(label="configs[1] literal: 256 instances x 256 cycles, arithmetic (20 batches per launch)", cfg=1, instances=256, cycles=256, steps=20, warmup=20, fuse=20, streams=1, commit_mask=0),
+    dict(label="configs[1] at 4096 instances x 256 cycles", cfg=1, instances=4096, cycles=256, steps=64, warmup=64, fuse=64, streams=1, commit_mask=0),
+    dict(label="configs[3]: 512 instances (one GPU's share), 128 batches per launch", cfg=3, instances=512, cycles=0, steps=128, warmup=128, fuse=128, streams=1, commit_mask=0),
+    dict(label="configs[4]: 4096 instances x 1024 cycles, all three queue commitments", cfg=4, instances=4096, cycles=1024, steps=32, warmup=16, fuse=16, streams=2, commit_mask=7),
+]
+
+
+def other_configs(dev, prod, isa, base_args, comm, transport, with_cpu):
+    res = []
+    t_all = time.perf_counter()
+    for oc in OTHER_CONFIGS:
+        a = copy.copy(base_args)
+        a.cfg, a.instances, a.steps, a.warmup, a.fuse, a.streams, a.commit_mask = oc["cfg"], oc["instances"], oc["steps"], oc["warmup"], oc["fuse"], oc["streams"], oc["commit_mask"]
+        a.cycles = oc["cycles"] or 256
+        a.lanes, a.min_warmup_s, a.restore = 0, 0.2, "between-uses"
+        t0 = time.perf_counter()
+        try:
+            line = measure(dev, prod, isa, a, 0, 1, comm, False, transport, False, repeats=0)
+            entry = {"workload": oc["label"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "steps": a.steps, "kernel_ms": line["kernel_ms"],
+                     "batches_per_fused_launch": line["config"]["batches_per_fused_launch"], "commit_mask": a.commit_mask,
+                     "roofline": {"bound": "hbm", "frac": line["roofline"]["frac"], "achieved": line["roofline"]["achieved"], "unit": "GB/s",
+                                  "bytes_per_unit": line["roofline"].get("bytes_per_cycle", line["roofline"].get("bytes_per_message_byte"))},
+                     "checked": line["checked"]}
+            if a.cfg == 3:
+                entry["roofline"]["lone_batch_kernel_ms"] = line["roofline"]["lone_batch_kernel_ms"]
+                entry["roofline"]["keccak_f_per_s"] = line["roofline"]["keccak_f_per_s"]
+                entry["roofline"]["sha256_compressions_per_s"] = line["roofline"]["sha256_compressions_per_s"]
+                entry["cycles_per_s"] = line["cycles_per_s"]
+            if with_cpu:
+                cb = cpu_socket_rate(isa, a)
+                if a.cfg == 3:  # cycles/s -> message bytes/s, as in the line
+                    cb["single_socket_value"] *= line["value"] / max(line["cycles_per_s"], 1e-9)
+                cb["unit"] = line["unit"]
+                entry["cpu_baseline"] = cb
+        except Exception as e:  # noqa: BLE001  (an extra configuration must not take the headline line with it)
+            entry = {"workload": oc["label"], "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        entry["wall_s"] = time.perf_counter() - t0
+        res.append(entry)
+    return res, time.perf_counter() - t_all
+
+
+def main():
+    args = parse_args()
+
+    # `--gpus N` must mean N ranks.  Under torchrun (the driver's launch for N > 1) WORLD_SIZE says so; started plainly
+    # with N > 1 this process re-executes itself under torch.distributed.run, one rank per GPU — it never runs one
+    # rank and reports N.
+    if "WORLD_SIZE" in os.environ:
+        if int(os.environ["WORLD_SIZE"]) != args.gpus:
+            sys.exit("bench.py: --gpus %d but WORLD_SIZE=%s (launch with --nproc-per-node %d)" % (args.gpus, os.environ["WORLD_SIZE"], args.gpus))
+    elif args.gpus > 1:
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import ctypes as C
+    import torch.distributed as dist
+    from era_zk_evm_amd import capi as K
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    emu = os.environ.get("ZKW_BENCH_BACKEND", "") == "emu"
+    dev = (EmuDev if emu else GpuDev)(local_rank)
+    collective = world > 1 or args.force_collective
+    if collective:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if world == 1:
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        dev.init_pg()
+
+    isa = K.Isa()
+    prod = dev.open_product(isa)
+    # The final exchange goes through the library's own entry point (zkw_reduce_commitments, include/zkw.h): an RCCL
+    # communicator created from an id that rank 0 generates and hands to the others (here over the process group that
+    # also serves the barriers).  One rank without --force-collective: a one-rank communicator without RCCL, used for
+    # the counter totals only.
+    from era_zk_evm_amd import shard
+    if collective:
+        # RCCL inside libzkw.so when every rank can create that communicator; otherwise all ranks together fall back to
+        # the library's external transport over the process group that is already up (era-zk_evm_amd/shard.py)
+        comm, transport = shard.make_comm(prod, rank, world, device=dev.tensor_device, prefer_rccl=not args.no_rccl)
+    else:
+        comm, transport = K.Comm.external(prod, 0, 1), "single rank (no transport)"
+
+    headline = args.cfg == 2 and args.instances == 4096 and args.cycles == 256 and args.lanes == 0
+    repeats = args.repeats if args.repeats >= 0 else (4 if headline and not emu else 0)
+    with_cpu = not args.no_cpu_baseline and world == 1 and not emu  # rank 0 at N = 1 only
+    out = measure(dev, prod, isa, args, rank, world, comm, collective, transport, with_cpu, repeats=repeats)
+    if rank == 0 and headline and world == 1 and not args.no_other_configs and not emu and not collective:
+        out["other_configs"], out["other_configs_wall_s"] = other_configs(dev, prod, isa, args, comm, transport, with_cpu)
     comm.close()
     if collective:
         dist.destroy_process_group()
@@ -433,13 +715,46 @@ def _cpu_topology():
     return model, out
 
 
+def _oracle_timed(orc, isa, args, cpus, n_inst, min_s=3.0, max_reps=40):
+    """best-of-N wall time of the oracle on `n_inst` instances of args' workload with persistent workers pinned to `cpus`"""
+    import ctypes as C
+    a = copy.copy(args)
+    a.instances = n_inst
+    wl = make_workload(a, isa, 0)
+    wl.limits["max_cycles"] = wl.n_cycles
+    b = orc.create_batch(wl)
+    arr = (C.c_int32 * len(cpus))(*cpus)
+    orc.lib.zkwo_batch_set_pool(b.h, C.c_uint32(len(cpus)), arr, C.c_uint32(len(cpus)))
+    best, reps, t0 = None, 0, time.perf_counter()
+    while reps < 3 or (time.perf_counter() - t0 < min_s and reps < max_reps):
+        b.reset()  # rebuilds the VMs and reserves the recorders (untimed)
+        b.run(wl.n_cycles)
+        ms = float(b.stats()["kernel_ms"])
+        best = ms if best is None else min(best, ms)
+        reps += 1
+    b.destroy()
+    return {"value": n_inst * wl.n_cycles / (best * 1e-3), "threads": len(cpus), "instances": n_inst, "best_ms": best, "runs": reps}
+
+
+def cpu_socket_rate(isa, args):
+    """other_configs: the oracle on one socket of this box, a bounded sample of the entry's workload"""
+    from tests._oracle import load_oracle  # the checker: only the cpu_baseline legs touch it
+    model, packages = _cpu_topology()
+    socket0 = packages[sorted(packages)[0]]
+    orc = load_oracle(native=True).open(isa)
+    n = max(2 * len(socket0), 256) if args.cfg in (3, 4) else max(16 * len(socket0), 1024)
+    r = _oracle_timed(orc, isa, args, socket0, n, min_s=1.0, max_reps=6)
+    orc.close()
+    return {"single_socket_value": r["value"], "single_socket_threads": r["threads"], "kind": "port", "cpu_model": model,
+            "sample": "%d instances on socket 0 (%d threads), best of %d runs of %.0f ms" % (r["instances"], r["threads"], r["runs"], r["best_ms"])}
+
+
 def cpu_baseline(isa, args, prod=None):
     """The oracle (C++ restatement of zk_evm v1.4.1 cycle(), -O3 -march=native) timed on this box's host cores on a
     bounded sample of the same workload: persistent pinned worker threads (no thread creation in the timed region),
     one contiguous block of >= 64 instances per worker, recorder capacity reserved before the clock starts.  Three
     figures: one core, one socket (every hardware thread of package 0), the whole box."""
-    from era_zk_evm_amd import capi as K, synth
-    import ctypes as C
+    from era_zk_evm_amd import capi as K
     import numpy as np
     from tests._oracle import load_oracle  # the checker: only the cpu_baseline leg touches it
 
@@ -449,27 +764,10 @@ def cpu_baseline(isa, args, prod=None):
     orc = load_oracle(native=True).open(isa)
     res = {}
     t_leg = time.perf_counter()
-
-    def timed(label, cpus, n_inst):
-        wl = synth.make(args.cfg, isa, n_instances=n_inst, n_cycles=args.cycles)
-        wl.limits["max_cycles"] = args.cycles
-        b = orc.create_batch(wl)
-        arr = (C.c_int32 * len(cpus))(*cpus)
-        orc.lib.zkwo_batch_set_pool(b.h, C.c_uint32(len(cpus)), arr, C.c_uint32(len(cpus)))
-        best, reps, t0 = None, 0, time.perf_counter()
-        while reps < 3 or (time.perf_counter() - t0 < 3.0 and reps < 40):
-            b.reset()  # rebuilds the VMs and reserves the recorders (untimed)
-            b.run(wl.n_cycles)
-            ms = float(b.stats()["kernel_ms"])
-            best = ms if best is None else min(best, ms)
-            reps += 1
-        res[label] = {"value": n_inst * wl.n_cycles / (best * 1e-3), "threads": len(cpus), "instances": n_inst, "best_ms": best, "runs": reps}
-        b.destroy()
-
-    timed("one_core", all_cpus[:1], 256)
-    timed("one_socket", socket0, max(64 * len(socket0), 4096))
+    res["one_core"] = _oracle_timed(orc, isa, args, all_cpus[:1], 256)
+    res["one_socket"] = _oracle_timed(orc, isa, args, socket0, max(64 * len(socket0), 4096))
     if len(all_cpus) > len(socket0):
-        timed("whole_box", all_cpus, max(64 * len(all_cpus), 4096))
+        res["whole_box"] = _oracle_timed(orc, isa, args, all_cpus, max(64 * len(all_cpus), 4096))
     else:
         res["whole_box"] = res["one_socket"]
     phys = len(set(all_cpus))
@@ -489,15 +787,19 @@ def cpu_baseline(isa, args, prod=None):
     # the same leg validates the product against the checker on a fresh small batch of the bench's workload: every
     # queue commitment of every instance and the full traces of a few instances, bit for bit
     if prod is not None:
-        wl = synth.make(args.cfg, isa, n_instances=128, n_cycles=args.cycles, seed=0x5EED0000 + args.cfg)
+        a = copy.copy(args)
+        a.instances = 128
+        wl = make_workload(a, isa, 0)
         bo, bp = orc.create_batch(wl), prod.create_batch(wl)
         for b in (bo, bp):
             b.reset(); b.run(wl.n_cycles); b.sync()
         same = bool(np.array_equal(bo.commitments(), bp.commitments()))
         traces = all(K.traces_equal(bo.trace(i), bp.trace(i))[0] for i in (0, 1, 63, 64, 127))
         out["product_vs_oracle"] = {"instances": 128, "commitments_equal": same, "traces_equal": traces}
+        bo.destroy(); bp.destroy()
         if not (same and traces):
             raise RuntimeError("bench: the product's witness differs from the oracle's on the validation batch")
+    orc.close()
     return out
 
 

@@ -284,6 +284,11 @@ class Backend:
         arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])
         self.call("batches_step", arr, C.c_uint32(len(batches)), C.c_uint32(max_cycles), C.c_uint32(queue_mask), C.c_void_p(stream))
 
+    def step_prepared_many(self, batches, max_cycles, queue_mask=0, stream=None):
+        """zkw_batches_step_prepared: run + commit of batches whose inputs are in place (uploaded / restored earlier)."""
+        arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])
+        self.call("batches_step_prepared", arr, C.c_uint32(len(batches)), C.c_uint32(max_cycles), C.c_uint32(queue_mask), C.c_void_p(stream))
+
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32)

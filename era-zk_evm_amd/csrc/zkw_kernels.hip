@@ -2580,7 +2580,10 @@ ZD void lane_writeback(ZKW_KP P, Shared& sh, const RegFile& rf, Lane& s, u32 com
   const u32 tid = s.lane;
   if (s.status == ZKW_STATUS_RUNNING && s.depth == 0) s.status = ZKW_STATUS_ENDED;  // execution_has_ended() (mod.rs:96-98)
   frame_writeback(P, sh, s);
-  hwm_writeback(P, sh, s);
+  // An instance that has ended has no current frame with pages: the root entry names the bootloader's arena slot, whose
+  // meta op_ret has just settled (finish_global_frame, memory.rs:668-731: stack page and the page that is not the
+  // returndata back to the pool) — the marks frame_load picked up before that must not go back over it.
+  if (s.depth != 0) hwm_writeback(P, sh, s);
   zkw_dev_scalars sc;
 #pragma unroll
   for (int i = 0; i < 4; i++) {

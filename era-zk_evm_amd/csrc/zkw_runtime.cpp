@@ -1039,7 +1039,10 @@ static int enqueue_run(zkw_batch* const* bs, uint32_t n, uint32_t max_cycles, hi
   }
   A.uniform_waves = uniform ? bs[0]->n_waves : 0;
   A.waves_per_group = pick_waves_per_group(c, A.wave_base[n]);
-  A.debug_flags = c->opt_debug_flags;  // profiling ablations / test hooks only
+  // profiling ablations / test hooks only; the launch-internal bits (inline decommit chain, helper waves) are decided
+  // below and never taken from the caller: set from outside with no helper wave launched they would make the cycle waves
+  // post into LDS address 0 (the ISA table) or wait for a helper that does not exist
+  A.debug_flags = c->opt_debug_flags & ~(16u | ZKW_DQ_HELPER | ZKW_KECCAK_HELPER);
   if (inline_decommit) A.debug_flags |= 16u;
   {
     // A helper wave per workgroup takes the decommit chain off the cycle waves (zkw_dq_helper) when the CUs have a wave
@@ -1176,6 +1179,15 @@ int zkw_batches_step(zkw_batch* const* batches, uint32_t n_batches, uint32_t max
   hipStream_t st = (hipStream_t)hip_stream;
   rc = enqueue_reset(batches, n_batches, st);
   if (rc == ZKW_OK) rc = enqueue_run(batches, n_batches, max_cycles, st, (queue_mask >> ZKW_QUEUE_DECOMMIT) & 1u, true);
+  if (rc == ZKW_OK && queue_mask) rc = enqueue_commit(batches, n_batches, queue_mask, st);
+  return rc;
+}
+
+int zkw_batches_step_prepared(zkw_batch* const* batches, uint32_t n_batches, uint32_t max_cycles, uint32_t queue_mask, void* hip_stream) {
+  int rc = check_group(batches, n_batches);
+  if (rc != ZKW_OK) return rc;
+  hipStream_t st = (hipStream_t)hip_stream;
+  rc = enqueue_run(batches, n_batches, max_cycles, st, (queue_mask >> ZKW_QUEUE_DECOMMIT) & 1u, true);
   if (rc == ZKW_OK && queue_mask) rc = enqueue_commit(batches, n_batches, queue_mask, st);
   return rc;
 }

@@ -982,6 +982,32 @@ def many_far_calls(isa, n_calls=64, n_instances=8, seed=0x5EED00F7, plan=None, m
 
 
 
+# ----------------------------------------------------------------------------------------
+# the bootloader itself returns (the instance ENDS) with its heap / aux heap as returndata, or panics: what
+# `dump_page_content` sees of the bootloader's pages afterwards follows finish_global_frame (memory.rs:660-758) — the stack
+# page and the page that is not the returndata go back to the pool
+# ----------------------------------------------------------------------------------------
+def bootloader_returns(isa, how="heap", n_instances=3, seed=0x5EED00F9):
+    e = isa.enc
+    wl = Workload("bootloader_returns_%s" % how, n_instances, 8)
+    ops = [e(K.OP_ADD, dst0_mode=K.MODE_STACK_ABS, src0=1, src1=2, dst0=0, imm1=7),               # stack[7]
+           e(K.OP_UMA, variant=K.UMA_AUX_WRITE, src0_mode=K.MODE_IMM, imm0=0, src1=3),            # aux[0]
+           e(K.OP_UMA, variant=K.UMA_HEAP_WRITE, src0_mode=K.MODE_IMM, imm0=40, src1=4),          # heap[1..2]
+           e(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=16, src1=0, dst0=13),
+           e(K.OP_RET, variant=K.RET_PANIC if how == "panic" else K.RET_OK, flags=0, src0=13)]
+    words = np.zeros((24, 4), dtype="<u8")
+    code = K.pack_code(ops)
+    words[: len(code)] = code
+    words[16] = ret_abi(0, 128, forwarding_mode={"heap": 0, "aux": 2, "panic": 0}[how])
+    wl.blobs.append(words)
+    wl.code_pages.append((0, n_instances, BOOTLOADER_CODE_PAGE, 0))
+    regs = Xoshiro(seed ^ 0xABCDEF, n_instances).words(15)
+    wl.states, wl.inner = initial_states(n_instances, regs)
+    wl.heaps = Xoshiro(seed ^ 0x4EA9, n_instances).words(16)
+    wl.limits.update(max_far_frames=2, heap_words=32, stack_words=16, aux_heap_words=8)
+    return wl
+
+
 def make(cfg, isa, **kw):  # noqa: F811
     return {0: config0, 1: config1, 2: config2, 3: config3, 4: config4}[cfg](isa, **kw)
 

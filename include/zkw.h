@@ -482,6 +482,12 @@ int zkw_batches_commit(zkw_batch* const* batches, uint32_t n_batches, uint32_t q
  * can chain while it runs (the decommit queue: one sponge permutation inside every far call that decommits) and a later
  * zkw_batches_commit / zkw_batch_commit skips those queues.  zkw_batches_step does the same implicitly. */
 int zkw_batches_run_committing(zkw_batch* const* batches, uint32_t n_batches, uint32_t max_cycles, uint32_t queue_mask, void* hip_stream);
+/* zkw_batches_step without its restore, for batches whose inputs are already in place: freshly uploaded, or restored by
+ * a zkw_batches_reset that the caller enqueued earlier (typically right behind the previous use of the group, on a side
+ * stream, so that the restore of a reused group never sits in front of its next run).  Run + commitments of one group on
+ * one stream — a whole step as far as the launch geometry is concerned (helper waves).  A batch that has
+ * run since its last reset continues from where it stopped, as with zkw_batches_run. */
+int zkw_batches_step_prepared(zkw_batch* const* batches, uint32_t n_batches, uint32_t max_cycles, uint32_t queue_mask, void* hip_stream);
 /* mean device time (ms) of the cycle-kernel launches recorded on this batch since the last call / sync — HIP event
  * pairs on the launch stream; for fused launches the pairs live on batches[0].  Waits for the last recorded launch only. */
 int zkw_batch_kernel_time(zkw_batch* batch, double* mean_ms, uint32_t* n_launches);

@@ -118,3 +118,19 @@ def _check_pair(j, path):
     # and the roofline figure is algorithmic bytes per launch over that duration
     r = j["roofline"]
     assert abs(r["achieved"] - r["bytes_per_cycle"] * r["cycles_per_launch"] / (j["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
+
+
+def test_roofline_accounting_is_frozen():
+    """DESIGN.md 6 (the rule): the headline workload's algorithmic bytes per VM cycle are the round-3 figure — a byte the
+    kernel stops writing raises `roofline.frac`, it does not lower the denominator; the run's own bytes are a separate field."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.ALGORITHMIC_BYTES_R3 == 149.125
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "b_cycle = ALGORITHMIC_BYTES_R3 if headline_shape else b_run" in src
+    assert '"bytes_per_cycle_this_run": b_run' in src and '"algorithmic_bytes_r3"' in src
+    j, _ = latest_bench_line()
+    if j["config"].get("instances_per_gpu") == 4096 and j["config"].get("cycles_per_instance") == 256 and "algorithmic_bytes_r3" in j["roofline"]:
+        assert j["roofline"]["bytes_per_cycle"] == 149.125

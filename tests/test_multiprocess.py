@@ -105,3 +105,69 @@ def test_two_rank_reduce_commitments_entry(tmp_path, oracle, isa, n_total):
             assert not gathered[r, j, sizes[r]:].any()  # padding rows
     st = b.stats()
     assert list(meta[3:]) == [2 * int(st["cycles"]), 2 * int(st["mem_queries"]), 2 * int(st["log_queries"]), 2 * int(st["aux_events"])]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.py's own N > 1 orchestration — launches, overlap over "streams", restore between uses, zkw_reduce_commitments per
+# launch, barriers, the MAX / SUM all-reduces of the line — on the CPU build of the product under gloo
+# (ZKW_BENCH_BACKEND=emu).  The 1 -> 8 GPU curve itself is unmeasured here: this covers the code path, not its speed.
+# ---------------------------------------------------------------------------------------------------------------------
+def _worker_bench(rank, world, port, argv, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      ZKW_BENCH_BACKEND="emu", ZKW_BENCH_DUMP_GATHERED=os.path.join(out_dir, "gathered.npy"))
+    sys.path.insert(0, ROOT)
+    sys.argv = ["bench.py", "--gpus", str(world)] + argv
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    if rank == 0:
+        sys.stdout = open(os.path.join(out_dir, "stdout.txt"), "w")
+    bench.main()
+    sys.stdout.flush()
+
+
+def _bench_flow(tmp_path, oracle, isa, world, argv, n_inst, fuse, groups):
+    import json
+    import torch.multiprocessing as mp
+    import importlib.util
+    port = _free_port()
+    mp.spawn(_worker_bench, args=(world, port, argv, str(tmp_path)), nprocs=world, join=True)
+    lines = [ln for ln in open(tmp_path / "stdout.txt").read().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # ONE JSON line, from rank 0
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == world and j["scaling"] == "weak" and j["config"]["backend"] == "emu"
+    assert j["config"]["collective"].startswith("external over torch.distributed (gloo)"), j["config"]["collective"]
+    assert j["checked"]["batches"] == world * groups * fuse and j["checked"]["instances_failed"] == 0
+    assert j["checked"]["cycles_executed"] == world * groups * fuse * n_inst * 256
+    assert abs(j["value"] - world * n_inst * 256 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6  # whole-job aggregate over all ranks
+    # the digests the last full launch of group 0 gathered: every rank's shard (its own seed), in rank order
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = bench.parse_args(["--gpus", str(world)] + argv)
+    gathered = np.load(tmp_path / "gathered.npy")  # [world][fuse][instances][2 queues][4]
+    assert gathered.shape == (world, fuse, n_inst, 2, 4)
+    for r in range(world):
+        wl = bench.make_workload(a, isa, r)
+        b = oracle.create_batch(wl)
+        b.reset(); b.run(wl.n_cycles); b.sync()
+        want = b.commitments()
+        for k in range(fuse):
+            assert np.array_equal(gathered[r, k, :, 0], want[:, 0]) and np.array_equal(gathered[r, k, :, 1], want[:, 2]), (r, k)
+        b.destroy()
+    return j
+
+
+def test_bench_flow_world2(tmp_path, oracle, isa):
+    """two groups in flight, a partial last launch, the restore of a reused group on its side 'stream'"""
+    argv = ["--steps", "5", "--warmup", "2", "--fuse", "2", "--streams", "2", "--instances", "5", "--commit-mask", "5", "--no-cpu-baseline", "--min-warmup-s", "0"]
+    j = _bench_flow(tmp_path, oracle, isa, 2, argv, 5, 2, 2)
+    assert j["config"]["cycle_kernel_launches"] == 3 and j["config"]["restores_in_timed_region"] == 1
+
+
+def test_bench_flow_world8(tmp_path, oracle, isa):
+    """the driver's N = 8 launch shape: one rank per GPU under torch.distributed, one fused group per rank and launch"""
+    argv = ["--steps", "4", "--warmup", "2", "--fuse", "2", "--streams", "2", "--instances", "3", "--commit-mask", "5", "--no-cpu-baseline", "--min-warmup-s", "0"]
+    j = _bench_flow(tmp_path, oracle, isa, 8, argv, 3, 2, 2)
+    assert j["config"]["cycle_kernel_launches"] == 2 and j["config"]["restores_in_timed_region"] == 0
