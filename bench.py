@@ -336,8 +336,11 @@ class Flow:
         t0 = time.perf_counter()
         n_launches = self.run_steps(k)
         t_enq = time.perf_counter() - t0  # host time spent enqueueing (launch-bound check)
-        self.sync_streams()
-        self.barrier()
+        if self.collective:
+            self.sync_streams()
+            self.barrier()
+        else:
+            self.dev.sync()  # one rank: torch.cuda.synchronize() IS the barrier + synchronize (every stream of the device)
         elapsed = time.perf_counter() - t0
         return elapsed, n_launches, t_enq, self.drain_timing(), self.restores - r0
 
@@ -566,8 +569,11 @@ def other_configs(dev, prod, isa, base_args, comm, transport, with_cpu):
         a.cycles = oc["cycles"] or 256
         a.lanes, a.min_warmup_s, a.restore = 0, 0.2, "between-uses"
         t0 = time.perf_counter()
+        oc_comm = None
         try:
-            line = measure(dev, prod, isa, a, 0, 1, comm, False, transport, False, repeats=0)
+            from era_zk_evm_amd import capi as K
+            oc_comm = K.Comm.external(prod, 0, 1)  # a communicator of its own: the shard size differs from the headline's
+            line = measure(dev, prod, isa, a, 0, 1, oc_comm, False, transport, False, repeats=0)
             entry = {"workload": oc["label"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "steps": a.steps, "kernel_ms": line["kernel_ms"],
                      "batches_per_fused_launch": line["config"]["batches_per_fused_launch"], "commit_mask": a.commit_mask,
                      "roofline": {"bound": "hbm", "frac": line["roofline"]["frac"], "achieved": line["roofline"]["achieved"], "unit": "GB/s",
@@ -586,6 +592,8 @@ def other_configs(dev, prod, isa, base_args, comm, transport, with_cpu):
                 entry["cpu_baseline"] = cb
         except Exception as e:  # noqa: BLE001  (an extra configuration must not take the headline line with it)
             entry = {"workload": oc["label"], "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        if oc_comm is not None:
+            oc_comm.close()
         entry["wall_s"] = time.perf_counter() - t0
         res.append(entry)
     return res, time.perf_counter() - t_all
@@ -742,7 +750,7 @@ def cpu_socket_rate(isa, args):
     model, packages = _cpu_topology()
     socket0 = packages[sorted(packages)[0]]
     orc = load_oracle(native=True).open(isa)
-    n = max(2 * len(socket0), 256) if args.cfg in (3, 4) else max(16 * len(socket0), 1024)
+    n = max(2 * len(socket0), 256) if args.cfg in (3, 4) else max(64 * len(socket0), 4096)
     r = _oracle_timed(orc, isa, args, socket0, n, min_s=1.0, max_reps=6)
     orc.close()
     return {"single_socket_value": r["value"], "single_socket_threads": r["threads"], "kind": "port", "cpu_model": model,

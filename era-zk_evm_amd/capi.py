@@ -61,8 +61,10 @@ ISA_CONSTS = _dt([("nop_encoding", "<u8", 0), ("exception_revert_encoding", "<u8
                   ("initial_storage_write_pubdata_bytes", "<u4", 56), ("l1_message_pubdata_bytes", "<u4", 60), ("max_offset_to_deref_low", "<u4", 64),
                   ("deployer_address_low", "<u4", 68), ("keccak_precompile_address", "<u4", 72), ("sha256_precompile_address", "<u4", 76),
                   ("ecrecover_precompile_address", "<u4", 80), ("storage_aux_byte", "u1", 84), ("event_aux_byte", "u1", 85),
-                  ("l1_message_aux_byte", "u1", 86), ("precompile_aux_byte", "u1", 87), ("ecrecover_input_layout", "<u4", 88), ("bootloader_calldata_page", "<u4", 92), ("reserved", ("<u4", 6), 96)], 120)
-ISA_TABLE = _dt([("entries", (ISA_ENTRY, ISA_TABLE_SIZE), 0), ("consts", ISA_CONSTS, 12 * ISA_TABLE_SIZE)], 12 * ISA_TABLE_SIZE + 120)
+                  ("l1_message_aux_byte", "u1", 86), ("precompile_aux_byte", "u1", 87), ("ecrecover_input_layout", "<u4", 88), ("bootloader_calldata_page", "<u4", 92),
+                  ("call_regs", "<u4", 96), ("call_ranges", "<u4", 100), ("ret_regs", "<u4", 104), ("forwarding_codes", "<u4", 108), ("unmapped_page", "<u4", 112),
+                  ("reserved0", "<u4", 116), ("max_offset_for_add_sub", "<u8", 120), ("condition_lut", "<u8", 128)], 136)
+ISA_TABLE = _dt([("entries", (ISA_ENTRY, ISA_TABLE_SIZE), 0), ("consts", ISA_CONSTS, 12 * ISA_TABLE_SIZE)], 12 * ISA_TABLE_SIZE + 136)
 
 CALLSTACK_ENTRY = _dt([("this_address", ("u1", 20), 0), ("msg_sender", ("u1", 20), 20), ("code_address", ("u1", 20), 40), ("base_memory_page", "<u4", 60),
                        ("code_page", "<u4", 64), ("sp", "<u2", 68), ("pc", "<u2", 70), ("exception_handler_location", "<u2", 72), ("is_static", "u1", 74),
@@ -168,8 +170,75 @@ class Isa:
             self._cache[key] = int(idx[0])
         return self._cache[key]
 
+    # truth tables of the eight Conditions over (lt | eq << 1 | gt << 2), in the order of COND_* (cycle.rs:193-209)
+    COND_TRUTH = (0xFF, 0xF0, 0xAA, 0xCC, 0xFC, 0xEE, 0x33, 0xFA)
+
+    def cond_field(self, cond):
+        """the 3-bit field value that names the logical condition COND_* under this table's condition_lut"""
+        lut = int(self.consts["condition_lut"])
+        for f in range(8):
+            if (lut >> (8 * f)) & 0xFF == self.COND_TRUTH[cond & 7]:
+                return f
+        raise KeyError("condition %d has no field value in this table" % cond)
+
+    def fwd_code(self, kind):
+        """ABI byte of FarCallForwardPageType `kind` (0 UseHeap, 1 ForwardFatPointer, 2 UseAuxHeap) under this table"""
+        return (int(self.consts["forwarding_codes"]) >> (8 * kind)) & 0xFF
+
+    @classmethod
+    def variant_of_default(cls, seed, permute=True, reprice=False, clip_mode=None, swap_forwarding=False, permute_conditions=False, shift_registers=False):
+        """A table that differs from the recalled default in what the absent crates decide: the numbering of
+        the 2048 variants, the prices, the clip mode, the forwarding-mode byte codes, the condition a field value names, the
+        register conventions of far_call / ret.  Programs built through `enc` / `fwd_code` follow the table."""
+        base = cls()
+        t = base.table.copy()
+        rng = np.random.default_rng(seed)
+        c = t["consts"][0]
+        if permute:
+            perm = rng.permutation(ISA_TABLE_SIZE)
+            e = base.table["entries"][0]
+            t["entries"][0][perm] = e
+            c["nop_variant_idx"] = perm[int(c["nop_variant_idx"])]
+            c["panic_variant_idx"] = perm[int(c["panic_variant_idx"])]
+        if reprice:
+            t["entries"][0]["price"] = t["entries"][0]["price"] * 3 + 5
+        if clip_mode is not None:
+            c["clip_mode"] = clip_mode
+        if swap_forwarding:
+            c["forwarding_codes"] = 2 | (7 << 8) | (0 << 16)  # UseHeap = 2, ForwardFatPointer = 7, UseAuxHeap = 0
+        if permute_conditions:
+            rows = [int(x) for x in rng.permutation(8)]
+            lut = int(c["condition_lut"])
+            c["condition_lut"] = sum(((lut >> (8 * rows[f])) & 0xFF) << (8 * f) for f in range(8))
+        if shift_registers:  # calldata pointer in r2, marker in r1, implicit parameter in r14, reserved range r13 + r15 ...
+            c["call_regs"] = 1 | (0 << 8) | (13 << 16)
+            c["call_ranges"] = 3 | (11 << 8) | (11 << 16) | (13 << 24)
+            c["ret_regs"] = 1 | (0 << 8) | (2 << 16) | (4 << 24)
+        out = cls(t)
+        always = out.cond_field(COND_ALWAYS)
+        c["nop_encoding"] = int(c["nop_variant_idx"]) | (always << 13)
+        c["exception_revert_encoding"] = int(c["panic_variant_idx"]) | (always << 13)
+        return out
+
+    def canonical_opcode(self, word):
+        """an opcode word of this table -> the same instruction under the default table (variant index and condition field
+        mapped back); None when the variant index names no instruction"""
+        if not hasattr(self, "_canon"):
+            d = Isa()
+            self._canon = d
+        e = self.table["entries"][0][int(word) & 0x7FF]
+        try:
+            idx = self._canon.find(int(e["opcode"]), int(e["variant"]), int(e["src0_mode"]), int(e["dst0_mode"]), int(e["flags"]))
+        except KeyError:
+            return None
+        lut = int(self.consts["condition_lut"])
+        truth = (lut >> (8 * ((int(word) >> 13) & 7))) & 0xFF
+        cond = self.COND_TRUTH.index(truth)
+        return (int(word) & ~0x7FF & ~(7 << 13)) | idx | (cond << 13)
+
     def enc(self, opcode, variant=0, src0_mode=MODE_REG, dst0_mode=MODE_REG, flags=0, cond=COND_ALWAYS, src0=0, src1=0, dst0=0, dst1=0, imm0=0, imm1=0):
         idx = self.find(opcode, variant, src0_mode, dst0_mode, flags)
+        cond = self.cond_field(cond)
         return (idx & 0x7FF) | ((cond & 7) << 13) | ((src0 & 15) << 16) | ((src1 & 15) << 20) | ((dst0 & 15) << 24) | ((dst1 & 15) << 28) | (
             (imm0 & 0xFFFF) << 32) | ((imm1 & 0xFFFF) << 48)
 

@@ -144,6 +144,15 @@ int zkw_isa_default(zkw_isa_table* out) {
   c.l1_message_aux_byte = 2;
   c.precompile_aux_byte = 3;
   c.bootloader_calldata_page = 3;  // recalled from zkevm_opcode_defs (UNVERIFIED; SURVEY App. B lists it as unknown): a table constant for that reason
+  c.call_regs = 0u | (1u << 8) | (14u << 16);
+  c.call_ranges = 2u | (12u << 8) | (12u << 16) | (14u << 24);
+  c.ret_regs = 0u | (1u << 8) | (2u << 16) | (3u << 24);
+  c.forwarding_codes = 0u | (1u << 8) | (2u << 16);
+  c.unmapped_page = 0;
+  c.reserved0 = 0;
+  c.max_offset_for_add_sub = 1ull << 32;
+  // Always, Gt, Lt, Eq, Ge, Le, Ne, GtOrLt over (lt | eq << 1 | gt << 2)
+  c.condition_lut = 0xffull | (0xf0ull << 8) | (0xaaull << 16) | (0xccull << 24) | (0xfcull << 32) | (0xeeull << 40) | (0x33ull << 48) | (0xfaull << 56);
   return ZKW_OK;
 }
 

@@ -112,6 +112,15 @@ enum {
   ZD void cfv_set_##name(const Shared&, const Lane&, u32 v) { asm volatile("v_mov_b32 " reg ", %0" : : "v"(v) : reg); }
 #endif
 
+// Profiling ablations (debug_flags 1 / 2 / 8 / 32 / 64 / 128, ZKW_NO_PREFETCH: stores or whole phases left out, WRONG results)
+// exist only in builds with -DZKW_ABLATION (profiles/tools/r06_ablate.sh builds one): in the product every one of them was
+// a scalar test + branch on the hot path — a dozen per VM cycle.  The TEST hooks (4: one lane per group, 1 << 24: variant
+// groups forced, 8..23: opcodes kept out of variant groups) stay: they sit on the divergent-wave path only.
+#ifdef ZKW_ABLATION
+#define ZKW_ABL(flags, bit) (((flags) & (bit)) != 0)
+#else
+#define ZKW_ABL(flags, bit) false
+#endif
 #define FLAG_LT 1u
 #define FLAG_EQ 2u
 #define FLAG_GT 4u
@@ -177,14 +186,14 @@ __shared__ unsigned long long zp_acc[ZKW_MAX_WAVES_PER_GROUP][80];  // 0-3 phase
 #define ZKW_SUB(i)                                                                       \
   {                                                                                      \
     const unsigned long long zs_now = __builtin_readcyclecounter();                      \
-    if (zkw_rank_below(__ballot(1)) == 0) zp_acc[sh.wib][(i)] += zs_now - zs_last;       \
+    if (zkw_rank_below(zkw_ballot(1)) == 0) zp_acc[sh.wib][(i)] += zs_now - zs_last;       \
     zs_last = zs_now;                                                                    \
   }
 #define ZKW_PROF_DECL unsigned long long zp_last = __builtin_readcyclecounter();
 #define ZKW_PROF(i)                                                                      \
   {                                                                                      \
     const unsigned long long zp_now = __builtin_readcyclecounter();                      \
-    if (zkw_rank_below(__ballot(1)) == 0) zp_acc[sh.wib][(i)] += zp_now - zp_last;       \
+    if (zkw_rank_below(zkw_ballot(1)) == 0) zp_acc[sh.wib][(i)] += zp_now - zp_last;       \
     zp_last = zp_now;                                                                    \
   }
 #define ZKW_PROF_RESET zp_last = __builtin_readcyclecounter();
@@ -192,12 +201,12 @@ __shared__ unsigned long long zp_acc[ZKW_MAX_WAVES_PER_GROUP][80];  // 0-3 phase
 #define ZKW_STAMP0                                                                        \
   {                                                                                      \
     const unsigned long long zt_now = __builtin_readcyclecounter();                      \
-    if (zkw_rank_below(__ballot(1)) == 0) zp_acc[sh.wib][63] = zt_now;                    \
+    if (zkw_rank_below(zkw_ballot(1)) == 0) zp_acc[sh.wib][63] = zt_now;                    \
   }
 #define ZKW_STAMP(i)                                                                     \
   {                                                                                      \
     const unsigned long long zt_now = __builtin_readcyclecounter();                      \
-    if (zkw_rank_below(__ballot(1)) == 0) {                                              \
+    if (zkw_rank_below(zkw_ballot(1)) == 0) {                                              \
       zp_acc[sh.wib][(i)] += zt_now - zp_acc[sh.wib][63];                                \
       zp_acc[sh.wib][63] = zt_now;                                                       \
     }                                                                                    \
@@ -218,6 +227,12 @@ __shared__ unsigned long long zp_acc[ZKW_MAX_WAVES_PER_GROUP][80];  // 0-3 phase
 // LDS and belongs to this wave alone, and a wave's LDS operations complete in program order, so the base is a plain
 // broadcast read by every participating lane followed by one plain write of the leader — no atomic, no shuffle.
 // ---------------------------------------------------------------------------------------------
+// wave mask of a per-lane condition: the compare writes the mask directly (HIP's zkw_ballot(int) first materialises 0 / 1 per lane)
+#ifdef __HIP_DEVICE_COMPILE__
+#define zkw_ballot(p) __builtin_amdgcn_ballot_w64((bool)(p))
+#else
+#define zkw_ballot(p) __ballot((p) ? 1 : 0)
+#endif
 // number of set bits of `mask` below this lane (v_mbcnt_lo/hi: no per-lane mask register to keep alive)
 #ifdef __HIP_DEVICE_COMPILE__
 ZD u32 zkw_rank_below(u64 mask) { return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u)); }
@@ -253,11 +268,7 @@ ZD void zkw_set_lane_regs(u32 cold_lds, u32 slot_lds, u32 lane) {
   asm volatile("v_mov_b32 v131, %0\n\tv_mov_b32 v132, %1\n\tv_mov_b32 v133, %2" : : "v"(cold_lds + lane * 4u), "v"(slot_lds + lane * 16u), "v"(lane) : "v131", "v132", "v133");
 }
 // bit `lane` of a wave mask: a select on the mask itself (no 1 << lane register to keep alive)
-ZD bool zkw_lane_bit(u64 mask) {
-  u32 r;
-  asm("v_cndmask_b32 %0, 0, 1, %1" : "=v"(r) : "s"(mask));
-  return r != 0;
-}
+ZD bool zkw_lane_bit(u64 mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }  // (the mask itself becomes the branch condition: no per-lane value at all)
 #else
 ZD bool zkw_lane_bit(u64 mask) { return ((mask >> (threadIdx.x & (ZKW_WAVE - 1))) & 1ull) != 0; }
 ZD u32 zkw_rank_below(u64 mask) { return (u32)__popcll(mask & ((1ull << (threadIdx.x & (ZKW_WAVE - 1))) - 1ull)); }
@@ -303,7 +314,7 @@ ZD void zkw_cursor_set(u32 v) {
 }
 template <int WHICH>
 ZD u32 stream_alloc(u32*) {
-  const u64 mask = __ballot(1);
+  const u64 mask = zkw_ballot(1);
   const u32 cnt = (u32)__popcll(mask);
   u32 base, next;
   asm volatile("v_readlane_b32 %0, v128, %2\n\ts_nop 0\n\ts_add_u32 %1, %0, %3\n\ts_nop 0\n\tv_writelane_b32 v128, %1, %2"
@@ -315,7 +326,7 @@ ZD u32 stream_alloc(u32*) {
 #else
 template <int WHICH>
 ZD u32 stream_alloc(u32* cursors) {
-  const u64 mask = __ballot(1);
+  const u64 mask = zkw_ballot(1);
   const u32 rank = zkw_rank_below(mask);
   const u32 base = *ZKW_LDS_WORD(cursors + WHICH);
   if (rank == 0) *ZKW_LDS_WORD(cursors + WHICH) = base + (u32)__popcll(mask);
@@ -375,7 +386,7 @@ __shared__ unsigned long long zw_acc[ZKW_MAX_WAVES_PER_GROUP][32];  // [site] cl
     const unsigned long long zw_t0 = __builtin_readcyclecounter();                                         \
     __builtin_amdgcn_s_waitcnt(0x0f70);                                                                    \
     const unsigned long long zw_t1 = __builtin_readcyclecounter();                                         \
-    if (zkw_rank_below(__ballot(1)) == 0) {                                                                \
+    if (zkw_rank_below(zkw_ballot(1)) == 0) {                                                                \
       zw_acc[threadIdx.x / ZKW_WAVE][(site)] += zw_t1 - zw_t0;                                             \
       zw_acc[threadIdx.x / ZKW_WAVE][16 + (site)] += 1;                                                    \
     }                                                                                                      \
@@ -386,7 +397,7 @@ __shared__ unsigned long long zw_acc[ZKW_MAX_WAVES_PER_GROUP][32];  // [site] cl
     const unsigned long long zw_t0 = __builtin_readcyclecounter();                                         \
     __builtin_amdgcn_s_waitcnt(0xc07f);                                                                    \
     const unsigned long long zw_t1 = __builtin_readcyclecounter();                                         \
-    if (zkw_rank_below(__ballot(1)) == 0) {                                                                \
+    if (zkw_rank_below(zkw_ballot(1)) == 0) {                                                                \
       zw_acc[threadIdx.x / ZKW_WAVE][(site)] += zw_t1 - zw_t0;                                             \
       zw_acc[threadIdx.x / ZKW_WAVE][16 + (site)] += 1;                                                    \
     }                                                                                                      \
@@ -506,7 +517,7 @@ ZD void emit_mem(ZKW_KP P, Shared& sh, Lane& s, u32 ts, u32 type, u32 page, u32 
     lane_fail(s, ZKW_STATUS_LIMIT);
     return;
   }
-  if (sh.debug_flags & 2u) return;
+  if (ZKW_ABL(sh.debug_flags, 2u)) return;
   const u32 meta = (type & ZKW_MQ_TYPE_MASK) | (is_ptr ? ZKW_MQ_IS_PTR : 0u) | (rw ? ZKW_MQ_RW : 0u) | (kind << ZKW_MQ_KIND_SHIFT);
   // three planes of 16-byte units (header | value low | value high), each [cap_mem]: every store instruction of the
   // wave then covers whole 64-byte lines.  As 48-byte records (three partial-line stores per record) the stream cost
@@ -617,17 +628,17 @@ struct RegFileVec {};
 // for all lanes, with the first lane's register.
 ZD u256 rf_get(const RegFileVec&, u32 reg) {
   u256 v = u256_zero();
-  u64 todo = __ballot(1);
+  u64 todo = zkw_ballot(1);
   while (todo) {
     const u32 r = (u32)__builtin_amdgcn_readlane((int)reg, (int)((u32)__ffsll((long long)todo) - 1u));
     const bool m = reg == r;
     if (m) v = rf_get(RegFile(), r);
-    todo &= ~__ballot(m);
+    todo &= ~zkw_ballot(m);
   }
   return v;
 }
 ZD void rf_set(RegFileVec&, u32 reg, const u256& v) {
-  u64 todo = __ballot(1);
+  u64 todo = zkw_ballot(1);
   while (todo) {
     const u32 r = (u32)__builtin_amdgcn_readlane((int)reg, (int)((u32)__ffsll((long long)todo) - 1u));
     const bool m = reg == r;
@@ -635,7 +646,7 @@ ZD void rf_set(RegFileVec&, u32 reg, const u256& v) {
       RegFile f;
       rf_set(f, r, v);
     }
-    todo &= ~__ballot(m);
+    todo &= ~zkw_ballot(m);
   }
 }
 #else  // single-lane CPU emulation build of tests/emu
@@ -707,7 +718,7 @@ ZD void stack_write(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, const u256& v,
     zkw_gstore1(sh.stack_ptrs + w, 0);
   }
   const u32 w = page_word_index(sh, s, cfv_slot(sh, s), sh.S, idx);
-  if (!(sh.debug_flags & 128u)) {  // (128: traffic ablation — the run is then wrong)
+  if (!ZKW_ABL(sh.debug_flags, 128u)) {  // (128: traffic ablation — the run is then wrong)
     zkw_gstore4(sh.stack_vals + (2 * w - s.lane), u256_lo4(v));
     zkw_gstore4(sh.stack_vals + (2 * w - s.lane + sh.L), u256_hi4(v));
     zkw_gstore1(sh.stack_ptrs + w, is_ptr ? 1 : 0);
@@ -745,11 +756,11 @@ ZD void heap_write_at(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 slot
     zkw_gstore4(base + (2 * w - s.lane + sh.L), make_uint4(0, 0, 0, 0));
   }
   const u32 w = page_word_index(sh, s, slot, words, idx);
-  if (!(sh.debug_flags & 64u)) {  // (64: traffic ablation — the run is then wrong)
+  if (!ZKW_ABL(sh.debug_flags, 64u)) {  // (64: traffic ablation — the run is then wrong)
     zkw_gstore4(base + (2 * w - s.lane), u256_lo4(v));
     zkw_gstore4(base + (2 * w - s.lane + sh.L), u256_hi4(v));
   }
-  if (!is_aux && slot == 0 && idx < sh.image_words && !(sh.debug_flags & 32u)) {  // (32: traffic ablation)
+  if (!is_aux && slot == 0 && idx < sh.image_words && !ZKW_ABL(sh.debug_flags, 32u)) {  // (32: traffic ablation)
     // a word of the uploaded heap image is overwritten: remember it, the next reset restores only those words
     u32* d = sh.heap_dirty + ((u64)sh.wave * ((sh.image_words + 31u) >> 5) + (idx >> 5)) * sh.L + s.lane;
     atomicOr(d, 1u << (idx & 31u));  // result unused: a fire-and-forget atomic instead of a load + store round trip
@@ -854,7 +865,7 @@ ZD u256 code_fetch(const Shared& sh, const Lane& s, u32 idx) {
   const u32 c_len = CF(sh, s, CF_CODE_LEN), c_off = CF(sh, s, CF_CODE_OFF);
   const u32 u_len = (u32)__builtin_amdgcn_readfirstlane((int)c_len), u_off = (u32)__builtin_amdgcn_readfirstlane((int)c_off);
   const u32 u_idx = (u32)__builtin_amdgcn_readfirstlane((int)idx);
-  if (__ballot((c_len != u_len) | (c_off != u_off) | (idx != u_idx)) == 0) {  // wave-uniform
+  if (zkw_ballot((c_len != u_len) | (c_off != u_off) | (idx != u_idx)) == 0) {  // wave-uniform
     u256 v = u256_zero();
     if (u_idx < u_len) {
       typedef u32 zkw_v8u __attribute__((ext_vector_type(8)));
@@ -1111,7 +1122,8 @@ ZD u32 fat_ptr_validate(const FatPtr& p, bool fresh) {
   if (p.start + p.length < p.start) e |= FPV_DEREF_BEYOND;
   return e;
 }
-ZD u32 forward_type(u32 b) { return b == 1u ? 1u : (b == 2u ? 2u : 0u); }  // 0 UseHeap, 1 ForwardFatPointer, 2 UseAuxHeap
+// FarCallForwardPageType of an ABI byte -> 0 UseHeap, 1 ForwardFatPointer, 2 UseAuxHeap; `codes` = zkw_isa_consts.forwarding_codes
+ZD u32 forward_type(u32 codes, u32 b) { return b == ((codes >> 8) & 0xffu) ? 1u : (b == ((codes >> 16) & 0xffu) ? 2u : 0u); }
 
 // build a callstack entry image (32 dwords) from the lane's current frame: cold fields come from HBM
 ZD void entry_image_current(ZKW_KP P, const Shared& sh, const Lane& s, u32 img[32]) {
@@ -1271,7 +1283,8 @@ ZD void op_ptr(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
   }
   u256 result = ps.src0;
   if (v == ZKW_PTR_ADD || v == ZKW_PTR_SUB) {
-    const bool too_far = (ps.src1.w[1] | ps.src1.w[2] | ps.src1.w[3] | ps.src1.w[4] | ps.src1.w[5] | ps.src1.w[6] | ps.src1.w[7]) != 0;  // >= 2^32 (:47)
+    const u64 max_off = P.consts.max_offset_for_add_sub;  // ptr::MAX_OFFSET_FOR_ADD_SUB (:47)
+    const bool too_far = (ps.src1.w[2] | ps.src1.w[3] | ps.src1.w[4] | ps.src1.w[5] | ps.src1.w[6] | ps.src1.w[7]) != 0 || (((u64)ps.src1.w[1] << 32) | ps.src1.w[0]) >= max_off;
     const u32 off = ps.src1.w[0];
     const u32 cur = ps.src0.w[0];
     u32 n;
@@ -1374,7 +1387,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
   // the accesses the code-word prefetch did not see — a register-held address, the first opcode of a code word, the aux
   // heap — are requested here, ~1500 clocks (exceptions, growth, query bookkeeping) before their loads are issued for
   // real (same-box A/B: +1.5 % on top of the code-word prefetch; requesting the covered ones here again changes nothing)
-  if (!is_ptr_read && !(sh.debug_flags & ZKW_NO_PREFETCH) && (!is_heap || ZKW_ATTR_SRC0(d.attr) != ZKW_MODE_IMM || ((ps.new_pc - 1u) & 3u) == 0) &&
+  if (!is_ptr_read && !ZKW_ABL(sh.debug_flags, ZKW_NO_PREFETCH) && (!is_heap || ZKW_ATTR_SRC0(d.attr) != ZKW_MODE_IMM || ((ps.new_pc - 1u) & 3u) == 0) &&
       !(ps.src0.w[1] | ps.src0.w[2] | ps.src0.w[3] | ps.src0.w[4] | ps.src0.w[5] | ps.src0.w[6] | ps.src0.w[7]))
     prefetch_page_words(is_heap ? sh.heap : sh.aux_heap, is_heap ? P.H : P.A, P.L, (u32)__builtin_amdgcn_readfirstlane((int)*ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor + 2)), f_slot, f_hwm, ps.src0.w[0]);
 #endif
@@ -1638,7 +1651,7 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
   const bool dst_is_kernel = called[0] < 0x10000u && (called[1] | called[2] | called[3] | called[4]) == 0;
   FatPtr abi = fat_ptr_from(ps.src0);
   const u32 abi_ergs = ps.src0.w[6];
-  const u32 fwd = forward_type(ps.src0.w[7] & 0xffu);
+  const u32 fwd = forward_type(K.forwarding_codes, ps.src0.w[7] & 0xffu);
   const u32 abi_shard = (ps.src0.w[7] >> 8) & 0xffu;
   bool constructor_call = ((ps.src0.w[7] >> 16) & 0xffu) != 0;
   bool to_system = ((ps.src0.w[7] >> 24) & 0xffu) != 0;
@@ -1769,7 +1782,7 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
     exceptions |= 4u;
     after_decommit = after_growth;
   }
-  u32 mapped_code_page = 0, mapped_blob = 0;
+  u32 mapped_code_page = K.unmapped_page, mapped_blob = 0;  // UNMAPPED_PAGE (:162,439)
   if (exceptions) {  // :435-439
     s.flags |= FLAG_PENDING;
   } else {  // :441-455 decommit (helpers.rs:164-194 + SimpleDecommitter decommitter.rs:32-98)
@@ -1961,7 +1974,7 @@ ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, H
     src0_ptr = false;
   }
   FatPtr ptr = fat_ptr_from(src0);
-  const u32 fwd = forward_type(src0.w[7] & 0xffu);
+  const u32 fwd = forward_type(K.forwarding_codes, src0.w[7] & 0xffu);
   bool to_label = ZKW_ATTR_FLAGS(d.attr) & 1u;
   const u32 label_pc = d.imm0;
   u32 pve = 0;
@@ -2093,7 +2106,7 @@ static __device__ __noinline__ Lane zkw_precompile_entry(const zkw_kparams ZKW_C
 ZD u32 stream_alloc_counted(u32 count, u32 cap) {
   const u32 base = zkw_cursor_get<0>();
   u32 total = 0, my = 0xffffffffu;
-  for (u64 m = __ballot(1); m; m &= m - 1) {
+  for (u64 m = zkw_ballot(1); m; m &= m - 1) {
     const u32 l = (u32)__builtin_ctzll(m);
     const u32 c = (u32)__builtin_amdgcn_readlane((int)count, (int)l);
     const bool fits = c <= cap && base + total <= cap - c;
@@ -2326,8 +2339,7 @@ ZD bool decode_exception(u32 max_depth, const Lane& s, u32 attr, u32 price) {
          (((props & ZKW_PROP_STATIC_OK) == 0) & ((s.kflags & KF_STATIC) != 0)) | (s.depth == max_depth);
 }
 // one bit per (condition, lt|eq<<1|gt<<2): Always, Gt, Lt, Eq, Ge, Le, Ne, GtOrLt
-ZD bool condition_resolved(u32 cond, u32 flags) {
-  const u64 lut = 0xffull | (0xf0ull << 8) | (0xaaull << 16) | (0xccull << 24) | (0xfcull << 32) | (0xeeull << 40) | (0x33ull << 48) | (0xfaull << 56);
+ZD bool condition_resolved(u64 lut, u32 cond, u32 flags) {  // lut = zkw_isa_consts.condition_lut
   return (lut >> (cond * 8 + (flags & 7u))) & 1ull;
 }
 
@@ -2503,7 +2515,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
         }
         ZKW_STAMP0
         if (opcode == ZKW_OP_FAR_CALL) {  // CALL_IMPLICIT_PARAMETER_REG_IDX, far_call.rs:506-508
-          const u256 r15 = rf_get(rf, 15);
+          const u256 r15 = rf_get(rf, ((P.consts.call_regs >> 16) & 0xffu) + 1u);
 #pragma unroll
           for (int i = 0; i < 8; i++) ZKW_XFER(sh, s, i) = r15.w[i];
         }
@@ -2548,17 +2560,24 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
         for (int i = 0; i < 8; i++) v1.w[i] = ZKW_XFER(sh, s, i);
       }
       if (action & ZKW_ACT_DST0) dst0_update(P, sh, rf, s, ps.dst0, d.dst0, v1, false);
-      if (action & (ZKW_ACT_FAR | ZKW_ACT_RET)) {
-        reg_write(sh, rf, s, 1, v1, true);
-        reg_write(sh, rf, s, 2, u256_from_u32(r[13]), false);  // ret: zero
-        if (action & ZKW_ACT_TO_SYSTEM) {
-          s.ptr_bitmap &= ~(0x3ffu << 2);  // CALL_SYSTEM_ABI_REGISTERS = 2..12: drop the pointer markers only
-        } else {
-#pragma unroll
-          for (u32 q = 3; q <= 12; q++) reg_write(sh, rf, s, q, u256_zero(), false);
+      if (action & ZKW_ACT_FAR) {  // far_call.rs:573-610, in the reference's order; the conventions are table constants (indices into `registers`: r1 = 0)
+        const u32 cr = P.consts.call_regs, rg = P.consts.call_ranges;
+        reg_write(sh, rf, s, (cr & 0xffu) + 1u, v1, true);                            // CALL_IMPLICIT_CALLDATA_FAT_PTR_REGISTER
+        reg_write(sh, rf, s, ((cr >> 8) & 0xffu) + 1u, u256_from_u32(r[13]), false);  // CALL_IMPLICIT_CONSTRUCTOR_MARKER_REGISTER
+        for (u32 q = rg & 0xffu; q < ((rg >> 8) & 0xffu); q++) {                       // CALL_SYSTEM_ABI_REGISTERS
+          if (action & ZKW_ACT_TO_SYSTEM) s.ptr_bitmap &= ~(1u << q);  // drop the pointer marker only
+          else reg_write(sh, rf, s, q + 1u, u256_zero(), false);
         }
-#pragma unroll
-        for (u32 q = 13; q <= 15; q++) reg_write(sh, rf, s, q, u256_zero(), false);
+        for (u32 q = (rg >> 16) & 0xffu; q < (rg >> 24); q++) reg_write(sh, rf, s, q + 1u, u256_zero(), false);  // CALL_RESERVED_RANGE
+        reg_write(sh, rf, s, ((cr >> 16) & 0xffu) + 1u, u256_zero(), false);          // CALL_IMPLICIT_PARAMETER_REG_IDX
+      }
+      if (action & ZKW_ACT_RET) {  // ret.rs:213-233
+        const u32 rr = P.consts.ret_regs;
+        reg_write(sh, rf, s, (rr & 0xffu) + 1u, v1, true);                            // RET_IMPLICIT_RETURNDATA_PARAMS_REGISTER
+        reg_write(sh, rf, s, ((rr >> 8) & 0xffu) + 1u, u256_zero(), false);           // RET_RESERVED_REGISTER_0..2
+        reg_write(sh, rf, s, ((rr >> 16) & 0xffu) + 1u, u256_zero(), false);
+        reg_write(sh, rf, s, (rr >> 24) + 1u, u256_zero(), false);
+        for (u32 q = (rr >> 24) + 1u; q < ZKW_REGISTERS_COUNT; q++) reg_write(sh, rf, s, q + 1u, u256_zero(), false);  // "ALL other registers are zeroed out"
       }
       ZKW_STAMP(56)  // actions
       ZKW_SETTLE(5 /* call actions */);  // (the operand descriptor is reloaded from scratch for the actions: not carried to the join either)
@@ -2817,7 +2836,7 @@ ZD void zkw_kh_helper(const zkw_launch_args& A, u32 tid, u32 h, u32 sub, u32 n_s
   const u32 area = area0 + h * ZKW_DQ_HELPER_BYTES, box = area0 + g * ZKW_DQ_HELPER_BYTES + h * ZKW_KH_BYTES;
   u32 consumed = 0;
   for (;;) {
-    const u64 req = __ballot(tid < ZKW_KH_MAX_LANES && tid % n_sub == sub && (zkw_lds_get(box + tid * 64u) >> 31));
+    const u64 req = zkw_ballot(tid < ZKW_KH_MAX_LANES && tid % n_sub == sub && (zkw_lds_get(box + tid * 64u) >> 31));
     if (req) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the heap words the requester stored
       zkw_kh_serve(P, wave, box, (u32)__builtin_ctzll(req), tid);
@@ -2872,6 +2891,8 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
 #endif
   u32 run_cycles = A.run_cycles, time_delta = P.consts.time_delta_per_cycle, cap_delta = P.cap_delta, max_depth = P.consts.vm_max_stack_depth;
   ZKW_PIN_SGPR(run_cycles); ZKW_PIN_SGPR(time_delta); ZKW_PIN_SGPR(cap_delta); ZKW_PIN_SGPR(max_depth);
+  u64 cond_lut = P.consts.condition_lut;  // Condition of the 3-bit field (cycle.rs:193-209): a table constant
+  ZKW_PIN_SGPR(cond_lut);
   // stage the packed ISA table in LDS (all threads of the workgroup, 16 B each per step)
   {
     const uint4* src = (const uint4*)P.isa;
@@ -3025,7 +3046,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
           for (int i = 0; i < 4; i++) ZKW_SLOT_WRITE(sh, s.lane, i, make_uint4(word.w[2 * i], word.w[2 * i + 1], e4[i].x, e4[i].y));
           s.prev_super_pc = super_pc;
 #ifdef __HIP_DEVICE_COMPILE__
-          if (!(A.debug_flags & ZKW_NO_PREFETCH)) {  // the opcodes behind this one (opcode k of the word = slot 3 - k): prefetch_uma_words
+          if (!ZKW_ABL(A.debug_flags, ZKW_NO_PREFETCH)) {  // the opcodes behind this one (opcode k of the word = slot 3 - k): prefetch_uma_words
 #pragma unroll
             for (int i = 0; i < 3; i++)
               if (3u - (u32)i > sub_pc) prefetch_uma_words(P, sh, s, lds_sink, e4[i].x, word.w[2 * i + 1]);
@@ -3044,7 +3065,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
         s.kflags |= KF_MASKED;
       }
       {
-        const u64 in_loop = __ballot(1);
+        const u64 in_loop = zkw_ballot(1);
         if (zkw_rank_below(in_loop) == 0) *(uint4*)dir_ptr = dir_entry;
       }
       // ----------------------------------------------------------------------------------------
@@ -3060,7 +3081,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
       // values are what the allocator spills to scratch memory.
       // ----------------------------------------------------------------------------------------
       ZKW_PROF(0)  // fetch, directory
-      u64 todo = __ballot(1);
+      u64 todo = zkw_ballot(1);
       while (todo) {
         const u32 leader = (u32)__ffsll((long long)todo) - 1u;
         const u32 lane_now = zkw_lane_id();
@@ -3072,9 +3093,12 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
         const u32 u_hi = (u32)__builtin_amdgcn_readlane((int)me.y, (int)leader);
         const u32 u_charged = (u32)__builtin_amdgcn_readlane((int)charged, (int)leader);
         // only lanes that are still waiting: a lane that already ran a genuine `nop` must not join the group of lanes
-        // that were masked into the nop encoding later in the same cycle
-        bool mine = zkw_lane_bit(todo) && me.x == u_lo && me.y == u_hi && charged == u_charged;
-        if (A.debug_flags & 4u) mine = lane_now == leader;  // test hook: one lane per group
+        // that were masked into the nop encoding later in the same cycle.  The group is kept as a wave MASK (a scalar
+        // register pair: compares write masks, masks combine on the scalar unit, a mask is a branch condition as it is) —
+        // as a per-lane bool every step of this selection went through a v_cndmask / v_cmp round trip
+        // (one ballot per compare, combined on the scalar unit: the ballot of an `&&` goes through a per-lane 0 / 1 again)
+        const u64 same_state = todo & zkw_ballot(charged == u_charged);
+        u64 grp = same_state & zkw_ballot(me.x == u_lo) & zkw_ballot(me.y == u_hi);
         const u32 u_attr = (u32)__builtin_amdgcn_readlane((int)me.z, (int)leader);
         const u32 u_price = (u32)__builtin_amdgcn_readlane((int)me.w, (int)leader);
         // Variant grouping.  When lanes are left over that do not hold the leader's word (the wave runs different
@@ -3083,26 +3107,31 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
         // runs with per-lane operand decode (zkw_vec_exec).  Not for the heavy opcodes, whose out-of-line bodies take the
         // instruction word as a scalar.  A shared tape never gets here (its first group is all of `todo`).
         bool vec = false;
+        if (A.debug_flags & 4u) {
+          grp = 1ull << leader;  // test hook: one lane per group
+        }
 #ifdef __HIP_DEVICE_COMPILE__
-        if ((__ballot(mine) != todo || (A.debug_flags & (1u << 24))) && !(A.debug_flags & 4u)) {  // (bit 24: every group the variant way — test hook)
+        else if (grp != todo || (A.debug_flags & (1u << 24))) {  // (bit 24: every group the variant way — test hook)
           const u32 u_op = ZKW_ATTR_OPCODE(u_attr);
           if (u_op != ZKW_OP_LOG && u_op != ZKW_OP_NEAR_CALL && u_op != ZKW_OP_FAR_CALL && u_op != ZKW_OP_RET &&
               !((A.debug_flags >> (8u + u_op)) & 1u)) {  // (debug_flags bits 8..23: opcodes kept out of variant groups — test hook)
-            const bool wide = zkw_lane_bit(todo) && me.z == u_attr && me.w == u_price && charged == u_charged;
-            if (__popcll(__ballot(wide)) > __popcll(__ballot(mine)) || (A.debug_flags & (1u << 24))) {
-              mine = wide;
+            const u64 wide = same_state & zkw_ballot(me.z == u_attr) & zkw_ballot(me.w == u_price);
+            if (__popcll(wide) > __popcll(grp) || (A.debug_flags & (1u << 24))) {
+              grp = wide;
               vec = true;
             }
           }
         }
 #endif
         if (!u_charged) {  // uniform: first visit of this opcode word
-          if (mine) {
+          bool masked_now = false;
+          if (zkw_lane_bit(grp)) {
             const bool err = decode_exception(max_depth, s, u_attr, u_price);  // :142-184
             if (s.ergs < u_price) s.ergs = 0; else s.ergs -= u_price;  // :153-161
-            const bool nop = !err && !condition_resolved((me.x >> 13) & 7u, s.flags);  // (the lane's own condition: a variant group mixes them)
+            const bool nop = !err && !condition_resolved(cond_lut, (me.x >> 13) & 7u, s.flags);  // (the lane's own condition: a variant group mixes them)
             s.kflags |= KF_CHARGED;
-            if (err | nop) {
+            masked_now = err | nop;
+            if (masked_now) {
               // mask_into_panic (:187-190) / mask_into_nop (:212-217): the lane re-enters the loop as a member of
               // the group of the panic / nop encoding (all operand fields zero, condition Always)
               // (both encodings as scalar loads, then a per-lane select: `err ? a : b` on the parameter block itself became a
@@ -3112,11 +3141,12 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
               const uint2 e1 = sh.isa[(u32)masked & (ZKW_ISA_TABLE_SIZE - 1)];
               ZKW_SLOT_WRITE(sh, lane_now, 4, make_uint4((u32)masked, (u32)(masked >> 32), e1.x, e1.y));
               s.kflags |= KF_MASKED;
-              mine = false;
             }
           }
+          grp &= ~zkw_ballot(masked_now);  // (they stay in `todo`)
         }
-        todo &= ~__ballot(mine);
+        todo &= ~grp;
+        const bool mine = zkw_lane_bit(grp);
         ZKW_PROF(1)  // group selection, price, exceptions, condition
         if (mine) {
           Decoded d;
@@ -3124,12 +3154,12 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
           d.attr = u_attr;
           d.cond = (u_lo >> 13) & 7u; d.src0 = (u_lo >> 16) & 15u; d.src1 = (u_lo >> 20) & 15u; d.dst0 = (u_lo >> 24) & 15u; d.dst1 = u_lo >> 28;
           d.imm0 = u_hi & 0xffffu; d.imm1 = u_hi >> 16;
-          if (A.debug_flags & 8u) s.pc = (s.pc + 1u) & 0xffffu;  // profiling ablation: no operand / opcode work
+          if (ZKW_ABL(A.debug_flags, 8u)) s.pc = (s.pc + 1u) & 0xffffu;  // profiling ablation: no operand / opcode work
           else exec_decoded(P, sh, rf, s, d, vec, me.x, me.y);
 #ifdef ZKW_PROFILE
           {
             const unsigned long long zp_now = __builtin_readcyclecounter();
-            if (zkw_rank_below(__ballot(1)) == 0) {
+            if (zkw_rank_below(zkw_ballot(1)) == 0) {
               zp_acc[sh.wib][8 + (ZKW_ATTR_OPCODE(u_attr) & 15u)] += zp_now - zp_last;
               zp_acc[sh.wib][24 + (ZKW_ATTR_OPCODE(u_attr) & 15u)] += 1;
             }
@@ -3157,7 +3187,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
           }
         }
       }
-      if (!(A.debug_flags & 1u)) {
+      if (!ZKW_ABL(A.debug_flags, 1u)) {
         // CycleRecord, delta form: the 512-byte snapshot the tracer observes (15 registers + 32-byte tail) is emitted as
         // the tail (dense [cycle][lane], coalesced) plus the 32-byte values of the registers THIS cycle wrote, compacted
         // per wave.  The delta of register r of a lane sits at base + (deltas of registers below r in this wave-cycle) +
@@ -3177,15 +3207,15 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
         // union of the lanes' dirty masks and the number of deltas of this wave-cycle; a shared tape makes all masks equal
         const u32 dm0 = (u32)__builtin_amdgcn_readfirstlane((int)dm);
         u32 any, total;
-        if (__ballot(dm != dm0) == 0) {
+        if (zkw_ballot(dm != dm0) == 0) {
           any = dm0;
-          total = (u32)__popcll((u64)dm0) * (u32)__popcll(__ballot(true));
+          total = (u32)__popcll((u64)dm0) * (u32)__popcll(zkw_ballot(true));
         } else {
           any = 0;
           total = 0;
 #pragma unroll
           for (u32 r = 0; r < ZKW_REGISTERS_COUNT + 1; r++) {
-            const u32 c = (u32)__popcll(__ballot((dm >> r) & 1u));
+            const u32 c = (u32)__popcll(zkw_ballot((dm >> r) & 1u));
             total += c;
             any |= c ? 1u << r : 0u;
           }
@@ -3199,7 +3229,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
           for (u32 left = any; left; left &= left - 1u) {  // scalar loop over the registers written in this wave-cycle
             const u32 r = (u32)__ffsll((long long)left) - 1u;
             const bool has = (dm >> r) & 1u;
-            const u64 part = __ballot(has);
+            const u64 part = zkw_ballot(has);
             if (has) {
               u256 v;
               if (r == ZKW_REGISTERS_COUNT) {  // (wave-uniform)
@@ -3231,13 +3261,13 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
 #ifdef __HIP_DEVICE_COMPILE__
           zkw_cursor_set<3>(delta_cur);
 #else
-          if (zkw_rank_below(__ballot(true)) == 0) ZKW_LDS_WORD(sh.cursor)[3] = delta_cur;
+          if (zkw_rank_below(zkw_ballot(true)) == 0) ZKW_LDS_WORD(sh.cursor)[3] = delta_cur;
 #endif
         }
       }
       ZKW_PROF(3)  // CycleRecord: delta ranks, delta + tail stores
 #ifdef __HIP_DEVICE_COMPILE__
-      if ((A.debug_flags & ZKW_DQ_HELPER) && __ballot((s.kflags & KF_DQ_CHAINED) != 0)) {  // (wave-uniform; rare: a far call with a decommit)
+      if ((A.debug_flags & ZKW_DQ_HELPER) && zkw_ballot((s.kflags & KF_DQ_CHAINED) != 0)) {  // (wave-uniform; rare: a far call with a decommit)
         // hand this cycle's decommits to the helper wave: every lane still in the loop marks its entry of the slot valid
         // (its cycle completed with a decommit) or empty, then the slot is posted — a wave's LDS operations complete in
         // order, so the helper that sees the new count sees the entries
@@ -3247,7 +3277,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
         const bool valid = (s.kflags & KF_DQ_CHAINED) && lane_ok(s);
         const u32 w0 = *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)row);
         *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)row) = valid ? (w0 | 0x80000000u) : 0u;
-        if (zkw_rank_below(__ballot(1)) == 0) *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)area) = posted + 1u;
+        if (zkw_rank_below(zkw_ballot(1)) == 0) *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)area) = posted + 1u;
       }
 #endif
       k++;

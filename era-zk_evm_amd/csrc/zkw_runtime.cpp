@@ -327,10 +327,26 @@ int zkw_ctx_set_isa(zkw_ctx* c, const zkw_isa_table* t) {
     c->last_error = "ISA table: panic/nop variant index out of range";
     return ZKW_ERR_INVALID;
   }
-  if ((t->consts.exception_revert_encoding & (ZKW_ISA_TABLE_SIZE - 1)) != t->consts.panic_variant_idx || (t->consts.exception_revert_encoding >> 11) != 0 ||
-      (t->consts.nop_encoding & (ZKW_ISA_TABLE_SIZE - 1)) != t->consts.nop_variant_idx || (t->consts.nop_encoding >> 11) != 0) {
-    c->last_error = "ISA table: nop/exception_revert encodings must be the bare nop/panic variant (Always, r0 operands, zero immediates)";
-    return ZKW_ERR_INVALID;
+  {
+    // the two masked encodings are the bare nop / panic variant: r0 operands, zero immediates, and a condition field that
+    // names Always under this table's condition_lut (cycle.rs:135-148, 212-217)
+    const zkw_isa_consts& k = t->consts;
+    auto bare = [&](uint64_t enc, uint32_t idx) {
+      const uint32_t field = (uint32_t)(enc >> 13) & 7u;
+      return (enc & (ZKW_ISA_TABLE_SIZE - 1)) == idx && (enc >> 16) == 0 && ((enc >> 11) & 3u) == 0 && ((k.condition_lut >> (8 * field)) & 0xffu) == 0xffu;
+    };
+    if (!bare(k.exception_revert_encoding, k.panic_variant_idx) || !bare(k.nop_encoding, k.nop_variant_idx)) {
+      c->last_error = "ISA table: nop/exception_revert encodings must be the bare nop/panic variant (Always, r0 operands, zero immediates)";
+      return ZKW_ERR_INVALID;
+    }
+    const uint32_t regs[] = {k.call_regs & 0xffu, (k.call_regs >> 8) & 0xffu, (k.call_regs >> 16) & 0xffu, k.ret_regs & 0xffu, (k.ret_regs >> 8) & 0xffu,
+                             (k.ret_regs >> 16) & 0xffu, k.ret_regs >> 24};
+    bool ok = ((k.call_ranges >> 8) & 0xffu) <= ZKW_REGISTERS_COUNT && (k.call_ranges >> 24) <= ZKW_REGISTERS_COUNT;
+    for (uint32_t r : regs) ok = ok && r < ZKW_REGISTERS_COUNT;
+    if (!ok) {
+      c->last_error = "ISA table: a far_call / ret register convention names a register beyond r15";
+      return ZKW_ERR_INVALID;
+    }
   }
   c->isa = *t;
   std::vector<uint2> packed(ZKW_ISA_TABLE_SIZE);

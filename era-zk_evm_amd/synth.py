@@ -131,6 +131,7 @@ def initial_states(n, registers, heap_bound=4096, ergs=0xFFFFFFFF, first_dynamic
 # cfg 0 / cfg 1
 # ----------------------------------------------------------------------------------------
 def config0(isa, n_cycles=1024, seed=0x5EED0000):
+    bind_isa(isa)
     wl = Workload("cfg0_nop_add", 1, n_cycles)
     ops = []
     n_add = 0
@@ -172,6 +173,7 @@ def arith_tape(isa, n_cycles, rng):
 
 
 def config1(isa, n_instances=256, n_cycles=256, seed=0x5EED0001):
+    bind_isa(isa)
     wl = Workload("cfg1_arith", n_instances, n_cycles)
     ops = arith_tape(isa, n_cycles, ScalarRng(seed))
     wl.blobs.append(K.pack_code(ops))
@@ -204,13 +206,23 @@ def versioned_code_hash(words):
     return K.u256_from_int(int.from_bytes(be, "big"))
 
 
+# FarCallForwardPageType -> its ABI byte under the table the workload is built for (a table constant, zkw_isa_consts.forwarding_codes):
+# every workload constructor binds its table first
+_FWD_CODES = [0, 1, 2]
+
+
+def bind_isa(isa):
+    _FWD_CODES[:] = [isa.fwd_code(k) for k in range(3)]
+
+
 def far_call_abi(start, length, ergs_passed, forwarding_mode=0):
-    v = (start << 64) | (length << 96) | (ergs_passed << 192) | (forwarding_mode << 224)
+    """forwarding_mode: 0 UseHeap, 1 ForwardFatPointer, 2 UseAuxHeap (logical; encoded through the bound table)"""
+    v = (start << 64) | (length << 96) | (ergs_passed << 192) | (_FWD_CODES[forwarding_mode] << 224)
     return K.u256_from_int(v)
 
 
 def ret_abi(start, length, forwarding_mode=0):
-    return K.u256_from_int((start << 64) | (length << 96) | (forwarding_mode << 224))
+    return K.u256_from_int((start << 64) | (length << 96) | (_FWD_CODES[forwarding_mode] << 224))
 
 
 class TapeBuilder:
@@ -366,6 +378,7 @@ def callee_program(isa, rng, ret_variant):
 
 
 def config2(isa, n_instances=4096, n_cycles=256, seed=0x5EED0002):
+    bind_isa(isa)
     assert n_cycles >= 2 * (1 + CALLEE_CYCLES + RELOAD_CYCLES) + 12
     wl = Workload("cfg2_mixed", n_instances, n_cycles)
     rng = ScalarRng(seed)
@@ -464,6 +477,7 @@ def config3(isa, n_instances=4096, n_cycles=64, seed=0x5EED0003, keccak_k=(1, 8,
             keccak_unalign=None):
     """keccak_bytes / keccak_unalign: optional explicit message lengths (bytes) and byte misalignments (default: 136 * k
     bytes, misalignment 0 / 31 alternating)"""
+    bind_isa(isa)
     klen = list(keccak_bytes) if keccak_bytes is not None else [136 * k for k in keccak_k]
     keccak_k = [b // 136 for b in klen]  # rounds - 1, for the ergs cost
     kun = list(keccak_unalign) if keccak_unalign is not None else [(31 if j % 2 else 0) for j in range(len(klen))]
@@ -671,6 +685,7 @@ class BlockTapeBuilder(TapeBuilder):
 
 
 def config4(isa, n_instances=4096, n_cycles=1024, seed=0x5EED0004):
+    bind_isa(isa)
     wl = Workload("cfg4_l2_block", n_instances, n_cycles)
     rng = ScalarRng(seed)
     tb = BlockTapeBuilder(isa, rng)
@@ -778,6 +793,7 @@ ECRECOVER_ADDRESS = 0x01
 
 
 def ecrecover_workload(isa, sig_words, tail_cycles=6):
+    bind_isa(isa)
     """sig_words: [n_instances][n_sigs][4] python ints, already in the memory order of isa.consts.ecrecover_input_layout.
     Signature j sits at heap words 4j..4j+3; the precompile writes (ok marker, address word) at words out_base + 2j,
     which the tail of the tape loads back into registers."""
@@ -824,6 +840,7 @@ def ecrecover_workload(isa, sig_words, tail_cycles=6):
 # reference_impls/event_sink.rs:160-176)
 # ----------------------------------------------------------------------------------------
 def nested_frames(isa, outer=K.RET_OK, inner=K.RET_OK, main_panics=False, n_instances=3, n_cycles=40, seed=0x5EED00F2):
+    bind_isa(isa)
     wl = Workload("nested_frames_%d_%d_%d" % (outer, inner, int(main_panics)), n_instances, n_cycles)
     A, B = 16, 32
     e = isa.enc
@@ -886,6 +903,7 @@ def nested_frames(isa, outer=K.RET_OK, inner=K.RET_OK, main_panics=False, n_inst
 #                slot goes back to the pool
 # ----------------------------------------------------------------------------------------
 def many_far_calls(isa, n_calls=64, n_instances=8, seed=0x5EED00F7, plan=None, max_far_frames=4):
+    bind_isa(isa)
     e = isa.enc
     ADDR_K, ADDR_P, ADDR_N = 0x10011, 0x10012, 0x10013
     local = CALLEE_CODE_WORDS - 8  # page-local constant pool of the callees
@@ -961,7 +979,7 @@ def many_far_calls(isa, n_calls=64, n_instances=8, seed=0x5EED00F7, plan=None, m
         words[local] = ret_abi(0, 128)
         words[local + 1] = far_call_abi(0, 64, 50000)
         words[local + 2] = K.u256_from_int(ADDR_K)
-        words[local + 3] = K.u256_from_int(1 << 224)  # RetABI forwarding_mode = ForwardFatPointer, in the half ptr.pack takes from src1
+        words[local + 3] = K.u256_from_int(_FWD_CODES[1] << 224)  # RetABI forwarding_mode = ForwardFatPointer, in the half ptr.pack takes from src1
         wl.blobs.append(words)
         h = versioned_code_hash(words)
         wl.preimages.append((h, 1 + which))
@@ -988,6 +1006,7 @@ def many_far_calls(isa, n_calls=64, n_instances=8, seed=0x5EED00F7, plan=None, m
 # page and the page that is not the returndata go back to the pool
 # ----------------------------------------------------------------------------------------
 def bootloader_returns(isa, how="heap", n_instances=3, seed=0x5EED00F9):
+    bind_isa(isa)
     e = isa.enc
     wl = Workload("bootloader_returns_%s" % how, n_instances, 8)
     ops = [e(K.OP_ADD, dst0_mode=K.MODE_STACK_ABS, src0=1, src1=2, dst0=0, imm1=7),               # stack[7]
@@ -1030,6 +1049,7 @@ def _shaped_u256(rng):
 
 
 def fuzz_workload(isa, n_instances=64, n_ops=96, seed=0xF022):
+    bind_isa(isa)
     wl = Workload("fuzz_%x" % seed, n_instances, n_ops)
     rng = ScalarRng(seed)
     e = isa.table["entries"][0]

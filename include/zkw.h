@@ -148,7 +148,23 @@ typedef struct zkw_isa_consts {
   uint32_t bootloader_calldata_page;  /* zkevm_opcode_defs::BOOTLOADER_CALLDATA_PAGE (memory.rs:11,229-231): the page that
                                          SimpleMemory keeps in `pages_with_extended_lifetime` from the start.  Value recalled,
                                          UNVERIFIED (the crate is not on disk) — hence a table constant, not code */
-  uint32_t reserved[6];
+  /* Conventions of the two absent crates that rounds 1-3 had compiled in (SURVEY App. B lists them as recalled): table
+   * constants since round 4, so that a shim built against the real zkevm_opcode_defs supplies the real values. */
+  uint32_t call_regs;                 /* far_call.rs:506-508,573-610, INDICES into VmLocalState.registers (r1 = 0): byte 0
+                                         CALL_IMPLICIT_CALLDATA_FAT_PTR_REGISTER (0), byte 1 CALL_IMPLICIT_CONSTRUCTOR_MARKER_REGISTER (1),
+                                         byte 2 CALL_IMPLICIT_PARAMETER_REG_IDX (14) */
+  uint32_t call_ranges;               /* byte 0 / 1: CALL_SYSTEM_ABI_REGISTERS first / end (2 / 12), byte 2 / 3: CALL_RESERVED_RANGE
+                                         first / end (12 / 14); ends exclusive */
+  uint32_t ret_regs;                  /* ret.rs:213-233: byte 0 RET_IMPLICIT_RETURNDATA_PARAMS_REGISTER (0), bytes 1..3
+                                         RET_RESERVED_REGISTER_0..2 (1, 2, 3); every register behind the last one is cleared */
+  uint32_t forwarding_codes;          /* FarCallForwardPageType as the ABI byte (far_call.rs:255, ret.rs:59): byte 0 UseHeap (0),
+                                         byte 1 ForwardFatPointer (1), byte 2 UseAuxHeap (2); any other byte decodes as UseHeap */
+  uint32_t unmapped_page;             /* UNMAPPED_PAGE (0)  far_call.rs:162,439 */
+  uint32_t reserved0;
+  uint64_t max_offset_for_add_sub;    /* ptr::MAX_OFFSET_FOR_ADD_SUB (2^32)  ptr.rs:47,111: an offset >= this panics */
+  uint64_t condition_lut;             /* Condition, as the 3-bit field of the opcode word decodes (cycle.rs:193-209): bit
+                                         8 * field + (lt_of | eq << 1 | gt << 2) = the condition holds.  Default order Always,
+                                         Gt, Lt, Eq, Ge, Le, Ne, GtOrLt = 0xfa33eefcccaaf0ff */
 } zkw_isa_consts;
 
 typedef struct zkw_isa_table {
@@ -417,7 +433,7 @@ int zkw_ctx_set_isa(zkw_ctx* ctx, const zkw_isa_table* table); /* copies */
  * environment variable of the same name (ZKW_DEBUG_FLAGS, ...) that is read ONCE, when the context is created, and
  * reported on stderr when it is set — a stray variable cannot silently change a production run, and the hot path reads
  * no environment.  zkw_ctx_set_option changes an option of a live context (what the parity tests use). */
-#define ZKW_OPT_DEBUG_FLAGS 1u         /* kernel test hooks / ablations: 4 = one lane per opcode group, 1 << 24 = every light group through the variant path, 1 / 2 / 32 / 64 / 128 = store ablations (WRONG results) */
+#define ZKW_OPT_DEBUG_FLAGS 1u         /* kernel test hooks / ablations: 4 = one lane per opcode group, 1 << 24 = every light group through the variant path, 1 / 2 / 8 / 32 / 64 / 128 = store / phase ablations (WRONG results; only in a library built with -DZKW_ABLATION, ignored otherwise) */
 #define ZKW_OPT_RESET_SKIP 2u          /* reset-kernel parts left out (ablation, WRONG results) */
 #define ZKW_OPT_NO_INLINE_DECOMMIT 3u  /* 1 = the decommit queue is never chained inside the cycle kernel */
 #define ZKW_OPT_DEBUG_SYNC 5u          /* 1 = synchronise after every cycle-kernel launch (diagnostics) */

@@ -99,7 +99,16 @@ static Decoded parse_opcode(const zkw_isa_table* isa, uint64_t enc, uint32_t* ra
   uint32_t idx = (uint32_t)(enc & (ZKW_ISA_TABLE_SIZE - 1));
   *raw_idx = idx;
   d.variant = isa->entries[idx];
-  d.condition = (uint8_t)((enc >> 13) & 7);
+  // Condition::from the 3-bit field (absent crate): which Condition a field value names is a table constant — the truth
+  // table of the field over (lt | eq << 1 | gt << 2) identifies it among the eight of cycle.rs:193-209
+  {
+    static const uint8_t truth[8] = {0xff /* Always */, 0xf0 /* Gt */, 0xaa /* Lt */, 0xcc /* Eq */, 0xfc /* Ge */, 0xee /* Le */, 0x33 /* Ne */, 0xfa /* GtOrLt */};
+    const uint8_t t = (uint8_t)(isa->consts.condition_lut >> (8 * ((enc >> 13) & 7)));
+    int which = -1;
+    for (int c = 0; c < 8; c++) if (truth[c] == t) which = c;
+    if (which < 0) throw RefPanic("condition_lut row names no Condition");
+    d.condition = (uint8_t)which;
+  }
   d.src0_reg_idx = (uint8_t)((enc >> 16) & 15);
   d.src1_reg_idx = (uint8_t)((enc >> 20) & 15);
   d.dst0_reg_idx = (uint8_t)((enc >> 24) & 15);
@@ -391,8 +400,8 @@ void Vm::ptr(const Decoded& op, const PreState& ps) {
   const U256& src1 = ps.src1.value;
   U256 result;
   if (v == ZKW_PTR_ADD || v == ZKW_PTR_SUB) {
-    // ptr::MAX_OFFSET_FOR_ADD_SUB = 2^32 (Appendix B)
-    if (src1.l[0] >= (1ULL << 32) || src1.l[1] || src1.l[2] || src1.l[3]) { set_shorthand_panic(); return; }  // :47-51
+    // ptr::MAX_OFFSET_FOR_ADD_SUB (2^32, Appendix B): a table constant
+    if (src1.l[0] >= isa->consts.max_offset_for_add_sub || src1.l[1] || src1.l[2] || src1.l[3]) { set_shorthand_panic(); return; }  // :47-51
     FatPointer fp = FatPointer::from_u256(src0);
     uint32_t offset = src1.low_u32();
     uint32_t new_off;
@@ -603,7 +612,8 @@ enum {
   FC_NOT_ENOUGH_ERGS_FOR_EXTRA_FAR_CALL_COSTS = 64
 };  // far_call.rs:15-25
 enum { FWD_USE_HEAP = 0, FWD_FORWARD_FAT_POINTER = 1, FWD_USE_AUX_HEAP = 2 };  // FarCallForwardPageType / RetForwardPageType
-static int forward_type_from_u8(uint8_t b) { return b == FWD_FORWARD_FAT_POINTER ? FWD_FORWARD_FAT_POINTER : (b == FWD_USE_AUX_HEAP ? FWD_USE_AUX_HEAP : FWD_USE_HEAP); }
+// FarCallForwardPageType::from_u8 (absent crate): the byte codes are table constants (forwarding_codes), anything else is UseHeap
+static int forward_type_from_u8(uint32_t codes, uint8_t b) { return b == ((codes >> 8) & 0xff) ? FWD_FORWARD_FAT_POINTER : (b == ((codes >> 16) & 0xff) ? FWD_USE_AUX_HEAP : FWD_USE_HEAP); }
 
 // VersionedHashGeneric<ContractCodeSha256> (absent crate; Appendix B): byte0 = version 1,
 // byte1 = marker (0 at rest, 1 yet constructed), bytes 2-3 = length in words BE
@@ -643,7 +653,7 @@ void Vm::far_call(const Decoded& op, const PreState& ps) {
   // FarCallABI::from_u256 (absent crate; Appendix B layout)
   FatPointer abi_ptr = FatPointer::from_u256(abi_src);
   uint32_t abi_ergs_passed = (uint32_t)abi_src.l[3];
-  int forwarding_mode = forward_type_from_u8((uint8_t)(abi_src.l[3] >> 32));
+  int forwarding_mode = forward_type_from_u8(K.forwarding_codes, (uint8_t)(abi_src.l[3] >> 32));
   uint8_t abi_shard_id = (uint8_t)(abi_src.l[3] >> 40);
   bool constructor_call = ((uint8_t)(abi_src.l[3] >> 48)) != 0;
   bool to_system = ((uint8_t)(abi_src.l[3] >> 56)) != 0;
@@ -754,7 +764,7 @@ void Vm::far_call(const Decoded& op, const PreState& ps) {
   uint32_t mapped_code_page;
   if (exceptions != 0) {  // :435-439
     set_shorthand_panic();
-    mapped_code_page = 0;
+    mapped_code_page = K.unmapped_page;  // UNMAPPED_PAGE
   } else {  // :441-455
     DecommittmentQuery dq = decommit(cc, code_hash, memory_page_candidate_for_code_decommittment, timestamp_for_first_decommit_or_precompile_read());
     if (dq.is_fresh == false) remaining_ergs_after_decommittment += cost_of_decommittment;
@@ -774,7 +784,8 @@ void Vm::far_call(const Decoded& op, const PreState& ps) {
   local_state.callstack.current.pc = ps.new_pc;
   bool new_context_is_static = local_state.callstack.current.is_static | is_static_call;  // :500
   local_state.memory_page_counter += K.new_memory_pages_per_far_call;                     // :503
-  Address address_from_implicit_reg = u256_to_address_unchecked(local_state.registers[14].value);  // CALL_IMPLICIT_PARAMETER_REG_IDX (:506-508)
+  const uint32_t CALL_IMPLICIT_PARAMETER_REG_IDX = (K.call_regs >> 16) & 0xff;  // (table constants: indices into `registers`)
+  Address address_from_implicit_reg = u256_to_address_unchecked(local_state.registers[CALL_IMPLICIT_PARAMETER_REG_IDX].value);  // :506-508
   Address address_for_next, msg_sender_for_next;
   switch (inner_variant) {  // :510-523
     case ZKW_FAR_NORMAL: address_for_next = called_address; msg_sender_for_next = current_address; break;
@@ -797,18 +808,20 @@ void Vm::far_call(const Decoded& op, const PreState& ps) {
   start_frame(cc, new_stack);                                                        // :562
   memory.start_global_frame(current_base_page, new_base_memory_page, abi_ptr, local_state.timestamp);  // :564-569
 
-  local_state.registers[0] = PrimitiveValue{abi_ptr.to_u256(), true};  // :573-577 CALL_IMPLICIT_CALLDATA_FAT_PTR_REGISTER
+  const uint32_t CALL_IMPLICIT_CALLDATA_FAT_PTR_REGISTER = K.call_regs & 0xff, CALL_IMPLICIT_CONSTRUCTOR_MARKER_REGISTER = (K.call_regs >> 8) & 0xff;
+  const uint32_t abi_first = K.call_ranges & 0xff, abi_end = (K.call_ranges >> 8) & 0xff, res_first = (K.call_ranges >> 16) & 0xff, res_end = K.call_ranges >> 24;
+  local_state.registers[CALL_IMPLICIT_CALLDATA_FAT_PTR_REGISTER] = PrimitiveValue{abi_ptr.to_u256(), true};  // :573-577
   U256 r2 = U256::zero();
   if (constructor_call) r2.l[0] |= 1;
   if (to_system) r2.l[0] |= 2;
-  local_state.registers[1] = PrimitiveValue{r2, false};  // :587-591
-  if (to_system == false) {                              // :593-603 CALL_SYSTEM_ABI_REGISTERS = 2..12
-    for (int i = 2; i < 12; i++) local_state.registers[i] = PrimitiveValue::empty();
+  local_state.registers[CALL_IMPLICIT_CONSTRUCTOR_MARKER_REGISTER] = PrimitiveValue{r2, false};  // :587-591
+  if (to_system == false) {                              // :593-603 CALL_SYSTEM_ABI_REGISTERS
+    for (uint32_t i = abi_first; i < abi_end; i++) local_state.registers[i] = PrimitiveValue::empty();
   } else {
-    for (int i = 2; i < 12; i++) local_state.registers[i].is_pointer = false;
+    for (uint32_t i = abi_first; i < abi_end; i++) local_state.registers[i].is_pointer = false;
   }
-  for (int i = 12; i < 14; i++) local_state.registers[i] = PrimitiveValue::empty();  // CALL_RESERVED_RANGE = 12..14
-  local_state.registers[14] = PrimitiveValue::empty();                               // :609-610
+  for (uint32_t i = res_first; i < res_end; i++) local_state.registers[i] = PrimitiveValue::empty();  // CALL_RESERVED_RANGE
+  local_state.registers[CALL_IMPLICIT_PARAMETER_REG_IDX] = PrimitiveValue::empty();                  // :609-610
 }
 
 // ret.rs:9-265
@@ -820,7 +833,7 @@ void Vm::ret(const Decoded& op, const PreState& ps) {
   bool src0_is_ptr = ps.src0.is_pointer;
   if (inner_variant == ZKW_RET_PANIC) { src0 = U256::zero(); src0_is_ptr = false; }  // :35-41
   FatPointer ptr = FatPointer::from_u256(src0);                                      // RetABI::from_u256
-  int page_forwarding_mode = forward_type_from_u8((uint8_t)(src0.l[3] >> 32));
+  int page_forwarding_mode = forward_type_from_u8(isa->consts.forwarding_codes, (uint8_t)(src0.l[3] >> 32));
   bool is_to_label = op.variant.flags & 1;  // RET_TO_LABEL_BIT_IDX
   uint16_t label_pc = op.imm_0;
   const CallStackEntry cs = local_state.callstack.current;
@@ -872,8 +885,12 @@ void Vm::ret(const Decoded& op, const PreState& ps) {
   is_to_label = is_to_label & finished.is_local_frame;                                   // :202
   if (finished.is_local_frame == false) {  // :204-236
     memory.finish_global_frame(finished.base_memory_page, ptr, local_state.timestamp);
-    local_state.registers[0] = PrimitiveValue{ptr.to_u256(), true};  // RET_IMPLICIT_RETURNDATA_PARAMS_REGISTER
-    for (int i = 1; i < ZKW_REGISTERS_COUNT; i++) local_state.registers[i] = PrimitiveValue::empty();  // :219-233
+    const uint32_t rr = isa->consts.ret_regs;  // RET_IMPLICIT_RETURNDATA_PARAMS_REGISTER, RET_RESERVED_REGISTER_0..2: table constants
+    local_state.registers[rr & 0xff] = PrimitiveValue{ptr.to_u256(), true};
+    local_state.registers[(rr >> 8) & 0xff] = PrimitiveValue::empty();
+    local_state.registers[(rr >> 16) & 0xff] = PrimitiveValue::empty();
+    local_state.registers[rr >> 24] = PrimitiveValue::empty();
+    for (uint32_t i = (rr >> 24) + 1; i < ZKW_REGISTERS_COUNT; i++) local_state.registers[i] = PrimitiveValue::empty();  // :219-233 .skip(RET_RESERVED_REGISTER_2 + 1)
     local_state.context_u128_register[0] = local_state.context_u128_register[1] = 0;  // :236
   }
   CallStackEntry& next = local_state.callstack.current;

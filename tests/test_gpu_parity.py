@@ -684,3 +684,89 @@ def test_arena_limit_is_a_status(product, isa):
     bp = _run(product, wl)
     assert all(bp.trace(i)["status"] == K.STATUS_LIMIT for i in range(wl.n_instances))
     bp.destroy()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the ISA table is an INPUT (tests/_metamorphic.py): the HIP path under tables that differ from the recalled
+# default in what the absent zkevm_opcode_defs decides
+# ---------------------------------------------------------------------------------------------------------------
+META_WORKLOADS = {
+    "cfg1": lambda isa: synth.make(1, isa, n_instances=256),
+    "cfg2": lambda isa: synth.make(2, isa, n_instances=192),
+    "cfg4": lambda isa: synth.make(4, isa, n_instances=96, n_cycles=1024),
+    "fuzz": lambda isa: synth.fuzz_workload(isa, n_instances=128, n_ops=128, seed=0xF0AB),
+    "far_calls": lambda isa: synth.many_far_calls(isa, n_calls=16, n_instances=64),
+}
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg4", "fuzz"])
+def test_renumbered_table_gives_the_same_witness(product, isa, name):
+    """permuted variant numbering + permuted condition fields + clip_mode 1: product == oracle under that table, and (the cfg
+    tapes, whose programs are the same instructions under either table) product == product under the default table once
+    the opcode words are mapped back"""
+    import _metamorphic as M
+    from _oracle import load_oracle
+    isa_v = M.renumbered(0x7AB1E + 16 * sum(map(ord, name)))
+    orc_v, prod_v = load_oracle().open(isa_v), K.load_product().open(isa_v)
+    try:
+        wl_v = META_WORKLOADS[name](isa_v)
+        b_ov, b_pv = _run(orc_v, wl_v), _run(prod_v, wl_v)
+        n_ok = 0
+        for i in range(wl_v.n_instances):
+            tp = b_pv.trace(i)
+            if name == "fuzz" and tp["status"] == K.STATUS_LIMIT:
+                continue
+            ok, why = K.traces_equal(b_ov.trace(i), tp)
+            assert ok, "%s instance %d vs the oracle: %s" % (name, i, why)
+            n_ok += 1
+        assert n_ok >= wl_v.n_instances * 7 // 8
+        assert np.array_equal(b_ov.commitments(), b_pv.commitments()) or name == "fuzz"
+        if name != "fuzz":
+            wl_d = META_WORKLOADS[name](isa)
+            b_pd = _run(product, wl_d)
+            for i in range(wl_d.n_instances):
+                ok, why = M.same_witness(isa_v, b_pd.trace(i), b_pv.trace(i))
+                assert ok, "%s instance %d vs the default table: %s" % (name, i, why)
+            b_pd.destroy()
+        b_ov.destroy(); b_pv.destroy()
+    finally:
+        orc_v.close(); prod_v.close()
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg4", "fuzz", "far_calls"])
+def test_estranged_table_matches_the_oracle(isa, name):
+    """on top of the renumbering: other prices, forwarding-mode byte codes and far_call / ret register conventions"""
+    import _metamorphic as M
+    from _oracle import load_oracle
+    isa_v = M.estranged(0xE57A + 16 * sum(map(ord, name)))
+    orc_v, prod_v = load_oracle().open(isa_v), K.load_product().open(isa_v)
+    try:
+        wl = META_WORKLOADS[name](isa_v)
+        b_o, b_p = _run(orc_v, wl), _run(prod_v, wl)
+        n_ok = 0
+        for i in range(wl.n_instances):
+            tp = b_p.trace(i)
+            if tp["status"] == K.STATUS_LIMIT:  # a capacity of the batch, a notion the reference does not have
+                continue
+            ok, why = K.traces_equal(b_o.trace(i), tp)
+            assert ok, "%s instance %d: %s" % (name, i, why)
+            n_ok += 1
+        assert n_ok >= wl.n_instances * 3 // 4
+        b_o.destroy(); b_p.destroy()
+    finally:
+        orc_v.close(); prod_v.close()
+
+
+@pytest.mark.parametrize("how", ["heap", "aux", "panic"])
+def test_pages_of_an_instance_that_ended(oracle, product, isa, how):
+    """the bootloader's own `ret` ends the instance: stack page and the page that is not the returndata back to the pool
+    (memory.rs:668-731) — zkw_batch_get_page must not see the marks of the returned frame (round-3 advisor finding)"""
+    wl = synth.bootloader_returns(isa, how, n_instances=70)
+    bo, bp = _run(oracle, wl), _run(product, wl)
+    base = synth.BOOTLOADER_BASE_PAGE
+    for i in range(wl.n_instances):
+        ok, why = K.traces_equal(bo.trace(i), bp.trace(i))
+        assert ok, why
+        for page in (base, base + 1, base + 2, base + 3):
+            assert np.array_equal(bo.page(i, page, 0, 16), bp.page(i, page, 0, 16)), (how, i, page)
+    bo.destroy(); bp.destroy()
