@@ -414,6 +414,31 @@ def measure(dev, prod, isa, args, rank, world, comm, collective, transport, with
     expect = world * len(flow.batches) * args.instances * cycles
     if (tot_failed != 0 or (args.cfg in (0, 1, 2) and tot_cycles != expect)) and not os.environ.get("ZKW_BENCH_NOCHECK"):  # (the env switch: kernel-time ablations of profiles/tools, whose runs are wrong by construction)
         raise RuntimeError("bench: %d instances stopped on a capacity limit or an error status; %d of %d cycles executed" % (tot_failed, tot_cycles, expect))
+    # untimed: the 512-byte snapshots the tracer contract names (witness_trace/mod.rs:11-20), materialised on the device by
+    # zkw_batch_expand_records for one batch (a streaming kernel: 512 B written per VM cycle), and what the host rebuild of
+    # zkw_batch_get_instance_trace manages on one core
+    expand = None
+    if dev.name == "gpu" and rank == 0 and args.instances * cycles * 512 <= (4 << 30):
+        exp_dst = torch.empty(args.instances * cycles * 512, dtype=torch.uint8, device=dev.tensor_device)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = None
+        with torch.cuda.stream(flow.main_stream):
+            for _ in range(4):
+                ev0.record(flow.main_stream)
+                batch.expand_records(0, args.instances, exp_dst.data_ptr(), cycles, flow.main_stream.cuda_stream)
+                ev1.record(flow.main_stream)
+                flow.main_stream.synchronize()
+                ms_ = ev0.elapsed_time(ev1)
+                best = ms_ if best is None else min(best, ms_)
+        n_rec = int(st["cycles"])
+        t_h = time.perf_counter()
+        tr0 = batch.trace(0)  # builds wave 0 on the host: downloads its streams, replays the deltas, de-interleaves the queries
+        t_h = time.perf_counter() - t_h
+        lanes_w0 = min(args.instances, int(batch.limits["lanes_per_wave"][0]) or 64)
+        expand = {"kernel_ms": best, "records": n_rec, "GBps": n_rec * 512 / (best * 1e-3) / 1e9, "frac_of_8TBps": n_rec * 512 / (best * 1e-3) / 8e12,
+                  "host_rebuild_one_wave_ms": 1e3 * t_h, "host_rebuild_records_per_s_one_core": lanes_w0 * int(tr0["n_cycles"]) / t_h,
+                  "host_rebuild_GBps_one_core": lanes_w0 * int(tr0["n_cycles"]) * 512 / t_h / 1e9}
+        del exp_dst
     # untimed: what pulling one step's whole trace over PCIe would cost
     dl_bytes, dl_ms = C.c_uint64(0), C.c_double(0)
     prod.call("batch_download_all", batch.h, C.byref(dl_bytes), C.byref(dl_ms))
@@ -477,7 +502,8 @@ def measure(dev, prod, isa, args, rank, world, comm, collective, transport, with
                          "frac_alone": b_cycle * cycles_per_step * len(flow.groups[0]) / (k_ms_alone * 1e-3) / 1e9 / 8000.0, "bytes_per_cycle": b_cycle,
                          "algorithmic_bytes_r3": ALGORITHMIC_BYTES_R3 if headline_shape else None, "bytes_per_cycle_this_run": b_run,
                          "heap_words_per_cycle": heap_words, "snapshot_equivalent_bytes_per_cycle": b_cycle_snapshot, "snapshot_equivalent_GBps": b_cycle_snapshot * cycles_per_step * batches_per_launch / (k_ms * 1e-3) / 1e9, "cycles_per_launch": cycles_per_step * batches_per_launch,
-                         "chip_achieved": b_cycle * value / 1e9, "chip_frac": b_cycle * value / 1e9 / 8000.0},
+                         "chip_achieved": b_cycle * value / 1e9, "chip_frac": b_cycle * value / 1e9 / 8000.0,
+                         "expand_GBps": expand["GBps"] if expand else None, "expand": expand},
         }
         if with_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(isa, args, prod)

@@ -559,6 +559,10 @@ class Batch:
             "final_storage": _from_ptr(t.final_storage, t.n_final_storage, STORAGE_SLOT),
         }
 
+    def expand_records(self, first, count, dst_device, stride_records=0, stream=None):
+        """zkw_batch_expand_records: the 512-byte CycleRecords of instances [first, first + count) written to device memory"""
+        self.be.call("batch_expand_records", self.h, C.c_uint32(first), C.c_uint32(count), C.c_void_p(dst_device), C.c_uint64(stride_records), C.c_void_p(stream))
+
     def commitments(self):
         out = np.zeros((self.wl.n_instances, QUEUE_COUNT, 4), dtype="<u8")
         self.be.call("batch_get_commitments", self.h, _ptr(out))

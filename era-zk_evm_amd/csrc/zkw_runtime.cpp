@@ -26,6 +26,8 @@ extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_launch_args* A, hipStrea
 extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_group);
 extern "C" hipError_t zkw_launch_reset_kernel(const zkw_fused_table* T, hipStream_t stream);
 extern "C" hipError_t zkw_launch_commit(const zkw_fused_table* T, int stage, hipStream_t stream);
+extern "C" hipError_t zkw_launch_expand(const zkw_kparams* kp, const zkw_dev_entry* callstack0, void* dst, uint64_t stride, uint32_t first, uint32_t count,
+                                        uint32_t L, uint32_t wave_threads, hipStream_t stream);
 
 static_assert(sizeof(zkw_callstack_entry) == 112, "abi");
 static_assert(sizeof(zkw_vm_local_state) == 680, "abi");
@@ -1540,6 +1542,25 @@ int zkw_batch_get_instance_trace(zkw_batch* b, uint32_t instance, zkw_instance_t
   zkw_dev_entry cur;
   HIP_TRY(c, hipMemcpy(&cur, b->d_callstack.p + (size_t)instance * (b->lim.max_callstack_depth + 1) + sc.depth, sizeof cur, hipMemcpyDeviceToHost));
   fs.current = cur.e;
+  return ZKW_OK;
+}
+
+int zkw_batch_expand_records(zkw_batch* b, uint32_t first, uint32_t count, void* dst_device, uint64_t stride_records, void* hip_stream) {
+  if (!b || !dst_device) return ZKW_ERR_INVALID;
+  zkw_ctx* c = b->ctx;
+  if (!b->uploaded) return ZKW_ERR_INVALID;
+  if (!b->ran) return ZKW_ERR_NOT_RUN;
+  if (count == 0 || first >= b->n || count > b->n - first) {
+    c->last_error = "zkw_batch_expand_records: instance range outside the batch";
+    return ZKW_ERR_INVALID;
+  }
+  if (stride_records == 0) stride_records = b->lim.max_cycles;
+  if (stride_records < b->cycles_run) {
+    c->last_error = "zkw_batch_expand_records: stride_records is smaller than the cycles run since the last reset";
+    return ZKW_ERR_INVALID;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, zkw_launch_expand(b->d_kp.p, b->d_callstack0.p, dst_device, stride_records, first, count, b->L, b->kp.wave_threads, (hipStream_t)hip_stream));
   return ZKW_OK;
 }
 

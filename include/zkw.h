@@ -521,6 +521,16 @@ int zkw_batch_get_instance_trace(zkw_batch* batch, uint32_t instance, zkw_instan
  * reused, i.e. while the run has opened no more than limits.max_far_frames far frames.  Synchronises the batch. */
 int zkw_batch_get_page(zkw_batch* batch, uint32_t instance, uint32_t page, uint32_t first_word, uint32_t n_words, zkw_u256* out);
 
+/* The 512-byte zkw_cycle_records of instances [first, first + count) materialised on the DEVICE, for a consumer that
+ * lives there: what start_new_execution_cycle(&local_state) / end_execution_cycle(&local_state) hand the tracer
+ * (witness_trace/mod.rs:11-20, cycle.rs:34,413), rebuilt from the delta form the cycle kernel stores (the same records
+ * zkw_batch_get_instance_trace rebuilds on the host, bit for bit).  Record k of instance i goes to
+ * dst_device + ((i - first) * stride_records + k) * 512; stride_records = 0 means limits.max_cycles, and must cover the cycles
+ * run since the last reset; records beyond an instance's cycle count are left untouched.  Asynchronous on `hip_stream`,
+ * ordered behind the run on the same stream (a different stream is the caller's to order).  A streaming kernel:
+ * 512 bytes written per VM cycle. */
+int zkw_batch_expand_records(zkw_batch* batch, uint32_t first, uint32_t count, void* dst_device, uint64_t stride_records, void* hip_stream);
+
 /* --- queue commitments (the build's own sponge spec) --- */
 #define ZKW_QUEUE_MEMORY 0
 #define ZKW_QUEUE_LOG 1

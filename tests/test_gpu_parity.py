@@ -770,3 +770,25 @@ def test_pages_of_an_instance_that_ended(oracle, product, isa, how):
         for page in (base, base + 1, base + 2, base + 3):
             assert np.array_equal(bo.page(i, page, 0, 16), bp.page(i, page, 0, 16)), (how, i, page)
     bo.destroy(); bp.destroy()
+
+
+@pytest.mark.parametrize("cfg,kw,lanes", [(2, dict(n_instances=200), 0), (2, dict(n_instances=77), 8), (4, dict(n_instances=96, n_cycles=1024), 0), (1, dict(n_instances=64), 1)])
+def test_expand_records_on_the_device(product, isa, cfg, kw, lanes):
+    """zkw_batch_expand_records: the 512-byte CycleRecords written by the streaming kernel into a device buffer are the
+    records zkw_batch_get_instance_trace rebuilds on the host (which the other tests compare with the oracle), for a sub-range
+    of the instances that starts and ends inside a wave; nothing is written beyond an instance's last cycle or outside the range"""
+    import torch
+    wl = synth.make(cfg, isa, **kw)
+    b = _run(product, wl, lanes)
+    first, count = 3, wl.n_instances - 7
+    stride = wl.n_cycles + 1
+    dst = torch.full((count, stride, 512), 0xAB, dtype=torch.uint8, device="cuda")
+    b.expand_records(first, count, dst.data_ptr(), stride, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    host = dst.cpu().numpy()
+    for i in list(range(first, first + count, 5)) + [first + count - 1]:
+        t = b.trace(i)
+        n = t["n_cycles"]
+        assert host[i - first, :n].tobytes() == t["records"].tobytes(), "instance %d" % i
+        assert (host[i - first, n:] == 0xAB).all()
+    b.destroy()
