@@ -358,6 +358,12 @@ class Backend:
         arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])
         self.call("batches_step_prepared", arr, C.c_uint32(len(batches)), C.c_uint32(max_cycles), C.c_uint32(queue_mask), C.c_void_p(stream))
 
+    def expand_records_many(self, batches, dst_ptrs, stride_records=0, stream=None):
+        """zkw_batches_expand_records: the 512-byte CycleRecords of every instance of the batches, to one device buffer each"""
+        arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])
+        dst = (C.c_void_p * len(batches))(*dst_ptrs)
+        self.call("batches_expand_records", arr, C.c_uint32(len(batches)), dst, C.c_uint64(stride_records), C.c_void_p(stream))
+
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32)

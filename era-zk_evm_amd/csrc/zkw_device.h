@@ -164,6 +164,7 @@ typedef struct zkw_kparams {
   uint64_t* dq_prev;            /* [n_instances][4] the tail before the decommit chained last: what a cycle that fails AFTER its decommit restores */
   uint32_t* dir;               /* [n_waves][max_cycles + 1][4] (mem, log, aux cursors at cycle start) */
   uint32_t* cursors;           /* [n_waves][4] persistent stream cursors: mem, log, aux, register deltas */
+  const zkw_dev_entry* callstack0; /* [n_instances][D + 1] pristine callstack (zkw_expand_kernel: the pc / memory bounds an instance started with) */
 } zkw_kparams;
 #define ZKW_KP const zkw_kparams ZKW_CONST_AS&
 

@@ -26,8 +26,8 @@ extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_launch_args* A, hipStrea
 extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_group);
 extern "C" hipError_t zkw_launch_reset_kernel(const zkw_fused_table* T, hipStream_t stream);
 extern "C" hipError_t zkw_launch_commit(const zkw_fused_table* T, int stage, hipStream_t stream);
-extern "C" hipError_t zkw_launch_expand(const zkw_kparams* kp, const zkw_dev_entry* callstack0, void* dst, uint64_t stride, uint32_t first, uint32_t count,
-                                        uint32_t L, uint32_t wave_threads, hipStream_t stream);
+extern "C" hipError_t zkw_launch_expand(const zkw_kparams* const* kp, void* const* dst, const uint32_t* n_waves, uint32_t n, uint64_t stride, uint32_t first,
+                                        uint32_t count, uint32_t L, uint32_t wave_threads, uint32_t max_cycles_run, uint32_t n_cus, hipStream_t stream);
 
 static_assert(sizeof(zkw_callstack_entry) == 112, "abi");
 static_assert(sizeof(zkw_vm_local_state) == 680, "abi");
@@ -875,7 +875,7 @@ int zkw_batch_upload(zkw_batch* b) {
   P.blob_words = b->d_blob_words.p; P.blob_dir = b->d_blob_dir.p; P.preimages = b->d_preimages.p;
   P.commit_rc = b->d_rc.p; P.midstates = b->d_midstates.p; P.blob_digests = b->d_blob_digests.p; P.commit_out = b->d_commit.p; P.dq_count = b->d_dq_count.p; P.dq_prev = b->d_dq_prev.p;
   P.tails = b->d_tails.p; P.deltas = b->d_deltas.p; P.wave_cycles = b->d_wave_cycles.p; P.cap_delta = b->cap_delta; P.heap_dirty = b->d_heap_dirty.p; P.heap_image_words = b->heap_image_words; P.mem_stream = b->d_mem.p; P.log_stream = b->d_log.p; P.aux_stream = b->d_auxs.p;
-  P.dir = b->d_dir.p; P.cursors = b->d_cursors.p;
+  P.dir = b->d_dir.p; P.cursors = b->d_cursors.p; P.callstack0 = b->d_callstack0.p;
   P.regs0 = b->d_regs0.p; P.scalars0 = b->d_scalars0.p; P.storage_dirty = b->d_storage_dirty.p;
   P.props = b->props;
   HIP_TRY(c, ensure(b->d_kp, 1));
@@ -1560,7 +1560,42 @@ int zkw_batch_expand_records(zkw_batch* b, uint32_t first, uint32_t count, void*
     return ZKW_ERR_INVALID;
   }
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, zkw_launch_expand(b->d_kp.p, b->d_callstack0.p, dst_device, stride_records, first, count, b->L, b->kp.wave_threads, (hipStream_t)hip_stream));
+  const zkw_kparams* kp = b->d_kp.p;
+  const uint32_t nw = b->n_waves;
+  HIP_TRY(c, zkw_launch_expand(&kp, &dst_device, &nw, 1, stride_records, first, count, b->L, b->kp.wave_threads, b->cycles_run, (uint32_t)c->n_cus, (hipStream_t)hip_stream));
+  return ZKW_OK;
+}
+
+int zkw_batches_expand_records(zkw_batch* const* batches, uint32_t n_batches, void* const* dst_device, uint64_t stride_records, void* hip_stream) {
+  int rc = check_group(batches, n_batches);
+  if (rc != ZKW_OK) return rc;
+  if (!dst_device) return ZKW_ERR_INVALID;
+  zkw_ctx* c = batches[0]->ctx;
+  uint32_t run = 0;
+  for (uint32_t i = 0; i < n_batches; i++) {
+    if (!batches[i]->ran) return ZKW_ERR_NOT_RUN;
+    if (!dst_device[i]) return ZKW_ERR_INVALID;
+    const uint64_t st = stride_records ? stride_records : batches[i]->lim.max_cycles;
+    if (st < batches[i]->cycles_run || (stride_records == 0 && batches[i]->lim.max_cycles != batches[0]->lim.max_cycles)) {
+      c->last_error = "zkw_batches_expand_records: stride_records must cover the cycles run (and, when 0, the batches must share limits.max_cycles)";
+      return ZKW_ERR_INVALID;
+    }
+    run = std::max(run, batches[i]->cycles_run);
+  }
+  if (stride_records == 0) stride_records = batches[0]->lim.max_cycles;
+  HIP_TRY(c, hipSetDevice(c->device));
+  for (uint32_t at = 0; at < n_batches; at += 128) {  // (the by-value table of a launch holds 128 batches)
+    const uint32_t n = std::min<uint32_t>(128, n_batches - at);
+    const zkw_kparams* kp[128];
+    void* dst[128];
+    uint32_t nw[128];
+    for (uint32_t i = 0; i < n; i++) {
+      kp[i] = batches[at + i]->d_kp.p;
+      dst[i] = dst_device[at + i];
+      nw[i] = batches[at + i]->n_waves;
+    }
+    HIP_TRY(c, zkw_launch_expand(kp, dst, nw, n, stride_records, 0, 0xffffffffu, batches[at]->L, batches[at]->kp.wave_threads, run, (uint32_t)c->n_cus, (hipStream_t)hip_stream));
+  }
   return ZKW_OK;
 }
 

@@ -530,6 +530,11 @@ int zkw_batch_get_page(zkw_batch* batch, uint32_t instance, uint32_t page, uint3
  * ordered behind the run on the same stream (a different stream is the caller's to order).  A streaming kernel:
  * 512 bytes written per VM cycle. */
 int zkw_batch_expand_records(zkw_batch* batch, uint32_t first, uint32_t count, void* dst_device, uint64_t stride_records, void* hip_stream);
+/* The same for every instance of up to 256 batches of one context in fused launches (what a device-side consumer of a
+ * zkw_batches_step calls): dst_device[b] receives batch b, laid out as above with first = 0.  One batch is 64 waves of a
+ * sequential chain each, so a lone batch is expanded in chunks of cycles (every chunk replays the cycles in front of it
+ * silently); a fused group has waves enough to run at the HBM write rate unchunked. */
+int zkw_batches_expand_records(zkw_batch* const* batches, uint32_t n_batches, void* const* dst_device, uint64_t stride_records, void* hip_stream);
 
 /* --- queue commitments (the build's own sponge spec) --- */
 #define ZKW_QUEUE_MEMORY 0

@@ -791,4 +791,14 @@ def test_expand_records_on_the_device(product, isa, cfg, kw, lanes):
         n = t["n_cycles"]
         assert host[i - first, :n].tobytes() == t["records"].tobytes(), "instance %d" % i
         assert (host[i - first, n:] == 0xAB).all()
-    b.destroy()
+    # the fused entry: every instance of two batches (the second with its own lane width), unchunked or chunked as the launch decides
+    b2 = _run(product, synth.make(cfg, isa, **kw), 0)
+    outs = [torch.full((wl.n_instances, stride, 512), 0xCD, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    product.expand_records_many([b, b2], [o.data_ptr() for o in outs], stride, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for o in outs:
+        host = o.cpu().numpy()
+        for i in list(range(0, wl.n_instances, 7)) + [wl.n_instances - 1]:
+            t = b.trace(i)
+            assert host[i, :t["n_cycles"]].tobytes() == t["records"].tobytes(), "fused: instance %d" % i
+    b.destroy(); b2.destroy()
