@@ -211,6 +211,7 @@ class Flow:
         self.pristine = [True] * n_groups      # the upload leaves every batch restored
         self.waits_ready = [False] * n_groups  # ev_ready[g] has been recorded behind work the group's next run must wait for
         self.restores = 0
+        self._arrays = {}
         # final exchange: all-gather of the per-instance queue digests, once per fused group; only the
         # committed queues travel: [world][batches][instances][n_committed][4] u64 per group (layout of zkw_reduce_commitments)
         self.committed = [q for q in range(3) if (args.commit_mask >> q) & 1]
@@ -270,7 +271,10 @@ class Flow:
             prod.reset_many(group, main.cuda_stream)
             self.restores += 1
         if not self.overlap:
-            prod.step_prepared_many(group[:n], self.cycles, args.commit_mask, main.cuda_stream)  # run + commitments: a whole step on one stream
+            key = (g, n)
+            if key not in self._arrays:
+                self._arrays[key] = prod.handle_array(group[:n])
+            prod.step_prepared_many(self._arrays[key], self.cycles, args.commit_mask, main.cuda_stream)  # run + commitments: a whole step on one stream
             self._reduce(g, n, main.cuda_stream)
             if used_again:
                 prod.reset_many(group, main.cuda_stream)
@@ -690,7 +694,7 @@ def main():
     repeats = args.repeats if args.repeats >= 0 else (4 if headline and not emu else 0)
     with_cpu = not args.no_cpu_baseline and world == 1 and not emu  # rank 0 at N = 1 only
     out = measure(dev, prod, isa, args, rank, world, comm, collective, transport, with_cpu, repeats=repeats)
-    if rank == 0 and headline and world == 1 and not args.no_other_configs and not emu and not collective:
+    if rank == 0 and headline and world == 1 and not args.no_other_configs and not emu and not collective and not os.environ.get("ZKW_BENCH_NO_OTHER_CONFIGS"):  # (the env switch: profiles/collect.sh's sweeps)
         out["other_configs"], out["other_configs_wall_s"] = other_configs(dev, prod, isa, args, comm, transport, with_cpu)
     comm.close()
     if collective:
@@ -785,7 +789,7 @@ def cpu_socket_rate(isa, args):
     model, packages = _cpu_topology()
     socket0 = packages[sorted(packages)[0]]
     orc = load_oracle(native=True).open(isa)
-    n = max(2 * len(socket0), 256) if args.cfg in (3, 4) else max(64 * len(socket0), 4096)
+    n = max(16 * len(socket0), 1024) if args.cfg in (3, 4) else max(64 * len(socket0), 4096)  # (every worker a block of >= 16 instances: well beyond its caches)
     r = _oracle_timed(orc, isa, args, socket0, n, min_s=1.0, max_reps=6)
     orc.close()
     return {"single_socket_value": r["value"], "single_socket_threads": r["threads"], "kind": "port", "cpu_model": model,

@@ -353,10 +353,17 @@ class Backend:
         arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])
         self.call("batches_step", arr, C.c_uint32(len(batches)), C.c_uint32(max_cycles), C.c_uint32(queue_mask), C.c_void_p(stream))
 
+    def handle_array(self, batches):
+        """the batch handles as the C array the fused entry points take (build once, pass as `batches` again: a caller that
+        steps the same group over and over does not rebuild it in front of every launch)"""
+        arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])
+        arr.n = len(batches)
+        return arr
+
     def step_prepared_many(self, batches, max_cycles, queue_mask=0, stream=None):
         """zkw_batches_step_prepared: run + commit of batches whose inputs are in place (uploaded / restored earlier)."""
-        arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])
-        self.call("batches_step_prepared", arr, C.c_uint32(len(batches)), C.c_uint32(max_cycles), C.c_uint32(queue_mask), C.c_void_p(stream))
+        arr = batches if hasattr(batches, "n") else self.handle_array(batches)
+        self.call("batches_step_prepared", arr, C.c_uint32(arr.n), C.c_uint32(max_cycles), C.c_uint32(queue_mask), C.c_void_p(stream))
 
     def expand_records_many(self, batches, dst_ptrs, stride_records=0, stream=None):
         """zkw_batches_expand_records: the 512-byte CycleRecords of every instance of the batches, to one device buffer each"""

@@ -1350,6 +1350,9 @@ ZD void prefetch_page_words(const uint4* arena, u32 words_per_page, u32 L, u32 l
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, off\n\tglobal_load_lds_dword %1, off" : : "v"(p), "v"(p + L), "s"(lds_sink) : "m0");
   }
 }
+// LDS address of the sink: right behind the ISA table in the dynamic segment (zkw_launch_cycle_kernel: args.lds_sink) — a
+// link-time constant, so neither a register nor an LDS word has to carry it to the opcode bodies
+ZD u32 zkw_lds_sink_addr() { return (u32)(size_t)(ZKW_LDS_AS char*)((char*)zkw_lds + ZKW_ISA_TABLE_SIZE * 8u); }
 ZD void prefetch_uma_words(ZKW_KP P, const Shared& sh, Lane& s, u32 lds_sink, u32 attr, u32 word_hi) {
   const u32 v = ZKW_ATTR_VARIANT(attr);
   if (ZKW_ATTR_OPCODE(attr) != ZKW_OP_UMA || ZKW_ATTR_SRC0(attr) != ZKW_MODE_IMM || (v != ZKW_UMA_HEAP_READ && v != ZKW_UMA_HEAP_WRITE)) return;
@@ -1389,7 +1392,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
   // real (same-box A/B: +1.5 % on top of the code-word prefetch; requesting the covered ones here again changes nothing)
   if (!is_ptr_read && !ZKW_ABL(sh.debug_flags, ZKW_NO_PREFETCH) && (!is_heap || ZKW_ATTR_SRC0(d.attr) != ZKW_MODE_IMM || ((ps.new_pc - 1u) & 3u) == 0) &&
       !(ps.src0.w[1] | ps.src0.w[2] | ps.src0.w[3] | ps.src0.w[4] | ps.src0.w[5] | ps.src0.w[6] | ps.src0.w[7]))
-    prefetch_page_words(is_heap ? sh.heap : sh.aux_heap, is_heap ? P.H : P.A, P.L, (u32)__builtin_amdgcn_readfirstlane((int)*ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor + 2)), f_slot, f_hwm, ps.src0.w[0]);
+    prefetch_page_words(is_heap ? sh.heap : sh.aux_heap, is_heap ? P.H : P.A, P.L, zkw_lds_sink_addr(), f_slot, f_hwm, ps.src0.w[0]);
 #endif
   u32 mem_type;
   if (is_ptr_read) {
@@ -1513,6 +1516,13 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
     }
     ZKW_SUB(47)  // write: destination
   }
+#ifdef __HIP_DEVICE_COMPILE__
+  // A heap access through a register with post-increment is a cursor: the next access through it is 32 bytes on, and its
+  // words can be requested now — cycles before that instruction arrives (the code-word prefetch cannot see a register-held
+  // address).  A hint like the others: wrong guesses cost two loads into the sink.
+  if (!is_ptr_read && increment && !set_panic && ZKW_ATTR_SRC0(d.attr) != ZKW_MODE_IMM && !ZKW_ABL(sh.debug_flags, ZKW_NO_PREFETCH))
+    prefetch_page_words(is_heap ? sh.heap : sh.aux_heap, is_heap ? P.H : P.A, P.L, zkw_lds_sink_addr(), f_slot, f_hwm, incremented);
+#endif
 }
 
 // log.rs:11-330 (precompile calls: see zkw_precompiles below)
@@ -2407,7 +2417,9 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
     ps.src0 = src0_mem;
     ps.src0_ptr = src0_mem_ptr;
   }
-  {  // swap_operands (:341-345) — limb-wise selects (a struct swap keeps both operands in scratch memory)
+  {  // swap_operands (:341-345) — limb-wise selects (a struct swap keeps both operands in scratch memory).  (Swapping the two
+     // register NUMBERS instead when both operands are registers — scalars, free — was measured: fewer instructions, kernel
+     // +1.6 % slower on the driver's command, profiles/r06_ab_log.txt)
     const bool sw = (props & ZKW_PROP_SWAP) != 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -2944,7 +2956,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
   zkw_wave_lds_fence();
 #endif
 #ifdef __HIP_DEVICE_COMPILE__
-  const u32 lds_sink = zkw_uniform((u32)(size_t)(ZKW_LDS_AS char*)((char*)zkw_lds + A.lds_sink));
+  const u32 lds_sink = zkw_lds_sink_addr();
 #endif
   const u32 cycle_base = P.wave_cycles[wave];  // wave-cycles run since the reset (records / directory index)
   // first launch after a reset: the lanes start from the pristine images (the reset does not copy them — 2.5 MB per 4096

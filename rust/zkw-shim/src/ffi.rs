@@ -49,7 +49,20 @@ pub struct zkw_isa_consts {
     pub precompile_aux_byte: u8,
     pub ecrecover_input_layout: u32,
     pub bootloader_calldata_page: u32,
-    pub reserved: [u32; 6],
+    /// far_call.rs:506-508,573-610: byte 0 CALL_IMPLICIT_CALLDATA_FAT_PTR_REGISTER, 1 CALL_IMPLICIT_CONSTRUCTOR_MARKER_REGISTER, 2 CALL_IMPLICIT_PARAMETER_REG_IDX
+    pub call_regs: u32,
+    /// bytes 0 / 1: CALL_SYSTEM_ABI_REGISTERS first / end, bytes 2 / 3: CALL_RESERVED_RANGE first / end (ends exclusive)
+    pub call_ranges: u32,
+    /// ret.rs:213-233: byte 0 RET_IMPLICIT_RETURNDATA_PARAMS_REGISTER, bytes 1..3 RET_RESERVED_REGISTER_0..2
+    pub ret_regs: u32,
+    /// FarCallForwardPageType as the ABI byte: byte 0 UseHeap, 1 ForwardFatPointer, 2 UseAuxHeap
+    pub forwarding_codes: u32,
+    pub unmapped_page: u32,
+    pub reserved0: u32,
+    /// ptr::MAX_OFFSET_FOR_ADD_SUB (ptr.rs:47)
+    pub max_offset_for_add_sub: u64,
+    /// bit 8 * field + (lt_of | eq << 1 | gt << 2): the Condition the 3-bit field names holds (cycle.rs:193-209)
+    pub condition_lut: u64,
 }
 
 #[repr(C)]
@@ -259,6 +272,34 @@ pub struct zkw_run_stats {
     pub reg_deltas: u64,
 }
 
+/// EventMessage, reference_impls/event_sink.rs:7-14
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct zkw_event_message {
+    pub shard_id: u8,
+    pub is_first: u8,
+    pub tx_number_in_block: u16,
+    pub address: [u8; 20],
+    pub key: zkw_u256,
+    pub value: zkw_u256,
+}
+
+/// get_final_net_states (testing/mod.rs:42-71) of one instance: library-owned arrays
+#[repr(C)]
+pub struct zkw_net_state {
+    pub n_storage_history: u32,
+    pub n_event_history: u32,
+    pub n_events: u32,
+    pub n_l1_messages: u32,
+    pub n_final_storage: u32,
+    pub reserved0: u32,
+    pub storage_history: *const zkw_log_query,
+    pub event_history: *const zkw_log_query,
+    pub events: *const zkw_event_message,
+    pub l1_messages: *const zkw_event_message,
+    pub final_storage: *const zkw_storage_slot,
+}
+
 pub enum zkw_ctx {}
 pub enum zkw_batch {}
 pub enum zkw_comm {}
@@ -292,6 +333,13 @@ extern "C" {
     pub fn zkw_batch_reset(batch: *mut zkw_batch, stream: *mut c_void) -> c_int;
     pub fn zkw_batch_run(batch: *mut zkw_batch, max_cycles: u32, stream: *mut c_void) -> c_int;
     pub fn zkw_batches_step(batches: *const *mut zkw_batch, n: u32, max_cycles: u32, queue_mask: u32, stream: *mut c_void) -> c_int;
+    pub fn zkw_batches_reset(batches: *const *mut zkw_batch, n: u32, stream: *mut c_void) -> c_int;
+    pub fn zkw_batches_step_prepared(batches: *const *mut zkw_batch, n: u32, max_cycles: u32, queue_mask: u32, stream: *mut c_void) -> c_int;
+    pub fn zkw_batch_commit(batch: *mut zkw_batch, queue_mask: u32, stream: *mut c_void) -> c_int;
+    pub fn zkw_batch_net_states(batch: *mut zkw_batch, stream: *mut c_void) -> c_int;
+    pub fn zkw_batch_get_net_state(batch: *mut zkw_batch, instance: u32, out: *mut zkw_net_state) -> c_int;
+    pub fn zkw_batch_expand_records(batch: *mut zkw_batch, first: u32, count: u32, dst_device: *mut c_void, stride_records: u64, stream: *mut c_void) -> c_int;
+    pub fn zkw_batches_expand_records(batches: *const *mut zkw_batch, n: u32, dst_device: *const *mut c_void, stride_records: u64, stream: *mut c_void) -> c_int;
     pub fn zkw_batch_sync(batch: *mut zkw_batch) -> c_int;
     pub fn zkw_batch_get_stats(batch: *mut zkw_batch, out: *mut zkw_run_stats) -> c_int;
     pub fn zkw_batch_get_instance_trace(batch: *mut zkw_batch, instance: u32, out: *mut zkw_instance_trace) -> c_int;

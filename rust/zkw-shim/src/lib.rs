@@ -26,6 +26,7 @@ use ffi::*;
 use zk_evm::aux_structures::{DecommittmentQuery, LogQuery, MemoryIndex, MemoryLocation, MemoryPage, MemoryQuery, Timestamp};
 use zk_evm::ethereum_types::{Address, U256};
 use zk_evm::flags::Flags;
+use zk_evm::reference_impls::event_sink::EventMessage;
 use zk_evm::tracing::Tracer;
 use zk_evm::vm_state::{CallStackEntry, Callstack, PrimitiveValue, VmLocalState};
 use zk_evm::witness_trace::VmWitnessTracer;
@@ -242,6 +243,44 @@ pub fn isa_from_opcode_defs() -> Box<zkw_isa_table> {
     c.l1_message_aux_byte = defs::system_params::L1_MESSAGE_AUX_BYTE;
     c.precompile_aux_byte = defs::system_params::PRECOMPILE_AUX_BYTE;
     c.bootloader_calldata_page = defs::BOOTLOADER_CALLDATA_PAGE; // memory.rs:11
+    // the conventions rounds 1-3 had compiled in: table constants since round 4 (include/zkw.h), filled from the real crate here
+    c.call_regs = (defs::CALL_IMPLICIT_CALLDATA_FAT_PTR_REGISTER as u32)                 // far_call.rs:577
+        | ((defs::CALL_IMPLICIT_CONSTRUCTOR_MARKER_REGISTER as u32) << 8)                 // far_call.rs:587
+        | ((defs::CALL_IMPLICIT_PARAMETER_REG_IDX as u32) << 16);                         // far_call.rs:507,609
+    c.call_ranges = (defs::CALL_SYSTEM_ABI_REGISTERS.start as u32)                        // far_call.rs:594
+        | ((defs::CALL_SYSTEM_ABI_REGISTERS.end as u32) << 8)
+        | ((defs::CALL_RESERVED_RANGE.start as u32) << 16)                                // far_call.rs:606
+        | ((defs::CALL_RESERVED_RANGE.end as u32) << 24);
+    c.ret_regs = (defs::RET_IMPLICIT_RETURNDATA_PARAMS_REGISTER as u32)                   // ret.rs:213
+        | ((defs::RET_RESERVED_REGISTER_0 as u32) << 8)                                   // ret.rs:218-223
+        | ((defs::RET_RESERVED_REGISTER_1 as u32) << 16)
+        | ((defs::RET_RESERVED_REGISTER_2 as u32) << 24);
+    c.forwarding_codes = (defs::FarCallForwardPageType::UseHeap as u32)                   // far_call.rs:255, ret.rs:59
+        | ((defs::FarCallForwardPageType::ForwardFatPointer as u32) << 8)
+        | ((defs::FarCallForwardPageType::UseAuxHeap as u32) << 16);
+    c.unmapped_page = defs::UNMAPPED_PAGE;                                                // far_call.rs:9,162,439
+    c.max_offset_for_add_sub = defs::ptr::MAX_OFFSET_FOR_ADD_SUB.low_u64();               // ptr.rs:47 (2^32)
+    // the Condition each value of the 3-bit field names (cycle.rs:193-209), as its truth table over (lt_of | eq << 1 | gt << 2)
+    c.condition_lut = 0;
+    for field in 0..8u64 {
+        let cond = defs::Condition::materialize_variant(field as u8);
+        let mut row = 0u64;
+        for f in 0..8u64 {
+            let (lt, eq, gt) = (f & 1 != 0, f & 2 != 0, f & 4 != 0);
+            let holds = match cond {
+                defs::Condition::Always => true,
+                defs::Condition::Gt => gt,
+                defs::Condition::Lt => lt,
+                defs::Condition::Eq => eq,
+                defs::Condition::Ge => gt | eq,
+                defs::Condition::Le => lt | eq,
+                defs::Condition::Ne => !eq,
+                defs::Condition::GtOrLt => gt | lt,
+            };
+            row |= (holds as u64) << f;
+        }
+        c.condition_lut |= row << (8 * field);
+    }
     t
 }
 
@@ -376,6 +415,52 @@ impl<'a> Batch<'a> {
         self.ctx.check(unsafe { zkw_batch_reset(self.raw, std::ptr::null_mut()) }, "zkw_batch_reset")?;
         self.ctx.check(unsafe { zkw_batch_run(self.raw, max_cycles, std::ptr::null_mut()) }, "zkw_batch_run")?;
         self.ctx.check(unsafe { zkw_batch_sync(self.raw) }, "zkw_batch_sync")
+    }
+    /// zkw_batches_step over several batches of one context: restore, run and commit them with fused launches (what a caller
+    /// that owns many blocks / transactions does per scheduling quantum); `queue_mask`: bit 0 memory, 1 log, 2 decommit queue
+    pub fn step_many(batches: &mut [&mut Batch<'a>], max_cycles: u32, queue_mask: u32) -> anyhow::Result<()> {
+        let ctx = batches.first().map(|b| b.ctx).ok_or_else(|| anyhow::anyhow!("step_many: no batches"))?;
+        for b in batches.iter() {
+            ctx.check(unsafe { zkw_batch_upload(b.raw) }, "zkw_batch_upload")?;
+        }
+        let raw: Vec<*mut zkw_batch> = batches.iter().map(|b| b.raw).collect();
+        ctx.check(unsafe { zkw_batches_step(raw.as_ptr(), raw.len() as u32, max_cycles, queue_mask, std::ptr::null_mut()) }, "zkw_batches_step")?;
+        for b in batches.iter() {
+            ctx.check(unsafe { zkw_batch_sync(b.raw) }, "zkw_batch_sync")?;
+        }
+        Ok(())
+    }
+    /// the queue commitments of every instance after a run: [instance][memory, log, decommit][4] Goldilocks elements
+    /// (the build's own sponge spec: the reference has none, far_call.rs:29-32)
+    pub fn commitments(&self, queue_mask: u32) -> anyhow::Result<Vec<[[u64; 4]; 3]>> {
+        self.ctx.check(unsafe { zkw_batch_commit(self.raw, queue_mask, std::ptr::null_mut()) }, "zkw_batch_commit")?;
+        let mut out = vec![[[0u64; 4]; 3]; self.n as usize];
+        self.ctx.check(unsafe { zkw_batch_get_commitments(self.raw, out.as_mut_ptr() as *mut u64) }, "zkw_batch_get_commitments")?;
+        Ok(out)
+    }
+    /// `get_final_net_states` of the reference's test tooling (testing/mod.rs:42-71) for one instance, netted on the device:
+    /// (full_storage_access_history, storage_pre_shard, events_log_history, events, l1_messages) with the rollback entries
+    /// of panicked frames spliced in as the reference's oracles do (testing/storage.rs:144-186, event_sink.rs:160-176)
+    #[allow(clippy::type_complexity)]
+    pub fn net_state(&self, instance: u32) -> anyhow::Result<(Vec<LogQuery>, Vec<(u8, Address, U256, U256)>, Vec<LogQuery>, Vec<EventMessage>, Vec<EventMessage>)> {
+        let mut ns: zkw_net_state = unsafe { std::mem::zeroed() };
+        self.ctx.check(unsafe { zkw_batch_get_net_state(self.raw, instance, &mut ns) }, "zkw_batch_get_net_state")?;
+        let logs = |p: *const zkw_log_query, n: u32| -> Vec<LogQuery> { (0..n as usize).map(|i| log_query_from_c(unsafe { &*p.add(i) })).collect() };
+        let msgs = |p: *const zkw_event_message, n: u32| -> Vec<EventMessage> {
+            (0..n as usize)
+                .map(|i| {
+                    let m = unsafe { &*p.add(i) };
+                    EventMessage { shard_id: m.shard_id, is_first: m.is_first != 0, tx_number_in_block: m.tx_number_in_block, address: address_from_c(&m.address), key: u256_from_c(&m.key), value: u256_from_c(&m.value) }
+                })
+                .collect()
+        };
+        let storage = (0..ns.n_final_storage as usize)
+            .map(|i| {
+                let s = unsafe { &*ns.final_storage.add(i) };
+                (s.shard_id, address_from_c(&s.address), u256_from_c(&s.key), u256_from_c(&s.value))
+            })
+            .collect();
+        Ok((logs(ns.storage_history, ns.n_storage_history), storage, logs(ns.event_history, ns.n_event_history), msgs(ns.events, ns.n_events), msgs(ns.l1_messages, ns.n_l1_messages)))
     }
     /// the drop-in `VmState` of one instance, served from the finished run
     pub fn vm_state<EV: EventSink, WT: VmWitnessTracer<8, E>>(&self, instance: u32, event_sink: EV, witness_tracer: WT) -> anyhow::Result<BatchedVmState<'_, EV, WT>> {
