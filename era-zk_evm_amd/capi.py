@@ -365,11 +365,13 @@ class Backend:
         arr = batches if hasattr(batches, "n") else self.handle_array(batches)
         self.call("batches_step_prepared", arr, C.c_uint32(arr.n), C.c_uint32(max_cycles), C.c_uint32(queue_mask), C.c_void_p(stream))
 
-    def expand_records_many(self, batches, dst_ptrs, stride_records=0, stream=None):
+    def expand_records_many(self, batches, dst_ptrs, instance_stride=0, stream=None, cycle_stride=None):
         """zkw_batches_expand_records: the 512-byte CycleRecords of every instance of the batches, to one device buffer each"""
+        if cycle_stride is None:
+            cycle_stride = 1 if instance_stride else 0
         arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])
         dst = (C.c_void_p * len(batches))(*dst_ptrs)
-        self.call("batches_expand_records", arr, C.c_uint32(len(batches)), dst, C.c_uint64(stride_records), C.c_void_p(stream))
+        self.call("batches_expand_records", arr, C.c_uint32(len(batches)), dst, C.c_uint64(instance_stride), C.c_uint64(cycle_stride), C.c_void_p(stream))
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
@@ -572,9 +574,12 @@ class Batch:
             "final_storage": _from_ptr(t.final_storage, t.n_final_storage, STORAGE_SLOT),
         }
 
-    def expand_records(self, first, count, dst_device, stride_records=0, stream=None):
-        """zkw_batch_expand_records: the 512-byte CycleRecords of instances [first, first + count) written to device memory"""
-        self.be.call("batch_expand_records", self.h, C.c_uint32(first), C.c_uint32(count), C.c_void_p(dst_device), C.c_uint64(stride_records), C.c_void_p(stream))
+    def expand_records(self, first, count, dst_device, instance_stride=0, stream=None, cycle_stride=None):
+        """zkw_batch_expand_records: the 512-byte CycleRecords of instances [first, first + count) written to device memory;
+        record (i, k) at ((i - first) * instance_stride + k * cycle_stride) * 512 (default: instance-major)"""
+        if cycle_stride is None:
+            cycle_stride = 1 if instance_stride else 0
+        self.be.call("batch_expand_records", self.h, C.c_uint32(first), C.c_uint32(count), C.c_void_p(dst_device), C.c_uint64(instance_stride), C.c_uint64(cycle_stride), C.c_void_p(stream))
 
     def commitments(self):
         out = np.zeros((self.wl.n_instances, QUEUE_COUNT, 4), dtype="<u8")

@@ -27,9 +27,9 @@ typedef uint64_t u64;
 
 typedef struct zkw_expand_args {
   const zkw_kparams* kp[ZKW_EXPAND_MAX];
-  uint4* dst[ZKW_EXPAND_MAX];        /* record (instance - first, cycle k) of batch b at 16-byte unit ((instance - first) * stride + k) * 32 of dst[b] */
+  uint4* dst[ZKW_EXPAND_MAX];        /* record (instance - first, cycle k) of batch b at 16-byte unit ((instance - first) * stride_i + k * stride_k) * 32 of dst[b] */
   u32 wave_base[ZKW_EXPAND_MAX + 1]; /* the waves of the launch numbered through its batches */
-  u64 stride;                        /* records per instance in dst */
+  u64 stride_i, stride_k;            /* records between consecutive instances / consecutive cycles in dst */
   u32 n_batches;
   u32 first, count;                  /* instances [first, first + count) of every batch (a ranged call has one batch) */
   u32 first_wave;                    /* first / L of a ranged call */
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) zkw_expand_kernel(zkw_expand_args X) {
       const u32 rec = idx >> 5, c = idx & 31u;
       const u32 ri = wave * L + rec;
       if (k < ncyc_s[rec] && ri >= X.first && ri - X.first < X.count) {
-        uint4* out = dst + ((u64)(ri - X.first) * X.stride + k) * 32u + c;
+        uint4* out = dst + ((u64)(ri - X.first) * X.stride_i + (u64)k * X.stride_k) * 32u + c;
 #ifdef __HIP_DEVICE_COMPILE__
         typedef unsigned int zkw_v4u __attribute__((ext_vector_type(4)));
         const uint4 v = snap[rec * ZKW_EXPAND_ROW + c];
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256) zkw_expand_kernel(zkw_expand_args X) {
 
 // n batches, instances [first, first + count) of each (a ranged call passes one batch); n_cus: the launch is cut into
 // chunks of cycles while it has fewer workgroups than ~4 per CU
-extern "C" hipError_t zkw_launch_expand(const zkw_kparams* const* kp, void* const* dst, const uint32_t* n_waves, uint32_t n, uint64_t stride, uint32_t first,
+extern "C" hipError_t zkw_launch_expand(const zkw_kparams* const* kp, void* const* dst, const uint32_t* n_waves, uint32_t n, uint64_t stride_i, uint64_t stride_k, uint32_t first,
                                         uint32_t count, uint32_t L, uint32_t wave_threads, uint32_t max_cycles_run, uint32_t n_cus, hipStream_t stream) {
   zkw_expand_args X;
   memset(&X, 0, sizeof X);
@@ -187,9 +187,10 @@ extern "C" hipError_t zkw_launch_expand(const zkw_kparams* const* kp, void* cons
     X.dst[i] = (uint4*)dst[i];
     X.wave_base[i + 1] = X.wave_base[i] + n_waves[i];
   }
-  X.stride = stride; X.first = first; X.count = count;
-  X.first_wave = n == 1 ? first / L : 0;
-  if (n == 1) X.wave_base[1] = (first + count - 1) / L - X.first_wave + 1;
+  X.stride_i = stride_i; X.stride_k = stride_k; X.first = first; X.count = count;
+  const bool ranged = n == 1 && count != 0xffffffffu;  // (a ranged call: the waves that hold instances [first, first + count) of the one batch)
+  X.first_wave = ranged ? first / L : 0;
+  if (ranged) X.wave_base[1] = (first + count - 1) / L - X.first_wave + 1;
   const uint32_t waves = X.wave_base[n];
   uint32_t chunks = 1;
   if (wave_threads > 1 && max_cycles_run > 1) {

@@ -26,7 +26,7 @@ extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_launch_args* A, hipStrea
 extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_group);
 extern "C" hipError_t zkw_launch_reset_kernel(const zkw_fused_table* T, hipStream_t stream);
 extern "C" hipError_t zkw_launch_commit(const zkw_fused_table* T, int stage, hipStream_t stream);
-extern "C" hipError_t zkw_launch_expand(const zkw_kparams* const* kp, void* const* dst, const uint32_t* n_waves, uint32_t n, uint64_t stride, uint32_t first,
+extern "C" hipError_t zkw_launch_expand(const zkw_kparams* const* kp, void* const* dst, const uint32_t* n_waves, uint32_t n, uint64_t stride_i, uint64_t stride_k, uint32_t first,
                                         uint32_t count, uint32_t L, uint32_t wave_threads, uint32_t max_cycles_run, uint32_t n_cus, hipStream_t stream);
 
 static_assert(sizeof(zkw_callstack_entry) == 112, "abi");
@@ -1545,7 +1545,20 @@ int zkw_batch_get_instance_trace(zkw_batch* b, uint32_t instance, zkw_instance_t
   return ZKW_OK;
 }
 
-int zkw_batch_expand_records(zkw_batch* b, uint32_t first, uint32_t count, void* dst_device, uint64_t stride_records, void* hip_stream) {
+// the two layouts of the expanded records: instance-major (stride_k == 1: the records of an instance are contiguous, the
+// layout of zkw_instance_trace.records) or cycle-major (stride_i == 1: the records of a cycle are contiguous — what the kernel
+// writes fastest: a wave's 64 records of a cycle are one 32 KB run)
+static int expand_strides(zkw_ctx* c, uint64_t& si, uint64_t& sk, uint32_t max_cycles, uint32_t cycles_run, uint32_t count) {
+  if (si == 0 && sk == 0) { si = max_cycles; sk = 1; }
+  const bool instance_major = sk == 1 && si >= cycles_run, cycle_major = si == 1 && sk >= count;
+  if (!instance_major && !cycle_major) {
+    c->last_error = "expand_records: strides must be (>= cycles run, 1) — instance-major — or (1, >= instances) — cycle-major";
+    return ZKW_ERR_INVALID;
+  }
+  return ZKW_OK;
+}
+
+int zkw_batch_expand_records(zkw_batch* b, uint32_t first, uint32_t count, void* dst_device, uint64_t instance_stride, uint64_t cycle_stride, void* hip_stream) {
   if (!b || !dst_device) return ZKW_ERR_INVALID;
   zkw_ctx* c = b->ctx;
   if (!b->uploaded) return ZKW_ERR_INVALID;
@@ -1554,19 +1567,16 @@ int zkw_batch_expand_records(zkw_batch* b, uint32_t first, uint32_t count, void*
     c->last_error = "zkw_batch_expand_records: instance range outside the batch";
     return ZKW_ERR_INVALID;
   }
-  if (stride_records == 0) stride_records = b->lim.max_cycles;
-  if (stride_records < b->cycles_run) {
-    c->last_error = "zkw_batch_expand_records: stride_records is smaller than the cycles run since the last reset";
-    return ZKW_ERR_INVALID;
-  }
+  int rc = expand_strides(c, instance_stride, cycle_stride, b->lim.max_cycles, b->cycles_run, count);
+  if (rc != ZKW_OK) return rc;
   HIP_TRY(c, hipSetDevice(c->device));
   const zkw_kparams* kp = b->d_kp.p;
   const uint32_t nw = b->n_waves;
-  HIP_TRY(c, zkw_launch_expand(&kp, &dst_device, &nw, 1, stride_records, first, count, b->L, b->kp.wave_threads, b->cycles_run, (uint32_t)c->n_cus, (hipStream_t)hip_stream));
+  HIP_TRY(c, zkw_launch_expand(&kp, &dst_device, &nw, 1, instance_stride, cycle_stride, first, count, b->L, b->kp.wave_threads, b->cycles_run, (uint32_t)c->n_cus, (hipStream_t)hip_stream));
   return ZKW_OK;
 }
 
-int zkw_batches_expand_records(zkw_batch* const* batches, uint32_t n_batches, void* const* dst_device, uint64_t stride_records, void* hip_stream) {
+int zkw_batches_expand_records(zkw_batch* const* batches, uint32_t n_batches, void* const* dst_device, uint64_t instance_stride, uint64_t cycle_stride, void* hip_stream) {
   int rc = check_group(batches, n_batches);
   if (rc != ZKW_OK) return rc;
   if (!dst_device) return ZKW_ERR_INVALID;
@@ -1575,14 +1585,20 @@ int zkw_batches_expand_records(zkw_batch* const* batches, uint32_t n_batches, vo
   for (uint32_t i = 0; i < n_batches; i++) {
     if (!batches[i]->ran) return ZKW_ERR_NOT_RUN;
     if (!dst_device[i]) return ZKW_ERR_INVALID;
-    const uint64_t st = stride_records ? stride_records : batches[i]->lim.max_cycles;
-    if (st < batches[i]->cycles_run || (stride_records == 0 && batches[i]->lim.max_cycles != batches[0]->lim.max_cycles)) {
-      c->last_error = "zkw_batches_expand_records: stride_records must cover the cycles run (and, when 0, the batches must share limits.max_cycles)";
+    uint64_t si = instance_stride, sk = cycle_stride;
+    rc = expand_strides(c, si, sk, batches[i]->lim.max_cycles, batches[i]->cycles_run, batches[i]->n);
+    if (rc != ZKW_OK) return rc;
+    if (instance_stride == 0 && cycle_stride == 0 && batches[i]->lim.max_cycles != batches[0]->lim.max_cycles) {
+      c->last_error = "zkw_batches_expand_records: default strides need batches that share limits.max_cycles";
       return ZKW_ERR_INVALID;
     }
     run = std::max(run, batches[i]->cycles_run);
   }
-  if (stride_records == 0) stride_records = batches[0]->lim.max_cycles;
+  {
+    uint64_t si = instance_stride, sk = cycle_stride;
+    expand_strides(c, si, sk, batches[0]->lim.max_cycles, 0, 0);
+    instance_stride = si; cycle_stride = sk;
+  }
   HIP_TRY(c, hipSetDevice(c->device));
   for (uint32_t at = 0; at < n_batches; at += 128) {  // (the by-value table of a launch holds 128 batches)
     const uint32_t n = std::min<uint32_t>(128, n_batches - at);
@@ -1594,7 +1610,7 @@ int zkw_batches_expand_records(zkw_batch* const* batches, uint32_t n_batches, vo
       dst[i] = dst_device[at + i];
       nw[i] = batches[at + i]->n_waves;
     }
-    HIP_TRY(c, zkw_launch_expand(kp, dst, nw, n, stride_records, 0, 0xffffffffu, batches[at]->L, batches[at]->kp.wave_threads, run, (uint32_t)c->n_cus, (hipStream_t)hip_stream));
+    HIP_TRY(c, zkw_launch_expand(kp, dst, nw, n, instance_stride, cycle_stride, 0, 0xffffffffu, batches[at]->L, batches[at]->kp.wave_threads, run, (uint32_t)c->n_cus, (hipStream_t)hip_stream));
   }
   return ZKW_OK;
 }

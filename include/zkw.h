@@ -147,7 +147,10 @@ typedef struct zkw_isa_consts {
                                          memory (testing/tests/precompiles/ecrecover.rs:3-49); 1 = (hash, v, r, s) */
   uint32_t bootloader_calldata_page;  /* zkevm_opcode_defs::BOOTLOADER_CALLDATA_PAGE (memory.rs:11,229-231): the page that
                                          SimpleMemory keeps in `pages_with_extended_lifetime` from the start.  Value recalled,
-                                         UNVERIFIED (the crate is not on disk) — hence a table constant, not code */
+                                         UNVERIFIED (the crate is not on disk) — hence a table constant, not code: a caller that
+                                         relies on zkw_batch_get_page for this page supplies the real value (the shim's
+                                         isa_from_opcode_defs does); a wrong value only moves which page number the words of
+                                         zkw_batch_set_bootloader_calldata are reported under, the VM cannot read the page */
   /* Conventions of the two absent crates that rounds 1-3 had compiled in (SURVEY App. B lists them as recalled): table
    * constants since round 4, so that a shim built against the real zkevm_opcode_defs supplies the real values. */
   uint32_t call_regs;                 /* far_call.rs:506-508,573-610, INDICES into VmLocalState.registers (r1 = 0): byte 0
@@ -243,7 +246,11 @@ typedef struct zkw_limits {
   uint32_t max_cycles;            /* cycles recorded per instance and per run                      */
   uint32_t max_far_frames;        /* far-call frames (incl. the bootloader frame) that are live or reachable at one time: a
                                      frame's arena slot is reused once it has returned and its heap / aux heap is no
-                                     returndata any more (the reference's page pools, memory.rs:660-758)              */
+                                     returndata any more (the reference's page pools, memory.rs:660-758).  It ALSO caps the
+                                     distinct code hashes an instance decommits per run (SimpleDecommitter's history,
+                                     decommitter.rs:38-47, is one row per fresh decommit, sized by this limit): the
+                                     max_far_frames + 1-th fresh decommit stops the instance with ZKW_STATUS_LIMIT, and
+                                     zkw_batch_get_page sees the code pages of the first max_far_frames only          */
   uint32_t max_callstack_depth;   /* near + far frames alive at once                                */
   uint32_t stack_words;           /* words per stack page   (reference: 65536, memory.rs:177-179)  */
   uint32_t heap_words;            /* words per heap page    (reference: grows on demand)            */
@@ -525,16 +532,19 @@ int zkw_batch_get_page(zkw_batch* batch, uint32_t instance, uint32_t page, uint3
  * lives there: what start_new_execution_cycle(&local_state) / end_execution_cycle(&local_state) hand the tracer
  * (witness_trace/mod.rs:11-20, cycle.rs:34,413), rebuilt from the delta form the cycle kernel stores (the same records
  * zkw_batch_get_instance_trace rebuilds on the host, bit for bit).  Record k of instance i goes to
- * dst_device + ((i - first) * stride_records + k) * 512; stride_records = 0 means limits.max_cycles, and must cover the cycles
- * run since the last reset; records beyond an instance's cycle count are left untouched.  Asynchronous on `hip_stream`,
- * ordered behind the run on the same stream (a different stream is the caller's to order).  A streaming kernel:
- * 512 bytes written per VM cycle. */
-int zkw_batch_expand_records(zkw_batch* batch, uint32_t first, uint32_t count, void* dst_device, uint64_t stride_records, void* hip_stream);
+ * dst_device + ((i - first) * instance_stride + k * cycle_stride) * 512, in one of two layouts: instance-major
+ * (cycle_stride = 1, instance_stride >= the cycles run since the last reset: the records of an instance are contiguous, as
+ * in zkw_instance_trace.records) or cycle-major (instance_stride = 1, cycle_stride >= count: the records of a cycle are
+ * contiguous — the faster one to write, a wave's 64 records of a cycle are one 32 KB run).  Both 0: instance-major with
+ * limits.max_cycles records per instance.  Records beyond an instance's cycle count are left untouched.  Asynchronous on
+ * `hip_stream`, ordered behind the run on the same stream (a different stream is the caller's to order).  A streaming
+ * kernel: 512 bytes written per VM cycle. */
+int zkw_batch_expand_records(zkw_batch* batch, uint32_t first, uint32_t count, void* dst_device, uint64_t instance_stride, uint64_t cycle_stride, void* hip_stream);
 /* The same for every instance of up to 256 batches of one context in fused launches (what a device-side consumer of a
  * zkw_batches_step calls): dst_device[b] receives batch b, laid out as above with first = 0.  One batch is 64 waves of a
  * sequential chain each, so a lone batch is expanded in chunks of cycles (every chunk replays the cycles in front of it
  * silently); a fused group has waves enough to run at the HBM write rate unchunked. */
-int zkw_batches_expand_records(zkw_batch* const* batches, uint32_t n_batches, void* const* dst_device, uint64_t stride_records, void* hip_stream);
+int zkw_batches_expand_records(zkw_batch* const* batches, uint32_t n_batches, void* const* dst_device, uint64_t instance_stride, uint64_t cycle_stride, void* hip_stream);
 
 /* --- queue commitments (the build's own sponge spec) --- */
 #define ZKW_QUEUE_MEMORY 0

@@ -338,8 +338,8 @@ extern "C" {
     pub fn zkw_batch_commit(batch: *mut zkw_batch, queue_mask: u32, stream: *mut c_void) -> c_int;
     pub fn zkw_batch_net_states(batch: *mut zkw_batch, stream: *mut c_void) -> c_int;
     pub fn zkw_batch_get_net_state(batch: *mut zkw_batch, instance: u32, out: *mut zkw_net_state) -> c_int;
-    pub fn zkw_batch_expand_records(batch: *mut zkw_batch, first: u32, count: u32, dst_device: *mut c_void, stride_records: u64, stream: *mut c_void) -> c_int;
-    pub fn zkw_batches_expand_records(batches: *const *mut zkw_batch, n: u32, dst_device: *const *mut c_void, stride_records: u64, stream: *mut c_void) -> c_int;
+    pub fn zkw_batch_expand_records(batch: *mut zkw_batch, first: u32, count: u32, dst_device: *mut c_void, instance_stride: u64, cycle_stride: u64, stream: *mut c_void) -> c_int;
+    pub fn zkw_batches_expand_records(batches: *const *mut zkw_batch, n: u32, dst_device: *const *mut c_void, instance_stride: u64, cycle_stride: u64, stream: *mut c_void) -> c_int;
     pub fn zkw_batch_sync(batch: *mut zkw_batch) -> c_int;
     pub fn zkw_batch_get_stats(batch: *mut zkw_batch, out: *mut zkw_run_stats) -> c_int;
     pub fn zkw_batch_get_instance_trace(batch: *mut zkw_batch, instance: u32, out: *mut zkw_instance_trace) -> c_int;

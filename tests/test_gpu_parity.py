@@ -791,6 +791,14 @@ def test_expand_records_on_the_device(product, isa, cfg, kw, lanes):
         n = t["n_cycles"]
         assert host[i - first, :n].tobytes() == t["records"].tobytes(), "instance %d" % i
         assert (host[i - first, n:] == 0xAB).all()
+    # cycle-major layout (the records of a cycle contiguous)
+    cm = torch.full((stride, count, 512), 0xEE, dtype=torch.uint8, device="cuda")
+    b.expand_records(first, count, cm.data_ptr(), 1, torch.cuda.current_stream().cuda_stream, cycle_stride=count)
+    torch.cuda.synchronize()
+    hcm = cm.cpu().numpy()
+    for i in list(range(first, first + count, 5)) + [first + count - 1]:
+        t = b.trace(i)
+        assert hcm[:t["n_cycles"], i - first].tobytes() == t["records"].tobytes(), "cycle-major: instance %d" % i
     # the fused entry: every instance of two batches (the second with its own lane width), unchunked or chunked as the launch decides
     b2 = _run(product, synth.make(cfg, isa, **kw), 0)
     outs = [torch.full((wl.n_instances, stride, 512), 0xCD, dtype=torch.uint8, device="cuda") for _ in range(2)]
