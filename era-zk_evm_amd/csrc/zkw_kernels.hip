@@ -121,6 +121,9 @@ enum {
 #else
 #define ZKW_ABL(flags, bit) false
 #endif
+// branch layout hints: the common case of the hot path falls through (a taken branch restarts the instruction fetch)
+#define ZKW_LIKELY(x) __builtin_expect(!!(x), 1)
+#define ZKW_UNLIKELY(x) __builtin_expect(!!(x), 0)
 #define FLAG_LT 1u
 #define FLAG_EQ 2u
 #define FLAG_GT 4u
@@ -503,7 +506,7 @@ ZD void shared_setup(Shared& sh, ZKW_KP P, u32 dbg, u32 wib, u32 wave, bool pin)
 
 ZD u32 next_seq(Lane& s) {
   const u32 q = s.counts & 255u;
-  if (q != 255u) s.counts++;
+  if (ZKW_LIKELY(q != 255u)) s.counts++;
   return q;
 }
 
@@ -512,8 +515,8 @@ ZD void emit_mem(ZKW_KP P, Shared& sh, Lane& s, u32 ts, u32 type, u32 page, u32 
   s.lane = zkw_lane_id();  // fresh, short-lived lane index (see struct Lane)
   const u32 pos = stream_alloc<0>(sh.cursor);
   const u32 seq = next_seq(s);
-  if ((s.counts & 0xff00u) != 0xff00u) s.counts += 0x100u;
-  if (pos >= sh.cap_mem) {
+  if (ZKW_LIKELY((s.counts & 0xff00u) != 0xff00u)) s.counts += 0x100u;
+  if (ZKW_UNLIKELY(pos >= sh.cap_mem)) {
     lane_fail(s, ZKW_STATUS_LIMIT);
     return;
   }
@@ -692,7 +695,7 @@ ZD u256 stack_read(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, u32& is_ptr) {
   is_ptr = 0;
   // a word that was never written reads as zero in the reference (the stack page is a zero-filled Vec); only WRITES
   // need capacity, and stack_hwm <= S
-  if (idx >= CF(sh, s, CF_STACK_HWM)) return u256_zero();
+  if (ZKW_UNLIKELY(idx >= CF(sh, s, CF_STACK_HWM))) return u256_zero();
   const u32 w = page_word_index(sh, s, cfv_slot(sh, s), sh.S, idx);
   // (the tag byte last: loads return in order, so a use of the tag scheduled early cannot split the three into two round trips)
   const uint4 lo = zkw_gload4(sh.stack_vals + (2 * w - s.lane)), hi = zkw_gload4(sh.stack_vals + (2 * w - s.lane + sh.L));
@@ -707,7 +710,7 @@ ZD u256 stack_read(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, u32& is_ptr) {
 // MemoryType::Stack write (memory.rs:413-425)
 ZD void stack_write(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, const u256& v, bool is_ptr) {
   s.lane = zkw_lane_id();  // fresh, short-lived lane index (see struct Lane)
-  if (idx >= sh.S) {
+  if (ZKW_UNLIKELY(idx >= sh.S)) {
     lane_fail(s, ZKW_STATUS_LIMIT);
     return;
   }
@@ -730,7 +733,7 @@ ZD void stack_write(ZKW_KP P, const Shared& sh, Lane& s, u32 idx, const u256& v,
 ZD u256 heap_read_at(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 slot, u32 hwm, u32 idx) {
   s.lane = zkw_lane_id();  // fresh, short-lived lane index (see struct Lane)
   const u32 words = is_aux ? sh.A : sh.H;
-  if (idx >= hwm) return u256_zero();  // the reference grows its Vec on a read (memory.rs:464,468): not observable; hwm <= words
+  if (ZKW_UNLIKELY(idx >= hwm)) return u256_zero();  // the reference grows its Vec on a read (memory.rs:464,468): not observable; hwm <= words
   const uint4* base = is_aux ? sh.aux_heap : sh.heap;
   const u32 w = page_word_index(sh, s, slot, words, idx);
   return u256_from_uint4(zkw_gload4(base + (2 * w - s.lane)), zkw_gload4(base + (2 * w - s.lane + sh.L)));
@@ -745,7 +748,7 @@ ZD u256 heap_read_cur(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 idx)
 ZD void heap_write_at(ZKW_KP P, const Shared& sh, Lane& s, bool is_aux, u32 slot, u32& hwm, u32 idx, const u256& v) {
   s.lane = zkw_lane_id();  // fresh, short-lived lane index (see struct Lane)
   const u32 words = is_aux ? sh.A : sh.H;
-  if (idx >= words) {
+  if (ZKW_UNLIKELY(idx >= words)) {
     lane_fail(s, ZKW_STATUS_LIMIT);
     return;
   }
@@ -865,9 +868,9 @@ ZD u256 code_fetch(const Shared& sh, const Lane& s, u32 idx) {
   const u32 c_len = CF(sh, s, CF_CODE_LEN), c_off = CF(sh, s, CF_CODE_OFF);
   const u32 u_len = (u32)__builtin_amdgcn_readfirstlane((int)c_len), u_off = (u32)__builtin_amdgcn_readfirstlane((int)c_off);
   const u32 u_idx = (u32)__builtin_amdgcn_readfirstlane((int)idx);
-  if (zkw_ballot((c_len != u_len) | (c_off != u_off) | (idx != u_idx)) == 0) {  // wave-uniform
+  if (ZKW_LIKELY(zkw_ballot((c_len != u_len) | (c_off != u_off) | (idx != u_idx)) == 0)) {  // wave-uniform
     u256 v = u256_zero();
-    if (u_idx < u_len) {
+    if (ZKW_LIKELY(u_idx < u_len)) {
       typedef u32 zkw_v8u __attribute__((ext_vector_type(8)));
       const zkw_v8u w = *(const ZKW_CONST_AS zkw_v8u*)((u64)sh.blob_words + (((u64)u_off + u_idx) << 5));
 #pragma unroll
@@ -1056,7 +1059,7 @@ ZD Operand compute_address(ZKW_KP P, const Shared& sh, Lane& s, u32& sp, const u
   o.page = 0;
   o.index = 0;
   // (`mode` is wave-uniform: a register / immediate operand costs neither the clip nor the LDS read of the base page)
-  if (mode != ZKW_MODE_STACK_PP && mode != ZKW_MODE_STACK_OFF && mode != ZKW_MODE_CODE && mode != ZKW_MODE_STACK_ABS) return o;
+  if (ZKW_LIKELY(mode != ZKW_MODE_STACK_PP && mode != ZKW_MODE_STACK_OFF && mode != ZKW_MODE_CODE && mode != ZKW_MODE_STACK_ABS)) return o;
   const u32 vaddr = (clip16(sh, reg_value) + imm) & 0xffffu;  // :34-35
   if (mode == ZKW_MODE_CODE) {  // :100-110
     o.type = ZKW_MEM_CODE;
@@ -1089,7 +1092,7 @@ ZD Operand compute_address(ZKW_KP P, const Shared& sh, Lane& s, u32& sp, const u
 template <class RF>
 ZD void dst0_update(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Operand& dst0, u32 dst0_idx, const u256& v, bool is_ptr) {
   s.lane = zkw_lane_id();  // fresh, short-lived lane index (see struct Lane)
-  if (dst0.has_loc) {
+  if (ZKW_UNLIKELY(dst0.has_loc)) {
     stack_write(P, sh, s, dst0.index, v, is_ptr);
     emit_mem(P, sh, s, s.timestamp + 3, ZKW_MEM_STACK, dst0.page, dst0.index, v, is_ptr, true, 0);
   } else {
@@ -1378,7 +1381,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
   // the frame fields this access needs, read from LDS together (one wait instead of one per use; the variant is
   // wave-uniform, so these selections are scalar branches)
   u32 f_base_page = 0, f_slot = 0, f_hwm = 0, f_bound = 0;
-  if (!is_ptr_read) {
+  if (ZKW_LIKELY(!is_ptr_read)) {
     f_base_page = CF(sh, s, CF_BASE_PAGE);
     f_slot = cfv_slot(sh, s);
     f_hwm = is_heap ? cfv_heap_hwm(sh, s) : CF(sh, s, CF_AUX_HWM);
@@ -1411,21 +1414,21 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
   } else {  // :121-135  src0 > MAX_OFFSET_TO_DEREF
     const bool beyond = (ps.src0.w[1] | ps.src0.w[2] | ps.src0.w[3] | ps.src0.w[4] | ps.src0.w[5] | ps.src0.w[6] | ps.src0.w[7]) != 0 ||
                         ps.src0.w[0] > sh.max_deref_low;
-    if (beyond) {
+    if (ZKW_UNLIKELY(beyond)) {
       exceptions |= 2u;  // DEREF_BEYOND_HEAP_RANGE
       skip_legit = true;
     }
     src_offset = fp.offset;
   }
   const u32 incremented = fp.offset + 32u;
-  if (incremented < fp.offset) {  // :139-147
+  if (ZKW_UNLIKELY(incremented < fp.offset)) {  // :139-147
     exceptions |= 4u;
     if (!is_ptr_read && !(exceptions & 2u)) lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
   }
   u32 growth = 0;  // :152-194
   if (!is_ptr_read) {
     const u32 bound = f_bound;
-    if (incremented >= bound) {
+    if (ZKW_UNLIKELY(incremented >= bound)) {
       growth = incremented - bound;
       if (is_heap) cfv_set_heap_bound(sh, s, incremented); else cfv_set_aux_bound(sh, s, incremented);
       s.kflags |= KF_TAIL2;
@@ -1433,7 +1436,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
   }
   u32 cost = growth * sh.growth_per_byte;  // :196-197
   if (exceptions & 2u) cost = 0xffffffffu;                   // :202-207
-  if (s.ergs < cost) {
+  if (ZKW_UNLIKELY(s.ergs < cost)) {
     s.ergs = 0;
     exceptions |= 8u;  // NOT_ENOUGH_ERGS_TO_GROW_MEMORY
   } else {
@@ -1450,7 +1453,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   ZKW_SUB(70)  // drain of the stores issued before this point
 #endif
-  if (!skip) {  // :265-288
+  if (ZKW_LIKELY(!skip)) {  // :265-288
     // both word loads are issued before the first query is emitted: the emission needs the loaded value, so reading
     // and emitting word by word would serialise two memory round trips (the dominant cost of this opcode)
     w0v = is_ptr_read ? fat_ptr_read(P, sh, s, fp.page, word0) : heap_read_at(P, sh, s, !is_heap, f_slot, f_hwm, word0);
@@ -1475,7 +1478,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
       result = u256_select_bits(u256_low_mask(beyond * 8), u256_zero(), result);  // the low `beyond` bytes read as zero
     }
     ZKW_SUB(43)  // read: shifts
-    if (!set_panic) {
+    if (ZKW_LIKELY(!set_panic)) {
       dst0_update(P, sh, rf, s, ps.dst0, d.dst0, result, false);
       if (increment) {
         u256 upd = ps.src0;
@@ -1493,7 +1496,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
     u256 n1 = u256_shr(u256_shl(w1v, unal * 8), unal * 8);
     n1 = u256_or(n1, u256_shl(ps.src1, (32 - unal) * 8));
     ZKW_SUB(45)  // write: shifts
-    if (!skip) {
+    if (ZKW_LIKELY(!skip)) {
       heap_write_at(P, sh, s, !is_heap, f_slot, f_hwm, word0, n0);
       emit_mem(P, sh, s, ts_w, mem_type, fp.page, word0, n0, false, true, 0);
       if (unaligned) {
@@ -1501,11 +1504,11 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
         emit_mem(P, sh, s, ts_w, mem_type, fp.page, word1, n1, false, true, 0);
       }
     }
-    if (f_hwm != f_hwm_in) {
+    if (ZKW_UNLIKELY(f_hwm != f_hwm_in)) {
       if (is_heap) cfv_set_heap_hwm(sh, s, f_hwm); else CF(sh, s, CF_AUX_HWM) = f_hwm;
     }
     ZKW_SUB(46)  // write: heap writes + write queries
-    if (!set_panic) {
+    if (ZKW_LIKELY(!set_panic)) {
       if (increment) {
         u256 upd = ps.src0;
         upd.w[0] = incremented;
@@ -2381,7 +2384,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
   zkw_v16 oa, ob;
 #pragma unroll
   for (int i = 0; i < 16; i++) oa[i] = ob[i] = 0;
-  if (!IS_VEC && vec) {  // wave-uniform
+  if (ZKW_UNLIKELY(!IS_VEC && vec)) {  // wave-uniform
     oa = lane_pack(s);
     oa[12] = vec_lo; oa[13] = vec_hi; oa[14] = d.attr; oa[15] = 1u;
     call_out = true;
@@ -2400,7 +2403,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
   u256 src0_mem = u256_zero();
   u32 src0_mem_ptr = 0;
   ZKW_SUB(68)  // operands: addresses
-  if (src0_loc.has_loc) {  // :304-325
+  if (ZKW_UNLIKELY(src0_loc.has_loc)) {  // :304-325
     if (src0_loc.type == ZKW_MEM_CODE) src0_mem = code_read(sh, s, src0_loc.index);
     else src0_mem = stack_read(P, sh, s, src0_loc.index, src0_mem_ptr);
     emit_mem(P, sh, s, s.timestamp, src0_loc.type, src0_loc.page, src0_loc.index, src0_mem, src0_mem_ptr, false, 0);
@@ -2432,7 +2435,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
     ps.src1_ptr = sw ? ap : bp;
   }
   ps.new_pc = (s.pc + 1) & 0xffffu;  // :347-350 (never a skip cycle here)
-  if (!(s.kflags & KF_KERNEL)) {     // erase_fat_pointer_metadata :374-396
+  if (ZKW_UNLIKELY(!(s.kflags & KF_KERNEL))) {     // erase_fat_pointer_metadata :374-396
     if (!(props & ZKW_PROP_SRC0_PTR_OK) && ps.src0_ptr) {
       ps.src0.w[1] = 0;
       ps.src0.w[2] = 0;
@@ -2448,7 +2451,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
   // apply (opcodes/parsing.rs:47-79)
   // ----------------------------------------------------------------------------------------
   ZKW_SUB(40)  // operands
-  if (lane_ok(s)) {
+  if (ZKW_LIKELY(lane_ok(s))) {
     switch (opcode) {
       case ZKW_OP_NOP: s.pc = ps.new_pc; break;  // noop.rs:16-19
       case ZKW_OP_ADD:
@@ -2548,7 +2551,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
   }  // !vec
 #if defined(__HIP_DEVICE_COMPILE__) || defined(ZKW_EMU_BUILD)
   if constexpr (!IS_VEC) {
-  if (call_out) {
+  if (ZKW_UNLIKELY(call_out)) {
     const zkw_v16 r = zkw_heavy_entry(oa, ob);
 #ifdef __HIP_DEVICE_COMPILE__
     {
@@ -3044,8 +3047,8 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
       // ----------------------------------------------------------------------------------------
       const bool pending = (s.flags & FLAG_PENDING) != 0;
       const u32 super_pc = s.pc >> 2, sub_pc = s.pc & 3u;
-      if (!pending) {
-        if ((s.kflags & KF_CODE_PAGE_CHANGED) || s.prev_super_pc != super_pc) {  // :59-95
+      if (ZKW_LIKELY(!pending)) {
+        if (ZKW_UNLIKELY((s.kflags & KF_CODE_PAGE_CHANGED) || s.prev_super_pc != super_pc)) {  // :59-95
           const u256 word = code_fetch(sh, s, super_pc);
           emit_mem(P, sh, s, s.timestamp, ZKW_MEM_CODE, CF(sh, s, CF_CODE_PAGE), super_pc, word, false, false, 0);
           // pre-decode the four opcodes of the word (four independent table reads) next to their encodings: a cycle
@@ -3070,7 +3073,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
         s.prev_super_pc = super_pc;
       }
       s.kflags &= ~(KF_CODE_PAGE_CHANGED | KF_CHARGED | KF_MASKED);  // previous_code_memory_page := code_page (:49)
-      if (pending) {  // the instruction is exception_revert_encoding() instead of the slot of the code word (:104-115)
+      if (ZKW_UNLIKELY(pending)) {  // the instruction is exception_revert_encoding() instead of the slot of the code word (:104-115)
         const u64 rv = P.consts.exception_revert_encoding;
         const uint2 e0 = sh.isa[(u32)rv & (ZKW_ISA_TABLE_SIZE - 1)];
         ZKW_SLOT_WRITE(sh, s.lane, 4, make_uint4((u32)rv, (u32)(rv >> 32), e0.x, e0.y));
@@ -3119,11 +3122,11 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
         // runs with per-lane operand decode (zkw_vec_exec).  Not for the heavy opcodes, whose out-of-line bodies take the
         // instruction word as a scalar.  A shared tape never gets here (its first group is all of `todo`).
         bool vec = false;
-        if (A.debug_flags & 4u) {
+        if (ZKW_UNLIKELY(A.debug_flags & 4u)) {
           grp = 1ull << leader;  // test hook: one lane per group
         }
 #ifdef __HIP_DEVICE_COMPILE__
-        else if (grp != todo || (A.debug_flags & (1u << 24))) {  // (bit 24: every group the variant way — test hook)
+        else if (ZKW_UNLIKELY(grp != todo || (A.debug_flags & (1u << 24)))) {  // (bit 24: every group the variant way — test hook)
           const u32 u_op = ZKW_ATTR_OPCODE(u_attr);
           if (u_op != ZKW_OP_LOG && u_op != ZKW_OP_NEAR_CALL && u_op != ZKW_OP_FAR_CALL && u_op != ZKW_OP_RET &&
               !((A.debug_flags >> (8u + u_op)) & 1u)) {  // (debug_flags bits 8..23: opcodes kept out of variant groups — test hook)
@@ -3135,7 +3138,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
           }
         }
 #endif
-        if (!u_charged) {  // uniform: first visit of this opcode word
+        if (ZKW_LIKELY(!u_charged)) {  // uniform: first visit of this opcode word
           bool masked_now = false;
           if (zkw_lane_bit(grp)) {
             const bool err = decode_exception(max_depth, s, u_attr, u_price);  // :142-184
@@ -3143,7 +3146,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
             const bool nop = !err && !condition_resolved(cond_lut, (me.x >> 13) & 7u, s.flags);  // (the lane's own condition: a variant group mixes them)
             s.kflags |= KF_CHARGED;
             masked_now = err | nop;
-            if (masked_now) {
+            if (ZKW_UNLIKELY(masked_now)) {
               // mask_into_panic (:187-190) / mask_into_nop (:212-217): the lane re-enters the loop as a member of
               // the group of the panic / nop encoding (all operand fields zero, condition Always)
               // (both encodings as scalar loads, then a per-lane select: `err ? a : b` on the parameter block itself became a
@@ -3191,7 +3194,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
 #else
         s.timestamp += time_delta;
 #endif
-        if (s.kflags & KF_COLD_DIRTY) {
+        if (ZKW_UNLIKELY(s.kflags & KF_COLD_DIRTY)) {
           uint4* a = aux_alloc(P, sh, s, ZKW_AUX_COLD_STATE, 0, CF(sh, s, CF_SPENT_PUBDATA), CF(sh, s, CF_ERGS_PP), CF(sh, s, CF_TX_NUMBER));
           if (a) {
             a[1] = make_uint4(CF(sh, s, CF_CTX0 + 0), CF(sh, s, CF_CTX0 + 1), CF(sh, s, CF_CTX0 + 2), CF(sh, s, CF_CTX0 + 3));
@@ -3219,7 +3222,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
         // union of the lanes' dirty masks and the number of deltas of this wave-cycle; a shared tape makes all masks equal
         const u32 dm0 = (u32)__builtin_amdgcn_readfirstlane((int)dm);
         u32 any, total;
-        if (zkw_ballot(dm != dm0) == 0) {
+        if (ZKW_LIKELY(zkw_ballot(dm != dm0) == 0)) {
           any = dm0;
           total = (u32)__popcll((u64)dm0) * (u32)__popcll(zkw_ballot(true));
         } else {
@@ -3234,8 +3237,8 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
         }
         const u32 base = delta_cur;
         const bool fits = base + total <= cap_delta;  // wave-uniform: either every lane's deltas fit or none are written
-        if (ok && !fits) lane_fail(s, ZKW_STATUS_LIMIT);
-        if (fits) {
+        if (ZKW_UNLIKELY(ok && !fits)) lane_fail(s, ZKW_STATUS_LIMIT);
+        if (ZKW_LIKELY(fits)) {
           uint4* dl = delta_base;
           u32 pos = base;
           for (u32 left = any; left; left &= left - 1u) {  // scalar loop over the registers written in this wave-cycle
@@ -3258,7 +3261,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
             pos += (u32)__popcll(part);
           }
         }
-        if (ok && fits) {
+        if (ZKW_LIKELY(ok && fits)) {
           const u32 cnt = s.counts >> 8;  // memory queries | log queries << 8 | aux events << 16 (saturating bytes)
           // dirty mask: bits 0-7 in the tail's reserved byte, bits 8-14 in the top byte of the event counts
           uint4* const tail_ptr = tails_wave + (u64)k * tail_step + s.lane;
@@ -3295,7 +3298,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
       k++;
       dir_ptr += 4;
       // leave: failed / out of cycles / execution_has_ended() (mod.rs:96-98: callers stop cycling at depth 0)
-      if (!lane_ok(s) || k >= run_cycles || s.depth == 0) {
+      if (ZKW_UNLIKELY(!lane_ok(s) || k >= run_cycles || s.depth == 0)) {
         if (!lane_ok(s)) dq_undo(P, sh, s);  // the failed cycle leaves no records: a decommit it chained inline goes too
         lane_writeback(P, sh, rf, s, lane_ok(s) ? k : k - 1u);  // a lane that failed did not complete its last cycle
         break;

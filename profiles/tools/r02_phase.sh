@@ -8,6 +8,6 @@ import sys, os; sys.path.insert(0,'.')
 import era_zk_evm_amd
 from era_zk_evm_amd import build as b
 b.build_lib(force=True, extra_flags=['-DZKW_PROFILE'] + os.environ.get('ZKW_PROFILE_EXTRA', '').split())"
-for F in 20; do echo "fuse $F" >> $T/phase.txt; timeout 300 python bench.py --no-cpu-baseline --steps $((F*2)) --warmup $F --fuse $F --streams 1 2>&1 | grep ZKWPROF | tail -40 >> $T/phase.txt; done
+for F in 20; do echo "fuse $F" >> $T/phase.txt; ZKW_BENCH_NO_OTHER_CONFIGS=1 timeout 300 python bench.py --no-cpu-baseline --repeats 0 --steps $((F*2)) --warmup $F --fuse $F --streams 1 2>&1 | grep ZKWPROF | tail -40 >> $T/phase.txt; done
 cp /tmp/libzkw_keep.so era-zk_evm_amd/libzkw.so
 cat $T/phase.txt
