@@ -1389,14 +1389,18 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
     ZKW_LGKM_PROBE(7 /* UMA frame fields */)
   }
   const u32 f_hwm_in = f_hwm;
-#ifdef __HIP_DEVICE_COMPILE__
-  // the accesses the code-word prefetch did not see — a register-held address, the first opcode of a code word, the aux
-  // heap — are requested here, ~1500 clocks (exceptions, growth, query bookkeeping) before their loads are issued for
-  // real (same-box A/B: +1.5 % on top of the code-word prefetch; requesting the covered ones here again changes nothing)
-  if (!is_ptr_read && !ZKW_ABL(sh.debug_flags, ZKW_NO_PREFETCH) && (!is_heap || ZKW_ATTR_SRC0(d.attr) != ZKW_MODE_IMM || ((ps.new_pc - 1u) & 3u) == 0) &&
-      !(ps.src0.w[1] | ps.src0.w[2] | ps.src0.w[3] | ps.src0.w[4] | ps.src0.w[5] | ps.src0.w[6] | ps.src0.w[7]))
-    prefetch_page_words(is_heap ? sh.heap : sh.aux_heap, is_heap ? P.H : P.A, P.L, zkw_lds_sink_addr(), f_slot, f_hwm, ps.src0.w[0]);
-#endif
+  // The word loads of a heap / aux-heap access are ISSUED here, in front of the exception / growth / cost arithmetic (~900
+  // clocks that need nothing from memory), and waited for behind it: the address needs only the offset and the frame fields
+  // above.  Speculative for the lanes that turn out to skip the access (an exception): those either hold an offset beyond
+  // 2^32 (no load: the guard below) or read a word of their own page that nobody looks at.
+  u256 e0 = u256_zero(), e1 = u256_zero();
+  if (ZKW_LIKELY(!is_ptr_read)) {
+    if (ZKW_LIKELY(!(ps.src0.w[1] | ps.src0.w[2] | ps.src0.w[3] | ps.src0.w[4] | ps.src0.w[5] | ps.src0.w[6] | ps.src0.w[7]))) {
+      const u32 ew = ps.src0.w[0] >> 5;
+      e0 = heap_read_at(P, sh, s, !is_heap, f_slot, f_hwm, ew);
+      if (ps.src0.w[0] & 31u) e1 = heap_read_at(P, sh, s, !is_heap, f_slot, f_hwm, ew + 1u);
+    }
+  }
   u32 mem_type;
   if (is_ptr_read) {
     mem_type = ZKW_MEM_FAT_PTR;
@@ -1456,8 +1460,13 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
   if (ZKW_LIKELY(!skip)) {  // :265-288
     // both word loads are issued before the first query is emitted: the emission needs the loaded value, so reading
     // and emitting word by word would serialise two memory round trips (the dominant cost of this opcode)
-    w0v = is_ptr_read ? fat_ptr_read(P, sh, s, fp.page, word0) : heap_read_at(P, sh, s, !is_heap, f_slot, f_hwm, word0);
-    if (unaligned) w1v = is_ptr_read ? fat_ptr_read(P, sh, s, fp.page, word1) : heap_read_at(P, sh, s, !is_heap, f_slot, f_hwm, word1);
+    if (is_ptr_read) {
+      w0v = fat_ptr_read(P, sh, s, fp.page, word0);
+      if (unaligned) w1v = fat_ptr_read(P, sh, s, fp.page, word1);
+    } else {  // requested above (an access that is not skipped has an offset below 2^32: these are its words)
+      w0v = e0;
+      w1v = e1;
+    }
     ZKW_SETTLE(2 /* UMA words */);
     ZKW_SUB(64)  // loads issued
 #ifdef ZKW_PROFILE
@@ -3061,10 +3070,10 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
           for (int i = 0; i < 4; i++) ZKW_SLOT_WRITE(sh, s.lane, i, make_uint4(word.w[2 * i], word.w[2 * i + 1], e4[i].x, e4[i].y));
           s.prev_super_pc = super_pc;
 #ifdef __HIP_DEVICE_COMPILE__
-          if (!ZKW_ABL(A.debug_flags, ZKW_NO_PREFETCH)) {  // the opcodes behind this one (opcode k of the word = slot 3 - k): prefetch_uma_words
+          if (!ZKW_ABL(A.debug_flags, ZKW_NO_PREFETCH)) {  // this opcode and the ones behind it (opcode k of the word = slot 3 - k): prefetch_uma_words
 #pragma unroll
-            for (int i = 0; i < 3; i++)
-              if (3u - (u32)i > sub_pc) prefetch_uma_words(P, sh, s, lds_sink, e4[i].x, word.w[2 * i + 1]);
+            for (int i = 0; i < 4; i++)
+              if (3u - (u32)i >= sub_pc) prefetch_uma_words(P, sh, s, lds_sink, e4[i].x, word.w[2 * i + 1]);
           }
 #endif
         }
