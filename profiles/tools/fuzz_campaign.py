@@ -11,9 +11,11 @@ from era_zk_evm_amd import capi as K, synth  # noqa: E402
 from tests._oracle import load_oracle  # noqa: E402
 
 first, count = int(sys.argv[1], 0), int(sys.argv[2])
-isa = K.Isa()
-prod = K.load_product().open(isa)
-orc = load_oracle().open(isa)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+import _metamorphic as M  # noqa: E402
+# round 4: every fourth seed under a renumbered, every fourth under an estranged ISA table (tests/_metamorphic.py)
+TABLES = [("default", K.Isa()), ("renumbered", M.renumbered(0x7AB1E)), ("estranged", M.estranged(0xE57A))]
+CTX = {name: (isa_, K.load_product().open(isa_), load_oracle().open(isa_)) for name, isa_ in TABLES}
 bad = 0
 t0 = time.time()
 for k in range(count):
@@ -21,6 +23,8 @@ for k in range(count):
     lanes = (64, 64, 16, 0, 8, 1)[k % 6]
     n_ops = (96, 160, 64, 128)[k % 4]
     forced = (k % 3) == 2
+    table = ("default", "renumbered", "default", "estranged")[k % 4]
+    isa, prod, orc = CTX[table]
     prod.set_option(K.OPT_DEBUG_FLAGS, (1 << 24) if forced else 0)
     wl = synth.fuzz_workload(isa, n_instances=512, n_ops=n_ops, seed=seed)
     bo = orc.create_batch(wl); bo.reset(); bo.run(wl.n_cycles); bo.sync()
@@ -46,7 +50,7 @@ for k in range(count):
         if not np.array_equal(co[keep], cp[keep]):
             bad += 1
             msg = "COMMITMENT MISMATCH"
-    print("seed %#x lanes %2d ops %3d forced %d: compared %d limited %d cycles %d %s" % (seed, lanes, n_ops, forced, compared, limited, executed, msg), flush=True)
+    print("seed %#x table %-10s lanes %2d ops %3d forced %d: compared %d limited %d cycles %d %s" % (seed, table, lanes, n_ops, forced, compared, limited, executed, msg), flush=True)
     bo.destroy(); bp.destroy()
 print("done: %d seeds, %d bad, %.0f s" % (count, bad, time.time() - t0))
 sys.exit(1 if bad else 0)

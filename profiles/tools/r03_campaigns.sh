@@ -1,4 +1,4 @@
-# differential campaigns on the final round-3 kernel: fuzz tapes (traces + commitments), precompile workloads, far-call plans with slot reuse + page read-back
+# differential campaigns on the final kernel of a round (r03, r06): fuzz tapes (traces + commitments), precompile workloads, far-call plans with slot reuse + page read-back
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 T=gpurun_out/$1; mkdir -p $T
 python profiles/tools/fuzz_campaign.py 0x4000 ${2:-60} > $T/fuzz_campaign.txt 2>&1; tail -2 $T/fuzz_campaign.txt
