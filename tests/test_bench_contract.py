@@ -134,3 +134,29 @@ def test_roofline_accounting_is_frozen():
     j, _ = latest_bench_line()
     if j["config"].get("instances_per_gpu") == 4096 and j["config"].get("cycles_per_instance") == 256 and "algorithmic_bytes_r3" in j["roofline"]:
         assert j["roofline"]["bytes_per_cycle"] == 149.125
+
+
+def test_driver_line_carries_the_round4_fields():
+    """the driver's command as the driver runs it (profiles/rNN_driver_full_line.json): five timed regions, every single-GPU
+    BASELINE configuration in `other_configs` with its roofline fraction and CPU baseline, the restore outside the one-launch
+    timed region, the device-side record expansion"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_driver_full_line.json")))
+    if not files:
+        import pytest
+        pytest.skip("no full driver line collected yet")
+    j = json.load(open(files[-1]))
+    assert j["steps"] == 20 and j["warmup"] == 5 and j["n_gpus"] == 1
+    assert j["timed_regions"] == 5 and j["value_min"] <= j["value_median"] <= j["value_max"]
+    assert j["value_min"] <= j["value"] <= j["value_max"]
+    assert j["config"]["restore"] == "between-uses" and j["config"]["restores_in_timed_region"] == 0 and j["config"]["cycle_kernel_launches"] == 1
+    assert j["ms_per_step"] - j["kernel_ms"] / 20 <= 0.003  # the step is the kernel + the launch gap
+    assert j["roofline"]["bytes_per_cycle"] == 149.125 and j["roofline"]["algorithmic_bytes_r3"] == 149.125
+    assert j["roofline"]["expand_GBps"] and j["roofline"]["expand"]["fused_batches"] == 20
+    oc = j["other_configs"]
+    assert len(oc) == 4 and not any("error" in e for e in oc), oc
+    for e, key in zip(oc, ("configs[1] literal", "configs[1] at 4096", "configs[3]", "configs[4]")):
+        assert e["workload"].startswith(key)
+        assert e["value"] > 0 and e["kernel_ms"] > 0 and 0 < e["roofline"]["frac"] < 1
+        assert e["cpu_baseline"]["single_socket_value"] > 0 and e["checked"]["instances_failed"] == 0
+    assert oc[2]["unit"] == "message bytes/s" and oc[2]["roofline"]["lone_batch_kernel_ms"]["two_lanes_per_wave"] > 0
+    assert oc[3]["commit_mask"] == 7
