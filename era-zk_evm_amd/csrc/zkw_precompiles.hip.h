@@ -75,6 +75,53 @@ ZD void zk_keccak_f1600(u64 a[25]) {
   }
 }
 
+// Keccak-f[1600] on a state whose lanes 1, 2, 8, 12, 17, 20 are held complemented (the "lane complementing transform" of the
+// Keccak implementation overview, 2.2): chi needs one NOT per plane instead of five, and and / or + xor (two-operand
+// encodings) take the place of the three-operand v_bfi the plain form compiles to — those issue at half the rate when two
+// waves share a SIMD (profiles/tools/kk: 5.9 -> 6.3 G permutations/s with the chip full).  Absorbing is an XOR and does not
+// care; the state starts with those lanes all-ones and the digest un-complements lanes 1 and 2 (precompile_keccak256).
+ZD void zk_keccak_f1600_lc(u64 a[25]) {
+  for (int round = 0; round < 24; round++) {
+    u64 c[5];
+#pragma unroll
+    for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+#pragma unroll
+    for (int x = 0; x < 5; x++) {
+      const u64 dd = c[(x + 4) % 5] ^ zk_rotl64(c[(x + 1) % 5], 1);
+#pragma unroll
+      for (int y = 0; y < 25; y += 5) a[y + x] ^= dd;
+    }
+    u64 t = a[1], b;
+#define ZK_RP(j, r) b = a[j]; a[j] = zk_rotl64(t, r); t = b;
+    ZK_RP(10, 1) ZK_RP(7, 3) ZK_RP(11, 6) ZK_RP(17, 10) ZK_RP(18, 15) ZK_RP(3, 21) ZK_RP(5, 28) ZK_RP(16, 36) ZK_RP(8, 45) ZK_RP(21, 55) ZK_RP(24, 2)
+    ZK_RP(4, 14) ZK_RP(15, 27) ZK_RP(23, 41) ZK_RP(19, 56) ZK_RP(13, 8) ZK_RP(12, 25) ZK_RP(2, 43) ZK_RP(20, 62) ZK_RP(14, 18) ZK_RP(22, 39)
+    ZK_RP(9, 61) ZK_RP(6, 20) ZK_RP(1, 44)
+#undef ZK_RP
+    {
+      const u64 B0 = a[0], B1 = a[1], B2 = a[2], B3 = a[3], B4 = a[4];
+      a[0] = B0 ^ (B1 | B2); a[1] = B1 ^ (~B2 | B3); a[2] = B2 ^ (B3 & B4); a[3] = B3 ^ (B4 | B0); a[4] = B4 ^ (B0 & B1);
+    }
+    {
+      const u64 B0 = a[5], B1 = a[6], B2 = a[7], B3 = a[8], B4 = a[9];
+      a[5] = B0 ^ (B1 | B2); a[6] = B1 ^ (B2 & B3); a[7] = B2 ^ (B3 | ~B4); a[8] = B3 ^ (B4 | B0); a[9] = B4 ^ (B0 & B1);
+    }
+    {
+      const u64 B0 = a[10], B1 = a[11], B2 = a[12], B3 = a[13], B4 = a[14], n3 = ~B3;
+      a[10] = B0 ^ (B1 | B2); a[11] = B1 ^ (B2 & B3); a[12] = B2 ^ (n3 & B4); a[13] = n3 ^ (B4 | B0); a[14] = B4 ^ (B0 & B1);
+    }
+    {
+      const u64 B0 = a[15], B1 = a[16], B2 = a[17], B3 = a[18], B4 = a[19], n3 = ~B3;
+      a[15] = B0 ^ (B1 & B2); a[16] = B1 ^ (B2 | B3); a[17] = B2 ^ (n3 | B4); a[18] = n3 ^ (B4 & B0); a[19] = B4 ^ (B0 | B1);
+    }
+    {
+      const u64 B0 = a[20], B1 = a[21], B2 = a[22], B3 = a[23], B4 = a[24], n1 = ~B1;
+      a[20] = B0 ^ (n1 & B2); a[21] = n1 ^ (B2 | B3); a[22] = B2 ^ (B3 & B4); a[23] = B3 ^ (B4 | B0); a[24] = B4 ^ (B0 & B1);
+    }
+    a[0] ^= ZKW_KECCAK_RC[round];
+  }
+}
+ZD void zk_keccak_lc_flip(u64 st[25]) { st[1] = ~st[1]; st[2] = ~st[2]; st[8] = ~st[8]; st[12] = ~st[12]; st[17] = ~st[17]; st[20] = ~st[20]; }
+
 #define ZKW_KECCAK_RATE 136
 
 ZD void keccak_absorb_block(Shared& sh, u32 lane, u64 st[25]) {
@@ -83,7 +130,7 @@ ZD void keccak_absorb_block(Shared& sh, u32 lane, u64 st[25]) {
     const u64 w = (u64)sh.krow[(2 * i) * sh.L + lane] | ((u64)sh.krow[(2 * i + 1) * sh.L + lane] << 32);
     st[i] ^= w;
   }
-  zk_keccak_f1600(st);
+  zk_keccak_f1600_lc(st);
 }
 
 // big-endian dword k (0 = most significant) of a memory word, k dynamic: select chain instead of register indexing
@@ -154,6 +201,7 @@ ZD void precompile_keccak256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   u64 st[25];
 #pragma unroll
   for (int i = 0; i < 25; i++) st[i] = 0;
+  zk_keccak_lc_flip(st);  // the state is kept in the lane-complemented form (zk_keccak_f1600_lc)
   const u32 sh8 = (in_off & 3u) * 8u;
   u256 w_cur = u256_zero(), w_next = u256_zero();
   u32 cur_idx = 0xffffffffu, next_idx = 0xffffffffu;  // word indices held in w_cur / w_next
@@ -173,6 +221,9 @@ ZD void precompile_keccak256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
       const u32 w0 = in_off >> 5;  // per lane
       const FatPage fpage = fat_ptr_resolve(P, sh, s, page_r);  // the page is resolved once: the call writes nothing before its reads are done
       u32 have = 0;                // words w0 .. w0 + have - 1 have been read (and witnessed), wave-uniform
+#ifdef __HIP_DEVICE_COMPILE__
+      const bool pf_ok = __ballot(lane_ok(s) && (!fpage.found || fpage.empty || fpage.is_aux)) == 0;  // (the requests ahead below: heap pages only, wave-uniform arena)
+#endif
       for (u32 b = 0; b < n_full; b++) {
         const u32 p0 = (u_phase >> 2) + 34u * b;                    // first stream dword of the block, in dwords from word w0
         const u32 r0 = p0 >> 3, r1 = (p0 + 33u + (u_sh8 ? 1u : 0u)) >> 3;  // words the block reaches into
@@ -198,7 +249,18 @@ ZD void precompile_keccak256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
         ZKW_KECCAK_WORD(0) ZKW_KECCAK_WORD(1) ZKW_KECCAK_WORD(2) ZKW_KECCAK_WORD(3) ZKW_KECCAK_WORD(4) ZKW_KECCAK_WORD(5)
 #undef ZKW_KECCAK_WORD
         xfer_store(sh, s, wv);
-        zk_keccak_f1600(st);
+#ifdef __HIP_DEVICE_COMPILE__
+        // the words of the NEXT block are requested before this block's permutation (two loads per word into the LDS sink:
+        // no destination register, nothing to wait for — prefetch_page_words): a message word is read once and comes from
+        // HBM, five dependent round trips per block otherwise, with two waves per SIMD to hide them behind
+        if (pf_ok) {
+          const u32 last = (u_phase + u_len - 1u) >> 5;  // last word of the message, from w0
+#pragma unroll
+          for (u32 j = 0; j < 5; j++)
+            if (have + j <= last) prefetch_page_words(sh.heap, P.H, P.L, zkw_lds_sink_addr(), fpage.slot, fpage.hwm, (w0 + have + j) << 5);
+        }
+#endif
+        zk_keccak_f1600_lc(st);
       }
       d_start = 34u * n_full;
       if (have) {  // the general loop continues behind the last word read
@@ -257,6 +319,7 @@ ZD void precompile_keccak256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   for (u32 p = slot; p < ZKW_KROW_WORDS; p++) sh.krow[p * sh.L + s.lane] = 0;
   sh.krow[(ZKW_KROW_WORDS - 1) * sh.L + s.lane] |= 0x80000000u;
   keccak_absorb_block(sh, s.lane, st);
+  zk_keccak_lc_flip(st);
   u256 digest;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
