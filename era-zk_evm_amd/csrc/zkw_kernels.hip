@@ -526,7 +526,9 @@ ZD void emit_mem(ZKW_KP P, Shared& sh, Lane& s, u32 ts, u32 type, u32 page, u32 
   // wave then covers whole 64-byte lines.  As 48-byte records (three partial-line stores per record) the stream cost
   // 1.7x its own bytes in HBM writes (profiles/r02_traffic.json) — and the kernel is bound by its stores.
   uint4* dst = sh.mem_base + pos;
-  zkw_stream_store(dst, make_uint4(ts, page, index, s.lane | (seq << 8) | (meta << 16)));
+  // (ablation builds only — pricing what the stream could leave out: 256 = no value planes for code-word queries, 512 = no header plane)
+  if (!ZKW_ABL(sh.debug_flags, 512u)) zkw_stream_store(dst, make_uint4(ts, page, index, s.lane | (seq << 8) | (meta << 16)));
+  if (ZKW_ABL(sh.debug_flags, 256u) && type == ZKW_MEM_CODE) return;
   zkw_stream_store(dst + sh.cap_mem, u256_lo4(value));
   zkw_stream_store(dst + 2u * (u64)sh.cap_mem, u256_hi4(value));
 }
