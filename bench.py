@@ -416,10 +416,15 @@ def measure(dev, prod, isa, args, rank, world, comm, collective, transport, with
     # reader who wants the step priced that way: reported beside `value`, never as it
     with_restore = None
     if repeats > 0 and not flow.every_step:
+        flow.prepare()  # every group restored and idle: with the restore on a side stream the every-step arrangement restores BEHIND a use, and the regions above left their last uses unrestored
         flow.every_step = True
         flow.timed(args.steps)
         el_r, _, _, kms_r, _ = flow.timed(args.steps)
         flow.every_step = False
+        flow.sync_streams()
+        for g in range(flow.n_groups):  # whatever that arrangement left behind: the next `prepare` restores every group
+            flow.pristine[g] = False
+            flow.waits_ready[g] = False
         with_restore = (el_r, sum(kms_r) / max(1, len(kms_r)))
     k_ms_alone = flow.lone_kernel_ms()
     tot_cycles, tot_failed = flow.verify()

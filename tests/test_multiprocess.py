@@ -171,3 +171,14 @@ def test_bench_flow_world8(tmp_path, oracle, isa):
     argv = ["--steps", "4", "--warmup", "2", "--fuse", "2", "--streams", "2", "--instances", "3", "--commit-mask", "5", "--no-cpu-baseline", "--min-warmup-s", "0"]
     j = _bench_flow(tmp_path, oracle, isa, 8, argv, 3, 2, 2)
     assert j["config"]["cycle_kernel_launches"] == 2 and j["config"]["restores_in_timed_region"] == 0
+
+
+def test_bench_flow_restore_every_step_region(tmp_path, oracle, isa):
+    """the further regions of the line (--repeats: value_min / median / max, then the same K steps with the restore in front of
+    every use) with two groups in flight and the restore on the side streams: the every-step region must start from restored
+    groups although the regions before it leave their last uses unrestored (the default command `python bench.py` stopped on
+    limits.max_cycles there; no CPU test ran a further region)"""
+    argv = ["--steps", "8", "--warmup", "2", "--fuse", "2", "--streams", "2", "--instances", "3", "--commit-mask", "5", "--no-cpu-baseline", "--min-warmup-s", "0",
+            "--repeats", "1", "--no-other-configs"]
+    j = _bench_flow(tmp_path, oracle, isa, 2, argv, 3, 2, 2)
+    assert j["timed_regions"] == 2 and j["restore_in_front_of_every_step"]["value"] > 0
