@@ -1480,8 +1480,33 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
     if (unaligned) emit_mem(P, sh, s, ts_r, mem_type, fp.page, word1, w1v, false, false, 0);
   }
   ZKW_SUB(42)  // word reads + read queries
+  // A wave whose lanes all access at a word boundary (a shared tape with an immediate or a common cursor: half of cfg 2's
+  // accesses) needs neither the byte window of a read (~50 instructions) nor the six 256-bit shifts that merge a written
+  // value into two words (~270): the word is the value.  One ballot decides; the general code gives the same for unal = 0.
+  const bool all_aligned = zkw_ballot(unal != 0) == 0;
+  // ... and a wave whose lanes share one unaligned offset shifts by scalar amounts with static indices (u256_byte_window_at /
+  // u256_merge_at): the dword part of the offset selects the case, a scalar branch
+  const u32 u_unal = (u32)__builtin_amdgcn_readfirstlane((int)unal);
+  const bool same_unal = zkw_ballot(unal != u_unal) == 0;
+  const u32 u_b8 = (u_unal & 3u) * 8u;
   if (!is_write) {  // :291-348
-    u256 result = u256_byte_window(w0v, w1v, unal);
+    u256 result;
+    if (all_aligned) {
+      result = w0v;
+    } else if (same_unal) {
+      switch (u_unal >> 2) {
+        case 0: result = u256_byte_window_at<0>(w0v, w1v, u_b8); break;
+        case 1: result = u256_byte_window_at<1>(w0v, w1v, u_b8); break;
+        case 2: result = u256_byte_window_at<2>(w0v, w1v, u_b8); break;
+        case 3: result = u256_byte_window_at<3>(w0v, w1v, u_b8); break;
+        case 4: result = u256_byte_window_at<4>(w0v, w1v, u_b8); break;
+        case 5: result = u256_byte_window_at<5>(w0v, w1v, u_b8); break;
+        case 6: result = u256_byte_window_at<6>(w0v, w1v, u_b8); break;
+        default: result = u256_byte_window_at<7>(w0v, w1v, u_b8); break;
+      }
+    } else {
+      result = u256_byte_window(w0v, w1v, unal);
+    }
     if (is_ptr_read) {
       u32 beyond = incremented - fp.length;
       if (incremented < fp.length || skip) beyond = 0;
@@ -1501,11 +1526,28 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
     }
     ZKW_SUB(44)  // read: destination
   } else {  // :349-423
-    const u32 lowest = 32 - unal;
-    u256 n0 = u256_shl(u256_shr(w0v, lowest * 8), lowest * 8);
-    n0 = u256_or(n0, u256_shr(ps.src1, unal * 8));
-    u256 n1 = u256_shr(u256_shl(w1v, unal * 8), unal * 8);
-    n1 = u256_or(n1, u256_shl(ps.src1, (32 - unal) * 8));
+    u256 n0, n1;
+    if (all_aligned) {
+      n0 = ps.src1;
+      n1 = u256_zero();
+    } else if (same_unal) {
+      switch (u_unal >> 2) {
+        case 0: u256_merge_at<0>(w0v, w1v, ps.src1, u_b8, n0, n1); break;
+        case 1: u256_merge_at<1>(w0v, w1v, ps.src1, u_b8, n0, n1); break;
+        case 2: u256_merge_at<2>(w0v, w1v, ps.src1, u_b8, n0, n1); break;
+        case 3: u256_merge_at<3>(w0v, w1v, ps.src1, u_b8, n0, n1); break;
+        case 4: u256_merge_at<4>(w0v, w1v, ps.src1, u_b8, n0, n1); break;
+        case 5: u256_merge_at<5>(w0v, w1v, ps.src1, u_b8, n0, n1); break;
+        case 6: u256_merge_at<6>(w0v, w1v, ps.src1, u_b8, n0, n1); break;
+        default: u256_merge_at<7>(w0v, w1v, ps.src1, u_b8, n0, n1); break;
+      }
+    } else {
+      const u32 lowest = 32 - unal;
+      n0 = u256_shl(u256_shr(w0v, lowest * 8), lowest * 8);
+      n0 = u256_or(n0, u256_shr(ps.src1, unal * 8));
+      n1 = u256_shr(u256_shl(w1v, unal * 8), unal * 8);
+      n1 = u256_or(n1, u256_shl(ps.src1, (32 - unal) * 8));
+    }
     ZKW_SUB(45)  // write: shifts
     if (ZKW_LIKELY(!skip)) {
       heap_write_at(P, sh, s, !is_heap, f_slot, f_hwm, word0, n0);

@@ -183,6 +183,41 @@ ZD u256 u256_byte_window(const u256& hi, const u256& lo, u32 unal) {
   for (int i = 0; i < 8; i++) out.w[i] = zk_sel(mr, zk_funnel_r(e[i + 1], e[i], 32u - r), e[i + 1]);
   return out;
 }
+// The same window, and the merge of a written value into the two words it straddles, for a byte offset that is the SAME for
+// every lane of the wave (a shared tape with an immediate or a common cursor): the dword part Q of the offset is a template
+// parameter (the caller switches on it: a scalar branch), the byte part `b8` = 8 * (offset & 3) a scalar — every index is
+// static and a dword costs one funnel shift: ~10 instructions instead of ~50 (window) / ~270 (the six per-lane 256-bit
+// shifts of the merge).  offset = 4 Q + b8 / 8, 0 < offset < 32.
+template <int Q>
+ZD u256 u256_byte_window_at(const u256& hi, const u256& lo, u32 b8) {
+  u32 c[16];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { c[i] = lo.w[i]; c[i + 8] = hi.w[i]; }
+  u256 out;
+#pragma unroll
+  for (int i = 0; i < 8; i++) out.w[i] = b8 ? zk_funnel_r(c[i + 8 - Q], c[i + 7 - Q], 32u - b8) : c[i + 8 - Q];
+  return out;
+}
+// (w0 : w1) with the 32 bytes at byte `offset` of w0 replaced by `v` -> (n0 : n1); big-endian bytes, w[7] most significant
+template <int Q>
+ZD void u256_merge_at(const u256& w0, const u256& w1, const u256& v, u32 b8, u256& n0, u256& n1) {
+  u32 t[16];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { t[i] = w1.w[i]; t[i + 8] = w0.w[i]; }
+  if (b8 == 0) {  // (wave-uniform) the value covers dwords 8 - Q .. 15 - Q
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[8 - Q + i] = v.w[i];
+  } else {  // the value starts 32 - b8 bits into dword D = 7 - Q and ends 32 - b8 bits into dword D + 8
+    constexpr int D = 7 - Q;
+    const u32 keep_lo = 0xffffffffu >> b8;
+    t[D] = (t[D] & keep_lo) | (v.w[0] << (32u - b8));
+#pragma unroll
+    for (int i = 1; i < 8; i++) t[D + i] = zk_funnel_r(v.w[i], v.w[i - 1], b8);
+    t[D + 8] = (t[D + 8] & ~keep_lo) | (v.w[7] >> b8);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) { n1.w[i] = t[i]; n0.w[i] = t[i + 8]; }
+}
 ZD u256 u256_or(const u256& a, const u256& b) {
   u256 r;
 #pragma unroll

@@ -26,4 +26,26 @@ void t_select_bits(const u32* m, const u32* a, const u32* b, u32* out) {
   const u256 r = u256_select_bits(mm, aa, bb);
   for (int i = 0; i < 8; i++) out[i] = r.w[i];
 }
+// the uniform-offset forms (offset the same for every lane: dword part as a template parameter, byte part a scalar)
+void t_window_at(const u32* hi, const u32* lo, u32 unal, u32* out) {
+  const u256 h = ld(hi), l = ld(lo);
+  const u32 b8 = (unal & 3u) * 8u;
+  u256 r;
+  switch (unal >> 2) {
+    case 0: r = u256_byte_window_at<0>(h, l, b8); break; case 1: r = u256_byte_window_at<1>(h, l, b8); break; case 2: r = u256_byte_window_at<2>(h, l, b8); break; case 3: r = u256_byte_window_at<3>(h, l, b8); break;
+    case 4: r = u256_byte_window_at<4>(h, l, b8); break; case 5: r = u256_byte_window_at<5>(h, l, b8); break; case 6: r = u256_byte_window_at<6>(h, l, b8); break; default: r = u256_byte_window_at<7>(h, l, b8); break;
+  }
+  st(r, out);
+}
+void t_merge_at(const u32* w0, const u32* w1, const u32* v, u32 unal, u32* n0, u32* n1) {
+  const u256 a = ld(w0), b = ld(w1), x = ld(v);
+  const u32 b8 = (unal & 3u) * 8u;
+  u256 r0, r1;
+  switch (unal >> 2) {
+    case 0: u256_merge_at<0>(a, b, x, b8, r0, r1); break; case 1: u256_merge_at<1>(a, b, x, b8, r0, r1); break; case 2: u256_merge_at<2>(a, b, x, b8, r0, r1); break;
+    case 3: u256_merge_at<3>(a, b, x, b8, r0, r1); break; case 4: u256_merge_at<4>(a, b, x, b8, r0, r1); break; case 5: u256_merge_at<5>(a, b, x, b8, r0, r1); break;
+    case 6: u256_merge_at<6>(a, b, x, b8, r0, r1); break; default: u256_merge_at<7>(a, b, x, b8, r0, r1); break;
+  }
+  st(r0, n0); st(r1, n1);
+}
 }

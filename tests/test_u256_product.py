@@ -73,6 +73,25 @@ def test_byte_window_for_every_offset(lib):
                 assert value(out) == (both >> (256 - 8 * u)) & M, (hex(hi), hex(lo), u)
 
 
+def test_uniform_offset_window_and_merge(lib):
+    """u256_byte_window_at / u256_merge_at (the wave-uniform forms op_uma takes when every lane has the same offset) for every
+    offset 1..31: the window equals bytes [u, u + 32) of hi || lo, the merge equals hi || lo with those 32 bytes replaced
+    (uma.rs:291-300, 349-400)"""
+    out, n0, n1 = A8(), A8(), A8()
+    ps = patterns()
+    for hi in ps[2:8]:
+        for lo in ps[3:9]:
+            both = (hi << 256) | lo
+            for u in range(1, 32):
+                lib.t_window_at(limbs(hi), limbs(lo), C.c_uint32(u), out)
+                assert value(out) == (both >> (256 - 8 * u)) & M, ("window", hex(hi), hex(lo), u)
+                for v in (ps[4], ps[5], ps[9]):
+                    lib.t_merge_at(limbs(hi), limbs(lo), limbs(v), C.c_uint32(u), n0, n1)
+                    sh = 256 - 8 * u
+                    want = (both & ~(M << sh)) | (v << sh)
+                    assert (value(n0) << 256) | value(n1) == want, ("merge", hex(hi), hex(lo), hex(v), u)
+
+
 def test_select_bits(lib):
     out = A8()
     rng = random.Random(5)
