@@ -2434,12 +2434,9 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
   // ----------------------------------------------------------------------------------------
   Pre ps;
   bool call_out = false;  // this lane leaves through the out-of-line call below
-  zkw_v16 oa, ob;
-#pragma unroll
-  for (int i = 0; i < 16; i++) oa[i] = ob[i] = 0;
+  // (the call's argument registers are filled at the call site, behind a SCALAR test of the opcode: as values defined up
+  // here they were live — and zeroed, 32 moves — on the path of every light opcode)
   if (ZKW_UNLIKELY(!IS_VEC && vec)) {  // wave-uniform
-    oa = lane_pack(s);
-    oa[12] = vec_lo; oa[13] = vec_hi; oa[14] = d.attr; oa[15] = 1u;
     call_out = true;
   } else {
   u32 sp = s.sp;
@@ -2587,13 +2584,6 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
 #pragma unroll
           for (int i = 0; i < 8; i++) ZKW_XFER(sh, s, i) = r15.w[i];
         }
-        oa = lane_pack(s);
-        oa[12] = d.word_lo; oa[13] = d.word_hi; oa[14] = d.attr | ((ps.src0_ptr ? 1u : 0u) << 30) | ((ps.src1_ptr ? 1u : 0u) << 31);
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-          ob[i] = ps.src0.w[i];
-          ob[8 + i] = ps.src1.w[i];
-        }
         call_out = true;
         break;
       }
@@ -2604,7 +2594,22 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
   }  // !vec
 #if defined(__HIP_DEVICE_COMPILE__) || defined(ZKW_EMU_BUILD)
   if constexpr (!IS_VEC) {
+  const bool out_of_line = vec || opcode == ZKW_OP_LOG || opcode == ZKW_OP_NEAR_CALL || opcode == ZKW_OP_FAR_CALL || opcode == ZKW_OP_RET;  // wave-uniform
+  if (ZKW_UNLIKELY(out_of_line))
   if (ZKW_UNLIKELY(call_out)) {
+    zkw_v16 oa = lane_pack(s), ob;
+#pragma unroll
+    for (int i = 0; i < 16; i++) ob[i] = 0;
+    if (vec) {
+      oa[12] = vec_lo; oa[13] = vec_hi; oa[14] = d.attr; oa[15] = 1u;
+    } else {
+      oa[12] = d.word_lo; oa[13] = d.word_hi; oa[14] = d.attr | ((ps.src0_ptr ? 1u : 0u) << 30) | ((ps.src1_ptr ? 1u : 0u) << 31);
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        ob[i] = ps.src0.w[i];
+        ob[8 + i] = ps.src1.w[i];
+      }
+    }
     const zkw_v16 r = zkw_heavy_entry(oa, ob);
 #ifdef __HIP_DEVICE_COMPILE__
     {
