@@ -1395,12 +1395,14 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
   // clocks that need nothing from memory), and waited for behind it: the address needs only the offset and the frame fields
   // above.  Speculative for the lanes that turn out to skip the access (an exception): those either hold an offset beyond
   // 2^32 (no load: the guard below) or read a word of their own page that nobody looks at.
-  u256 e0 = u256_zero(), e1 = u256_zero();
+  // (straight into the words the access works on: a lane that turns out to skip a heap / aux access has set_panic and
+  // nobody looks at what it loaded; a fat-pointer read loads behind the checks, below)
+  u256 w0v = u256_zero(), w1v = u256_zero();
   if (ZKW_LIKELY(!is_ptr_read)) {
     if (ZKW_LIKELY(!(ps.src0.w[1] | ps.src0.w[2] | ps.src0.w[3] | ps.src0.w[4] | ps.src0.w[5] | ps.src0.w[6] | ps.src0.w[7]))) {
       const u32 ew = ps.src0.w[0] >> 5;
-      e0 = heap_read_at(P, sh, s, !is_heap, f_slot, f_hwm, ew);
-      if (ps.src0.w[0] & 31u) e1 = heap_read_at(P, sh, s, !is_heap, f_slot, f_hwm, ew + 1u);
+      w0v = heap_read_at(P, sh, s, !is_heap, f_slot, f_hwm, ew);
+      if (ps.src0.w[0] & 31u) w1v = heap_read_at(P, sh, s, !is_heap, f_slot, f_hwm, ew + 1u);
     }
   }
   u32 mem_type;
@@ -1453,7 +1455,6 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
   const u32 word0 = src_offset >> 5, word1 = word0 + 1, unal = src_offset & 31u;
   const bool unaligned = unal != 0;
   const u32 ts_r = s.timestamp, ts_w = s.timestamp + 3;
-  u256 w0v = u256_zero(), w1v = u256_zero();
   ZKW_SUB(41)  // exceptions, growth, cost
 #ifdef ZKW_PROFILE_DRAIN
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1465,10 +1466,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
     if (is_ptr_read) {
       w0v = fat_ptr_read(P, sh, s, fp.page, word0);
       if (unaligned) w1v = fat_ptr_read(P, sh, s, fp.page, word1);
-    } else {  // requested above (an access that is not skipped has an offset below 2^32: these are its words)
-      w0v = e0;
-      w1v = e1;
-    }
+    }  // (else: requested above — an access that is not skipped has an offset below 2^32: these are its words)
     ZKW_SETTLE(2 /* UMA words */);
     ZKW_SUB(64)  // loads issued
 #ifdef ZKW_PROFILE
