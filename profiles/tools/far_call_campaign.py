@@ -30,6 +30,14 @@ for k in range(count):
     plan = "".join(rng.choice("PPPPKN") for _ in range(n))
     # live returndata pages at the end: one per K, one per N (its inner K), all owned by the bootloader frame
     need = 1 + sum(1 for c in plan if c in "KN") + (1 if "N" in plan else 0)
+    # ... and while a call runs its own slot (and the nested callee's, for N) sits beside the pages kept so far: a plan
+    # that calls again behind its last K needs one slot more than its kept pages (seeds 0x583d / 0x5841 of the round-4 long
+    # campaign stopped on the limit there, rightly, under the first formula alone)
+    kept = 0
+    for c in plan:
+        need = max(need, 1 + kept + 1 + (1 if c == "N" else 0))
+        if c in "KN":
+            kept += 1
     lanes = (0, 64, 8, 1)[k % 4]
     wl = synth.many_far_calls(isa, n_calls=n, plan=plan, n_instances=70, seed=seed, max_far_frames=F)
     bo = orc.create_batch(wl); bo.reset(); bo.run(wl.n_cycles); bo.sync()
