@@ -3,8 +3,10 @@
 cd $GRAFT_REPO_ROOT
 T=gpurun_out/$1; mkdir -p $T
 cp era-zk_evm_amd/libzkw.so /tmp/libzkw_keep.so
+LIBS=(era-zk_evm_amd/ab_*.so); NL=${#LIBS[@]}
 for R in $(seq 1 ${2:-3}); do
-for L in era-zk_evm_amd/ab_*.so; do
+# (the order rotates from round to round: a box that warms up or drifts during the run otherwise favours the libraries that come late)
+for I in $(seq 0 $((NL-1))); do L=${LIBS[$(( (I + R) % NL ))]}
   cp $L era-zk_evm_amd/libzkw.so
   CMDS=("--steps 20 --warmup 5")
   [ "${3:-0}" = "1" ] && CMDS+=("")
