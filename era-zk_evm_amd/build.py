@@ -13,7 +13,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libzkw.so")
 ISA_LIB = os.path.join(PKG, "libzkw_isa.so")
 
-HIP_SOURCES = ["zkw_kernels.hip", "zkw_commit.hip", "zkw_blake2s.hip", "zkw_expand.hip", "zkw_runtime.cpp", "isa_default.cpp"]
+HIP_SOURCES = ["zkw_kernels.hip", "zkw_commit.hip", "zkw_blake2s.hip", "zkw_expand.hip", "zkw_pack.hip", "zkw_runtime.cpp", "isa_default.cpp"]
 
 
 def _stale(target, sources):

@@ -374,6 +374,100 @@ class Backend:
         self.call("batches_expand_records", arr, C.c_uint32(len(batches)), dst, C.c_uint64(instance_stride), C.c_uint64(cycle_stride), C.c_void_p(stream))
 
 
+class DeliveredC(C.Structure):
+    _fields_ = [("bytes", C.c_uint64), ("pack_ms", C.c_double), ("n_batches", C.c_uint32), ("n_waves", C.c_uint32), ("overflow", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+CYCLE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32)
+
+
+def trace_checksum(t):
+    """the fold of zkw_delivery_replay's built-in consumer over one per-instance trace (include/zkw.h): sum over the records of
+    sum_j u64[j] * (2 j + 1), over the memory / log / aux records with weights 2 j + 3 / 5 / 7, mod 2^64"""
+    acc = 0
+    for key, words, w0 in (("records", 64, 1), ("mem", 6, 3), ("log", 16, 5), ("aux", 32, 7)):
+        a = t[key]
+        if len(a) == 0:
+            continue
+        u = np.frombuffer(a.tobytes(), dtype="<u8").reshape(len(a), words)
+        wts = (2 * np.arange(words, dtype=np.uint64) + np.uint64(w0))
+        with np.errstate(over="ignore"):
+            acc += int((u * wts).sum(dtype=np.uint64))
+    return acc & 0xFFFFFFFFFFFFFFFF
+
+
+class Delivery:
+    """zkw_delivery (include/zkw.h): whole steps delivered into a persistent pinned host ring by one pack kernel per step;
+    traces rebuilt / replayed from the ring on a pool of host threads."""
+
+    def __init__(self, backend, n_slots, slot_bytes, host_threads=1):
+        self.be = backend
+        self.h = C.c_void_p()
+        backend.call("delivery_create", backend.ctx, C.c_uint32(n_slots), C.c_uint64(slot_bytes), C.c_uint32(host_threads), C.byref(self.h))
+        self._keep = []
+
+    @staticmethod
+    def worst_case_bytes(backend, batches):
+        arr = (C.c_void_p * len(batches))(*[b.h.value for b in batches])
+        out = C.c_uint64()
+        backend.call("delivery_slot_bytes", arr, C.c_uint32(len(batches)), C.byref(out))
+        return out.value
+
+    def submit(self, batches, stream=None):
+        arr = batches if hasattr(batches, "n") else self.be.handle_array(batches)
+        t = C.c_uint32()
+        self.be.call("delivery_submit", self.h, arr, C.c_uint32(arr.n), C.c_void_p(stream), C.byref(t))
+        return t.value
+
+    def order_after(self, ticket, stream=None):
+        self.be.call("delivery_order_after", self.h, C.c_uint32(ticket), C.c_void_p(stream))
+
+    def wait(self, ticket):
+        info = DeliveredC()
+        self.be.call("delivery_wait", self.h, C.c_uint32(ticket), C.byref(info))
+        return {"bytes": info.bytes, "pack_ms": info.pack_ms, "n_batches": info.n_batches, "n_waves": info.n_waves, "overflow": info.overflow}
+
+    def trace(self, ticket, batch_index, i):
+        t = InstanceTraceC()
+        self.be.call("delivery_get_instance_trace", self.h, C.c_uint32(ticket), C.c_uint32(batch_index), C.c_uint32(i), C.byref(t))
+        return _trace_dict(t)
+
+    def replay(self, ticket, fn=None):
+        """-> (cycles, checksum).  fn(thread, batch, instance, cycle, record_ptr, mem_ptr, n_mem, log_ptr, n_log, aux_ptr, n_aux) or
+        None for the built-in fold"""
+        n, acc = C.c_uint64(), C.c_uint64()
+        if fn is None:
+            cb = C.cast(None, CYCLE_FN)
+        else:
+            cb = CYCLE_FN(lambda user, *a: fn(*a))
+        self.be.call("delivery_replay", self.h, C.c_uint32(ticket), cb, None, C.byref(n), C.byref(acc))
+        return n.value, acc.value
+
+    def release(self, ticket):
+        self.be.call("delivery_release", self.h, C.c_uint32(ticket))
+
+    def close(self):
+        if self.h:
+            self.be.fn("delivery_destroy")(self.h)
+            self.h = C.c_void_p()
+
+
+def _trace_dict(t):
+    n = t.n_cycles
+    return {
+        "status": t.status,
+        "n_cycles": n,
+        "records": _from_ptr(t.records, n, CYCLE_RECORD),
+        "mem": _from_ptr(t.mem, t.n_mem, MEM_QUERY),
+        "log": _from_ptr(t.log, t.n_log, LOG_QUERY),
+        "aux": _from_ptr(t.aux, t.n_aux, AUX_EVENT),
+        "mem_off": _from_ptr(t.mem_off, n + 1, np.dtype("<u4")),
+        "log_off": _from_ptr(t.log_off, n + 1, np.dtype("<u4")),
+        "aux_off": _from_ptr(t.aux_off, n + 1, np.dtype("<u4")),
+        "final_state": np.frombuffer(bytes(t.final_state), dtype=VM_LOCAL_STATE, count=1).copy()[0],
+    }
+
+
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32)
 
@@ -391,6 +485,12 @@ class Comm:
         self.h = C.c_void_p()
         self.world = 1
         self._keep = []
+
+    @staticmethod
+    def probe(backend):
+        """zkw_comm_probe: librccl loads and has the symbols the RCCL transport uses (no side effects); raises ZkwError otherwise"""
+        backend.call("comm_probe")
+        return True
 
     @staticmethod
     def unique_id(backend):
@@ -540,19 +640,18 @@ class Batch:
     def trace(self, i):
         t = InstanceTraceC()
         self.be.call("batch_get_instance_trace", self.h, C.c_uint32(i), C.byref(t))
-        n = t.n_cycles
-        return {
-            "status": t.status,
-            "n_cycles": n,
-            "records": _from_ptr(t.records, n, CYCLE_RECORD),
-            "mem": _from_ptr(t.mem, t.n_mem, MEM_QUERY),
-            "log": _from_ptr(t.log, t.n_log, LOG_QUERY),
-            "aux": _from_ptr(t.aux, t.n_aux, AUX_EVENT),
-            "mem_off": _from_ptr(t.mem_off, n + 1, np.dtype("<u4")),
-            "log_off": _from_ptr(t.log_off, n + 1, np.dtype("<u4")),
-            "aux_off": _from_ptr(t.aux_off, n + 1, np.dtype("<u4")),
-            "final_state": np.frombuffer(bytes(t.final_state), dtype=VM_LOCAL_STATE, count=1).copy()[0],
-        }
+        return _trace_dict(t)
+
+    def restage(self, states, heaps=None, stream=None):
+        """zkw_batch_restage: new VmLocalStates (and heap images) for every instance of the uploaded batch, asynchronously on
+        `stream`; the batch is restored to them (as after zkw_batch_reset)"""
+        states = np.ascontiguousarray(states)
+        assert states.dtype == VM_LOCAL_STATE and len(states) == self.wl.n_instances
+        hw, nh = None, 0
+        if heaps is not None:
+            heaps = np.ascontiguousarray(heaps, dtype="<u8")  # [n, words, 4]
+            hw, nh = _ptr(heaps), heaps.shape[1]
+        self.be.call("batch_restage", self.h, _ptr(states), hw, C.c_uint32(nh), C.c_void_p(stream))
 
     def page(self, i, page, first_word, n_words):
         """`vm.memory.dump_page_content_as_u256_words(page, first..first + n)` of instance i after the run

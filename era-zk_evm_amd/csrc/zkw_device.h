@@ -90,9 +90,12 @@ typedef struct zkw_dev_preimage {
   uint32_t reserved[3];
 } zkw_dev_preimage; /* 48 B */
 
+/* SimpleDecommitter's history (decommitter.rs:38-47: a map hash -> page, one row per fresh decommit, never bounded): one
+ * row per (hash -> blob) pair the batch knows, indexed by the pair — a lookup is one load, and the decommits of a run are
+ * capped by nothing but the number of known code hashes (an unknown hash is the reference's Err) */
 typedef struct zkw_dev_history {
-  uint32_t preimage; /* index into the preimage table */
-  uint32_t page;
+  uint32_t valid; /* 1: this code hash was decommitted since the reset ... */
+  uint32_t page;  /* ... into this page */
 } zkw_dev_history;
 
 /* The parameter block of a batch lives in device memory (written once at upload) and is read through the
@@ -103,6 +106,17 @@ typedef struct zkw_dev_history {
 #else
 #define ZKW_CONST_AS
 #endif
+/* slot of a code hash in zkw_kparams.pre_index (host: zkw_batch_upload; device: op_far_call) */
+#if defined(__HIP__)
+#define ZKW_HD __host__ __device__
+#else
+#define ZKW_HD
+#endif
+ZKW_HD static inline uint32_t zkw_pre_hash(const uint32_t h[8]) {
+  uint32_t x = h[0] ^ (h[1] * 0x9e3779b9u) ^ (h[2] * 0x85ebca6bu);
+  x ^= x >> 15;
+  return x * 0xc2b2ae35u;
+}
 #define ZKW_MAX_FUSED 256 /* batches per fused launch (the by-value tables stay under the 4 KB kernel-argument segment) */
 
 /* kernel parameter block */
@@ -137,7 +151,7 @@ typedef struct zkw_kparams {
   uint4* aux_heap;             /* [n_waves][F][A][2][L]                  */
   zkw_dev_storage_entry* storage;  /* [n_instances][storage_slots]       */
   zkw_dev_journal_entry* journal;  /* [n_instances][storage_journal]     */
-  zkw_dev_history* history;        /* [n_instances][F]                   */
+  zkw_dev_history* history;        /* [n_instances][hist_pitch]: row p = preimage p (zkw_dev_history) */
   /* read-only inputs */
   const uint4* blob_words;     /* all code blobs, 2 x uint4 per word     */
   const uint2* blob_dir;       /* [n_blobs] (first word, n_words)        */
@@ -151,7 +165,10 @@ typedef struct zkw_kparams {
   const zkw_dev_scalars* scalars0; /* reset (wave_cycles == 0) — the reset does not copy them into the working buffers   */
   uint32_t* storage_dirty;     /* [n_instances][ceil(storage_slots / 32)]: one bit per storage-table slot written since the reset */
   uint32_t heap_image_words;   /* words of the uploaded heap image (frame slot 0) */
-  uint32_t reserved4;
+  uint32_t hist_pitch;         /* rows of `history` per instance = max(1, n_preimages) */
+  const uint32_t* pre_index;   /* [pre_mask + 1] open addressing over the code hashes: 0 = empty, else preimage index + 1 (zkw_pre_hash) */
+  uint32_t pre_mask;
+  uint32_t reserved5;
   uint4* mem_stream;           /* [n_waves][3][cap_mem]: planes header | value low | value high of the 48-byte zkw_mem_query */
   uint4* log_stream;           /* [n_waves][cap_log][8]                  */
   uint4* aux_stream;           /* [n_waves][cap_aux][16]                 */
@@ -232,4 +249,7 @@ typedef struct zkw_reset_params {
   uint32_t n_instances;
   uint32_t storage_slots;    /* slots per instance of the storage table ([4]: restored per dirty slot after the first reset) */
   uint32_t* storage_dirty;   /* [n_instances][ceil(storage_slots / 32)] */
+  uint4* history;            /* decommit history rows, cleared by every reset ... */
+  uint32_t history16;        /* ... 16-byte units of it */
+  uint32_t reserved0;
 } zkw_reset_params;

@@ -1850,36 +1850,38 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
   if (exceptions) {  // :435-439
     s.flags |= FLAG_PENDING;
   } else {  // :441-455 decommit (helpers.rs:164-194 + SimpleDecommitter decommitter.rs:32-98)
+    // known_hashes.get(&hash) (decommitter.rs:52-56): open addressing over the code hashes (built at upload, zkw_pre_hash),
+    // normally one probe = one index load + the two wide loads of the candidate's hash
     u32 pre = 0xffffffffu;
-    for (u32 i = 0; i < P.n_preimages; i++) {
-      const uint4* h4 = (const uint4*)P.preimages[i].hash;  // two wide loads, not eight dependent dword round trips
-      const uint4 h0 = h4[0], h1 = h4[1];
-      const u32 diff = (h0.x ^ code_hash.w[0]) | (h0.y ^ code_hash.w[1]) | (h0.z ^ code_hash.w[2]) | (h0.w ^ code_hash.w[3]) | (h1.x ^ code_hash.w[4]) |
-                       (h1.y ^ code_hash.w[5]) | (h1.z ^ code_hash.w[6]) | (h1.w ^ code_hash.w[7]);
-      if (diff == 0) pre = i;
-    }
-    zkw_dev_history* hist = P.history + (u64)lane_inst(sh, s) * P.F;
-    bool fresh = true;
-    u32 page = candidate_page;
-    for (u32 i = 0; i < CF(sh, s, CF_N_HISTORY); i++) {
-      if (hist[i].preimage == pre && pre != 0xffffffffu) {
-        fresh = false;
-        page = hist[i].page;
+    if (P.n_preimages) {
+      u32 slot = zkw_pre_hash(code_hash.w) & P.pre_mask;
+      for (u32 probe = 0; probe <= P.pre_mask; probe++, slot = (slot + 1u) & P.pre_mask) {
+        const u32 cand = P.pre_index[slot];
+        if (cand == 0) break;
+        const uint4* h4 = (const uint4*)P.preimages[cand - 1u].hash;
+        const uint4 h0 = h4[0], h1 = h4[1];
+        const u32 diff = (h0.x ^ code_hash.w[0]) | (h0.y ^ code_hash.w[1]) | (h0.z ^ code_hash.w[2]) | (h0.w ^ code_hash.w[3]) | (h1.x ^ code_hash.w[4]) |
+                         (h1.y ^ code_hash.w[5]) | (h1.z ^ code_hash.w[6]) | (h1.w ^ code_hash.w[7]);
+        if (diff == 0) {
+          pre = cand - 1u;
+          break;
+        }
       }
     }
     if (pre == 0xffffffffu) {  // decommitter.rs:54-56: Err propagates out of cycle()
       lane_fail(s, ZKW_STATUS_UNKNOWN_CODE_HASH);
       return;
     }
+    // history.get(&hash) (decommitter.rs:58-79): the row of this (hash -> blob) pair — no scan, no capacity
+    zkw_dev_history* hist = P.history + (u64)lane_inst(sh, s) * P.hist_pitch + pre;
+    const zkw_dev_history seen = *hist;
+    const bool fresh = seen.valid == 0;
+    const u32 page = fresh ? candidate_page : seen.page;
     const u32 blob = P.preimages[pre].blob;
     const u32 blob_len = P.blob_dir[blob].y & 0xffffu;  // `values.len() as u16`
     if (fresh) {
-      if (CF(sh, s, CF_N_HISTORY) >= P.F) {
-        lane_fail(s, ZKW_STATUS_LIMIT);
-        return;
-      }
-      hist[CF(sh, s, CF_N_HISTORY)].preimage = pre;
-      hist[CF(sh, s, CF_N_HISTORY)].page = page;
+      hist->valid = 1u;
+      hist->page = page;
       CF(sh, s, CF_N_HISTORY)++;
     } else {
       after_decommit += decommit_cost;  // :450-453 refund
@@ -3543,6 +3545,7 @@ __global__ void zkw_reset_kernel(zkw_fused_table T) {
       }
     for (u32 i = t0; i < R.n_waves * 4; i += stride) R.cursors[i] = 0;
     for (u32 i = t0; i < R.n_waves; i += stride) R.wave_cycles[i] = 0;
+    for (u32 i = t0; i < R.history16; i += stride) R.history[i] = make_uint4(0, 0, 0, 0);  // SimpleDecommitter starts with an empty history
   }
 }
 

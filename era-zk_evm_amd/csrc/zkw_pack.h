@@ -1,0 +1,91 @@
+// Link format of a delivered step (zkw_pack_kernel -> pinned host memory -> the host rebuild of zkw_runtime.cpp).
+//
+// What the reference hands its VmWitnessTracer lives on the HOST (all ten callbacks of witness_trace/mod.rs:11-72 run on the
+// CPU), so every trace has to cross PCIe.  The cycle kernel leaves its streams in HBM at fixed capacities per wave; the pack
+// kernel writes the USED extents of one step — every wave of every batch of a fused group — into ONE contiguous block, and it
+// writes that block straight into pinned host memory (the kernel's stores go over the link: 55 GB/s of the 57 GB/s a
+// hipMemcpyAsync of the same bytes reaches on these boxes, profiles/r08_pcie_probe.txt — and no staging copy, no sizes the
+// host would have to know before it can enqueue a copy).  The block is also a denser encoding than the device streams:
+//   memory-query header  16 B -> 12 B   three u32 planes (page | index | lane, seq, meta, low byte of the timestamp: a query's
+//                                       timestamp is the cycle's + 0..3, mod.rs:220-231, and the rebuild knows the cycle's)
+//   code-word queries    no value       MemoryType::Code reads (cycle.rs:76-81, mem_ops.rs:100-110) return words of a code page
+//                                       the host holds (the blobs it uploaded): the value planes carry the other queries only
+//   aux events           256 B -> used  FRAME_START 240 B, DECOMMIT 64 B, COLD_STATE 48 B, FRAME_FINISH 16 B
+// All offsets and sizes are in 16-byte units from the start of the block.
+//
+//   [0, 4)                      zkw_pack_header (written by the host at submit; `used_units` / `overflow` land behind the kernel)
+//   [4, ...)                    zkw_pack_batch   x n_batches   (host)
+//   [...]                       zkw_pack_wave    x n_waves     (kernel: one entry per wave of the step, numbered through the batches)
+//   per batch, when the step was packed `with_instances`:
+//     scalars  [n_instances] x 8 units      zkw_dev_scalars (status, cycle counts, the scalar half of the final VmLocalState)
+//     regs     [n_waves][30][L]             the final register files, device layout
+//     entries  [n_instances] x 8 units      callstack.current of the final state (zkw_dev_entry)
+//   wave data, allocated in the order the workgroups get to them (zkw_pack_wave.off):
+//     dir      (max_cyc + 1)                stream cursors at every cycle start
+//     tails    max_cyc x L
+//     deltas   n_delta (low plane), n_delta (high plane)
+//     mem      3 planes of ceil4(n_mem) u32 (page | index | misc), then n_val (value low), n_val (value high): the values of
+//              the queries whose type is not Code, in stream order
+//     log      n_log x 8
+//     aux      aux_units (records back to back, each as long as its type uses)
+#pragma once
+#include <stdint.h>
+
+#include "zkw_device.h"
+
+#define ZKW_PACK_MAGIC 0x50574b5au /* "ZKWP" */
+#define ZKW_PACK_VERSION 1u
+#define ZKW_PACK_HEADER_UNITS 4u
+#define ZKW_PACK_BATCH_UNITS 2u
+#define ZKW_PACK_WAVE_UNITS 4u
+#define ZKW_PACK_THREADS 256u
+#define ZKW_PACK_MAX 256u /* batches per launch */
+
+typedef struct zkw_pack_header { /* 64 B */
+  uint32_t magic, version, n_batches, n_waves;
+  uint32_t fixed_units;    /* header + tables + instance sections: where the wave data starts */
+  uint32_t with_instances; /* 1: the per-instance sections are present */
+  uint32_t used_units;     /* total units of the block (copied behind the kernel from its allocation cursor) */
+  uint32_t overflow;       /* != 0: the block did not fit the slot: waves without data have off == 0 */
+  uint32_t reserved[8];
+} zkw_pack_header;
+
+typedef struct zkw_pack_batch { /* 32 B */
+  uint32_t n_instances, L, n_waves, first_wave; /* first_wave: index of its wave 0 in the wave table */
+  uint32_t scalars_off, regs_off, entries_off;  /* unit offsets of the instance sections (0 without them) */
+  uint32_t max_cycles;
+} zkw_pack_batch;
+
+typedef struct zkw_pack_wave { /* 64 B */
+  uint32_t off;       /* first unit of the wave's data; 0 = not packed (overflow) */
+  uint32_t max_cyc;   /* wave-cycles run since the reset */
+  uint32_t n_delta, n_mem, n_val, n_log, n_aux, aux_units;
+  uint32_t units;     /* units of the wave's data */
+  uint32_t reserved[7];
+} zkw_pack_wave;
+
+/* units a record of the aux stream uses, by type (the kernel writes only those: zkw_kernels.hip start_frame / op_far_call) */
+ZKW_HD static inline uint32_t zkw_aux_used_units(uint32_t type) {
+  return type == ZKW_AUX_FRAME_START ? 15u : type == ZKW_AUX_DECOMMIT ? 4u : type == ZKW_AUX_COLD_STATE ? 3u : 1u;
+}
+ZKW_HD static inline uint32_t zkw_ceil4(uint32_t n) { return (n + 3u) >> 2; }
+/* units of a wave's data */
+ZKW_HD static inline uint64_t zkw_pack_wave_units(uint32_t max_cyc, uint32_t L, uint32_t n_delta, uint32_t n_mem, uint32_t n_val, uint32_t n_log, uint32_t aux_units) {
+  return (uint64_t)(max_cyc + 1u) + (uint64_t)max_cyc * L + 2ull * n_delta + 3ull * zkw_ceil4(n_mem) + 2ull * n_val + 8ull * n_log + aux_units;
+}
+
+/* by-value arguments of one launch of the pack kernel */
+typedef struct zkw_pack_args {
+  const zkw_kparams* kp[ZKW_PACK_MAX];
+  uint32_t wave_base[ZKW_PACK_MAX + 1]; /* the waves of the launch numbered through its batches */
+  const zkw_pack_batch* batches;        /* device copy of the block's batch table (the instance-section offsets; the by-value
+                                           tables above already fill most of the 4 KB kernel-argument segment) */
+  uint4* dst;           /* the block (device-visible address of the pinned slot, or device memory) */
+  uint32_t* state;      /* device: [0] allocation cursor (units; starts at fixed_units), [1] overflow flag */
+  uint32_t dst_units;   /* capacity of the block */
+  uint32_t n_batches;
+  uint32_t wave_table;  /* unit offset of the wave table */
+  uint32_t with_instances;
+  uint32_t only_wave;   /* 0xffffffff: every wave; else the one wave (of the one batch) to pack — the on-demand path of zkw_batch_get_instance_trace */
+  uint32_t reserved;
+} zkw_pack_args;

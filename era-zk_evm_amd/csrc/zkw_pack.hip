@@ -1,0 +1,226 @@
+// zkw_pack_kernel — one step's witness, packed for the host (link format: zkw_pack.h).
+//
+// The consumers the reference names are host code: VmWitnessTracer's ten callbacks (witness_trace/mod.rs:11-72) run on the
+// CPU, so what the cycle kernel leaves in HBM has to cross PCIe, and the link (57 GB/s on these boxes) is 100x slower than
+// the kernel that fills it.  This kernel is the one consumer of the device streams on that path: it gathers the USED extents
+// of every wave of a fused group of batches — directory, record tails, register deltas, the three query streams, final
+// scalars / register files / callstack entries — into one contiguous block in a denser encoding, and its destination is the
+// pinned host ring itself: the stores ARE the transfer (no staging buffer, no hipMemcpy per stream and wave — round 4 issued
+// 576 of them per batch and reached 16 GB/s).
+// A persistent grid of a few dozen workgroups (the link, not the chip, is the bound: 64 workgroups saturate it) walks the
+// waves; per wave: count (non-code memory queries, used aux units) -> one atomic allocation of the wave's extent in the
+// block -> copies.  Bound: PCIe.  Runs beside the cycle kernel of the next group on a stream of its own.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "zkw_pack.h"
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#ifdef __HIP_DEVICE_COMPILE__
+#define ZKW_PACK_LANE(t) ((t) & 63u)
+#define ZKW_PACK_WAVE_OF(t) ((t) >> 6)
+#else
+#define ZKW_PACK_LANE(t) 0u
+#define ZKW_PACK_WAVE_OF(t) (t)
+#endif
+#define ZKW_PACK_MAX_WAVES (ZKW_PACK_THREADS / 64u)
+
+static __device__ __forceinline__ void pack_copy(uint4* dst, const uint4* src, u64 n, u32 t, u32 nt) {
+  u64 i = t;
+  for (; i + 3ull * nt < n; i += 4ull * nt) {  // four loads in flight per thread
+    const uint4 a = src[i], b = src[i + nt], c = src[i + 2ull * nt], d = src[i + 3ull * nt];
+    dst[i] = a; dst[i + nt] = b; dst[i + 2ull * nt] = c; dst[i + 3ull * nt] = d;
+  }
+  for (; i < n; i += nt) dst[i] = src[i];
+}
+
+// exclusive rank of this thread's flag among the flags of the workgroup's threads (thread order) + their total
+static __device__ __forceinline__ u32 pack_flag_scan(bool f, u32* wave_counts, u32 t, u32 nt, u32& total) {
+  const unsigned long long m = __ballot(f ? 1 : 0);
+  const u32 lane = ZKW_PACK_LANE(t), wv = ZKW_PACK_WAVE_OF(t);
+  const u32 below = (u32)__popcll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_counts[wv] = (u32)__popcll(m);
+  __syncthreads();
+  u32 off = 0, tot = 0;
+  const u32 nw = (nt + 63u) / 64u;
+#ifdef __HIP_DEVICE_COMPILE__
+  for (u32 i = 0; i < nw; i++) {
+    const u32 c = wave_counts[i];
+    if (i < wv) off += c;
+    tot += c;
+  }
+#else
+  (void)nw;
+  tot = wave_counts[wv];
+#endif
+  __syncthreads();
+  total = tot;
+  return off + below;
+}
+
+__global__ void __launch_bounds__(ZKW_PACK_THREADS) zkw_pack_kernel(zkw_pack_args A) {
+  __shared__ u32 s_wave_counts[4][ZKW_PACK_MAX_WAVES + 1];
+  __shared__ u32 s_sums[ZKW_PACK_THREADS];
+  __shared__ u32 s_bcast[4];
+  const u32 t = threadIdx.x, nt = blockDim.x;
+  const bool one = A.only_wave != 0xffffffffu;
+  const u32 total_waves = one ? 1u : A.wave_base[A.n_batches];
+  for (u32 gw = blockIdx.x; gw < total_waves; gw += gridDim.x) {
+    u32 b = 0, w = A.only_wave;
+    if (!one) {  // largest b with wave_base[b] <= gw
+      u32 lo = 0, hi = A.n_batches;
+      while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (A.wave_base[mid] <= gw) lo = mid; else hi = mid;
+      }
+      b = lo;
+      w = gw - A.wave_base[lo];
+    }
+    const zkw_kparams ZKW_CONST_AS& P = *(const zkw_kparams ZKW_CONST_AS*)A.kp[b];
+    const u32 L = P.L;
+    const u32 max_cyc = P.wave_cycles[w] < P.max_cycles ? P.wave_cycles[w] : P.max_cycles;
+    const u32* cur = P.cursors + (u64)w * 4;
+    const u32 n_mem = cur[0] < P.cap_mem ? cur[0] : P.cap_mem, n_log = cur[1] < P.cap_log ? cur[1] : P.cap_log;
+    const u32 n_aux = cur[2] < P.cap_aux ? cur[2] : P.cap_aux, n_delta = cur[3] < P.cap_delta ? cur[3] : P.cap_delta;
+    const uint4* mem_hdr = P.mem_stream + (u64)w * P.cap_mem * 3;
+    const uint4* aux_src = P.aux_stream + (u64)w * P.cap_aux * 16;
+    // ---- count: memory queries that carry a value (every type but Code), units of the aux records ----
+    u32 my_val = 0, my_aux = 0;
+    for (u32 i = t; i < n_mem; i += nt) my_val += ((mem_hdr[i].w >> 16) & ZKW_MQ_TYPE_MASK) != ZKW_MEM_CODE ? 1u : 0u;
+    for (u32 i = t; i < n_aux; i += nt) my_aux += zkw_aux_used_units(aux_src[(u64)i * 16].x & 0xffu);
+    s_sums[t] = my_val;
+    __syncthreads();
+    u32 n_val = 0;
+    for (u32 i = 0; i < nt; i++) n_val += s_sums[i];
+    __syncthreads();
+    s_sums[t] = my_aux;
+    __syncthreads();
+    u32 aux_units = 0;
+    for (u32 i = 0; i < nt; i++) aux_units += s_sums[i];
+    __syncthreads();
+    // ---- allocate the wave's extent ----
+    const u64 units64 = zkw_pack_wave_units(max_cyc, L, n_delta, n_mem, n_val, n_log, aux_units);
+    if (t == 0) {
+      u32 off = 0;
+      if (units64 < 0xffffffffull) {
+        off = atomicAdd(A.state, (u32)units64);
+        if ((u64)off + units64 > A.dst_units) off = 0;
+      }
+      if (off == 0) atomicOr(A.state + 1, 1u);
+      s_bcast[0] = off;
+    }
+    __syncthreads();
+    const u32 off = s_bcast[0];
+    __syncthreads();
+    if (t == 0) {  // the wave's table entry
+      uint4* e = A.dst + A.wave_table + (u64)(one ? 0u : gw) * ZKW_PACK_WAVE_UNITS;
+      e[0] = make_uint4(off, max_cyc, n_delta, n_mem);
+      e[1] = make_uint4(n_val, n_log, n_aux, aux_units);
+      e[2] = make_uint4((u32)units64, 0, 0, 0);
+      e[3] = make_uint4(0, 0, 0, 0);
+    }
+    // ---- the per-instance sections of this wave's instances ----
+    if (A.with_instances) {
+      const zkw_pack_batch pb = A.batches[b];
+      const u32 i0 = w * L, i1 = (i0 + L < P.n_instances) ? i0 + L : P.n_instances;
+      pack_copy(A.dst + pb.scalars_off + (u64)i0 * 8, (const uint4*)P.scalars + (u64)i0 * 8, (u64)(i1 - i0) * 8, t, nt);
+      pack_copy(A.dst + pb.regs_off + (u64)w * ZKW_REG_CHUNKS * L, P.regs + (u64)w * ZKW_REG_CHUNKS * L, (u64)ZKW_REG_CHUNKS * L, t, nt);
+      for (u32 j = t; j < (i1 - i0) * 8u; j += nt) {
+        const u32 i = i0 + j / 8u, u = j % 8u;
+        u32 depth = P.scalars[i].depth;
+        if (depth > P.D) depth = P.D;
+        A.dst[pb.entries_off + (u64)i * 8 + u] = ((const uint4*)(P.callstack + (u64)i * (P.D + 1) + depth))[u];
+      }
+    }
+    if (off == 0) continue;  // the block is full: the host sees off == 0 and the overflow flag
+    uint4* d = A.dst + off;
+    // ---- directory, tails, register deltas: plain extents ----
+    pack_copy(d, (const uint4*)(P.dir + ((u64)w * (P.max_cycles + 1)) * 4), (u64)max_cyc + 1, t, nt);
+    d += max_cyc + 1;
+    pack_copy(d, P.tails + (u64)w * P.max_cycles * L, (u64)max_cyc * L, t, nt);
+    d += (u64)max_cyc * L;
+    pack_copy(d, P.deltas + (u64)w * P.cap_delta * 2, n_delta, t, nt);
+    pack_copy(d + n_delta, P.deltas + (u64)w * P.cap_delta * 2 + P.cap_delta, n_delta, t, nt);
+    d += 2ull * n_delta;
+    // ---- memory queries: 12-byte headers as three u32 planes, values of the non-code queries only ----
+    {
+      const u32 q4 = zkw_ceil4(n_mem);
+      uint4* pl_page = d;
+      uint4* pl_index = d + q4;
+      uint4* pl_misc = d + 2ull * q4;
+      uint4* v_lo = d + 3ull * q4;
+      uint4* v_hi = v_lo + n_val;
+      const uint4* src_lo = mem_hdr + P.cap_mem;
+      const uint4* src_hi = mem_hdr + 2ull * P.cap_mem;
+      u32 vbase = 0;
+      for (u32 base = 0; base < q4; base += nt) {  // a thread takes four consecutive records: one 16-byte store per plane
+        const u32 g = base + t;
+        uint4 h[4];
+        bool has[4];
+        for (int j = 0; j < 4; j++) {
+          const u32 i = 4u * g + (u32)j;
+          const bool in = g < q4 && i < n_mem;
+          h[j] = in ? mem_hdr[i] : make_uint4(0, 0, 0, 0);
+          has[j] = in && ((h[j].w >> 16) & ZKW_MQ_TYPE_MASK) != ZKW_MEM_CODE;
+        }
+        if (g < q4) {
+          pl_page[g] = make_uint4(h[0].y, h[1].y, h[2].y, h[3].y);
+          pl_index[g] = make_uint4(h[0].z, h[1].z, h[2].z, h[3].z);
+          pl_misc[g] = make_uint4((h[0].w & 0x00ffffffu) | (h[0].x << 24), (h[1].w & 0x00ffffffu) | (h[1].x << 24), (h[2].w & 0x00ffffffu) | (h[2].x << 24),
+                                  (h[3].w & 0x00ffffffu) | (h[3].x << 24));
+        }
+        // value positions: records in stream order = thread order, then j
+        u32 tot[4], rk[4], tile = 0, mine_before = 0;
+        for (int j = 0; j < 4; j++) rk[j] = pack_flag_scan(has[j], s_wave_counts[j], t, nt, tot[j]);
+        // rank of record (t, j) = sum over j' of flags of threads below t + flags (t, j' < j)
+        u32 below_threads = rk[0] + rk[1] + rk[2] + rk[3];
+        for (int j = 0; j < 4; j++) {
+          if (has[j]) {
+            const u32 at = vbase + below_threads + mine_before;
+            const u32 i = 4u * g + (u32)j;
+            v_lo[at] = src_lo[i];
+            v_hi[at] = src_hi[i];
+            mine_before++;
+          }
+          tile += tot[j];
+        }
+        vbase += tile;
+      }
+      d = v_hi + n_val;
+    }
+    // ---- log queries ----
+    pack_copy(d, P.log_stream + (u64)w * P.cap_log * 8, (u64)n_log * 8, t, nt);
+    d += (u64)n_log * 8;
+    // ---- aux events: each as long as its type uses ----
+    {
+      u32 abase = 0;
+      for (u32 base = 0; base < n_aux; base += nt) {
+        const u32 i = base + t;
+        const u32 used = i < n_aux ? zkw_aux_used_units(aux_src[(u64)i * 16].x & 0xffu) : 0u;
+        s_sums[t] = used;
+        __syncthreads();
+        u32 before = 0, tile = 0;
+        for (u32 k = 0; k < nt; k++) {
+          const u32 c = s_sums[k];
+          if (k < t) before += c;
+          tile += c;
+        }
+        __syncthreads();
+        for (u32 u = 0; u < used; u++) d[abase + before + u] = aux_src[(u64)i * 16 + u];
+        abase += tile;
+      }
+    }
+  }
+}
+
+extern "C" hipError_t zkw_launch_pack(const zkw_pack_args* A, uint32_t wave_threads, uint32_t blocks, hipStream_t stream) {
+  const uint32_t waves = A->only_wave != 0xffffffffu ? 1u : A->wave_base[A->n_batches];
+  if (waves == 0) return hipSuccess;
+  uint32_t g = blocks ? blocks : 64u;
+  if (g > waves) g = waves;
+  hipLaunchKernelGGL(zkw_pack_kernel, dim3(g), dim3(wave_threads > 1 ? ZKW_PACK_THREADS : 1), 0, stream, *A);
+  return hipGetLastError();
+}

@@ -14,18 +14,25 @@
 #include <cstdlib>
 #include <cstring>
 #include <array>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <memory>
 #include <string>
 #include <vector>
 
 #include "zkw_commit.h"
 #include "zkw_device.h"
+#include "zkw_pack.h"
 
 extern "C" hipError_t zkw_launch_cycle_kernel(const zkw_launch_args* A, hipStream_t stream);
 extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_group);
 extern "C" hipError_t zkw_launch_reset_kernel(const zkw_fused_table* T, hipStream_t stream);
 extern "C" hipError_t zkw_launch_commit(const zkw_fused_table* T, int stage, hipStream_t stream);
+extern "C" hipError_t zkw_launch_pack(const zkw_pack_args* A, uint32_t wave_threads, uint32_t blocks, hipStream_t stream);
 extern "C" hipError_t zkw_launch_expand(const zkw_kparams* const* kp, void* const* dst, const uint32_t* n_waves, uint32_t n, uint64_t stride_i, uint64_t stride_k, uint32_t first,
                                         uint32_t count, uint32_t L, uint32_t wave_threads, uint32_t max_cycles_run, uint32_t n_cus, hipStream_t stream);
 
@@ -50,7 +57,7 @@ struct zkw_ctx {
   uint2* d_isa = nullptr;
   std::string last_error;
   // test hooks / ablations (zkw_ctx_set_option; the environment is read once, in zkw_ctx_create)
-  uint32_t opt_debug_flags = 0, opt_reset_skip = 0, opt_waves_per_group = 0, opt_lanes_per_wave = 0;
+  uint32_t opt_debug_flags = 0, opt_reset_skip = 0, opt_waves_per_group = 0, opt_lanes_per_wave = 0, opt_pack_blocks = 0;
   bool opt_no_inline_decommit = false, opt_debug_sync = false, opt_no_graph = false;
   // digests of code blobs already hashed on this context, keyed by a 128-bit content hash + length: batches that
   // share bytecode (the usual case) skip the sequential blob chain (~0.1 s for a 2000-word blob) at upload
@@ -142,6 +149,8 @@ struct zkw_batch {
   DevBuf<uint4> d_blob_words;
   DevBuf<uint2> d_blob_dir;
   DevBuf<zkw_dev_preimage> d_preimages;
+  DevBuf<uint32_t> d_pre_index;  // open addressing over the code hashes (zkw_kparams.pre_index)
+  uint32_t pre_mask = 0;
   // device: outputs
   DevBuf<uint4> d_tails, d_deltas, d_mem, d_log, d_auxs;
   DevBuf<uint32_t> d_wave_cycles, d_heap_dirty, d_storage_dirty;
@@ -180,6 +189,13 @@ struct zkw_batch {
   std::vector<zkw_log_query> ns_st_hist, ns_ev_hist;
   std::vector<zkw_event_message> ns_events, ns_l1;
   std::vector<zkw_storage_slot> ns_final;
+  uint8_t* h_stage = nullptr;    // pinned staging of zkw_batch_restage ([regs | scalars | callstack | heap image])
+  size_t h_stage_bytes = 0;
+  hipEvent_t ev_stage = nullptr;
+  bool stage_busy = false;
+  uint4* h_pack = nullptr;       // pinned block of the on-demand pack (one wave at a time: zkw_batch_get_instance_trace)
+  uint64_t h_pack_units = 0;
+  DevBuf<uint32_t> d_pack_state;  // allocation cursor + overflow flag of the pack kernel
   DevBuf<zkw_reset_params> d_reset_params;    // [1]
   DevBuf<zkw_commit_params> d_commit_params;  // [ZKW_QUEUE_COUNT] + [1] for the blob digests of the upload
 };
@@ -220,7 +236,7 @@ int zkw_ctx_create(int device, zkw_ctx** out) {
     static const struct { const char* name; uint32_t opt; } envs[] = {
         {"ZKW_DEBUG_FLAGS", ZKW_OPT_DEBUG_FLAGS}, {"ZKW_RESET_SKIP", ZKW_OPT_RESET_SKIP}, {"ZKW_NO_INLINE_DECOMMIT", ZKW_OPT_NO_INLINE_DECOMMIT},
 {"ZKW_DEBUG_SYNC", ZKW_OPT_DEBUG_SYNC}, {"ZKW_NO_GRAPH", ZKW_OPT_NO_GRAPH},
-        {"ZKW_WAVES_PER_GROUP", ZKW_OPT_WAVES_PER_GROUP}, {"ZKW_LANES_PER_WAVE", ZKW_OPT_LANES_PER_WAVE}};
+        {"ZKW_WAVES_PER_GROUP", ZKW_OPT_WAVES_PER_GROUP}, {"ZKW_LANES_PER_WAVE", ZKW_OPT_LANES_PER_WAVE}, {"ZKW_PACK_BLOCKS", ZKW_OPT_PACK_BLOCKS}};
     for (const auto& e : envs)
       if (const char* v = getenv(e.name)) {
         const uint64_t val = strtoull(v, nullptr, 0);
@@ -248,6 +264,7 @@ int zkw_ctx_set_option(zkw_ctx* c, uint32_t option, uint64_t value) {
       c->opt_waves_per_group = (uint32_t)value;
       break;
     case ZKW_OPT_LANES_PER_WAVE: c->opt_lanes_per_wave = (uint32_t)value; break;
+    case ZKW_OPT_PACK_BLOCKS: c->opt_pack_blocks = (uint32_t)value; break;
     default: c->last_error = "unknown option"; return ZKW_ERR_INVALID;
   }
   return ZKW_OK;
@@ -349,6 +366,31 @@ int zkw_ctx_set_isa(zkw_ctx* c, const zkw_isa_table* t) {
       c->last_error = "ISA table: a far_call / ret register convention names a register beyond r15";
       return ZKW_ERR_INVALID;
     }
+    // every row of condition_lut is the truth table of one of the eight Conditions over (lt | eq << 1 | gt << 2)
+    // (cycle.rs:193-209: Always, Gt, Lt, Eq, Ge, Le, Ne, GtOrLt) — any other row would be a predicate the reference cannot name
+    static const uint8_t kTruth[8] = {0xff, 0xf0, 0xaa, 0xcc, 0xfc, 0xee, 0x33, 0xfa};
+    for (uint32_t f = 0; f < 8; f++) {
+      const uint8_t row = (uint8_t)(k.condition_lut >> (8 * f));
+      bool known = false;
+      for (uint8_t t8 : kTruth) known = known || row == t8;
+      if (!known) {
+        char buf[96];
+        std::snprintf(buf, sizeof buf, "ISA table: condition_lut row %u (0x%02x) names no Condition", f, (unsigned)row);
+        c->last_error = buf;
+        return ZKW_ERR_INVALID;
+      }
+    }
+    {  // FarCallForwardPageType: three different ABI bytes (far_call.rs:255, ret.rs:59)
+      const uint32_t f0 = k.forwarding_codes & 0xffu, f1 = (k.forwarding_codes >> 8) & 0xffu, f2 = (k.forwarding_codes >> 16) & 0xffu;
+      if (f0 == f1 || f0 == f2 || f1 == f2) {
+        c->last_error = "ISA table: forwarding_codes must be three distinct bytes (UseHeap, ForwardFatPointer, UseAuxHeap)";
+        return ZKW_ERR_INVALID;
+      }
+    }
+    if (k.max_offset_for_add_sub == 0) {  // ptr.rs:47: with 0 every ptr.add / ptr.sub would panic
+      c->last_error = "ISA table: max_offset_for_add_sub is zero";
+      return ZKW_ERR_INVALID;
+    }
   }
   c->isa = *t;
   std::vector<uint2> packed(ZKW_ISA_TABLE_SIZE);
@@ -429,12 +471,15 @@ void zkw_batch_destroy(zkw_batch* b) {
   b->d_regs0.release(); b->d_scalars0.release(); b->d_callstack0.release(); b->d_frames0.release(); b->d_storage0.release(); b->d_heap0.release();
   b->d_regs.release(); b->d_scalars.release(); b->d_callstack.release(); b->d_frames.release(); b->d_storage.release(); b->d_journal.release();
   b->d_history.release(); b->d_stack_vals.release(); b->d_heap.release(); b->d_aux.release(); b->d_stack_ptrs.release(); b->d_blob_words.release();
-  b->d_blob_dir.release(); b->d_preimages.release(); b->d_tails.release(); b->d_deltas.release(); b->d_wave_cycles.release(); b->d_heap_dirty.release(); b->d_storage_dirty.release(); b->d_mem.release(); b->d_log.release(); b->d_auxs.release();
+  b->d_blob_dir.release(); b->d_preimages.release(); b->d_pre_index.release(); b->d_tails.release(); b->d_deltas.release(); b->d_wave_cycles.release(); b->d_heap_dirty.release(); b->d_storage_dirty.release(); b->d_mem.release(); b->d_log.release(); b->d_auxs.release();
   b->d_dir.release(); b->d_cursors.release(); b->d_krow.release(); b->d_kp.release(); b->d_reset_params.release(); b->d_commit_params.release();
   b->d_ns_log_idx.release(); b->d_ns_log_cnt.release(); b->d_ns_aux_idx.release(); b->d_ns_aux_cnt.release(); b->d_ns_st_hist.release();
   b->d_ns_ev_hist.release(); b->d_ns_rb_st.release(); b->d_ns_rb_ev.release(); b->d_ns_marks.release(); b->d_ns_counts.release();
   b->d_ns_bucket_params.release(); b->d_ns_params.release(); b->d_commit.release(); b->d_rc.release(); b->d_blob_digests.release(); b->d_leaves.release(); b->d_midstates.release();
-  b->d_idx.release(); b->d_counts.release(); b->d_dq_count.release(); b->d_dq_prev.release();
+  b->d_idx.release(); b->d_counts.release(); b->d_dq_count.release(); b->d_dq_prev.release(); b->d_pack_state.release();
+  if (b->h_pack) (void)hipHostFree(b->h_pack);
+  if (b->h_stage) (void)hipHostFree(b->h_stage);
+  if (b->ev_stage) (void)hipEventDestroy(b->ev_stage);
   if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
   if (b->graph) (void)hipGraphDestroy(b->graph);
   for (hipEvent_t e : b->evs) (void)hipEventDestroy(e);
@@ -560,6 +605,91 @@ static void entry_to_dev(const zkw_callstack_entry& e, uint32_t blob, uint32_t s
   o->journal_mark = 0;
 }
 
+// The device images of instance i — register file, scalars, callstack rows, frame metas, heap image — written at the
+// instance's places of the batch-wide arrays (zkw_batch_upload formats every instance, zkw_batch_restage the ones it is given;
+// instances write disjoint elements, so host threads may format different instances at once).  `frames` rows must be zeroed.
+static int format_instance(const zkw_batch* b, uint32_t i, uint32_t himg, uint4* regs, zkw_dev_scalars* scal, zkw_dev_entry* stack, zkw_dev_frame_meta* frames, uint4* heap0,
+                           std::string* err) {
+  const StagedInstance& s = b->staged[i];
+  const uint32_t L = b->L, F = b->lim.max_far_frames, D = b->lim.max_callstack_depth;
+  const uint32_t w = i / L, l = i % L;
+  const zkw_vm_local_state& st = s.state;
+  for (int r = 0; r < ZKW_REGISTERS_COUNT; r++) {
+    const uint32_t* v = (const uint32_t*)st.registers[r].l;
+    regs[((size_t)w * ZKW_REG_CHUNKS + 2 * r) * L + l] = make_uint4(v[0], v[1], v[2], v[3]);
+    regs[((size_t)w * ZKW_REG_CHUNKS + 2 * r + 1) * L + l] = make_uint4(v[4], v[5], v[6], v[7]);
+  }
+  zkw_dev_scalars& sc = scal[i];
+  std::memcpy(sc.prev_code_word, st.previous_code_word.l, 32);
+  std::memcpy(sc.ctx_u128_reg, st.context_u128_register, 16);
+  sc.ptr_bitmap = st.register_ptr_bitmap & 0x7fffu;
+  sc.flags = (st.flags & 7u) | (st.pending_exception ? 8u : 0u);
+  sc.prev_code_page = st.previous_code_memory_page;
+  sc.timestamp = st.timestamp;
+  sc.cycle_counter = st.monotonic_cycle_counter;
+  sc.spent_pubdata = st.spent_pubdata_counter;
+  sc.memory_page_counter = st.memory_page_counter;
+  sc.absolute_execution_step = st.absolute_execution_step;
+  sc.ergs_per_pubdata = st.current_ergs_per_pubdata_byte;
+  sc.tx_number = st.tx_number_in_block;
+  sc.prev_super_pc = st.previous_super_pc;
+  sc.depth = st.callstack_depth;
+  sc.status = ZKW_STATUS_RUNNING;
+  sc.n_cycles = 0;
+  sc.first_dynamic_page = st.memory_page_counter;
+  // callstack: entries 0..depth-1 = inner, entry depth = current.  Far frames alive at reset get
+  // arena slots in order (push_bootloader_context's start_global_frame, helpers.rs:306-315).
+  uint32_t next_slot = 0;
+  auto blob_of = [&](uint32_t page) -> int64_t {
+    if (page == 0) return 0;
+    for (auto it = s.code_pages.rbegin(); it != s.code_pages.rend(); ++it)
+      if (it->first == page) return it->second;
+    return -1;
+  };
+  const uint32_t depth = st.callstack_depth;
+  for (uint32_t d = 0; d <= depth; d++) {
+    const zkw_callstack_entry& e = d < depth ? s.inner[d] : st.current;
+    uint32_t slot = 0;
+    if (d > 0) {
+      if (!e.is_local_frame) {
+        if (next_slot >= F) {
+          *err = "initial far frames exceed limits.max_far_frames";
+          return ZKW_ERR_LIMIT;
+        }
+        frames[(size_t)i * F + next_slot].base_page = e.base_memory_page;
+        slot = next_slot++;
+      } else {
+        slot = next_slot ? next_slot - 1 : 0;
+      }
+    }
+    int64_t blob = blob_of(e.code_page);
+    if (blob < 0) {
+      *err = "instance " + std::to_string(i) + ": code page " + std::to_string(e.code_page) + " has no blob (zkw_batch_set_code_page)";
+      return ZKW_ERR_INVALID;
+    }
+    entry_to_dev(e, (uint32_t)blob, slot, &stack[(size_t)i * (D + 1) + d]);
+  }
+  if (next_slot == 0) next_slot = 1;  // slot 0 is reserved even for an already-ended VM
+  sc.n_initial_slots = next_slot;
+  sc.next_slot = next_slot;
+  for (uint32_t k = next_slot; k < F; k++) frames[(size_t)i * F + k].stack_hwm = 0xffffffffu;  // ZKW_SLOT_FREE (zkw_kernels.hip)
+  // heap image of the current frame
+  if (!s.heap.empty()) {
+    const uint32_t cur_slot = stack[(size_t)i * (D + 1) + depth].frame_slot;
+    if (cur_slot != 0) {
+      *err = "zkw_batch_set_heap supports the first far frame only";
+      return ZKW_ERR_INVALID;
+    }
+    frames[(size_t)i * F + cur_slot].heap_hwm = (uint32_t)s.heap.size();
+    for (size_t k = 0; k < s.heap.size(); k++) {
+      const uint32_t* v = (const uint32_t*)s.heap[k].l;
+      heap0[(((size_t)w * himg + k) * 2) * L + l] = make_uint4(v[0], v[1], v[2], v[3]);      // [word][2][L]: low halves,
+      heap0[(((size_t)w * himg + k) * 2 + 1) * L + l] = make_uint4(v[4], v[5], v[6], v[7]);  // then high halves
+    }
+  }
+  return ZKW_OK;
+}
+
 int zkw_batch_upload(zkw_batch* b) {
   if (!b) return ZKW_ERR_INVALID;
   zkw_ctx* c = b->ctx;
@@ -619,6 +749,19 @@ int zkw_batch_upload(zkw_batch* b) {
   }
   HIP_TRY(c, b->d_preimages.alloc(pre.size()));
   HIP_TRY(c, hipMemcpy(b->d_preimages.p, pre.data(), pre.size() * sizeof(zkw_dev_preimage), hipMemcpyHostToDevice));
+  {  // known_hashes as a lookup structure (decommitter.rs:23-28, 52): open addressing over the code hashes, at most half full
+    const uint32_t slots = pow2_ceil(std::max<uint32_t>(4u, 2u * (uint32_t)b->preimages.size()));
+    std::vector<uint32_t> index(slots, 0u);
+    for (size_t i = 0; i < b->preimages.size(); i++) {
+      uint32_t at = zkw_pre_hash(pre[i].hash) & (slots - 1);
+      while (index[at]) at = (at + 1) & (slots - 1);
+      index[at] = (uint32_t)i + 1;
+    }
+    b->pre_mask = slots - 1;
+    b->d_pre_index.release();
+    HIP_TRY(c, b->d_pre_index.alloc(slots));
+    HIP_TRY(c, hipMemcpy(b->d_pre_index.p, index.data(), (size_t)slots * 4, hipMemcpyHostToDevice));
+  }
 
   // ---- blob digests for the decommit-queue commitment, once per upload ----
   {
@@ -709,80 +852,13 @@ int zkw_batch_upload(zkw_batch* b) {
   std::vector<uint4> heap0((size_t)W * himg * L * 2, make_uint4(0, 0, 0, 0));
   for (uint32_t i = 0; i < n; i++) {
     const StagedInstance& s = b->staged[i];
-    const uint32_t w = i / L, l = i % L;
-    const zkw_vm_local_state& st = s.state;
-    for (int r = 0; r < ZKW_REGISTERS_COUNT; r++) {
-      const uint32_t* v = (const uint32_t*)st.registers[r].l;
-      regs[((size_t)w * ZKW_REG_CHUNKS + 2 * r) * L + l] = make_uint4(v[0], v[1], v[2], v[3]);
-      regs[((size_t)w * ZKW_REG_CHUNKS + 2 * r + 1) * L + l] = make_uint4(v[4], v[5], v[6], v[7]);
-    }
-    zkw_dev_scalars& sc = scal[i];
-    std::memcpy(sc.prev_code_word, st.previous_code_word.l, 32);
-    std::memcpy(sc.ctx_u128_reg, st.context_u128_register, 16);
-    sc.ptr_bitmap = st.register_ptr_bitmap & 0x7fffu;
-    sc.flags = (st.flags & 7u) | (st.pending_exception ? 8u : 0u);
-    sc.prev_code_page = st.previous_code_memory_page;
-    sc.timestamp = st.timestamp;
-    sc.cycle_counter = st.monotonic_cycle_counter;
-    sc.spent_pubdata = st.spent_pubdata_counter;
-    sc.memory_page_counter = st.memory_page_counter;
-    sc.absolute_execution_step = st.absolute_execution_step;
-    sc.ergs_per_pubdata = st.current_ergs_per_pubdata_byte;
-    sc.tx_number = st.tx_number_in_block;
-    sc.prev_super_pc = st.previous_super_pc;
-    sc.depth = st.callstack_depth;
-    sc.status = ZKW_STATUS_RUNNING;
-    sc.n_cycles = 0;
-    sc.first_dynamic_page = st.memory_page_counter;
-    // callstack: entries 0..depth-1 = inner, entry depth = current.  Far frames alive at reset get
-    // arena slots in order (push_bootloader_context's start_global_frame, helpers.rs:306-315).
-    uint32_t next_slot = 0;
-    auto blob_of = [&](uint32_t page) -> int64_t {
-      if (page == 0) return 0;
-      for (auto it = s.code_pages.rbegin(); it != s.code_pages.rend(); ++it)
-        if (it->first == page) return it->second;
-      return -1;
-    };
-    const uint32_t depth = st.callstack_depth;
-    b->max_initial_depth = std::max(b->max_initial_depth, depth);
-    for (uint32_t d = 0; d <= depth; d++) {
-      const zkw_callstack_entry& e = d < depth ? s.inner[d] : st.current;
-      uint32_t slot = 0;
-      if (d > 0) {
-        if (!e.is_local_frame) {
-          if (next_slot >= F) {
-            c->last_error = "initial far frames exceed limits.max_far_frames";
-            return ZKW_ERR_LIMIT;
-          }
-          frames[(size_t)i * F + next_slot].base_page = e.base_memory_page;
-          slot = next_slot++;
-        } else {
-          slot = next_slot ? next_slot - 1 : 0;
-        }
-      }
-      int64_t blob = blob_of(e.code_page);
-      if (blob < 0) {
-        c->last_error = "instance " + std::to_string(i) + ": code page " + std::to_string(e.code_page) + " has no blob (zkw_batch_set_code_page)";
-        return ZKW_ERR_INVALID;
-      }
-      entry_to_dev(e, (uint32_t)blob, slot, &stack[(size_t)i * (D + 1) + d]);
-    }
-    if (next_slot == 0) next_slot = 1;  // slot 0 is reserved even for an already-ended VM
-    sc.n_initial_slots = next_slot;
-    sc.next_slot = next_slot;
-    for (uint32_t k = next_slot; k < F; k++) frames[(size_t)i * F + k].stack_hwm = 0xffffffffu;  // ZKW_SLOT_FREE (zkw_kernels.hip)
-    // heap image of the current frame
-    if (!s.heap.empty()) {
-      const uint32_t cur_slot = stack[(size_t)i * (D + 1) + depth].frame_slot;
-      if (cur_slot != 0) {
-        c->last_error = "zkw_batch_set_heap supports the first far frame only";
-        return ZKW_ERR_INVALID;
-      }
-      frames[(size_t)i * F + cur_slot].heap_hwm = (uint32_t)s.heap.size();
-      for (size_t k = 0; k < s.heap.size(); k++) {
-        const uint32_t* v = (const uint32_t*)s.heap[k].l;
-        heap0[(((size_t)w * himg + k) * 2) * L + l] = make_uint4(v[0], v[1], v[2], v[3]);      // [word][2][L]: low halves,
-        heap0[(((size_t)w * himg + k) * 2 + 1) * L + l] = make_uint4(v[4], v[5], v[6], v[7]);  // then high halves
+    b->max_initial_depth = std::max(b->max_initial_depth, s.state.callstack_depth);
+    {
+      std::string err;
+      const int frc = format_instance(b, i, himg, regs.data(), scal.data(), stack.data(), frames.data(), heap0.data(), &err);
+      if (frc != ZKW_OK) {
+        c->last_error = err;
+        return frc;
       }
     }
     // storage snapshot
@@ -832,7 +908,9 @@ int zkw_batch_upload(zkw_batch* b) {
   HIP_TRY(c, ensure(b->d_frames, frames.size()));
   HIP_TRY(c, ensure(b->d_storage, storage.size()));
   HIP_TRY(c, ensure(b->d_journal, (size_t)n * lim.storage_journal));
-  HIP_TRY(c, ensure(b->d_history, (size_t)n * F));
+  const uint32_t hist_pitch = std::max<uint32_t>(1u, (uint32_t)b->preimages.size());  // one row per known code hash: 8 bytes, half a 16-byte unit — pitch rounded to even
+  const uint32_t hist_pitch2 = (hist_pitch + 1u) & ~1u;
+  HIP_TRY(c, ensure(b->d_history, (size_t)n * hist_pitch2));
   HIP_TRY(c, ensure(b->d_stack_vals, (size_t)W * F * lim.stack_words * L * 2));
   HIP_TRY(c, ensure(b->d_stack_ptrs, (size_t)W * F * lim.stack_words * L));
   HIP_TRY(c, ensure(b->d_heap, (size_t)W * F * lim.heap_words * L * 2));
@@ -871,7 +949,8 @@ int zkw_batch_upload(zkw_batch* b) {
   P.krow = b->d_krow.p;
   P.regs = b->d_regs.p; P.scalars = b->d_scalars.p; P.callstack = b->d_callstack.p; P.frames = b->d_frames.p;
   P.stack_vals = b->d_stack_vals.p; P.stack_ptrs = b->d_stack_ptrs.p; P.heap = b->d_heap.p; P.aux_heap = b->d_aux.p;
-  P.storage = b->d_storage.p; P.journal = b->d_journal.p; P.history = b->d_history.p;
+  P.storage = b->d_storage.p; P.journal = b->d_journal.p; P.history = b->d_history.p; P.hist_pitch = hist_pitch2;
+  P.pre_index = b->d_pre_index.p; P.pre_mask = b->pre_mask;
   P.blob_words = b->d_blob_words.p; P.blob_dir = b->d_blob_dir.p; P.preimages = b->d_preimages.p;
   P.commit_rc = b->d_rc.p; P.midstates = b->d_midstates.p; P.blob_digests = b->d_blob_digests.p; P.commit_out = b->d_commit.p; P.dq_count = b->d_dq_count.p; P.dq_prev = b->d_dq_prev.p;
   P.tails = b->d_tails.p; P.deltas = b->d_deltas.p; P.wave_cycles = b->d_wave_cycles.p; P.cap_delta = b->cap_delta; P.heap_dirty = b->d_heap_dirty.p; P.heap_image_words = b->heap_image_words; P.mem_stream = b->d_mem.p; P.log_stream = b->d_log.p; P.aux_stream = b->d_auxs.p;
@@ -901,6 +980,7 @@ int zkw_batch_upload(zkw_batch* b) {
     R.heap_dirty = b->d_heap_dirty.p; R.image_words = b->heap_image_words; R.L = b->L;
     R.commit_out = b->d_commit.p; R.dq_count = b->d_dq_count.p; R.n_instances = b->n;
     R.storage_slots = b->lim.storage_slots; R.storage_dirty = b->d_storage_dirty.p;
+    R.history = (uint4*)b->d_history.p; R.history16 = (uint32_t)(b->d_history.bytes() / 16);
     HIP_TRY(c, ensure(b->d_reset_params, 1));
     HIP_TRY(c, hipMemcpy(b->d_reset_params.p, &R, sizeof R, hipMemcpyHostToDevice));
     const uint32_t caps[3] = {b->cap_mem, b->cap_log, b->cap_aux};
@@ -1313,6 +1393,7 @@ int zkw_batch_download_all(zkw_batch* b, uint64_t* n_bytes, double* ms) {
   return ZKW_OK;
 }
 
+
 int zkw_batch_get_stats(zkw_batch* b, zkw_run_stats* out) {
   if (!b || !out) return ZKW_ERR_INVALID;
   if (!b->synced) {
@@ -1336,159 +1417,422 @@ int zkw_batch_get_stats(zkw_batch* b, zkw_run_stats* out) {
   return ZKW_OK;
 }
 
-static int build_wave(zkw_batch* b, uint32_t w) {
-  zkw_ctx* c = b->ctx;
-  const uint32_t L = b->L, MC = b->lim.max_cycles;
-  auto wt = std::make_unique<WaveTrace>();
-  wt->records.resize(L); wt->mem.resize(L); wt->log.resize(L); wt->aux.resize(L);
-  wt->mem_off.resize(L); wt->log_off.resize(L); wt->aux_off.resize(L);
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Host rebuild of a wave's witness from the link format (zkw_pack.h): ONE walk over the packed streams of a wave, cycle by
+// cycle, that keeps the current 512-byte snapshot of every lane (initial register file + the deltas applied so far), gives
+// every lane its queries of the cycle in emission order, and hands both to a sink.  Two sinks: the materialising one behind
+// zkw_batch_get_instance_trace / zkw_delivery_get_instance_trace (per-instance arrays, as the C ABI returns them) and the
+// streaming one behind zkw_delivery_replay (a callback per instance and cycle with a pointer to the live snapshot — what
+// start_new_execution_cycle(&local_state) / end_execution_cycle(&local_state) are in the reference, witness_trace/mod.rs:11-20:
+// a reference to the VM's state, not a copy per cycle).  Read-only on the batch: any number of threads may walk different
+// waves at once.
+// ---------------------------------------------------------------------------------------------------------------------
+struct WaveView {  // host pointers to the packed data of one wave
+  uint32_t L = 0, max_cyc = 0, n_delta = 0, n_mem = 0, n_val = 0, n_log = 0, n_aux = 0, aux_units = 0;
+  const uint32_t* dir = nullptr;
+  const uint4 *tails = nullptr, *dlo = nullptr, *dhi = nullptr;
+  const uint32_t *m_page = nullptr, *m_index = nullptr, *m_misc = nullptr;
+  const uint4 *v_lo = nullptr, *v_hi = nullptr, *log = nullptr, *aux = nullptr;
+};
+
+static bool wave_view(const uint4* block, const zkw_pack_wave& e, uint32_t L, WaveView& v) {
+  if (e.off == 0) return false;
+  v.L = L; v.max_cyc = e.max_cyc; v.n_delta = e.n_delta; v.n_mem = e.n_mem; v.n_val = e.n_val; v.n_log = e.n_log; v.n_aux = e.n_aux; v.aux_units = e.aux_units;
+  const uint4* d = block + e.off;
+  v.dir = (const uint32_t*)d; d += e.max_cyc + 1;
+  v.tails = d; d += (size_t)e.max_cyc * L;
+  v.dlo = d; v.dhi = d + e.n_delta; d += 2 * (size_t)e.n_delta;
+  const uint32_t q4 = zkw_ceil4(e.n_mem);
+  v.m_page = (const uint32_t*)d; v.m_index = (const uint32_t*)(d + q4); v.m_misc = (const uint32_t*)(d + 2 * (size_t)q4); d += 3 * (size_t)q4;
+  v.v_lo = d; v.v_hi = d + e.n_val; d += 2 * (size_t)e.n_val;
+  v.log = d; d += (size_t)e.n_log * 8;
+  v.aux = d;
+  return true;
+}
+
+// what a sink sees of one instance in one cycle; the arrays live until the next call
+struct CycleView {
+  uint32_t lane, cycle;
+  const zkw_cycle_record* record;
+  const zkw_mem_query* mem; uint32_t n_mem;
+  const zkw_log_query* log; uint32_t n_log;
+  const zkw_aux_event* aux; uint32_t n_aux;
+};
+
+template <class Sink>
+static void walk_wave(const zkw_batch* b, uint32_t w, const WaveView& v, const uint32_t* ncyc, Sink& sink) {
+  const zkw_ctx* c = b->ctx;
+  const uint32_t L = v.L;
   uint32_t max_cycles_lane = 0;
-  std::vector<uint32_t> ncyc(L, 0);
-  for (uint32_t l = 0; l < L; l++) {
-    const uint32_t i = w * L + l;
-    if (i < b->n) ncyc[l] = b->h_scalars[i].n_cycles;
-    max_cycles_lane = std::max(max_cycles_lane, ncyc[l]);
-  }
-  // directory + streams of this wave
-  std::vector<uint32_t> dir((size_t)(MC + 1) * 4);
-  HIP_TRY(c, hipMemcpy(dir.data(), b->d_dir.p + (size_t)w * (MC + 1) * 4, dir.size() * 4, hipMemcpyDeviceToHost));
-  const uint32_t n_mem = std::min(b->h_cursors[(size_t)w * 4 + 0], b->cap_mem);
-  const uint32_t n_log = std::min(b->h_cursors[(size_t)w * 4 + 1], b->cap_log);
-  const uint32_t n_aux = std::min(b->h_cursors[(size_t)w * 4 + 2], b->cap_aux);
-  std::vector<zkw_mem_query> mem(n_mem);
-  std::vector<zkw_log_query> log(n_log);
-  std::vector<zkw_aux_event> aux(n_aux);
-  if (n_mem) {  // the stream is stored as three planes of 16-byte units (header | value low | value high)
-    std::vector<uint4> planes((size_t)n_mem * 3);
-    for (int pl = 0; pl < 3; pl++)
-      HIP_TRY(c, hipMemcpy(planes.data() + (size_t)pl * n_mem, b->d_mem.p + ((size_t)w * 3 + pl) * b->cap_mem, (size_t)n_mem * 16, hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < n_mem; i++) {
-      uint4* q = (uint4*)&mem[i];
-      q[0] = planes[i]; q[1] = planes[(size_t)n_mem + i]; q[2] = planes[(size_t)2 * n_mem + i];
+  for (uint32_t l = 0; l < L; l++) max_cycles_lane = std::max(max_cycles_lane, ncyc[l]);
+  max_cycles_lane = std::min(max_cycles_lane, v.max_cyc);
+  // aux records sit back to back, each as long as its type uses: expand them once (zeros behind the used part, as the ABI has it)
+  std::vector<zkw_aux_event> aux(v.n_aux);
+  {
+    const uint4* a = v.aux;
+    for (uint32_t i = 0; i < v.n_aux; i++) {
+      const uint32_t used = zkw_aux_used_units(a->x & 0xffu);
+      std::memset(&aux[i], 0, sizeof(zkw_aux_event));
+      std::memcpy(&aux[i], a, (size_t)used * 16);
+      a += used;
     }
   }
-  if (n_log) HIP_TRY(c, hipMemcpy(log.data(), b->d_log.p + (size_t)w * b->cap_log * 8, (size_t)n_log * 128, hipMemcpyDeviceToHost));
-  if (n_aux) HIP_TRY(c, hipMemcpy(aux.data(), b->d_auxs.p + (size_t)w * b->cap_aux * 16, (size_t)n_aux * 256, hipMemcpyDeviceToHost));
-  for (uint32_t i = 0; i < n_aux; i++) {  // the kernel writes only the bytes a record type uses: the rest of the 256 bytes is zero in the ABI
-    const uint32_t used = aux[i].type == ZKW_AUX_FRAME_START ? 240u : aux[i].type == ZKW_AUX_DECOMMIT ? 64u : aux[i].type == ZKW_AUX_COLD_STATE ? 48u : 16u;
-    std::memset((uint8_t*)&aux[i] + used, 0, 256 - used);
+  // code pages of every lane: what the host staged + what the run decommitted (page -> blob; a page number is never reused).
+  // A Code query's value does not travel (zkw_pack.h): it is word `index` of the page's blob, zero beyond its length
+  // (memory.rs:556-569 read_code_query on a page populated by populate_code / the decommitter, decommitter.rs:81-96).
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> pages(L);
+  for (uint32_t l = 0; l < L; l++) {
+    const uint32_t inst = w * L + l;
+    if (inst >= b->n) continue;
+    for (const auto& pg : b->staged[inst].code_pages) pages[l].push_back(pg);  // (later registrations win: searched from the back)
   }
-  // records: tails [cycle][L] (16 B) + the deltas of the wave; the 512-byte snapshots are rebuilt from the initial state
-  // by replaying every lane's deltas (positions from the 16-bit masks in the tails, see zkw_cycle_kernel): bits 0..14 the
-  // registers the cycle wrote, bit 15 the slow half of the tail (heap bound, aux-heap bound, callstack depth).  Two tail
-  // fields are not stored at all: the timestamp advances by time_delta_per_cycle with every completed cycle
-  // (cycle.rs:408-411), and previous_super_pc after a cycle is the super-pc that cycle started from — the pc of the record
-  // before it (cycle.rs:84,113: set on every fetch and on every pending exception, and left alone only when it already
-  // equals it).
-  std::vector<uint4> tails((size_t)max_cycles_lane * L);
-  if (max_cycles_lane)
-    HIP_TRY(c, hipMemcpy(tails.data(), b->d_tails.p + (size_t)w * MC * L, tails.size() * sizeof(uint4), hipMemcpyDeviceToHost));
-  const uint32_t n_delta = std::min(b->h_cursors[(size_t)w * 4 + 3], b->cap_delta);
-  std::vector<uint4> deltas((size_t)n_delta * 2);  // [2][n_delta]: the used extents of the two planes
-  if (n_delta) {
-    HIP_TRY(c, hipMemcpy(deltas.data(), b->d_deltas.p + (size_t)w * b->cap_delta * 2, (size_t)n_delta * sizeof(uint4), hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(deltas.data() + n_delta, b->d_deltas.p + (size_t)w * b->cap_delta * 2 + b->cap_delta, (size_t)n_delta * sizeof(uint4), hipMemcpyDeviceToHost));
-  }
-  std::vector<uint4> regs0((size_t)ZKW_REG_CHUNKS * L);
-  HIP_TRY(c, hipMemcpy(regs0.data(), b->d_regs0.p + (size_t)w * ZKW_REG_CHUNKS * L, regs0.size() * sizeof(uint4), hipMemcpyDeviceToHost));
-  std::vector<std::array<uint4, ZKW_REG_CHUNKS>> cur(L);
+  for (uint32_t i = 0; i < v.n_aux; i++)
+    if (aux[i].type == ZKW_AUX_DECOMMIT && aux[i].lane < L) pages[aux[i].lane].emplace_back(aux[i].b, aux[i].c >> 16);
+  auto code_word = [&](uint32_t l, uint32_t page, uint32_t index, zkw_u256* out) {
+    std::memset(out, 0, sizeof *out);
+    const auto& pv = pages[l];
+    for (size_t k = pv.size(); k-- > 0;)
+      if (pv[k].first == page) {
+        const auto& blob = b->blobs[pv[k].second < b->blobs.size() ? pv[k].second : 0];
+        if (index < blob.size()) *out = blob[index];
+        return;
+      }
+  };
+  // the live snapshots: registers from the staged initial state, the slow tail fields beside them
+  std::vector<zkw_cycle_record> cur(L);
   struct Slow { uint32_t heap_bound, aux_bound, depth, timestamp, pc; };
   std::vector<Slow> slow(L);
   const uint32_t time_delta = c->isa.consts.time_delta_per_cycle;
   for (uint32_t l = 0; l < L; l++) {
-    wt->records[l].resize(ncyc[l]);
-    for (uint32_t ch = 0; ch < ZKW_REG_CHUNKS; ch++) cur[l][ch] = regs0[(size_t)ch * L + l];
+    std::memset(&cur[l], 0, sizeof(zkw_cycle_record));
     const uint32_t inst = w * L + l;
     if (inst < b->n) {
       const zkw_vm_local_state& st0 = b->staged[inst].state;
+      std::memcpy(cur[l].registers, st0.registers, sizeof st0.registers);
       slow[l] = Slow{st0.current.heap_bound, st0.current.aux_heap_bound, st0.callstack_depth, st0.timestamp, st0.current.pc};
+    } else {
+      slow[l] = Slow{0, 0, 0, 0, 0};
     }
   }
-  {
-    std::vector<uint32_t> mask(L), cnt(L);
-    for (uint32_t k = 0; k < max_cycles_lane; k++) {
-      const uint32_t base = dir[(size_t)k * 4 + 3];
-      uint32_t max_cnt = 0;
+  std::vector<uint32_t> mask(L), cnt_m(L + 1), cnt_l(L + 1), cnt_a(L + 1), fill(L);
+  std::vector<zkw_mem_query> cm;
+  std::vector<zkw_log_query> cl;
+  std::vector<zkw_aux_event> ca;
+  uint32_t vpos = 0;  // next entry of the value planes (the queries that are no Code reads, in stream order)
+  uint32_t pm = 0;    // next memory query of the stream
+  for (uint32_t k = 0; k < max_cycles_lane; k++) {
+    const uint32_t* d0 = v.dir + (size_t)k * 4;
+    const uint32_t* d1 = v.dir + (size_t)(k + 1) * 4;
+    // ---- the cycle's register deltas: by mask bit (ascending), lanes in lane order within a bit (zkw_cycle_kernel) ----
+    uint32_t any = 0;
+    for (uint32_t l = 0; l < L; l++) {
+      mask[l] = 0;
+      if (k >= ncyc[l]) continue;
+      const uint4 t0 = v.tails[(size_t)k * L + l];
+      mask[l] = (t0.x >> 24) | ((t0.w >> 24) << 8);
+      any |= mask[l];
+    }
+    uint32_t pos = d0[3];
+    for (uint32_t r = 0; r < ZKW_REGISTERS_COUNT + 1 && (any >> r); r++) {
+      if (!((any >> r) & 1u)) continue;
       for (uint32_t l = 0; l < L; l++) {
-        mask[l] = 0; cnt[l] = 0;
-        if (k >= ncyc[l]) continue;
-        const uint4 t0 = tails[(size_t)k * L + l];
-        mask[l] = (t0.x >> 24) | ((t0.w >> 24) << 8);
-        cnt[l] = (uint32_t)__builtin_popcount(mask[l]);
-        max_cnt = std::max(max_cnt, cnt[l]);
-      }
-      // order inside a wave-cycle: by mask bit (ascending), lanes in lane order within a bit (zkw_cycle_kernel)
-      uint32_t pos = base;
-      for (uint32_t r = 0; r < ZKW_REGISTERS_COUNT + 1 && max_cnt; r++) {
-        for (uint32_t l = 0; l < L; l++) {
-          if (!((mask[l] >> r) & 1u)) continue;
-          if (pos < n_delta) {
-            if (r < ZKW_REGISTERS_COUNT) {
-              cur[l][2 * r] = deltas[(size_t)pos];
-              cur[l][2 * r + 1] = deltas[(size_t)n_delta + pos];
-            } else {
-              const uint4 v = deltas[(size_t)pos];
-              slow[l].heap_bound = v.x; slow[l].aux_bound = v.y; slow[l].depth = v.z;
-            }
+        if (!((mask[l] >> r) & 1u)) continue;
+        if (pos < v.n_delta) {
+          if (r < ZKW_REGISTERS_COUNT) {
+            std::memcpy(&cur[l].registers[r].l[0], &v.dlo[pos], 16);
+            std::memcpy(&cur[l].registers[r].l[2], &v.dhi[pos], 16);
+          } else {
+            const uint4 sv = v.dlo[pos];
+            slow[l].heap_bound = sv.x; slow[l].aux_bound = sv.y; slow[l].depth = sv.z;
           }
-          pos++;
         }
-      }
-      for (uint32_t l = 0; l < L; l++) {
-        if (k >= ncyc[l]) continue;
-        uint4* dst = (uint4*)&wt->records[l][k];
-        for (uint32_t ch = 0; ch < ZKW_REG_CHUNKS; ch++) dst[ch] = cur[l][ch];
-        const uint4 t0 = tails[(size_t)k * L + l];
-        const uint32_t super_pc = (slow[l].pc & 0xffffu) >> 2;  // of the pc this cycle started from
-        slow[l].timestamp += time_delta;
-        slow[l].pc = t0.y & 0xffffu;
-        // (the delta mask is device bookkeeping: reserved byte and top byte of the counts are zero in the ABI)
-        dst[30] = make_uint4(t0.x & 0x00ffffffu, t0.y, t0.z, slow[l].timestamp);
-        dst[31] = make_uint4(slow[l].heap_bound, slow[l].aux_bound, (slow[l].depth & 0xffffu) | (super_pc << 16), t0.w & 0x00ffffffu);
+        pos++;
       }
     }
+    // ---- the cycle's queries, bucketed by lane (stream order preserves each lane's order): count, place ----
+    const uint32_t m0 = std::min(d0[0], v.n_mem), m1 = std::min(d1[0], v.n_mem);
+    const uint32_t l0 = std::min(d0[1], v.n_log), l1 = std::min(d1[1], v.n_log);
+    const uint32_t a0 = std::min(d0[2], v.n_aux), a1 = std::min(d1[2], v.n_aux);
+    std::fill(cnt_m.begin(), cnt_m.end(), 0u); std::fill(cnt_l.begin(), cnt_l.end(), 0u); std::fill(cnt_a.begin(), cnt_a.end(), 0u);
+    auto live = [&](uint32_t l) { return l < L && k < ncyc[l]; };
+    for (uint32_t p = m0; p < m1; p++) { const uint32_t l = v.m_misc[p] & 0xffu; if (live(l)) cnt_m[l + 1]++; }
+    for (uint32_t p = l0; p < l1; p++) { const uint32_t l = ((const zkw_log_query*)v.log)[p].lane; if (live(l)) cnt_l[l + 1]++; }
+    for (uint32_t p = a0; p < a1; p++) { const uint32_t l = aux[p].lane; if (live(l)) cnt_a[l + 1]++; }
+    for (uint32_t l = 0; l < L; l++) { cnt_m[l + 1] += cnt_m[l]; cnt_l[l + 1] += cnt_l[l]; cnt_a[l + 1] += cnt_a[l]; }
+    cm.resize(cnt_m[L]); cl.resize(cnt_l[L]); ca.resize(cnt_a[L]);
+    // (memory queries of earlier stream positions that belong to no cycle range cannot exist: the ranges tile the stream)
+    for (; pm < m0; pm++) if (((v.m_misc[pm] >> 16) & ZKW_MQ_TYPE_MASK) != ZKW_MEM_CODE) vpos++;
+    std::fill(fill.begin(), fill.end(), 0u);
+    for (uint32_t p = m0; p < m1; p++, pm++) {
+      const uint32_t misc = v.m_misc[p], l = misc & 0xffu, meta = (misc >> 16) & 0xffu;
+      const bool is_code = (meta & ZKW_MQ_TYPE_MASK) == ZKW_MEM_CODE;
+      const uint32_t vi = is_code ? 0u : vpos++;
+      if (!live(l)) continue;
+      zkw_mem_query& q = cm[cnt_m[l] + fill[l]++];
+      const uint32_t cycle_ts = slow[l].timestamp;  // the lane's timestamp at the start of this cycle
+      q.timestamp = cycle_ts + (((misc >> 24) - cycle_ts) & 0xffu);
+      q.page = v.m_page[p]; q.index = v.m_index[p];
+      q.lane = 0; q.seq = (uint8_t)(misc >> 8); q.meta = (uint8_t)meta; q.reserved0 = 0;
+      if (is_code) code_word(l, q.page, q.index, &q.value);
+      else if (vi < v.n_val) { std::memcpy(&q.value.l[0], &v.v_lo[vi], 16); std::memcpy(&q.value.l[2], &v.v_hi[vi], 16); }
+      else std::memset(&q.value, 0, sizeof q.value);
+    }
+    std::fill(fill.begin(), fill.end(), 0u);
+    for (uint32_t p = l0; p < l1; p++) {
+      const zkw_log_query& src = ((const zkw_log_query*)v.log)[p];
+      const uint32_t l = src.lane;
+      if (!live(l)) continue;
+      zkw_log_query& q = cl[cnt_l[l] + fill[l]++];
+      q = src;
+      q.lane = 0;
+    }
+    std::fill(fill.begin(), fill.end(), 0u);
+    for (uint32_t p = a0; p < a1; p++) {
+      const uint32_t l = aux[p].lane;
+      if (!live(l)) continue;
+      zkw_aux_event& q = ca[cnt_a[l] + fill[l]++];
+      q = aux[p];
+      q.lane = 0;
+    }
+    // ---- the tails, then the sink ----
+    for (uint32_t l = 0; l < L; l++) {
+      if (k >= ncyc[l]) continue;
+      const uint4 t0 = v.tails[(size_t)k * L + l];
+      const uint32_t super_pc = (slow[l].pc & 0xffffu) >> 2;  // of the pc this cycle started from
+      slow[l].timestamp += time_delta;
+      slow[l].pc = t0.y & 0xffffu;
+      // (the delta mask is device bookkeeping: reserved byte and top byte of the counts are zero in the ABI)
+      uint4* tl = (uint4*)&cur[l].tail;
+      tl[0] = make_uint4(t0.x & 0x00ffffffu, t0.y, t0.z, slow[l].timestamp);
+      tl[1] = make_uint4(slow[l].heap_bound, slow[l].aux_bound, (slow[l].depth & 0xffffu) | (super_pc << 16), t0.w & 0x00ffffffu);
+      CycleView cv;
+      cv.lane = l; cv.cycle = k; cv.record = &cur[l];
+      cv.mem = cm.data() + cnt_m[l]; cv.n_mem = cnt_m[l + 1] - cnt_m[l];
+      cv.log = cl.data() + cnt_l[l]; cv.n_log = cnt_l[l + 1] - cnt_l[l];
+      cv.aux = ca.data() + cnt_a[l]; cv.n_aux = cnt_a[l + 1] - cnt_a[l];
+      sink.cycle(cv);
+    }
   }
+}
+
+struct MaterialiseSink {  // -> the per-instance arrays of zkw_instance_trace
+  WaveTrace& wt;
+  void cycle(const CycleView& cv) {
+    const uint32_t l = cv.lane;
+    wt.records[l].push_back(*cv.record);
+    wt.mem[l].insert(wt.mem[l].end(), cv.mem, cv.mem + cv.n_mem);
+    wt.log[l].insert(wt.log[l].end(), cv.log, cv.log + cv.n_log);
+    wt.aux[l].insert(wt.aux[l].end(), cv.aux, cv.aux + cv.n_aux);
+    wt.mem_off[l].push_back((uint32_t)wt.mem[l].size());
+    wt.log_off[l].push_back((uint32_t)wt.log[l].size());
+    wt.aux_off[l].push_back((uint32_t)wt.aux[l].size());
+  }
+};
+
+static std::unique_ptr<WaveTrace> materialise_wave(const zkw_batch* b, uint32_t w, const WaveView& v, const uint32_t* ncyc) {
+  const uint32_t L = v.L;
+  auto wt = std::make_unique<WaveTrace>();
+  wt->records.resize(L); wt->mem.resize(L); wt->log.resize(L); wt->aux.resize(L);
+  wt->mem_off.resize(L); wt->log_off.resize(L); wt->aux_off.resize(L);
   for (uint32_t l = 0; l < L; l++) {
+    wt->records[l].reserve(ncyc[l]);
+    wt->mem_off[l].reserve(ncyc[l] + 1); wt->log_off[l].reserve(ncyc[l] + 1); wt->aux_off[l].reserve(ncyc[l] + 1);
     wt->mem_off[l].assign(1, 0); wt->log_off[l].assign(1, 0); wt->aux_off[l].assign(1, 0);
   }
-  // bucket the stream records by lane, cycle by cycle (stream order preserves each lane's order)
-  for (uint32_t k = 0; k < max_cycles_lane; k++) {
-    const uint32_t* d0 = &dir[(size_t)k * 4];
-    const uint32_t* d1 = &dir[(size_t)(k + 1) * 4];
-    for (uint32_t p = std::min(d0[0], n_mem); p < std::min(d1[0], n_mem); p++) {
-      const uint32_t l = mem[p].lane;
-      if (l < L && k < ncyc[l]) {
-        zkw_mem_query q = mem[p];
-        q.lane = 0;
-        wt->mem[l].push_back(q);
-      }
-    }
-    for (uint32_t p = std::min(d0[1], n_log); p < std::min(d1[1], n_log); p++) {
-      const uint32_t l = log[p].lane;
-      if (l < L && k < ncyc[l]) {
-        zkw_log_query q = log[p];
-        q.lane = 0;
-        wt->log[l].push_back(q);
-      }
-    }
-    for (uint32_t p = std::min(d0[2], n_aux); p < std::min(d1[2], n_aux); p++) {
-      const uint32_t l = aux[p].lane;
-      if (l < L && k < ncyc[l]) {
-        zkw_aux_event q = aux[p];
-        q.lane = 0;
-        wt->aux[l].push_back(q);
-      }
-    }
-    for (uint32_t l = 0; l < L; l++)
-      if (k < ncyc[l]) {
-        wt->mem_off[l].push_back((uint32_t)wt->mem[l].size());
-        wt->log_off[l].push_back((uint32_t)wt->log[l].size());
-        wt->aux_off[l].push_back((uint32_t)wt->aux[l].size());
-      }
+  MaterialiseSink sink{*wt};
+  walk_wave(b, w, v, ncyc, sink);
+  return wt;
+}
+
+// zkw_instance_trace.final_state from the device's scalars, the lane's 30 register chunks (`stride` units apart) and its
+// current callstack entry
+static void fill_final_state(zkw_vm_local_state* out, const zkw_dev_scalars& sc, const uint4* regs, size_t stride, const zkw_dev_entry& cur) {
+  zkw_vm_local_state& fs = *out;
+  std::memcpy(fs.previous_code_word.l, sc.prev_code_word, 32);
+  for (uint32_t ch = 0; ch < ZKW_REG_CHUNKS; ch++) std::memcpy((uint8_t*)fs.registers + 16 * ch, &regs[ch * stride], 16);
+  fs.register_ptr_bitmap = (uint16_t)sc.ptr_bitmap;
+  fs.flags = sc.flags & 7u;
+  fs.pending_exception = (sc.flags >> 3) & 1u;
+  fs.previous_code_memory_page = sc.prev_code_page;
+  fs.timestamp = sc.timestamp;
+  fs.monotonic_cycle_counter = sc.cycle_counter;
+  fs.spent_pubdata_counter = sc.spent_pubdata;
+  fs.memory_page_counter = sc.memory_page_counter;
+  fs.absolute_execution_step = sc.absolute_execution_step;
+  fs.current_ergs_per_pubdata_byte = sc.ergs_per_pubdata;
+  fs.tx_number_in_block = (uint16_t)sc.tx_number;
+  fs.previous_super_pc = (uint16_t)sc.prev_super_pc;
+  fs.callstack_depth = sc.depth;
+  std::memcpy(fs.context_u128_register, sc.ctx_u128_reg, 16);
+  fs.current = cur.e;
+}
+
+// The on-demand path of zkw_batch_get_instance_trace: ONE wave of a synced batch through the pack kernel into a pinned block
+// of the batch (grown on demand), then the same rebuild as a delivered step — every parity test that reads a trace runs the
+// pack kernel and the link-format rebuild.
+static int build_wave(zkw_batch* b, uint32_t w) {
+  zkw_ctx* c = b->ctx;
+  const uint32_t L = b->L;
+  std::vector<uint32_t> ncyc(L, 0);
+  for (uint32_t l = 0; l < L; l++) {
+    const uint32_t i = w * L + l;
+    if (i < b->n) ncyc[l] = b->h_scalars[i].n_cycles;
   }
-  b->wave_cache[w] = std::move(wt);
+  // capacity: everything the wave's streams hold (the cursors are on the host since zkw_batch_sync)
+  const uint32_t* hc = &b->h_cursors[(size_t)w * 4];
+  const uint32_t n_mem = std::min(hc[0], b->cap_mem), n_log = std::min(hc[1], b->cap_log), n_aux = std::min(hc[2], b->cap_aux), n_delta = std::min(hc[3], b->cap_delta);
+  const uint64_t fixed = ZKW_PACK_HEADER_UNITS + ZKW_PACK_BATCH_UNITS + ZKW_PACK_WAVE_UNITS;
+  const uint64_t need = fixed + zkw_pack_wave_units(b->lim.max_cycles, L, n_delta, n_mem, n_mem, n_log, 16u * n_aux) + 16;
+  if (need >= (1ull << 32)) {
+    c->last_error = "wave trace beyond 64 GB";
+    return ZKW_ERR_LIMIT;
+  }
+  if (b->h_pack_units < need) {
+    if (b->h_pack) (void)hipHostFree(b->h_pack);
+    b->h_pack = nullptr;
+    HIP_TRY(c, hipHostMalloc((void**)&b->h_pack, (size_t)need * 16, hipHostMallocDefault));
+    b->h_pack_units = need;
+  }
+  if (!b->d_pack_state.p) HIP_TRY(c, b->d_pack_state.alloc(4));
+  const uint32_t state0[4] = {(uint32_t)fixed, 0, 0, 0};
+  HIP_TRY(c, hipMemcpyAsync(b->d_pack_state.p, state0, sizeof state0, hipMemcpyHostToDevice, b->run_stream));
+  zkw_pack_args A;
+  std::memset(&A, 0, sizeof A);
+  A.kp[0] = b->d_kp.p;
+  A.wave_base[1] = b->n_waves;
+  A.dst = b->h_pack; A.state = b->d_pack_state.p; A.dst_units = (uint32_t)need; A.n_batches = 1;
+  A.wave_table = ZKW_PACK_HEADER_UNITS + ZKW_PACK_BATCH_UNITS; A.with_instances = 0; A.only_wave = w;
+  HIP_TRY(c, zkw_launch_pack(&A, (uint32_t)c->wave_width, 1, b->run_stream));
+  uint32_t state1[4] = {0, 0, 0, 0};
+  HIP_TRY(c, hipMemcpyAsync(state1, b->d_pack_state.p, sizeof state1, hipMemcpyDeviceToHost, b->run_stream));
+  HIP_TRY(c, hipStreamSynchronize(b->run_stream));
+  zkw_pack_wave e;
+  std::memcpy(&e, b->h_pack + A.wave_table, sizeof e);
+  WaveView v;
+  if (state1[1] != 0 || !wave_view(b->h_pack, e, L, v)) {
+    c->last_error = "pack kernel: the wave did not fit its block";
+    return ZKW_ERR_LIMIT;
+  }
+  b->wave_cache[w] = materialise_wave(b, w, v, ncyc.data());
   return ZKW_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// zkw_delivery: whole steps in a persistent pinned ring (include/zkw.h)
+// ---------------------------------------------------------------------------------------------------------------------
+struct DeliverySlot {
+  uint4* h = nullptr;  // the pinned block ...
+  uint4* d = nullptr;  // ... and its address on the device
+  uint64_t units = 0;
+  int state = 0;       // 0 free, 1 submitted, 2 landed (the host has waited for it)
+  uint32_t ticket = 0;
+  std::vector<zkw_batch*> batches;
+  hipEvent_t ev_run = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr;
+  uint32_t* d_state = nullptr;          // [4] allocation cursor, overflow flag
+  zkw_pack_batch* d_batches = nullptr;  // [ZKW_PACK_MAX] device copy of the block's batch table
+  uint32_t wave_table = 0, n_waves = 0;
+  std::map<std::pair<uint32_t, uint32_t>, std::unique_ptr<WaveTrace>> cache;  // (batch, wave) -> materialised traces
+};
+
+struct zkw_delivery {
+  zkw_ctx* ctx = nullptr;
+  std::vector<DeliverySlot> slots;
+  hipStream_t stream = nullptr;
+  uint32_t next_ticket = 0;
+  uint32_t pack_blocks = 64;
+  // the pool: persistent workers, one job at a time (a job = a function of the thread index, run once by every worker)
+  uint32_t n_threads = 1;
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::function<void(uint32_t)> job;
+  uint64_t job_gen = 0;
+  uint32_t job_left = 0;
+  bool stopping = false;
+};
+
+static void delivery_worker(zkw_delivery* d, uint32_t t) {
+  uint64_t seen = 0;
+  for (;;) {
+    std::function<void(uint32_t)> fn;
+    {
+      std::unique_lock<std::mutex> lk(d->mu);
+      d->cv_work.wait(lk, [&] { return d->stopping || d->job_gen != seen; });
+      if (d->stopping) return;
+      seen = d->job_gen;
+      fn = d->job;
+    }
+    fn(t);
+    {
+      std::lock_guard<std::mutex> lk(d->mu);
+      if (--d->job_left == 0) d->cv_done.notify_all();
+    }
+  }
+}
+static void delivery_run(zkw_delivery* d, std::function<void(uint32_t)> fn) {
+  if (d->workers.empty()) {  // (one thread: the caller's)
+    fn(0);
+    return;
+  }
+  std::unique_lock<std::mutex> lk(d->mu);
+  d->job = std::move(fn);
+  d->job_left = (uint32_t)d->workers.size();
+  d->job_gen++;
+  d->cv_work.notify_all();
+  d->cv_done.wait(lk, [&] { return d->job_left == 0; });
+}
+
+struct FoldSink {  // the built-in consumer of zkw_delivery_replay: reads every byte it is handed
+  uint64_t acc = 0, cycles = 0;
+  static uint64_t fold(const void* p, uint32_t words, uint64_t w0) {
+    const uint64_t* u = (const uint64_t*)p;
+    uint64_t a = 0;
+    for (uint32_t j = 0; j < words; j++) a += u[j] * (2ull * j + w0);
+    return a;
+  }
+  void cycle(const CycleView& cv) {
+    acc += fold(cv.record, 64, 1);
+    for (uint32_t i = 0; i < cv.n_mem; i++) acc += fold(cv.mem + i, 6, 3);
+    for (uint32_t i = 0; i < cv.n_log; i++) acc += fold(cv.log + i, 16, 5);
+    for (uint32_t i = 0; i < cv.n_aux; i++) acc += fold(cv.aux + i, 32, 7);
+    cycles++;
+  }
+};
+struct CallbackSink {
+  zkw_cycle_fn fn;
+  void* user;
+  uint32_t thread, batch_index, first_instance;
+  uint64_t cycles = 0;
+  void cycle(const CycleView& cv) {
+    fn(user, thread, batch_index, first_instance + cv.lane, cv.cycle, cv.record, cv.mem, cv.n_mem, cv.log, cv.n_log, cv.aux, cv.n_aux);
+    cycles++;
+  }
+};
+
+static DeliverySlot* delivery_slot(zkw_delivery* d, uint32_t ticket, bool landed) {
+  if (!d || d->slots.empty()) return nullptr;
+  DeliverySlot& sl = d->slots[ticket % d->slots.size()];
+  if (sl.state == 0 || sl.ticket != ticket || (landed && sl.state != 2)) return nullptr;
+  return &sl;
+}
+// the view of wave (bi, w) of a landed slot + the cycle counts of its lanes (from the packed scalars)
+static bool delivery_wave(const DeliverySlot& sl, uint32_t bi, uint32_t w, WaveView& v, uint32_t* ncyc) {
+  const zkw_pack_batch* pbs = (const zkw_pack_batch*)(sl.h + ZKW_PACK_HEADER_UNITS);
+  const zkw_pack_batch& pb = pbs[bi];
+  const zkw_pack_wave* wt = (const zkw_pack_wave*)(sl.h + sl.wave_table);
+  if (!wave_view(sl.h, wt[pb.first_wave + w], pb.L, v)) return false;
+  const zkw_dev_scalars* sc = (const zkw_dev_scalars*)(sl.h + pb.scalars_off);
+  for (uint32_t l = 0; l < pb.L; l++) {
+    const uint32_t i = w * pb.L + l;
+    ncyc[l] = i < pb.n_instances ? sc[i].n_cycles : 0u;
+  }
+  return true;
+}
+
+extern "C" {
 
 int zkw_batch_get_instance_trace(zkw_batch* b, uint32_t instance, zkw_instance_trace* out) {
   if (!b || !out || instance >= b->n) return ZKW_ERR_INVALID;
@@ -1519,30 +1863,331 @@ int zkw_batch_get_instance_trace(zkw_batch* b, uint32_t instance, zkw_instance_t
   out->log_off = wt.log_off[l].data();
   out->aux_off = wt.aux_off[l].data();
   // final VmLocalState: scalars + register file + current callstack entry
-  zkw_vm_local_state& fs = out->final_state;
-  std::memcpy(fs.previous_code_word.l, sc.prev_code_word, 32);
   std::vector<uint4> regs(ZKW_REG_CHUNKS);
   for (uint32_t ch = 0; ch < ZKW_REG_CHUNKS; ch++)
     HIP_TRY(c, hipMemcpy(&regs[ch], b->d_regs.p + ((size_t)w * ZKW_REG_CHUNKS + ch) * b->L + l, sizeof(uint4), hipMemcpyDeviceToHost));
-  std::memcpy(fs.registers, regs.data(), 480);
-  fs.register_ptr_bitmap = (uint16_t)sc.ptr_bitmap;
-  fs.flags = sc.flags & 7u;
-  fs.pending_exception = (sc.flags >> 3) & 1u;
-  fs.previous_code_memory_page = sc.prev_code_page;
-  fs.timestamp = sc.timestamp;
-  fs.monotonic_cycle_counter = sc.cycle_counter;
-  fs.spent_pubdata_counter = sc.spent_pubdata;
-  fs.memory_page_counter = sc.memory_page_counter;
-  fs.absolute_execution_step = sc.absolute_execution_step;
-  fs.current_ergs_per_pubdata_byte = sc.ergs_per_pubdata;
-  fs.tx_number_in_block = (uint16_t)sc.tx_number;
-  fs.previous_super_pc = (uint16_t)sc.prev_super_pc;
-  fs.callstack_depth = sc.depth;
-  std::memcpy(fs.context_u128_register, sc.ctx_u128_reg, 16);
   zkw_dev_entry cur;
   HIP_TRY(c, hipMemcpy(&cur, b->d_callstack.p + (size_t)instance * (b->lim.max_callstack_depth + 1) + sc.depth, sizeof cur, hipMemcpyDeviceToHost));
-  fs.current = cur.e;
+  fill_final_state(&out->final_state, sc, regs.data(), 1, cur);
   return ZKW_OK;
+}
+
+int zkw_delivery_slot_bytes(zkw_batch* const* batches, uint32_t n_batches, uint64_t* worst_case) {
+  if (!batches || !n_batches || !worst_case) return ZKW_ERR_INVALID;
+  uint64_t units = ZKW_PACK_HEADER_UNITS + (uint64_t)n_batches * ZKW_PACK_BATCH_UNITS;
+  for (uint32_t i = 0; i < n_batches; i++) {
+    const zkw_batch* b = batches[i];
+    if (!b || !b->uploaded) return ZKW_ERR_INVALID;
+    units += (uint64_t)b->n_waves * ZKW_PACK_WAVE_UNITS + (uint64_t)b->n * 16 + (uint64_t)b->n_waves * ZKW_REG_CHUNKS * b->L;
+    units += (uint64_t)b->n_waves * zkw_pack_wave_units(b->lim.max_cycles, b->L, b->cap_delta, b->cap_mem, b->cap_mem, b->cap_log, 16u * b->cap_aux);
+  }
+  *worst_case = units * 16;
+  return ZKW_OK;
+}
+
+int zkw_delivery_create(zkw_ctx* c, uint32_t n_slots, uint64_t slot_bytes, uint32_t host_threads, zkw_delivery** out) {
+  if (!c || !out || n_slots == 0 || slot_bytes < 4096 || host_threads == 0 || host_threads > 4096) return ZKW_ERR_INVALID;
+  if (slot_bytes / 16 >= (1ull << 32)) {
+    c->last_error = "zkw_delivery_create: a slot holds at most 64 GB (32-bit offsets in 16-byte units)";
+    return ZKW_ERR_LIMIT;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  auto* d = new zkw_delivery();
+  d->ctx = c;
+  d->n_threads = host_threads;
+  if (c->opt_pack_blocks) d->pack_blocks = c->opt_pack_blocks;
+  d->slots.resize(n_slots);
+  auto fail = [&](hipError_t e, const char* what) {
+    c->last_error = std::string(what) + ": " + hipGetErrorString(e);
+    zkw_delivery_destroy(d);
+    return ZKW_ERR_DEVICE;
+  };
+  hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) return fail(e, "hipStreamCreateWithFlags");
+  for (DeliverySlot& sl : d->slots) {
+    sl.units = slot_bytes / 16;
+    if ((e = hipHostMalloc((void**)&sl.h, sl.units * 16, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc (the pinned ring)");
+    if ((e = hipHostGetDevicePointer((void**)&sl.d, sl.h, 0)) != hipSuccess) return fail(e, "hipHostGetDevicePointer");
+    if ((e = hipMalloc((void**)&sl.d_state, 16)) != hipSuccess) return fail(e, "hipMalloc");
+    if ((e = hipMalloc((void**)&sl.d_batches, sizeof(zkw_pack_batch) * ZKW_PACK_MAX)) != hipSuccess) return fail(e, "hipMalloc");
+    for (hipEvent_t* ev : {&sl.ev_run, &sl.ev_k0, &sl.ev_k1, &sl.ev_done})
+      if ((e = hipEventCreate(ev)) != hipSuccess) return fail(e, "hipEventCreate");
+  }
+  if (host_threads > 1)
+    for (uint32_t t = 0; t < host_threads; t++) d->workers.emplace_back(delivery_worker, d, t);
+  *out = d;
+  return ZKW_OK;
+}
+
+void zkw_delivery_destroy(zkw_delivery* d) {
+  if (!d) return;
+  {
+    std::lock_guard<std::mutex> lk(d->mu);
+    d->stopping = true;
+  }
+  d->cv_work.notify_all();
+  for (std::thread& t : d->workers) t.join();
+  (void)hipSetDevice(d->ctx->device);
+  if (d->stream) (void)hipStreamSynchronize(d->stream);
+  for (DeliverySlot& sl : d->slots) {
+    if (sl.h) (void)hipHostFree(sl.h);
+    if (sl.d_state) (void)hipFree(sl.d_state);
+    if (sl.d_batches) (void)hipFree(sl.d_batches);
+    for (hipEvent_t ev : {sl.ev_run, sl.ev_k0, sl.ev_k1, sl.ev_done})
+      if (ev) (void)hipEventDestroy(ev);
+  }
+  if (d->stream) (void)hipStreamDestroy(d->stream);
+  delete d;
+}
+
+int zkw_delivery_submit(zkw_delivery* d, zkw_batch* const* batches, uint32_t n, void* run_stream, uint32_t* ticket) {
+  if (!d || !ticket) return ZKW_ERR_INVALID;
+  int rc = check_group(batches, n);
+  if (rc != ZKW_OK) return rc;
+  zkw_ctx* c = d->ctx;
+  if (batches[0]->ctx != c) return ZKW_ERR_INVALID;
+  DeliverySlot& sl = d->slots[d->next_ticket % d->slots.size()];
+  if (sl.state != 0) {
+    c->last_error = "zkw_delivery_submit: the ring is full (release the oldest ticket)";
+    return ZKW_ERR_LIMIT;
+  }
+  for (uint32_t i = 0; i < n; i++)
+    if (!batches[i]->ran) {
+      c->last_error = "zkw_delivery_submit: a batch has not run";
+      return ZKW_ERR_NOT_RUN;
+    }
+  HIP_TRY(c, hipSetDevice(c->device));
+  // the fixed part of the block: header, batch table, wave table, the instance sections — written here, by the host
+  zkw_pack_args A;
+  std::memset(&A, 0, sizeof A);
+  uint64_t at = ZKW_PACK_HEADER_UNITS + (uint64_t)n * ZKW_PACK_BATCH_UNITS;
+  uint32_t waves = 0;
+  for (uint32_t i = 0; i < n; i++) waves += batches[i]->n_waves;
+  const uint64_t wave_table = at;
+  at += (uint64_t)waves * ZKW_PACK_WAVE_UNITS;
+  zkw_pack_batch* pbs = (zkw_pack_batch*)(sl.h + ZKW_PACK_HEADER_UNITS);
+  uint32_t first_wave = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    const zkw_batch* b = batches[i];
+    zkw_pack_batch pb;
+    pb.n_instances = b->n; pb.L = b->L; pb.n_waves = b->n_waves; pb.first_wave = first_wave; pb.max_cycles = b->lim.max_cycles;
+    pb.scalars_off = (uint32_t)at; at += (uint64_t)b->n * 8;
+    pb.regs_off = (uint32_t)at; at += (uint64_t)b->n_waves * ZKW_REG_CHUNKS * b->L;
+    pb.entries_off = (uint32_t)at; at += (uint64_t)b->n * 8;
+    if (at >= sl.units) {
+      c->last_error = "zkw_delivery_submit: the slot is smaller than the fixed part of this step";
+      return ZKW_ERR_LIMIT;
+    }
+    pbs[i] = pb;
+    A.kp[i] = b->d_kp.p;
+    A.wave_base[i + 1] = A.wave_base[i] + b->n_waves;
+    first_wave += b->n_waves;
+  }
+  zkw_pack_header* hd = (zkw_pack_header*)sl.h;
+  std::memset(hd, 0, sizeof *hd);
+  hd->magic = ZKW_PACK_MAGIC; hd->version = ZKW_PACK_VERSION; hd->n_batches = n; hd->n_waves = waves; hd->fixed_units = (uint32_t)at; hd->with_instances = 1;
+  hd->used_units = (uint32_t)at;  // the allocation cursor starts behind the fixed part (copied to the device below, and back behind the kernel)
+  hd->overflow = 0;
+  A.batches = sl.d_batches; A.dst = sl.d; A.state = sl.d_state; A.dst_units = (uint32_t)sl.units; A.n_batches = n;
+  A.wave_table = (uint32_t)wave_table; A.with_instances = 1; A.only_wave = 0xffffffffu;
+  hipStream_t rs = (hipStream_t)run_stream;
+  HIP_TRY(c, hipEventRecord(sl.ev_run, rs));
+  HIP_TRY(c, hipStreamWaitEvent(d->stream, sl.ev_run, 0));
+  HIP_TRY(c, hipMemcpyAsync(sl.d_state, &hd->used_units, 8, hipMemcpyHostToDevice, d->stream));  // (from the pinned slot itself)
+  HIP_TRY(c, hipMemcpyAsync(sl.d_batches, pbs, sizeof(zkw_pack_batch) * n, hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(c, hipEventRecord(sl.ev_k0, d->stream));
+  HIP_TRY(c, zkw_launch_pack(&A, (uint32_t)c->wave_width, d->pack_blocks, d->stream));
+  HIP_TRY(c, hipEventRecord(sl.ev_k1, d->stream));
+  HIP_TRY(c, hipMemcpyAsync(&hd->used_units, sl.d_state, 8, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(c, hipEventRecord(sl.ev_done, d->stream));
+  sl.state = 1;
+  sl.ticket = d->next_ticket;
+  sl.batches.assign(batches, batches + n);
+  sl.wave_table = (uint32_t)wave_table;
+  sl.n_waves = waves;
+  sl.cache.clear();
+  *ticket = d->next_ticket++;
+  return ZKW_OK;
+}
+
+int zkw_delivery_order_after(zkw_delivery* d, uint32_t ticket, void* hip_stream) {
+  DeliverySlot* sl = delivery_slot(d, ticket, false);
+  if (!sl) return ZKW_ERR_INVALID;
+  HIP_TRY(d->ctx, hipSetDevice(d->ctx->device));
+  HIP_TRY(d->ctx, hipStreamWaitEvent((hipStream_t)hip_stream, sl->ev_done, 0));
+  return ZKW_OK;
+}
+
+int zkw_delivery_wait(zkw_delivery* d, uint32_t ticket, zkw_delivered* info) {
+  DeliverySlot* sl = delivery_slot(d, ticket, false);
+  if (!sl) return ZKW_ERR_INVALID;
+  zkw_ctx* c = d->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipEventSynchronize(sl->ev_done));
+  sl->state = 2;
+  const zkw_pack_header* hd = (const zkw_pack_header*)sl->h;
+  if (info) {
+    float ms = 0;
+    HIP_TRY(c, hipEventElapsedTime(&ms, sl->ev_k0, sl->ev_k1));
+    info->bytes = (uint64_t)std::min<uint64_t>(hd->used_units, sl->units) * 16;
+    info->pack_ms = ms;
+    info->n_batches = hd->n_batches; info->n_waves = hd->n_waves; info->overflow = hd->overflow; info->reserved = 0;
+  }
+  if (hd->overflow) {
+    c->last_error = "zkw_delivery_wait: the step did not fit its slot (slot_bytes too small)";
+    return ZKW_ERR_LIMIT;
+  }
+  return ZKW_OK;
+}
+
+int zkw_delivery_get_instance_trace(zkw_delivery* d, uint32_t ticket, uint32_t bi, uint32_t instance, zkw_instance_trace* out) {
+  DeliverySlot* sl = delivery_slot(d, ticket, true);
+  if (!sl || !out || bi >= sl->batches.size()) return ZKW_ERR_INVALID;
+  const zkw_batch* b = sl->batches[bi];
+  const zkw_pack_batch& pb = ((const zkw_pack_batch*)(sl->h + ZKW_PACK_HEADER_UNITS))[bi];
+  if (instance >= pb.n_instances) return ZKW_ERR_INVALID;
+  const uint32_t L = pb.L, w = instance / L, l = instance % L;
+  auto key = std::make_pair(bi, w);
+  if (!sl->cache.count(key)) {
+    WaveView v;
+    std::vector<uint32_t> ncyc(L, 0);
+    if (!delivery_wave(*sl, bi, w, v, ncyc.data())) {
+      d->ctx->last_error = "zkw_delivery_get_instance_trace: the wave was not delivered (overflow)";
+      return ZKW_ERR_LIMIT;
+    }
+    sl->cache[key] = materialise_wave(b, w, v, ncyc.data());
+  }
+  WaveTrace& wt = *sl->cache[key];
+  const zkw_dev_scalars& sc = ((const zkw_dev_scalars*)(sl->h + pb.scalars_off))[instance];
+  std::memset(out, 0, sizeof *out);
+  out->status = sc.status;
+  out->n_cycles = sc.n_cycles;
+  out->n_mem = (uint32_t)wt.mem[l].size(); out->n_log = (uint32_t)wt.log[l].size(); out->n_aux = (uint32_t)wt.aux[l].size();
+  out->records = wt.records[l].data(); out->mem = wt.mem[l].data(); out->log = wt.log[l].data(); out->aux = wt.aux[l].data();
+  out->mem_off = wt.mem_off[l].data(); out->log_off = wt.log_off[l].data(); out->aux_off = wt.aux_off[l].data();
+  const uint4* regs = sl->h + pb.regs_off + (size_t)w * ZKW_REG_CHUNKS * L + l;
+  fill_final_state(&out->final_state, sc, regs, L, ((const zkw_dev_entry*)(sl->h + pb.entries_off))[instance]);
+  return ZKW_OK;
+}
+
+int zkw_delivery_replay(zkw_delivery* d, uint32_t ticket, zkw_cycle_fn fn, void* user, uint64_t* n_cycles, uint64_t* checksum) {
+  DeliverySlot* sl = delivery_slot(d, ticket, true);
+  if (!sl) return ZKW_ERR_INVALID;
+  const zkw_pack_batch* pbs = (const zkw_pack_batch*)(sl->h + ZKW_PACK_HEADER_UNITS);
+  const uint32_t nb = (uint32_t)sl->batches.size();
+  std::atomic<uint32_t> next{0};
+  std::atomic<uint64_t> cycles{0}, acc{0};
+  std::atomic<uint32_t> missing{0};
+  delivery_run(d, [&](uint32_t t) {
+    uint64_t my_cycles = 0, my_acc = 0;
+    std::vector<uint32_t> ncyc(ZKW_WAVE, 0);
+    for (;;) {
+      const uint32_t gw = next.fetch_add(1);
+      if (gw >= sl->n_waves) break;
+      uint32_t bi = 0;
+      while (bi + 1 < nb && pbs[bi + 1].first_wave <= gw) bi++;
+      const uint32_t w = gw - pbs[bi].first_wave;
+      WaveView v;
+      if (!delivery_wave(*sl, bi, w, v, ncyc.data())) {
+        missing.fetch_add(1);
+        continue;
+      }
+      if (fn) {
+        CallbackSink sink{fn, user, t, bi, w * pbs[bi].L};
+        walk_wave(sl->batches[bi], w, v, ncyc.data(), sink);
+        my_cycles += sink.cycles;
+      } else {
+        FoldSink sink;
+        walk_wave(sl->batches[bi], w, v, ncyc.data(), sink);
+        my_cycles += sink.cycles;
+        my_acc += sink.acc;
+      }
+    }
+    cycles.fetch_add(my_cycles);
+    acc.fetch_add(my_acc);
+  });
+  if (n_cycles) *n_cycles = cycles.load();
+  if (checksum) *checksum = acc.load();
+  if (missing.load()) {
+    d->ctx->last_error = "zkw_delivery_replay: waves were not delivered (overflow)";
+    return ZKW_ERR_LIMIT;
+  }
+  return ZKW_OK;
+}
+
+int zkw_delivery_release(zkw_delivery* d, uint32_t ticket) {
+  DeliverySlot* sl = delivery_slot(d, ticket, false);
+  if (!sl) return ZKW_ERR_INVALID;
+  if (sl->state == 1) {  // not waited for: the block may still be in flight
+    HIP_TRY(d->ctx, hipSetDevice(d->ctx->device));
+    HIP_TRY(d->ctx, hipEventSynchronize(sl->ev_done));
+  }
+  sl->state = 0;
+  sl->cache.clear();
+  sl->batches.clear();
+  return ZKW_OK;
+}
+
+int zkw_batch_restage(zkw_batch* b, const zkw_vm_local_state* states, const zkw_u256* heap_words, uint32_t n_heap_words, void* hip_stream) {
+  if (!b || !states) return ZKW_ERR_INVALID;
+  zkw_ctx* c = b->ctx;
+  if (!b->uploaded) {
+    c->last_error = "zkw_batch_restage: the batch has not been uploaded";
+    return ZKW_ERR_INVALID;
+  }
+  const uint32_t n = b->n, L = b->L, W = b->n_waves, himg = b->heap_image_words, D = b->lim.max_callstack_depth;
+  if (heap_words && n_heap_words != himg) {
+    c->last_error = "zkw_batch_restage: the heap images must be as long as the uploaded ones (" + std::to_string(himg) + " words)";
+    return ZKW_ERR_INVALID;
+  }
+  for (uint32_t i = 0; i < n; i++)
+    if (states[i].callstack_depth != b->staged[i].state.callstack_depth) {
+      c->last_error = "zkw_batch_restage: instance " + std::to_string(i) + " changes its callstack depth (geometry is fixed at upload)";
+      return ZKW_ERR_INVALID;
+    }
+  HIP_TRY(c, hipSetDevice(c->device));
+  // pinned staging of the batch: [regs | scalars | callstack | heap image], allocated once
+  const size_t n_regs = (size_t)W * ZKW_REG_CHUNKS * L, n_stack = (size_t)n * (D + 1), n_heap = (size_t)W * himg * L * 2;
+  const size_t bytes = n_regs * 16 + (size_t)n * sizeof(zkw_dev_scalars) + n_stack * sizeof(zkw_dev_entry) + n_heap * 16;
+  if (b->h_stage_bytes < bytes) {
+    if (b->h_stage) (void)hipHostFree(b->h_stage);
+    b->h_stage = nullptr;
+    HIP_TRY(c, hipHostMalloc((void**)&b->h_stage, bytes, hipHostMallocDefault));
+    b->h_stage_bytes = bytes;
+    if (!b->ev_stage) HIP_TRY(c, hipEventCreate(&b->ev_stage));
+    b->stage_busy = false;
+  }
+  if (b->stage_busy) HIP_TRY(c, hipEventSynchronize(b->ev_stage));  // the copies of the previous restage still read the staging memory
+  uint4* regs = (uint4*)b->h_stage;
+  zkw_dev_scalars* scal = (zkw_dev_scalars*)(regs + n_regs);
+  zkw_dev_entry* stack = (zkw_dev_entry*)(scal + n);
+  uint4* heap0 = (uint4*)(stack + n_stack);
+  std::memset(scal, 0, (size_t)n * sizeof(zkw_dev_scalars));
+  std::memset(stack, 0, n_stack * sizeof(zkw_dev_entry));
+  if (n_regs > (size_t)n * ZKW_REG_CHUNKS) std::memset(regs, 0, n_regs * 16);  // (lanes of the last wave without an instance)
+  std::vector<zkw_dev_frame_meta> frames_scratch((size_t)n * b->lim.max_far_frames);  // (the frame metas do not change: geometry is fixed)
+  std::memset(frames_scratch.data(), 0, frames_scratch.size() * sizeof(zkw_dev_frame_meta));
+  for (uint32_t i = 0; i < n; i++) {
+    StagedInstance& si = b->staged[i];
+    si.state = states[i];
+    if (heap_words) si.heap.assign(heap_words + (size_t)i * himg, heap_words + (size_t)(i + 1) * himg);
+    std::string err;
+    const int frc = format_instance(b, i, himg, regs, scal, stack, frames_scratch.data(), heap0, &err);
+    if (frc != ZKW_OK) {
+      c->last_error = err;
+      return frc;
+    }
+  }
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIP_TRY(c, hipMemcpyAsync(b->d_regs0.p, regs, n_regs * 16, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(b->d_scalars0.p, scal, (size_t)n * sizeof(zkw_dev_scalars), hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(b->d_callstack0.p, stack, n_stack * sizeof(zkw_dev_entry), hipMemcpyHostToDevice, st));
+  if (n_heap && (heap_words || true)) HIP_TRY(c, hipMemcpyAsync(b->d_heap0.p, heap0, n_heap * 16, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipEventRecord(b->ev_stage, st));
+  b->stage_busy = true;
+  b->full_reset_pending = true;  // the whole heap image goes into the arena, not the words a run had dirtied
+  zkw_batch* one[1] = {b};
+  return enqueue_reset(one, 1, st);
 }
 
 // the two layouts of the expanded records: instance-major (stride_k == 1: the records of an instance are contiguous, the
@@ -1707,12 +2352,12 @@ int zkw_batch_get_page(zkw_batch* b, uint32_t instance, uint32_t page, uint32_t 
     }
   {
     const zkw_dev_scalars& sc = b->h_scalars[instance];  // (zkw_batch_sync has refreshed them)
-    const uint32_t nh = std::min(sc.n_history, F);
-    std::vector<zkw_dev_history> hist(nh);
-    if (nh) HIP_TRY(c, hipMemcpy(hist.data(), b->d_history.p + (size_t)instance * F, (size_t)nh * sizeof(zkw_dev_history), hipMemcpyDeviceToHost));
-    for (uint32_t k = 0; k < nh; k++)
-      if (hist[k].page == page && hist[k].preimage < b->preimages.size()) {
-        from_vector(b->blobs[b->preimages[hist[k].preimage].second]);
+    const uint32_t pitch = b->kp.hist_pitch, np = (uint32_t)b->preimages.size();  // row p = (hash -> blob) pair p (zkw_dev_history)
+    std::vector<zkw_dev_history> hist(sc.n_history ? np : 0);
+    if (!hist.empty()) HIP_TRY(c, hipMemcpy(hist.data(), b->d_history.p + (size_t)instance * pitch, (size_t)np * sizeof(zkw_dev_history), hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < hist.size(); k++)
+      if (hist[k].valid && hist[k].page == page) {
+        from_vector(b->blobs[b->preimages[k].second]);
         return ZKW_OK;
       }
   }
@@ -1936,6 +2581,7 @@ uint32_t zkw_abi_sizeof(uint32_t which) {
     case 12: return sizeof(zkw_isa_consts);
     case 13: return sizeof(zkw_event_message);
     case 14: return sizeof(zkw_net_state);
+    case 15: return sizeof(zkw_delivered);
     default: return 0;
   }
 }
@@ -2073,6 +2719,22 @@ static int comm_allreduce_host(zkw_comm* cm, uint64_t* inout, uint32_t count, bo
 }
 
 extern "C" {
+
+// Can this process reach RCCL at all?  dlopen + symbol lookup only: no bootstrap root, no socket, no thread (ncclGetUniqueId
+// starts all three — a probe through it left one listening root per rank for the life of the process).
+int zkw_comm_probe(void) {
+#ifndef ZKW_EMU_BUILD
+  RcclApi* api = rccl_api();
+  if (!api->handle) {
+    g_create_error = api->error;
+    return ZKW_ERR_DEVICE;
+  }
+  return ZKW_OK;
+#else
+  g_create_error = "RCCL is not part of the CPU emulation build";
+  return ZKW_ERR_DEVICE;
+#endif
+}
 
 int zkw_comm_get_unique_id(zkw_comm_id* out) {
   if (!out) return ZKW_ERR_INVALID;

@@ -31,9 +31,10 @@ def make_comm(backend, rank, world, device=None, prefer_rccl=True):
     """-> (capi.Comm, description of the transport that will carry zkw_reduce_commitments).
 
     world == 1 without a process group: a one-rank external communicator (no transport at all).  Otherwise the ranks
-    first try the library's own RCCL communicator: every rank probes locally that it can make an id
-    (zkw_comm_get_unique_id: librccl loads), the ranks agree on that with one all-reduce, and only then rank 0's id is
-    broadcast and zkw_comm_create_rccl — a collective — runs everywhere, its outcome agreed on with a second all-reduce;
+    first try the library's own RCCL communicator: every rank probes locally that librccl loads (zkw_comm_probe: dlopen
+    + dlsym, no side effects), the ranks agree on that with one all-reduce, and only then rank 0 alone makes the id
+    (ncclGetUniqueId starts a bootstrap root — a listening socket and a thread — which only the id in use should own), the
+    id is broadcast and zkw_comm_create_rccl — a collective — runs everywhere, its outcome agreed on with a second all-reduce;
     if ANY rank failed at either step every rank falls back to zkw_comm_create_external with all-gather / all-reduce
     callbacks over the process group that is already up."""
     if world == 1 and not (dist.is_available() and dist.is_initialized()):
@@ -41,24 +42,33 @@ def make_comm(backend, rank, world, device=None, prefer_rccl=True):
     dev = _pg_device(device)
     comm, why = None, ""
     if prefer_rccl:
-        # Step 1, local only: can this rank load librccl and make an id at all?  Agreed on BEFORE the collective init —
-        # ncclCommInitRank is itself a collective, so a rank that cannot even reach it would leave the others blocked in
-        # zkw_comm_create_rccl until the NCCL timeout instead of falling back with them.
-        my_id = None
+        # Step 1, local only and free of side effects: can this rank load librccl at all?  Agreed on BEFORE the collective
+        # init — ncclCommInitRank is itself a collective, so a rank that cannot even reach it would leave the others blocked
+        # in zkw_comm_create_rccl until the NCCL timeout instead of falling back with them.
+        can = False
         try:
-            my_id = K.Comm.unique_id(backend)
+            can = K.Comm.probe(backend)
         except K.ZkwError as e:  # e.g. librccl cannot be loaded on this rank
             why = str(e)
-        able = torch.tensor([1 if my_id is not None else 0], dtype=torch.int64, device=dev)
+        able = torch.tensor([1 if can else 0], dtype=torch.int64, device=dev)
         dist.all_reduce(able, op=dist.ReduceOp.MIN)
         if int(able.item()) == 1:
-            # Step 2: rank 0's id to everyone, then the collective init, then agree on its outcome
-            ids = [my_id if rank == 0 else None]
+            # Step 2: rank 0 makes the id (the only bootstrap root of the job), hands it to everyone, then the collective
+            # init, then the ranks agree on its outcome
+            my_id = None
+            if rank == 0:
+                try:
+                    my_id = K.Comm.unique_id(backend)
+                except K.ZkwError as e:
+                    why = str(e)
+            ids = [my_id]
             dist.broadcast_object_list(ids, src=0, device=dev)
             try:
+                if ids[0] is None:
+                    raise K.ZkwError("rank 0 could not make an RCCL id")
                 comm = K.Comm.rccl(backend, rank, world, ids[0])
             except K.ZkwError as e:
-                why = str(e)
+                why = why or str(e)
             ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 1:

@@ -131,7 +131,6 @@ def initial_states(n, registers, heap_bound=4096, ergs=0xFFFFFFFF, first_dynamic
 # cfg 0 / cfg 1
 # ----------------------------------------------------------------------------------------
 def config0(isa, n_cycles=1024, seed=0x5EED0000):
-    bind_isa(isa)
     wl = Workload("cfg0_nop_add", 1, n_cycles)
     ops = []
     n_add = 0
@@ -173,7 +172,6 @@ def arith_tape(isa, n_cycles, rng):
 
 
 def config1(isa, n_instances=256, n_cycles=256, seed=0x5EED0001):
-    bind_isa(isa)
     wl = Workload("cfg1_arith", n_instances, n_cycles)
     ops = arith_tape(isa, n_cycles, ScalarRng(seed))
     wl.blobs.append(K.pack_code(ops))
@@ -206,23 +204,17 @@ def versioned_code_hash(words):
     return K.u256_from_int(int.from_bytes(be, "big"))
 
 
-# FarCallForwardPageType -> its ABI byte under the table the workload is built for (a table constant, zkw_isa_consts.forwarding_codes):
-# every workload constructor binds its table first
-_FWD_CODES = [0, 1, 2]
-
-
-def bind_isa(isa):
-    _FWD_CODES[:] = [isa.fwd_code(k) for k in range(3)]
-
-
-def far_call_abi(start, length, ergs_passed, forwarding_mode=0):
-    """forwarding_mode: 0 UseHeap, 1 ForwardFatPointer, 2 UseAuxHeap (logical; encoded through the bound table)"""
-    v = (start << 64) | (length << 96) | (ergs_passed << 192) | (_FWD_CODES[forwarding_mode] << 224)
+# FarCallForwardPageType -> its ABI byte is a constant of the table the workload is built for (zkw_isa_consts.forwarding_codes):
+# the table is an explicit argument (a module-level binding was overwritten by whichever constructor ran last — the metamorphic
+# tests build workloads for two tables in one process)
+def far_call_abi(isa, start, length, ergs_passed, forwarding_mode=0):
+    """forwarding_mode: 0 UseHeap, 1 ForwardFatPointer, 2 UseAuxHeap (logical; encoded through `isa`)"""
+    v = (start << 64) | (length << 96) | (ergs_passed << 192) | (isa.fwd_code(forwarding_mode) << 224)
     return K.u256_from_int(v)
 
 
-def ret_abi(start, length, forwarding_mode=0):
-    return K.u256_from_int((start << 64) | (length << 96) | (_FWD_CODES[forwarding_mode] << 224))
+def ret_abi(isa, start, length, forwarding_mode=0):
+    return K.u256_from_int((start << 64) | (length << 96) | (isa.fwd_code(forwarding_mode) << 224))
 
 
 class TapeBuilder:
@@ -378,7 +370,6 @@ def callee_program(isa, rng, ret_variant):
 
 
 def config2(isa, n_instances=4096, n_cycles=256, seed=0x5EED0002):
-    bind_isa(isa)
     assert n_cycles >= 2 * (1 + CALLEE_CYCLES + RELOAD_CYCLES) + 12
     wl = Workload("cfg2_mixed", n_instances, n_cycles)
     rng = ScalarRng(seed)
@@ -389,7 +380,7 @@ def config2(isa, n_instances=4096, n_cycles=256, seed=0x5EED0002):
     s3 = budget - s1 - s2
     # bootloader constants: [0]=far-call ABI A, [1]=dest A, [2]=far-call ABI B, [3]=dest B, [4..8) random words
     rnd = Xoshiro(seed ^ 0x77, 1).words(4)[0]
-    consts = [far_call_abi(64, 256, 100000), K.u256_from_int(ADDR_A), far_call_abi(512, 96, 50000), K.u256_from_int(ADDR_B), rnd[0], rnd[1], rnd[2], rnd[3]]
+    consts = [far_call_abi(isa, 64, 256, 100000), K.u256_from_int(ADDR_A), far_call_abi(isa, 512, 96, 50000), K.u256_from_int(ADDR_B), rnd[0], rnd[1], rnd[2], rnd[3]]
     tb.random_segment(s1)
     tb.far_call()
     tb.executed += CALLEE_CYCLES
@@ -427,7 +418,7 @@ def config2(isa, n_instances=4096, n_cycles=256, seed=0x5EED0002):
         ops[11] = isa.enc(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=local, src1=0, dst0=13)
         code = K.pack_code(ops)
         words[: len(code)] = code
-        words[local] = ret_abi(0, 64)
+        words[local] = ret_abi(isa, 0, 64)
         wl.blobs.append(words)
         h = versioned_code_hash(words)
         wl.preimages.append((h, 1 + which))
@@ -477,7 +468,6 @@ def config3(isa, n_instances=4096, n_cycles=64, seed=0x5EED0003, keccak_k=(1, 8,
             keccak_unalign=None):
     """keccak_bytes / keccak_unalign: optional explicit message lengths (bytes) and byte misalignments (default: 136 * k
     bytes, misalignment 0 / 31 alternating)"""
-    bind_isa(isa)
     klen = list(keccak_bytes) if keccak_bytes is not None else [136 * k for k in keccak_k]
     keccak_k = [b // 136 for b in klen]  # rounds - 1, for the ergs cost
     kun = list(keccak_unalign) if keccak_unalign is not None else [(31 if j % 2 else 0) for j in range(len(klen))]
@@ -503,7 +493,7 @@ def config3(isa, n_instances=4096, n_cycles=64, seed=0x5EED0003, keccak_k=(1, 8,
     consts = []
     for j, r in enumerate(sha_rounds):
         consts.append(precompile_abi(sha_off[j] // 32, 0, out_base_boot + j, 0, 0, 0, extra=r))
-    consts.append(far_call_abi(0, heap_words * 32, 0x7FFFFFFF))  # [4] far-call ABI: whole heap as calldata
+    consts.append(far_call_abi(isa, 0, heap_words * 32, 0x7FFFFFFF))  # [4] far-call ABI: whole heap as calldata
     consts.append(K.u256_from_int(KECCAK_ADDRESS))                # [5]
     ops = []
     for j, r in enumerate(sha_rounds):
@@ -528,7 +518,7 @@ def config3(isa, n_instances=4096, n_cycles=64, seed=0x5EED0003, keccak_k=(1, 8,
     cconsts = []
     for j, k in enumerate(keccak_k):
         cconsts.append(precompile_abi(kec_off[j], klen[j], j, 0, boot_page_heap, 0))
-    cconsts.append(ret_abi(0, 32 * len(keccak_k)))
+    cconsts.append(ret_abi(isa, 0, 32 * len(keccak_k)))
     local = 64
     for j, k in enumerate(keccak_k):
         cops.append(isa.enc(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=local + j, src1=0, dst0=3))
@@ -685,12 +675,11 @@ class BlockTapeBuilder(TapeBuilder):
 
 
 def config4(isa, n_instances=4096, n_cycles=1024, seed=0x5EED0004):
-    bind_isa(isa)
     wl = Workload("cfg4_l2_block", n_instances, n_cycles)
     rng = ScalarRng(seed)
     tb = BlockTapeBuilder(isa, rng)
     consts_rnd = Xoshiro(seed ^ 0x77, 1).words(4)[0]
-    consts = [far_call_abi(64, 256, 100000), K.u256_from_int(ADDR_A), far_call_abi(512, 96, 50000), K.u256_from_int(ADDR_B),
+    consts = [far_call_abi(isa, 64, 256, 100000), K.u256_from_int(ADDR_A), far_call_abi(isa, 512, 96, 50000), K.u256_from_int(ADDR_B),
               consts_rnd[0], consts_rnd[1], consts_rnd[2], consts_rnd[3]]
     # subroutines (near-call targets) are placed after the main program; their bodies write storage and
     # emit events so that a reverting return exercises the rollback journals
@@ -748,7 +737,7 @@ def config4(isa, n_instances=4096, n_cycles=1024, seed=0x5EED0004):
         ops[11] = isa.enc(K.OP_ADD, src0_mode=K.MODE_CODE, imm0=local, src1=0, dst0=13)
         code = K.pack_code(ops)
         words[: len(code)] = code
-        words[local] = ret_abi(0, 64)
+        words[local] = ret_abi(isa, 0, 64)
         wl.blobs.append(words)
         wl.preimages.append((versioned_code_hash(words), 1 + which))
     # storage: deployer entries + 256 pre-populated slots of the bootloader's own account
@@ -793,7 +782,6 @@ ECRECOVER_ADDRESS = 0x01
 
 
 def ecrecover_workload(isa, sig_words, tail_cycles=6):
-    bind_isa(isa)
     """sig_words: [n_instances][n_sigs][4] python ints, already in the memory order of isa.consts.ecrecover_input_layout.
     Signature j sits at heap words 4j..4j+3; the precompile writes (ok marker, address word) at words out_base + 2j,
     which the tail of the tape loads back into registers."""
@@ -840,7 +828,6 @@ def ecrecover_workload(isa, sig_words, tail_cycles=6):
 # reference_impls/event_sink.rs:160-176)
 # ----------------------------------------------------------------------------------------
 def nested_frames(isa, outer=K.RET_OK, inner=K.RET_OK, main_panics=False, n_instances=3, n_cycles=40, seed=0x5EED00F2):
-    bind_isa(isa)
     wl = Workload("nested_frames_%d_%d_%d" % (outer, inner, int(main_panics)), n_instances, n_cycles)
     A, B = 16, 32
     e = isa.enc
@@ -902,8 +889,10 @@ def nested_frames(isa, outer=K.RET_OK, inner=K.RET_OK, main_panics=False, n_inst
 #   N  (nested)  far-calls K itself and return-forwards K's returndata pointer: K's page is handed to N's caller, N's own
 #                slot goes back to the pool
 # ----------------------------------------------------------------------------------------
-def many_far_calls(isa, n_calls=64, n_instances=8, seed=0x5EED00F7, plan=None, max_far_frames=4):
-    bind_isa(isa)
+def many_far_calls(isa, n_calls=64, n_instances=8, seed=0x5EED00F7, plan=None, max_far_frames=4, distinct=0):
+    """distinct > 0: the plan calls `distinct` DIFFERENT contracts (copies of P with their own code hash and address, "P0" ..)
+    one after the other and then the first few again (decommits that are no longer fresh): SimpleDecommitter's history is
+    unbounded (decommitter.rs:38-47) — the decommits of a run are not capped by limits.max_far_frames"""
     e = isa.enc
     ADDR_K, ADDR_P, ADDR_N = 0x10011, 0x10012, 0x10013
     local = CALLEE_CODE_WORDS - 8  # page-local constant pool of the callees
@@ -941,19 +930,26 @@ def many_far_calls(isa, n_calls=64, n_instances=8, seed=0x5EED00F7, plan=None, m
                 e(K.OP_RET, variant=K.RET_OK, flags=0, src0=13)]
 
     programs = {"K": (ADDR_K, callee_k()), "P": (ADDR_P, callee_p()), "N": (ADDR_N, callee_n())}
+    order = ["K", "P", "N"]
+    if distinct:
+        for j in range(distinct):
+            programs["P%d" % j] = (0x10100 + j, callee_p())
+            order.append("P%d" % j)
+        again = min(8, distinct)
+        plan = ["K"] + ["P%d" % j for j in range(distinct)] + ["P%d" % j for j in range(again)] + ["N"] + ["P%d" % (distinct - 1 - j) for j in range(again)]
+        n_calls = len(plan)
     if plan is None:
         plan = "K" + "P" * 5 + "N" + "P" * (n_calls - 7)  # two live returndata pages + the bootloader: one slot left to reuse
     assert len(plan) == n_calls
     n_cycles = 4
     for c in plan:
         n_cycles += 1 + len(programs[c][1]) + (len(programs["K"][1]) if c == "N" else 0) + RELOAD_CYCLES
-    wl = Workload("many_far_calls_%s" % plan[:12], n_instances, n_cycles)
+    wl = Workload("many_far_calls_%s" % "".join(plan)[:12], n_instances, n_cycles)
     rng = ScalarRng(seed)
     tb = TapeBuilder(isa, rng)
-    order = ["K", "P", "N"]
     consts = []
     for c in order:
-        consts += [far_call_abi(64, 128, 200000), K.u256_from_int(programs[c][0])]
+        consts += [far_call_abi(isa, 64, 128, 200000), K.u256_from_int(programs[c][0])]
     for j, c in enumerate(plan):  # r13 / r14 hold the ABI / address of callee j: preset for the first, reloaded after every return
         tb.far_call()
         k = order.index(plan[min(j + 1, n_calls - 1)])
@@ -976,10 +972,10 @@ def many_far_calls(isa, n_calls=64, n_instances=8, seed=0x5EED00F7, plan=None, m
         words[: len(code)] = code
         fill = Xoshiro(seed ^ (0x2000 + which), 1).words(64)[0]
         words[64:128] = fill
-        words[local] = ret_abi(0, 128)
-        words[local + 1] = far_call_abi(0, 64, 50000)
+        words[local] = ret_abi(isa, 0, 128)
+        words[local + 1] = far_call_abi(isa, 0, 64, 50000)
         words[local + 2] = K.u256_from_int(ADDR_K)
-        words[local + 3] = K.u256_from_int(_FWD_CODES[1] << 224)  # RetABI forwarding_mode = ForwardFatPointer, in the half ptr.pack takes from src1
+        words[local + 3] = K.u256_from_int(isa.fwd_code(1) << 224)  # RetABI forwarding_mode = ForwardFatPointer, in the half ptr.pack takes from src1
         wl.blobs.append(words)
         h = versioned_code_hash(words)
         wl.preimages.append((h, 1 + which))
@@ -994,7 +990,7 @@ def many_far_calls(isa, n_calls=64, n_instances=8, seed=0x5EED00F7, plan=None, m
     regs[:, 14] = 0
     wl.states, wl.inner = initial_states(n_instances, regs)
     wl.heaps = Xoshiro(seed ^ 0x4EA9, n_instances).words(HEAP_BYTES // 32)
-    wl.limits.update(max_far_frames=max_far_frames, heap_words=320, stack_words=16, aux_heap_words=8, storage_slots=8, storage_journal=4,
+    wl.limits.update(max_far_frames=max_far_frames, heap_words=320, stack_words=16, aux_heap_words=8, storage_slots=max(8, 4 * len(order)), storage_journal=4,
                      max_aux_events=8 * n_calls + 32, max_reg_deltas=2 * n_cycles + 40 * n_calls)
     return wl
 
@@ -1006,7 +1002,6 @@ def many_far_calls(isa, n_calls=64, n_instances=8, seed=0x5EED00F7, plan=None, m
 # page and the page that is not the returndata go back to the pool
 # ----------------------------------------------------------------------------------------
 def bootloader_returns(isa, how="heap", n_instances=3, seed=0x5EED00F9):
-    bind_isa(isa)
     e = isa.enc
     wl = Workload("bootloader_returns_%s" % how, n_instances, 8)
     ops = [e(K.OP_ADD, dst0_mode=K.MODE_STACK_ABS, src0=1, src1=2, dst0=0, imm1=7),               # stack[7]
@@ -1017,7 +1012,7 @@ def bootloader_returns(isa, how="heap", n_instances=3, seed=0x5EED00F9):
     words = np.zeros((24, 4), dtype="<u8")
     code = K.pack_code(ops)
     words[: len(code)] = code
-    words[16] = ret_abi(0, 128, forwarding_mode={"heap": 0, "aux": 2, "panic": 0}[how])
+    words[16] = ret_abi(isa, 0, 128, forwarding_mode={"heap": 0, "aux": 2, "panic": 0}[how])
     wl.blobs.append(words)
     wl.code_pages.append((0, n_instances, BOOTLOADER_CODE_PAGE, 0))
     regs = Xoshiro(seed ^ 0xABCDEF, n_instances).words(15)
@@ -1049,7 +1044,6 @@ def _shaped_u256(rng):
 
 
 def fuzz_workload(isa, n_instances=64, n_ops=96, seed=0xF022):
-    bind_isa(isa)
     wl = Workload("fuzz_%x" % seed, n_instances, n_ops)
     rng = ScalarRng(seed)
     e = isa.table["entries"][0]
@@ -1073,7 +1067,7 @@ def fuzz_workload(isa, n_instances=64, n_ops=96, seed=0xF022):
         words = np.zeros((CALLEE_CODE_WORDS, 4), dtype="<u8")
         code = K.pack_code(ops)
         words[: len(code)] = code
-        words[local] = ret_abi(0, 64)
+        words[local] = ret_abi(isa, 0, 64)
         callee_words.append(words)
     n_words = (n_ops + 3) // 4 + 8
     regs = np.zeros((n_instances, 15, 4), dtype="<u8")
@@ -1120,7 +1114,7 @@ def fuzz_workload(isa, n_instances=64, n_ops=96, seed=0xF022):
         wl.code_pages.append((i, 1, BOOTLOADER_CODE_PAGE, i))
         for k in range(15):
             regs[i, k] = K.u256_from_int(_shaped_u256(rng))
-        regs[i, 12] = far_call_abi(32 * rng.below(8), 32 * rng.below(8), 20000 + rng.below(1 << 20))  # r13
+        regs[i, 12] = far_call_abi(isa, 32 * rng.below(8), 32 * rng.below(8), 20000 + rng.below(1 << 20))  # r13
         regs[i, 13] = K.u256_from_int((ADDR_A, ADDR_B)[rng.below(2)])                                 # r14
     for which, words in enumerate(callee_words):
         wl.blobs.append(words)

@@ -246,11 +246,9 @@ typedef struct zkw_limits {
   uint32_t max_cycles;            /* cycles recorded per instance and per run                      */
   uint32_t max_far_frames;        /* far-call frames (incl. the bootloader frame) that are live or reachable at one time: a
                                      frame's arena slot is reused once it has returned and its heap / aux heap is no
-                                     returndata any more (the reference's page pools, memory.rs:660-758).  It ALSO caps the
-                                     distinct code hashes an instance decommits per run (SimpleDecommitter's history,
-                                     decommitter.rs:38-47, is one row per fresh decommit, sized by this limit): the
-                                     max_far_frames + 1-th fresh decommit stops the instance with ZKW_STATUS_LIMIT, and
-                                     zkw_batch_get_page sees the code pages of the first max_far_frames only          */
+                                     returndata any more (the reference's page pools, memory.rs:660-758).  It does NOT cap
+                                     the code hashes an instance decommits: SimpleDecommitter's history (decommitter.rs:38-47)
+                                     has one row per registered (hash -> blob) pair, so a run may decommit every known hash */
   uint32_t max_callstack_depth;   /* near + far frames alive at once                                */
   uint32_t stack_words;           /* words per stack page   (reference: 65536, memory.rs:177-179)  */
   uint32_t heap_words;            /* words per heap page    (reference: grows on demand)            */
@@ -447,6 +445,7 @@ int zkw_ctx_set_isa(zkw_ctx* ctx, const zkw_isa_table* table); /* copies */
 #define ZKW_OPT_NO_GRAPH 6u            /* 1 = zkw_batch_step never captures / replays a hipGraph */
 #define ZKW_OPT_WAVES_PER_GROUP 7u     /* 1 .. 8 waves per workgroup of the cycle kernel instead of the choice made per launch (0) */
 #define ZKW_OPT_LANES_PER_WAVE 8u      /* overrides zkw_limits.lanes_per_wave (batches created afterwards) */
+#define ZKW_OPT_PACK_BLOCKS 9u         /* workgroups of the pack kernel of deliveries created afterwards (0 = 64: the link, not the chip, bounds it) */
 int zkw_ctx_set_option(zkw_ctx* ctx, uint32_t option, uint64_t value);
 
 int zkw_batch_create(zkw_ctx* ctx, uint32_t n_instances, const zkw_limits* limits, zkw_batch** out);
@@ -575,6 +574,10 @@ typedef struct zkw_comm zkw_comm;
 typedef struct zkw_comm_id {
   uint8_t bytes[128]; /* ncclUniqueId */
 } zkw_comm_id;
+/* Side-effect free: ZKW_OK when librccl can be loaded and has the symbols the RCCL transport uses (dlopen + dlsym only).
+ * What every rank checks BEFORE rank 0 makes the id: ncclGetUniqueId starts a bootstrap root (a listening socket and a
+ * thread), which only the rank whose id is used should own. */
+int zkw_comm_probe(void);
 int zkw_comm_get_unique_id(zkw_comm_id* out);
 int zkw_comm_create_rccl(zkw_ctx* ctx, int rank, int world, const zkw_comm_id* id, zkw_comm** out);
 /* recv = world x bytes_per_rank, rank order; return 0 on success */
@@ -639,6 +642,69 @@ int zkw_batch_net_states(zkw_batch* batch, void* hip_stream);
  * overflowed its per-instance index capacity (limits.max_log_queries / max_aux_events), ZKW_ERR_INVALID for a failed
  * instance. */
 int zkw_batch_get_net_state(zkw_batch* batch, uint32_t instance, zkw_net_state* out);
+
+/* ---- delivery to the host (SURVEY §8d ii "run + record download"; the drop-in the north star names is a HOST tracer) ----
+ * All ten VmWitnessTracer callbacks (reference src/witness_trace/mod.rs:11-72) run on the CPU, so the witness of every step
+ * has to cross PCIe.  A zkw_delivery owns a persistent ring of pinned host slots (allocated once), a stream of its own and a
+ * pool of host threads.  zkw_delivery_submit enqueues, behind the run of a group of batches, ONE pack kernel that writes the
+ * used extents of everything the step produced — every wave of every batch: directory, record tails, register deltas, the
+ * three query streams, the final scalars / register files / callstack entries — as one contiguous block straight into a
+ * slot of the ring (the kernel's stores are the transfer; the block is a denser encoding than the device streams:
+ * era-zk_evm_amd/csrc/zkw_pack.h).  Step k's delivery runs beside step k + 1's cycle kernel when the caller alternates two
+ * groups of batches.  The host side of a delivered step:
+ *   zkw_delivery_get_instance_trace   the zkw_instance_trace of one instance, rebuilt from the ring (what
+ *                                     zkw_batch_get_instance_trace returns, bit for bit, without touching the device)
+ *   zkw_delivery_replay               every (instance, cycle) of the step handed to a callback on the pool's threads, waves in
+ *                                     parallel, with a pointer to the instance's LIVE 512-byte snapshot — the contract of
+ *                                     start_new_execution_cycle(&local_state) / end_execution_cycle(&local_state)
+ *                                     (witness_trace/mod.rs:11-20): a reference to the state, not a copy per cycle — and the
+ *                                     cycle's queries in emission order
+ * Tickets count submissions (0, 1, 2, ...); ticket t lives in slot t % n_slots until it is released. */
+typedef struct zkw_delivery zkw_delivery;
+typedef struct zkw_delivered {
+  uint64_t bytes;     /* bytes of the block that crossed the link */
+  double pack_ms;     /* device time of the pack kernel (HIP events on the delivery's stream) */
+  uint32_t n_batches, n_waves;
+  uint32_t overflow;  /* != 0: the step did not fit the slot (slot_bytes too small): nothing of it can be read */
+  uint32_t reserved;
+} zkw_delivered;
+/* n_slots >= 1 slots of slot_bytes each (hipHostMalloc, once); host_threads >= 1 worker threads for the replay / rebuild */
+int zkw_delivery_create(zkw_ctx* ctx, uint32_t n_slots, uint64_t slot_bytes, uint32_t host_threads, zkw_delivery** out);
+void zkw_delivery_destroy(zkw_delivery* d);
+/* Upper bound of the block a step of these batches can produce (every stream at its capacity): what slot_bytes must cover
+ * in the worst case; a typical step uses a fraction (zkw_delivered.bytes). */
+int zkw_delivery_slot_bytes(zkw_batch* const* batches, uint32_t n_batches, uint64_t* worst_case);
+/* Delivers the step the batches have just run on `run_stream` (asynchronous: an event on run_stream orders the pack kernel
+ * behind the run; nothing waits on the host).  ZKW_ERR_LIMIT while the slot of the new ticket is still held. */
+int zkw_delivery_submit(zkw_delivery* d, zkw_batch* const* batches, uint32_t n_batches, void* run_stream, uint32_t* ticket);
+/* Makes `hip_stream` wait (on the device) until the pack kernel of `ticket` has read the batches' streams: what the next
+ * reset / restage / run of those batches has to be ordered behind. */
+int zkw_delivery_order_after(zkw_delivery* d, uint32_t ticket, void* hip_stream);
+/* Blocks the host until the block of `ticket` is in the ring. */
+int zkw_delivery_wait(zkw_delivery* d, uint32_t ticket, zkw_delivered* info);
+int zkw_delivery_get_instance_trace(zkw_delivery* d, uint32_t ticket, uint32_t batch_index, uint32_t instance, zkw_instance_trace* out);
+/* `thread` = index of the pool thread that calls (0 .. host_threads - 1): calls of one instance come in cycle order from one
+ * thread, different instances from different threads at once; the pointers are valid during the call only */
+typedef void (*zkw_cycle_fn)(void* user, uint32_t thread, uint32_t batch_index, uint32_t instance, uint32_t cycle, const zkw_cycle_record* state_after,
+                             const zkw_mem_query* mem, uint32_t n_mem, const zkw_log_query* log, uint32_t n_log, const zkw_aux_event* aux, uint32_t n_aux);
+/* fn == NULL: a built-in consumer that reads every byte handed over and folds it into `checksum` (sum over all records of
+ * sum_j u64[j] * (2 j + 1), over the queries with weights 2 j + 3 / 2 j + 5 / 2 j + 7 for memory / log / aux records, mod 2^64:
+ * order-independent, so that a test can compare it with the same fold over zkw_delivery_get_instance_trace).  n_cycles /
+ * checksum may be NULL. */
+int zkw_delivery_replay(zkw_delivery* d, uint32_t ticket, zkw_cycle_fn fn, void* user, uint64_t* n_cycles, uint64_t* checksum);
+int zkw_delivery_release(zkw_delivery* d, uint32_t ticket);
+
+/* ---- fresh inputs for an uploaded batch (the input side of a pipelined caller) ----
+ * New VmLocalStates (registers, flags, pc / sp / ergs ... of the current frame — VmState::empty_state +
+ * push_bootloader_context with other values, reference src/vm_state/mod.rs:188-207, helpers.rs:289-316) and new heap
+ * images (SimpleMemory::populate_heap, memory.rs:287-291) for EVERY instance of a batch that keeps its geometry: same
+ * limits, code, decommit preimages, storage snapshot, callstack depth and heap-image length as uploaded.  The host formats
+ * the images into pinned staging memory of the batch (allocated on first use), one H2D copy per image is enqueued on
+ * `hip_stream` and behind them the device-side restore — asynchronous: the call returns when the copies are enqueued, and a
+ * caller restages group B on a side stream while group A runs.  states [n_instances]; heap_words [n_instances][n_heap_words]
+ * with n_heap_words == the uploaded image length (or NULL / 0: heaps unchanged).  The staged inputs of the batch are updated:
+ * traces rebuilt afterwards replay onto the new initial states. */
+int zkw_batch_restage(zkw_batch* batch, const zkw_vm_local_state* states, const zkw_u256* heap_words, uint32_t n_heap_words, void* hip_stream);
 
 /* Pulls everything the last run produced (record tails, register deltas, the three query streams, the directory; used
  * extents only) over PCIe into pinned staging memory and reports the volume and the transfer time: the cost a host-side

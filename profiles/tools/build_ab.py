@@ -15,7 +15,7 @@ try:
     src = os.path.join(tmp, "era-zk_evm_amd", "csrc")
     out = os.path.join(ROOT, "era-zk_evm_amd", "ab_%s.so" % name)
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-structurizecfg-skip-uniform-regions", "-I", os.path.join(tmp, "include"),
-           "-o", out] + extra + [os.path.join(src, f) for f in ("zkw_kernels.hip", "zkw_commit.hip", "zkw_blake2s.hip", "zkw_expand.hip", "zkw_runtime.cpp", "isa_default.cpp") if os.path.exists(os.path.join(src, f))] + ["-ldl"]
+           "-o", out] + extra + [os.path.join(src, f) for f in ("zkw_kernels.hip", "zkw_commit.hip", "zkw_blake2s.hip", "zkw_expand.hip", "zkw_pack.hip", "zkw_runtime.cpp", "isa_default.cpp") if os.path.exists(os.path.join(src, f))] + ["-ldl"]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     print(out)
 finally:

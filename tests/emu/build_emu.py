@@ -10,7 +10,7 @@ OUT = os.path.join(HERE, "libzkw_emu.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(CSRC, "zkw_kernels.hip"), os.path.join(CSRC, "zkw_commit.hip"), os.path.join(CSRC, "zkw_blake2s.hip"), os.path.join(CSRC, "zkw_expand.hip"), os.path.join(CSRC, "zkw_runtime.cpp"), os.path.join(CSRC, "isa_default.cpp"),
+    srcs = [os.path.join(CSRC, "zkw_kernels.hip"), os.path.join(CSRC, "zkw_commit.hip"), os.path.join(CSRC, "zkw_blake2s.hip"), os.path.join(CSRC, "zkw_expand.hip"), os.path.join(CSRC, "zkw_pack.hip"), os.path.join(CSRC, "zkw_runtime.cpp"), os.path.join(CSRC, "isa_default.cpp"),
             os.path.join(HERE, "emu_glue.cpp")]
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "zkw.h"),
                                                                 os.path.join(HERE, "emu_glue.cpp")]

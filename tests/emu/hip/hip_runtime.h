@@ -118,3 +118,13 @@ static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = mall
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 
 static inline int __shfl_xor(int v, int) { return v; }
+
+// round 5 (zkw_delivery / zkw_batch_restage): streams of their own, stream-to-event ordering, device view of pinned memory —
+// all synchronous here
+enum { hipStreamNonBlocking = 1 };
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }

@@ -123,3 +123,36 @@ def test_trace_pointers_stay_valid_across_more_than_64_waves(emu, isa):
         assert C.string_at(t.records, t.n_cycles * K.CYCLE_RECORD.itemsize) == copies[i][0], i
         assert C.string_at(t.mem, t.n_mem * K.MEM_QUERY.itemsize) == copies[i][1], i
     b.destroy()
+
+
+def test_malformed_isa_tables_are_rejected(isa):
+    """zkw_ctx_set_isa refuses a table whose constants the kernel would evaluate blindly: a condition_lut row that is none of
+    the eight Condition truth tables (cycle.rs:193-209), forwarding codes that collide (far_call.rs:255, ret.rs:59), a zero
+    MAX_OFFSET_FOR_ADD_SUB (ptr.rs:47) — the round-4 advisor finding."""
+    import build_emu
+    be = K.Backend(build_emu.build(), "zkw_")
+    be.call("ctx_create", C.c_int(0), C.byref(be.ctx))
+
+    def rejected(edit, needle):
+        t = isa.table.copy()
+        edit(t["consts"][0])
+        rc = be.fn("ctx_set_isa")(be.ctx, K._ptr(t))
+        msg = (be.fn("last_error")(be.ctx) or b"").decode()
+        assert rc == K.ERR_INVALID and needle in msg, (rc, msg)
+
+    def bad_lut(c):
+        c["condition_lut"] = (int(c["condition_lut"]) & ~(0xFF << 16)) | (0x5A << 16)  # row 2: no Condition
+    rejected(bad_lut, "names no Condition")
+
+    def same_codes(c):
+        c["forwarding_codes"] = 0 | (1 << 8) | (1 << 16)
+    rejected(same_codes, "distinct")
+
+    def zero_max(c):
+        c["max_offset_for_add_sub"] = 0
+    rejected(zero_max, "max_offset_for_add_sub")
+    be.call("ctx_set_isa", be.ctx, K._ptr(isa.table))  # the default table still passes
+    for seed in (1, 2):  # ... and so do the tables of the metamorphic tests
+        v = K.Isa.variant_of_default(seed, swap_forwarding=True, permute_conditions=True, shift_registers=True)
+        be.call("ctx_set_isa", be.ctx, K._ptr(v.table))
+    be.close()

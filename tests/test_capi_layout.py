@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_every_symbol_cited_in_integration_md_exists(lib):
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    cited = sorted(set(re.findall(r"\b(zkw_(?:(?:ctx|batch|batches|isa|abi|comm|reduce)_[a-z0-9_]+|blake2s256(?:_device)?))\b", text)))
+    cited = sorted(set(re.findall(r"\b(zkw_(?:(?:ctx|batch|batches|isa|abi|comm|reduce|delivery)_[a-z0-9_]+|blake2s256(?:_device)?))\b", text)))
     types = {"zkw_isa_table", "zkw_isa_consts", "zkw_isa_entry", "zkw_comm_id"}  # struct names of include/zkw.h, not entry points
     assert cited
     missing = [n for n in cited if n not in types and not hasattr(lib, n)]
@@ -52,7 +52,7 @@ def test_struct_sizes_match_the_bindings(lib):
     expect = {0: K.ISA_TABLE.itemsize, 1: K.CALLSTACK_ENTRY.itemsize, 2: K.VM_LOCAL_STATE.itemsize, 3: K.BLOCK_PROPERTIES.itemsize,
               4: K.STORAGE_SLOT.itemsize, 5: K.LIMITS.itemsize, 6: K.CYCLE_RECORD.itemsize, 7: K.MEM_QUERY.itemsize, 8: K.LOG_QUERY.itemsize,
               9: K.AUX_EVENT.itemsize, 10: C.sizeof(K.InstanceTraceC), 11: K.RUN_STATS.itemsize, 12: K.ISA_CONSTS.itemsize,
-              13: K.EVENT_MESSAGE.itemsize, 14: C.sizeof(K.NetStateC)}
+              13: K.EVENT_MESSAGE.itemsize, 14: C.sizeof(K.NetStateC), 15: C.sizeof(K.DeliveredC)}
     for which, size in expect.items():
         assert lib.zkw_abi_sizeof(which) == size, which
     assert lib.zkw_abi_sizeof(99) == 0

@@ -679,6 +679,27 @@ def test_arena_slots_are_reused(oracle, product, isa, lanes):
     bp.destroy()
 
 
+@pytest.mark.parametrize("lanes", [0, 8])
+def test_decommits_are_not_capped_by_the_frame_limit(oracle, product, isa, lanes):
+    """64 distinct code hashes under max_far_frames = 4 (decommitter.rs:38-96: the history is unbounded), the hashed
+    known_hashes lookup and the per-pair history rows on the device; 17 decommits are repeats (not fresh)"""
+    from test_emu_parity import compare_pages
+    wl = synth.many_far_calls(isa, n_instances=70, distinct=64, max_far_frames=4)
+    bo, bp = _run(oracle, wl), _run(product, wl, lanes)
+    for i in range(wl.n_instances):
+        tp = bp.trace(i)
+        assert tp["status"] == K.STATUS_RUNNING
+        ok, why = K.traces_equal(bo.trace(i), tp)
+        assert ok, "instance %d: %s" % (i, why)
+    dec = bp.trace(69)["aux"]
+    dec = dec[dec["type"] == K.AUX_DECOMMIT]
+    assert int(np.sum(dec["flag"] == 1)) == 66 and int(np.sum(dec["flag"] == 0)) == 17
+    assert np.array_equal(bo.commitments(), bp.commitments())
+    assert compare_pages(bo, bp, wl, [0, 63, 64, 69]) > 50
+    bo.destroy()
+    bp.destroy()
+
+
 def test_arena_limit_is_a_status(product, isa):
     wl = synth.many_far_calls(isa, n_calls=6, plan="KKKKKK", n_instances=70, max_far_frames=4)
     bp = _run(product, wl)
@@ -809,4 +830,54 @@ def test_expand_records_on_the_device(product, isa, cfg, kw, lanes):
         for i in list(range(0, wl.n_instances, 7)) + [wl.n_instances - 1]:
             t = b.trace(i)
             assert host[i, :t["n_cycles"]].tobytes() == t["records"].tobytes(), "fused: instance %d" % i
+    b.destroy(); b2.destroy()
+
+
+RAGGED = {
+    "fuzz": lambda isa: synth.fuzz_workload(isa, n_instances=200, n_ops=96, seed=0xF0E1),
+    "far_calls": lambda isa: synth.many_far_calls(isa, n_calls=12, n_instances=70),
+    "bootloader_returns": lambda isa: synth.bootloader_returns(isa, "heap", n_instances=70),
+    "arena_limit": lambda isa: synth.many_far_calls(isa, n_calls=6, plan="KKKKKK", n_instances=70, max_far_frames=4),
+}
+
+
+@pytest.mark.parametrize("name,lanes", [("fuzz", 0), ("fuzz", 8), ("far_calls", 0), ("bootloader_returns", 0), ("arena_limit", 0)])
+def test_expand_records_of_ragged_waves(product, isa, name, lanes):
+    """The device path of zkw_expand_kernel (the software-pipelined applying wave + the streaming waves with their kmin / kmax
+    branch) on waves whose lanes run DIFFERENT numbers of cycles: instances that ended early, failed lanes (the far-call plan
+    that overruns its arena: ZKW_STATUS_LIMIT), fuzz tapes with several dirty-mask bits per cycle and lanes dropping out —
+    a lone chunked batch and a fused call, both layouts (round-4 advisor finding: only the single-thread emulation branch had
+    seen these)."""
+    import torch
+    wl = RAGGED[name](isa)
+    b = _run(product, wl, lanes)
+    ncy = [b.trace(i)["n_cycles"] for i in range(wl.n_instances)]
+    if name in ("fuzz", "bootloader_returns", "arena_limit"):
+        assert min(ncy) < wl.n_cycles, "the workload was meant to leave some instances short"
+    stride = wl.n_cycles + 1
+    sp = torch.cuda.current_stream().cuda_stream
+    first, count = 1, wl.n_instances - 2
+    dst = torch.full((count, stride, 512), 0xAB, dtype=torch.uint8, device="cuda")
+    b.expand_records(first, count, dst.data_ptr(), stride, sp)  # a lone batch: chunked
+    cm = torch.full((stride, count, 512), 0xEE, dtype=torch.uint8, device="cuda")
+    b.expand_records(first, count, cm.data_ptr(), 1, sp, cycle_stride=count)
+    torch.cuda.synchronize()
+    host, hcm = dst.cpu().numpy(), cm.cpu().numpy()
+    for i in range(first, first + count):
+        t = b.trace(i)
+        n = t["n_cycles"]
+        assert host[i - first, :n].tobytes() == t["records"].tobytes(), "%s instance %d (%d cycles)" % (name, i, n)
+        assert (host[i - first, n:] == 0xAB).all(), "%s instance %d: written behind its last cycle" % (name, i)
+        assert hcm[:n, i - first].tobytes() == t["records"].tobytes(), "cycle-major: instance %d" % i
+        assert (hcm[n:, i - first] == 0xEE).all()
+    b2 = _run(product, RAGGED[name](isa), 0)
+    outs = [torch.full((wl.n_instances, stride, 512), 0xCD, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    product.expand_records_many([b, b2], [o.data_ptr() for o in outs], stride, sp)  # fused
+    torch.cuda.synchronize()
+    for o, bb in zip(outs, (b, b2)):  # (each against its OWN batch: an instance that overruns a stream capacity stops where its wave's pooled capacity ends, which depends on the lane width)
+        host = o.cpu().numpy()
+        for i in range(wl.n_instances):
+            t = bb.trace(i)
+            assert host[i, :t["n_cycles"]].tobytes() == t["records"].tobytes(), "fused: instance %d" % i
+            assert (host[i, t["n_cycles"]:] == 0xCD).all()
     b.destroy(); b2.destroy()
