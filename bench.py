@@ -53,6 +53,8 @@ def parse_args(argv=None):
     ap.add_argument("--cfg", type=int, default=2)
     ap.add_argument("--min-warmup-s", type=float, default=0.6, help="untimed warm-up is extended to at least this long (clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-legs", action="store_true", help="run the two host legs on a workload that is not the headline one (tests)")
+    ap.add_argument("--no-host-legs", action="store_true", help="skip the two host legs the headline command runs after its timed regions: `delivered` (pipelined steps packed into the pinned ring and replayed on the host's cores) and `upload` (fresh inputs for every step)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the other BASELINE configurations that the headline command runs after its timed region")
     ap.add_argument("--repeats", type=int, default=-1, help="further timed regions of the same K steps behind the first (value_min / median / max); default 4 on the headline workload, else 0")
     ap.add_argument("--restore", choices=["between-uses", "every-step"], default="between-uses",
@@ -194,6 +196,7 @@ class Flow:
     def __init__(self, dev, prod, isa, args, rank, world, comm, collective):
         import numpy as np
         self.dev, self.prod, self.args, self.comm, self.collective, self.world, self.rank = dev, prod, args, comm, collective, world, rank
+        self.isa = isa
         self.wl = wl = make_workload(args, isa, rank)
         self.cycles = wl.n_cycles  # (cfg 3: the tape decides — 8 precompile calls + the frame changes around them)
         self.fuse = fuse = max(1, min(args.fuse, 256, args.steps))
@@ -501,6 +504,18 @@ def measure(dev, prod, isa, args, rank, world, comm, collective, transport, with
             hw += int(((ty == K.MEM_HEAP) | (ty == K.MEM_AUX_HEAP)).sum())
             cy += int(tr["n_cycles"])
         heap_words = hw / max(1, cy)
+        # untimed for the headline: the two host legs (N = 1: the link and the host cores are per box)
+        delivered = upload = upload_in_place = None
+        if getattr(args, "host_legs", False) and world == 1 and rank == 0:
+            try:
+                delivered = delivered_leg(dev, prod, flow, st)
+            except Exception as e:  # noqa: BLE001  (an auxiliary measurement must not take the headline line with it)
+                delivered = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            try:
+                upload = upload_leg(dev, prod, flow, in_place=False)
+                upload_in_place = upload_leg(dev, prod, flow, in_place=True)
+            except Exception as e:  # noqa: BLE001
+                upload = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         n_delta = float(st["reg_deltas"]) / max(1, cycles_per_step)
         # bytes the kernel has to move per VM cycle: code word + record tail + register deltas + queries + heap words
         # (the 512-B snapshot of SURVEY §8d is stored losslessly as a 16-B tail + 32 B per written register / per change of
@@ -532,6 +547,7 @@ def measure(dev, prod, isa, args, rank, world, comm, collective, transport, with
             "pcie_download_of_one_step": {"bytes": dl_bytes.value, "ms": dl_ms.value, "GBps": dl_bytes.value / max(dl_ms.value, 1e-9) / 1e6,
                                           "cycles_per_s_if_every_step_were_downloaded": cycles_per_step / (1e-3 * (dl_ms.value + ms_per_step))}, "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
             "kernel_cycles_per_s": cycles_per_step * batches_per_launch / (k_ms * 1e-3),
+            "delivered": delivered, "upload": upload, "upload_in_place": upload_in_place,
             "checked": {"batches": len(flow.batches) * world, "cycles_executed": tot_cycles, "instances_failed": tot_failed},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "frac_alone": b_cycle * cycles_per_step * len(flow.groups[0]) / (k_ms_alone * 1e-3) / 1e9 / 8000.0, "bytes_per_cycle": b_cycle,
@@ -553,6 +569,173 @@ def measure(dev, prod, isa, args, rank, world, comm, collective, transport, with
         np.save(os.environ["ZKW_BENCH_DUMP_GATHERED"], g0.cpu().numpy().astype("<u8") if hasattr(g0, "cpu") else g0)
     flow.close()
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the host side of a caller (SURVEY §8d ii): what reaches a HOST tracer, and what fresh inputs cost — both pipelined, N = 1
+# ---------------------------------------------------------------------------------------------------------------------
+def _host_threads():
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    return max(1, int(os.environ.get("ZKW_BENCH_HOST_THREADS", min(128, max(1, n // 2)))))
+
+
+def delivered_leg(dev, prod, flow, st, steps_min=200, dfuse=None, n_slots=3):
+    """Steps delivered to the host, pipelined: run (cycle kernel + commitments) -> zkw_delivery_submit (ONE pack kernel per
+    group of batches, straight into a slot of the pinned ring, on the delivery's own stream beside the next group's run) ->
+    zkw_delivery_replay on the pool's threads (every cycle of every instance handed to a consumer that reads all of it).
+    A group is restored and run again only behind the delivery of its previous use."""
+    from era_zk_evm_amd import capi as K
+    args, cycles = flow.args, flow.cycles
+    batches = flow.batches
+    if dfuse is None:
+        dfuse = next(d for d in (5, 4, 8, 2, 1) if len(batches) % d == 0 or d == 1)
+    dfuse = max(1, min(dfuse, len(batches)))
+    glist = [batches[i:i + dfuse] for i in range(0, len(batches) - dfuse + 1, dfuse)]
+    n_g = len(glist)
+    if dev.name != "gpu":
+        steps_min = 20  # (tests: the code path)
+    n_sub = max(n_g, (max(steps_min, 3 * n_g * dfuse) + dfuse - 1) // dfuse)
+    # slot size from the counters of a finished run: tails + deltas + 12-byte headers + values + log + aux + the per-instance
+    # sections and tables, 15 % on top (a step that does not fit is reported, never truncated)
+    cyc, inst = int(st["cycles"]), args.instances
+    per_batch = 16 * cyc + 32 * int(st["reg_deltas"]) + 44 * int(st["mem_queries"]) + 128 * int(st["log_queries"]) + 256 * int(st["aux_events"]) + 736 * inst + 64 * (inst // 8 + 64) + 16 * (cycles + 2) * (inst // 8 + 64)
+    slot_bytes = int(1.15 * per_batch * dfuse) + (1 << 20)
+    threads = _host_threads()
+    dv = K.Delivery(prod, n_slots, slot_bytes, threads)
+    arrays = [prod.handle_array(g) for g in glist]
+    main = flow.main_stream
+    flow.prepare()
+    tickets, infos, replay_s, cycles_seen = {}, [], [0.0], [0]
+    per_ticket = []
+
+    def consume(it):
+        t_w = time.perf_counter()
+        info = dv.wait(tickets[it])
+        t_r = time.perf_counter()
+        n, _ = dv.replay(tickets[it])
+        replay_s[0] += time.perf_counter() - t_r
+        per_ticket.append((round(1e3 * (t_r - t_w), 2), round(1e3 * (time.perf_counter() - t_r), 2), round(info["pack_ms"], 2)))
+        cycles_seen[0] += n
+        dv.release(tickets[it])
+        infos.append(info)
+        del tickets[it]
+
+    flow.barrier()
+    t0 = time.perf_counter()
+    for it in range(n_sub):
+        g = it % n_g
+        if it >= n_slots:
+            consume(it - n_slots)
+        if it >= n_g:
+            if (it - n_g) in tickets:
+                dv.order_after(tickets[it - n_g], main.cuda_stream)  # the pack kernel of the group's previous use has read its streams
+            prod.reset_many(glist[g], main.cuda_stream)
+        prod.step_prepared_many(arrays[g], cycles, args.commit_mask, main.cuda_stream)
+        tickets[it] = dv.submit(arrays[g], main.cuda_stream)
+    for it in sorted(tickets):
+        consume(it)
+    dev.sync()
+    wall = time.perf_counter() - t0
+    for g in range(flow.n_groups):
+        flow.pristine[g] = False
+        flow.waits_ready[g] = False
+    dv.close()
+    total_bytes = sum(i["bytes"] for i in infos)
+    pack_ms = sum(i["pack_ms"] for i in infos)
+    steps = n_sub * dfuse
+    return {"cycles_per_s": cycles_seen[0] / wall, "pcie_GBps": total_bytes / max(pack_ms, 1e-9) / 1e6, "pcie_GBps_over_the_region": total_bytes / wall / 1e9,
+            "host_threads": threads, "bytes_per_cycle": total_bytes / max(1, cycles_seen[0]), "steps": steps, "batches_per_delivery": dfuse, "ring_slots": n_slots,
+            "slot_MB": slot_bytes / 1e6, "ms_per_step": 1e3 * wall / steps, "pack_kernel_ms_per_step": pack_ms / steps,
+            "host_replay_cycles_per_s": cycles_seen[0] / max(replay_s[0], 1e-9), "cycles_delivered": cycles_seen[0], "per_ticket_wait_replay_pack_ms_first_and_last": per_ticket[:4] + per_ticket[-4:],
+            "steady_state_cycles_per_s": dfuse * int(st["cycles"]) / (1e-3 * sorted(w + r for w, r, _ in per_ticket)[len(per_ticket) // 2]),
+            "consumer": "zkw_delivery_replay, built-in fold (reads every record and query byte; a pointer to the live 512-byte snapshot per cycle, as the tracer contract has it)"}
+
+
+def upload_leg(dev, prod, flow, steps_min=20, in_place=False, pool_threads=16):
+    """Fresh instances for every step, pipelined: zkw_batch_restage of one half of the batches on a side stream (host copy into the
+    batch's pinned staging, one H2D copy per image, the device-side transpose + restore) while the other half runs; no restore
+    of old inputs anywhere.  Two input sets alternate (other register seeds, other heaps)."""
+    import copy as _copy
+    from concurrent.futures import ThreadPoolExecutor
+    args, cycles = flow.args, flow.cycles
+    batches = flow.batches
+    half = max(1, len(batches) // 2)
+    glist = [batches[:half], batches[half:2 * half]] if len(batches) >= 2 else [batches]
+    n_g = len(glist)
+    a2 = _copy.copy(args)
+    sets = []
+    for k in range(2):
+        from era_zk_evm_amd import synth
+        wl = synth.make(args.cfg, flow.isa, n_instances=args.instances, n_cycles=args.cycles, seed=0x5EED9000 + k) if args.cfg in (1, 2, 4) else flow.wl
+        sets.append((wl.states, wl.heaps))
+    if sets[0][1] is None:
+        return None
+    arrays = [prod.handle_array(g) for g in glist]
+    main = flow.main_stream
+    sides = [dev.stream() for _ in range(n_g)]
+    ev_ready = [dev.event() for _ in range(n_g)]
+    ev_run = [dev.event() for _ in range(n_g)]
+    n_it = max(2 * n_g, (steps_min + half - 1) // half)
+    pool = ThreadPoolExecutor(max_workers=pool_threads)
+    if in_place:
+        views = {id(b): b.staging() for g in glist for b in g}
+
+    def restage(b, k, stream):
+        states, heaps = sets[k]
+        if in_place:
+            sv, hv = views[id(b)]
+            sv[:64] = states[:64]  # (the caller built its inputs in place: a token write — the H2D copies are the cost)
+            b.restage(sv, hv, stream)
+        else:
+            b.restage(states, heaps, stream)
+
+    flow.prepare()
+    if in_place:
+        for g in glist:
+            for b in g:
+                sv, hv = views[id(b)]
+                sv[:] = sets[0][0]
+                hv[:] = sets[0][1]
+    flow.barrier()
+    ran = [False] * n_g
+    t0 = time.perf_counter()
+    t_host = 0.0
+    for it in range(n_it):
+        g = it % n_g
+        side = sides[g]
+        if ran[g]:
+            side.wait_event(ev_run[g])  # the previous run of the group has read its inputs
+        t_h = time.perf_counter()
+        list(pool.map(lambda b: restage(b, (it // n_g) % 2, side.cuda_stream), glist[g]))
+        t_host += time.perf_counter() - t_h
+        ev_ready[g].record(side)
+        main.wait_event(ev_ready[g])
+        prod.step_prepared_many(arrays[g], cycles, args.commit_mask, main.cuda_stream)
+        ev_run[g].record(main)
+        ran[g] = True
+    dev.sync()
+    wall = time.perf_counter() - t0
+    pool.shutdown()
+    for g in range(flow.n_groups):
+        flow.pristine[g] = False
+        flow.waits_ready[g] = False
+    steps = n_it * half
+    per_step = args.instances * (K_VM_STATE_BYTES + 32 * sets[0][1].shape[1])
+    # the restaged states are input set (n_it - 1) // n_g % 2 ...: restore the workload's own inputs for whatever runs next
+    for g in glist:
+        for b in g:
+            b.restage(flow.wl.states, flow.wl.heaps, main.cuda_stream)
+    dev.sync()
+    return {"bytes_per_step": per_step, "GBps": per_step * steps / wall / 1e9, "cycles_per_s_with_fresh_inputs": steps * args.instances * cycles / wall, "steps": steps,
+            "ms_per_step": 1e3 * wall / steps, "host_ms_per_step": 1e3 * t_host / steps, "host_threads": pool_threads, "in_place": in_place,
+            "batches_per_restage_group": half}
+
+
+K_VM_STATE_BYTES = 680
 
 
 def cfg3_line(out, args, flow, prod, isa, value, elapsed, k_ms, k_ms_alone, batches_per_launch, world):
@@ -628,7 +811,7 @@ def other_configs(dev, prod, isa, base_args, comm, transport, with_cpu):
         a = copy.copy(base_args)
         a.cfg, a.instances, a.steps, a.warmup, a.fuse, a.streams, a.commit_mask = oc["cfg"], oc["instances"], oc["steps"], oc["warmup"], oc["fuse"], oc["streams"], oc["commit_mask"]
         a.cycles = oc["cycles"] or 256
-        a.lanes, a.min_warmup_s, a.restore = 0, 0.2, "between-uses"
+        a.lanes, a.min_warmup_s, a.restore, a.host_legs = 0, 0.2, "between-uses", False
         t0 = time.perf_counter()
         oc_comm = None
         try:
@@ -715,6 +898,7 @@ def main():
     headline = args.cfg == 2 and args.instances == 4096 and args.cycles == 256 and args.lanes == 0
     repeats = args.repeats if args.repeats >= 0 else (4 if headline and not emu else 0)
     with_cpu = not args.no_cpu_baseline and world == 1 and not emu  # rank 0 at N = 1 only
+    args.host_legs = (headline or args.host_legs) and world == 1 and not collective and not args.no_host_legs and not os.environ.get("ZKW_BENCH_NO_HOST_LEGS")
     out = measure(dev, prod, isa, args, rank, world, comm, collective, transport, with_cpu, repeats=repeats)
     if rank == 0 and headline and world == 1 and not args.no_other_configs and not emu and not collective and not os.environ.get("ZKW_BENCH_NO_OTHER_CONFIGS"):  # (the env switch: profiles/collect.sh's sweeps)
         out["other_configs"], out["other_configs_wall_s"] = other_configs(dev, prod, isa, args, comm, transport, with_cpu)

@@ -642,6 +642,18 @@ class Batch:
         self.be.call("batch_get_instance_trace", self.h, C.c_uint32(i), C.byref(t))
         return _trace_dict(t)
 
+    def staging(self):
+        """zkw_batch_staging: numpy views of the batch's pinned staging buffers — states [n] and heap images [n, words, 4] — for a
+        caller that builds its next inputs in place (restage(*batch.staging()) then copies nothing on the host)"""
+        sp, hp, nh = C.c_void_p(), C.c_void_p(), C.c_uint32()
+        self.be.call("batch_staging", self.h, C.byref(sp), C.byref(hp), C.byref(nh))
+        n = self.wl.n_instances
+        states = np.frombuffer((C.c_uint8 * (n * VM_LOCAL_STATE.itemsize)).from_address(sp.value), dtype=VM_LOCAL_STATE, count=n)
+        heaps = None
+        if nh.value:
+            heaps = np.frombuffer((C.c_uint8 * (n * nh.value * 32)).from_address(hp.value), dtype="<u8").reshape(n, nh.value, 4)
+        return states, heaps
+
     def restage(self, states, heaps=None, stream=None):
         """zkw_batch_restage: new VmLocalStates (and heap images) for every instance of the uploaded batch, asynchronously on
         `stream`; the batch is restored to them (as after zkw_batch_reset)"""

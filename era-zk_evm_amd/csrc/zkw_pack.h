@@ -89,3 +89,18 @@ typedef struct zkw_pack_args {
   uint32_t only_wave;   /* 0xffffffff: every wave; else the one wave (of the one batch) to pack — the on-demand path of zkw_batch_get_instance_trace */
   uint32_t reserved;
 } zkw_pack_args;
+
+/* zkw_restage_kernel: fresh inputs of an uploaded batch, brought into the device layouts ON the device.  The host hands over
+ * what the C ABI takes — VmLocalStates [n] and heap images [n][image_words] u256, instance-major, through pinned staging and
+ * one H2D copy each — and the kernel writes the pristine images: the lane-interleaved register files ([wave][30][L]) and heap
+ * image ([wave][word][2][L]), the scalars, the `current` row of the callstack.  (Formatted on the host the interleave is a
+ * 33 MB scatter per 4096-instance batch: several milliseconds of one core against the 0.65 ms its H2D copy takes.) */
+typedef struct zkw_restage_params {
+  const zkw_vm_local_state* states; /* device copy of the caller's states [n_instances] */
+  const uint4* heaps;               /* device copy of the heap images [n_instances][image_words][2] (NULL: heaps unchanged) */
+  uint4* regs0;                     /* [n_waves][30][L] */
+  zkw_dev_scalars* scalars0;        /* [n_instances] */
+  zkw_dev_entry* callstack0;        /* [n_instances][D + 1] */
+  uint4* heap0;                     /* [n_waves][image_words][2][L] */
+  uint32_t n_instances, L, n_waves, D, image_words, reserved0;
+} zkw_restage_params;

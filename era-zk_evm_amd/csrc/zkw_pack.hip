@@ -224,3 +224,69 @@ extern "C" hipError_t zkw_launch_pack(const zkw_pack_args* A, uint32_t wave_thre
   hipLaunchKernelGGL(zkw_pack_kernel, dim3(g), dim3(wave_threads > 1 ? ZKW_PACK_THREADS : 1), 0, stream, *A);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// zkw_restage_kernel (zkw_pack.h): VmLocalStates + instance-major heap images -> the pristine device images of a batch
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) zkw_restage_kernel(zkw_restage_params R) {
+  const u64 stride = (u64)gridDim.x * blockDim.x, t0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  // states: one thread per instance (lane = instance: the 30 register chunks of adjacent threads are adjacent)
+  for (u64 i = t0; i < R.n_instances; i += stride) {
+    const zkw_vm_local_state* st = R.states + i;
+    const u32 w = (u32)(i / R.L), l = (u32)(i % R.L);
+    const uint4* rv = (const uint4*)st->registers;
+    for (u32 ch = 0; ch < ZKW_REG_CHUNKS; ch++) R.regs0[((u64)w * ZKW_REG_CHUNKS + ch) * R.L + l] = rv[ch];
+    // the scalar half (the same mapping as format_instance in zkw_runtime.cpp; the arena bookkeeping — first dynamic page,
+    // initial slots — follows the state, the rest of the row is what the upload put there)
+    zkw_dev_scalars sc = R.scalars0[i];
+    const u32* pcw = (const u32*)st->previous_code_word.l;
+    for (int k = 0; k < 8; k++) sc.prev_code_word[k] = pcw[k];
+    const u32* cx = (const u32*)st->context_u128_register;
+    for (int k = 0; k < 4; k++) sc.ctx_u128_reg[k] = cx[k];
+    sc.ptr_bitmap = st->register_ptr_bitmap & 0x7fffu;
+    sc.flags = (st->flags & 7u) | (st->pending_exception ? 8u : 0u);
+    sc.prev_code_page = st->previous_code_memory_page;
+    sc.timestamp = st->timestamp;
+    sc.cycle_counter = st->monotonic_cycle_counter;
+    sc.spent_pubdata = st->spent_pubdata_counter;
+    sc.memory_page_counter = st->memory_page_counter;
+    sc.absolute_execution_step = st->absolute_execution_step;
+    sc.ergs_per_pubdata = st->current_ergs_per_pubdata_byte;
+    sc.tx_number = st->tx_number_in_block;
+    sc.prev_super_pc = st->previous_super_pc;
+    sc.depth = st->callstack_depth;
+    sc.status = ZKW_STATUS_RUNNING;
+    sc.n_cycles = 0;
+    sc.first_dynamic_page = st->memory_page_counter;
+    R.scalars0[i] = sc;
+    // callstack.current: the ABI struct of the row at `depth`; blob, arena slot and journal mark of the row stay (the host has
+    // checked that code page and base page are the uploaded ones)
+    zkw_dev_entry* row = R.callstack0 + i * (R.D + 1) + st->callstack_depth;
+    zkw_callstack_entry e = st->current;
+    e.reserved0 = 0;
+    e.reserved1 = 0;
+    row->e = e;
+  }
+  // heap images: out[((w * words + k) * 2 + half) * L + l] = in[(i * words + k) * 2 + half]; consecutive threads = consecutive lanes
+  // of one (word, half): the stores are whole lines, the loads 16 bytes out of each lane's own image
+  if (R.heaps && R.image_words) {
+    const u64 per_wave = (u64)R.image_words * 2u * R.L, total = per_wave * R.n_waves;
+    for (u64 o = t0; o < total; o += stride) {
+      const u32 w = (u32)(o / per_wave);
+      const u64 r = o % per_wave;
+      const u32 l = (u32)(r % R.L);
+      const u64 kh = r / R.L;  // word * 2 + half
+      const u64 i = (u64)w * R.L + l;
+      R.heap0[o] = i < R.n_instances ? R.heaps[i * R.image_words * 2u + kh] : make_uint4(0, 0, 0, 0);
+    }
+  }
+}
+
+extern "C" hipError_t zkw_launch_restage(const zkw_restage_params* R, uint32_t wave_threads, hipStream_t stream) {
+  const uint64_t work = (uint64_t)R->n_waves * R->image_words * 2u * R->L + R->n_instances;
+  uint32_t blocks = (uint32_t)((work + 4u * 256u - 1) / (4u * 256u));
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(zkw_restage_kernel, dim3(wave_threads > 1 ? blocks : 1), dim3(wave_threads > 1 ? 256 : 1), 0, stream, *R);
+  return hipGetLastError();
+}

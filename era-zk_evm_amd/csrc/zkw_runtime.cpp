@@ -33,6 +33,7 @@ extern "C" uint32_t zkw_cycle_kernel_lds_bytes(uint32_t L, uint32_t waves_per_gr
 extern "C" hipError_t zkw_launch_reset_kernel(const zkw_fused_table* T, hipStream_t stream);
 extern "C" hipError_t zkw_launch_commit(const zkw_fused_table* T, int stage, hipStream_t stream);
 extern "C" hipError_t zkw_launch_pack(const zkw_pack_args* A, uint32_t wave_threads, uint32_t blocks, hipStream_t stream);
+extern "C" hipError_t zkw_launch_restage(const zkw_restage_params* R, uint32_t wave_threads, hipStream_t stream);
 extern "C" hipError_t zkw_launch_expand(const zkw_kparams* const* kp, void* const* dst, const uint32_t* n_waves, uint32_t n, uint64_t stride_i, uint64_t stride_k, uint32_t first,
                                         uint32_t count, uint32_t L, uint32_t wave_threads, uint32_t max_cycles_run, uint32_t n_cus, hipStream_t stream);
 
@@ -189,7 +190,9 @@ struct zkw_batch {
   std::vector<zkw_log_query> ns_st_hist, ns_ev_hist;
   std::vector<zkw_event_message> ns_events, ns_l1;
   std::vector<zkw_storage_slot> ns_final;
-  uint8_t* h_stage = nullptr;    // pinned staging of zkw_batch_restage ([regs | scalars | callstack | heap image])
+  uint8_t* h_stage = nullptr;    // pinned staging of zkw_batch_restage ([states | heap images], instance-major) ...
+  DevBuf<uint8_t> d_stage;       // ... and where its H2D copies land (zkw_restage_kernel brings them into the device layouts)
+  bool heaps_restaged = false;   // the staged heap vectors are older than the device's images
   size_t h_stage_bytes = 0;
   hipEvent_t ev_stage = nullptr;
   bool stage_busy = false;
@@ -479,6 +482,7 @@ void zkw_batch_destroy(zkw_batch* b) {
   b->d_idx.release(); b->d_counts.release(); b->d_dq_count.release(); b->d_dq_prev.release(); b->d_pack_state.release();
   if (b->h_pack) (void)hipHostFree(b->h_pack);
   if (b->h_stage) (void)hipHostFree(b->h_stage);
+  b->d_stage.release();
   if (b->ev_stage) (void)hipEventDestroy(b->ev_stage);
   if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
   if (b->graph) (void)hipGraphDestroy(b->graph);
@@ -554,6 +558,7 @@ int zkw_batch_set_heap(zkw_batch* b, uint32_t instance, const zkw_u256* words, u
     return ZKW_ERR_LIMIT;
   }
   b->staged[instance].heap.assign(words, words + n_words);
+  b->heaps_restaged = false;  // (the caller is setting heaps again: a re-upload uses these)
   invalidate_inputs(b);
   return ZKW_OK;
 }
@@ -695,6 +700,10 @@ int zkw_batch_upload(zkw_batch* b) {
   zkw_ctx* c = b->ctx;
   HIP_TRY(c, hipSetDevice(c->device));
   invalidate_inputs(b);  // a re-upload may change the geometry (wave width, wave count) a captured step graph holds by value
+  if (b->heaps_restaged) {
+    c->last_error = "zkw_batch_upload: the heap images were replaced by zkw_batch_restage and the staged ones are stale: zkw_batch_set_heap again first";
+    return ZKW_ERR_INVALID;
+  }
   for (uint32_t i = 0; i < b->n; i++)
     if (!b->staged[i].has_state) {
       c->last_error = "instance " + std::to_string(i) + " has no state (zkw_batch_set_state)";
@@ -2128,6 +2137,44 @@ int zkw_delivery_release(zkw_delivery* d, uint32_t ticket) {
   return ZKW_OK;
 }
 
+// pinned staging of a batch's fresh inputs ([states | heap images], instance-major as the C ABI takes them) + the device
+// buffers the H2D copies land in: allocated on first use
+static int ensure_stage(zkw_batch* b) {
+  zkw_ctx* c = b->ctx;
+  const size_t bytes = (size_t)b->n * sizeof(zkw_vm_local_state) + (size_t)b->n * b->heap_image_words * 32 + 16;
+  if (b->h_stage_bytes >= bytes) return ZKW_OK;
+  if (b->stage_busy) HIP_TRY(c, hipEventSynchronize(b->ev_stage));
+  b->stage_busy = false;
+  if (b->h_stage) (void)hipHostFree(b->h_stage);
+  b->h_stage = nullptr;
+  b->d_stage.release();
+  HIP_TRY(c, hipHostMalloc((void**)&b->h_stage, bytes, hipHostMallocDefault));
+  HIP_TRY(c, b->d_stage.alloc(bytes));
+  b->h_stage_bytes = bytes;
+  if (!b->ev_stage) HIP_TRY(c, hipEventCreate(&b->ev_stage));
+  return ZKW_OK;
+}
+
+int zkw_batch_staging(zkw_batch* b, zkw_vm_local_state** states, zkw_u256** heap_words, uint32_t* n_heap_words) {
+  if (!b || !states) return ZKW_ERR_INVALID;
+  zkw_ctx* c = b->ctx;
+  if (!b->uploaded) {
+    c->last_error = "zkw_batch_staging: the batch has not been uploaded";
+    return ZKW_ERR_INVALID;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = ensure_stage(b);
+  if (rc != ZKW_OK) return rc;
+  if (b->stage_busy) {  // the copies of the previous restage still read the staging memory
+    HIP_TRY(c, hipEventSynchronize(b->ev_stage));
+    b->stage_busy = false;
+  }
+  *states = (zkw_vm_local_state*)b->h_stage;
+  if (heap_words) *heap_words = (zkw_u256*)(b->h_stage + (((size_t)b->n * sizeof(zkw_vm_local_state) + 15) & ~(size_t)15));
+  if (n_heap_words) *n_heap_words = b->heap_image_words;
+  return ZKW_OK;
+}
+
 int zkw_batch_restage(zkw_batch* b, const zkw_vm_local_state* states, const zkw_u256* heap_words, uint32_t n_heap_words, void* hip_stream) {
   if (!b || !states) return ZKW_ERR_INVALID;
   zkw_ctx* c = b->ctx;
@@ -2135,57 +2182,50 @@ int zkw_batch_restage(zkw_batch* b, const zkw_vm_local_state* states, const zkw_
     c->last_error = "zkw_batch_restage: the batch has not been uploaded";
     return ZKW_ERR_INVALID;
   }
-  const uint32_t n = b->n, L = b->L, W = b->n_waves, himg = b->heap_image_words, D = b->lim.max_callstack_depth;
+  const uint32_t n = b->n, himg = b->heap_image_words;
   if (heap_words && n_heap_words != himg) {
     c->last_error = "zkw_batch_restage: the heap images must be as long as the uploaded ones (" + std::to_string(himg) + " words)";
     return ZKW_ERR_INVALID;
   }
-  for (uint32_t i = 0; i < n; i++)
-    if (states[i].callstack_depth != b->staged[i].state.callstack_depth) {
-      c->last_error = "zkw_batch_restage: instance " + std::to_string(i) + " changes its callstack depth (geometry is fixed at upload)";
+  // geometry is fixed at upload: callstack depth, code page and base page of the current frame (their blob and arena slot stay)
+  for (uint32_t i = 0; i < n; i++) {
+    const zkw_vm_local_state& o = b->staged[i].state;
+    if (states[i].callstack_depth != o.callstack_depth || states[i].current.code_page != o.current.code_page || states[i].current.base_memory_page != o.current.base_memory_page ||
+        states[i].current.is_local_frame != o.current.is_local_frame) {
+      c->last_error = "zkw_batch_restage: instance " + std::to_string(i) + " changes its callstack depth / code page / base page (fixed at upload: upload again)";
       return ZKW_ERR_INVALID;
     }
+  }
   HIP_TRY(c, hipSetDevice(c->device));
-  // pinned staging of the batch: [regs | scalars | callstack | heap image], allocated once
-  const size_t n_regs = (size_t)W * ZKW_REG_CHUNKS * L, n_stack = (size_t)n * (D + 1), n_heap = (size_t)W * himg * L * 2;
-  const size_t bytes = n_regs * 16 + (size_t)n * sizeof(zkw_dev_scalars) + n_stack * sizeof(zkw_dev_entry) + n_heap * 16;
-  if (b->h_stage_bytes < bytes) {
-    if (b->h_stage) (void)hipHostFree(b->h_stage);
-    b->h_stage = nullptr;
-    HIP_TRY(c, hipHostMalloc((void**)&b->h_stage, bytes, hipHostMallocDefault));
-    b->h_stage_bytes = bytes;
-    if (!b->ev_stage) HIP_TRY(c, hipEventCreate(&b->ev_stage));
-    b->stage_busy = false;
-  }
-  if (b->stage_busy) HIP_TRY(c, hipEventSynchronize(b->ev_stage));  // the copies of the previous restage still read the staging memory
-  uint4* regs = (uint4*)b->h_stage;
-  zkw_dev_scalars* scal = (zkw_dev_scalars*)(regs + n_regs);
-  zkw_dev_entry* stack = (zkw_dev_entry*)(scal + n);
-  uint4* heap0 = (uint4*)(stack + n_stack);
-  std::memset(scal, 0, (size_t)n * sizeof(zkw_dev_scalars));
-  std::memset(stack, 0, n_stack * sizeof(zkw_dev_entry));
-  if (n_regs > (size_t)n * ZKW_REG_CHUNKS) std::memset(regs, 0, n_regs * 16);  // (lanes of the last wave without an instance)
-  std::vector<zkw_dev_frame_meta> frames_scratch((size_t)n * b->lim.max_far_frames);  // (the frame metas do not change: geometry is fixed)
-  std::memset(frames_scratch.data(), 0, frames_scratch.size() * sizeof(zkw_dev_frame_meta));
-  for (uint32_t i = 0; i < n; i++) {
-    StagedInstance& si = b->staged[i];
-    si.state = states[i];
-    if (heap_words) si.heap.assign(heap_words + (size_t)i * himg, heap_words + (size_t)(i + 1) * himg);
-    std::string err;
-    const int frc = format_instance(b, i, himg, regs, scal, stack, frames_scratch.data(), heap0, &err);
-    if (frc != ZKW_OK) {
-      c->last_error = err;
-      return frc;
+  int rc = ensure_stage(b);
+  if (rc != ZKW_OK) return rc;
+  const size_t st_bytes = (size_t)n * sizeof(zkw_vm_local_state), heap_off = (st_bytes + 15) & ~(size_t)15, heap_bytes = (size_t)n * himg * 32;
+  const bool in_place = (const uint8_t*)states == b->h_stage;  // the caller filled the staging memory of zkw_batch_staging: nothing to copy
+  if (!in_place) {
+    if (b->stage_busy) {
+      HIP_TRY(c, hipEventSynchronize(b->ev_stage));
+      b->stage_busy = false;
     }
+    std::memcpy(b->h_stage, states, st_bytes);
   }
+  if (heap_words && (const uint8_t*)heap_words != b->h_stage + heap_off) std::memcpy(b->h_stage + heap_off, heap_words, heap_bytes);
+  // the library's own copy of the initial states (what a trace is rebuilt onto); the staged heap vectors are not kept in step —
+  // a later zkw_batch_upload needs zkw_batch_set_heap again
+  for (uint32_t i = 0; i < n; i++) b->staged[i].state = states[i];
+  if (heap_words) b->heaps_restaged = true;
   hipStream_t st = (hipStream_t)hip_stream;
-  HIP_TRY(c, hipMemcpyAsync(b->d_regs0.p, regs, n_regs * 16, hipMemcpyHostToDevice, st));
-  HIP_TRY(c, hipMemcpyAsync(b->d_scalars0.p, scal, (size_t)n * sizeof(zkw_dev_scalars), hipMemcpyHostToDevice, st));
-  HIP_TRY(c, hipMemcpyAsync(b->d_callstack0.p, stack, n_stack * sizeof(zkw_dev_entry), hipMemcpyHostToDevice, st));
-  if (n_heap && (heap_words || true)) HIP_TRY(c, hipMemcpyAsync(b->d_heap0.p, heap0, n_heap * 16, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(b->d_stage.p, b->h_stage, st_bytes, hipMemcpyHostToDevice, st));
+  if (heap_words && heap_bytes) HIP_TRY(c, hipMemcpyAsync(b->d_stage.p + heap_off, b->h_stage + heap_off, heap_bytes, hipMemcpyHostToDevice, st));
   HIP_TRY(c, hipEventRecord(b->ev_stage, st));
   b->stage_busy = true;
-  b->full_reset_pending = true;  // the whole heap image goes into the arena, not the words a run had dirtied
+  zkw_restage_params R;
+  std::memset(&R, 0, sizeof R);
+  R.states = (const zkw_vm_local_state*)b->d_stage.p;
+  R.heaps = heap_words ? (const uint4*)(b->d_stage.p + heap_off) : nullptr;
+  R.regs0 = b->d_regs0.p; R.scalars0 = b->d_scalars0.p; R.callstack0 = b->d_callstack0.p; R.heap0 = b->d_heap0.p;
+  R.n_instances = n; R.L = b->L; R.n_waves = b->n_waves; R.D = b->lim.max_callstack_depth; R.image_words = himg;
+  HIP_TRY(c, zkw_launch_restage(&R, (uint32_t)c->wave_width, st));
+  b->full_reset_pending = true;  // the whole heap image goes into the arena, not just the words a run had dirtied
   zkw_batch* one[1] = {b};
   return enqueue_reset(one, 1, st);
 }

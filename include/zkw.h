@@ -703,7 +703,14 @@ int zkw_delivery_release(zkw_delivery* d, uint32_t ticket);
  * `hip_stream` and behind them the device-side restore — asynchronous: the call returns when the copies are enqueued, and a
  * caller restages group B on a side stream while group A runs.  states [n_instances]; heap_words [n_instances][n_heap_words]
  * with n_heap_words == the uploaded image length (or NULL / 0: heaps unchanged).  The staged inputs of the batch are updated:
- * traces rebuilt afterwards replay onto the new initial states. */
+ * traces rebuilt afterwards replay onto the new initial states.
+ * The interleaved device layouts are produced ON the device (zkw_restage_kernel): the host only copies the caller's arrays
+ * into pinned memory — or not even that: zkw_batch_staging hands out the pinned buffers themselves (states [n_instances],
+ * heap_words [n_instances][*n_heap_words]), a caller that builds its inputs there passes those pointers to zkw_batch_restage
+ * and nothing is copied on the host.  (zkw_batch_staging waits until the copies of the previous restage have left the
+ * buffers.)  After a restage with heap images the library no longer holds the batch's heaps on the host: another
+ * zkw_batch_upload needs zkw_batch_set_heap again. */
+int zkw_batch_staging(zkw_batch* batch, zkw_vm_local_state** states, zkw_u256** heap_words, uint32_t* n_heap_words);
 int zkw_batch_restage(zkw_batch* batch, const zkw_vm_local_state* states, const zkw_u256* heap_words, uint32_t n_heap_words, void* hip_stream);
 
 /* Pulls everything the last run produced (record tails, register deltas, the three query streams, the directory; used

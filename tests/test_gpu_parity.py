@@ -881,3 +881,52 @@ def test_expand_records_of_ragged_waves(product, isa, name, lanes):
             assert host[i, :t["n_cycles"]].tobytes() == t["records"].tobytes(), "fused: instance %d" % i
             assert (host[i, t["n_cycles"]:] == 0xCD).all()
     b.destroy(); b2.destroy()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the host-delivery path (zkw_delivery, include/zkw.h): whole steps through the 256-thread pack kernel into the pinned ring,
+# traces rebuilt from the ring == oracle; fresh inputs through zkw_batch_restage
+# ---------------------------------------------------------------------------------------------------------------
+DELIVERY_WORKLOADS = {
+    "cfg2": lambda isa: synth.make(2, isa, n_instances=200),
+    "cfg4": lambda isa: synth.make(4, isa, n_instances=96, n_cycles=512),
+    "cfg3": lambda isa: synth.make(3, isa, n_instances=70, keccak_bytes=(136, 300, 40, 272), keccak_unalign=(0, 31, 7, 1), sha_rounds=(1, 2, 1, 3)),
+    "fuzz": lambda isa: synth.fuzz_workload(isa, n_instances=150, n_ops=96, seed=0xF0D1),
+    "far_calls": lambda isa: synth.many_far_calls(isa, n_calls=12, n_instances=70),
+    "ended": lambda isa: synth.bootloader_returns(isa, "heap", n_instances=70),
+}
+
+
+@pytest.mark.parametrize("names,lanes,threads", [(["cfg2", "cfg4", "far_calls"], None, 8), (["fuzz", "cfg3", "ended"], None, 3), (["cfg2", "fuzz"], 8, 5)])
+def test_traces_rebuilt_from_the_ring_equal_the_oracle(oracle, product, isa, names, lanes, threads):
+    """zkw_delivery: one pack kernel per step writes the used extents of every wave of every batch into a pinned slot; every
+    trace rebuilt from the ring == the oracle's == zkw_batch_get_instance_trace; the multi-threaded replay hands over every
+    cycle once (count + order-independent checksum == the fold over the traces)"""
+    from test_delivery import check_delivered_step
+    info = check_delivered_step(oracle, product, isa, names, threads, lanes=lanes, workloads=DELIVERY_WORKLOADS, sample=[0, 1, 7, 8, 63, 64, 65, 95, 127, 128, 149])
+    assert info["pack_ms"] > 0
+
+
+def test_restage_gives_fresh_inputs_on_the_device(oracle, product, isa):
+    """zkw_batch_restage on a side stream: new register files, scalars, callstack rows and heap images arrive by H2D copies from
+    the batch's pinned staging, the restore follows on the same stream, the run on another one is ordered behind it by an event"""
+    import torch
+    wl_a = synth.make(2, isa, n_instances=200)
+    b = product.create_batch(wl_a)
+    side, main = torch.cuda.Stream(), torch.cuda.Stream()
+    ev = torch.cuda.Event()
+    for seed in (0x5EED7700, 0x5EED7701, 0x5EED7702):
+        wl_b = synth.make(2, isa, n_instances=200, seed=seed)
+        b.restage(wl_b.states, wl_b.heaps, side.cuda_stream)
+        ev.record(side)
+        main.wait_event(ev)
+        b.run(wl_a.n_cycles, main.cuda_stream)
+        b.sync()
+        wl_ref = synth.make(2, isa, n_instances=200)
+        wl_ref.states, wl_ref.heaps = wl_b.states, wl_b.heaps
+        bo = _run(oracle, wl_ref)
+        for i in (0, 1, 63, 64, 127, 199):
+            ok, why = K.traces_equal(bo.trace(i), b.trace(i))
+            assert ok, "seed %x instance %d: %s" % (seed, i, why)
+        bo.destroy()
+    b.destroy()

@@ -182,3 +182,22 @@ def test_bench_flow_restore_every_step_region(tmp_path, oracle, isa):
             "--repeats", "1", "--no-other-configs"]
     j = _bench_flow(tmp_path, oracle, isa, 2, argv, 3, 2, 2)
     assert j["timed_regions"] == 2 and j["restore_in_front_of_every_step"]["value"] > 0
+
+
+def test_bench_host_legs_on_the_emulation_build(tmp_path, isa):
+    """bench.py's `delivered` and `upload` legs — groups of batches delivered into the pinned ring behind their runs and
+    replayed on host threads, a reused group restored only behind its delivery; fresh inputs restaged on a side 'stream' for
+    every step, both the copying and the in-place form — run end to end on the CPU build (the code path, not its speed)"""
+    import json
+    import subprocess
+    env = dict(os.environ, ZKW_BENCH_BACKEND="emu", ZKW_BENCH_HOST_THREADS="3", PYTHONPATH=ROOT)
+    argv = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--fuse", "4", "--streams", "1", "--instances", "3", "--commit-mask", "4",
+            "--no-cpu-baseline", "--min-warmup-s", "0", "--no-other-configs", "--host-legs", "--repeats", "0"]
+    r = subprocess.run(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    d, u, ui = j["delivered"], j["upload"], j["upload_in_place"]
+    assert "error" not in d and "error" not in u, (d, u)
+    assert d["steps"] >= 20 and d["cycles_delivered"] == d["steps"] * 3 * 256 and d["host_threads"] == 3 and 60 < d["bytes_per_cycle"] < 400
+    assert u["steps"] >= 20 and u["bytes_per_step"] == 3 * (680 + 32 * 256) and not u["in_place"] and ui["in_place"]
+    assert j["checked"]["instances_failed"] == 0
