@@ -462,6 +462,20 @@ def measure(dev, prod, isa, args, rank, world, comm, collective, transport, with
             fused_ms = best_ms(lambda: prod.expand_records_many(group0, [x.data_ptr() for x in bufs], cycles, sp))
             fused_cm_ms = best_ms(lambda: prod.expand_records_many(group0, [x.data_ptr() for x in bufs], 1, sp, cycle_stride=args.instances))  # cycle-major
             n_rec = int(st["cycles"])
+            # the whole snapshot pipeline: a step (cycle kernel + commitments) and the expansion of its records back to back on one
+            # stream — what a DEVICE-side consumer of SURVEY 8d's 512-byte CycleRecords gets per second
+            g0_arr = prod.handle_array(group0)
+            pipe_ms = None
+            for _ in range(4):
+                prod.reset_many(group0, sp)
+                ev0.record(flow.main_stream)
+                prod.step_prepared_many(g0_arr, cycles, args.commit_mask, sp)
+                prod.expand_records_many(group0, [x.data_ptr() for x in bufs], 1, sp, cycle_stride=args.instances)
+                ev1.record(flow.main_stream)
+                flow.main_stream.synchronize()
+                ms_ = ev0.elapsed_time(ev1)
+                pipe_ms = ms_ if pipe_ms is None else min(pipe_ms, ms_)
+            flow.pristine[0] = False
             t_h = time.perf_counter()
             tr0 = batch.trace(0)  # builds wave 0 on the host: downloads its streams, replays the deltas, de-interleaves the queries
             t_h = time.perf_counter() - t_h
@@ -470,6 +484,7 @@ def measure(dev, prod, isa, args, rank, world, comm, collective, transport, with
                       "frac_of_8TBps": len(group0) * n_rec * 512 / (fused_ms * 1e-3) / 8e12, "layout": "instance-major (records of an instance contiguous)",
                       "cycle_major_kernel_ms": fused_cm_ms, "cycle_major_GBps": len(group0) * n_rec * 512 / (fused_cm_ms * 1e-3) / 1e9,
                       "one_batch_kernel_ms": one_ms, "one_batch_GBps": n_rec * 512 / (one_ms * 1e-3) / 1e9, "records_per_batch": n_rec,
+                      "snapshot_pipeline_ms": pipe_ms, "snapshot_pipeline_cycles_per_s": len(group0) * n_rec / (pipe_ms * 1e-3),
                       "host_rebuild_one_wave_ms": 1e3 * t_h, "host_rebuild_records_per_s_one_core": lanes_w0 * int(tr0["n_cycles"]) / t_h,
                       "host_rebuild_GBps_one_core": lanes_w0 * int(tr0["n_cycles"]) * 512 / t_h / 1e9}
             del bufs
@@ -548,7 +563,12 @@ def measure(dev, prod, isa, args, rank, world, comm, collective, transport, with
                                           "cycles_per_s_if_every_step_were_downloaded": cycles_per_step / (1e-3 * (dl_ms.value + ms_per_step))}, "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
             "kernel_cycles_per_s": cycles_per_step * batches_per_launch / (k_ms * 1e-3),
             "delivered": delivered, "upload": upload, "upload_in_place": upload_in_place,
+            # cycle kernel + device-side expansion of the 512-byte snapshots back to back (cycle-major), on SURVEY 8d's literal bytes
+            "snapshot_pipeline": ({"cycles_per_s": expand["snapshot_pipeline_cycles_per_s"], "ms_per_launch": expand["snapshot_pipeline_ms"], "batches_per_launch": expand["fused_batches"],
+                                   "bytes_per_cycle": b_cycle_snapshot, "GBps": b_cycle_snapshot * expand["snapshot_pipeline_cycles_per_s"] / 1e9,
+                                   "frac_of_8TBps": b_cycle_snapshot * expand["snapshot_pipeline_cycles_per_s"] / 8e12} if expand and "snapshot_pipeline_ms" in expand else None),
             "checked": {"batches": len(flow.batches) * world, "cycles_executed": tot_cycles, "instances_failed": tot_failed},
+            "stats_per_step": {"cycles": cycles_per_step, "mem_queries": int(st["mem_queries"]), "log_queries": int(st["log_queries"]), "aux_events": int(st["aux_events"]), "reg_deltas": int(st["reg_deltas"])},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "frac_alone": b_cycle * cycles_per_step * len(flow.groups[0]) / (k_ms_alone * 1e-3) / 1e9 / 8000.0, "bytes_per_cycle": b_cycle,
                          "algorithmic_bytes_r3": ALGORITHMIC_BYTES_R3 if headline_shape else None, "bytes_per_cycle_this_run": b_run,
@@ -574,13 +594,34 @@ def measure(dev, prod, isa, args, rank, world, comm, collective, transport, with
 # ---------------------------------------------------------------------------------------------------------------------
 # the host side of a caller (SURVEY §8d ii): what reaches a HOST tracer, and what fresh inputs cost — both pipelined, N = 1
 # ---------------------------------------------------------------------------------------------------------------------
+def _cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None: threads beyond it only get the
+    group throttled — 128 busy threads under a 16-CPU quota run 12 ms and are then stopped for the rest of the 100 ms period"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def _host_threads():
     n = os.cpu_count() or 1
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
-    return max(1, int(os.environ.get("ZKW_BENCH_HOST_THREADS", min(128, max(1, n // 2)))))
+    q = _cpu_quota()
+    if q is not None:
+        n = max(1, min(n, int(q)))  # a sustained consumer cannot use more than the quota
+    else:
+        n = min(128, max(1, n // 2))
+    return max(1, int(os.environ.get("ZKW_BENCH_HOST_THREADS", n)))
 
 
 def delivered_leg(dev, prod, flow, st, steps_min=200, dfuse=None, n_slots=3):
@@ -648,7 +689,7 @@ def delivered_leg(dev, prod, flow, st, steps_min=200, dfuse=None, n_slots=3):
     pack_ms = sum(i["pack_ms"] for i in infos)
     steps = n_sub * dfuse
     return {"cycles_per_s": cycles_seen[0] / wall, "pcie_GBps": total_bytes / max(pack_ms, 1e-9) / 1e6, "pcie_GBps_over_the_region": total_bytes / wall / 1e9,
-            "host_threads": threads, "bytes_per_cycle": total_bytes / max(1, cycles_seen[0]), "steps": steps, "batches_per_delivery": dfuse, "ring_slots": n_slots,
+            "host_threads": threads, "cgroup_cpu_quota": _cpu_quota(), "bytes_per_cycle": total_bytes / max(1, cycles_seen[0]), "steps": steps, "batches_per_delivery": dfuse, "ring_slots": n_slots,
             "slot_MB": slot_bytes / 1e6, "ms_per_step": 1e3 * wall / steps, "pack_kernel_ms_per_step": pack_ms / steps,
             "host_replay_cycles_per_s": cycles_seen[0] / max(replay_s[0], 1e-9), "cycles_delivered": cycles_seen[0], "per_ticket_wait_replay_pack_ms_first_and_last": per_ticket[:4] + per_ticket[-4:],
             "steady_state_cycles_per_s": dfuse * int(st["cycles"]) / (1e-3 * sorted(w + r for w, r, _ in per_ticket)[len(per_ticket) // 2]),
@@ -818,11 +859,22 @@ def other_configs(dev, prod, isa, base_args, comm, transport, with_cpu):
             from era_zk_evm_amd import capi as K
             oc_comm = K.Comm.external(prod, 0, 1)  # a communicator of its own: the shard size differs from the headline's
             line = measure(dev, prod, isa, a, 0, 1, oc_comm, False, transport, False, repeats=0)
+            rl = line["roofline"]
+            bpu = rl.get("bytes_per_cycle", rl.get("bytes_per_message_byte"))
+            # the fraction on the STEP (units per second of the whole step x bytes per unit / 8 TB/s) next to the cycle kernel's own:
+            # where another kernel carries the step (configs[4]: the queue-commitment chains) the kernel's fraction says nothing
+            step_GBps = bpu * line["value"] / 1e9
+            share = line["kernel_ms"] * line["config"]["cycle_kernel_launches"] / max(1e-9, line["ms_per_step"] * a.steps)
             entry = {"workload": oc["label"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "steps": a.steps, "kernel_ms": line["kernel_ms"],
                      "batches_per_fused_launch": line["config"]["batches_per_fused_launch"], "commit_mask": a.commit_mask,
-                     "roofline": {"bound": "hbm", "frac": line["roofline"]["frac"], "achieved": line["roofline"]["achieved"], "unit": "GB/s",
-                                  "bytes_per_unit": line["roofline"].get("bytes_per_cycle", line["roofline"].get("bytes_per_message_byte"))},
+                     "roofline": {"bound": "hbm", "frac": step_GBps / 8000.0, "achieved": step_GBps, "unit": "GB/s", "bytes_per_unit": bpu,
+                                  "cycle_kernel_frac": rl["frac"], "cycle_kernel_achieved": rl["achieved"], "cycle_kernel_share_of_the_step": share,
+                                  "dominant_kernel": "zkw_cycle_kernel" if share >= 0.5 or not (a.commit_mask & 3) else "zkw_chain_kernel (memory / log queue commitments: one sponge permutation per memory query, three per log query)"},
                      "checked": line["checked"]}
+            if share < 0.5 and (a.commit_mask & 3):  # the chains' own bound: the chip's permutation rate (profiles/tools/perm_probe.hip: 3.56 G/s)
+                perms = float(line["stats_per_step"]["mem_queries"]) + 3.0 * float(line["stats_per_step"]["log_queries"])
+                rate = perms / (line["ms_per_step"] * 1e-3)
+                entry["roofline"]["dominant_bound"] = {"bound": "integer ALU (Goldilocks sponge permutations)", "permutations_per_s": rate, "peak_permutations_per_s": 3.56e9, "frac": rate / 3.56e9}
             if a.cfg == 3:
                 entry["roofline"]["lone_batch_kernel_ms"] = line["roofline"]["lone_batch_kernel_ms"]
                 entry["roofline"]["keccak_f_per_s"] = line["roofline"]["keccak_f_per_s"]
@@ -1027,7 +1079,7 @@ def cpu_baseline(isa, args, prod=None):
     # `value` is the best the host did in this leg: the two-socket run varies from run to run (110-450 M cycles/s on these
     # boxes) and is often SLOWER than one socket; the CPU should not be understated by that
     top = max((res["whole_box"], res["one_socket"]), key=lambda r: r["value"])
-    out = {"value": top["value"], "unit": "cycles/s", "cores": top["threads"], "kind": "port",
+    out = {"value": top["value"], "unit": "cycles/s", "cores": top["threads"], "kind": "port", "cgroup_cpu_quota": _cpu_quota(),
            "whole_box_value": res["whole_box"]["value"], "whole_box_threads": res["whole_box"]["threads"],
            "single_core_value": res["one_core"]["value"], "single_socket_value": res["one_socket"]["value"], "single_socket_threads": res["one_socket"]["threads"],
            "cpu_model": model, "nproc": os.cpu_count(), "packages": len(packages), "logical_cpus_used": phys,

@@ -382,17 +382,18 @@ CYCLE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c
 
 
 def trace_checksum(t):
-    """the fold of zkw_delivery_replay's built-in consumer over one per-instance trace (include/zkw.h): sum over the records of
-    sum_j u64[j] * (2 j + 1), over the memory / log / aux records with weights 2 j + 3 / 5 / 7, mod 2^64"""
+    """the fold of zkw_delivery_replay's built-in consumer over one per-instance trace (include/zkw.h): the sum, mod 2^64, over the
+    records / memory / log / aux records of sum_j (u64[j] ^ K * (j + 1 + w0)), K = 0x9E3779B97F4A7C15, w0 = 1 / 3 / 5 / 7"""
     acc = 0
+    kk = 0x9E3779B97F4A7C15
     for key, words, w0 in (("records", 64, 1), ("mem", 6, 3), ("log", 16, 5), ("aux", 32, 7)):
         a = t[key]
         if len(a) == 0:
             continue
         u = np.frombuffer(a.tobytes(), dtype="<u8").reshape(len(a), words)
-        wts = (2 * np.arange(words, dtype=np.uint64) + np.uint64(w0))
+        ks = np.array([(kk * (j + 1 + w0)) & 0xFFFFFFFFFFFFFFFF for j in range(words)], dtype=np.uint64)
         with np.errstate(over="ignore"):
-            acc += int((u * wts).sum(dtype=np.uint64))
+            acc += int((u ^ ks).sum(dtype=np.uint64))
     return acc & 0xFFFFFFFFFFFFFFFF
 
 

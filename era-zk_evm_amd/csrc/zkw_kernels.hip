@@ -2153,17 +2153,54 @@ ZD u32 zkw_uniform(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); 
 
 
 // The precompile bodies (Keccak-f state of 50 VGPRs, SHA-256 schedule, secp256k1) are compiled as ONE out-of-line
-// function that takes and returns the lane state by value (the wave's Shared view is rebuilt from the uniform wave
-// coordinates instead of being passed through ~30 vector argument registers).
-static __device__ __noinline__ Lane zkw_precompile_entry(const zkw_kparams ZKW_CONST_AS* Pp, u32 dbg, u32 wib, u32 wave, Lane s, LogQ q, u32 which) {
+// function.  Everything crosses the call in the 32 vector argument registers — a: the lane state (lane_pack) + [12] which
+// precompile, [13] the query's timestamp; b: the eight dwords of the call's ABI word (PrecompileCallABI: offsets, lengths,
+// pages) — and the lane state comes back the same way; the wave's Shared view is rebuilt from the wave's LDS header as in
+// zkw_heavy_body.  (Round 4 passed the Lane and a whole LogQuery by value: 49 dwords, i.e. through scratch memory — 608 bytes
+// of frame in the caller and 336 here, on the call chain that sizes the cycle kernel's private segment.)
+#ifndef ZKW_EMU_BUILD
+typedef u32 zkw_v16 __attribute__((ext_vector_type(16)));
+#else  // g++ (tests/emu) has no ext_vector_type
+struct zkw_v16 {
+  u32 v[16];
+  u32& operator[](int i) { return v[i]; }
+  const u32& operator[](int i) const { return v[i]; }
+};
+#endif
+ZD zkw_v16 lane_pack(const Lane& s) {
+  zkw_v16 a;
+  a[0] = s.pc; a[1] = s.sp; a[2] = s.ergs; a[3] = s.timestamp; a[4] = s.prev_super_pc; a[5] = s.depth; a[6] = s.status; a[7] = s.flags;
+  a[8] = s.kflags; a[9] = s.ptr_bitmap; a[10] = s.reg_dirty; a[11] = s.counts; a[12] = 0; a[13] = 0; a[14] = 0; a[15] = 0;
+  return a;
+}
+ZD void lane_unpack(Lane& s, const zkw_v16& a) {
+  s.pc = a[0]; s.sp = a[1]; s.ergs = a[2]; s.timestamp = a[3]; s.prev_super_pc = a[4]; s.depth = a[5]; s.status = a[6]; s.flags = a[7];
+  s.kflags = a[8]; s.ptr_bitmap = a[9]; s.reg_dirty = a[10]; s.counts = a[11];
+}
+static __device__ __noinline__ zkw_v16 zkw_precompile_entry(zkw_v16 a, zkw_v16 b) {
+  const u32 wib = zkw_uniform(threadIdx.x / ZKW_WAVE);
+  const uint4 hdr = *(zkw_lds + ZKW_LDS_WAVES0 + wib * zkw_wave_lds_units() + 1);  // written by the kernel prologue
+  const zkw_kparams ZKW_CONST_AS* Pp = (const zkw_kparams ZKW_CONST_AS*)(((u64)zkw_uniform(hdr.y) << 32) | zkw_uniform(hdr.x));
   ZKW_KP P = *Pp;
   Shared sh;
-  shared_setup(sh, P, zkw_uniform(dbg), zkw_uniform(wib), zkw_uniform(wave), false);
-  which = zkw_uniform(which);
+  shared_setup(sh, P, zkw_uniform(hdr.z), wib, zkw_uniform(hdr.w), false);
+  Lane s;
+  s.lane = zkw_lane_id();
+  lane_unpack(s, a);
+  LogQ q;  // (the precompiles read the ABI word and the timestamp only)
+#pragma unroll
+  for (int i = 0; i < 8; i++) q.key.w[i] = b[i];
+  q.read_value = u256_zero(); q.written_value = u256_zero();
+#pragma unroll
+  for (int i = 0; i < 5; i++) q.address[i] = 0;
+  q.timestamp = a[13]; q.tx_number = 0; q.aux_byte = 0; q.shard_id = 0;
+  q.rw = false; q.rollback = false; q.is_service = false;
+  const u32 which = zkw_uniform(a[12]);
   if (which == 0) precompile_keccak256(P, sh, s, q);
   else if (which == 1) precompile_sha256(P, sh, s, q);
   else precompile_ecrecover(P, sh, s, q);
-  return s;
+  s.lane = zkw_lane_id();
+  return lane_pack(s);
 }
 
 #ifdef __HIP_DEVICE_COMPILE__
@@ -2245,7 +2282,16 @@ ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   // precompiles (the address is per lane): one call per kind present.
   for (u32 k = 0; k < 3; k++) {
     if (which == k) {
-      s = zkw_precompile_entry(&P, sh.debug_flags, sh.wib, sh.wave, s, q, k);
+      zkw_v16 pa = lane_pack(s), pb;
+      pa[12] = k; pa[13] = q.timestamp;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        pb[i] = q.key.w[i];
+        pb[8 + i] = 0;
+      }
+      const zkw_v16 pr = zkw_precompile_entry(pa, pb);
+      lane_unpack(s, pr);
+      s.lane = zkw_lane_id();
     }
   }
 }
@@ -2258,25 +2304,6 @@ ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
 // memory, i.e. through HBM at this kernel's footprint) or in LDS: the parameter-block pointer and the debug flags sit in
 // the wave's LDS header, one 256-bit value per lane (r15 in, the value for dst0 / r1 out) in sh.xfer.  All lanes of a
 // call hold the same instruction word, so it is made scalar again on entry.
-#ifndef ZKW_EMU_BUILD
-typedef u32 zkw_v16 __attribute__((ext_vector_type(16)));
-#else  // g++ (tests/emu) has no ext_vector_type
-struct zkw_v16 {
-  u32 v[16];
-  u32& operator[](int i) { return v[i]; }
-  const u32& operator[](int i) const { return v[i]; }
-};
-#endif
-ZD zkw_v16 lane_pack(const Lane& s) {
-  zkw_v16 a;
-  a[0] = s.pc; a[1] = s.sp; a[2] = s.ergs; a[3] = s.timestamp; a[4] = s.prev_super_pc; a[5] = s.depth; a[6] = s.status; a[7] = s.flags;
-  a[8] = s.kflags; a[9] = s.ptr_bitmap; a[10] = s.reg_dirty; a[11] = s.counts; a[12] = 0; a[13] = 0; a[14] = 0; a[15] = 0;
-  return a;
-}
-ZD void lane_unpack(Lane& s, const zkw_v16& a) {
-  s.pc = a[0]; s.sp = a[1]; s.ergs = a[2]; s.timestamp = a[3]; s.prev_super_pc = a[4]; s.depth = a[5]; s.status = a[6]; s.flags = a[7];
-  s.kflags = a[8]; s.ptr_bitmap = a[9]; s.reg_dirty = a[10]; s.counts = a[11];
-}
 // a: lane state (lane_pack) + [12] opcode word low, [13] high, [14] packed ISA attributes | src0_ptr << 30 | src1_ptr << 31
 // b: src0 (8 dwords), src1 (8 dwords)
 // result: lane state + [12] action bits (ZKW_ACT_*), [13] low dword of the second value (far call: r2)

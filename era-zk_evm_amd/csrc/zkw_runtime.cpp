@@ -1796,10 +1796,13 @@ static void delivery_run(zkw_delivery* d, std::function<void(uint32_t)> fn) {
 
 struct FoldSink {  // the built-in consumer of zkw_delivery_replay: reads every byte it is handed
   uint64_t acc = 0, cycles = 0;
+  // sum_j (u64[j] ^ K (j + 1 + w0)), K = 2^64 / phi: position-sensitive, and a plain sum over the records — the order in which
+  // threads get to the waves does not matter.  An XOR and an add per word (two vector operations per 16 bytes even with the
+  // baseline x86-64 instruction set this file is compiled for): the stand-in tracer should not cost more than the walk.
   static uint64_t fold(const void* p, uint32_t words, uint64_t w0) {
     const uint64_t* u = (const uint64_t*)p;
-    uint64_t a = 0;
-    for (uint32_t j = 0; j < words; j++) a += u[j] * (2ull * j + w0);
+    uint64_t a = 0, k = 0x9E3779B97F4A7C15ull * (w0 + 1);
+    for (uint32_t j = 0; j < words; j++, k += 0x9E3779B97F4A7C15ull) a += u[j] ^ k;
     return a;
   }
   void cycle(const CycleView& cv) {
@@ -1919,8 +1922,10 @@ int zkw_delivery_create(zkw_ctx* c, uint32_t n_slots, uint64_t slot_bytes, uint3
     if ((e = hipHostGetDevicePointer((void**)&sl.d, sl.h, 0)) != hipSuccess) return fail(e, "hipHostGetDevicePointer");
     if ((e = hipMalloc((void**)&sl.d_state, 16)) != hipSuccess) return fail(e, "hipMalloc");
     if ((e = hipMalloc((void**)&sl.d_batches, sizeof(zkw_pack_batch) * ZKW_PACK_MAX)) != hipSuccess) return fail(e, "hipMalloc");
-    for (hipEvent_t* ev : {&sl.ev_run, &sl.ev_k0, &sl.ev_k1, &sl.ev_done})
+    for (hipEvent_t* ev : {&sl.ev_run, &sl.ev_k0, &sl.ev_k1})
       if ((e = hipEventCreate(ev)) != hipSuccess) return fail(e, "hipEventCreate");
+    // (the event a host thread waits on: blocking, so that the waiter sleeps — the host's cores belong to the replay)
+    if ((e = hipEventCreateWithFlags(&sl.ev_done, hipEventBlockingSync)) != hipSuccess) return fail(e, "hipEventCreateWithFlags");
   }
   if (host_threads > 1)
     for (uint32_t t = 0; t < host_threads; t++) d->workers.emplace_back(delivery_worker, d, t);

@@ -687,10 +687,10 @@ int zkw_delivery_get_instance_trace(zkw_delivery* d, uint32_t ticket, uint32_t b
  * thread, different instances from different threads at once; the pointers are valid during the call only */
 typedef void (*zkw_cycle_fn)(void* user, uint32_t thread, uint32_t batch_index, uint32_t instance, uint32_t cycle, const zkw_cycle_record* state_after,
                              const zkw_mem_query* mem, uint32_t n_mem, const zkw_log_query* log, uint32_t n_log, const zkw_aux_event* aux, uint32_t n_aux);
-/* fn == NULL: a built-in consumer that reads every byte handed over and folds it into `checksum` (sum over all records of
- * sum_j u64[j] * (2 j + 1), over the queries with weights 2 j + 3 / 2 j + 5 / 2 j + 7 for memory / log / aux records, mod 2^64:
- * order-independent, so that a test can compare it with the same fold over zkw_delivery_get_instance_trace).  n_cycles /
- * checksum may be NULL. */
+/* fn == NULL: a built-in consumer that reads every byte handed over and folds it into `checksum`: the sum, mod 2^64, over all
+ * records and queries of sum_j (u64[j] ^ K * (j + 1 + w0)) with K = 0x9E3779B97F4A7C15 and w0 = 1 / 3 / 5 / 7 for cycle records /
+ * memory / log / aux records — order-independent, so that a test can compare it with the same fold over
+ * zkw_delivery_get_instance_trace.  n_cycles / checksum may be NULL. */
 int zkw_delivery_replay(zkw_delivery* d, uint32_t ticket, zkw_cycle_fn fn, void* user, uint64_t* n_cycles, uint64_t* checksum);
 int zkw_delivery_release(zkw_delivery* d, uint32_t ticket);
 

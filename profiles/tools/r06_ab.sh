@@ -11,7 +11,7 @@ for I in $(seq 0 $((NL-1))); do L=${LIBS[$(( (I + R) % NL ))]}
   CMDS=("--steps 20 --warmup 5")
   [ "${3:-0}" = "1" ] && CMDS+=("")
   for A in "${CMDS[@]}"; do
-    ZKW_BENCH_NOCHECK=1 python bench.py $A --no-cpu-baseline --no-other-configs --repeats 2 2>/dev/null | grep '^{' | python3 -c "
+    ZKW_BENCH_NOCHECK=1 python bench.py $A --no-cpu-baseline --no-other-configs --no-host-legs --repeats 2 2>/dev/null | grep '^{' | python3 -c "
 import json,sys
 j=json.loads(sys.stdin.read()); print('$L [$A] value G', round(j['value_median']/1e9,2), 'kernel_ms', round(j['kernel_ms'],4), 'frac', round(j['roofline']['frac'],3))" | tee -a $T/ab_libs.txt
   done
