@@ -12,7 +12,9 @@
 
 #define ZKW_WAVE 64            /* CDNA wavefront width */
 #define ZKW_WAVES_PER_GROUP 4   /* waves per workgroup of the cycle kernel: one per SIMD, sharing the LDS ISA table */
-#define ZKW_KROW_WORDS 34      /* Keccak rate block (136 B) in dwords */
+#define ZKW_KRATE_WORDS 34     /* Keccak rate block (136 B) in dwords */
+#define ZKW_EC_SLOTS 12        /* 256-bit values of the ecrecover precompile's point arithmetic kept in the lane's scratch row */
+#define ZKW_KROW_WORDS (ZKW_KRATE_WORDS + 8 * ZKW_EC_SLOTS) /* dwords of a lane's scratch row: Keccak block assembly | secp256k1 points */
 #define ZKW_REC_CHUNKS 32      /* 512-byte CycleRecord = 32 x 16 B */
 #define ZKW_REG_CHUNKS 30      /* 15 registers x 2 halves */
 

@@ -2177,7 +2177,8 @@ ZD void lane_unpack(Lane& s, const zkw_v16& a) {
   s.pc = a[0]; s.sp = a[1]; s.ergs = a[2]; s.timestamp = a[3]; s.prev_super_pc = a[4]; s.depth = a[5]; s.status = a[6]; s.flags = a[7];
   s.kflags = a[8]; s.ptr_bitmap = a[9]; s.reg_dirty = a[10]; s.counts = a[11];
 }
-static __device__ __noinline__ zkw_v16 zkw_precompile_entry(zkw_v16 a, zkw_v16 b) {
+template <int WHICH>
+ZD zkw_v16 zkw_precompile_body(zkw_v16 a, zkw_v16 b) {
   const u32 wib = zkw_uniform(threadIdx.x / ZKW_WAVE);
   const uint4 hdr = *(zkw_lds + ZKW_LDS_WAVES0 + wib * zkw_wave_lds_units() + 1);  // written by the kernel prologue
   const zkw_kparams ZKW_CONST_AS* Pp = (const zkw_kparams ZKW_CONST_AS*)(((u64)zkw_uniform(hdr.y) << 32) | zkw_uniform(hdr.x));
@@ -2195,13 +2196,16 @@ static __device__ __noinline__ zkw_v16 zkw_precompile_entry(zkw_v16 a, zkw_v16 b
   for (int i = 0; i < 5; i++) q.address[i] = 0;
   q.timestamp = a[13]; q.tx_number = 0; q.aux_byte = 0; q.shard_id = 0;
   q.rw = false; q.rollback = false; q.is_service = false;
-  const u32 which = zkw_uniform(a[12]);
-  if (which == 0) precompile_keccak256(P, sh, s, q);
-  else if (which == 1) precompile_sha256(P, sh, s, q);
+  if (WHICH == 0) precompile_keccak256(P, sh, s, q);
+  else if (WHICH == 1) precompile_sha256(P, sh, s, q);
   else precompile_ecrecover(P, sh, s, q);
   s.lane = zkw_lane_id();
   return lane_pack(s);
 }
+// (one function per precompile: each has the frame IT needs — as one function the frame was the three side by side)
+static __device__ __noinline__ zkw_v16 zkw_precompile_keccak(zkw_v16 a, zkw_v16 b) { return zkw_precompile_body<0>(a, b); }
+static __device__ __noinline__ zkw_v16 zkw_precompile_sha(zkw_v16 a, zkw_v16 b) { return zkw_precompile_body<1>(a, b); }
+static __device__ __noinline__ zkw_v16 zkw_precompile_ec(zkw_v16 a, zkw_v16 b) { return zkw_precompile_body<2>(a, b); }
 
 #ifdef __HIP_DEVICE_COMPILE__
 // `count` consecutive positions of the memory-query stream for every active lane (stream_alloc: one).  A lane whose
@@ -2289,7 +2293,7 @@ ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
         pb[i] = q.key.w[i];
         pb[8 + i] = 0;
       }
-      const zkw_v16 pr = zkw_precompile_entry(pa, pb);
+      const zkw_v16 pr = k == 0 ? zkw_precompile_keccak(pa, pb) : (k == 1 ? zkw_precompile_sha(pa, pb) : zkw_precompile_ec(pa, pb));
       lane_unpack(s, pr);
       s.lane = zkw_lane_id();
     }

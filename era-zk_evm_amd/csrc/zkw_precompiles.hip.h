@@ -305,7 +305,7 @@ ZD void precompile_keccak256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
     if (need < 4u) le |= 0x01u << (8u * need);  // the pad byte follows the last message byte inside this dword
     sh.krow[slot * sh.L + s.lane] = le;
     slot++;
-    if (slot == ZKW_KROW_WORDS && !(need < 4u)) {  // a full block of message bytes
+    if (slot == ZKW_KRATE_WORDS && !(need < 4u)) {  // a full block of message bytes
       keccak_absorb_block(sh, s.lane, st);
       slot = 0;
     }
@@ -316,8 +316,8 @@ ZD void precompile_keccak256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
     sh.krow[slot * sh.L + s.lane] = 0x01u;
     slot++;
   }
-  for (u32 p = slot; p < ZKW_KROW_WORDS; p++) sh.krow[p * sh.L + s.lane] = 0;
-  sh.krow[(ZKW_KROW_WORDS - 1) * sh.L + s.lane] |= 0x80000000u;
+  for (u32 p = slot; p < ZKW_KRATE_WORDS; p++) sh.krow[p * sh.L + s.lane] = 0;
+  sh.krow[(ZKW_KRATE_WORDS - 1) * sh.L + s.lane] |= 0x80000000u;
   keccak_absorb_block(sh, s.lane, st);
   zk_keccak_lc_flip(st);
   u256 digest;
@@ -405,7 +405,7 @@ ZD void precompile_ecrecover(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
     lane_fail(s, ZKW_STATUS_REFERENCE_PANIC);
     return;
   }
-  const ec_result res = zkw_ecrecover(w0, r, sg, vw.w[0]);
+  const ec_result res = zkw_ecrecover(sh.krow + ZKW_KRATE_WORDS * sh.L + s.lane, sh.L, w0, r, sg, vw.w[0]);
   const u256 marker = u256_from_u32(res.ok);
   heap_write_cur(P, sh, s, false, out_off, marker);
   emit_mem(P, sh, s, q.timestamp + 1, ZKW_MEM_HEAP, page_w, out_off, marker, false, true, 2);

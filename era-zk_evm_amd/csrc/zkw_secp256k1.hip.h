@@ -28,7 +28,7 @@ ZD bool ec_ge(const u256& a, const u256& b) {  // a >= b
 }
 
 // a * b mod m; which = 0: m = p (field), 1: m = n (group order).  (hi : lo) is folded with 2^256 = c (mod m).
-ZNI u256 ec_mulmod(u256 a, u256 b, u32 which) {
+ZD u256 ec_mulmod_inl(const u256& a, const u256& b, u32 which) {
   u256 lo, hi;
   u256_mul(a, b, lo, hi);
 #pragma unroll 1
@@ -79,6 +79,7 @@ ZNI u256 ec_mulmod(u256 a, u256 b, u32 which) {
   }
   return lo;
 }
+ZNI u256 ec_mulmod(u256 a, u256 b, u32 which) { return ec_mulmod_inl(a, b, which); }
 ZD u256 ec_addmod(const u256& a, const u256& b, const u256& m) {  // a, b < m
   bool of, of2;
   u256 r = u256_add(a, b, of);
@@ -108,50 +109,101 @@ ZNI u256 ec_powmod(u256 a, u256 e, u32 which) {
   return r;
 }
 
-struct ec_jac {
-  u256 x, y, z;  // z == 0: infinity
-};
+// Points live in the lane's scratch row in global memory (Shared::krow behind the Keccak block: ZKW_EC_SLOTS 256-bit slots,
+// dword k of slot i at row[(8 i + k) * L]), not in by-value structs: as `ec_jac` arguments and locals (96 bytes each) they put
+// 1184 bytes of frame on the call chain that sizes the cycle kernel's private segment — every launch reserved scratch memory for a
+// precompile that a cfg-2 tape never calls.  Performance of this path does not matter (about 6500 modular multiplications).
+//   slots 0..2 acc (x, y, z; z == 0: infinity), 3..4 R (affine), 5..7 G + R (Jacobian), 8..9 u1, u2
+#define EC_ACC 0u
+#define EC_R 3u
+#define EC_GR 5u
+#define EC_U1 8u
+#define EC_U2 9u
+ZD u256 ecr_load(const u32* row, u32 L, u32 slot) {
+  u256 v;
+#pragma unroll
+  for (u32 k = 0; k < 8; k++) v.w[k] = row[(u64)(8u * slot + k) * L];
+  return v;
+}
+ZD void ecr_store(u32* row, u32 L, u32 slot, const u256& v) {
+#pragma unroll
+  for (u32 k = 0; k < 8; k++) row[(u64)(8u * slot + k) * L] = v.w[k];
+}
+ZD u256 ec_gx() {
+  u256 g;
+  g.w[0] = 0x16F81798u; g.w[1] = 0x59F2815Bu; g.w[2] = 0x2DCE28D9u; g.w[3] = 0x029BFCDBu; g.w[4] = 0xCE870B07u; g.w[5] = 0x55A06295u; g.w[6] = 0xF9DCBBACu; g.w[7] = 0x79BE667Eu;
+  return g;
+}
+ZD u256 ec_gy() {
+  u256 g;
+  g.w[0] = 0xFB10D4B8u; g.w[1] = 0x9C47D08Fu; g.w[2] = 0xA6855419u; g.w[3] = 0xFD17B448u; g.w[4] = 0x0E1108A8u; g.w[5] = 0x5DA4FBFCu; g.w[6] = 0x26A3C465u; g.w[7] = 0x483ADA77u;
+  return g;
+}
 #define EC_M(a, b) ec_mulmod(a, b, 0)
-ZNI ec_jac ec_double(ec_jac p) {  // dbl-2009-l (a = 0)
+#define EC_MI(a, b) ec_mulmod_inl(a, b, 0) /* inside the point operations: inlined — no call, so nothing has to survive one on the stack */
+// point at slots [dst, dst + 3) := 2 * point at [src, src + 3)          dbl-2009-l (a = 0)
+ZNI void ec_double_row(u32* row, u32 L, u32 dst, u32 src) {
   const u256 P = ec_p();
-  ec_jac r;
-  if (u256_is_zero(p.z) || u256_is_zero(p.y)) {
-    r.x = u256_from_u32(1); r.y = u256_from_u32(1); r.z = u256_zero();
-    return r;
+  const u256 py = ecr_load(row, L, src + 1), pz = ecr_load(row, L, src + 2);
+  if (u256_is_zero(pz) || u256_is_zero(py)) {
+    ecr_store(row, L, dst, u256_from_u32(1)); ecr_store(row, L, dst + 1, u256_from_u32(1)); ecr_store(row, L, dst + 2, u256_zero());
+    return;
   }
-  const u256 A = EC_M(p.x, p.x), B = EC_M(p.y, p.y), C = EC_M(B, B);
-  const u256 t = ec_addmod(p.x, B, P);
-  u256 D = ec_submod(ec_submod(EC_M(t, t), A, P), C, P);
+  const u256 yz = EC_MI(py, pz);
+  ecr_store(row, L, dst + 2, ec_addmod(yz, yz, P));  // (z first: x and y of the source are still in place when dst == src)
+  const u256 px = ecr_load(row, L, src);
+  const u256 A = EC_MI(px, px), B = EC_MI(py, py), C = EC_MI(B, B);
+  const u256 t = ec_addmod(px, B, P);
+  u256 D = ec_submod(ec_submod(EC_MI(t, t), A, P), C, P);
   D = ec_addmod(D, D, P);
-  const u256 E = ec_addmod(ec_addmod(A, A, P), A, P), F = EC_M(E, E);
-  r.x = ec_submod(F, ec_addmod(D, D, P), P);
+  const u256 E = ec_addmod(ec_addmod(A, A, P), A, P), F = EC_MI(E, E);
+  const u256 rx = ec_submod(F, ec_addmod(D, D, P), P);
   u256 C8 = ec_addmod(C, C, P);
   C8 = ec_addmod(C8, C8, P);
   C8 = ec_addmod(C8, C8, P);
-  r.y = ec_submod(EC_M(E, ec_submod(D, r.x, P)), C8, P);
-  const u256 yz = EC_M(p.y, p.z);
-  r.z = ec_addmod(yz, yz, P);
-  return r;
+  ecr_store(row, L, dst, rx);
+  ecr_store(row, L, dst + 1, ec_submod(EC_MI(E, ec_submod(D, rx, P)), C8, P));
 }
-ZNI ec_jac ec_add(ec_jac p, ec_jac q) {  // general Jacobian addition with the equal / opposite cases
+// the second operand of an addition: 0 = G (affine), 1 = R (affine, slots EC_R), 2 = G + R (Jacobian, slots EC_GR)
+ZD u256 ec_q_coord(const u32* row, u32 L, u32 which, u32 c) {
+  if (which == 0u) return c == 0u ? ec_gx() : (c == 1u ? ec_gy() : u256_from_u32(1));
+  if (which == 1u) return c == 2u ? u256_from_u32(1) : ecr_load(row, L, EC_R + c);
+  return ecr_load(row, L, EC_GR + c);
+}
+// point at [dst, dst + 3) := point at [p, p + 3) + operand `which`: general Jacobian addition with the equal / opposite cases.
+// (One intermediate, S1, waits in slot 10.  Staging every intermediate through the row, or inlining both point operations into the
+// caller, made the frames LARGER: what a function of this size keeps on the stack is mostly the callee-saved registers it touches.)
+// returns true when the operands are the same point: the caller doubles instead (no call from here: the two frames do not stack)
+ZNI bool ec_add_row(u32* row, u32 L, u32 dst, u32 p, u32 which) {
   const u256 P = ec_p();
-  if (u256_is_zero(p.z)) return q;
-  if (u256_is_zero(q.z)) return p;
-  const u256 Z1Z1 = EC_M(p.z, p.z), Z2Z2 = EC_M(q.z, q.z);
-  const u256 U1 = EC_M(p.x, Z2Z2), U2 = EC_M(q.x, Z1Z1);
-  const u256 S1 = EC_M(EC_M(p.y, q.z), Z2Z2), S2 = EC_M(EC_M(q.y, p.z), Z1Z1);
-  ec_jac r;
-  if (u256_eq(U1, U2)) {
-    if (u256_eq(S1, S2)) return ec_double(p);
-    r.x = u256_from_u32(1); r.y = u256_from_u32(1); r.z = u256_zero();
-    return r;
+  const u256 pz = ecr_load(row, L, p + 2), qz = ec_q_coord(row, L, which, 2);
+  if (u256_is_zero(pz)) {
+    ecr_store(row, L, dst, ec_q_coord(row, L, which, 0)); ecr_store(row, L, dst + 1, ec_q_coord(row, L, which, 1)); ecr_store(row, L, dst + 2, qz);
+    return false;
   }
-  const u256 H = ec_submod(U2, U1, P), R = ec_submod(S2, S1, P);
-  const u256 HH = EC_M(H, H), HHH = EC_M(H, HH), V = EC_M(U1, HH);
-  r.x = ec_submod(ec_submod(EC_M(R, R), HHH, P), ec_addmod(V, V, P), P);
-  r.y = ec_submod(EC_M(R, ec_submod(V, r.x, P)), EC_M(S1, HHH), P);
-  r.z = EC_M(EC_M(p.z, q.z), H);
-  return r;
+  if (u256_is_zero(qz)) {
+    if (dst != p) {
+      ecr_store(row, L, dst, ecr_load(row, L, p)); ecr_store(row, L, dst + 1, ecr_load(row, L, p + 1)); ecr_store(row, L, dst + 2, pz);
+    }
+    return false;
+  }
+  const u256 Z1Z1 = EC_MI(pz, pz), Z2Z2 = EC_MI(qz, qz);
+  const u256 U1 = EC_MI(ecr_load(row, L, p), Z2Z2), U2 = EC_MI(ec_q_coord(row, L, which, 0), Z1Z1);
+  const u256 S1 = EC_MI(EC_MI(ecr_load(row, L, p + 1), qz), Z2Z2);
+  ecr_store(row, L, 10u, S1);
+  const u256 S2 = EC_MI(EC_MI(ec_q_coord(row, L, which, 1), pz), Z1Z1);
+  if (u256_eq(U1, U2)) {
+    if (u256_eq(S1, S2)) return true;
+    ecr_store(row, L, dst, u256_from_u32(1)); ecr_store(row, L, dst + 1, u256_from_u32(1)); ecr_store(row, L, dst + 2, u256_zero());
+    return false;
+  }
+  const u256 H = ec_submod(U2, U1, P), R = ec_submod(S2, ecr_load(row, L, 10u), P);
+  ecr_store(row, L, dst + 2, EC_MI(EC_MI(pz, qz), H));  // (x, y of p have been consumed: dst may be p)
+  const u256 HH = EC_MI(H, H), HHH = EC_MI(H, HH), V = EC_MI(U1, HH);
+  const u256 rx = ec_submod(ec_submod(EC_MI(R, R), HHH, P), ec_addmod(V, V, P), P);
+  ecr_store(row, L, dst, rx);
+  ecr_store(row, L, dst + 1, ec_submod(EC_MI(R, ec_submod(V, rx, P)), EC_MI(ecr_load(row, L, 10u), HHH), P));
+  return false;
 }
 
 struct ec_result {
@@ -159,8 +211,9 @@ struct ec_result {
   u32 ok;
 };
 
-// v_odd: parity of R.y.  Failure (ok = 0) for everything the k256 path reports as Err.
-ZNI ec_result zkw_ecrecover(u256 digest, u256 r, u256 s, u32 v_odd) {
+// v_odd: parity of R.y.  Failure (ok = 0) for everything the k256 path reports as Err.  `row`: the lane's scratch row
+// (ZKW_EC_SLOTS slots, stride L dwords).
+ZD ec_result zkw_ecrecover(u32* row, u32 L, const u256& digest, const u256& r, const u256& s, u32 v_odd) {
   ec_result out;
   out.address_word = u256_zero();
   out.ok = 0;
@@ -175,37 +228,34 @@ ZNI ec_result zkw_ecrecover(u256 digest, u256 r, u256 s, u32 v_odd) {
     bool of;
     y = u256_sub(P, y, of);
   }
-  bool of;
-  u256 z = digest;
-  if (ec_ge(z, N)) z = u256_sub(z, N, of);  // digest < 2^256 < 2n: one subtraction reduces it
-  u256 nm2 = u256_sub(N, u256_from_u32(2), of);
-  const u256 rinv = ec_powmod(r, nm2, 1);
-  const u256 u1 = ec_mulmod(ec_submod(u256_zero(), z, N), rinv, 1);
-  const u256 u2 = ec_mulmod(s, rinv, 1);
-  ec_jac G, Rp;
-  G.x.w[0] = 0x16F81798u; G.x.w[1] = 0x59F2815Bu; G.x.w[2] = 0x2DCE28D9u; G.x.w[3] = 0x029BFCDBu; G.x.w[4] = 0xCE870B07u; G.x.w[5] = 0x55A06295u;
-  G.x.w[6] = 0xF9DCBBACu; G.x.w[7] = 0x79BE667Eu;
-  G.y.w[0] = 0xFB10D4B8u; G.y.w[1] = 0x9C47D08Fu; G.y.w[2] = 0xA6855419u; G.y.w[3] = 0xFD17B448u; G.y.w[4] = 0x0E1108A8u; G.y.w[5] = 0x5DA4FBFCu;
-  G.y.w[6] = 0x26A3C465u; G.y.w[7] = 0x483ADA77u;
-  G.z = u256_from_u32(1);
-  Rp.x = r; Rp.y = y; Rp.z = u256_from_u32(1);
-  const ec_jac GR = ec_add(G, Rp);
-  ec_jac acc;
-  acc.x = u256_from_u32(1); acc.y = u256_from_u32(1); acc.z = u256_zero();
+  ecr_store(row, L, EC_R, r);
+  ecr_store(row, L, EC_R + 1, y);
+  {
+    bool of;
+    u256 z = digest;
+    if (ec_ge(z, N)) z = u256_sub(z, N, of);  // digest < 2^256 < 2n: one subtraction reduces it
+    const u256 nm2 = u256_sub(N, u256_from_u32(2), of);
+    const u256 rinv = ec_powmod(r, nm2, 1);
+    ecr_store(row, L, EC_U1, ec_mulmod(ec_submod(u256_zero(), z, N), rinv, 1));
+    ecr_store(row, L, EC_U2, ec_mulmod(s, rinv, 1));
+  }
+  // G + R once, then Shamir's double-and-add over (u1, u2)
+  ecr_store(row, L, EC_GR, ec_gx()); ecr_store(row, L, EC_GR + 1, ec_gy()); ecr_store(row, L, EC_GR + 2, u256_from_u32(1));
+  if (ec_add_row(row, L, EC_GR, EC_GR, 1u)) ec_double_row(row, L, EC_GR, EC_GR);  // (R == G)
+  ecr_store(row, L, EC_ACC, u256_from_u32(1)); ecr_store(row, L, EC_ACC + 1, u256_from_u32(1)); ecr_store(row, L, EC_ACC + 2, u256_zero());
 #pragma unroll 1
   for (int i = 255; i >= 0; i--) {
-    acc = ec_double(acc);
-    const u32 b1 = ec_bit(u1, i), b2 = ec_bit(u2, i);
-    if (b1 | b2) {
-      ec_jac t = G;
-      if (b2) t = b1 ? GR : Rp;
-      acc = ec_add(acc, t);
-    }
+    ec_double_row(row, L, EC_ACC, EC_ACC);
+    const u32 b1 = (row[(u64)(8u * EC_U1 + (u32)(i >> 5)) * L] >> (i & 31)) & 1u, b2 = (row[(u64)(8u * EC_U2 + (u32)(i >> 5)) * L] >> (i & 31)) & 1u;
+    if (b1 | b2)
+      if (ec_add_row(row, L, EC_ACC, EC_ACC, b2 ? (b1 ? 2u : 1u) : 0u)) ec_double_row(row, L, EC_ACC, EC_ACC);
   }
-  if (u256_is_zero(acc.z)) return out;
-  u256 pm2 = u256_sub(P, u256_from_u32(2), of);
-  const u256 zi = ec_powmod(acc.z, pm2, 0), zi2 = EC_M(zi, zi);
-  const u256 ax = EC_M(acc.x, zi2), ay = EC_M(acc.y, EC_M(zi2, zi));
+  const u256 az = ecr_load(row, L, EC_ACC + 2);
+  if (u256_is_zero(az)) return out;
+  bool of;
+  const u256 pm2 = u256_sub(P, u256_from_u32(2), of);
+  const u256 zi = ec_powmod(az, pm2, 0), zi2 = EC_M(zi, zi);
+  const u256 ax = EC_M(ecr_load(row, L, EC_ACC), zi2), ay = EC_M(ecr_load(row, L, EC_ACC + 1), EC_M(zi2, zi));
   // keccak256(x_be || y_be): one 136-byte block
   u64 st[25];
 #pragma unroll
