@@ -339,11 +339,18 @@ ZD u32 stream_alloc(u32* cursors) {
 
 // streaming store of a 16-byte unit of a witness stream: written once, read by a later kernel / the host
 #ifdef __HIP_DEVICE_COMPILE__
+#ifndef ZKW_GLOBAL_AS
+#define ZKW_GLOBAL_AS __attribute__((address_space(1)))
+#endif
 typedef unsigned int zkw_v4u __attribute__((ext_vector_type(4)));
 ZD void zkw_stream_store(uint4* p, const uint4 v) {
   zkw_v4u t;
   t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+#ifdef ZKW_NO_NT /* (A/B partner: plain stores measured 4 % / 10 % slower on the driver's / the default command, profiles/r08_ab_log.txt) */
+  *(ZKW_GLOBAL_AS zkw_v4u*)p = t;
+#else
   __builtin_nontemporal_store(t, (zkw_v4u*)p);
+#endif
 }
 #else
 ZD void zkw_stream_store(uint4* p, const uint4 v) { *p = v; }
@@ -354,7 +361,6 @@ ZD void zkw_stream_store(uint4* p, const uint4 v) { *p = v; }
 // global memory and emits FLAT instructions — which count on BOTH vmcnt and lgkmcnt, so every LDS wait behind one of
 // them (the cold lane state lives in LDS) also waits for it to leave the vector-memory queue.
 #ifdef __HIP_DEVICE_COMPILE__
-#define ZKW_GLOBAL_AS __attribute__((address_space(1)))
 ZD uint4 zkw_gload4(const uint4* p) {
   const zkw_v4u v = *(const ZKW_GLOBAL_AS zkw_v4u*)p;
   return make_uint4(v.x, v.y, v.z, v.w);
@@ -3120,6 +3126,99 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
     ZKW_PROF_DECL
     for (;;) {
       s.lane = zkw_lane_id();
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZKW_NO_FAST_ALU) /* (-DZKW_NO_FAST_ALU: the A/B partner) */
+      // ------------------------------------------------------------------------------------------------------------
+      // The short cycle.  A wave on a shared tape whose lanes all stand at the same pc, inside the code word they fetched last,
+      // in kernel mode, with nothing pending, executes an ALU instruction with register / immediate operands (nop, add, sub,
+      // and / or / xor, jump) here: one slot read, scalar decode, the operation, the record — no group loop, no operand
+      // addressing, no opcode switch, no out-of-line call site on the path.  Every test below is wave-uniform; a cycle that
+      // does not qualify (a fetch, a memory operand, an exception, a heavier opcode, diverged lanes) takes the general path
+      // underneath, untouched: nothing is written before the cycle is known to qualify.  Same witness, bit for bit
+      // (cycle.rs:19-236 read_and_decode, :275-350 operands, add.rs / sub.rs / binop.rs / jump.rs / noop.rs, :408-413).
+      // ------------------------------------------------------------------------------------------------------------
+      if (ZKW_LIKELY(k + 1u < run_cycles && !(A.debug_flags & (4u | (1u << 24))))) {  // (the last cycle of a launch leaves through the general path; test hooks: general path)
+        const u32 pc0 = (u32)__builtin_amdgcn_readfirstlane((int)s.pc);
+        const bool odd = (s.pc != pc0) | ((s.flags & FLAG_PENDING) != 0) | ((s.kflags & (KF_CODE_PAGE_CHANGED | KF_TAIL2 | KF_STATIC | KF_KERNEL)) != KF_KERNEL) |
+                         (s.prev_super_pc != (pc0 >> 2)) | (s.depth == max_depth);
+        if (zkw_ballot(odd) == 0) {
+          const uint4 me = ZKW_SLOT_READ(sh, s.lane, 3u - (pc0 & 3u));
+          const u32 u_lo = (u32)__builtin_amdgcn_readfirstlane((int)me.x), u_hi = (u32)__builtin_amdgcn_readfirstlane((int)me.y);
+          const u32 u_attr = (u32)__builtin_amdgcn_readfirstlane((int)me.z), u_price = (u32)__builtin_amdgcn_readfirstlane((int)me.w);
+          const u32 opcode = ZKW_ATTR_OPCODE(u_attr), props = ZKW_ATTR_PROPS(u_attr), src0_mode = ZKW_ATTR_SRC0(u_attr);
+          const bool light = ((1u << opcode) & ((1u << ZKW_OP_NOP) | (1u << ZKW_OP_ADD) | (1u << ZKW_OP_SUB) | (1u << ZKW_OP_JUMP) | (1u << ZKW_OP_BINOP))) != 0 &&
+                             ZKW_ATTR_DST0(u_attr) == ZKW_MODE_REG && (src0_mode == ZKW_MODE_REG || src0_mode == ZKW_MODE_IMM) && !(props & ZKW_PROP_EXPLICIT_PANIC) &&
+                             delta_cur + ZKW_WAVE <= cap_delta;
+          // (the ISA entry follows from the opcode word: one table per batch, one batch per wave)
+          if (light && zkw_ballot((me.x != u_lo) | (me.y != u_hi) | (s.ergs < u_price)) == 0) {
+            // ---- the cycle qualifies: from here on it is executed here ----
+            {  // directory: the stream cursors at the start of the wave-cycle
+              const uint4 dir_entry = make_uint4(zkw_cursor_get<0>(), zkw_cursor_get<1>(), zkw_cursor_get<2>(), delta_cur);
+              if (zkw_rank_below(zkw_ballot(1)) == 0) *(uint4*)dir_ptr = dir_entry;
+            }
+            s.kflags = (s.kflags & ~(KF_COLD_DIRTY | KF_DQ_CHAINED | KF_MASKED)) | KF_CHARGED;
+            s.ergs -= u_price;                                                                  // :153-161
+            const bool run = condition_resolved(cond_lut, (u_lo >> 13) & 7u, s.flags);          // :193-217: a lane whose condition fails runs a nop
+            const u32 r_src0 = (u_lo >> 16) & 15u, r_src1 = (u_lo >> 20) & 15u, r_dst0 = (u_lo >> 24) & 15u;
+            u32 new_pc = (s.pc + 1u) & 0xffffu;
+            u32 dm = 0;
+            u256 res = u256_zero();
+            if (opcode != ZKW_OP_NOP) {
+              u256 a = src0_mode == ZKW_MODE_REG ? rf_get(rf, r_src0) : u256_from_u32(u_hi & 0xffffu);
+              u256 b = rf_get(rf, r_src1);
+              if (props & ZKW_PROP_SWAP) {  // :341-345 (wave-uniform)
+                const u256 t = a;
+                a = b;
+                b = t;
+              }
+              if (opcode == ZKW_OP_JUMP) {
+                if (run) new_pc = clip16(sh, a);  // jump.rs:23-25
+              } else {
+                bool of = false;
+                if (opcode == ZKW_OP_ADD) res = u256_add(a, b, of);
+                else if (opcode == ZKW_OP_SUB) res = u256_sub(a, b, of);
+                else {
+                  const u32 v = ZKW_ATTR_VARIANT(u_attr);
+                  res = v == ZKW_BINOP_XOR ? u256_xor(a, b) : (v == ZKW_BINOP_AND ? u256_and(a, b) : u256_or(a, b));
+                }
+                if (run) {
+                  if (ZKW_ATTR_FLAGS(u_attr) & 1u) {
+                    const bool eq = u256_is_zero(res);
+                    if (opcode == ZKW_OP_BINOP) set_flags3(s, false, eq, false);  // binop.rs:49-50
+                    else set_flags3(s, of, eq, !eq && !of);                       // add.rs:39-43, sub.rs:39-44
+                  }
+                  if (r_dst0 != 0) {
+                    rf_set(rf, r_dst0, res);
+                    dm = 1u << (r_dst0 - 1u);
+                    s.ptr_bitmap &= ~dm;
+                  }
+                }
+              }
+            }
+            s.pc = new_pc;
+            s.reg_dirty = dm;
+            s.counts = 0;
+            asm("v_add_u32 %0, %1, %0" : "+v"(s.timestamp) : "s"(time_delta));  // :408-411
+            // CycleRecord: the one register this cycle wrote (lanes in lane order), then the tails
+            const u64 part = zkw_ballot(dm != 0);
+            const u32 total = (u32)__popcll(part);
+            if (dm) {
+              const u32 at = delta_cur + zkw_rank_below(part);
+              zkw_stream_store(delta_base + (u64)at, u256_lo4(res));
+              zkw_stream_store(delta_base + (u64)cap_delta + at, u256_hi4(res));
+            }
+            zkw_stream_store(tails_wave + (u64)k * tail_step + s.lane,
+                             make_uint4((s.ptr_bitmap & 0xffffu) | ((s.flags & 0xfu) << 16) | ((dm & 0xffu) << 24), (s.pc & 0xffffu) | (s.sp << 16), s.ergs, (dm >> 8) << 24));
+            if (total) {
+              delta_cur += total;
+              zkw_cursor_set<3>(delta_cur);
+            }
+            k++;
+            dir_ptr += 4;
+            continue;
+          }
+        }
+      }
+#endif
       ZKW_PROF_RESET
       // directory: stream cursors at the start of wave-cycle (cycle_base + k).  Read here (one broadcast 16-B LDS read),
       // stored by the first remaining lane after the fetch below, so that the LDS latency hides behind it.  The
