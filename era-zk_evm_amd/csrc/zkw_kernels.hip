@@ -3126,6 +3126,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
     ZKW_PROF_DECL
     for (;;) {
       s.lane = zkw_lane_id();
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ZKW_SLEEP_PROBE) /* (experiment: N x 64 idle clocks per cycle — does the launch get longer by as much?) */
+      __builtin_amdgcn_s_sleep(ZKW_SLEEP_PROBE);
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(ZKW_NO_FAST_ALU) /* (-DZKW_NO_FAST_ALU: the A/B partner) */
       // ------------------------------------------------------------------------------------------------------------
       // The short cycle.  A wave on a shared tape whose lanes all stand at the same pc, inside the code word they fetched last,
