@@ -303,6 +303,19 @@ pub struct zkw_net_state {
 pub enum zkw_ctx {}
 pub enum zkw_batch {}
 pub enum zkw_comm {}
+pub enum zkw_delivery {}
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct zkw_delivered {
+    pub bytes: u64,
+    pub pack_ms: f64,
+    pub n_batches: u32,
+    pub n_waves: u32,
+    pub overflow: u32,
+    pub reserved: u32,
+}
+pub type zkw_cycle_fn = unsafe extern "C" fn(user: *mut c_void, thread: u32, batch_index: u32, instance: u32, cycle: u32, state_after: *const zkw_cycle_record, mem: *const zkw_mem_query,
+                                            n_mem: u32, log: *const zkw_log_query, n_log: u32, aux: *const zkw_aux_event, n_aux: u32);
 #[repr(C)]
 pub struct zkw_comm_id {
     pub bytes: [u8; 128],
@@ -346,11 +359,25 @@ extern "C" {
     pub fn zkw_batch_get_page(batch: *mut zkw_batch, instance: u32, page: u32, first_word: u32, n_words: u32, out: *mut zkw_u256) -> c_int;
     pub fn zkw_batch_set_bootloader_calldata(batch: *mut zkw_batch, instance: u32, words: *const zkw_u256, n_words: u32) -> c_int;
     pub fn zkw_batch_get_commitments(batch: *mut zkw_batch, out: *mut u64) -> c_int;
+    pub fn zkw_comm_probe() -> c_int;
     pub fn zkw_comm_get_unique_id(out: *mut zkw_comm_id) -> c_int;
     pub fn zkw_comm_create_rccl(ctx: *mut zkw_ctx, rank: c_int, world: c_int, id: *const zkw_comm_id, out: *mut *mut zkw_comm) -> c_int;
     pub fn zkw_comm_destroy(comm: *mut zkw_comm);
     pub fn zkw_reduce_commitments(comm: *mut zkw_comm, batches: *const *mut zkw_batch, n_batches: u32, queue_mask: u32, gathered: *mut c_void,
                                   n_max_out: *mut u32, sizes_out: *mut u32, total: *mut zkw_run_stats, stream: *mut c_void) -> c_int;
+    // delivery to the host: whole steps in a persistent pinned ring (include/zkw.h)
+    pub fn zkw_delivery_create(ctx: *mut zkw_ctx, n_slots: u32, slot_bytes: u64, host_threads: u32, out: *mut *mut zkw_delivery) -> c_int;
+    pub fn zkw_delivery_destroy(d: *mut zkw_delivery);
+    pub fn zkw_delivery_slot_bytes(batches: *const *mut zkw_batch, n_batches: u32, worst_case: *mut u64) -> c_int;
+    pub fn zkw_delivery_submit(d: *mut zkw_delivery, batches: *const *mut zkw_batch, n_batches: u32, run_stream: *mut c_void, ticket: *mut u32) -> c_int;
+    pub fn zkw_delivery_order_after(d: *mut zkw_delivery, ticket: u32, stream: *mut c_void) -> c_int;
+    pub fn zkw_delivery_wait(d: *mut zkw_delivery, ticket: u32, info: *mut zkw_delivered) -> c_int;
+    pub fn zkw_delivery_get_instance_trace(d: *mut zkw_delivery, ticket: u32, batch_index: u32, instance: u32, out: *mut zkw_instance_trace) -> c_int;
+    pub fn zkw_delivery_replay(d: *mut zkw_delivery, ticket: u32, f: Option<zkw_cycle_fn>, user: *mut c_void, n_cycles: *mut u64, checksum: *mut u64) -> c_int;
+    pub fn zkw_delivery_release(d: *mut zkw_delivery, ticket: u32) -> c_int;
+    // fresh inputs of an uploaded batch
+    pub fn zkw_batch_staging(batch: *mut zkw_batch, states: *mut *mut zkw_vm_local_state, heap_words: *mut *mut zkw_u256, n_heap_words: *mut u32) -> c_int;
+    pub fn zkw_batch_restage(batch: *mut zkw_batch, states: *const zkw_vm_local_state, heap_words: *const zkw_u256, n_heap_words: u32, stream: *mut c_void) -> c_int;
     pub fn zkw_blake2s256(ctx: *mut zkw_ctx, data: *const u8, offsets: *const u64, n_messages: u32, digests: *mut u8) -> c_int;
     pub fn zkw_blake2s256_device(ctx: *mut zkw_ctx, d_data: *const c_void, total_bytes: u64, d_offsets: *const u64, n_messages: u32,
                                  d_digests: *mut c_void, stream: *mut c_void) -> c_int;

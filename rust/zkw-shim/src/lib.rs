@@ -430,6 +430,31 @@ impl<'a> Batch<'a> {
         }
         Ok(())
     }
+    /// New VmLocalStates (and heap images) for every instance of an uploaded batch that keeps its geometry — what a caller that
+    /// pushes the next transactions through the same batch object does instead of upload: VmState::empty_state +
+    /// push_bootloader_context with other values (vm_state/mod.rs:188-207, helpers.rs:289-316), SimpleMemory::populate_heap
+    /// (reference_impls/memory.rs:287-291).  Asynchronous on the library's side (zkw_batch_restage); the traces rebuilt afterwards
+    /// replay onto these states.
+    pub fn restage(&mut self, states: &[VmLocalState<8, E>], heaps: Option<&[Vec<U256>]>) -> anyhow::Result<()> {
+        anyhow::ensure!(states.len() == self.n as usize, "restage: one state per instance");
+        let mut cs = Vec::with_capacity(states.len());
+        for (i, st) in states.iter().enumerate() {
+            let (c, inner) = state_to_c(st);
+            self.initial[i] = (c, inner);
+            cs.push(c);
+        }
+        let (hp, nh, flat): (*const zkw_u256, u32, Vec<zkw_u256>) = match heaps {
+            Some(h) => {
+                let n = h.first().map(|v| v.len()).unwrap_or(0);
+                let flat: Vec<zkw_u256> = h.iter().flat_map(|v| v.iter().map(u256_to_c)).collect();
+                (flat.as_ptr(), n as u32, flat)
+            }
+            None => (std::ptr::null(), 0, Vec::new()),
+        };
+        let rc = unsafe { zkw_batch_restage(self.raw, cs.as_ptr(), hp, nh, std::ptr::null_mut()) };
+        drop(flat);
+        self.ctx.check(rc, "zkw_batch_restage")
+    }
     /// the queue commitments of every instance after a run: [instance][memory, log, decommit][4] Goldilocks elements
     /// (the build's own sponge spec: the reference has none, far_call.rs:29-32)
     pub fn commitments(&self, queue_mask: u32) -> anyhow::Result<Vec<[[u64; 4]; 3]>> {
@@ -473,6 +498,64 @@ impl<'a> Batch<'a> {
 impl<'a> Drop for Batch<'a> {
     fn drop(&mut self) {
         unsafe { zkw_batch_destroy(self.raw) }
+    }
+}
+
+/// zkw_delivery: whole steps of groups of batches delivered into a persistent ring of pinned host slots by ONE pack kernel per
+/// step (the kernel's stores are the transfer), for the consumer the reference names — a VmWitnessTracer on the HOST
+/// (witness_trace/mod.rs:11-72).  `submit` behind a step, `wait`, then `vm_state` per instance (the drop-in BatchedVmState served
+/// from the ring: nothing is read from the device any more) and `release`; step k's delivery runs beside step k + 1's kernels.
+pub struct Delivery<'a> {
+    ctx: &'a Context,
+    raw: *mut zkw_delivery,
+}
+impl<'a> Delivery<'a> {
+    pub fn new(ctx: &'a Context, n_slots: u32, slot_bytes: u64, host_threads: u32) -> anyhow::Result<Self> {
+        let mut raw = std::ptr::null_mut();
+        ctx.check(unsafe { zkw_delivery_create(ctx.raw, n_slots, slot_bytes, host_threads, &mut raw) }, "zkw_delivery_create")?;
+        Ok(Delivery { ctx, raw })
+    }
+    /// upper bound of the block a step of these batches can produce (every stream at its capacity)
+    pub fn worst_case_bytes(ctx: &Context, batches: &[&Batch<'a>]) -> anyhow::Result<u64> {
+        let raw: Vec<*mut zkw_batch> = batches.iter().map(|b| b.raw).collect();
+        let mut out = 0u64;
+        ctx.check(unsafe { zkw_delivery_slot_bytes(raw.as_ptr(), raw.len() as u32, &mut out) }, "zkw_delivery_slot_bytes")?;
+        Ok(out)
+    }
+    /// delivers the step these batches have just run (asynchronous); the ticket names it from now on
+    pub fn submit(&mut self, batches: &[&Batch<'a>]) -> anyhow::Result<u32> {
+        let raw: Vec<*mut zkw_batch> = batches.iter().map(|b| b.raw).collect();
+        let mut ticket = 0u32;
+        self.ctx.check(unsafe { zkw_delivery_submit(self.raw, raw.as_ptr(), raw.len() as u32, std::ptr::null_mut(), &mut ticket) }, "zkw_delivery_submit")?;
+        Ok(ticket)
+    }
+    /// blocks until the block of `ticket` is in the ring: (bytes that crossed the link, device time of the pack kernel in ms)
+    pub fn wait(&mut self, ticket: u32) -> anyhow::Result<(u64, f64)> {
+        let mut info = zkw_delivered::default();
+        self.ctx.check(unsafe { zkw_delivery_wait(self.raw, ticket, &mut info) }, "zkw_delivery_wait")?;
+        Ok((info.bytes, info.pack_ms))
+    }
+    /// the drop-in `VmState` of one instance of a delivered step (Batch::vm_state, served from the ring)
+    pub fn delivered_trace<'b, EV: EventSink, WT: VmWitnessTracer<8, E>>(&'b self, ticket: u32, batch_index: u32, batch: &'b Batch<'a>, instance: u32, event_sink: EV, witness_tracer: WT)
+        -> anyhow::Result<BatchedVmState<'b, EV, WT>> {
+        let mut trace: zkw_instance_trace = unsafe { std::mem::zeroed() };
+        self.ctx.check(unsafe { zkw_delivery_get_instance_trace(self.raw, ticket, batch_index, instance, &mut trace) }, "zkw_delivery_get_instance_trace")?;
+        let (c, inner) = &batch.initial[instance as usize];
+        Ok(BatchedVmState { local_state: local_state_from_c(c, inner), event_sink, witness_tracer, trace, k: 0, blobs: &batch.blobs })
+    }
+    /// every (instance, cycle) of the step through the library's thread pool: the built-in consumer (cycles, checksum)
+    pub fn replay(&mut self, ticket: u32) -> anyhow::Result<(u64, u64)> {
+        let (mut n, mut sum) = (0u64, 0u64);
+        self.ctx.check(unsafe { zkw_delivery_replay(self.raw, ticket, None, std::ptr::null_mut(), &mut n, &mut sum) }, "zkw_delivery_replay")?;
+        Ok((n, sum))
+    }
+    pub fn release(&mut self, ticket: u32) -> anyhow::Result<()> {
+        self.ctx.check(unsafe { zkw_delivery_release(self.raw, ticket) }, "zkw_delivery_release")
+    }
+}
+impl<'a> Drop for Delivery<'a> {
+    fn drop(&mut self) {
+        unsafe { zkw_delivery_destroy(self.raw) }
     }
 }
 
