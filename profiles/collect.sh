@@ -12,21 +12,21 @@ cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 export ZKW_BENCH_NO_OTHER_CONFIGS=1   # every bench.py below measures ITS workload only; the driver's full line is taken with the switch unset
 OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
 hipcc --offload-arch=gfx950 -O2 -Wno-unused-result profiles/tools/occupancy_probe.hip -o /tmp/occ_probe 2>/dev/null && /tmp/occ_probe > $OUT/occupancy_probe.txt 2>&1
-DRIVER="python bench.py --gpus 1 --steps 20 --warmup 5 --no-other-configs"   # (the traced / counted process runs the headline workload only: its rocprof averages then describe one launch shape)
+DRIVER="python bench.py --gpus 1 --steps 20 --warmup 5 --no-other-configs --no-host-legs"   # (the traced / counted process runs the headline workload only: its rocprof averages then describe one launch shape)
 # The published bench line of each command is the one printed by the SAME process rocprofv3 traced (kernel-trace only:
 # its overhead is not measurable here), so that the HIP-event duration in the line and the rocprof average describe the
 # same launches: processes on one box differ by up to 6 % from each other (15.05 vs 15.98 G in the r03c collection,
 # same library, seconds apart), boxes by +-3 %.  The untraced runs before them are kept as *_plain.json.
 # the driver's command exactly as the driver runs it (cpu_baseline, other_configs, 5 timed regions): the line BENCH_rNN.json will carry
 env -u ZKW_BENCH_NO_OTHER_CONFIGS python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_full.log 2>&1; grep '^{' $OUT/bench_driver_full.log > $OUT/bench_driver_full.json
-python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $OUT/bench_driver_plain.log 2>&1; grep '^{' $OUT/bench_driver_plain.log > $OUT/bench_driver_plain.json
-python bench.py --no-cpu-baseline --no-other-configs > $OUT/bench_plain.log 2>&1; grep '^{' $OUT/bench_plain.log > $OUT/bench_plain.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_driver -o $TAG -- $DRIVER > $OUT/trace_driver.log 2>&1; grep '^{' $OUT/trace_driver.log > $OUT/bench_driver.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- python bench.py --no-other-configs > $OUT/trace.log 2>&1; grep '^{' $OUT/trace.log > $OUT/bench.json
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_insts -o $TAG -- $DRIVER --no-cpu-baseline > $OUT/pmc_insts.log 2>&1
-rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_wait -o $TAG -- $DRIVER --no-cpu-baseline > $OUT/pmc_wait.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o $TAG -- $DRIVER --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o $TAG -- $DRIVER --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-host-legs > $OUT/bench_driver_plain.log 2>&1; grep '^{' $OUT/bench_driver_plain.log > $OUT/bench_driver_plain.json
+python bench.py --no-cpu-baseline --no-other-configs --no-host-legs > $OUT/bench_plain.log 2>&1; grep '^{' $OUT/bench_plain.log > $OUT/bench_plain.json
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_driver -o $TAG -- $DRIVER > $OUT/trace_driver.log 2>&1; grep '^{' $OUT/trace_driver.log > $OUT/bench_driver.json
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- python bench.py --no-other-configs --no-host-legs > $OUT/trace.log 2>&1; grep '^{' $OUT/trace.log > $OUT/bench.json
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_insts -o $TAG -- $DRIVER --no-cpu-baseline > $OUT/pmc_insts.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_wait -o $TAG -- $DRIVER --no-cpu-baseline > $OUT/pmc_wait.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o $TAG -- $DRIVER --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o $TAG -- $DRIVER --no-cpu-baseline > $OUT/pmc_write.log 2>&1
 # the other single-GPU BASELINE configurations, each alone in a traced process with the arguments bench.py's other_configs uses
 # (bench.py: OTHER_CONFIGS): one kernel-stats CSV and one line per configuration
 i=0
@@ -34,7 +34,7 @@ for A in "--cfg 1 --instances 256 --cycles 256 --steps 20 --warmup 20 --fuse 20 
          "--cfg 1 --instances 4096 --cycles 256 --steps 64 --warmup 64 --fuse 64 --streams 1 --commit-mask 0" \
          "--cfg 3 --instances 512 --steps 128 --warmup 128 --fuse 128 --streams 1 --commit-mask 0" \
          "--cfg 4 --instances 4096 --cycles 1024 --steps 32 --warmup 16 --fuse 16 --streams 2 --commit-mask 7"; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_oc$i -o $TAG -- python bench.py $A --no-cpu-baseline --min-warmup-s 0.2 > $OUT/trace_oc$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_oc$i -o $TAG -- python bench.py $A --no-cpu-baseline --min-warmup-s 0.2 > $OUT/trace_oc$i.log 2>&1
   grep '^{' $OUT/trace_oc$i.log >> $OUT/other_configs_traced.jsonl
   cp $OUT/trace_oc$i/${TAG}_kernel_stats.csv $OUT/oc${i}_kernel_stats.csv 2>/dev/null || find $OUT/trace_oc$i -name "*kernel_stats.csv" -exec cp {} $OUT/oc${i}_kernel_stats.csv \;
   i=$((i+1))
@@ -52,7 +52,7 @@ python bench.py --cfg 4 --instances 4096 --cycles 1024 --steps 32 --warmup 16 --
 python bench.py --cfg 2 --steps 64 --warmup 32 --fuse 32 --commit-mask 7 --no-cpu-baseline 2>/dev/null | grep '^{' >> $OUT/other_cfgs.jsonl
 # BASELINE configs[3] (precompile-dominant, 512 instances = one GPU's share): its own bench line with roofline + cpu_baseline
 # from the traced process, a lone batch, and the kernel stats
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg3 -o $TAG -- python bench.py --cfg 3 --commit-mask 0 --fuse 128 --steps 256 --warmup 128 --streams 1 > $OUT/trace_cfg3.log 2>&1; grep '^{' $OUT/trace_cfg3.log > $OUT/cfg3_bench.json
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg3 -o $TAG -- python bench.py --cfg 3 --commit-mask 0 --fuse 128 --steps 256 --warmup 128 --streams 1 > $OUT/trace_cfg3.log 2>&1; grep '^{' $OUT/trace_cfg3.log > $OUT/cfg3_bench.json
 python bench.py --cfg 3 --commit-mask 0 --fuse 1 --steps 4 --warmup 2 --streams 1 --no-cpu-baseline 2>/dev/null | grep '^{' > $OUT/cfg3_lone_batch.json
 # ... the lone batch as a caller after latency runs it: 2 lanes per wave, keccak256 served by helper waves (second line of the file)
 python bench.py --cfg 3 --commit-mask 0 --fuse 1 --steps 8 --warmup 2 --streams 1 --lanes 2 --no-cpu-baseline 2>/dev/null | grep '^{' >> $OUT/cfg3_lone_batch.json
