@@ -3124,103 +3124,24 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
   if (exists && !(s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0)) lane_writeback(P, sh, rf, s, 0);  // does not cycle
   if (exists && s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0) {
     ZKW_PROF_DECL
+#ifdef ZKW_SHORT_STATS
+    u32 zs_short = 0, zs_odd = 0, zs_heavy = 0, zs_bad = 0, zs_ops[16] = {0}, zs_cls = 0, zs_n[40] = {0};
+    unsigned long long zs_t[40] = {0}, zs_last = __builtin_readcyclecounter();  // class 0-15: general path by (last) opcode, 16-31: short path by opcode, 32: refused after the slot read
+#define ZKW_SS(x) x
+#else
+#define ZKW_SS(x)
+#endif
     for (;;) {
       s.lane = zkw_lane_id();
+#ifdef ZKW_SHORT_STATS
+      if (k) {
+        const unsigned long long zs_now = __builtin_readcyclecounter();
+        zs_t[zs_cls] += zs_now - zs_last; zs_n[zs_cls]++;
+        zs_last = zs_now;
+      }
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && defined(ZKW_SLEEP_PROBE) /* (experiment: N x 64 idle clocks per cycle — does the launch get longer by as much?) */
       __builtin_amdgcn_s_sleep(ZKW_SLEEP_PROBE);
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZKW_NO_FAST_ALU) /* (-DZKW_NO_FAST_ALU: the A/B partner) */
-      // ------------------------------------------------------------------------------------------------------------
-      // The short cycle.  A wave on a shared tape whose lanes all stand at the same pc, inside the code word they fetched last,
-      // in kernel mode, with nothing pending, executes an ALU instruction with register / immediate operands (nop, add, sub,
-      // and / or / xor, jump) here: one slot read, scalar decode, the operation, the record — no group loop, no operand
-      // addressing, no opcode switch, no out-of-line call site on the path.  Every test below is wave-uniform; a cycle that
-      // does not qualify (a fetch, a memory operand, an exception, a heavier opcode, diverged lanes) takes the general path
-      // underneath, untouched: nothing is written before the cycle is known to qualify.  Same witness, bit for bit
-      // (cycle.rs:19-236 read_and_decode, :275-350 operands, add.rs / sub.rs / binop.rs / jump.rs / noop.rs, :408-413).
-      // ------------------------------------------------------------------------------------------------------------
-      if (ZKW_LIKELY(k + 1u < run_cycles && !(A.debug_flags & (4u | (1u << 24))))) {  // (the last cycle of a launch leaves through the general path; test hooks: general path)
-        const u32 pc0 = (u32)__builtin_amdgcn_readfirstlane((int)s.pc);
-        const bool odd = (s.pc != pc0) | ((s.flags & FLAG_PENDING) != 0) | ((s.kflags & (KF_CODE_PAGE_CHANGED | KF_TAIL2 | KF_STATIC | KF_KERNEL)) != KF_KERNEL) |
-                         (s.prev_super_pc != (pc0 >> 2)) | (s.depth == max_depth);
-        if (zkw_ballot(odd) == 0) {
-          const uint4 me = ZKW_SLOT_READ(sh, s.lane, 3u - (pc0 & 3u));
-          const u32 u_lo = (u32)__builtin_amdgcn_readfirstlane((int)me.x), u_hi = (u32)__builtin_amdgcn_readfirstlane((int)me.y);
-          const u32 u_attr = (u32)__builtin_amdgcn_readfirstlane((int)me.z), u_price = (u32)__builtin_amdgcn_readfirstlane((int)me.w);
-          const u32 opcode = ZKW_ATTR_OPCODE(u_attr), props = ZKW_ATTR_PROPS(u_attr), src0_mode = ZKW_ATTR_SRC0(u_attr);
-          const bool light = ((1u << opcode) & ((1u << ZKW_OP_NOP) | (1u << ZKW_OP_ADD) | (1u << ZKW_OP_SUB) | (1u << ZKW_OP_JUMP) | (1u << ZKW_OP_BINOP))) != 0 &&
-                             ZKW_ATTR_DST0(u_attr) == ZKW_MODE_REG && (src0_mode == ZKW_MODE_REG || src0_mode == ZKW_MODE_IMM) && !(props & ZKW_PROP_EXPLICIT_PANIC) &&
-                             delta_cur + ZKW_WAVE <= cap_delta;
-          // (the ISA entry follows from the opcode word: one table per batch, one batch per wave)
-          if (light && zkw_ballot((me.x != u_lo) | (me.y != u_hi) | (s.ergs < u_price)) == 0) {
-            // ---- the cycle qualifies: from here on it is executed here ----
-            {  // directory: the stream cursors at the start of the wave-cycle
-              const uint4 dir_entry = make_uint4(zkw_cursor_get<0>(), zkw_cursor_get<1>(), zkw_cursor_get<2>(), delta_cur);
-              if (zkw_rank_below(zkw_ballot(1)) == 0) *(uint4*)dir_ptr = dir_entry;
-            }
-            s.kflags = (s.kflags & ~(KF_COLD_DIRTY | KF_DQ_CHAINED | KF_MASKED)) | KF_CHARGED;
-            s.ergs -= u_price;                                                                  // :153-161
-            const bool run = condition_resolved(cond_lut, (u_lo >> 13) & 7u, s.flags);          // :193-217: a lane whose condition fails runs a nop
-            const u32 r_src0 = (u_lo >> 16) & 15u, r_src1 = (u_lo >> 20) & 15u, r_dst0 = (u_lo >> 24) & 15u;
-            u32 new_pc = (s.pc + 1u) & 0xffffu;
-            u32 dm = 0;
-            u256 res = u256_zero();
-            if (opcode != ZKW_OP_NOP) {
-              u256 a = src0_mode == ZKW_MODE_REG ? rf_get(rf, r_src0) : u256_from_u32(u_hi & 0xffffu);
-              u256 b = rf_get(rf, r_src1);
-              if (props & ZKW_PROP_SWAP) {  // :341-345 (wave-uniform)
-                const u256 t = a;
-                a = b;
-                b = t;
-              }
-              if (opcode == ZKW_OP_JUMP) {
-                if (run) new_pc = clip16(sh, a);  // jump.rs:23-25
-              } else {
-                bool of = false;
-                if (opcode == ZKW_OP_ADD) res = u256_add(a, b, of);
-                else if (opcode == ZKW_OP_SUB) res = u256_sub(a, b, of);
-                else {
-                  const u32 v = ZKW_ATTR_VARIANT(u_attr);
-                  res = v == ZKW_BINOP_XOR ? u256_xor(a, b) : (v == ZKW_BINOP_AND ? u256_and(a, b) : u256_or(a, b));
-                }
-                if (run) {
-                  if (ZKW_ATTR_FLAGS(u_attr) & 1u) {
-                    const bool eq = u256_is_zero(res);
-                    if (opcode == ZKW_OP_BINOP) set_flags3(s, false, eq, false);  // binop.rs:49-50
-                    else set_flags3(s, of, eq, !eq && !of);                       // add.rs:39-43, sub.rs:39-44
-                  }
-                  if (r_dst0 != 0) {
-                    rf_set(rf, r_dst0, res);
-                    dm = 1u << (r_dst0 - 1u);
-                    s.ptr_bitmap &= ~dm;
-                  }
-                }
-              }
-            }
-            s.pc = new_pc;
-            s.reg_dirty = dm;
-            s.counts = 0;
-            asm("v_add_u32 %0, %1, %0" : "+v"(s.timestamp) : "s"(time_delta));  // :408-411
-            // CycleRecord: the one register this cycle wrote (lanes in lane order), then the tails
-            const u64 part = zkw_ballot(dm != 0);
-            const u32 total = (u32)__popcll(part);
-            if (dm) {
-              const u32 at = delta_cur + zkw_rank_below(part);
-              zkw_stream_store(delta_base + (u64)at, u256_lo4(res));
-              zkw_stream_store(delta_base + (u64)cap_delta + at, u256_hi4(res));
-            }
-            zkw_stream_store(tails_wave + (u64)k * tail_step + s.lane,
-                             make_uint4((s.ptr_bitmap & 0xffffu) | ((s.flags & 0xfu) << 16) | ((dm & 0xffu) << 24), (s.pc & 0xffffu) | (s.sp << 16), s.ergs, (dm >> 8) << 24));
-            if (total) {
-              delta_cur += total;
-              zkw_cursor_set<3>(delta_cur);
-            }
-            k++;
-            dir_ptr += 4;
-            continue;
-          }
-        }
-      }
 #endif
       ZKW_PROF_RESET
       // directory: stream cursors at the start of wave-cycle (cycle_base + k).  Read here (one broadcast 16-B LDS read),
@@ -3263,6 +3184,219 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
         s.flags &= ~FLAG_PENDING;
         s.prev_super_pc = super_pc;
       }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZKW_NO_FAST_ALU) /* (-DZKW_NO_FAST_ALU: the A/B partner) */
+      // ------------------------------------------------------------------------------------------------------------
+      // The short cycle.  A wave on a shared tape whose lanes all stand at the same pc, in kernel mode, with nothing pending,
+      // executes here (a) an ALU instruction with register / immediate operands (nop, add, sub, and / or / xor, jump) and
+      // (b) a heap / aux-heap access (uma.rs:26-425) that raises no exception and grows no bound: one slot read, scalar
+      // decode, the operation, the record — no group loop, no operand addressing, no opcode switch, no out-of-line call site
+      // on the path.  The fetch above is shared with the general path (a cycle that starts a code word qualifies like any
+      // other).  Every test below is wave-uniform; a cycle that does not qualify (a memory operand, an exception, a growing
+      // heap, a heavier opcode, diverged lanes) takes the general path underneath, untouched: nothing is written before the
+      // cycle is known to qualify.  Same witness, bit for bit (cycle.rs:19-236 read_and_decode, :275-350 operands, add.rs /
+      // sub.rs / binop.rs / jump.rs / noop.rs / uma.rs, :408-413).
+      // ------------------------------------------------------------------------------------------------------------
+      if (ZKW_LIKELY(k + 1u < run_cycles && !(A.debug_flags & (4u | (1u << 24))))) {  // (the last cycle of a launch leaves through the general path; test hooks: general path)
+        const u32 pc0 = (u32)__builtin_amdgcn_readfirstlane((int)s.pc);
+        const bool odd = (s.pc != pc0) | pending | ((s.kflags & (KF_TAIL2 | KF_STATIC | KF_KERNEL)) != KF_KERNEL) | (s.depth == max_depth) | !lane_ok(s);
+        if (zkw_ballot(odd) == 0) {
+          const uint4 me = ZKW_SLOT_READ(sh, s.lane, 3u - (pc0 & 3u));
+          const u32 u_lo = (u32)__builtin_amdgcn_readfirstlane((int)me.x), u_hi = (u32)__builtin_amdgcn_readfirstlane((int)me.y);
+          const u32 u_attr = (u32)__builtin_amdgcn_readfirstlane((int)me.z), u_price = (u32)__builtin_amdgcn_readfirstlane((int)me.w);
+          const u32 opcode = ZKW_ATTR_OPCODE(u_attr), props = ZKW_ATTR_PROPS(u_attr), src0_mode = ZKW_ATTR_SRC0(u_attr), variant = ZKW_ATTR_VARIANT(u_attr);
+          const bool alu = ((1u << opcode) & ((1u << ZKW_OP_NOP) | (1u << ZKW_OP_ADD) | (1u << ZKW_OP_SUB) | (1u << ZKW_OP_JUMP) | (1u << ZKW_OP_BINOP))) != 0;
+#ifndef ZKW_NO_FAST_UMA
+          const bool uma = opcode == ZKW_OP_UMA && variant <= ZKW_UMA_AUX_WRITE && !(props & ZKW_PROP_SWAP) &&
+                           zkw_cursor_get<0>() + 4u * ZKW_WAVE <= sh.cap_mem;  // (its four queries at most cannot run out of stream)
+#else
+          const bool uma = false;
+#endif
+          const bool light = (alu || uma) && ZKW_ATTR_DST0(u_attr) == ZKW_MODE_REG && (src0_mode == ZKW_MODE_REG || src0_mode == ZKW_MODE_IMM) &&
+                             !(props & ZKW_PROP_EXPLICIT_PANIC) && delta_cur + 2u * ZKW_WAVE <= cap_delta;
+          if (light) {
+            const u32 r_src0 = (u_lo >> 16) & 15u, r_src1 = (u_lo >> 20) & 15u, r_dst0 = (u_lo >> 24) & 15u, r_dst1 = u_lo >> 28;
+            const bool run = condition_resolved(cond_lut, (u_lo >> 13) & 7u, s.flags);          // :193-217: a lane whose condition fails runs a nop
+            // (the ISA entry follows from the opcode word: one table per batch, one batch per wave)
+            bool bad = (me.x != u_lo) | (me.y != u_hi) | (s.ergs < u_price);
+            const bool uma_heap = variant == ZKW_UMA_HEAP_READ || variant == ZKW_UMA_HEAP_WRITE;
+            const bool uma_write = variant == ZKW_UMA_HEAP_WRITE || variant == ZKW_UMA_AUX_WRITE;
+            u256 a = u256_zero();
+            if (opcode != ZKW_OP_NOP) a = src0_mode == ZKW_MODE_REG ? rf_get(rf, r_src0) : u256_from_u32(u_hi & 0xffffu);
+            if (uma) {  // uma.rs:121-207: the offset dereferenceable, no overflow of the increment, inside the bound paid for, inside the arena
+              const u32 off = a.w[0], inc = off + 32u;
+              const u32 bound = uma_heap ? cfv_heap_bound(sh, s) : cfv_aux_bound(sh, s);
+              bad |= run & (((a.w[1] | a.w[2] | a.w[3] | a.w[4] | a.w[5] | a.w[6] | a.w[7]) != 0) | (off > sh.max_deref_low) | (inc < off) | (inc >= bound) |
+                            ((off >> 5) + 1u >= (uma_heap ? sh.H : sh.A)));
+            }
+            if (zkw_ballot(bad) == 0) {
+              // ---- the cycle qualifies: from here on it is executed here ----
+              ZKW_SS(zs_short++; zs_cls = 16u + (opcode & 15u);)
+              if (zkw_rank_below(zkw_ballot(1)) == 0) *(uint4*)dir_ptr = dir_entry;
+              s.kflags = (s.kflags & ~(KF_CODE_PAGE_CHANGED | KF_MASKED)) | KF_CHARGED;
+              s.ergs -= u_price;                                                                  // :153-161
+              u32 new_pc = (s.pc + 1u) & 0xffffu;
+              u32 dm = 0;
+              u256 res = u256_zero();
+              if (uma) {
+                const u32 increment = ZKW_ATTR_FLAGS(u_attr) & 1u;
+                if (run) {
+                  const u32 f_slot = cfv_slot(sh, s);
+                  const u32 f_hwm_in = uma_heap ? cfv_heap_hwm(sh, s) : CF(sh, s, CF_AUX_HWM);
+                  u32 f_hwm = f_hwm_in;
+                  const u32 page = CF(sh, s, CF_BASE_PAGE) + (uma_heap ? 2u : 3u);
+                  const u32 mem_type = uma_heap ? ZKW_MEM_HEAP : ZKW_MEM_AUX_HEAP;
+                  const u32 off = a.w[0], word0 = off >> 5, unal = off & 31u;
+                  const u32 src0_ptr = src0_mode == ZKW_MODE_REG ? ((s.ptr_bitmap << 1) >> r_src0) & 1u : 0u;
+                  const u32 ts_r = s.timestamp, ts_w = s.timestamp + 3u;
+                  u256 w0v = heap_read_at(P, sh, s, !uma_heap, f_slot, f_hwm, word0), w1v = u256_zero();
+                  if (unal) w1v = heap_read_at(P, sh, s, !uma_heap, f_slot, f_hwm, word0 + 1u);
+                  ZKW_SETTLE(2 /* UMA words */);
+                  emit_mem(P, sh, s, ts_r, mem_type, page, word0, w0v, false, false, 0);
+                  if (unal) emit_mem(P, sh, s, ts_r, mem_type, page, word0 + 1u, w1v, false, false, 0);
+                  const bool all_aligned = zkw_ballot(unal != 0) == 0;
+                  const u32 u_unal = (u32)__builtin_amdgcn_readfirstlane((int)unal);
+                  const bool same_unal = zkw_ballot(unal != u_unal) == 0;
+                  const u32 u_b8 = (u_unal & 3u) * 8u;
+                  u256 upd = u256_zero();
+                  upd.w[0] = off + 32u;
+                  if (!uma_write) {  // uma.rs:291-348
+                    if (all_aligned) {
+                      res = w0v;
+                    } else if (same_unal) {
+                      switch (u_unal >> 2) {
+                        case 0: res = u256_byte_window_at<0>(w0v, w1v, u_b8); break;
+                        case 1: res = u256_byte_window_at<1>(w0v, w1v, u_b8); break;
+                        case 2: res = u256_byte_window_at<2>(w0v, w1v, u_b8); break;
+                        case 3: res = u256_byte_window_at<3>(w0v, w1v, u_b8); break;
+                        case 4: res = u256_byte_window_at<4>(w0v, w1v, u_b8); break;
+                        case 5: res = u256_byte_window_at<5>(w0v, w1v, u_b8); break;
+                        case 6: res = u256_byte_window_at<6>(w0v, w1v, u_b8); break;
+                        default: res = u256_byte_window_at<7>(w0v, w1v, u_b8); break;
+                      }
+                    } else {
+                      res = u256_byte_window(w0v, w1v, unal);
+                    }
+                    if (r_dst0 != 0) {
+                      rf_set(rf, r_dst0, res);
+                      dm = 1u << (r_dst0 - 1u);
+                      s.ptr_bitmap &= ~dm;
+                    }
+                    if (increment && r_dst1 != 0) {  // (l[0] & TOP_32) + incremented :337-338; the pointer tag of src0 travels with it
+                      rf_set(rf, r_dst1, upd);
+                      dm |= 1u << (r_dst1 - 1u);
+                      s.ptr_bitmap = (s.ptr_bitmap & ~(1u << (r_dst1 - 1u))) | (src0_ptr << (r_dst1 - 1u));
+                    }
+                  } else {  // uma.rs:349-423
+                    const u256 b = rf_get(rf, r_src1);
+                    u256 n0, n1;
+                    if (all_aligned) {
+                      n0 = b;
+                      n1 = u256_zero();
+                    } else if (same_unal) {
+                      switch (u_unal >> 2) {
+                        case 0: u256_merge_at<0>(w0v, w1v, b, u_b8, n0, n1); break;
+                        case 1: u256_merge_at<1>(w0v, w1v, b, u_b8, n0, n1); break;
+                        case 2: u256_merge_at<2>(w0v, w1v, b, u_b8, n0, n1); break;
+                        case 3: u256_merge_at<3>(w0v, w1v, b, u_b8, n0, n1); break;
+                        case 4: u256_merge_at<4>(w0v, w1v, b, u_b8, n0, n1); break;
+                        case 5: u256_merge_at<5>(w0v, w1v, b, u_b8, n0, n1); break;
+                        case 6: u256_merge_at<6>(w0v, w1v, b, u_b8, n0, n1); break;
+                        default: u256_merge_at<7>(w0v, w1v, b, u_b8, n0, n1); break;
+                      }
+                    } else {
+                      const u32 lowest = 32 - unal;
+                      n0 = u256_shl(u256_shr(w0v, lowest * 8), lowest * 8);
+                      n0 = u256_or(n0, u256_shr(b, unal * 8));
+                      n1 = u256_shr(u256_shl(w1v, unal * 8), unal * 8);
+                      n1 = u256_or(n1, u256_shl(b, (32 - unal) * 8));
+                    }
+                    heap_write_at(P, sh, s, !uma_heap, f_slot, f_hwm, word0, n0);
+                    emit_mem(P, sh, s, ts_w, mem_type, page, word0, n0, false, true, 0);
+                    if (unal) {
+                      heap_write_at(P, sh, s, !uma_heap, f_slot, f_hwm, word0 + 1u, n1);
+                      emit_mem(P, sh, s, ts_w, mem_type, page, word0 + 1u, n1, false, true, 0);
+                    }
+                    if (ZKW_UNLIKELY(f_hwm != f_hwm_in)) {
+                      if (uma_heap) cfv_set_heap_hwm(sh, s, f_hwm); else CF(sh, s, CF_AUX_HWM) = f_hwm;
+                    }
+                    if (increment && r_dst0 != 0) {
+                      rf_set(rf, r_dst0, upd);
+                      dm = 1u << (r_dst0 - 1u);
+                      s.ptr_bitmap &= ~dm;
+                    }
+                  }
+                  // (a cursor: the next access through the register is 32 bytes on — see op_uma)
+                  if (increment && src0_mode != ZKW_MODE_IMM && !ZKW_ABL(sh.debug_flags, ZKW_NO_PREFETCH))
+                    prefetch_page_words(uma_heap ? sh.heap : sh.aux_heap, uma_heap ? P.H : P.A, P.L, zkw_lds_sink_addr(), f_slot, f_hwm, off + 32u);
+                }
+              } else if (opcode != ZKW_OP_NOP) {
+                u256 b = rf_get(rf, r_src1);
+                if (props & ZKW_PROP_SWAP) {  // :341-345 (wave-uniform)
+                  const u256 t = a;
+                  a = b;
+                  b = t;
+                }
+                if (opcode == ZKW_OP_JUMP) {
+                  if (run) new_pc = clip16(sh, a);  // jump.rs:23-25
+                } else {
+                  bool of = false;
+                  if (opcode == ZKW_OP_ADD) res = u256_add(a, b, of);
+                  else if (opcode == ZKW_OP_SUB) res = u256_sub(a, b, of);
+                  else res = variant == ZKW_BINOP_XOR ? u256_xor(a, b) : (variant == ZKW_BINOP_AND ? u256_and(a, b) : u256_or(a, b));
+                  if (run) {
+                    if (ZKW_ATTR_FLAGS(u_attr) & 1u) {
+                      const bool eq = u256_is_zero(res);
+                      if (opcode == ZKW_OP_BINOP) set_flags3(s, false, eq, false);  // binop.rs:49-50
+                      else set_flags3(s, of, eq, !eq && !of);                       // add.rs:39-43, sub.rs:39-44
+                    }
+                    if (r_dst0 != 0) {
+                      rf_set(rf, r_dst0, res);
+                      dm = 1u << (r_dst0 - 1u);
+                      s.ptr_bitmap &= ~dm;
+                    }
+                  }
+                }
+              }
+              s.lane = zkw_lane_id();
+              s.pc = new_pc;
+              asm("v_add_u32 %0, %1, %0" : "+v"(s.timestamp) : "s"(time_delta));  // :408-411
+              // CycleRecord: the registers this cycle wrote (ascending, lanes in lane order within a register: every lane
+              // that wrote holds the same mask), then the tails
+              const u64 part = zkw_ballot(dm != 0);
+              const u32 per_reg = (u32)__popcll(part);
+              u32 pos = delta_cur;
+              if (per_reg) {
+                const u32 any = (u32)__builtin_amdgcn_readlane((int)dm, (int)((u32)__ffsll((long long)part) - 1u));
+                const u32 my = pos + zkw_rank_below(part);
+                for (u32 left = any; left; left &= left - 1u) {
+                  const u32 r = (u32)__ffsll((long long)left) - 1u;
+                  if (dm) {
+                    const u256 v = uma ? rf_get(rf, r + 1u) : res;  // (wave-uniform choice: an ALU cycle writes one register and still holds its value)
+                    const u32 at = my + (pos - delta_cur);
+                    zkw_stream_store(delta_base + (u64)at, u256_lo4(v));
+                    zkw_stream_store(delta_base + (u64)cap_delta + at, u256_hi4(v));
+                  }
+                  pos += per_reg;
+                }
+              }
+              zkw_stream_store(tails_wave + (u64)k * tail_step + s.lane,
+                               make_uint4((s.ptr_bitmap & 0xffffu) | ((s.flags & 0xfu) << 16) | ((dm & 0xffu) << 24), (s.pc & 0xffffu) | (s.sp << 16), s.ergs,
+                                          (s.counts >> 8) | ((dm >> 8) << 24)));
+              if (pos != delta_cur) {
+                delta_cur = pos;
+                zkw_cursor_set<3>(delta_cur);
+              }
+              k++;
+              dir_ptr += 4;
+              continue;
+            }
+            ZKW_SS(else zs_bad++;)
+          }
+          ZKW_SS(else { zs_heavy++; zs_ops[opcode & 15u]++; })
+        }
+        ZKW_SS(else zs_odd++;)
+      }
+#endif
       s.kflags &= ~(KF_CODE_PAGE_CHANGED | KF_CHARGED | KF_MASKED);  // previous_code_memory_page := code_page (:49)
       if (ZKW_UNLIKELY(pending)) {  // the instruction is exception_revert_encoding() instead of the slot of the code word (:104-115)
         const u64 rv = P.consts.exception_revert_encoding;
@@ -3362,6 +3496,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
           d.imm0 = u_hi & 0xffffu; d.imm1 = u_hi >> 16;
           if (ZKW_ABL(A.debug_flags, 8u)) s.pc = (s.pc + 1u) & 0xffffu;  // profiling ablation: no operand / opcode work
           else exec_decoded(P, sh, rf, s, d, vec, me.x, me.y);
+          ZKW_SS(zs_cls = ZKW_ATTR_OPCODE(u_attr) & 15u;)
 #ifdef ZKW_PROFILE
           {
             const unsigned long long zp_now = __builtin_readcyclecounter();
@@ -3490,6 +3625,13 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
       dir_ptr += 4;
       // leave: failed / out of cycles / execution_has_ended() (mod.rs:96-98: callers stop cycling at depth 0)
       if (ZKW_UNLIKELY(!lane_ok(s) || k >= run_cycles || s.depth == 0)) {
+#ifdef ZKW_SHORT_STATS
+        if (blockIdx.x == 1 && threadIdx.x == 0) {
+          printf("ZKWSHORT cycles %u short %u odd %u heavy %u bad %u\n", k, zs_short, zs_odd, zs_heavy, zs_bad);
+          for (int o = 0; o < 16; o++) if (zs_ops[o]) printf("ZKWSHORT refused opcode %d: %u\n", o, zs_ops[o]);
+          for (int o = 0; o < 40; o++) if (zs_n[o]) printf("ZKWSHORT class %d: %u cycles, %llu clocks each, %llu in total\n", o, zs_n[o], zs_t[o] / zs_n[o], zs_t[o]);
+        }
+#endif
         if (!lane_ok(s)) dq_undo(P, sh, s);  // the failed cycle leaves no records: a decommit it chained inline goes too
         lane_writeback(P, sh, rf, s, lane_ok(s) ? k : k - 1u);  // a lane that failed did not complete its last cycle
         break;

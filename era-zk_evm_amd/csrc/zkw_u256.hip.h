@@ -291,6 +291,15 @@ ZD void u256_divmod(const u256& a, const u256& b, u256& q, u256& r) {
 #pragma unroll
     for (int i = 8; i >= 1; i--) rem[i] = rem[i - 1];
     rem[0] = ulo.w[j];
+#ifdef __HIP_DEVICE_COMPILE__
+    // a step whose window is below the divisor in every lane of the wave (top limb of the window zero, the next one below the
+    // divisor's top limb) produces the digit 0 and leaves the window as it is: skipped as a scalar branch.  Operands of similar
+    // size — the common case — need one or two of the eight steps.
+    if (__builtin_amdgcn_ballot_w64((rem[8] != 0) | (rem[7] >= v.w[7])) == 0) {
+      q.w[j] = 0;
+      continue;
+    }
+#endif
     // estimate qhat from (rem[8]:rem[7]) / v[7]
     u32 qhat, rhat;
     bool rhat_big = false;  // rhat >= B: no further correction possible/needed
