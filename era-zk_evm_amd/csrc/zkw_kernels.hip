@@ -3125,8 +3125,11 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
   if (exists && s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0) {
     ZKW_PROF_DECL
 #ifdef ZKW_SHORT_STATS
-    u32 zs_short = 0, zs_odd = 0, zs_heavy = 0, zs_bad = 0, zs_ops[16] = {0}, zs_cls = 0, zs_n[40] = {0};
-    unsigned long long zs_t[40] = {0}, zs_last = __builtin_readcyclecounter();  // class 0-15: general path by (last) opcode, 16-31: short path by opcode, 32: refused after the slot read
+    // (scalars only: counters in an array would live in scratch memory, and every cycle would wait for its stores)
+    u32 zs_short = 0, zs_odd = 0, zs_heavy = 0, zs_bad = 0, zs_cls = 0;
+    u32 zs_n0 = 0, zs_n1 = 0, zs_n2 = 0, zs_n3 = 0, zs_n4 = 0, zs_n5 = 0;
+    unsigned long long zs_t0 = 0, zs_t1 = 0, zs_t2 = 0, zs_t3 = 0, zs_t4 = 0, zs_t5 = 0, zs_last = __builtin_readcyclecounter();
+    // class 0: general path, light opcode; 1: general path, UMA; 2: general path, log / near call / far call / ret; 3: short path, ALU; 4: short path, UMA; 5: short path, mul
 #define ZKW_SS(x) x
 #else
 #define ZKW_SS(x)
@@ -3136,12 +3139,17 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
 #ifdef ZKW_SHORT_STATS
       if (k) {
         const unsigned long long zs_now = __builtin_readcyclecounter();
-        zs_t[zs_cls] += zs_now - zs_last; zs_n[zs_cls]++;
+        const unsigned long long zs_d = zs_now - zs_last;
+        if (zs_cls == 0) { zs_t0 += zs_d; zs_n0++; } else if (zs_cls == 1) { zs_t1 += zs_d; zs_n1++; } else if (zs_cls == 2) { zs_t2 += zs_d; zs_n2++; }
+        else if (zs_cls == 3) { zs_t3 += zs_d; zs_n3++; } else if (zs_cls == 4) { zs_t4 += zs_d; zs_n4++; } else { zs_t5 += zs_d; zs_n5++; }
         zs_last = zs_now;
       }
 #endif
 #if defined(__HIP_DEVICE_COMPILE__) && defined(ZKW_SLEEP_PROBE) /* (experiment: N x 64 idle clocks per cycle — does the launch get longer by as much?) */
       __builtin_amdgcn_s_sleep(ZKW_SLEEP_PROBE);
+#endif
+#ifdef ZKW_ASM_MARKS
+      asm volatile("; MARK loop top");
 #endif
       ZKW_PROF_RESET
       // directory: stream cursors at the start of wave-cycle (cycle_base + k).  Read here (one broadcast 16-B LDS read),
@@ -3196,6 +3204,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
       // cycle is known to qualify.  Same witness, bit for bit (cycle.rs:19-236 read_and_decode, :275-350 operands, add.rs /
       // sub.rs / binop.rs / jump.rs / noop.rs / uma.rs, :408-413).
       // ------------------------------------------------------------------------------------------------------------
+#ifdef ZKW_ASM_MARKS
+      asm volatile("; MARK short test");
+#endif
       if (ZKW_LIKELY(k + 1u < run_cycles && !(A.debug_flags & (4u | (1u << 24))))) {  // (the last cycle of a launch leaves through the general path; test hooks: general path)
         const u32 pc0 = (u32)__builtin_amdgcn_readfirstlane((int)s.pc);
         const bool odd = (s.pc != pc0) | pending | ((s.kflags & (KF_TAIL2 | KF_STATIC | KF_KERNEL)) != KF_KERNEL) | (s.depth == max_depth) | !lane_ok(s);
@@ -3204,15 +3215,19 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
           const u32 u_lo = (u32)__builtin_amdgcn_readfirstlane((int)me.x), u_hi = (u32)__builtin_amdgcn_readfirstlane((int)me.y);
           const u32 u_attr = (u32)__builtin_amdgcn_readfirstlane((int)me.z), u_price = (u32)__builtin_amdgcn_readfirstlane((int)me.w);
           const u32 opcode = ZKW_ATTR_OPCODE(u_attr), props = ZKW_ATTR_PROPS(u_attr), src0_mode = ZKW_ATTR_SRC0(u_attr), variant = ZKW_ATTR_VARIANT(u_attr);
-          const bool alu = ((1u << opcode) & ((1u << ZKW_OP_NOP) | (1u << ZKW_OP_ADD) | (1u << ZKW_OP_SUB) | (1u << ZKW_OP_JUMP) | (1u << ZKW_OP_BINOP))) != 0;
+          // (div stays with the general path: a second inlined u256_divmod in the loop made the driver's command 0.7 % slower, profiles/r08_ab_log.txt)
+          const bool alu = ((1u << opcode) & ((1u << ZKW_OP_NOP) | (1u << ZKW_OP_ADD) | (1u << ZKW_OP_SUB) | (1u << ZKW_OP_MUL) | (1u << ZKW_OP_JUMP) | (1u << ZKW_OP_SHIFT) |
+                                              (1u << ZKW_OP_BINOP))) != 0;
+          const bool two_regs = opcode == ZKW_OP_MUL;  // (dst0 and dst1)
+          const bool code_operand = src0_mode == ZKW_MODE_CODE && alu && opcode != ZKW_OP_NOP;  // a constant from the code page (mem_ops.rs:100-110)
 #ifndef ZKW_NO_FAST_UMA
-          const bool uma = opcode == ZKW_OP_UMA && variant <= ZKW_UMA_AUX_WRITE && !(props & ZKW_PROP_SWAP) &&
-                           zkw_cursor_get<0>() + 4u * ZKW_WAVE <= sh.cap_mem;  // (its four queries at most cannot run out of stream)
+          const bool uma = opcode == ZKW_OP_UMA && variant <= ZKW_UMA_AUX_WRITE && !(props & ZKW_PROP_SWAP);
 #else
           const bool uma = false;
 #endif
-          const bool light = (alu || uma) && ZKW_ATTR_DST0(u_attr) == ZKW_MODE_REG && (src0_mode == ZKW_MODE_REG || src0_mode == ZKW_MODE_IMM) &&
-                             !(props & ZKW_PROP_EXPLICIT_PANIC) && delta_cur + 2u * ZKW_WAVE <= cap_delta;
+          const bool light = (alu || uma) && ZKW_ATTR_DST0(u_attr) == ZKW_MODE_REG && (src0_mode == ZKW_MODE_REG || src0_mode == ZKW_MODE_IMM || code_operand) &&
+                             !(props & ZKW_PROP_EXPLICIT_PANIC) && delta_cur + 2u * ZKW_WAVE <= cap_delta &&
+                             (!(uma || code_operand) || zkw_cursor_get<0>() + 4u * ZKW_WAVE <= sh.cap_mem);  // (its four queries at most cannot run out of stream)
           if (light) {
             const u32 r_src0 = (u_lo >> 16) & 15u, r_src1 = (u_lo >> 20) & 15u, r_dst0 = (u_lo >> 24) & 15u, r_dst1 = u_lo >> 28;
             const bool run = condition_resolved(cond_lut, (u_lo >> 13) & 7u, s.flags);          // :193-217: a lane whose condition fails runs a nop
@@ -3221,7 +3236,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
             const bool uma_heap = variant == ZKW_UMA_HEAP_READ || variant == ZKW_UMA_HEAP_WRITE;
             const bool uma_write = variant == ZKW_UMA_HEAP_WRITE || variant == ZKW_UMA_AUX_WRITE;
             u256 a = u256_zero();
-            if (opcode != ZKW_OP_NOP) a = src0_mode == ZKW_MODE_REG ? rf_get(rf, r_src0) : u256_from_u32(u_hi & 0xffffu);
+            if (opcode != ZKW_OP_NOP) a = src0_mode == ZKW_MODE_IMM ? u256_from_u32(u_hi & 0xffffu) : rf_get(rf, r_src0);  // (a code operand: the register part of its address)
             if (uma) {  // uma.rs:121-207: the offset dereferenceable, no overflow of the increment, inside the bound paid for, inside the arena
               const u32 off = a.w[0], inc = off + 32u;
               const u32 bound = uma_heap ? cfv_heap_bound(sh, s) : cfv_aux_bound(sh, s);
@@ -3229,9 +3244,14 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
                             ((off >> 5) + 1u >= (uma_heap ? sh.H : sh.A)));
             }
             if (zkw_ballot(bad) == 0) {
+#ifdef ZKW_ASM_MARKS
+      asm volatile("; MARK short qualified");
+#endif
               // ---- the cycle qualifies: from here on it is executed here ----
-              ZKW_SS(zs_short++; zs_cls = 16u + (opcode & 15u);)
+              ZKW_SS(zs_short++; zs_cls = uma ? 4u : (two_regs ? 5u : 3u);)
+#ifndef ZKW_EXP_NODIR /* (experiment: what the directory store costs — wrong results) */
               if (zkw_rank_below(zkw_ballot(1)) == 0) *(uint4*)dir_ptr = dir_entry;
+#endif
               s.kflags = (s.kflags & ~(KF_CODE_PAGE_CHANGED | KF_MASKED)) | KF_CHARGED;
               s.ergs -= u_price;                                                                  // :153-161
               u32 new_pc = (s.pc + 1u) & 0xffffu;
@@ -3248,11 +3268,23 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
                   const u32 off = a.w[0], word0 = off >> 5, unal = off & 31u;
                   const u32 src0_ptr = src0_mode == ZKW_MODE_REG ? ((s.ptr_bitmap << 1) >> r_src0) & 1u : 0u;
                   const u32 ts_r = s.timestamp, ts_w = s.timestamp + 3u;
+#ifdef ZKW_EXP_NOLOAD /* (experiment: what the exposed latency of the word loads costs — wrong results) */
+                  u256 w0v = u256_from_u32(word0), w1v = u256_zero();
+#else
                   u256 w0v = heap_read_at(P, sh, s, !uma_heap, f_slot, f_hwm, word0), w1v = u256_zero();
                   if (unal) w1v = heap_read_at(P, sh, s, !uma_heap, f_slot, f_hwm, word0 + 1u);
+#endif
                   ZKW_SETTLE(2 /* UMA words */);
+#ifdef ZKW_ASM_MARKS
+                  asm volatile("; MARK emit0 begin");
+#endif
+#ifndef ZKW_EXP_NOEMIT /* (experiment: what the read queries cost — wrong results) */
                   emit_mem(P, sh, s, ts_r, mem_type, page, word0, w0v, false, false, 0);
                   if (unal) emit_mem(P, sh, s, ts_r, mem_type, page, word0 + 1u, w1v, false, false, 0);
+#endif
+#ifdef ZKW_ASM_MARKS
+                  asm volatile("; MARK emit0 end");
+#endif
                   const bool all_aligned = zkw_ballot(unal != 0) == 0;
                   const u32 u_unal = (u32)__builtin_amdgcn_readfirstlane((int)unal);
                   const bool same_unal = zkw_ballot(unal != u_unal) == 0;
@@ -3330,6 +3362,13 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
                     prefetch_page_words(uma_heap ? sh.heap : sh.aux_heap, uma_heap ? P.H : P.A, P.L, zkw_lds_sink_addr(), f_slot, f_hwm, off + 32u);
                 }
               } else if (opcode != ZKW_OP_NOP) {
+                if (code_operand) {  // cycle.rs:304-325: the word of the code page at (register + imm0), and its query
+                  if (run) {
+                    const u32 idx = (clip16(sh, a) + (u_hi & 0xffffu)) & 0xffffu;  // mem_ops.rs:34-35
+                    a = code_fetch(sh, s, idx);
+                    emit_mem(P, sh, s, s.timestamp, ZKW_MEM_CODE, CF(sh, s, CF_CODE_PAGE), idx, a, false, false, 0);
+                  }
+                }
                 u256 b = rf_get(rf, r_src1);
                 if (props & ZKW_PROP_SWAP) {  // :341-345 (wave-uniform)
                   const u256 t = a;
@@ -3339,24 +3378,49 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
                 if (opcode == ZKW_OP_JUMP) {
                   if (run) new_pc = clip16(sh, a);  // jump.rs:23-25
                 } else {
-                  bool of = false;
-                  if (opcode == ZKW_OP_ADD) res = u256_add(a, b, of);
-                  else if (opcode == ZKW_OP_SUB) res = u256_sub(a, b, of);
-                  else res = variant == ZKW_BINOP_XOR ? u256_xor(a, b) : (variant == ZKW_BINOP_AND ? u256_and(a, b) : u256_or(a, b));
-                  if (run) {
-                    if (ZKW_ATTR_FLAGS(u_attr) & 1u) {
-                      const bool eq = u256_is_zero(res);
-                      if (opcode == ZKW_OP_BINOP) set_flags3(s, false, eq, false);  // binop.rs:49-50
-                      else set_flags3(s, of, eq, !eq && !of);                       // add.rs:39-43, sub.rs:39-44
+                  bool of = false, eq = false, gt = false;
+                  u256 res1 = u256_zero();  // dst1 of mul
+                  if (opcode == ZKW_OP_ADD) {  // add.rs:35-53
+                    res = u256_add(a, b, of);
+                    eq = u256_is_zero(res); gt = !eq && !of;
+                  } else if (opcode == ZKW_OP_SUB) {  // sub.rs:35-54
+                    res = u256_sub(a, b, of);
+                    eq = u256_is_zero(res); gt = !eq && !of;
+                  } else if (opcode == ZKW_OP_BINOP) {  // binop.rs:42-61
+                    res = variant == ZKW_BINOP_XOR ? u256_xor(a, b) : (variant == ZKW_BINOP_AND ? u256_and(a, b) : u256_or(a, b));
+                    eq = u256_is_zero(res);
+                  } else if (opcode == ZKW_OP_SHIFT) {  // shift.rs:44-78
+                    const u32 n = b.w[0] & 0xffu;
+                    const bool cyclic = variant == ZKW_SHIFT_ROL || variant == ZKW_SHIFT_ROR, right = variant == ZKW_SHIFT_SHR || variant == ZKW_SHIFT_ROR;
+                    if (right) {
+                      res = u256_shr(a, n);
+                      if (cyclic) res = u256_or(res, u256_shl(a, 256u - n));
+                    } else {
+                      res = u256_shl(a, n);
+                      if (cyclic) res = u256_or(res, u256_shr(a, 256u - n));
                     }
+                    eq = u256_is_zero(res);
+                  } else {  // mul.rs:35-65
+                    if (run) u256_mul(a, b, res, res1);
+                    of = !u256_is_zero(res1); eq = u256_is_zero(res); gt = !of && !eq;
+                  }
+                  if (run) {
+                    if (ZKW_ATTR_FLAGS(u_attr) & 1u) set_flags3(s, of, eq, gt);
                     if (r_dst0 != 0) {
                       rf_set(rf, r_dst0, res);
                       dm = 1u << (r_dst0 - 1u);
-                      s.ptr_bitmap &= ~dm;
                     }
+                    if (two_regs && r_dst1 != 0) {
+                      rf_set(rf, r_dst1, res1);
+                      dm |= 1u << (r_dst1 - 1u);
+                    }
+                    s.ptr_bitmap &= ~dm;
                   }
                 }
               }
+#ifdef ZKW_ASM_MARKS
+      asm volatile("; MARK short record");
+#endif
               s.lane = zkw_lane_id();
               s.pc = new_pc;
               asm("v_add_u32 %0, %1, %0" : "+v"(s.timestamp) : "s"(time_delta));  // :408-411
@@ -3371,7 +3435,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
                 for (u32 left = any; left; left &= left - 1u) {
                   const u32 r = (u32)__ffsll((long long)left) - 1u;
                   if (dm) {
-                    const u256 v = uma ? rf_get(rf, r + 1u) : res;  // (wave-uniform choice: an ALU cycle writes one register and still holds its value)
+                    const u256 v = (uma || two_regs) ? rf_get(rf, r + 1u) : res;  // (wave-uniform choice: a one-register ALU cycle still holds its value)
                     const u32 at = my + (pos - delta_cur);
                     zkw_stream_store(delta_base + (u64)at, u256_lo4(v));
                     zkw_stream_store(delta_base + (u64)cap_delta + at, u256_hi4(v));
@@ -3379,20 +3443,25 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
                   pos += per_reg;
                 }
               }
+#ifndef ZKW_EXP_NOTAIL /* (experiment: what the tail store costs — wrong results) */
               zkw_stream_store(tails_wave + (u64)k * tail_step + s.lane,
                                make_uint4((s.ptr_bitmap & 0xffffu) | ((s.flags & 0xfu) << 16) | ((dm & 0xffu) << 24), (s.pc & 0xffffu) | (s.sp << 16), s.ergs,
                                           (s.counts >> 8) | ((dm >> 8) << 24)));
+#endif
               if (pos != delta_cur) {
                 delta_cur = pos;
                 zkw_cursor_set<3>(delta_cur);
               }
+#ifdef ZKW_ASM_MARKS
+      asm volatile("; MARK short end");
+#endif
               k++;
               dir_ptr += 4;
               continue;
             }
             ZKW_SS(else zs_bad++;)
           }
-          ZKW_SS(else { zs_heavy++; zs_ops[opcode & 15u]++; })
+          ZKW_SS(else zs_heavy++;)
         }
         ZKW_SS(else zs_odd++;)
       }
@@ -3496,7 +3565,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
           d.imm0 = u_hi & 0xffffu; d.imm1 = u_hi >> 16;
           if (ZKW_ABL(A.debug_flags, 8u)) s.pc = (s.pc + 1u) & 0xffffu;  // profiling ablation: no operand / opcode work
           else exec_decoded(P, sh, rf, s, d, vec, me.x, me.y);
-          ZKW_SS(zs_cls = ZKW_ATTR_OPCODE(u_attr) & 15u;)
+          ZKW_SS({ const u32 zo = ZKW_ATTR_OPCODE(u_attr); zs_cls = zo == ZKW_OP_UMA ? 1u : ((zo == ZKW_OP_LOG || zo == ZKW_OP_NEAR_CALL || zo == ZKW_OP_FAR_CALL || zo == ZKW_OP_RET) ? 2u : 0u); })
 #ifdef ZKW_PROFILE
           {
             const unsigned long long zp_now = __builtin_readcyclecounter();
@@ -3628,8 +3697,8 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
 #ifdef ZKW_SHORT_STATS
         if (blockIdx.x == 1 && threadIdx.x == 0) {
           printf("ZKWSHORT cycles %u short %u odd %u heavy %u bad %u\n", k, zs_short, zs_odd, zs_heavy, zs_bad);
-          for (int o = 0; o < 16; o++) if (zs_ops[o]) printf("ZKWSHORT refused opcode %d: %u\n", o, zs_ops[o]);
-          for (int o = 0; o < 40; o++) if (zs_n[o]) printf("ZKWSHORT class %d: %u cycles, %llu clocks each, %llu in total\n", o, zs_n[o], zs_t[o] / zs_n[o], zs_t[o]);
+          printf("ZKWSHORT general light %u x %llu, general UMA %u x %llu, general heavy %u x %llu, short ALU %u x %llu, short UMA %u x %llu, short mul %u x %llu clocks\n", zs_n0, zs_t0 / (zs_n0 ? zs_n0 : 1), zs_n1,
+                 zs_t1 / (zs_n1 ? zs_n1 : 1), zs_n2, zs_t2 / (zs_n2 ? zs_n2 : 1), zs_n3, zs_t3 / (zs_n3 ? zs_n3 : 1), zs_n4, zs_t4 / (zs_n4 ? zs_n4 : 1), zs_n5, zs_t5 / (zs_n5 ? zs_n5 : 1));
         }
 #endif
         if (!lane_ok(s)) dq_undo(P, sh, s);  // the failed cycle leaves no records: a decommit it chained inline goes too
