@@ -1134,3 +1134,103 @@ def fuzz_workload(isa, n_instances=64, n_ops=96, seed=0xF022):
     wl.limits.update(max_far_frames=8, max_callstack_depth=32, heap_words=(ergs + 4096) // 32 + 2, stack_words=1 << 16, aux_heap_words=(ergs + 4096) // 32 + 2,
                      storage_slots=64, storage_journal=64)
     return wl
+
+
+def uniform_fuzz(isa, n_instances=128, n_ops=192, seed=0xF100):
+    """ONE random tape for every instance, per-instance registers and heaps: the lanes of a wave stay at one pc (what the cycle
+    kernel's short cycle needs) while everything data-dependent differs between them — condition flags (a conditional
+    instruction runs in some lanes and is a nop in others), operand values, heap offsets and alignments held in registers.
+    Light opcodes with register / immediate / code-page operands and heap / aux-heap accesses dominate; stack operands, a
+    fat-pointer-free mix of context reads and a few forward jumps ride along.  r1..r4 are address registers (small values:
+    only cursor set-ups and post-increments write them), so that an access rarely leaves the heap and a panic stays rare."""
+    wl = Workload("uniform_fuzz_%x" % seed, n_instances, n_ops)
+    rng = ScalarRng(seed)
+    ops = []
+    n_consts = 8
+
+    def cond():
+        return K.COND_ALWAYS if rng.below(10) < 6 else rng.below(8)
+
+    def src():
+        return rng.below(16)
+
+    def dst():
+        return 0 if rng.below(12) == 0 else 5 + rng.below(11)
+
+    def addr():
+        return 1 + rng.below(4)
+
+    while len(ops) < n_ops:
+        x = rng.below(100)
+        if x < 32:  # ALU, register / immediate / code-page operands
+            which = rng.below(7)
+            mode = (K.MODE_REG, K.MODE_REG, K.MODE_IMM, K.MODE_CODE)[rng.below(4)]
+            kw = dict(src0_mode=mode, cond=cond(), src0=src() if mode == K.MODE_REG else 0, src1=src(), dst0=dst(),
+                      imm0=(CONST_BASE + rng.below(n_consts + 2)) if mode == K.MODE_CODE else rng.below(1 << 16))
+            sf = rng.below(2)
+            if which == 0:
+                ops.append(isa.enc(K.OP_ADD, flags=sf, **kw))
+            elif which == 1:
+                ops.append(isa.enc(K.OP_SUB, flags=sf | (rng.below(2) << 1), **kw))
+            elif which == 2:
+                ops.append(isa.enc(K.OP_MUL, flags=sf, dst1=dst(), **kw))
+            elif which == 3:
+                ops.append(isa.enc(K.OP_DIV, flags=sf | (rng.below(2) << 1), dst1=dst(), **kw))
+            elif which == 4:
+                ops.append(isa.enc(K.OP_SHIFT, variant=rng.below(4), flags=sf | (rng.below(2) << 1), **kw))
+            else:
+                ops.append(isa.enc(K.OP_BINOP, variant=rng.below(3), flags=sf, **kw))
+        elif x < 70:  # heap / aux-heap accesses: immediate or register offsets, with and without post-increment
+            variant = (K.UMA_HEAP_READ, K.UMA_HEAP_WRITE, K.UMA_HEAP_READ, K.UMA_HEAP_WRITE, K.UMA_AUX_READ, K.UMA_AUX_WRITE)[rng.below(6)]
+            write = variant in (K.UMA_HEAP_WRITE, K.UMA_AUX_WRITE)
+            if rng.below(2):
+                a = addr()
+                inc = rng.below(2)
+                if write:
+                    ops.append(isa.enc(K.OP_UMA, variant=variant, src0_mode=K.MODE_REG, flags=inc, cond=cond(), src0=a, src1=src(), dst0=a if rng.below(4) else addr()))
+                else:
+                    d = dst()
+                    ops.append(isa.enc(K.OP_UMA, variant=variant, src0_mode=K.MODE_REG, flags=inc, cond=cond(), src0=a, dst0=d, dst1=a if rng.below(4) else addr()))
+            else:
+                y = rng.below(8)
+                off = 32 * rng.below(100) if y < 3 else (rng.below(3200) if y < 7 else 4000 + rng.below(300))  # (the last: across the bound paid for)
+                ops.append(isa.enc(K.OP_UMA, variant=variant, src0_mode=K.MODE_IMM, flags=0, cond=cond(), imm0=off, src1=src(), dst0=0 if write else dst()))
+        elif x < 80:  # cursor set-ups: a small per-lane value into an address register
+            a = addr()
+            ops.append(isa.enc(K.OP_BINOP, variant=K.BINOP_AND, src0_mode=K.MODE_IMM, imm0=(31, 63, 255, 1023)[rng.below(4)], src1=5 + rng.below(11), dst0=a))
+            if len(ops) < n_ops and rng.below(2):
+                ops.append(isa.enc(K.OP_ADD, src0_mode=K.MODE_IMM, imm0=32 * rng.below(64), src1=a, dst0=a))
+        elif x < 86:  # stack operands (the general path)
+            if rng.below(2):
+                ops.append(isa.enc(K.OP_ADD, dst0_mode=K.MODE_STACK_PP, cond=cond(), src0=src(), src1=src(), dst0=0, imm1=1))
+            else:
+                ops.append(isa.enc(K.OP_BINOP, variant=K.BINOP_XOR, src0_mode=K.MODE_STACK_OFF, src0=0, imm0=1 + rng.below(2), src1=src(), dst0=dst()))
+        elif x < 91:  # context reads
+            ops.append(isa.enc(K.OP_CONTEXT, variant=(K.CTX_THIS, K.CTX_CALLER, K.CTX_ERGS_LEFT, K.CTX_SP, K.CTX_META)[rng.below(5)], cond=cond(), dst0=dst()))
+        elif x < 95:
+            ops.append(isa.enc(K.OP_NOP, cond=cond()))
+        else:  # a forward jump over up to three instructions; one in three conditional (the lanes then part for a few cycles and meet again)
+            skip = rng.below(4)
+            target = len(ops) + 1 + skip
+            ops.append(isa.enc(K.OP_JUMP, src0_mode=K.MODE_IMM, imm0=target, cond=K.COND_ALWAYS if rng.below(3) else rng.below(8)))
+            for _ in range(skip):
+                ops.append(isa.enc(K.OP_ADD, src0=src(), src1=src(), dst0=dst()))
+    ops = ops[:n_ops] + [isa.enc(K.OP_NOP)] * 8
+    code = K.pack_code(ops)
+    assert len(code) < CONST_BASE
+    words = np.zeros((CONST_BASE + n_consts, 4), dtype="<u8")
+    words[: len(code)] = code
+    for k in range(n_consts):
+        words[CONST_BASE + k] = K.u256_from_int(_shaped_u256(rng))
+    wl.blobs.append(words)
+    wl.code_pages.append((0, n_instances, BOOTLOADER_CODE_PAGE, 0))
+    regs = np.zeros((n_instances, 15, 4), dtype="<u8")
+    for i in range(n_instances):
+        for k in range(15):
+            regs[i, k] = K.u256_from_int(_shaped_u256(rng))
+        for k in range(4):  # r1..r4: offsets inside the heap, every alignment
+            regs[i, k] = K.u256_from_int(rng.below(3000))
+    wl.states, wl.inner = initial_states(n_instances, regs, ergs=1 << 24)
+    wl.heaps = Xoshiro(seed ^ 0x4EA9, n_instances).words(HEAP_BYTES // 32)
+    wl.limits.update(max_far_frames=2, heap_words=320, stack_words=256, aux_heap_words=320, storage_slots=8, storage_journal=4)
+    return wl

@@ -1,6 +1,8 @@
 """One-off differential campaign: fuzz tapes (synth.fuzz_workload) through libzkw.so and the oracle for many seeds, lane
 widths and tape lengths, also with every light group forced onto the variant-group path, commitments included.
-   python profiles/tools/fuzz_campaign.py <first seed> <n seeds>        (prints one line per seed; exits 1 on a mismatch)"""
+   python profiles/tools/fuzz_campaign.py <first seed> <n seeds> [uniform]     (prints one line per seed; exits 1 on a mismatch)
+`uniform` (round 5): synth.uniform_fuzz instead — ONE random tape per workload, per-instance data: the waves stay at one pc and the
+cycle kernel's short cycle executes what qualifies; every third seed with the short cycle switched off (test hook)."""
 import os
 import sys
 import time
@@ -11,6 +13,7 @@ from era_zk_evm_amd import capi as K, synth  # noqa: E402
 from tests._oracle import load_oracle  # noqa: E402
 
 first, count = int(sys.argv[1], 0), int(sys.argv[2])
+UNIFORM = len(sys.argv) > 3 and sys.argv[3] == "uniform"
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import _metamorphic as M  # noqa: E402
 # round 4: every fourth seed under a renumbered, every fourth under an estranged ISA table (tests/_metamorphic.py)
@@ -26,7 +29,7 @@ for k in range(count):
     table = ("default", "renumbered", "default", "estranged")[k % 4]
     isa, prod, orc = CTX[table]
     prod.set_option(K.OPT_DEBUG_FLAGS, (1 << 24) if forced else 0)
-    wl = synth.fuzz_workload(isa, n_instances=512, n_ops=n_ops, seed=seed)
+    wl = synth.uniform_fuzz(isa, n_instances=(320, 512, 192)[k % 3], n_ops=2 * n_ops, seed=seed) if UNIFORM else synth.fuzz_workload(isa, n_instances=512, n_ops=n_ops, seed=seed)
     bo = orc.create_batch(wl); bo.reset(); bo.run(wl.n_cycles); bo.sync()
     wl.limits["lanes_per_wave"] = lanes
     bp = prod.create_batch(wl); bp.reset(); bp.run(wl.n_cycles); bp.sync()

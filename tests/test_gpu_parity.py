@@ -542,6 +542,35 @@ def test_reference_keccak_kats_through_the_helper_waves(product, isa, lanes):
         bp.destroy()
 
 
+@pytest.mark.parametrize("seed,lanes,hook", [(0xF100, 64, 0), (0xF101, 64, 0), (0xF102, 0, 0), (0xF103, 16, 0), (0xF104, 64, 0), (0xF105, 64, 0), (0xF100, 64, 1 << 24)])
+def test_uniform_fuzz_shared_tape(oracle, product, isa, seed, lanes, hook):
+    """One random tape for every instance, per-instance registers and heaps (synth.uniform_fuzz): the lanes of a wave stay
+    at one pc, so the cycle kernel's SHORT CYCLE executes what qualifies — ALU instructions with register / immediate /
+    code-page operands, mul, shifts, heap and aux-heap accesses at per-lane offsets and alignments, conditional
+    instructions that run in some lanes only, r0 destinations, dst0 == dst1 — and refuses, before it has written
+    anything, what does not (a growing heap, an exception in one lane, stack operands).  Every record and query of every
+    instance against the oracle; the last case runs the same tape with the short cycle switched off (test hook)."""
+    wl = synth.uniform_fuzz(isa, n_instances=320, n_ops=192, seed=seed)
+    bo = _run(oracle, wl)
+    if hook:
+        product.set_option(K.OPT_DEBUG_FLAGS, hook)
+    try:
+        bp = _run(product, wl, lanes)
+    finally:
+        if hook:
+            product.set_option(K.OPT_DEBUG_FLAGS, 0)
+    executed = 0
+    for i in range(wl.n_instances):
+        tp = bp.trace(i)
+        assert int(tp["status"]) != K.STATUS_LIMIT
+        ok, why = K.traces_equal(bo.trace(i), tp)
+        assert ok, "uniform fuzz %x instance %d (lanes=%d): %s" % (seed, i, lanes, why)
+        executed += len(tp["records"])
+    assert executed > 150 * wl.n_instances
+    assert np.array_equal(bo.commitments(), bp.commitments())
+    bo.destroy(); bp.destroy()
+
+
 @pytest.mark.parametrize("seed,lanes", [(0xF001, 64), (0xF002, 64), (0xF003, 16), (0xF004, 0)])
 def test_fuzz_tapes(oracle, product, isa, seed, lanes):
     """Every instance runs its own tape of random valid encodings (synth.fuzz_workload): all 64 lanes of a wave diverge
