@@ -192,6 +192,16 @@ def test_host_replay_on_gpu(oracle, product, isa):
         assert len(got) == len(logs[i]) and (got == logs[i]).all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [64, 0])
+def test_tracer_calls_replayed_from_the_delivery_ring_on_gpu(oracle, product, isa, lanes):
+    """The north star's boundary end to end on the device: steps of three different workloads delivered into the pinned ring by the
+    pack kernel, every instance's trace rebuilt from the ring and replayed through the host mirror of VmState::cycle: the ten
+    VmWitnessTracer callbacks, argument for argument, equal the calls the oracle's own cycle() made."""
+    from test_host_replay import build_replay_lib, check_tracer_calls_from_the_ring
+    check_tracer_calls_from_the_ring(oracle, product, build_replay_lib(), isa, ["cfg2", "cfg4", "cfg3"], host_threads=4, lanes=lanes)
+
+
 @pytest.mark.parametrize("cfg,kw", [(1, dict()), (2, dict(n_instances=320)), (4, dict(n_instances=128, n_cycles=512))])
 def test_generic_per_lane_path_forced(oracle, product, isa, cfg, kw):
     """ZKW_OPT_DEBUG_FLAGS = 4 disables the wave-uniform fast path: the fully per-lane decode must give the same bits."""

@@ -39,9 +39,13 @@ def oracle_callback_log(oracle, wl):
     return b, logs
 
 
-def replay_log(lib, backend_batch, wl, i):
-    t = K.InstanceTraceC()
-    backend_batch.be.call("batch_get_instance_trace", backend_batch.h, C.c_uint32(i), C.byref(t))
+def replay_log(lib, backend_batch, wl, i, trace=None):
+    """the host mirror's callback log for instance i: replayed from `trace` (a filled InstanceTraceC, e.g. one rebuilt from the
+    delivery ring) or from zkw_batch_get_instance_trace of `backend_batch`"""
+    t = trace
+    if t is None:
+        t = K.InstanceTraceC()
+        backend_batch.be.call("batch_get_instance_trace", backend_batch.h, C.c_uint32(i), C.byref(t))
     words = np.concatenate([np.zeros((0, 4), dtype="<u8")] + [np.ascontiguousarray(b, dtype="<u8").reshape(-1, 4) for b in wl.blobs]) if wl.blobs else np.zeros((1, 4), "<u8")
     first = np.zeros(len(wl.blobs) + 1, dtype=np.uint32)
     length = np.zeros(len(wl.blobs) + 1, dtype=np.uint32)
@@ -104,6 +108,38 @@ def test_replay_of_kernel_trace_equals_reference_calls(oracle, emu, replay_lib, 
     for i in range(wl.n_instances):
         got, rc = replay_log(replay_lib, be, wl, i)
         assert len(got) == len(logs[i]) and (got == logs[i]).all()
+
+
+def check_tracer_calls_from_the_ring(oracle, prod, replay_lib, isa, names, host_threads=2, lanes=None):
+    """The drop-in boundary end to end: steps run on the device, DELIVERED into the pinned ring (zkw_delivery_submit), every
+    instance's trace rebuilt from the ring (zkw_delivery_get_instance_trace) and replayed through the host mirror of
+    VmState::cycle — the ten VmWitnessTracer callbacks, argument for argument — against the calls the oracle's own cycle() made."""
+    wls = [CASES[n](isa) for n in names]
+    logs = [oracle_callback_log(oracle, CASES[n](isa))[1] for n in names]
+    bps = []
+    for wl in wls:
+        if lanes is not None:
+            wl.limits["lanes_per_wave"] = lanes
+        b = prod.create_batch(wl)
+        b.reset(); b.run(wl.n_cycles)
+        bps.append(b)
+    dv = K.Delivery(prod, 2, K.Delivery.worst_case_bytes(prod, bps), host_threads)
+    t = dv.submit(bps)
+    assert dv.wait(t)["overflow"] == 0
+    for bi, (wl, lg) in enumerate(zip(wls, logs)):
+        for i in range(wl.n_instances):
+            tr = K.InstanceTraceC()
+            prod.call("delivery_get_instance_trace", dv.h, C.c_uint32(t), C.c_uint32(bi), C.c_uint32(i), C.byref(tr))
+            got, rc = replay_log(replay_lib, None, wl, i, trace=tr)
+            assert len(got) == len(lg[i]) and (got == lg[i]).all(), (names[bi], i)
+    dv.release(t)
+    dv.close()
+    for b in bps:
+        b.destroy()
+
+
+def test_tracer_calls_replayed_from_the_delivery_ring_equal_reference_calls(oracle, emu, replay_lib, isa):
+    check_tracer_calls_from_the_ring(oracle, emu, replay_lib, isa, ["cfg2", "cfg4", "cfg3"])
 
 
 def test_replay_surfaces_reference_errors(oracle, replay_lib, isa):
