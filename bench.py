@@ -520,7 +520,7 @@ def measure(dev, prod, isa, args, rank, world, comm, collective, transport, with
             cy += int(tr["n_cycles"])
         heap_words = hw / max(1, cy)
         # untimed for the headline: the two host legs (N = 1: the link and the host cores are per box)
-        delivered = upload = upload_in_place = None
+        delivered = upload = upload_in_place = end_to_end = None
         if getattr(args, "host_legs", False) and world == 1 and rank == 0:
             try:
                 delivered = delivered_leg(dev, prod, flow, st)
@@ -531,6 +531,10 @@ def measure(dev, prod, isa, args, rank, world, comm, collective, transport, with
                 upload_in_place = upload_leg(dev, prod, flow, in_place=True)
             except Exception as e:  # noqa: BLE001
                 upload = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            try:
+                end_to_end = {"copying": end_to_end_leg(dev, prod, flow, st, in_place=False), "in_place": end_to_end_leg(dev, prod, flow, st, in_place=True)}
+            except Exception as e:  # noqa: BLE001
+                end_to_end = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         n_delta = float(st["reg_deltas"]) / max(1, cycles_per_step)
         # bytes the kernel has to move per VM cycle: code word + record tail + register deltas + queries + heap words
         # (the 512-B snapshot of SURVEY §8d is stored losslessly as a 16-B tail + 32 B per written register / per change of
@@ -562,7 +566,7 @@ def measure(dev, prod, isa, args, rank, world, comm, collective, transport, with
             "pcie_download_of_one_step": {"bytes": dl_bytes.value, "ms": dl_ms.value, "GBps": dl_bytes.value / max(dl_ms.value, 1e-9) / 1e6,
                                           "cycles_per_s_if_every_step_were_downloaded": cycles_per_step / (1e-3 * (dl_ms.value + ms_per_step))}, "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
             "kernel_cycles_per_s": cycles_per_step * batches_per_launch / (k_ms * 1e-3),
-            "delivered": delivered, "upload": upload, "upload_in_place": upload_in_place,
+            "delivered": delivered, "upload": upload, "upload_in_place": upload_in_place, "end_to_end": end_to_end,
             # cycle kernel + device-side expansion of the 512-byte snapshots back to back (cycle-major), on SURVEY 8d's literal bytes
             "snapshot_pipeline": ({"cycles_per_s": expand["snapshot_pipeline_cycles_per_s"], "ms_per_launch": expand["snapshot_pipeline_ms"], "batches_per_launch": expand["fused_batches"],
                                    "bytes_per_cycle": b_cycle_snapshot, "GBps": b_cycle_snapshot * expand["snapshot_pipeline_cycles_per_s"] / 1e9,
@@ -774,6 +778,108 @@ def upload_leg(dev, prod, flow, steps_min=20, in_place=False, pool_threads=16):
     return {"bytes_per_step": per_step, "GBps": per_step * steps / wall / 1e9, "cycles_per_s_with_fresh_inputs": steps * args.instances * cycles / wall, "steps": steps,
             "ms_per_step": 1e3 * wall / steps, "host_ms_per_step": 1e3 * t_host / steps, "host_threads": pool_threads, "in_place": in_place,
             "batches_per_restage_group": half}
+
+
+def end_to_end_leg(dev, prod, flow, st, in_place, steps_min=200, dfuse=None, n_slots=3, pool_threads=16):
+    """Both ends of the link at once — what a caller that REPLACES the reference's host loop gets: every step starts from fresh
+    VmLocalStates and heap images (zkw_batch_restage on a side stream: H2D, the device-side transpose and restore), runs, is
+    packed into the pinned ring (zkw_delivery_submit) and replayed on the host's cores (zkw_delivery_replay: every cycle of every
+    instance handed to a consumer).  H2D and D2H share the link, the restage calls and the replay share the host's cores.
+    A group is restaged only behind the replay of its previous use (its traces are rebuilt onto the inputs it ran from)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from era_zk_evm_amd import capi as K, synth
+    args, cycles = flow.args, flow.cycles
+    batches = flow.batches
+    if flow.wl.heaps is None or args.cfg not in (1, 2, 4):
+        return None
+    if dfuse is None:
+        dfuse = next(d for d in (5, 4, 8, 2, 1) if len(batches) % d == 0 or d == 1)
+    dfuse = max(1, min(dfuse, len(batches)))
+    glist = [batches[i:i + dfuse] for i in range(0, len(batches) - dfuse + 1, dfuse)]
+    n_g = len(glist)
+    if n_g <= n_slots:  # (a group's previous ticket must be consumed before it is restaged: more groups than ring slots)
+        n_slots = max(1, n_g - 1)
+    if dev.name != "gpu":
+        steps_min = 20
+    n_sub = max(2 * n_g, (max(steps_min, 3 * n_g * dfuse) + dfuse - 1) // dfuse)
+    sets = []
+    for k in range(2):
+        wl = synth.make(args.cfg, flow.isa, n_instances=args.instances, n_cycles=args.cycles, seed=0x5EED9000 + k)
+        sets.append((wl.states, wl.heaps))
+    cyc, inst = int(st["cycles"]), args.instances
+    per_batch = 16 * cyc + 32 * int(st["reg_deltas"]) + 44 * int(st["mem_queries"]) + 128 * int(st["log_queries"]) + 256 * int(st["aux_events"]) + 736 * inst + 64 * (inst // 8 + 64) + 16 * (cycles + 2) * (inst // 8 + 64)
+    slot_bytes = int(1.25 * per_batch * dfuse) + (1 << 20)  # (other register seeds than the counted run: a little more room)
+    threads = _host_threads()
+    dv = K.Delivery(prod, n_slots, slot_bytes, threads)
+    arrays = [prod.handle_array(g) for g in glist]
+    main = flow.main_stream
+    sides = [dev.stream() for _ in range(n_g)]
+    ev_ready = [dev.event() for _ in range(n_g)]
+    pool = ThreadPoolExecutor(max_workers=pool_threads)
+    views = {id(b): b.staging() for g in glist for b in g} if in_place else None
+
+    def restage(b, k, stream):
+        states, heaps = sets[k]
+        if in_place:
+            sv, hv = views[id(b)]
+            sv[:64] = states[:64]  # (the caller builds its inputs in the pinned staging: a token write stands for that work)
+            b.restage(sv, hv, stream)
+        else:
+            b.restage(states, heaps, stream)
+
+    flow.prepare()
+    dev.sync()
+    if in_place:
+        for g in glist:
+            for b in g:
+                sv, hv = views[id(b)]
+                sv[:] = sets[0][0]
+                hv[:] = sets[0][1]
+    tickets, infos, cycles_seen, t_host = {}, [], [0], [0.0]
+
+    def consume(it):
+        info = dv.wait(tickets[it])
+        n, _ = dv.replay(tickets[it])
+        cycles_seen[0] += n
+        dv.release(tickets[it])
+        infos.append(info)
+        del tickets[it]
+
+    flow.barrier()
+    t0 = time.perf_counter()
+    for it in range(n_sub):
+        g = it % n_g
+        if it >= n_slots:
+            consume(it - n_slots)
+        side = sides[g]
+        if it >= n_g:
+            assert (it - n_g) not in tickets  # consumed: its pack kernel has read the group's streams, its replay the group's inputs
+        t_h = time.perf_counter()
+        list(pool.map(lambda b: restage(b, (it // n_g) % 2, side.cuda_stream), glist[g]))
+        t_host[0] += time.perf_counter() - t_h
+        ev_ready[g].record(side)
+        main.wait_event(ev_ready[g])
+        prod.step_prepared_many(arrays[g], cycles, args.commit_mask, main.cuda_stream)
+        tickets[it] = dv.submit(arrays[g], main.cuda_stream)
+    for it in sorted(tickets):
+        consume(it)
+    dev.sync()
+    wall = time.perf_counter() - t0
+    pool.shutdown()
+    dv.close()
+    for g in range(flow.n_groups):
+        flow.pristine[g] = False
+        flow.waits_ready[g] = False
+    for g in glist:  # the workload's own inputs for whatever runs next
+        for b in g:
+            b.restage(flow.wl.states, flow.wl.heaps, main.cuda_stream)
+    dev.sync()
+    steps = n_sub * dfuse
+    d2h = sum(i["bytes"] for i in infos)
+    h2d = steps * args.instances * (K_VM_STATE_BYTES + 32 * sets[0][1].shape[1])
+    return {"cycles_per_s": cycles_seen[0] / wall, "steps": steps, "ms_per_step": 1e3 * wall / steps, "in_place": in_place, "d2h_GBps": d2h / wall / 1e9, "h2d_GBps": h2d / wall / 1e9,
+            "d2h_bytes_per_cycle": d2h / max(1, cycles_seen[0]), "h2d_bytes_per_cycle": h2d / max(1, cycles_seen[0]), "host_threads": threads, "restage_threads": pool_threads,
+            "host_restage_ms_per_step": 1e3 * t_host[0] / steps, "batches_per_delivery": dfuse, "ring_slots": n_slots, "cycles_delivered": cycles_seen[0]}
 
 
 K_VM_STATE_BYTES = 680

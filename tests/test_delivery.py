@@ -170,3 +170,59 @@ def test_restage_gives_fresh_inputs(oracle, emu, isa):
     with pytest.raises(K.ZkwError):
         b.restage(wl_b.states, wl_b.heaps[:, :7])  # another image length: geometry is fixed at upload
     bo.destroy(); b.destroy()
+
+
+def check_end_to_end_pipeline(oracle, prod, isa, n_instances, n_groups=3, per_group=2, iterations=7, host_threads=3, sample=None, streams=None):
+    """bench.py's `end_to_end` loop with every result checked: groups of batches are restaged with fresh inputs (two input sets
+    alternate), run, delivered into a ring with FEWER slots than groups and consumed two submissions later — every trace
+    rebuilt from the ring must equal the oracle's run of the inputs that iteration was given, i.e. neither a restage of the
+    group's next inputs nor the reuse of a ring slot may reach a ticket that is still being read."""
+    wl0 = synth.make(2, isa, n_instances=n_instances)
+    sets, refs = [], []
+    for k in range(2):
+        w = synth.make(2, isa, n_instances=n_instances, seed=0x5EED8800 + k)
+        sets.append((w.states, w.heaps))
+        wr = synth.make(2, isa, n_instances=n_instances)
+        wr.states, wr.heaps = w.states, w.heaps
+        bo = _run(oracle, wr)
+        bo.sync()
+        refs.append(bo)
+    groups = [[prod.create_batch(synth.make(2, isa, n_instances=n_instances)) for _ in range(per_group)] for _ in range(n_groups)]
+    n_slots = n_groups - 1
+    dv = K.Delivery(prod, n_slots, K.Delivery.worst_case_bytes(prod, groups[0]), host_threads)
+    pick = range(n_instances) if sample is None else sorted(set(i for i in sample if i < n_instances))
+    tickets = {}
+    main, sides, evs = (None, [None] * n_groups, None) if streams is None else streams
+
+    def consume(it):
+        t, k = tickets.pop(it)
+        assert dv.wait(t)["overflow"] == 0
+        for bi in range(per_group):
+            for i in pick:
+                ok, why = K.traces_equal(refs[k].trace(i), dv.trace(t, bi, i))
+                assert ok, "iteration %d batch %d instance %d: %s" % (it, bi, i, why)
+        n, _ = dv.replay(t)
+        assert n == per_group * n_instances * wl0.n_cycles
+        dv.release(t)
+
+    for it in range(iterations):
+        g, k = it % n_groups, (it // n_groups + it) % 2
+        if it >= n_slots:
+            consume(it - n_slots)
+        for b in groups[g]:
+            b.restage(sets[k][0], sets[k][1], None if sides[g] is None else sides[g].cuda_stream)
+        if evs is not None:
+            evs[g].record(sides[g])
+            main.wait_event(evs[g])
+        arr = prod.handle_array(groups[g])
+        prod.step_prepared_many(arr, wl0.n_cycles, 4, None if main is None else main.cuda_stream)
+        tickets[it] = (dv.submit(arr, None if main is None else main.cuda_stream), k)
+    for it in sorted(tickets):
+        consume(it)
+    dv.close()
+    for b in [b for g in groups for b in g] + refs:
+        b.destroy()
+
+
+def test_end_to_end_pipeline_restage_run_deliver_replay(oracle, emu, isa):
+    check_end_to_end_pipeline(oracle, emu, isa, n_instances=4)

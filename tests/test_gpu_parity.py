@@ -946,6 +946,19 @@ def test_traces_rebuilt_from_the_ring_equal_the_oracle(oracle, product, isa, nam
     assert info["pack_ms"] > 0
 
 
+def test_end_to_end_pipeline_on_the_device(oracle, product, isa):
+    """bench.py's `end_to_end` loop with every sampled result checked: fresh inputs restaged on side streams, the run and the pack
+    kernel on the main stream, a ring with fewer slots than groups, tickets consumed two submissions later — no restage and
+    no slot reuse reaches a ticket that is still being read (tests/test_delivery.py: check_end_to_end_pipeline)"""
+    import torch
+    from test_delivery import check_end_to_end_pipeline
+    main = torch.cuda.Stream()
+    sides = [torch.cuda.Stream() for _ in range(3)]
+    evs = [torch.cuda.Event() for _ in range(3)]
+    check_end_to_end_pipeline(oracle, product, isa, n_instances=200, n_groups=3, per_group=2, iterations=8, host_threads=6, sample=[0, 1, 63, 64, 127, 128, 199],
+                              streams=(main, sides, evs))
+
+
 def test_restage_gives_fresh_inputs_on_the_device(oracle, product, isa):
     """zkw_batch_restage on a side stream: new register files, scalars, callstack rows and heap images arrive by H2D copies from
     the batch's pinned staging, the restore follows on the same stream, the run on another one is ordered behind it by an event"""

@@ -200,4 +200,8 @@ def test_bench_host_legs_on_the_emulation_build(tmp_path, isa):
     assert "error" not in d and "error" not in u, (d, u)
     assert d["steps"] >= 20 and d["cycles_delivered"] == d["steps"] * 3 * 256 and d["host_threads"] == 3 and 60 < d["bytes_per_cycle"] < 400
     assert u["steps"] >= 20 and u["bytes_per_step"] == 3 * (680 + 32 * 256) and not u["in_place"] and ui["in_place"]
+    e = j["end_to_end"]
+    assert "error" not in e, e
+    for form in ("copying", "in_place"):  # fresh inputs, run, delivery and replay in one pipeline
+        assert e[form]["steps"] >= 20 and e[form]["cycles_delivered"] == e[form]["steps"] * 3 * 256 and e[form]["in_place"] == (form == "in_place")
     assert j["checked"]["instances_failed"] == 0
