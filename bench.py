@@ -69,11 +69,11 @@ def fill_defaults(args):
     if args.instances <= 0:
         args.instances = 512 if args.cfg == 3 else 4096
     if args.fuse <= 0:
-        args.fuse = 128 if args.cfg == 3 else 64
+        args.fuse = 256 if args.cfg == 3 else 64  # (cfg 3: 256 batches of 8 waves = two waves per SIMD)
     if args.commit_mask < 0:
         args.commit_mask = 0 if args.cfg == 3 else 4
     if args.cfg == 3 and args.streams <= 0:
-        args.streams = 1  # (128 batches of 8 waves fill the chip in one launch; nothing to pipeline beside it)
+        args.streams = 1  # (256 batches of 8 waves fill the chip in one launch; nothing to pipeline beside it)
     if args.streams <= 0:
         args.streams = 2
     return args
@@ -946,7 +946,9 @@ def cfg3_line(out, args, flow, prod, isa, value, elapsed, k_ms, k_ms_alone, batc
 OTHER_CONFIGS = [
     dict(label="configs[1] literal: 256 instances x 256 cycles, arithmetic (20 batches per launch)", cfg=1, instances=256, cycles=256, steps=20, warmup=20, fuse=20, streams=1, commit_mask=0),
     dict(label="configs[1] at 4096 instances x 256 cycles", cfg=1, instances=4096, cycles=256, steps=64, warmup=64, fuse=64, streams=1, commit_mask=0),
-    dict(label="configs[3]: 512 instances (one GPU's share), 128 batches per launch", cfg=3, instances=512, cycles=0, steps=128, warmup=128, fuse=128, streams=1, commit_mask=0),
+    # (256 batches = 2048 waves = two per SIMD: the scalar, branch and memory instructions of one wave then issue beside the other's integer
+    # stream — 585 -> 700 GB/s of message against 128 batches per launch, one wave per SIMD; profiles/r08_ab_log.txt)
+    dict(label="configs[3]: 512 instances (one GPU's share), 256 batches per launch", cfg=3, instances=512, cycles=0, steps=256, warmup=256, fuse=256, streams=1, commit_mask=0),
     dict(label="configs[4]: 4096 instances x 1024 cycles, all three queue commitments", cfg=4, instances=4096, cycles=1024, steps=32, warmup=16, fuse=16, streams=2, commit_mask=7),
 ]
 

@@ -32,7 +32,7 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o 
 i=0
 for A in "--cfg 1 --instances 256 --cycles 256 --steps 20 --warmup 20 --fuse 20 --streams 1 --commit-mask 0" \
          "--cfg 1 --instances 4096 --cycles 256 --steps 64 --warmup 64 --fuse 64 --streams 1 --commit-mask 0" \
-         "--cfg 3 --instances 512 --steps 128 --warmup 128 --fuse 128 --streams 1 --commit-mask 0" \
+         "--cfg 3 --instances 512 --steps 256 --warmup 256 --fuse 256 --streams 1 --commit-mask 0" \
          "--cfg 4 --instances 4096 --cycles 1024 --steps 32 --warmup 16 --fuse 16 --streams 2 --commit-mask 7"; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_oc$i -o $TAG -- python bench.py $A --no-cpu-baseline --min-warmup-s 0.2 > $OUT/trace_oc$i.log 2>&1
   grep '^{' $OUT/trace_oc$i.log >> $OUT/other_configs_traced.jsonl
@@ -52,7 +52,7 @@ python bench.py --cfg 4 --instances 4096 --cycles 1024 --steps 32 --warmup 16 --
 python bench.py --cfg 2 --steps 64 --warmup 32 --fuse 32 --commit-mask 7 --no-cpu-baseline 2>/dev/null | grep '^{' >> $OUT/other_cfgs.jsonl
 # BASELINE configs[3] (precompile-dominant, 512 instances = one GPU's share): its own bench line with roofline + cpu_baseline
 # from the traced process, a lone batch, and the kernel stats
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg3 -o $TAG -- python bench.py --cfg 3 --commit-mask 0 --fuse 128 --steps 256 --warmup 128 --streams 1 > $OUT/trace_cfg3.log 2>&1; grep '^{' $OUT/trace_cfg3.log > $OUT/cfg3_bench.json
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg3 -o $TAG -- python bench.py --cfg 3 --commit-mask 0 --fuse 256 --steps 256 --warmup 256 --streams 1 > $OUT/trace_cfg3.log 2>&1; grep '^{' $OUT/trace_cfg3.log > $OUT/cfg3_bench.json
 python bench.py --cfg 3 --commit-mask 0 --fuse 1 --steps 4 --warmup 2 --streams 1 --no-cpu-baseline 2>/dev/null | grep '^{' > $OUT/cfg3_lone_batch.json
 # ... the lone batch as a caller after latency runs it: 2 lanes per wave, keccak256 served by helper waves (second line of the file)
 python bench.py --cfg 3 --commit-mask 0 --fuse 1 --steps 8 --warmup 2 --streams 1 --lanes 2 --no-cpu-baseline 2>/dev/null | grep '^{' >> $OUT/cfg3_lone_batch.json
