@@ -133,10 +133,11 @@ __global__ void zkw_bucket_kernel(zkw_fused_table T) {
         const u64 m = __ballot(keep && b);
         same &= b ? m : ~m;
       }
-      if (keep) {
+      ZKW_DIV_IF(keep) {
         const u32 rank = (u32)__popcll(same & ((1ull << (tid & 63u)) - 1ull));
         const u32 before = s_count[tag];
         const u32 inst = wave * C.L + tag;
+        ZKW_LOCKSTEP();  // (every lane of a group has read the running count before the group's leader advances it)
         if (pass == 1u) {
           if (C.pooled) C.idx[(u64)wave * C.cap + s_off[tag] + before + rank] = p;
           else if (before + rank < C.per_instance_cap) C.idx[(u64)inst * C.per_instance_cap + before + rank] = p;

@@ -11,6 +11,17 @@
 #include "../../include/zkw.h"
 
 #define ZKW_WAVE 64            /* CDNA wavefront width */
+/* ZKW_WIDE: this translation unit runs on real 64-lane waves — the device pass, or the 64-lane CPU emulation of tests/emu
+ * (ZKW_EMU_WAVE == 64: every lane a fiber); not defined for the host pass and the one-lane emulation build */
+#if defined(__HIP_DEVICE_COMPILE__) || (defined(ZKW_EMU_WAVE) && ZKW_EMU_WAVE > 1)
+#define ZKW_WIDE 1
+#endif
+/* Divergence annotations (no-ops on the device; the 64-lane emulation takes its execution mask from them: zkw_kernels.hip) */
+#ifndef ZKW_DIV_IF
+#define ZKW_DIV_IF(c) if (c)
+#define ZKW_DIV_SCOPE ((void)0)
+#define ZKW_LOCKSTEP() ((void)0)
+#endif
 #define ZKW_WAVES_PER_GROUP 4   /* waves per workgroup of the cycle kernel: one per SIMD, sharing the LDS ISA table */
 #define ZKW_KRATE_WORDS 34     /* Keccak rate block (136 B) in dwords */
 #define ZKW_EC_SLOTS 12        /* 256-bit values of the ecrecover precompile's point arithmetic kept in the lane's scratch row */

@@ -41,6 +41,13 @@ typedef struct zkw_expand_args {
   u32 reserved;
 } zkw_expand_args;
 
+// rank of this lane among the set bits of a wave mask
+#ifdef __HIP_DEVICE_COMPILE__
+#define ZKW_X_RANK(part) __builtin_amdgcn_mbcnt_hi((u32)((part) >> 32), __builtin_amdgcn_mbcnt_lo((u32)(part), 0u))
+#else
+#define ZKW_X_RANK(part) ((u32)__popcll((part) & ((1ull << (threadIdx.x & 63u)) - 1ull)))
+#endif
+
 struct zkw_expand_lane {  // what a lane carries from cycle to cycle besides its LDS row
   u32 heap_bound, aux_bound, depth, timestamp, pc;
 };
@@ -140,7 +147,7 @@ __global__ void __launch_bounds__(ZKW_EXPAND_THREADS, 7) zkw_expand_kernel(zkw_e
   // the records a streaming thread writes: unit st % 32 of records st / 32 + 8 j (st = 0..255).  It keeps two numbers: up to
   // cycle `kmin` all eight of them exist (and are inside the requested range), from `kmax` on none does; in between — ragged
   // ends, a ranged call — the cycle counts are read again (eight registers more would spill in the stream loop)
-#ifdef __HIP_DEVICE_COMPILE__
+#ifdef ZKW_WIDE
   const u32 st = tid - 64u;  // (streaming threads: tid >= 64)
   u32 kmin = 0xffffffffu, kmax = 0;
 #pragma unroll
@@ -151,7 +158,7 @@ __global__ void __launch_bounds__(ZKW_EXPAND_THREADS, 7) zkw_expand_kernel(zkw_e
     kmax = n > kmax ? n : kmax;
   }
 #else
-  u32 ncyc_e[64];  // (single-thread emulation build)
+  u32 ncyc_e[64];  // (one-lane emulation build: the one thread does both)
   for (u32 l = 0; l < 64; l++) ncyc_e[l] = ncyc_s[l];
 #endif
   __syncthreads();
@@ -166,7 +173,7 @@ __global__ void __launch_bounds__(ZKW_EXPAND_THREADS, 7) zkw_expand_kernel(zkw_e
   const u32 time_delta = P.consts.time_delta_per_cycle;
   const uint4* tails = P.tails + (u64)wave * P.max_cycles * L + lane;
   const u32* dirw = P.dir + (u64)wave * (P.max_cycles + 1) * 4 + 3;  // word 3 of entry k: the delta cursor at the start of wave-cycle k
-#ifdef __HIP_DEVICE_COMPILE__
+#ifdef ZKW_WIDE
   if (first_wave) {
     // The applying wave is a software pipeline.  A load of this kernel returns microseconds later (the chip is writing at its
     // ceiling, reads queue behind the writes), and a cycle's delta positions need its tail (the mask) and its directory word:
@@ -195,7 +202,7 @@ __global__ void __launch_bounds__(ZKW_EXPAND_THREADS, 7) zkw_expand_kernel(zkw_e
     auto first_at = [&](u32 mask, u32 any, u32 pos) -> u32 {
       const u32 r = any ? (u32)__ffs((int)any) - 1u : 0u;
       const unsigned long long part = __ballot((mask >> r) & 1u);
-      const u32 at = pos + __builtin_amdgcn_mbcnt_hi((u32)(part >> 32), __builtin_amdgcn_mbcnt_lo((u32)part, 0u));
+      const u32 at = pos + ZKW_X_RANK(part);
       return at < nd1 ? at : nd1;
     };
     // Pipeline state at the top of cycle k: (tc, pc) tail and cursor of cycle k; (clo, chi) the first deltas of cycle k;
@@ -233,7 +240,7 @@ __global__ void __launch_bounds__(ZKW_EXPAND_THREADS, 7) zkw_expand_kernel(zkw_e
         const bool has = (mask >> r) & 1u;
         const unsigned long long part = __ballot(has ? 1 : 0);
         if (has) {
-          const u32 at = pos + __builtin_amdgcn_mbcnt_hi((u32)(part >> 32), __builtin_amdgcn_mbcnt_lo((u32)part, 0u));
+          const u32 at = pos + ZKW_X_RANK(part);
           if (at < n_delta) {
             uint4 lo = clo, hi = chi;
             if (!first) { lo = dl[at]; hi = dl[(u64)P.cap_delta + at]; }
@@ -266,7 +273,9 @@ __global__ void __launch_bounds__(ZKW_EXPAND_THREADS, 7) zkw_expand_kernel(zkw_e
 #undef ZKW_X_MASK
   } else {
     // stream the snapshots out: two whole records (2 x 512 contiguous bytes) per store instruction of a wave
+#ifdef __HIP_DEVICE_COMPILE__
     typedef unsigned int zkw_v4u __attribute__((ext_vector_type(4)));
+#endif
     const u32 rec0 = st >> 5, c = st & 31u;
     // (a thread's first record may lie in front of the requested range while its later ones are inside: the difference is signed)
     uint4* const out0 = dst + ((long long)(wave * L + rec0) - (long long)X.first) * (long long)(X.stride_i * 32u) + c;
@@ -277,7 +286,9 @@ __global__ void __launch_bounds__(ZKW_EXPAND_THREADS, 7) zkw_expand_kernel(zkw_e
 #pragma unroll
         for (u32 j = 0; j < 8; j++) {
           u32 rec = rec0 + 8u * j;
+#ifdef __HIP_DEVICE_COMPILE__
           asm volatile("" : "+v"(rec));  // (opaque: or the eight addresses of this rare path are computed in front of the loop and spilled)
+#endif
           const u32 ri = wave * L + rec;
           if (rec < L && ri < P.n_instances && ri >= X.first && ri - X.first < X.count && k < P.scalars[ri].n_cycles) m |= 1u << j;
         }
@@ -292,9 +303,13 @@ __global__ void __launch_bounds__(ZKW_EXPAND_THREADS, 7) zkw_expand_kernel(zkw_e
 #pragma unroll
       for (u32 j = 0; j < 8; j++) {
         if ((m >> j) & 1u) {
+#ifdef __HIP_DEVICE_COMPILE__
           zkw_v4u t;
           t.x = v[j].x; t.y = v[j].y; t.z = v[j].z; t.w = v[j].w;
           __builtin_nontemporal_store(t, (zkw_v4u*)(outk + j * step_j));
+#else
+          outk[j * step_j] = v[j];
+#endif
         }
       }
     }

@@ -35,6 +35,24 @@
 #include "zkw_u256.hip.h"
 #include "zkw_goldilocks.hip.h"
 
+// Divergence annotations.  A region that only some lanes of a wave enter AND that holds a cross-lane operation (a ballot, a
+// stream allocation, a readlane ...) is opened with ZKW_DIV_IF instead of `if`; a loop or function body that lanes leave
+// at different times and that holds one is wrapped in ZKW_DIV_SCOPE.  On the device both are nothing (`if` / empty: the
+// compiler's structurizer and the execution mask do the work); the 64-lane CPU emulation of tests/emu — every lane a
+// fiber — takes its execution mask from them (tests/emu/emu_simt.cpp) and aborts on a cross-lane operation that not
+// every active lane reaches, so a missing annotation is an error there, never a silent difference.
+// (defined in zkw_device.h; ZKW_LOCKSTEP() marks a place where the code relies on the lanes of a wave running in lockstep
+// through wave-shared memory: nothing on the device, a rendezvous of the lanes in the emulation.)
+
+// Test hook of the CPU emulation builds (tests/emu): lane-cycles by path, so that a test can assert that a tape really
+// went through the short cycle / a variant group.  Nothing in the product.
+#ifdef ZKW_EMU_BUILD
+extern "C" unsigned long long zkw_emu_path_counts[8];  // [0] short cycle, [1] ... of them heap / aux accesses, [2] general path, [3] ... of them in a variant group, [4] keccak256 calls served by helper waves, [5] decommits chained by helper waves
+#define ZKW_EMU_COUNT(i) (zkw_emu_path_counts[(i)]++)
+#else
+#define ZKW_EMU_COUNT(i) ((void)0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // per-lane execution context (lives in VGPRs; every helper below is force-inlined)
 // ---------------------------------------------------------------------------------------------
@@ -79,7 +97,7 @@ enum {
 #ifndef ZKW_EMU_BUILD
 #define ZKW_LDS_STRIDE ZKW_WAVE /* the same in the host pass: zkw_cycle_kernel_lds_bytes sizes the launch with it */
 #else
-#define ZKW_LDS_STRIDE 1 /* single-lane CPU emulation build (tests/emu) */
+#define ZKW_LDS_STRIDE ZKW_EMU_WAVE /* CPU emulation build (tests/emu): one-lane waves, or 64 on the SIMT engine */
 #endif
 // (the lane index goes through zkw_opaque at every access: a shared, long-lived address register would be the first
 // thing the allocator spills around the opcode switch — one v_lshl_add per access is cheaper than that reload)
@@ -159,6 +177,19 @@ ZD bool lane_ok(const Lane& s) { return s.status == ZKW_STATUS_RUNNING; }
 #else
 #define ZKW_LDS_WORD(p) ((volatile u32*)(p))
 #endif
+// An LDS location as a 32-bit byte address (the hand-over areas of the helper waves are addressed that way: the address
+// travels through LDS words and registers).  The emulation build's "LDS" is the array zkw_lds: the address is the offset.
+#ifdef __HIP_DEVICE_COMPILE__
+#define ZKW_LDS_ADDR(p) ((u32)(size_t)(__attribute__((address_space(3))) uint4*)(p))
+#define ZKW_LDS_AT(addr) ZKW_LDS_WORD((__attribute__((address_space(3))) u32*)(size_t)(addr))
+#define ZKW_SLEEP(n) __builtin_amdgcn_s_sleep(n)
+#else
+#define ZKW_LDS_ADDR(p) ((u32)((const char*)(p) - (const char*)zkw_lds))
+#define ZKW_LDS_AT(addr) ZKW_LDS_WORD((char*)zkw_lds + (addr))
+#define ZKW_SLEEP(n) ZKW_EMU_YIELD() /* a waiting wave hands the processor to the other waves of the workgroup */
+#endif
+ZD u32 zkw_lds_get(u32 addr) { return *ZKW_LDS_AT(addr); }
+ZD void zkw_lds_put(u32 addr, u32 v) { *ZKW_LDS_AT(addr) = v; }
 // the four stream cursors of a wave in one volatile 16-byte LDS read
 #ifdef __HIP_DEVICE_COMPILE__
 ZD uint4 zkw_lds_read4(const u32* p) {
@@ -326,14 +357,16 @@ ZD u32 stream_alloc(u32*) {
                : "scc");
   return base + zkw_rank_below(mask);
 }
-#else
+#else  // CPU emulation build: the cursors are scalar registers of the emulated wave (tests/emu/hip/hip_runtime.h)
 template <int WHICH>
-ZD u32 stream_alloc(u32* cursors) {
+ZD u32 zkw_cursor_get() { return zkw_emu_wave_sregs()[WHICH]; }
+template <int WHICH>
+ZD void zkw_cursor_set(u32 v) { zkw_emu_wave_sregs()[WHICH] = v; }  // (wave-uniform value: every active lane writes the same)
+template <int WHICH>
+ZD u32 stream_alloc(u32*) {
   const u64 mask = zkw_ballot(1);
-  const u32 rank = zkw_rank_below(mask);
-  const u32 base = *ZKW_LDS_WORD(cursors + WHICH);
-  if (rank == 0) *ZKW_LDS_WORD(cursors + WHICH) = base + (u32)__popcll(mask);
-  return base + rank;
+  const u32 base = ZKW_EMU_FETCH_ADD(WHICH, (u32)__popcll(mask));  // one read-and-advance for the wave
+  return base + zkw_rank_below(mask);
 }
 #endif
 
@@ -473,7 +506,9 @@ ZKW_CFV_EMU(heap_hwm, CF_HEAP_HWM)
 #else
 #define ZKW_PIN_SGPR(x) ((void)0)
 #endif
+#ifndef ZKW_EMU_BUILD
 extern __shared__ uint4 zkw_lds[];
+#endif  // (the emulation build's stand-in header declares the segment)
 // dynamic LDS of a workgroup, in 16-byte units: ISA table | 256-byte sink of the prefetches (prefetch_page_words; kept below
 // 64 KB whatever the workgroup size) | one area per cycle wave | the hand-over areas of the helper waves
 #define ZKW_LDS_SINK_UNITS 16u
@@ -667,8 +702,18 @@ struct RegFile {
 ZD u256 rf_get(const RegFile& rf, u32 reg) { return rf.r[reg]; }
 ZD void rf_set(RegFile& rf, u32 reg, const u256& v) { rf.r[reg] = v; }
 ZD void rf_init(RegFile& rf) { rf.r[0] = u256_zero(); }
+#ifdef ZKW_WIDE  // the 64-lane emulation forms variant groups: zkw_vec_exec reaches the lane's register file through a pointer
+struct RegFileVec {
+  RegFile* f;
+};
+#define ZKW_RF_IS_VEC(RF) (std::is_same<RF, RegFileVec>::value)
+ZD u256 rf_get(const RegFileVec& rf, u32 reg) { return rf.f->r[reg & 15u]; }  // (the register number is the lane's own: no waterfall to emulate)
+ZD void rf_set(RegFileVec& rf, u32 reg, const u256& v) { rf.f->r[reg & 15u] = v; }
+static RegFile* zkw_emu_rf_ptr[ZKW_WAVE * 2 * ZKW_MAX_WAVES_PER_GROUP];  // [thread of the workgroup] -> the register file in its kernel frame
+#else
 typedef RegFile RegFileVec;  // (the single-lane emulation build never forms a variant group)
 #define ZKW_RF_IS_VEC(RF) false
+#endif
 #endif
 template <class RF>
 ZD u256 reg_read(Shared& sh, const RF& rf, const Lane& s, u32 idx, u32& is_ptr) {
@@ -1286,6 +1331,7 @@ ZD void op_context(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, cons
 // ptr.rs:6-194
 template <class RF>
 ZD void op_ptr(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pre& ps) {
+  ZKW_DIV_SCOPE;  // (lanes return early with a pending exception; the others may emit a stack write below)
   s.pc = ps.new_pc;
   const u32 v = ZKW_ATTR_VARIANT(d.attr);
   if (!ps.src0_ptr || ps.src1_ptr) {  // :35-45
@@ -1466,7 +1512,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   ZKW_SUB(70)  // drain of the stores issued before this point
 #endif
-  if (ZKW_LIKELY(!skip)) {  // :265-288
+  ZKW_DIV_IF(ZKW_LIKELY(!skip)) {  // :265-288
     // both word loads are issued before the first query is emitted: the emission needs the loaded value, so reading
     // and emitting word by word would serialise two memory round trips (the dominant cost of this opcode)
     if (is_ptr_read) {
@@ -1481,7 +1527,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
 #endif
     emit_mem(P, sh, s, ts_r, mem_type, fp.page, word0, w0v, false, false, 0);
     ZKW_SUB(66)  // first read query
-    if (unaligned) emit_mem(P, sh, s, ts_r, mem_type, fp.page, word1, w1v, false, false, 0);
+    ZKW_DIV_IF(unaligned) emit_mem(P, sh, s, ts_r, mem_type, fp.page, word1, w1v, false, false, 0);
   }
   ZKW_SUB(42)  // word reads + read queries
   // A wave whose lanes all access at a word boundary (a shared tape with an immediate or a common cursor: half of cfg 2's
@@ -1518,7 +1564,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
       result = u256_select_bits(u256_low_mask(beyond * 8), u256_zero(), result);  // the low `beyond` bytes read as zero
     }
     ZKW_SUB(43)  // read: shifts
-    if (ZKW_LIKELY(!set_panic)) {
+    ZKW_DIV_IF(ZKW_LIKELY(!set_panic)) {
       dst0_update(P, sh, rf, s, ps.dst0, d.dst0, result, false);
       if (increment) {
         u256 upd = ps.src0;
@@ -1553,10 +1599,10 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
       n1 = u256_or(n1, u256_shl(ps.src1, (32 - unal) * 8));
     }
     ZKW_SUB(45)  // write: shifts
-    if (ZKW_LIKELY(!skip)) {
+    ZKW_DIV_IF(ZKW_LIKELY(!skip)) {
       heap_write_at(P, sh, s, !is_heap, f_slot, f_hwm, word0, n0);
       emit_mem(P, sh, s, ts_w, mem_type, fp.page, word0, n0, false, true, 0);
-      if (unaligned) {
+      ZKW_DIV_IF(unaligned) {
         heap_write_at(P, sh, s, !is_heap, f_slot, f_hwm, word1, n1);
         emit_mem(P, sh, s, ts_w, mem_type, fp.page, word1, n1, false, true, 0);
       }
@@ -1565,7 +1611,7 @@ ZD void op_uma(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, const Pr
       if (is_heap) cfv_set_heap_hwm(sh, s, f_hwm); else CF(sh, s, CF_AUX_HWM) = f_hwm;
     }
     ZKW_SUB(46)  // write: heap writes + write queries
-    if (ZKW_LIKELY(!set_panic)) {
+    ZKW_DIV_IF(ZKW_LIKELY(!set_panic)) {
       if (increment) {
         u256 upd = ps.src0;
         upd.w[0] = incremented;
@@ -1593,6 +1639,7 @@ ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q);
 // callee-saved registers with the precompile call; the variant checks below then fold away
 template <int KIND>
 ZD void op_log(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, HeavyOut& out) {
+  ZKW_DIV_SCOPE;  // (lanes return early — not enough ergs, a failed storage probe — while the others emit their query)
   const u32 v = ZKW_ATTR_VARIANT(d.attr);
   if (KIND == 0 && !(v == ZKW_LOG_STORAGE_READ || v == ZKW_LOG_STORAGE_WRITE)) return;
   if (KIND == 1 && !(v == ZKW_LOG_EVENT || v == ZKW_LOG_TO_L1)) return;
@@ -1690,11 +1737,16 @@ ZD void versioned_hash(const u256& h, bool& ok, u32& marker, u32& len_words, u25
 }
 
 // takes back the decommit this cycle chained into the running commitment (the cycle failed behind it: see op_far_call)
-#ifdef __HIP_DEVICE_COMPILE__
+#ifdef ZKW_WIDE
 // LDS byte address of this wave's hand-over area to the helper wave (0: no helper in this launch); kept in the first
 // dword of the wave's LDS header, which the device build does not use otherwise (the stream cursors live in v128)
+#ifdef __HIP_DEVICE_COMPILE__
 ZD u32 dq_helper_area(const Shared& sh) { return *ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor); }
 ZD u32 kh_box(const Shared& sh) { return *ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor + 1); }
+#else
+ZD u32 dq_helper_area(const Shared& sh) { return *ZKW_LDS_WORD(sh.cursor); }
+ZD u32 kh_box(const Shared& sh) { return *ZKW_LDS_WORD(sh.cursor + 1); }
+#endif
 #endif
 ZD void dq_undo(ZKW_KP P, const Shared& sh, Lane& s) {
   if (!(s.kflags & KF_DQ_CHAINED)) return;
@@ -1709,6 +1761,7 @@ ZD void dq_undo(ZKW_KP P, const Shared& sh, Lane& s) {
 
 // far_call.rs:35-613
 ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, const u256& r15, HeavyOut& out) {
+  ZKW_DIV_SCOPE;  // (lanes return early on a failed probe / an unknown code hash / no arena slot left)
   const zkw_isa_consts ZKW_CONST_AS& K = P.consts;
   const u32 variant = ZKW_ATTR_VARIANT(d.attr);
   s.flags &= FLAG_PENDING;  // :69
@@ -1736,7 +1789,7 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
   const u32 new_base = CF(sh, s, CF_MPC);  // :118
   u256 code_hash;
   bool map_to_trivial;
-  if (new_code_shard != 0 && !P.props.zkporter_is_available) {  // :123-129
+  ZKW_DIV_IF(new_code_shard != 0 && !P.props.zkporter_is_available) {  // :123-129
     code_hash = u256_zero();
     map_to_trivial = true;
   } else {
@@ -1853,7 +1906,7 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
     after_decommit = after_growth;
   }
   u32 mapped_code_page = K.unmapped_page, mapped_blob = 0;  // UNMAPPED_PAGE (:162,439)
-  if (exceptions) {  // :435-439
+  ZKW_DIV_IF(exceptions) {  // :435-439
     s.flags |= FLAG_PENDING;
   } else {  // :441-455 decommit (helpers.rs:164-194 + SimpleDecommitter decommitter.rs:32-98)
     // known_hashes.get(&hash) (decommitter.rs:52-56): open addressing over the code hashes (built at upload, zkw_pre_hash),
@@ -1899,18 +1952,18 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
       a[2] = u256_hi4(code_hash);
       a[3] = make_uint4(pre, 0, 0, 0);  // preimage index: selects the cached sponge midstate of this code hash (zkw_commit.hip)
     }
-#ifdef __HIP_DEVICE_COMPILE__
+#ifdef ZKW_WIDE
     if (a && P.commit_out && (sh.debug_flags & 16u) && (sh.debug_flags & ZKW_DQ_HELPER)) {
       // The workgroup has a helper wave (zkw_dq_helper): the decommit is handed over through LDS instead of being
       // chained here, where its permutation (~80k clocks for a lone wave) sits on this wave's critical path.  The record
       // goes into the slot the wave posts next; it becomes valid at the end of the cycle, if the cycle completes.
       const u32 area = dq_helper_area(sh);
-      u32 posted = *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)area);
-      while (posted - *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(area + 4u)) >= 2u) __builtin_amdgcn_s_sleep(8);  // both slots still with the helper
+      u32 posted = *ZKW_LDS_AT(area);
+      while (posted - *ZKW_LDS_AT(area + 4u) >= 2u) ZKW_SLEEP(8);  // both slots still with the helper
       const u32 row = area + 16u + (posted & 1u) * 768u + zkw_lane_id() * 4u;
-      *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)row) = pre | ((fresh ? 1u : 0u) << 30);  // (bit 31 = valid: set at the end of the cycle)
-      *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(row + 256u)) = s.timestamp + 1;
-      *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(row + 512u)) = page;
+      *ZKW_LDS_AT(row) = pre | ((fresh ? 1u : 0u) << 30);  // (bit 31 = valid: set at the end of the cycle)
+      *ZKW_LDS_AT(row + 256u) = s.timestamp + 1;
+      *ZKW_LDS_AT(row + 512u) = page;
       s.kflags |= KF_DQ_CHAINED;
     } else
 #endif
@@ -2036,6 +2089,7 @@ ZD void op_far_call(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& 
 
 // ret.rs:9-265
 ZD void op_ret(ZKW_KP P, Shared& sh, Lane& s, const Decoded& d, const Pre& ps, HeavyOut& out) {
+  ZKW_DIV_SCOPE;
   const zkw_isa_consts ZKW_CONST_AS& K = P.consts;
   u32 variant = ZKW_ATTR_VARIANT(d.attr);
   s.flags &= FLAG_PENDING;  // :27
@@ -2213,7 +2267,7 @@ static __device__ __noinline__ zkw_v16 zkw_precompile_keccak(zkw_v16 a, zkw_v16 
 static __device__ __noinline__ zkw_v16 zkw_precompile_sha(zkw_v16 a, zkw_v16 b) { return zkw_precompile_body<1>(a, b); }
 static __device__ __noinline__ zkw_v16 zkw_precompile_ec(zkw_v16 a, zkw_v16 b) { return zkw_precompile_body<2>(a, b); }
 
-#ifdef __HIP_DEVICE_COMPILE__
+#ifdef ZKW_WIDE
 // `count` consecutive positions of the memory-query stream for every active lane (stream_alloc: one).  A lane whose
 // positions would not fit below `cap` takes none and gets ~0.
 ZD u32 stream_alloc_counted(u32 count, u32 cap) {
@@ -2235,6 +2289,7 @@ ZD u32 stream_alloc_counted(u32 count, u32 cap) {
 // own), allocates the stream positions and the sequence numbers of the input reads — its later records then follow
 // them, in the order the reference emits — posts the request in its row of the mailbox and waits for the digest.
 ZD void keccak_request(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
+  ZKW_DIV_SCOPE;  // (a lane that fails leaves early; the others wait for their digests and write them)
   const u32 in_off = q.key.w[0], in_len = q.key.w[1], out_off = q.key.w[2];
   const u32 page_r = q.key.w[4], page_w = q.key.w[5];
   const u32 n_words = in_len ? ((in_off & 31u) + in_len + 31u) >> 5 : 0u;
@@ -2252,7 +2307,11 @@ ZD void keccak_request(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the heap words this wave has stored are what the helper reads
   const u32 row = kh_box(sh) + zkw_lane_id() * 64u;
+#ifdef __HIP_DEVICE_COMPILE__
   ZKW_LDS_AS u32* rw = (ZKW_LDS_AS u32*)(size_t)row;
+#else
+  u32* rw = (u32*)((char*)zkw_lds + row);
+#endif
   *ZKW_LDS_WORD(rw + 1) = in_off;
   *ZKW_LDS_WORD(rw + 2) = in_len;
   *ZKW_LDS_WORD(rw + 3) = fp.hwm;
@@ -2262,7 +2321,10 @@ ZD void keccak_request(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   *ZKW_LDS_WORD(rw + 7) = page_r;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   *ZKW_LDS_WORD(rw) = 0x80000000u | fp.slot | (fp.is_aux ? 1u << 16 : 0u) | (fp.empty ? 1u << 17 : 0u);
-  while (*ZKW_LDS_WORD(rw) >> 31) __builtin_amdgcn_s_sleep(1);
+  {
+    ZKW_DIV_SCOPE;  // (the digests of the lanes arrive one by one)
+    while (*ZKW_LDS_WORD(rw) >> 31) ZKW_SLEEP(1);
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   u256 digest;
 #pragma unroll
@@ -2280,10 +2342,10 @@ ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   if (addr_low == P.consts.keccak_precompile_address) which = 0;
   else if (addr_low == P.consts.sha256_precompile_address) which = 1;
   else if (addr_low == P.consts.ecrecover_precompile_address) which = 2;
-#ifdef __HIP_DEVICE_COMPILE__
+#ifdef ZKW_WIDE
   // (lengths near 2^32 — no real call: the stream capacity ends it — keep the one path whose arithmetic on them the oracle
   // is checked against; the helper's block count must stay bounded by the positions the requester could allocate)
-  if (which == 0 && (sh.debug_flags & ZKW_KECCAK_HELPER) && q.key.w[1] < 0x40000000u) {
+  ZKW_DIV_IF(which == 0 && (sh.debug_flags & ZKW_KECCAK_HELPER) && q.key.w[1] < 0x40000000u) {
     keccak_request(P, sh, s, q);
     which = 3;
   }
@@ -2291,7 +2353,7 @@ ZD void call_precompile(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   // anything else behaves as an unknown precompile: no memory traffic.  The lanes of a group may call different
   // precompiles (the address is per lane): one call per kind present.
   for (u32 k = 0; k < 3; k++) {
-    if (which == k) {
+    ZKW_DIV_IF(which == k) {
       zkw_v16 pa = lane_pack(s), pb;
       pa[12] = k; pa[13] = q.timestamp;
 #pragma unroll
@@ -2390,7 +2452,7 @@ static __device__ __noinline__ zkw_v16 zkw_heavy_ret(zkw_v16 a, zkw_v16 b) { ret
 template <class RF>
 ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bool vec, u32 vec_lo, u32 vec_hi);
 static __device__ __noinline__ zkw_v16 zkw_vec_exec(zkw_v16 a, zkw_v16 b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(ZKW_WIDE)
   const u32 wib = zkw_uniform(threadIdx.x / ZKW_WAVE);
   const uint4 hdr = *(zkw_lds + ZKW_LDS_WAVES0 + wib * zkw_wave_lds_units() + 1);  // written by the kernel prologue
   const zkw_kparams ZKW_CONST_AS* Pp = (const zkw_kparams ZKW_CONST_AS*)(((u64)zkw_uniform(hdr.y) << 32) | zkw_uniform(hdr.x));
@@ -2407,6 +2469,9 @@ static __device__ __noinline__ zkw_v16 zkw_vec_exec(zkw_v16 a, zkw_v16 b) {
   d.cond = (lo >> 13) & 7u; d.src0 = (lo >> 16) & 15u; d.src1 = (lo >> 20) & 15u; d.dst0 = (lo >> 24) & 15u; d.dst1 = lo >> 28;
   d.imm0 = hi & 0xffffu; d.imm1 = hi >> 16;
   RegFileVec rf;
+#ifdef ZKW_EMU_BUILD
+  rf.f = zkw_emu_rf_ptr[threadIdx.x];
+#endif
   exec_decoded(P, sh, rf, s, d, false, 0u, 0u);
   s.lane = zkw_lane_id();
   return lane_pack(s);
@@ -2538,7 +2603,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
   // apply (opcodes/parsing.rs:47-79)
   // ----------------------------------------------------------------------------------------
   ZKW_SUB(40)  // operands
-  if (ZKW_LIKELY(lane_ok(s))) {
+  ZKW_DIV_IF(ZKW_LIKELY(lane_ok(s))) {
     switch (opcode) {
       case ZKW_OP_NOP: s.pc = ps.new_pc; break;  // noop.rs:16-19
       case ZKW_OP_ADD:
@@ -2633,7 +2698,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
   if constexpr (!IS_VEC) {
   const bool out_of_line = vec || opcode == ZKW_OP_LOG || opcode == ZKW_OP_NEAR_CALL || opcode == ZKW_OP_FAR_CALL || opcode == ZKW_OP_RET;  // wave-uniform
   if (ZKW_UNLIKELY(out_of_line))
-  if (ZKW_UNLIKELY(call_out)) {
+  ZKW_DIV_IF(ZKW_UNLIKELY(call_out)) {
     zkw_v16 oa = lane_pack(s), ob;
 #pragma unroll
     for (int i = 0; i < 16; i++) ob[i] = 0;
@@ -2669,7 +2734,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
 #pragma unroll
         for (int i = 0; i < 8; i++) v1.w[i] = ZKW_XFER(sh, s, i);
       }
-      if (action & ZKW_ACT_DST0) dst0_update(P, sh, rf, s, ps.dst0, d.dst0, v1, false);
+      ZKW_DIV_IF(action & ZKW_ACT_DST0) dst0_update(P, sh, rf, s, ps.dst0, d.dst0, v1, false);
       if (action & ZKW_ACT_FAR) {  // far_call.rs:573-610, in the reference's order; the conventions are table constants (indices into `registers`: r1 = 0)
         const u32 cr = P.consts.call_regs, rg = P.consts.call_ranges;
         reg_write(sh, rf, s, (cr & 0xffu) + 1u, v1, true);                            // CALL_IMPLICIT_CALLDATA_FAT_PTR_REGISTER
@@ -2737,7 +2802,7 @@ ZD void lane_writeback(ZKW_KP P, Shared& sh, const RegFile& rf, Lane& s, u32 com
   }
 }
 
-#ifdef __HIP_DEVICE_COMPILE__
+#ifdef ZKW_WIDE
 // The helper wave of a workgroup (zkw_launch_args.helpers): chains the decommit-queue commitment for the cycle waves of
 // its workgroup.  A far call that decommits posts (preimage, timestamp | fresh, page) per lane into a two-slot ring in
 // LDS (op_far_call, end of cycle); this wave takes the slots in order — lane l serves lane l of the posting wave: one
@@ -2762,8 +2827,6 @@ ZD bool zkw_find_wave(const zkw_launch_args& A, u32 gw, u32& b, u32& wave) {
   }
   return true;
 }
-ZD u32 zkw_lds_get(u32 addr) { return *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)addr); }
-ZD void zkw_lds_put(u32 addr, u32 v) { *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)addr) = v; }
 
 // one look at the hand-over area of a cycle wave: 0 = nothing posted and the wave still cycles, 1 = one slot served,
 // 2 = nothing posted and the wave has left its loop
@@ -2786,6 +2849,7 @@ ZD u32 zkw_dq_serve(ZKW_KP P, u32 wave, u32 area, u32& consumed, u32 tid) {
     gl_chain_step(P.commit_rc, leaf, tail, (u64)j + 1, ZKW_QUEUE_DECOMMIT, (u64)ts | ((u64)fresh << 32), (u64)page);
     tail_p[0] = tail[0]; tail_p[1] = tail[1]; tail_p[2] = tail[2]; tail_p[3] = tail[3];
     P.dq_count[inst] = j + 1;
+    ZKW_EMU_COUNT(5);
   }
   zkw_lds_put(row, 0);  // the entry is empty again (a lane that has left its loop never rewrites it)
   consumed++;
@@ -2795,7 +2859,7 @@ ZD u32 zkw_dq_serve(ZKW_KP P, u32 wave, u32 area, u32& consumed, u32 tid) {
 
 ZD void zkw_dq_helper(const zkw_launch_args& A, u32 tid) {
   const u32 g = A.waves_per_group;
-  const u32 area0 = (u32)(size_t)(ZKW_LDS_AS uint4*)(zkw_lds + ZKW_LDS_WAVES0 + g * zkw_wave_lds_units());
+  const u32 area0 = ZKW_LDS_ADDR(zkw_lds + ZKW_LDS_WAVES0 + g * zkw_wave_lds_units());
   u32 consumed[ZKW_MAX_WAVES_PER_GROUP];
 #pragma unroll
   for (int h = 0; h < ZKW_MAX_WAVES_PER_GROUP; h++) consumed[h] = 0;
@@ -2811,7 +2875,7 @@ ZD void zkw_dq_helper(const zkw_launch_args& A, u32 tid) {
       if (zkw_dq_serve(P, wave, area0 + (u32)h * ZKW_DQ_HELPER_BYTES, consumed[h], tid) != 2u) all_done = false;
     }
     if (all_done) break;
-    __builtin_amdgcn_s_sleep(32);
+    ZKW_SLEEP(32);
   }
 }
 
@@ -2931,6 +2995,7 @@ ZD void zkw_kh_serve(ZKW_KP P, u32 wave, u32 box, u32 r, u32 tid) {
   }
   if (idx < 4u) zkw_lds_put(row + 32u + (7u - 2u * idx - h) * 4u, __builtin_bswap32(st));  // digest = state words 0..3, big-endian (as precompile_keccak256 writes it)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (tid == 0) ZKW_EMU_COUNT(4);
   if (tid == 0) zkw_lds_put(row, 0);  // served
 }
 
@@ -2942,7 +3007,7 @@ ZD void zkw_kh_helper(const zkw_launch_args& A, u32 tid, u32 h, u32 sub, u32 n_s
   if (!zkw_find_wave(A, blockIdx.x * g + h, b, wave)) return;
   ZKW_KP P = *(const zkw_kparams ZKW_CONST_AS*)A.kp[b];
   if (wave >= P.n_waves) return;
-  const u32 area0 = (u32)(size_t)(ZKW_LDS_AS uint4*)(zkw_lds + ZKW_LDS_WAVES0 + g * zkw_wave_lds_units());
+  const u32 area0 = ZKW_LDS_ADDR(zkw_lds + ZKW_LDS_WAVES0 + g * zkw_wave_lds_units());
   const u32 area = area0 + h * ZKW_DQ_HELPER_BYTES, box = area0 + g * ZKW_DQ_HELPER_BYTES + h * ZKW_KH_BYTES;
   u32 consumed = 0;
   for (;;) {
@@ -2955,10 +3020,10 @@ ZD void zkw_kh_helper(const zkw_launch_args& A, u32 tid, u32 h, u32 sub, u32 n_s
     if (sub == 0) {
       const u32 st = zkw_dq_serve(P, wave, area, consumed, tid);
       if (st == 2u) break;  // (a wave that has left its loop has no request pending: the requester waits for its digest)
-      if (st == 0u) __builtin_amdgcn_s_sleep(2);
+      if (st == 0u) ZKW_SLEEP(2);
     } else {
       if (zkw_lds_get(area + 8u)) break;
-      __builtin_amdgcn_s_sleep(2);
+      ZKW_SLEEP(2);
     }
   }
 }
@@ -3015,7 +3080,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
 #ifdef ZKW_WAITPROF
   for (u32 i = threadIdx.x; i < ZKW_MAX_WAVES_PER_GROUP * 32; i += blockDim.x) (&zw_acc[0][0])[i] = 0;
 #endif
-#ifdef __HIP_DEVICE_COMPILE__
+#ifdef ZKW_WIDE
   if (is_helper) {  // counters and entries of every hand-over area start empty (before the barrier: the cycle waves post after it)
     u32* area = (u32*)(zkw_lds + ZKW_LDS_WAVES0 + A.waves_per_group * zkw_wave_lds_units());
     const u32 per_wave = (ZKW_DQ_HELPER_BYTES + ((A.debug_flags & ZKW_KECCAK_HELPER) ? ZKW_KH_BYTES : 0u)) / 4u;
@@ -3023,7 +3088,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
   }
 #endif
   __syncthreads();
-#ifdef __HIP_DEVICE_COMPILE__
+#ifdef ZKW_WIDE
   if (is_helper) {
     if (A.debug_flags & ZKW_KECCAK_HELPER) {
       const u32 n_sub = A.helpers / A.waves_per_group, hx = wib - A.waves_per_group;
@@ -3042,17 +3107,16 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
     *ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor) = A.helpers ? area0 + wib * ZKW_DQ_HELPER_BYTES : 0u;  // dq_helper_area
     *ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor + 1) = area0 + A.waves_per_group * ZKW_DQ_HELPER_BYTES + wib * ZKW_KH_BYTES;  // kh_box (ZKW_KECCAK_HELPER)
     *ZKW_LDS_WORD((ZKW_LDS_AS u32*)sh.cursor + 2) = (u32)(size_t)(ZKW_LDS_AS char*)((char*)zkw_lds + A.lds_sink);  // the prefetch sink (op_uma)
+#elif defined(ZKW_WIDE)
+    const u32 area0 = ZKW_LDS_ADDR(zkw_lds + ZKW_LDS_WAVES0 + A.waves_per_group * zkw_wave_lds_units());
+    *ZKW_LDS_WORD(sh.cursor) = A.helpers ? area0 + wib * ZKW_DQ_HELPER_BYTES : 0u;
+    *ZKW_LDS_WORD(sh.cursor + 1) = area0 + A.waves_per_group * ZKW_DQ_HELPER_BYTES + wib * ZKW_KH_BYTES;
 #endif
   }
-#ifdef __HIP_DEVICE_COMPILE__
   {  // the wave's stream cursors -> lanes 0..3 of v128 (see stream_alloc); uniform loads
     const u32* cp = P.cursors + wave * 4;
     zkw_cursor_set<0>(zkw_uniform(cp[0])); zkw_cursor_set<1>(zkw_uniform(cp[1])); zkw_cursor_set<2>(zkw_uniform(cp[2])); zkw_cursor_set<3>(zkw_uniform(cp[3]));
   }
-#else
-  for (u32 i = tid; i < 4; i += P.wave_threads) sh.cursor[i] = P.cursors[wave * 4 + i];
-  zkw_wave_lds_fence();
-#endif
 #ifdef __HIP_DEVICE_COMPILE__
   const u32 lds_sink = zkw_lds_sink_addr();
 #endif
@@ -3078,6 +3142,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
   s.pc = s.sp = s.ergs = s.timestamp = s.prev_super_pc = s.flags = s.kflags = s.ptr_bitmap = s.reg_dirty = s.counts = 0;
   RegFile rf;
   rf_init(rf);
+#if defined(ZKW_EMU_BUILD) && defined(ZKW_WIDE)
+  zkw_emu_rf_ptr[threadIdx.x] = &rf;
+#endif
   if (exists) {
     const zkw_dev_scalars sc = scalars_in[inst];
 #pragma unroll
@@ -3116,13 +3183,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
   // fails or has used its cycles: the lane state is then modified unconditionally inside the loop body instead of inside
   // an `if (active)` region of every iteration (whose merge points cost ~75 register copies per VM cycle).
   u32 k = 0;
-#ifdef __HIP_DEVICE_COMPILE__
   u32 delta_cur = zkw_cursor_get<3>();
-#else
-  u32 delta_cur = ZKW_LDS_WORD(sh.cursor)[3];
-#endif
   if (exists && !(s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0)) lane_writeback(P, sh, rf, s, 0);  // does not cycle
-  if (exists && s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0) {
+  ZKW_DIV_IF(exists && s.status == ZKW_STATUS_RUNNING && run_cycles != 0 && s.depth != 0) {  // (lanes leave the loop one by one and wait for the others behind this region)
     ZKW_PROF_DECL
 #ifdef ZKW_SHORT_STATS
     // (scalars only: counters in an array would live in scratch memory, and every cycle would wait for its stores)
@@ -3155,20 +3218,15 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
       // directory: stream cursors at the start of wave-cycle (cycle_base + k).  Read here (one broadcast 16-B LDS read),
       // stored by the first remaining lane after the fetch below, so that the LDS latency hides behind it.  The
       // register-delta cursor is carried in a register: only the end of the cycle advances it.
-#ifdef __HIP_DEVICE_COMPILE__
       const uint4 dir_entry = make_uint4(zkw_cursor_get<0>(), zkw_cursor_get<1>(), zkw_cursor_get<2>(), delta_cur);
-#else
-      uint4 dir_entry = zkw_lds_read4(sh.cursor);
-      dir_entry.w = delta_cur;
-#endif
       s.counts = 0; s.kflags &= ~(KF_COLD_DIRTY | KF_DQ_CHAINED); s.reg_dirty = 0;
       // ----------------------------------------------------------------------------------------
       // read_and_decode (cycle.rs:19-236)
       // ----------------------------------------------------------------------------------------
       const bool pending = (s.flags & FLAG_PENDING) != 0;
       const u32 super_pc = s.pc >> 2, sub_pc = s.pc & 3u;
-      if (ZKW_LIKELY(!pending)) {
-        if (ZKW_UNLIKELY((s.kflags & KF_CODE_PAGE_CHANGED) || s.prev_super_pc != super_pc)) {  // :59-95
+      ZKW_DIV_IF(ZKW_LIKELY(!pending)) {
+        ZKW_DIV_IF(ZKW_UNLIKELY((s.kflags & KF_CODE_PAGE_CHANGED) || s.prev_super_pc != super_pc)) {  // :59-95
           const u256 word = code_fetch(sh, s, super_pc);
           emit_mem(P, sh, s, s.timestamp, ZKW_MEM_CODE, CF(sh, s, CF_CODE_PAGE), super_pc, word, false, false, 0);
           // pre-decode the four opcodes of the word (four independent table reads) next to their encodings: a cycle
@@ -3192,7 +3250,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
         s.flags &= ~FLAG_PENDING;
         s.prev_super_pc = super_pc;
       }
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZKW_NO_FAST_ALU) /* (-DZKW_NO_FAST_ALU: the A/B partner) */
+#if !defined(ZKW_NO_FAST_ALU) /* (-DZKW_NO_FAST_ALU: the A/B partner) */
       // ------------------------------------------------------------------------------------------------------------
       // The short cycle.  A wave on a shared tape whose lanes all stand at the same pc, in kernel mode, with nothing pending,
       // executes here (a) an ALU instruction with register / immediate operands (nop, add, sub, and / or / xor, jump) and
@@ -3249,6 +3307,8 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
 #endif
               // ---- the cycle qualifies: from here on it is executed here ----
               ZKW_SS(zs_short++; zs_cls = uma ? 4u : (two_regs ? 5u : 3u);)
+              ZKW_EMU_COUNT(0);
+              if (uma) ZKW_EMU_COUNT(1);
 #ifndef ZKW_EXP_NODIR /* (experiment: what the directory store costs — wrong results) */
               if (zkw_rank_below(zkw_ballot(1)) == 0) *(uint4*)dir_ptr = dir_entry;
 #endif
@@ -3259,7 +3319,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
               u256 res = u256_zero();
               if (uma) {
                 const u32 increment = ZKW_ATTR_FLAGS(u_attr) & 1u;
-                if (run) {
+                ZKW_DIV_IF(run) {
                   const u32 f_slot = cfv_slot(sh, s);
                   const u32 f_hwm_in = uma_heap ? cfv_heap_hwm(sh, s) : CF(sh, s, CF_AUX_HWM);
                   u32 f_hwm = f_hwm_in;
@@ -3280,7 +3340,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
 #endif
 #ifndef ZKW_EXP_NOEMIT /* (experiment: what the read queries cost — wrong results) */
                   emit_mem(P, sh, s, ts_r, mem_type, page, word0, w0v, false, false, 0);
-                  if (unal) emit_mem(P, sh, s, ts_r, mem_type, page, word0 + 1u, w1v, false, false, 0);
+                  ZKW_DIV_IF(unal) emit_mem(P, sh, s, ts_r, mem_type, page, word0 + 1u, w1v, false, false, 0);
 #endif
 #ifdef ZKW_ASM_MARKS
                   asm volatile("; MARK emit0 end");
@@ -3344,7 +3404,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
                     }
                     heap_write_at(P, sh, s, !uma_heap, f_slot, f_hwm, word0, n0);
                     emit_mem(P, sh, s, ts_w, mem_type, page, word0, n0, false, true, 0);
-                    if (unal) {
+                    ZKW_DIV_IF(unal) {
                       heap_write_at(P, sh, s, !uma_heap, f_slot, f_hwm, word0 + 1u, n1);
                       emit_mem(P, sh, s, ts_w, mem_type, page, word0 + 1u, n1, false, true, 0);
                     }
@@ -3357,13 +3417,15 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
                       s.ptr_bitmap &= ~dm;
                     }
                   }
+#ifdef __HIP_DEVICE_COMPILE__
                   // (a cursor: the next access through the register is 32 bytes on — see op_uma)
                   if (increment && src0_mode != ZKW_MODE_IMM && !ZKW_ABL(sh.debug_flags, ZKW_NO_PREFETCH))
                     prefetch_page_words(uma_heap ? sh.heap : sh.aux_heap, uma_heap ? P.H : P.A, P.L, zkw_lds_sink_addr(), f_slot, f_hwm, off + 32u);
+#endif
                 }
               } else if (opcode != ZKW_OP_NOP) {
                 if (code_operand) {  // cycle.rs:304-325: the word of the code page at (register + imm0), and its query
-                  if (run) {
+                  ZKW_DIV_IF(run) {
                     const u32 idx = (clip16(sh, a) + (u_hi & 0xffffu)) & 0xffffu;  // mem_ops.rs:34-35
                     a = code_fetch(sh, s, idx);
                     emit_mem(P, sh, s, s.timestamp, ZKW_MEM_CODE, CF(sh, s, CF_CODE_PAGE), idx, a, false, false, 0);
@@ -3423,7 +3485,11 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
 #endif
               s.lane = zkw_lane_id();
               s.pc = new_pc;
+#ifdef __HIP_DEVICE_COMPILE__
               asm("v_add_u32 %0, %1, %0" : "+v"(s.timestamp) : "s"(time_delta));  // :408-411
+#else
+              s.timestamp += time_delta;
+#endif
               // CycleRecord: the registers this cycle wrote (ascending, lanes in lane order within a register: every lane
               // that wrote holds the same mask), then the tails
               const u64 part = zkw_ballot(dm != 0);
@@ -3519,7 +3585,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
         if (ZKW_UNLIKELY(A.debug_flags & 4u)) {
           grp = 1ull << leader;  // test hook: one lane per group
         }
-#ifdef __HIP_DEVICE_COMPILE__
+#ifdef ZKW_WIDE
         else if (ZKW_UNLIKELY(grp != todo || (A.debug_flags & (1u << 24)))) {  // (bit 24: every group the variant way — test hook)
           const u32 u_op = ZKW_ATTR_OPCODE(u_attr);
           if (u_op != ZKW_OP_LOG && u_op != ZKW_OP_NEAR_CALL && u_op != ZKW_OP_FAR_CALL && u_op != ZKW_OP_RET &&
@@ -3557,7 +3623,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
         todo &= ~grp;
         const bool mine = zkw_lane_bit(grp);
         ZKW_PROF(1)  // group selection, price, exceptions, condition
-        if (mine) {
+        ZKW_DIV_IF(mine) {
+          ZKW_EMU_COUNT(2);
+          if (vec) ZKW_EMU_COUNT(3);
           Decoded d;
           d.word_lo = u_lo; d.word_hi = u_hi;
           d.attr = u_attr;
@@ -3581,7 +3649,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
       // ----------------------------------------------------------------------------------------
       // end of cycle (cycle.rs:408-413)
       // ----------------------------------------------------------------------------------------
-      if (lane_ok(s)) {
+      ZKW_DIV_IF(lane_ok(s)) {
 #ifdef __HIP_DEVICE_COMPILE__
         // the scalar operand spelled out: left to itself the optimiser hoists a vector copy of `time_delta` out of the
         // loop and then keeps that copy in scratch memory
@@ -3589,7 +3657,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
 #else
         s.timestamp += time_delta;
 #endif
-        if (ZKW_UNLIKELY(s.kflags & KF_COLD_DIRTY)) {
+        ZKW_DIV_IF(ZKW_UNLIKELY(s.kflags & KF_COLD_DIRTY)) {
           uint4* a = aux_alloc(P, sh, s, ZKW_AUX_COLD_STATE, 0, CF(sh, s, CF_SPENT_PUBDATA), CF(sh, s, CF_ERGS_PP), CF(sh, s, CF_TX_NUMBER));
           if (a) {
             a[1] = make_uint4(CF(sh, s, CF_CTX0 + 0), CF(sh, s, CF_CTX0 + 1), CF(sh, s, CF_CTX0 + 2), CF(sh, s, CF_CTX0 + 3));
@@ -3668,26 +3736,22 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
           // `total` is the same for every lane still in the loop (ballots over exactly those lanes); the LDS copy is
           // only read after the loop (final directory entry), and a wave's LDS operations complete in order
           delta_cur = base + total;
-#ifdef __HIP_DEVICE_COMPILE__
           zkw_cursor_set<3>(delta_cur);
-#else
-          if (zkw_rank_below(zkw_ballot(true)) == 0) ZKW_LDS_WORD(sh.cursor)[3] = delta_cur;
-#endif
         }
       }
       ZKW_PROF(3)  // CycleRecord: delta ranks, delta + tail stores
-#ifdef __HIP_DEVICE_COMPILE__
+#ifdef ZKW_WIDE
       if ((A.debug_flags & ZKW_DQ_HELPER) && zkw_ballot((s.kflags & KF_DQ_CHAINED) != 0)) {  // (wave-uniform; rare: a far call with a decommit)
         // hand this cycle's decommits to the helper wave: every lane still in the loop marks its entry of the slot valid
         // (its cycle completed with a decommit) or empty, then the slot is posted — a wave's LDS operations complete in
         // order, so the helper that sees the new count sees the entries
         const u32 area = dq_helper_area(sh);
-        const u32 posted = *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)area);
+        const u32 posted = *ZKW_LDS_AT(area);
         const u32 row = area + 16u + (posted & 1u) * 768u + zkw_lane_id() * 4u;
         const bool valid = (s.kflags & KF_DQ_CHAINED) && lane_ok(s);
-        const u32 w0 = *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)row);
-        *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)row) = valid ? (w0 | 0x80000000u) : 0u;
-        if (zkw_rank_below(zkw_ballot(1)) == 0) *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)area) = posted + 1u;
+        const u32 w0 = *ZKW_LDS_AT(row);
+        *ZKW_LDS_AT(row) = valid ? (w0 | 0x80000000u) : 0u;
+        if (zkw_rank_below(zkw_ballot(1)) == 0) *ZKW_LDS_AT(area) = posted + 1u;
       }
 #endif
       k++;
@@ -3707,8 +3771,8 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
       }
     }
   }
-#ifdef __HIP_DEVICE_COMPILE__
-  if (A.helpers && tid == 0) *ZKW_LDS_WORD((ZKW_LDS_AS u32*)(size_t)(dq_helper_area(sh) + 8u)) = 1u;  // every lane has left the loop: nothing more will be posted (before the barriers of the profiling builds below: the helper waves leave on it)
+#ifdef ZKW_WIDE
+  if (A.helpers && tid == 0) *ZKW_LDS_AT(dq_helper_area(sh) + 8u) = 1u;  // every lane has left the loop: nothing more will be posted (before the barriers of the profiling builds below: the helper waves leave on it)
 #endif
 #ifdef ZKW_PROFILE
   __syncthreads();
@@ -3735,7 +3799,6 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
   }
   dir_ptr = P.dir + ((u64)wave * (P.max_cycles + 1) + cycle_base + k) * 4;
   // final directory entry
-#ifdef __HIP_DEVICE_COMPILE__
   {
     const uint4 fin = make_uint4(zkw_cursor_get<0>(), zkw_cursor_get<1>(), zkw_cursor_get<2>(), zkw_cursor_get<3>());
     if (tid == 0) {
@@ -3743,13 +3806,6 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
       *(uint4*)(P.cursors + wave * 4) = fin;
     }
   }
-#else
-  for (u32 i = tid; i < 4; i += P.wave_threads) {
-    const u32 cur = ZKW_LDS_WORD(sh.cursor)[i];
-    dir_ptr[i] = cur;
-    P.cursors[wave * 4 + i] = cur;
-  }
-#endif
   if (tid == 0) P.wave_cycles[wave] = cycle_base + k;
 }
 

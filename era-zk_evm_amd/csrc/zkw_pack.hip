@@ -19,7 +19,7 @@
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-#ifdef __HIP_DEVICE_COMPILE__
+#ifdef ZKW_WIDE
 #define ZKW_PACK_LANE(t) ((t) & 63u)
 #define ZKW_PACK_WAVE_OF(t) ((t) >> 6)
 #else
@@ -46,7 +46,7 @@ static __device__ __forceinline__ u32 pack_flag_scan(bool f, u32* wave_counts, u
   __syncthreads();
   u32 off = 0, tot = 0;
   const u32 nw = (nt + 63u) / 64u;
-#ifdef __HIP_DEVICE_COMPILE__
+#ifdef ZKW_WIDE
   for (u32 i = 0; i < nw; i++) {
     const u32 c = wave_counts[i];
     if (i < wv) off += c;

@@ -196,6 +196,7 @@ ZD void keccak_xor_word_phase(u64 st[25], const u256& w, u32 phase, u32 sh8) {
 }
 
 ZD void precompile_keccak256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
+  ZKW_DIV_SCOPE;  // (a lane that fails — an unreachable page, a full stream — leaves early; the others write their digest)
   const u32 in_off = q.key.w[0], in_len = q.key.w[1], out_off = q.key.w[2];
   const u32 page_r = q.key.w[4], page_w = q.key.w[5];
   u64 st[25];
@@ -235,7 +236,7 @@ ZD void precompile_keccak256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
     const u32 r = r0 + (u32)(J); /* wave-uniform */                                                              \
     if (r <= r1) {                                                                                               \
       if (r >= have) {                                                                                           \
-        if (lane_ok(s)) {                                                                                        \
+        ZKW_DIV_IF(lane_ok(s)) {                                                                                 \
           wv = fat_page_read(sh, s, fpage, w0 + r);                                                              \
           emit_mem(P, sh, s, q.timestamp, ZKW_MEM_FAT_PTR, page_r, w0 + r, wv, false, false, 1);                 \
         }                                                                                                        \
@@ -269,14 +270,16 @@ ZD void precompile_keccak256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
       }
     }
   }
+  {
+  ZKW_DIV_SCOPE;  // (the lanes' messages differ in length: a lane that is through waits behind the loop)
   for (u32 d = d_start; d < n_dwords && lane_ok(s); d++) {
     const u32 need = in_len - 4u * d < 4u ? in_len - 4u * d : 4u;  // message bytes in this stream dword
     const u32 m0 = (in_off >> 2) + d;                               // memory dword holding its first byte
     const bool two = (in_off & 3u) + need > 4u;                     // the dword straddles two memory dwords
     // fetch (in order, once) the words that hold m0 and, if used, m0 + 1
     const u32 wi0 = m0 >> 3, wi1 = (m0 + 1u) >> 3;
-    if (wi0 != cur_idx) {
-      if (wi0 == next_idx) {
+    ZKW_DIV_IF(wi0 != cur_idx) {
+      ZKW_DIV_IF(wi0 == next_idx) {
         w_cur = w_next;
         cur_idx = next_idx;
       } else {
@@ -286,9 +289,9 @@ ZD void precompile_keccak256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
       }
     }
     u32 b = 0;
-    if (two) {
-      if (wi1 != cur_idx) {
-        if (wi1 != next_idx) {
+    ZKW_DIV_IF(two) {
+      ZKW_DIV_IF(wi1 != cur_idx) {
+        ZKW_DIV_IF(wi1 != next_idx) {
           w_next = fat_ptr_read(P, sh, s, page_r, wi1);
           emit_mem(P, sh, s, q.timestamp, ZKW_MEM_FAT_PTR, page_r, wi1, w_next, false, false, 1);
           next_idx = wi1;
@@ -309,6 +312,7 @@ ZD void precompile_keccak256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
       keccak_absorb_block(sh, s.lane, st);
       slot = 0;
     }
+  }
   }
   if (!lane_ok(s)) return;
   // pad10*1 with the legacy 0x01 domain byte: 0x01 right after the message, 0x80 on the last byte of the block
@@ -340,6 +344,7 @@ ZD void precompile_sha256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
   const u32 rounds = q.key.w[6];  // low half of the u64; > 2^32 rounds cannot be paid for
   u32 h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
   u32 rd = in_word;
+  ZKW_DIV_SCOPE;  // (the lanes' round counts differ)
   for (u32 round = 0; round < rounds && lane_ok(s); round++) {
     u32 w[16];
 #pragma unroll
@@ -368,7 +373,7 @@ ZD void precompile_sha256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
       hh = g; g = f; f = e; e = dd + t1; dd = c; c = b; b = a; a = t1 + t2;
     }
     h[0] += a; h[1] += b; h[2] += c; h[3] += dd; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
-    if (round == rounds - 1) {
+    ZKW_DIV_IF(round == rounds - 1) {
       u256 digest;
 #pragma unroll
       for (int i = 0; i < 8; i++) digest.w[7 - i] = h[i];
@@ -384,6 +389,7 @@ ZD void precompile_sha256(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
 // consts.ecrecover_input_layout), two words at `output_memory_offset`: the ok marker (1 / 0) and the address as the
 // low 20 bytes of a big-endian word (reference test src/testing/tests/precompiles/ecrecover.rs:51-95).
 ZD void precompile_ecrecover(ZKW_KP P, Shared& sh, Lane& s, const LogQ& q) {
+  ZKW_DIV_SCOPE;  // (a lane with a malformed recovery id leaves early)
   const u32 in_word = q.key.w[0], out_off = q.key.w[2];
   const u32 page_r = q.key.w[4], page_w = q.key.w[5];
   u256 w0, w1, w2, w3;

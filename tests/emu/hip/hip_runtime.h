@@ -1,13 +1,22 @@
 // TEST INFRASTRUCTURE ONLY — never part of the product, never loaded by the package.
 //
 // A stand-in for <hip/hip_runtime.h> that lets g++ compile era-zk_evm_amd/csrc/*.hip|cpp
-// UNMODIFIED into tests/emu/libzkw_emu.so: a single-lane "wave" (warpSize 1) executed
-// sequentially on the host.  It exists so that the `-m "not gpu"` suite can run the real kernel
+// UNMODIFIED into tests/emu/libzkw_emu*.so, so that the `-m "not gpu"` suite can run the real kernel
 // logic and host runtime (decode, opcodes, stream compaction indices, gather) against the oracle
-// on a box without a GPU.  Lane-parallel behaviour (ballot ranks across 64 lanes, LDS banking,
-// coalescing) is only exercised by the `-m gpu` tests on a real MI355X.
+// on a box without a GPU.  Two flavours (build_emu.py):
+//   ZKW_EMU_WAVE == 1  (libzkw_emu.so)   a single-lane "wave" (warpSize 1) executed sequentially: fast, no lane-parallel
+//                                        behaviour;
+//   ZKW_EMU_WAVE == 64 (libzkw_emu64.so) 64-lane waves on the SIMT engine of emu_simt.cpp: every thread of a workgroup
+//                                        is a fiber, cross-lane operations and barriers are rendezvous points, the
+//                                        execution mask comes from the ZKW_DIV_IF / ZKW_DIV_SCOPE annotations of the
+//                                        kernel source — ballot ranks, group selection, the short cycle's wave-uniform
+//                                        tests and divergent lanes run on the CPU.
+// (LDS banking, coalescing and timing are only ever seen by the `-m gpu` tests on a real MI355X.)
 #pragma once
 #define ZKW_EMU_BUILD 1 /* the product sources see this only in the tests/emu build */
+#ifndef ZKW_EMU_WAVE
+#define ZKW_EMU_WAVE 1
+#endif
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -16,7 +25,11 @@
 #define __global__
 #define __device__
 #define __host__
+#if ZKW_EMU_WAVE > 1
+#define __shared__ static /* one workgroup runs at a time (emu_simt.cpp): a static is what its fibers share */
+#else
 #define __shared__
+#endif
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 
@@ -31,11 +44,50 @@ struct dim3 {
 extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 extern uint4 zkw_lds[];  // the dynamic LDS segment
 
-static inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+static inline int __ffs(int v) { return __builtin_ffs(v); }
+// cross-lane operations (ZKW_EMU_WAVE > 1: rendezvous points of the lanes' fibers, emu_simt.cpp)
+enum { ZE_BALLOT, ZE_READFIRST, ZE_READLANE, ZE_SHFL, ZE_SHFL_XOR, ZE_BPERMUTE, ZE_WAVE_BARRIER, ZE_FETCH_ADD, ZE_YIELD, ZE_SCOPE_BEGIN, ZE_SYNCTHREADS };
+#if ZKW_EMU_WAVE > 1
+extern "C" uint64_t zkw_emu_collective(int kind, uint64_t operand, uint32_t arg, const char* file, int line);
+extern "C" void zkw_emu_scope_end(void);
+extern "C" uint32_t* zkw_emu_wave_sregs(void);
+extern "C" void zkw_emu_launch(void (*entry)(void*), void* arg, dim3 grid, dim3 block);
+#define __ballot(p) ((unsigned long long)zkw_emu_collective(ZE_BALLOT, (p) ? 1u : 0u, 0u, __FILE__, __LINE__))
+#define __shfl(v, l) ((int)zkw_emu_collective(ZE_SHFL, (uint32_t)(v), (uint32_t)(l), __FILE__, __LINE__))
+#define __shfl_xor(v, o) ((int)zkw_emu_collective(ZE_SHFL_XOR, (uint32_t)(v), (uint32_t)(o), __FILE__, __LINE__))
+#define __syncthreads() ((void)zkw_emu_collective(ZE_SYNCTHREADS, 0u, 0u, __FILE__, __LINE__))
+// A divergence scope = what the execution mask does on the hardware: the lanes whose condition holds run the region
+// while the others wait, then the others run (the else arm, or nothing), and all of them continue together behind it —
+// also the lanes that left the region early (break / continue / return run the destructor).
+struct zkw_emu_scope {
+  bool taken;
+  zkw_emu_scope(bool c, const char* f, int l) { taken = zkw_emu_collective(ZE_SCOPE_BEGIN, c ? 1u : 0u, 0u, f, l) != 0; }
+  ~zkw_emu_scope() { zkw_emu_scope_end(); }
+  zkw_emu_scope(const zkw_emu_scope&) = delete;
+};
+#define ZKW_DIV_IF(c) if (zkw_emu_scope zkw_sc{(bool)(c), __FILE__, __LINE__}; zkw_sc.taken)
+#define ZKW_DIV_SCOPE zkw_emu_scope zkw_sc_region{true, __FILE__, __LINE__}
+// "the lanes of the wave are in lockstep here": between a read of wave-shared memory by every lane and its update by one
+#define ZKW_LOCKSTEP() ((void)zkw_emu_collective(ZE_WAVE_BARRIER, 0u, 0u, __FILE__, __LINE__))
+static inline uint32_t zkw_emu_fetch_add(uint32_t reg, uint32_t n, const char* f, int l) { return (uint32_t)zkw_emu_collective(ZE_FETCH_ADD, n, reg, f, l); }
+#define ZKW_EMU_FETCH_ADD(reg, n) zkw_emu_fetch_add((reg), (n), __FILE__, __LINE__)
+#define ZKW_EMU_YIELD() ((void)zkw_emu_collective(ZE_YIELD, 0u, 0u, __FILE__, __LINE__))
+#else
+static inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; }
 static inline int __shfl(int v, int) { return v; }
+static inline int __shfl_xor(int v, int) { return v; }
 static inline void __syncthreads() {}
+#define ZKW_DIV_IF(c) if (c)
+#define ZKW_DIV_SCOPE ((void)0)
+#define ZKW_LOCKSTEP() ((void)0)
+extern uint32_t zkw_emu_sregs_1[64][16];  // one-lane waves: the "wave" is the thread
+static inline uint32_t* zkw_emu_wave_sregs(void) { return zkw_emu_sregs_1[threadIdx.x & 63u]; }
+static inline uint32_t zkw_emu_fetch_add_1(uint32_t reg, uint32_t n) { uint32_t* r = zkw_emu_wave_sregs(); const uint32_t o = r[reg]; r[reg] = o + n; return o; }
+#define ZKW_EMU_FETCH_ADD(reg, n) zkw_emu_fetch_add_1((reg), (n))
+#define ZKW_EMU_YIELD() ((void)0)
+#endif
 static inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 static inline uint32_t atomicOr(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 
@@ -52,7 +104,7 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) { *v = a == hipDeviceAttributeWarpSize ? 1 : 4; return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) { *v = a == hipDeviceAttributeWarpSize ? ZKW_EMU_WAVE : 4; return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
@@ -72,6 +124,14 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t
   return hipSuccess;
 }
 
+#if ZKW_EMU_WAVE > 1
+template <typename K, typename... Args>
+static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, Args... args) {
+  auto thunk = [&]() { kernel(args...); };
+  typedef decltype(thunk) thunk_t;
+  zkw_emu_launch([](void* p) { (*static_cast<thunk_t*>(p))(); }, &thunk, grid, block);
+}
+#else
 template <typename K, typename... Args>
 static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, Args... args) {
   gridDim = grid;
@@ -86,12 +146,19 @@ static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, h
       }
     }
 }
+#endif
 
 // wave-uniform broadcast of the first active lane: identity for a one-lane wave
+#if ZKW_EMU_WAVE > 1
+#define __builtin_amdgcn_readfirstlane(x) ((int)zkw_emu_collective(ZE_READFIRST, (uint32_t)(x), 0u, __FILE__, __LINE__))
+#define __builtin_amdgcn_readlane(x, l) ((int)zkw_emu_collective(ZE_READLANE, (uint32_t)(x), (uint32_t)(l), __FILE__, __LINE__))
+#define __builtin_amdgcn_ds_bpermute(a, v) ((int)zkw_emu_collective(ZE_BPERMUTE, (uint32_t)(v), (uint32_t)(a), __FILE__, __LINE__))
+#else
 static inline int zkw_emu_readfirstlane(int x) { return x; }
 #define __builtin_amdgcn_readfirstlane(x) zkw_emu_readfirstlane(x)
 static inline int zkw_emu_readlane(int x, int) { return x; }
 #define __builtin_amdgcn_readlane(x, l) zkw_emu_readlane(x, l)
+#endif
 static inline uint32_t zkw_emu_alignbit(uint32_t hi, uint32_t lo, uint32_t n) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (n & 31u)); }
 #define __builtin_amdgcn_alignbit(hi, lo, n) zkw_emu_alignbit(hi, lo, n)
 
@@ -107,7 +174,11 @@ static inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+#if ZKW_EMU_WAVE > 1
+#define __builtin_amdgcn_wave_barrier() ((void)zkw_emu_collective(ZE_WAVE_BARRIER, 0u, 0u, __FILE__, __LINE__))
+#else
 #define __builtin_amdgcn_wave_barrier() ((void)0)
+#endif
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 
@@ -116,8 +187,6 @@ static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int)
 enum { hipHostMallocDefault = 0 };
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); return *p ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
-
-static inline int __shfl_xor(int v, int) { return v; }
 
 // round 5 (zkw_delivery / zkw_batch_restage): streams of their own, stream-to-event ordering, device view of pinned memory —
 // all synchronous here
