@@ -606,8 +606,9 @@ class Batch:
         be.call("batch_set_state", self.h, C.c_uint32(0), C.c_uint32(wl.n_instances), _ptr(states), _ptr(inner), C.c_uint32(depth))
         if wl.heaps is not None:
             heaps = np.ascontiguousarray(wl.heaps, dtype="<u8")  # [n, words, 4]
+            lens = getattr(wl, "heap_lens", None)  # (optional: a shorter image per instance — words beyond it read as zero)
             for i in range(wl.n_instances):
-                be.call("batch_set_heap", self.h, C.c_uint32(i), _ptr(heaps[i]), C.c_uint32(heaps.shape[1]))
+                be.call("batch_set_heap", self.h, C.c_uint32(i), _ptr(heaps[i]), C.c_uint32(heaps.shape[1] if lens is None else int(lens[i])))
         if getattr(wl, "bootloader_calldata", None) is not None:
             cd = np.ascontiguousarray(wl.bootloader_calldata, dtype="<u8")  # [n, words, 4]
             for i in range(wl.n_instances):

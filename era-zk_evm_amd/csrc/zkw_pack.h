@@ -102,5 +102,8 @@ typedef struct zkw_restage_params {
   zkw_dev_scalars* scalars0;        /* [n_instances] */
   zkw_dev_entry* callstack0;        /* [n_instances][D + 1] */
   uint4* heap0;                     /* [n_waves][image_words][2][L] */
-  uint32_t n_instances, L, n_waves, D, image_words, reserved0;
+  uint32_t n_instances, L, n_waves, D, image_words;
+  uint32_t F;                       /* arena slots per instance (rows of frames0) */
+  zkw_dev_frame_meta* frames0;      /* [n_instances][F]: with heaps, slot 0's heap mark becomes image_words — the uploaded images may
+                                       have been shorter per instance (words at and beyond the mark read as zero) */
 } zkw_restage_params;

@@ -266,6 +266,9 @@ __global__ void __launch_bounds__(256) zkw_restage_kernel(zkw_restage_params R) 
     e.reserved0 = 0;
     e.reserved1 = 0;
     row->e = e;
+    // a restaged heap image is image_words long for every instance, whatever the instance had uploaded: the page's mark
+    // (words at and beyond it read as zero, heap_read_at) follows the new image
+    if (R.heaps && R.image_words) R.frames0[i * R.F].heap_hwm = R.image_words;
   }
   // heap images: out[((w * words + k) * 2 + half) * L + l] = in[(i * words + k) * 2 + half]; consecutive threads = consecutive lanes
   // of one (word, half): the stores are whole lines, the loads 16 bytes out of each lane's own image

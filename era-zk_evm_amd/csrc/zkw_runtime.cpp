@@ -90,6 +90,21 @@ struct StagedInstance {
   bool has_state = false;
 };
 
+// What a witness is rebuilt onto on the host: the initial states the step ran on and the code of the batch (page -> blob, the
+// blobs' words: a Code query's value does not travel).  Immutable once built and shared by reference count: the batch holds the
+// inputs of its current staging, a delivery ticket those of ITS step — a restage, a new upload or the destruction of the batch
+// while a ticket is still being read neither changes nor frees what the ticket rebuilds from.
+struct CodeInputs {
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> pages;  // [instance] page -> blob, in registration order
+  std::vector<std::vector<zkw_u256>> blobs;
+  std::vector<uint32_t> preimage_blob;                             // [preimage] -> blob
+  uint32_t time_delta = 0;                                         // consts.time_delta_per_cycle of the table the batch ran under
+};
+struct BatchInputs {
+  std::vector<zkw_vm_local_state> states;  // [n]
+  std::shared_ptr<const CodeInputs> code;
+};
+
 struct WaveTrace {  // de-interleaved streams of one wave
   std::vector<std::vector<zkw_cycle_record>> records;
   std::vector<std::vector<zkw_mem_query>> mem;
@@ -125,6 +140,7 @@ struct zkw_batch {
   std::vector<std::vector<zkw_u256>> blobs;
   std::vector<std::pair<zkw_u256, uint32_t>> preimages;
   std::vector<StagedInstance> staged;
+  std::shared_ptr<const BatchInputs> inputs;  // of the last upload / restage (what traces are rebuilt onto)
   zkw_block_properties props;
   bool uploaded = false, ran = false, synced = false;
   uint32_t cycles_run = 0;  // wave cycles since reset
@@ -1019,6 +1035,20 @@ int zkw_batch_upload(zkw_batch* b) {
     HIP_TRY(c, ensure(b->d_commit_params, ZKW_QUEUE_COUNT + 1));
     HIP_TRY(c, hipMemcpy(b->d_commit_params.p, CP, sizeof CP, hipMemcpyHostToDevice));
   }
+  {  // the host side of the inputs, as the rebuild needs them (BatchInputs)
+    auto code = std::make_shared<CodeInputs>();
+    code->pages.resize(b->n);
+    for (uint32_t i = 0; i < b->n; i++) code->pages[i] = b->staged[i].code_pages;
+    code->blobs = b->blobs;
+    code->preimage_blob.reserve(b->preimages.size());
+    for (const auto& pr : b->preimages) code->preimage_blob.push_back(pr.second);
+    code->time_delta = c->isa.consts.time_delta_per_cycle;
+    auto in = std::make_shared<BatchInputs>();
+    in->states.resize(b->n);
+    for (uint32_t i = 0; i < b->n; i++) in->states[i] = b->staged[i].state;
+    in->code = code;
+    b->inputs = in;
+  }
   b->uploaded = true;
   b->ran = false;
   return zkw_batch_reset(b, nullptr);
@@ -1471,8 +1501,9 @@ struct CycleView {
 };
 
 template <class Sink>
-static void walk_wave(const zkw_batch* b, uint32_t w, const WaveView& v, const uint32_t* ncyc, Sink& sink) {
-  const zkw_ctx* c = b->ctx;
+static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, const uint32_t* ncyc, Sink& sink) {
+  const CodeInputs& code = *in.code;
+  const uint32_t n_inst = (uint32_t)in.states.size();
   const uint32_t L = v.L;
   uint32_t max_cycles_lane = 0;
   for (uint32_t l = 0; l < L; l++) max_cycles_lane = std::max(max_cycles_lane, ncyc[l]);
@@ -1494,17 +1525,21 @@ static void walk_wave(const zkw_batch* b, uint32_t w, const WaveView& v, const u
   std::vector<std::vector<std::pair<uint32_t, uint32_t>>> pages(L);
   for (uint32_t l = 0; l < L; l++) {
     const uint32_t inst = w * L + l;
-    if (inst >= b->n) continue;
-    for (const auto& pg : b->staged[inst].code_pages) pages[l].push_back(pg);  // (later registrations win: searched from the back)
+    if (inst >= n_inst) continue;
+    for (const auto& pg : code.pages[inst]) pages[l].push_back(pg);  // (later registrations win: searched from the back)
   }
+  // (the blob of a decommit through its preimage index: the blob id in `c` is the 16-bit field of the reference's decommit query)
   for (uint32_t i = 0; i < v.n_aux; i++)
-    if (aux[i].type == ZKW_AUX_DECOMMIT && aux[i].lane < L) pages[aux[i].lane].emplace_back(aux[i].b, aux[i].c >> 16);
+    if (aux[i].type == ZKW_AUX_DECOMMIT && aux[i].lane < L) {
+      const uint32_t pre = aux[i].u.decommit.preimage_index;
+      pages[aux[i].lane].emplace_back(aux[i].b, pre < code.preimage_blob.size() ? code.preimage_blob[pre] : 0u);
+    }
   auto code_word = [&](uint32_t l, uint32_t page, uint32_t index, zkw_u256* out) {
     std::memset(out, 0, sizeof *out);
     const auto& pv = pages[l];
     for (size_t k = pv.size(); k-- > 0;)
       if (pv[k].first == page) {
-        const auto& blob = b->blobs[pv[k].second < b->blobs.size() ? pv[k].second : 0];
+        const auto& blob = code.blobs[pv[k].second < code.blobs.size() ? pv[k].second : 0];
         if (index < blob.size()) *out = blob[index];
         return;
       }
@@ -1513,12 +1548,12 @@ static void walk_wave(const zkw_batch* b, uint32_t w, const WaveView& v, const u
   std::vector<zkw_cycle_record> cur(L);
   struct Slow { uint32_t heap_bound, aux_bound, depth, timestamp, pc; };
   std::vector<Slow> slow(L);
-  const uint32_t time_delta = c->isa.consts.time_delta_per_cycle;
+  const uint32_t time_delta = code.time_delta;
   for (uint32_t l = 0; l < L; l++) {
     std::memset(&cur[l], 0, sizeof(zkw_cycle_record));
     const uint32_t inst = w * L + l;
-    if (inst < b->n) {
-      const zkw_vm_local_state& st0 = b->staged[inst].state;
+    if (inst < n_inst) {
+      const zkw_vm_local_state& st0 = in.states[inst];
       std::memcpy(cur[l].registers, st0.registers, sizeof st0.registers);
       slow[l] = Slow{st0.current.heap_bound, st0.current.aux_heap_bound, st0.callstack_depth, st0.timestamp, st0.current.pc};
     } else {
@@ -1640,7 +1675,7 @@ struct MaterialiseSink {  // -> the per-instance arrays of zkw_instance_trace
   }
 };
 
-static std::unique_ptr<WaveTrace> materialise_wave(const zkw_batch* b, uint32_t w, const WaveView& v, const uint32_t* ncyc) {
+static std::unique_ptr<WaveTrace> materialise_wave(const BatchInputs& in, uint32_t w, const WaveView& v, const uint32_t* ncyc) {
   const uint32_t L = v.L;
   auto wt = std::make_unique<WaveTrace>();
   wt->records.resize(L); wt->mem.resize(L); wt->log.resize(L); wt->aux.resize(L);
@@ -1651,7 +1686,7 @@ static std::unique_ptr<WaveTrace> materialise_wave(const zkw_batch* b, uint32_t 
     wt->mem_off[l].assign(1, 0); wt->log_off[l].assign(1, 0); wt->aux_off[l].assign(1, 0);
   }
   MaterialiseSink sink{*wt};
-  walk_wave(b, w, v, ncyc, sink);
+  walk_wave(in, w, v, ncyc, sink);
   return wt;
 }
 
@@ -1724,7 +1759,7 @@ static int build_wave(zkw_batch* b, uint32_t w) {
     c->last_error = "pack kernel: the wave did not fit its block";
     return ZKW_ERR_LIMIT;
   }
-  b->wave_cache[w] = materialise_wave(b, w, v, ncyc.data());
+  b->wave_cache[w] = materialise_wave(*b->inputs, w, v, ncyc.data());
   return ZKW_OK;
 }
 
@@ -1738,7 +1773,8 @@ struct DeliverySlot {
   uint64_t units = 0;
   int state = 0;       // 0 free, 1 submitted, 2 landed (the host has waited for it)
   uint32_t ticket = 0;
-  std::vector<zkw_batch*> batches;
+  std::vector<std::shared_ptr<const BatchInputs>> inputs;  // per batch of the block: what ITS step ran on (the batches themselves may be
+                                                           // restaged, uploaded again or destroyed while the ticket is read)
   hipEvent_t ev_run = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr;
   uint32_t* d_state = nullptr;          // [4] allocation cursor, overflow flag
   zkw_pack_batch* d_batches = nullptr;  // [ZKW_PACK_MAX] device copy of the block's batch table
@@ -2016,7 +2052,8 @@ int zkw_delivery_submit(zkw_delivery* d, zkw_batch* const* batches, uint32_t n, 
   HIP_TRY(c, hipEventRecord(sl.ev_done, d->stream));
   sl.state = 1;
   sl.ticket = d->next_ticket;
-  sl.batches.assign(batches, batches + n);
+  sl.inputs.clear();
+  for (uint32_t i = 0; i < n; i++) sl.inputs.push_back(batches[i]->inputs);
   sl.wave_table = (uint32_t)wave_table;
   sl.n_waves = waves;
   sl.cache.clear();
@@ -2056,8 +2093,7 @@ int zkw_delivery_wait(zkw_delivery* d, uint32_t ticket, zkw_delivered* info) {
 
 int zkw_delivery_get_instance_trace(zkw_delivery* d, uint32_t ticket, uint32_t bi, uint32_t instance, zkw_instance_trace* out) {
   DeliverySlot* sl = delivery_slot(d, ticket, true);
-  if (!sl || !out || bi >= sl->batches.size()) return ZKW_ERR_INVALID;
-  const zkw_batch* b = sl->batches[bi];
+  if (!sl || !out || bi >= sl->inputs.size()) return ZKW_ERR_INVALID;
   const zkw_pack_batch& pb = ((const zkw_pack_batch*)(sl->h + ZKW_PACK_HEADER_UNITS))[bi];
   if (instance >= pb.n_instances) return ZKW_ERR_INVALID;
   const uint32_t L = pb.L, w = instance / L, l = instance % L;
@@ -2069,7 +2105,7 @@ int zkw_delivery_get_instance_trace(zkw_delivery* d, uint32_t ticket, uint32_t b
       d->ctx->last_error = "zkw_delivery_get_instance_trace: the wave was not delivered (overflow)";
       return ZKW_ERR_LIMIT;
     }
-    sl->cache[key] = materialise_wave(b, w, v, ncyc.data());
+    sl->cache[key] = materialise_wave(*sl->inputs[bi], w, v, ncyc.data());
   }
   WaveTrace& wt = *sl->cache[key];
   const zkw_dev_scalars& sc = ((const zkw_dev_scalars*)(sl->h + pb.scalars_off))[instance];
@@ -2088,7 +2124,7 @@ int zkw_delivery_replay(zkw_delivery* d, uint32_t ticket, zkw_cycle_fn fn, void*
   DeliverySlot* sl = delivery_slot(d, ticket, true);
   if (!sl) return ZKW_ERR_INVALID;
   const zkw_pack_batch* pbs = (const zkw_pack_batch*)(sl->h + ZKW_PACK_HEADER_UNITS);
-  const uint32_t nb = (uint32_t)sl->batches.size();
+  const uint32_t nb = (uint32_t)sl->inputs.size();
   std::atomic<uint32_t> next{0};
   std::atomic<uint64_t> cycles{0}, acc{0};
   std::atomic<uint32_t> missing{0};
@@ -2108,11 +2144,11 @@ int zkw_delivery_replay(zkw_delivery* d, uint32_t ticket, zkw_cycle_fn fn, void*
       }
       if (fn) {
         CallbackSink sink{fn, user, t, bi, w * pbs[bi].L};
-        walk_wave(sl->batches[bi], w, v, ncyc.data(), sink);
+        walk_wave(*sl->inputs[bi], w, v, ncyc.data(), sink);
         my_cycles += sink.cycles;
       } else {
         FoldSink sink;
-        walk_wave(sl->batches[bi], w, v, ncyc.data(), sink);
+        walk_wave(*sl->inputs[bi], w, v, ncyc.data(), sink);
         my_cycles += sink.cycles;
         my_acc += sink.acc;
       }
@@ -2138,7 +2174,7 @@ int zkw_delivery_release(zkw_delivery* d, uint32_t ticket) {
   }
   sl->state = 0;
   sl->cache.clear();
-  sl->batches.clear();
+  sl->inputs.clear();
   return ZKW_OK;
 }
 
@@ -2217,6 +2253,12 @@ int zkw_batch_restage(zkw_batch* b, const zkw_vm_local_state* states, const zkw_
   // the library's own copy of the initial states (what a trace is rebuilt onto); the staged heap vectors are not kept in step —
   // a later zkw_batch_upload needs zkw_batch_set_heap again
   for (uint32_t i = 0; i < n; i++) b->staged[i].state = states[i];
+  {  // a NEW inputs object: the tickets of earlier steps keep the one their step ran on
+    auto in = std::make_shared<BatchInputs>();
+    in->states.assign(states, states + n);
+    in->code = b->inputs->code;
+    b->inputs = in;
+  }
   if (heap_words) b->heaps_restaged = true;
   hipStream_t st = (hipStream_t)hip_stream;
   HIP_TRY(c, hipMemcpyAsync(b->d_stage.p, b->h_stage, st_bytes, hipMemcpyHostToDevice, st));
@@ -2229,6 +2271,7 @@ int zkw_batch_restage(zkw_batch* b, const zkw_vm_local_state* states, const zkw_
   R.heaps = heap_words ? (const uint4*)(b->d_stage.p + heap_off) : nullptr;
   R.regs0 = b->d_regs0.p; R.scalars0 = b->d_scalars0.p; R.callstack0 = b->d_callstack0.p; R.heap0 = b->d_heap0.p;
   R.n_instances = n; R.L = b->L; R.n_waves = b->n_waves; R.D = b->lim.max_callstack_depth; R.image_words = himg;
+  R.F = b->lim.max_far_frames; R.frames0 = b->d_frames0.p;
   HIP_TRY(c, zkw_launch_restage(&R, (uint32_t)c->wave_width, st));
   b->full_reset_pending = true;  // the whole heap image goes into the arena, not just the words a run had dirtied
   zkw_batch* one[1] = {b};

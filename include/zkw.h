@@ -709,7 +709,12 @@ int zkw_delivery_release(zkw_delivery* d, uint32_t ticket);
  * heap_words [n_instances][*n_heap_words]), a caller that builds its inputs there passes those pointers to zkw_batch_restage
  * and nothing is copied on the host.  (zkw_batch_staging waits until the copies of the previous restage have left the
  * buffers.)  After a restage with heap images the library no longer holds the batch's heaps on the host: another
- * zkw_batch_upload needs zkw_batch_set_heap again. */
+ * zkw_batch_upload needs zkw_batch_set_heap again.
+ * The uploaded image length is the LONGEST heap any instance was given (zkw_batch_set_heap); a restaged image has that length
+ * for every instance, whatever the instance itself had uploaded — all of its words are readable afterwards.
+ * Delivery tickets are self-contained: a ticket submitted before the restage (the order a pipeline wants: submit,
+ * zkw_delivery_order_after on the side stream, restage) keeps the inputs its own step ran on, so its traces / replay are
+ * unchanged by the restage — and by a later zkw_batch_upload or zkw_batch_destroy of the batch. */
 int zkw_batch_staging(zkw_batch* batch, zkw_vm_local_state** states, zkw_u256** heap_words, uint32_t* n_heap_words);
 int zkw_batch_restage(zkw_batch* batch, const zkw_vm_local_state* states, const zkw_u256* heap_words, uint32_t n_heap_words, void* hip_stream);
 
