@@ -445,7 +445,10 @@ impl<'a> Batch<'a> {
         }
         let (hp, nh, flat): (*const zkw_u256, u32, Vec<zkw_u256>) = match heaps {
             Some(h) => {
+                anyhow::ensure!(h.len() == self.n as usize, "restage: one heap image per instance");
                 let n = h.first().map(|v| v.len()).unwrap_or(0);
+                // (the C ABI takes one flat [n_instances][n_words] array: images of different lengths would shift every later instance)
+                anyhow::ensure!(h.iter().all(|v| v.len() == n), "restage: the heap images must all have the uploaded length");
                 let flat: Vec<zkw_u256> = h.iter().flat_map(|v| v.iter().map(u256_to_c)).collect();
                 (flat.as_ptr(), n as u32, flat)
             }
@@ -453,6 +456,26 @@ impl<'a> Batch<'a> {
         };
         let rc = unsafe { zkw_batch_restage(self.raw, cs.as_ptr(), hp, nh, std::ptr::null_mut()) };
         drop(flat);
+        self.ctx.check(rc, "zkw_batch_restage")
+    }
+    /// The zero-copy form of `restage`: `fill` writes the next inputs straight into the batch's pinned staging buffers
+    /// (zkw_batch_staging: states [n_instances], heap images [n_instances][n_heap_words] — the slice is empty when the batch was
+    /// uploaded without heaps) and the library copies nothing on the host.  `fill` returns whether it wrote heap images.
+    pub fn restage_in_place<F>(&mut self, fill: F) -> anyhow::Result<()>
+    where
+        F: FnOnce(&mut [zkw_vm_local_state], &mut [zkw_u256], usize) -> bool,
+    {
+        let (mut sp, mut hp, mut nh): (*mut zkw_vm_local_state, *mut zkw_u256, u32) = (std::ptr::null_mut(), std::ptr::null_mut(), 0);
+        self.ctx.check(unsafe { zkw_batch_staging(self.raw, &mut sp, &mut hp, &mut nh) }, "zkw_batch_staging")?;
+        let n = self.n as usize;
+        let states = unsafe { std::slice::from_raw_parts_mut(sp, n) };
+        let heaps: &mut [zkw_u256] = if nh == 0 || hp.is_null() { &mut [] } else { unsafe { std::slice::from_raw_parts_mut(hp, n * nh as usize) } };
+        let with_heaps = fill(states, heaps, nh as usize);
+        for (i, c) in states.iter().enumerate() {
+            self.initial[i].0 = *c;  // (the inner entries of the callstack keep the uploaded geometry: zkw_batch_restage checks it)
+        }
+        let (hw, nw) = if with_heaps && nh != 0 { (hp as *const zkw_u256, nh) } else { (std::ptr::null(), 0) };
+        let rc = unsafe { zkw_batch_restage(self.raw, sp as *const zkw_vm_local_state, hw, nw, std::ptr::null_mut()) };
         self.ctx.check(rc, "zkw_batch_restage")
     }
     /// the queue commitments of every instance after a run: [instance][memory, log, decommit][4] Goldilocks elements
