@@ -10,6 +10,13 @@
 //                                       timestamp is the cycle's + 0..3, mod.rs:220-231, and the rebuild knows the cycle's)
 //   code-word queries    no value       MemoryType::Code reads (cycle.rs:76-81, mem_ops.rs:100-110) return words of a code page
 //                                       the host holds (the blobs it uploaded): the value planes carry the other queries only
+//   memory READS         no value       (version 2, ZKW_PACK_NO_READ_VALUES in the header's flags) what a read of a stack / heap / aux-heap page
+//                                       returns follows from what was written there before: the host rebuild keeps a shadow of every
+//                                       page a lane touches — the heap image it staged, zero elsewhere (SimpleMemory: fresh pages are
+//                                       zero-filled, reference_impls/memory.rs:15-148, 413-521), every write query of the stream applied
+//                                       in order — and fills `MemoryQuery.value` of the reads itself; only WRITES carry their value.
+//                                       Used when the host holds the heap images the step ran on (always after an upload; after a
+//                                       restage with heap images only under ZKW_OPT_KEEP_RESTAGED_HEAPS — else reads keep their values)
 //   aux events           256 B -> used  FRAME_START 240 B, DECOMMIT 64 B, COLD_STATE 48 B, FRAME_FINISH 16 B
 // All offsets and sizes are in 16-byte units from the start of the block.
 //
@@ -25,7 +32,8 @@
 //     tails    max_cyc x L
 //     deltas   n_delta (low plane), n_delta (high plane)
 //     mem      3 planes of ceil4(n_mem) u32 (page | index | misc), then n_val (value low), n_val (value high): the values of
-//              the queries whose type is not Code, in stream order
+//              the queries that carry one (zkw_pack_has_value: no Code reads; under ZKW_PACK_NO_READ_VALUES no reads at all), in
+//              stream order
 //     log      n_log x 8
 //     aux      aux_units (records back to back, each as long as its type uses)
 #pragma once
@@ -34,7 +42,8 @@
 #include "zkw_device.h"
 
 #define ZKW_PACK_MAGIC 0x50574b5au /* "ZKWP" */
-#define ZKW_PACK_VERSION 1u
+#define ZKW_PACK_VERSION 2u
+#define ZKW_PACK_NO_READ_VALUES 1u /* zkw_pack_header.flags / zkw_pack_args.flags: the value planes hold the values of WRITES only */
 #define ZKW_PACK_HEADER_UNITS 4u
 #define ZKW_PACK_BATCH_UNITS 2u
 #define ZKW_PACK_WAVE_UNITS 4u
@@ -47,7 +56,8 @@ typedef struct zkw_pack_header { /* 64 B */
   uint32_t with_instances; /* 1: the per-instance sections are present */
   uint32_t used_units;     /* total units of the block (copied behind the kernel from its allocation cursor) */
   uint32_t overflow;       /* != 0: the block did not fit the slot: waves without data have off == 0 */
-  uint32_t reserved[8];
+  uint32_t flags;          /* ZKW_PACK_* */
+  uint32_t reserved[7];
 } zkw_pack_header;
 
 typedef struct zkw_pack_batch { /* 32 B */
@@ -87,8 +97,14 @@ typedef struct zkw_pack_args {
   uint32_t wave_table;  /* unit offset of the wave table */
   uint32_t with_instances;
   uint32_t only_wave;   /* 0xffffffff: every wave; else the one wave (of the one batch) to pack — the on-demand path of zkw_batch_get_instance_trace */
-  uint32_t reserved;
+  uint32_t flags;       /* ZKW_PACK_NO_READ_VALUES */
 } zkw_pack_args;
+/* does memory query `hdr_w` (word 3 of its header: lane | seq << 8 | meta << 16) carry its value on the link? */
+ZKW_HD static inline bool zkw_pack_has_value(uint32_t hdr_w, uint32_t flags) {
+  const uint32_t meta = hdr_w >> 16;
+  if ((meta & ZKW_MQ_TYPE_MASK) == ZKW_MEM_CODE) return false;
+  return !(flags & ZKW_PACK_NO_READ_VALUES) || (meta & ZKW_MQ_RW) != 0;
+}
 
 /* zkw_restage_kernel: fresh inputs of an uploaded batch, brought into the device layouts ON the device.  The host hands over
  * what the C ABI takes — VmLocalStates [n] and heap images [n][image_words] u256, instance-major, through pinned staging and

@@ -87,9 +87,9 @@ __global__ void __launch_bounds__(ZKW_PACK_THREADS) zkw_pack_kernel(zkw_pack_arg
     const u32 n_aux = cur[2] < P.cap_aux ? cur[2] : P.cap_aux, n_delta = cur[3] < P.cap_delta ? cur[3] : P.cap_delta;
     const uint4* mem_hdr = P.mem_stream + (u64)w * P.cap_mem * 3;
     const uint4* aux_src = P.aux_stream + (u64)w * P.cap_aux * 16;
-    // ---- count: memory queries that carry a value (every type but Code), units of the aux records ----
+    // ---- count: memory queries that carry a value (zkw_pack_has_value), units of the aux records ----
     u32 my_val = 0, my_aux = 0;
-    for (u32 i = t; i < n_mem; i += nt) my_val += ((mem_hdr[i].w >> 16) & ZKW_MQ_TYPE_MASK) != ZKW_MEM_CODE ? 1u : 0u;
+    for (u32 i = t; i < n_mem; i += nt) my_val += zkw_pack_has_value(mem_hdr[i].w, A.flags) ? 1u : 0u;
     for (u32 i = t; i < n_aux; i += nt) my_aux += zkw_aux_used_units(aux_src[(u64)i * 16].x & 0xffu);
     s_sums[t] = my_val;
     __syncthreads();
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(ZKW_PACK_THREADS) zkw_pack_kernel(zkw_pack_arg
           const u32 i = 4u * g + (u32)j;
           const bool in = g < q4 && i < n_mem;
           h[j] = in ? mem_hdr[i] : make_uint4(0, 0, 0, 0);
-          has[j] = in && ((h[j].w >> 16) & ZKW_MQ_TYPE_MASK) != ZKW_MEM_CODE;
+          has[j] = in && zkw_pack_has_value(h[j].w, A.flags);
         }
         if (g < q4) {
           pl_page[g] = make_uint4(h[0].y, h[1].y, h[2].y, h[3].y);

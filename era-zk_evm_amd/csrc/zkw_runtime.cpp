@@ -59,6 +59,7 @@ struct zkw_ctx {
   std::string last_error;
   // test hooks / ablations (zkw_ctx_set_option; the environment is read once, in zkw_ctx_create)
   uint32_t opt_debug_flags = 0, opt_reset_skip = 0, opt_waves_per_group = 0, opt_lanes_per_wave = 0, opt_pack_blocks = 0;
+  bool opt_keep_restaged_heaps = false, opt_read_values = false;
   bool opt_no_inline_decommit = false, opt_debug_sync = false, opt_no_graph = false;
   // digests of code blobs already hashed on this context, keyed by a 128-bit content hash + length: batches that
   // share bytecode (the usual case) skip the sequential blob chain (~0.1 s for a 2000-word blob) at upload
@@ -103,6 +104,12 @@ struct CodeInputs {
 struct BatchInputs {
   std::vector<zkw_vm_local_state> states;  // [n]
   std::shared_ptr<const CodeInputs> code;
+  // the heap images the step ran on ([n][heap_words], zero-padded) — what the shadow memory of the rebuild starts from when the
+  // values of memory reads did not travel (ZKW_PACK_NO_READ_VALUES); heaps_known = false: the host does not hold them (a restage
+  // with heap images without ZKW_OPT_KEEP_RESTAGED_HEAPS) and every value has to travel
+  std::shared_ptr<const std::vector<zkw_u256>> heaps;
+  uint32_t heap_words = 0;
+  bool heaps_known = false;
 };
 
 struct WaveTrace {  // de-interleaved streams of one wave
@@ -283,6 +290,8 @@ int zkw_ctx_set_option(zkw_ctx* c, uint32_t option, uint64_t value) {
       c->opt_waves_per_group = (uint32_t)value;
       break;
     case ZKW_OPT_LANES_PER_WAVE: c->opt_lanes_per_wave = (uint32_t)value; break;
+    case ZKW_OPT_KEEP_RESTAGED_HEAPS: c->opt_keep_restaged_heaps = value != 0; break;
+    case ZKW_OPT_READ_VALUES: c->opt_read_values = value != 0; break;
     case ZKW_OPT_PACK_BLOCKS: c->opt_pack_blocks = (uint32_t)value; break;
     default: c->last_error = "unknown option"; return ZKW_ERR_INVALID;
   }
@@ -1047,6 +1056,16 @@ int zkw_batch_upload(zkw_batch* b) {
     in->states.resize(b->n);
     for (uint32_t i = 0; i < b->n; i++) in->states[i] = b->staged[i].state;
     in->code = code;
+    {
+      auto hv = std::make_shared<std::vector<zkw_u256>>((size_t)b->n * b->heap_image_words);
+      for (uint32_t i = 0; i < b->n; i++) {
+        const auto& h = b->staged[i].heap;
+        if (!h.empty()) std::memcpy(hv->data() + (size_t)i * b->heap_image_words, h.data(), std::min<size_t>(h.size(), b->heap_image_words) * 32);
+      }
+      in->heaps = hv;
+      in->heap_words = b->heap_image_words;
+      in->heaps_known = true;  // (an upload is refused while the staged heaps are older than a restage's)
+    }
     b->inputs = in;
   }
   b->uploaded = true;
@@ -1469,6 +1488,7 @@ int zkw_batch_get_stats(zkw_batch* b, zkw_run_stats* out) {
 // waves at once.
 // ---------------------------------------------------------------------------------------------------------------------
 struct WaveView {  // host pointers to the packed data of one wave
+  uint32_t flags = 0;  // ZKW_PACK_* of the block
   uint32_t L = 0, max_cyc = 0, n_delta = 0, n_mem = 0, n_val = 0, n_log = 0, n_aux = 0, aux_units = 0;
   const uint32_t* dir = nullptr;
   const uint4 *tails = nullptr, *dlo = nullptr, *dhi = nullptr;
@@ -1476,8 +1496,9 @@ struct WaveView {  // host pointers to the packed data of one wave
   const uint4 *v_lo = nullptr, *v_hi = nullptr, *log = nullptr, *aux = nullptr;
 };
 
-static bool wave_view(const uint4* block, const zkw_pack_wave& e, uint32_t L, WaveView& v) {
+static bool wave_view(const uint4* block, const zkw_pack_wave& e, uint32_t L, uint32_t flags, WaveView& v) {
   if (e.off == 0) return false;
+  v.flags = flags;
   v.L = L; v.max_cyc = e.max_cyc; v.n_delta = e.n_delta; v.n_mem = e.n_mem; v.n_val = e.n_val; v.n_log = e.n_log; v.n_aux = e.n_aux; v.aux_units = e.aux_units;
   const uint4* d = block + e.off;
   v.dir = (const uint32_t*)d; d += e.max_cyc + 1;
@@ -1560,6 +1581,64 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
       slow[l] = Slow{0, 0, 0, 0, 0};
     }
   }
+  // Shadow memory (blocks packed with ZKW_PACK_NO_READ_VALUES): what a read returns is what was written there before — the
+  // heap image the instance was staged with (page base + 2 of the frame it started in: zkw_batch_set_heap), zero on every other
+  // page (SimpleMemory hands out zero-filled pages, memory.rs:15-148; `.get(index).unwrap_or(zero)` :490-495), then every write
+  // query of the lane in stream order.  A page is a dense array grown on demand with one "written" bit per word; the image is
+  // never copied: a word that was not written reads through to it.
+  const bool shadowed = (v.flags & ZKW_PACK_NO_READ_VALUES) != 0;
+  struct ShadowPage {
+    uint32_t page = 0;
+    const zkw_u256* image = nullptr;  // what unwritten words read as (nullptr: zero)
+    uint32_t image_words = 0;
+    std::vector<zkw_u256> w;
+    std::vector<uint8_t> written;
+  };
+  struct Shadow {
+    std::vector<ShadowPage> pages;
+    uint32_t last = 0;
+    ShadowPage* find(uint32_t page) {
+      if (last < pages.size() && pages[last].page == page) return &pages[last];
+      for (uint32_t i = 0; i < pages.size(); i++)
+        if (pages[i].page == page) { last = i; return &pages[i]; }
+      return nullptr;
+    }
+    void read(uint32_t page, uint32_t index, zkw_u256* out) {
+      const ShadowPage* p = find(page);
+      if (p) {
+        if (index < p->written.size() && p->written[index]) { *out = p->w[index]; return; }
+        if (index < p->image_words) { *out = p->image[index]; return; }
+      }
+      std::memset(out, 0, sizeof *out);
+    }
+    void write(uint32_t page, uint32_t index, const zkw_u256& val) {
+      ShadowPage* p = find(page);
+      if (!p) {
+        pages.emplace_back();
+        last = (uint32_t)pages.size() - 1;
+        p = &pages[last];
+        p->page = page;
+      }
+      if (index >= p->w.size()) {
+        const size_t n = std::max<size_t>((size_t)index + 1, p->w.size() * 2);
+        p->w.resize(n);
+        p->written.resize(n, 0);
+      }
+      p->w[index] = val;
+      p->written[index] = 1;
+    }
+  };
+  std::vector<Shadow> shadow(shadowed ? L : 0);
+  if (shadowed && in.heaps && in.heap_words)
+    for (uint32_t l = 0; l < L; l++) {
+      const uint32_t inst = w * L + l;
+      if (inst >= n_inst) continue;
+      ShadowPage pg;
+      pg.page = in.states[inst].current.base_memory_page + 2u;  // heap_page_from_base of the frame the image was staged for
+      pg.image = in.heaps->data() + (size_t)inst * in.heap_words;
+      pg.image_words = in.heap_words;
+      shadow[l].pages.push_back(std::move(pg));
+    }
   std::vector<uint32_t> mask(L), cnt_m(L + 1), cnt_l(L + 1), cnt_a(L + 1), fill(L);
   std::vector<zkw_mem_query> cm;
   std::vector<zkw_log_query> cl;
@@ -1607,12 +1686,13 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
     for (uint32_t l = 0; l < L; l++) { cnt_m[l + 1] += cnt_m[l]; cnt_l[l + 1] += cnt_l[l]; cnt_a[l + 1] += cnt_a[l]; }
     cm.resize(cnt_m[L]); cl.resize(cnt_l[L]); ca.resize(cnt_a[L]);
     // (memory queries of earlier stream positions that belong to no cycle range cannot exist: the ranges tile the stream)
-    for (; pm < m0; pm++) if (((v.m_misc[pm] >> 16) & ZKW_MQ_TYPE_MASK) != ZKW_MEM_CODE) vpos++;
+    for (; pm < m0; pm++) if (zkw_pack_has_value(v.m_misc[pm], v.flags)) vpos++;
     std::fill(fill.begin(), fill.end(), 0u);
     for (uint32_t p = m0; p < m1; p++, pm++) {
       const uint32_t misc = v.m_misc[p], l = misc & 0xffu, meta = (misc >> 16) & 0xffu;
       const bool is_code = (meta & ZKW_MQ_TYPE_MASK) == ZKW_MEM_CODE;
-      const uint32_t vi = is_code ? 0u : vpos++;
+      const bool has_value = zkw_pack_has_value(misc, v.flags);
+      const uint32_t vi = has_value ? vpos++ : 0u;
       if (!live(l)) continue;
       zkw_mem_query& q = cm[cnt_m[l] + fill[l]++];
       const uint32_t cycle_ts = slow[l].timestamp;  // the lane's timestamp at the start of this cycle
@@ -1620,8 +1700,10 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
       q.page = v.m_page[p]; q.index = v.m_index[p];
       q.lane = 0; q.seq = (uint8_t)(misc >> 8); q.meta = (uint8_t)meta; q.reserved0 = 0;
       if (is_code) code_word(l, q.page, q.index, &q.value);
+      else if (!has_value) shadow[l].read(q.page, q.index, &q.value);  // a read under ZKW_PACK_NO_READ_VALUES
       else if (vi < v.n_val) { std::memcpy(&q.value.l[0], &v.v_lo[vi], 16); std::memcpy(&q.value.l[2], &v.v_hi[vi], 16); }
       else std::memset(&q.value, 0, sizeof q.value);
+      if (shadowed && (meta & ZKW_MQ_RW)) shadow[l].write(q.page, q.index, q.value);
     }
     std::fill(fill.begin(), fill.end(), 0u);
     for (uint32_t p = l0; p < l1; p++) {
@@ -1713,6 +1795,15 @@ static void fill_final_state(zkw_vm_local_state* out, const zkw_dev_scalars& sc,
   fs.current = cur.e;
 }
 
+// The link flags of a block: memory reads travel without their values when the host holds, for EVERY batch of the block, the heap
+// images the step ran on (the shadow memory of walk_wave starts from them)
+static uint32_t pack_flags(const zkw_ctx* c, zkw_batch* const* bs, uint32_t n) {
+  if (c->opt_read_values) return 0;
+  for (uint32_t i = 0; i < n; i++)
+    if (!bs[i]->inputs || !bs[i]->inputs->heaps_known) return 0;
+  return ZKW_PACK_NO_READ_VALUES;
+}
+
 // The on-demand path of zkw_batch_get_instance_trace: ONE wave of a synced batch through the pack kernel into a pinned block
 // of the batch (grown on demand), then the same rebuild as a delivered step — every parity test that reads a trace runs the
 // pack kernel and the link-format rebuild.
@@ -1748,6 +1839,7 @@ static int build_wave(zkw_batch* b, uint32_t w) {
   A.wave_base[1] = b->n_waves;
   A.dst = b->h_pack; A.state = b->d_pack_state.p; A.dst_units = (uint32_t)need; A.n_batches = 1;
   A.wave_table = ZKW_PACK_HEADER_UNITS + ZKW_PACK_BATCH_UNITS; A.with_instances = 0; A.only_wave = w;
+  A.flags = pack_flags(c, &b, 1);
   HIP_TRY(c, zkw_launch_pack(&A, (uint32_t)c->wave_width, 1, b->run_stream));
   uint32_t state1[4] = {0, 0, 0, 0};
   HIP_TRY(c, hipMemcpyAsync(state1, b->d_pack_state.p, sizeof state1, hipMemcpyDeviceToHost, b->run_stream));
@@ -1755,7 +1847,7 @@ static int build_wave(zkw_batch* b, uint32_t w) {
   zkw_pack_wave e;
   std::memcpy(&e, b->h_pack + A.wave_table, sizeof e);
   WaveView v;
-  if (state1[1] != 0 || !wave_view(b->h_pack, e, L, v)) {
+  if (state1[1] != 0 || !wave_view(b->h_pack, e, L, A.flags, v)) {
     c->last_error = "pack kernel: the wave did not fit its block";
     return ZKW_ERR_LIMIT;
   }
@@ -1871,7 +1963,7 @@ static bool delivery_wave(const DeliverySlot& sl, uint32_t bi, uint32_t w, WaveV
   const zkw_pack_batch* pbs = (const zkw_pack_batch*)(sl.h + ZKW_PACK_HEADER_UNITS);
   const zkw_pack_batch& pb = pbs[bi];
   const zkw_pack_wave* wt = (const zkw_pack_wave*)(sl.h + sl.wave_table);
-  if (!wave_view(sl.h, wt[pb.first_wave + w], pb.L, v)) return false;
+  if (!wave_view(sl.h, wt[pb.first_wave + w], pb.L, ((const zkw_pack_header*)sl.h)->flags, v)) return false;
   const zkw_dev_scalars* sc = (const zkw_dev_scalars*)(sl.h + pb.scalars_off);
   for (uint32_t l = 0; l < pb.L; l++) {
     const uint32_t i = w * pb.L + l;
@@ -2038,6 +2130,7 @@ int zkw_delivery_submit(zkw_delivery* d, zkw_batch* const* batches, uint32_t n, 
   hd->magic = ZKW_PACK_MAGIC; hd->version = ZKW_PACK_VERSION; hd->n_batches = n; hd->n_waves = waves; hd->fixed_units = (uint32_t)at; hd->with_instances = 1;
   hd->used_units = (uint32_t)at;  // the allocation cursor starts behind the fixed part (copied to the device below, and back behind the kernel)
   hd->overflow = 0;
+  hd->flags = A.flags = pack_flags(c, batches, n);
   A.batches = sl.d_batches; A.dst = sl.d; A.state = sl.d_state; A.dst_units = (uint32_t)sl.units; A.n_batches = n;
   A.wave_table = (uint32_t)wave_table; A.with_instances = 1; A.only_wave = 0xffffffffu;
   hipStream_t rs = (hipStream_t)run_stream;
@@ -2257,6 +2350,14 @@ int zkw_batch_restage(zkw_batch* b, const zkw_vm_local_state* states, const zkw_
     auto in = std::make_shared<BatchInputs>();
     in->states.assign(states, states + n);
     in->code = b->inputs->code;
+    in->heap_words = himg;
+    if (!heap_words) {  // the images stay what they were
+      in->heaps = b->inputs->heaps;
+      in->heaps_known = b->inputs->heaps_known;
+    } else if (c->opt_keep_restaged_heaps) {
+      in->heaps = std::make_shared<std::vector<zkw_u256>>((const zkw_u256*)(b->h_stage + heap_off), (const zkw_u256*)(b->h_stage + heap_off) + (size_t)n * himg);
+      in->heaps_known = true;
+    }
     b->inputs = in;
   }
   if (heap_words) b->heaps_restaged = true;

@@ -446,6 +446,10 @@ int zkw_ctx_set_isa(zkw_ctx* ctx, const zkw_isa_table* table); /* copies */
 #define ZKW_OPT_WAVES_PER_GROUP 7u     /* 1 .. 8 waves per workgroup of the cycle kernel instead of the choice made per launch (0) */
 #define ZKW_OPT_LANES_PER_WAVE 8u      /* overrides zkw_limits.lanes_per_wave (batches created afterwards) */
 #define ZKW_OPT_PACK_BLOCKS 9u         /* workgroups of the pack kernel of deliveries created afterwards (0 = 64: the link, not the chip, bounds it) */
+#define ZKW_OPT_KEEP_RESTAGED_HEAPS 10u /* 1 = zkw_batch_restage keeps a host copy of the heap images it is given, so that steps run on them are
+                                          delivered without the values of memory reads too (link format: csrc/zkw_pack.h); 0 = no copy, such steps
+                                          carry every value */
+#define ZKW_OPT_READ_VALUES 11u        /* 1 = the values of memory reads always travel (the round-5 link format: A/B, tests) */
 int zkw_ctx_set_option(zkw_ctx* ctx, uint32_t option, uint64_t value);
 
 int zkw_batch_create(zkw_ctx* ctx, uint32_t n_instances, const zkw_limits* limits, zkw_batch** out);
