@@ -582,6 +582,13 @@ def measure(dev, prod, isa, args, rank, world, comm, collective, transport, with
         }
         if with_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(isa, args, prod)
+            # ratios against the LARGEST CPU figure of the leg (burst, sustained or ideal socket) — kernel-side only here; the host
+            # legs (delivered / end_to_end) add theirs where they are measured
+            den = out["cpu_baseline"]["speedup_denominator"]
+            out["speedup_vs_cpu"] = {"denominator": den, "witness_in_hbm": value / den}
+            for leg in ("delivered", "end_to_end"):  # the host legs: what a caller with a HOST tracer gets
+                if isinstance(out.get(leg), dict) and out[leg].get("cycles_per_s"):
+                    out["speedup_vs_cpu"][leg] = out[leg]["cycles_per_s"] / den
         if args.cfg == 3:
             cfg3_line(out, args, flow, prod, isa, value, elapsed, k_ms, k_ms_alone, batches_per_launch, world)
     if os.environ.get("ZKW_BENCH_MEMINFO") and dev.name == "gpu":
@@ -1131,6 +1138,17 @@ def _cpu_topology():
     return model, out
 
 
+def _physical_cores(cpus):
+    """distinct cores among the logical cpus of one package (the list has one hardware thread per core first)"""
+    base, seen = "/sys/devices/system/cpu", set()
+    for cpu in cpus:
+        try:
+            seen.add(int(open("%s/cpu%d/topology/core_id" % (base, cpu)).read()))
+        except (OSError, ValueError):
+            seen.add(cpu)
+    return max(1, len(seen))
+
+
 def _oracle_timed(orc, isa, args, cpus, n_inst, min_s=3.0, max_reps=40):
     """best-of-N wall time of the oracle on `n_inst` instances of args' workload with persistent workers pinned to `cpus`"""
     import ctypes as C
@@ -1150,6 +1168,30 @@ def _oracle_timed(orc, isa, args, cpus, n_inst, min_s=3.0, max_reps=40):
         reps += 1
     b.destroy()
     return {"value": n_inst * wl.n_cycles / (best * 1e-3), "threads": len(cpus), "instances": n_inst, "best_ms": best, "runs": reps}
+
+
+def _oracle_sustained(orc, isa, args, cpus, n_inst, seconds=3.0):
+    """MEAN rate of the oracle over >= `seconds` of back-to-back runs on persistent workers pinned to `cpus` — what a caller gets
+    that keeps the CPU path busy (a cgroup quota throttles a burst of more threads than it covers after ~10 ms of each 100 ms
+    period: a best-of-N of short runs measures the burst, this measures the steady state)"""
+    import ctypes as C
+    a = copy.copy(args)
+    a.instances = n_inst
+    wl = make_workload(a, isa, 0)
+    wl.limits["max_cycles"] = wl.n_cycles
+    b = orc.create_batch(wl)
+    arr = (C.c_int32 * len(cpus))(*cpus)
+    orc.lib.zkwo_batch_set_pool(b.h, C.c_uint32(len(cpus)), arr, C.c_uint32(len(cpus)))
+    b.reset(); b.run(wl.n_cycles)  # warm-up
+    busy_ms, runs, t0 = 0.0, 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds or runs < 3:
+        b.reset()  # rebuilds the VMs and reserves the recorders (untimed)
+        b.run(wl.n_cycles)
+        busy_ms += float(b.stats()["kernel_ms"])
+        runs += 1
+    wall = time.perf_counter() - t0
+    b.destroy()
+    return {"value": runs * n_inst * wl.n_cycles / (busy_ms * 1e-3), "threads": len(cpus), "instances": n_inst, "runs": runs, "busy_s": busy_ms * 1e-3, "wall_s": wall}
 
 
 def cpu_socket_rate(isa, args):
@@ -1187,6 +1229,16 @@ def cpu_baseline(isa, args, prod=None):
     else:
         res["whole_box"] = res["one_socket"]
     phys = len(set(all_cpus))
+    # The honest denominators.  (1) sustained: the MEAN over >= 3 s of continuous work on exactly the threads the container is
+    # entitled to — min(cgroup quota, physical cores of socket 0), one per core — not the best of a few millisecond bursts of
+    # 128 threads under a 16-CPU quota.  (2) ideal_one_socket: single core x the physical cores of one socket — what the socket
+    # would do without the quota if the path scaled perfectly (it has no shared state; memory bandwidth is the only reason it
+    # would not).  Speed-ups are quoted against the LARGEST of all the figures (`speedup_denominator`).
+    cores_socket0 = _physical_cores(socket0)
+    quota = _cpu_quota()
+    n_sus = max(1, min(cores_socket0, int(quota) if quota else cores_socket0))
+    res["sustained"] = _oracle_sustained(orc, isa, args, socket0[:n_sus], max(64 * n_sus, 1024))
+    ideal = res["one_core"]["value"] * cores_socket0
     # `value` is the best the host did in this leg: the two-socket run varies from run to run (110-450 M cycles/s on these
     # boxes) and is often SLOWER than one socket; the CPU should not be understated by that
     top = max((res["whole_box"], res["one_socket"]), key=lambda r: r["value"])
@@ -1195,11 +1247,16 @@ def cpu_baseline(isa, args, prod=None):
            "single_core_value": res["one_core"]["value"], "single_socket_value": res["one_socket"]["value"], "single_socket_threads": res["one_socket"]["threads"],
            "cpu_model": model, "nproc": os.cpu_count(), "packages": len(packages), "logical_cpus_used": phys,
            "scaling_all_over_one": res["whole_box"]["value"] / res["one_core"]["value"],
+           "sustained_value": res["sustained"]["value"], "sustained_threads": res["sustained"]["threads"], "sustained_busy_s": res["sustained"]["busy_s"],
+           "sustained_runs": res["sustained"]["runs"], "physical_cores_per_socket": cores_socket0, "ideal_one_socket_value": ideal,
+           "speedup_denominator": max(top["value"], res["sustained"]["value"], ideal),
            "sample": "cfg-%d tape, %d cycles per instance: %d instances on one core, %d on socket 0 (%d threads), %d on the whole box (%d threads); "
                      "persistent pinned workers, >= 64 instances each, recorders pre-reserved, best of %d-%d runs; the whole leg took %.1f s"
                      % (args.cfg, args.cycles, res["one_core"]["instances"], res["one_socket"]["instances"], res["one_socket"]["threads"],
                         res["whole_box"]["instances"], res["whole_box"]["threads"], min(r["runs"] for r in res.values()), max(r["runs"] for r in res.values()),
-                        time.perf_counter() - t_leg)}
+                        time.perf_counter() - t_leg)
+                     + "; sustained: %d back-to-back runs of %d instances on %d pinned threads (one per core, within the quota), %.1f s busy, mean rate"
+                     % (res["sustained"]["runs"], res["sustained"]["instances"], res["sustained"]["threads"], res["sustained"]["busy_s"])}
     # the same leg validates the product against the checker on a fresh small batch of the bench's workload: every
     # queue commitment of every instance and the full traces of a few instances, bit for bit
     if prod is not None:
