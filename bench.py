@@ -989,10 +989,21 @@ def other_configs(dev, prod, isa, base_args, comm, transport, with_cpu):
                                   "cycle_kernel_frac": rl["frac"], "cycle_kernel_achieved": rl["achieved"], "cycle_kernel_share_of_the_step": share,
                                   "dominant_kernel": "zkw_cycle_kernel" if share >= 0.5 or not (a.commit_mask & 3) else "zkw_chain_kernel (memory / log queue commitments: one sponge permutation per memory query, three per log query)"},
                      "checked": line["checked"]}
-            if share < 0.5 and (a.commit_mask & 3):  # the chains' own bound: the chip's permutation rate (profiles/tools/perm_probe.hip: 3.56 G/s)
+            if share < 0.5 and (a.commit_mask & 3):
+                # The chains' own bound, derived from instructions and not from this build's permutation kernel: a permutation of
+                # the sponge is 472 Goldilocks multiplications, a 64 x 64 -> 128 bit product is at least four 32 x 32 -> 64
+                # multiply-adds (v_mad_u64_u32; the reduction mod 2^64 - 2^32 + 1 and the linear layers add 32-bit ALU work on
+                # top), and the chip issues 35.29 T of those per second (measured: profiles/r02_perm_probe.txt, all CUs busy).
+                # peak = 35.29e12 / (472 * 4) = 18.7 G permutations/s.  For orientation only: the build's own permutation kernel
+                # running alone does 3.56 G/s (~12 k instructions per permutation, VALU-issue bound) — that is a
+                # self-comparison, not a roofline.
                 perms = float(line["stats_per_step"]["mem_queries"]) + 3.0 * float(line["stats_per_step"]["log_queries"])
                 rate = perms / (line["ms_per_step"] * 1e-3)
-                entry["roofline"]["dominant_bound"] = {"bound": "integer ALU (Goldilocks sponge permutations)", "permutations_per_s": rate, "peak_permutations_per_s": 3.56e9, "frac": rate / 3.56e9}
+                mads_min, chip_mads = 472 * 4, 35.29e12
+                entry["roofline"]["dominant_bound"] = {"bound": "v_mad_u64_u32 issue (Goldilocks sponge permutations: 472 field multiplications of >= 4 multiply-adds each)",
+                                                       "permutations_per_s": rate, "mads_per_permutation_min": mads_min, "chip_mads_per_s_measured": chip_mads,
+                                                       "peak_permutations_per_s": chip_mads / mads_min, "frac": rate / (chip_mads / mads_min),
+                                                       "own_permutation_kernel_alone_per_s": 3.56e9, "frac_of_own_kernel_alone": rate / 3.56e9}
             if a.cfg == 3:
                 entry["roofline"]["lone_batch_kernel_ms"] = line["roofline"]["lone_batch_kernel_ms"]
                 entry["roofline"]["keccak_f_per_s"] = line["roofline"]["keccak_f_per_s"]
