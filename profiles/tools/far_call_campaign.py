@@ -13,12 +13,24 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 from era_zk_evm_amd import capi as K, synth  # noqa: E402
+
+
+def _campaign_backend():
+    """the product (libzkw.so on a GPU) — or, with ZKW_CAMPAIGN_BACKEND=emu64 / emu1, the same sources compiled for the CPU
+    (tests/emu: 64-lane waves on the SIMT engine / one-lane waves): the campaigns then run without a GPU"""
+    which = os.environ.get("ZKW_CAMPAIGN_BACKEND", "")
+    if which in ("emu64", "emu1"):
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "emu"))
+        import build_emu
+        return K.Backend(build_emu.build(wave=64 if which == "emu64" else 1), "zkw_")
+    return K.load_product()
+
 from tests._oracle import load_oracle  # noqa: E402
 from test_emu_parity import compare_pages  # noqa: E402
 
 first, count = int(sys.argv[1], 0), int(sys.argv[2])
 isa = K.Isa()
-prod = K.load_product().open(isa)
+prod = _campaign_backend().open(isa)
 orc = load_oracle().open(isa)
 bad = 0
 t0 = time.time()

@@ -10,6 +10,18 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np  # noqa: E402
 from era_zk_evm_amd import capi as K, synth  # noqa: E402
+
+
+def _campaign_backend():
+    """the product (libzkw.so on a GPU) — or, with ZKW_CAMPAIGN_BACKEND=emu64 / emu1, the same sources compiled for the CPU
+    (tests/emu: 64-lane waves on the SIMT engine / one-lane waves): the campaigns then run without a GPU"""
+    which = os.environ.get("ZKW_CAMPAIGN_BACKEND", "")
+    if which in ("emu64", "emu1"):
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "emu"))
+        import build_emu
+        return K.Backend(build_emu.build(wave=64 if which == "emu64" else 1), "zkw_")
+    return K.load_product()
+
 from tests._oracle import load_oracle  # noqa: E402
 
 first, count = int(sys.argv[1], 0), int(sys.argv[2])
@@ -18,7 +30,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(
 import _metamorphic as M  # noqa: E402
 # round 4: every fourth seed under a renumbered, every fourth under an estranged ISA table (tests/_metamorphic.py)
 TABLES = [("default", K.Isa()), ("renumbered", M.renumbered(0x7AB1E)), ("estranged", M.estranged(0xE57A))]
-CTX = {name: (isa_, K.load_product().open(isa_), load_oracle().open(isa_)) for name, isa_ in TABLES}
+CTX = {name: (isa_, _campaign_backend().open(isa_), load_oracle().open(isa_)) for name, isa_ in TABLES}
 bad = 0
 t0 = time.time()
 for k in range(count):
