@@ -2630,7 +2630,7 @@ ZD void exec_decoded(ZKW_KP P, Shared& sh, RF& rf, Lane& s, const Decoded& d, bo
       }
       case ZKW_OP_DIV: {  // div.rs:35-75
         s.pc = ps.new_pc;
-        if (u256_is_zero(ps.src1)) {
+        ZKW_DIV_IF(u256_is_zero(ps.src1)) {  // (the division holds a ballot: u256_divmod skips digit steps no lane needs)
           if (set_flags) set_flags3(s, true, false, false);
           dst0_update(P, sh, rf, s, ps.dst0, d.dst0, u256_zero(), false);
           reg_write(sh, rf, s, d.dst1, u256_zero(), false);

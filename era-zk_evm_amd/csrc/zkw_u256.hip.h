@@ -291,11 +291,15 @@ ZD void u256_divmod(const u256& a, const u256& b, u256& q, u256& r) {
 #pragma unroll
     for (int i = 8; i >= 1; i--) rem[i] = rem[i - 1];
     rem[0] = ulo.w[j];
-#ifdef __HIP_DEVICE_COMPILE__
+#if defined(__HIP_DEVICE_COMPILE__) || (defined(ZKW_EMU_WAVE) && ZKW_EMU_WAVE > 1) /* (real waves: the device, or the 64-lane emulation of tests/emu) */
     // a step whose window is below the divisor in every lane of the wave (top limb of the window zero, the next one below the
     // divisor's top limb) produces the digit 0 and leaves the window as it is: skipped as a scalar branch.  Operands of similar
     // size — the common case — need one or two of the eight steps.
+#ifdef __HIP_DEVICE_COMPILE__
     if (__builtin_amdgcn_ballot_w64((rem[8] != 0) | (rem[7] >= v.w[7])) == 0) {
+#else
+    if (__ballot((rem[8] != 0) | (rem[7] >= v.w[7])) == 0) {
+#endif
       q.w[j] = 0;
       continue;
     }

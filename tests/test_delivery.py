@@ -173,7 +173,7 @@ def test_restage_gives_fresh_inputs(oracle, emu, isa):
     bo.destroy(); b.destroy()
 
 
-def test_restage_after_a_ragged_upload(oracle, emu, isa):
+def check_restage_after_a_ragged_upload(oracle, emu, isa):
     """Heap images of different lengths per instance at upload (one word for instance 0, none for instance 1), full images at
     the restage: every word of the restaged images must be readable — the page marks follow the NEW images, not the lengths
     the instances were uploaded with (a restaged word beyond an instance's uploaded length used to read as zero)."""
@@ -197,7 +197,7 @@ def test_restage_after_a_ragged_upload(oracle, emu, isa):
     bo.destroy(); b.destroy()
 
 
-def test_reads_travel_without_their_values(oracle, emu, isa):
+def check_reads_travel_without_their_values(oracle, emu, isa):
     """Link format 2: memory reads cross the link as headers only, the rebuild fills their values from a shadow of the pages
     (staged heap image + the writes of the stream).  Every workload, both ways (ZKW_OPT_READ_VALUES = 1 is the old format):
     the same traces, fewer bytes — cfg 2 on 64-lane waves: 84.6 B per VM cycle instead of 104.2."""
@@ -246,7 +246,7 @@ def test_reads_travel_without_their_values(oracle, emu, isa):
         b.destroy()
 
 
-def test_a_ticket_outlives_the_restage_and_the_destruction_of_its_batch(oracle, emu, isa):
+def check_a_ticket_outlives_the_restage_and_the_destruction_of_its_batch(oracle, emu, isa):
     """A delivered step is rebuilt onto the inputs IT ran on: restaging the batch (the natural call order of a pipeline:
     zkw_delivery_order_after, then the next inputs) before the ticket is read, and even destroying the batch, must change
     nothing of what the ticket returns."""
@@ -333,3 +333,16 @@ def check_end_to_end_pipeline(oracle, prod, isa, n_instances, n_groups=3, per_gr
 
 def test_end_to_end_pipeline_restage_run_deliver_replay(oracle, emu, isa):
     check_end_to_end_pipeline(oracle, emu, isa, n_instances=4)
+
+
+# (the bodies above take any backend: tests/test_gpu_parity.py runs them on the device)
+def test_restage_after_a_ragged_upload(oracle, emu, isa):
+    check_restage_after_a_ragged_upload(oracle, emu, isa)
+
+
+def test_reads_travel_without_their_values(oracle, emu, isa):
+    check_reads_travel_without_their_values(oracle, emu, isa)
+
+
+def test_a_ticket_outlives_the_restage_and_the_destruction_of_its_batch(oracle, emu, isa):
+    check_a_ticket_outlives_the_restage_and_the_destruction_of_its_batch(oracle, emu, isa)

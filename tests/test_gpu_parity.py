@@ -982,3 +982,22 @@ def test_restage_gives_fresh_inputs_on_the_device(oracle, product, isa):
             assert ok, "seed %x instance %d: %s" % (seed, i, why)
         bo.destroy()
     b.destroy()
+
+
+# ---- round 6: the host paths that changed without a GPU to run them on (bodies shared with tests/test_delivery.py, where they run on
+# both CPU emulation builds) ----
+def test_reads_travel_without_their_values_on_gpu(oracle, product, isa):
+    """link format 2 through the 256-thread pack kernel on the device: memory reads without values, rebuilt from the shadow memory ==
+    the oracle, for every workload and both settings of ZKW_OPT_READ_VALUES"""
+    from test_delivery import check_reads_travel_without_their_values
+    check_reads_travel_without_their_values(oracle, product, isa)
+
+
+def test_restage_after_a_ragged_upload_on_gpu(oracle, product, isa):
+    from test_delivery import check_restage_after_a_ragged_upload
+    check_restage_after_a_ragged_upload(oracle, product, isa)
+
+
+def test_a_ticket_outlives_the_restage_and_the_destruction_of_its_batch_on_gpu(oracle, product, isa):
+    from test_delivery import check_a_ticket_outlives_the_restage_and_the_destruction_of_its_batch
+    check_a_ticket_outlives_the_restage_and_the_destruction_of_its_batch(oracle, product, isa)
