@@ -1584,15 +1584,14 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
   // Shadow memory (blocks packed with ZKW_PACK_NO_READ_VALUES): what a read returns is what was written there before — the
   // heap image the instance was staged with (page base + 2 of the frame it started in: zkw_batch_set_heap), zero on every other
   // page (SimpleMemory hands out zero-filled pages, memory.rs:15-148; `.get(index).unwrap_or(zero)` :490-495), then every write
-  // query of the lane in stream order.  A page is a dense array grown on demand with one "written" bit per word; the image is
-  // never copied: a word that was not written reads through to it.
+  // query of the lane in stream order.  A page is a dense array grown on demand (zero-filled); the page that holds the staged heap
+  // image starts as a copy of it, made when the lane first touches the page.
   const bool shadowed = (v.flags & ZKW_PACK_NO_READ_VALUES) != 0;
   struct ShadowPage {
     uint32_t page = 0;
-    const zkw_u256* image = nullptr;  // what unwritten words read as (nullptr: zero)
+    const zkw_u256* image = nullptr;  // the staged heap image of this page (copied into `w` when the page is first touched)
     uint32_t image_words = 0;
-    std::vector<zkw_u256> w;
-    std::vector<uint8_t> written;
+    std::vector<zkw_u256> w;          // dense; words at and beyond w.size() are zero
   };
   struct Shadow {
     std::vector<ShadowPage> pages;
@@ -1603,11 +1602,17 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
         if (pages[i].page == page) { last = i; return &pages[i]; }
       return nullptr;
     }
+    static void materialise(ShadowPage* p) {
+      if (p->image) {
+        p->w.assign(p->image, p->image + p->image_words);
+        p->image = nullptr;
+      }
+    }
     void read(uint32_t page, uint32_t index, zkw_u256* out) {
-      const ShadowPage* p = find(page);
+      ShadowPage* p = find(page);
       if (p) {
-        if (index < p->written.size() && p->written[index]) { *out = p->w[index]; return; }
-        if (index < p->image_words) { *out = p->image[index]; return; }
+        materialise(p);
+        if (index < p->w.size()) { *out = p->w[index]; return; }
       }
       std::memset(out, 0, sizeof *out);
     }
@@ -1619,13 +1624,13 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
         p = &pages[last];
         p->page = page;
       }
+      materialise(p);
       if (index >= p->w.size()) {
-        const size_t n = std::max<size_t>((size_t)index + 1, p->w.size() * 2);
-        p->w.resize(n);
-        p->written.resize(n, 0);
+        zkw_u256 zero;
+        std::memset(&zero, 0, sizeof zero);
+        p->w.resize(std::max<size_t>((size_t)index + 1, p->w.size() * 2), zero);
       }
       p->w[index] = val;
-      p->written[index] = 1;
     }
   };
   std::vector<Shadow> shadow(shadowed ? L : 0);
