@@ -917,15 +917,19 @@ ZD u256 code_read(const Shared& sh, const Lane& s, u32 idx) {
 // waited ~1000 clocks, 90 times per 256 cycles).  Code blobs are read-only for the lifetime of a batch, so the scalar
 // cache cannot hold a stale word.  Lanes that disagree on (blob, length, word index) take the per-lane path.
 ZD u256 code_fetch(const Shared& sh, const Lane& s, u32 idx) {
-#ifdef __HIP_DEVICE_COMPILE__
+#ifdef ZKW_WIDE
   const u32 c_len = CF(sh, s, CF_CODE_LEN), c_off = CF(sh, s, CF_CODE_OFF);
   const u32 u_len = (u32)__builtin_amdgcn_readfirstlane((int)c_len), u_off = (u32)__builtin_amdgcn_readfirstlane((int)c_off);
   const u32 u_idx = (u32)__builtin_amdgcn_readfirstlane((int)idx);
   if (ZKW_LIKELY(zkw_ballot((c_len != u_len) | (c_off != u_off) | (idx != u_idx)) == 0)) {  // wave-uniform
     u256 v = u256_zero();
     if (ZKW_LIKELY(u_idx < u_len)) {
+#ifdef __HIP_DEVICE_COMPILE__
       typedef u32 zkw_v8u __attribute__((ext_vector_type(8)));
       const zkw_v8u w = *(const ZKW_CONST_AS zkw_v8u*)((u64)sh.blob_words + (((u64)u_off + u_idx) << 5));
+#else  // (the 64-lane emulation takes the same wave-uniform decision; its "scalar load" is a plain one)
+      const u32* w = (const u32*)((const char*)sh.blob_words + (((u64)u_off + u_idx) << 5));
+#endif
 #pragma unroll
       for (int i = 0; i < 8; i++) v.w[i] = w[i];
     }
