@@ -17,6 +17,11 @@
 //                                       in order — and fills `MemoryQuery.value` of the reads itself; only WRITES carry their value.
 //                                       Used when the host holds the heap images the step ran on (always after an upload; after a
 //                                       restage with heap images only under ZKW_OPT_KEEP_RESTAGED_HEAPS — else reads keep their values)
+//   memory-query page    implied        (version 2, ZKW_PACK_IMPLIED_PAGES) the page of a stack / heap / aux-heap / code query of the VM itself is
+//                                       base + 1 / + 2 / + 3 / the code page of the frame that is current in that cycle (execution_stack.rs:67-81,
+//                                       mem_ops.rs:51-121, uma.rs:100-135): the rebuild tracks the frames (initial callstack + the FRAME_START /
+//                                       FRAME_FINISH events of the aux stream) and fills it in; only queries that NAME a page travel with it —
+//                                       fat-pointer reads and the reads / writes of precompiles.  The header of the others is 8 bytes.
 //   aux events           256 B -> used  FRAME_START 240 B, DECOMMIT 64 B, COLD_STATE 48 B, FRAME_FINISH 16 B
 // All offsets and sizes are in 16-byte units from the start of the block.
 //
@@ -31,7 +36,9 @@
 //     dir      (max_cyc + 1)                stream cursors at every cycle start
 //     tails    max_cyc x L
 //     deltas   n_delta (low plane), n_delta (high plane)
-//     mem      3 planes of ceil4(n_mem) u32 (page | index | misc), then n_val (value low), n_val (value high): the values of
+//     mem      the page list (ceil4(n_page) units of u32: the pages of the queries that carry one, zkw_pack_has_page, in stream
+//              order — every query when pages are not implied), 2 planes of ceil4(n_mem) u32 (index | misc), then n_val (value
+//              low), n_val (value high): the values of
 //              the queries that carry one (zkw_pack_has_value: no Code reads; under ZKW_PACK_NO_READ_VALUES no reads at all), in
 //              stream order
 //     log      n_log x 8
@@ -44,6 +51,7 @@
 #define ZKW_PACK_MAGIC 0x50574b5au /* "ZKWP" */
 #define ZKW_PACK_VERSION 2u
 #define ZKW_PACK_NO_READ_VALUES 1u /* zkw_pack_header.flags / zkw_pack_args.flags: the value planes hold the values of WRITES only */
+#define ZKW_PACK_IMPLIED_PAGES 2u  /* ... the page list holds the pages of fat-pointer and precompile queries only */
 #define ZKW_PACK_HEADER_UNITS 4u
 #define ZKW_PACK_BATCH_UNITS 2u
 #define ZKW_PACK_WAVE_UNITS 4u
@@ -71,7 +79,8 @@ typedef struct zkw_pack_wave { /* 64 B */
   uint32_t max_cyc;   /* wave-cycles run since the reset */
   uint32_t n_delta, n_mem, n_val, n_log, n_aux, aux_units;
   uint32_t units;     /* units of the wave's data */
-  uint32_t reserved[7];
+  uint32_t n_page;    /* entries of the page list */
+  uint32_t reserved[6];
 } zkw_pack_wave;
 
 /* units a record of the aux stream uses, by type (the kernel writes only those: zkw_kernels.hip start_frame / op_far_call) */
@@ -80,8 +89,8 @@ ZKW_HD static inline uint32_t zkw_aux_used_units(uint32_t type) {
 }
 ZKW_HD static inline uint32_t zkw_ceil4(uint32_t n) { return (n + 3u) >> 2; }
 /* units of a wave's data */
-ZKW_HD static inline uint64_t zkw_pack_wave_units(uint32_t max_cyc, uint32_t L, uint32_t n_delta, uint32_t n_mem, uint32_t n_val, uint32_t n_log, uint32_t aux_units) {
-  return (uint64_t)(max_cyc + 1u) + (uint64_t)max_cyc * L + 2ull * n_delta + 3ull * zkw_ceil4(n_mem) + 2ull * n_val + 8ull * n_log + aux_units;
+ZKW_HD static inline uint64_t zkw_pack_wave_units(uint32_t max_cyc, uint32_t L, uint32_t n_delta, uint32_t n_mem, uint32_t n_page, uint32_t n_val, uint32_t n_log, uint32_t aux_units) {
+  return (uint64_t)(max_cyc + 1u) + (uint64_t)max_cyc * L + 2ull * n_delta + zkw_ceil4(n_page) + 2ull * zkw_ceil4(n_mem) + 2ull * n_val + 8ull * n_log + aux_units;
 }
 
 /* by-value arguments of one launch of the pack kernel */
@@ -100,6 +109,11 @@ typedef struct zkw_pack_args {
   uint32_t flags;       /* ZKW_PACK_NO_READ_VALUES */
 } zkw_pack_args;
 /* does memory query `hdr_w` (word 3 of its header: lane | seq << 8 | meta << 16) carry its value on the link? */
+/* ... and its page?  (with implied pages: only what names one — a fat-pointer read, a precompile's read or write) */
+ZKW_HD static inline bool zkw_pack_has_page(uint32_t hdr_w, uint32_t flags) {
+  const uint32_t meta = (hdr_w >> 16) & 0xffu;
+  return !(flags & ZKW_PACK_IMPLIED_PAGES) || (meta >> ZKW_MQ_KIND_SHIFT) != 0 || (meta & ZKW_MQ_TYPE_MASK) == ZKW_MEM_FAT_PTR;
+}
 ZKW_HD static inline bool zkw_pack_has_value(uint32_t hdr_w, uint32_t flags) {
   const uint32_t meta = hdr_w >> 16;
   if ((meta & ZKW_MQ_TYPE_MASK) == ZKW_MEM_CODE) return false;

@@ -88,8 +88,12 @@ __global__ void __launch_bounds__(ZKW_PACK_THREADS) zkw_pack_kernel(zkw_pack_arg
     const uint4* mem_hdr = P.mem_stream + (u64)w * P.cap_mem * 3;
     const uint4* aux_src = P.aux_stream + (u64)w * P.cap_aux * 16;
     // ---- count: memory queries that carry a value (zkw_pack_has_value), units of the aux records ----
-    u32 my_val = 0, my_aux = 0;
-    for (u32 i = t; i < n_mem; i += nt) my_val += zkw_pack_has_value(mem_hdr[i].w, A.flags) ? 1u : 0u;
+    u32 my_val = 0, my_aux = 0, my_page = 0;
+    for (u32 i = t; i < n_mem; i += nt) {
+      const u32 hw = mem_hdr[i].w;
+      my_val += zkw_pack_has_value(hw, A.flags) ? 1u : 0u;
+      my_page += zkw_pack_has_page(hw, A.flags) ? 1u : 0u;
+    }
     for (u32 i = t; i < n_aux; i += nt) my_aux += zkw_aux_used_units(aux_src[(u64)i * 16].x & 0xffu);
     s_sums[t] = my_val;
     __syncthreads();
@@ -101,8 +105,13 @@ __global__ void __launch_bounds__(ZKW_PACK_THREADS) zkw_pack_kernel(zkw_pack_arg
     u32 aux_units = 0;
     for (u32 i = 0; i < nt; i++) aux_units += s_sums[i];
     __syncthreads();
+    s_sums[t] = my_page;
+    __syncthreads();
+    u32 n_page = 0;
+    for (u32 i = 0; i < nt; i++) n_page += s_sums[i];
+    __syncthreads();
     // ---- allocate the wave's extent ----
-    const u64 units64 = zkw_pack_wave_units(max_cyc, L, n_delta, n_mem, n_val, n_log, aux_units);
+    const u64 units64 = zkw_pack_wave_units(max_cyc, L, n_delta, n_mem, n_page, n_val, n_log, aux_units);
     if (t == 0) {
       u32 off = 0;
       if (units64 < 0xffffffffull) {
@@ -119,7 +128,7 @@ __global__ void __launch_bounds__(ZKW_PACK_THREADS) zkw_pack_kernel(zkw_pack_arg
       uint4* e = A.dst + A.wave_table + (u64)(one ? 0u : gw) * ZKW_PACK_WAVE_UNITS;
       e[0] = make_uint4(off, max_cyc, n_delta, n_mem);
       e[1] = make_uint4(n_val, n_log, n_aux, aux_units);
-      e[2] = make_uint4((u32)units64, 0, 0, 0);
+      e[2] = make_uint4((u32)units64, n_page, 0, 0);
       e[3] = make_uint4(0, 0, 0, 0);
     }
     // ---- the per-instance sections of this wave's instances ----
@@ -147,27 +156,27 @@ __global__ void __launch_bounds__(ZKW_PACK_THREADS) zkw_pack_kernel(zkw_pack_arg
     d += 2ull * n_delta;
     // ---- memory queries: 12-byte headers as three u32 planes, values of the non-code queries only ----
     {
-      const u32 q4 = zkw_ceil4(n_mem);
-      uint4* pl_page = d;
-      uint4* pl_index = d + q4;
-      uint4* pl_misc = d + 2ull * q4;
-      uint4* v_lo = d + 3ull * q4;
+      const u32 q4 = zkw_ceil4(n_mem), p4 = zkw_ceil4(n_page);
+      u32* pl_page = (u32*)d;  // the page list: one u32 per query that carries its page
+      uint4* pl_index = d + p4;
+      uint4* pl_misc = d + p4 + q4;
+      uint4* v_lo = d + p4 + 2ull * q4;
       uint4* v_hi = v_lo + n_val;
       const uint4* src_lo = mem_hdr + P.cap_mem;
       const uint4* src_hi = mem_hdr + 2ull * P.cap_mem;
-      u32 vbase = 0;
+      u32 vbase = 0, pbase = 0;
       for (u32 base = 0; base < q4; base += nt) {  // a thread takes four consecutive records: one 16-byte store per plane
         const u32 g = base + t;
         uint4 h[4];
-        bool has[4];
+        bool has[4], hasp[4];
         for (int j = 0; j < 4; j++) {
           const u32 i = 4u * g + (u32)j;
           const bool in = g < q4 && i < n_mem;
           h[j] = in ? mem_hdr[i] : make_uint4(0, 0, 0, 0);
           has[j] = in && zkw_pack_has_value(h[j].w, A.flags);
+          hasp[j] = in && zkw_pack_has_page(h[j].w, A.flags);
         }
         if (g < q4) {
-          pl_page[g] = make_uint4(h[0].y, h[1].y, h[2].y, h[3].y);
           pl_index[g] = make_uint4(h[0].z, h[1].z, h[2].z, h[3].z);
           pl_misc[g] = make_uint4((h[0].w & 0x00ffffffu) | (h[0].x << 24), (h[1].w & 0x00ffffffu) | (h[1].x << 24), (h[2].w & 0x00ffffffu) | (h[2].x << 24),
                                   (h[3].w & 0x00ffffffu) | (h[3].x << 24));
@@ -188,6 +197,18 @@ __global__ void __launch_bounds__(ZKW_PACK_THREADS) zkw_pack_kernel(zkw_pack_arg
           tile += tot[j];
         }
         vbase += tile;
+        // the page list, the same way (records in stream order = thread order, then j)
+        tile = 0; mine_before = 0;
+        for (int j = 0; j < 4; j++) rk[j] = pack_flag_scan(hasp[j], s_wave_counts[j], t, nt, tot[j]);
+        below_threads = rk[0] + rk[1] + rk[2] + rk[3];
+        for (int j = 0; j < 4; j++) {
+          if (hasp[j]) {
+            pl_page[pbase + below_threads + mine_before] = h[j].y;
+            mine_before++;
+          }
+          tile += tot[j];
+        }
+        pbase += tile;
       }
       d = v_hi + n_val;
     }

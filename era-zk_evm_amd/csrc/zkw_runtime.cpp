@@ -99,6 +99,9 @@ struct CodeInputs {
   std::vector<std::vector<std::pair<uint32_t, uint32_t>>> pages;  // [instance] page -> blob, in registration order
   std::vector<std::vector<zkw_u256>> blobs;
   std::vector<uint32_t> preimage_blob;                             // [preimage] -> blob
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> frames0; // [instance] (base page, code page) of the INNER callstack entries,
+                                                                   // outermost first (the current one is in the state): what the
+                                                                   // implied pages of the link format are resolved against
   uint32_t time_delta = 0;                                         // consts.time_delta_per_cycle of the table the batch ran under
 };
 struct BatchInputs {
@@ -1048,6 +1051,9 @@ int zkw_batch_upload(zkw_batch* b) {
     auto code = std::make_shared<CodeInputs>();
     code->pages.resize(b->n);
     for (uint32_t i = 0; i < b->n; i++) code->pages[i] = b->staged[i].code_pages;
+    code->frames0.resize(b->n);
+    for (uint32_t i = 0; i < b->n; i++)
+      for (const zkw_callstack_entry& e : b->staged[i].inner) code->frames0[i].emplace_back(e.base_memory_page, e.code_page);
     code->blobs = b->blobs;
     code->preimage_blob.reserve(b->preimages.size());
     for (const auto& pr : b->preimages) code->preimage_blob.push_back(pr.second);
@@ -1489,7 +1495,7 @@ int zkw_batch_get_stats(zkw_batch* b, zkw_run_stats* out) {
 // ---------------------------------------------------------------------------------------------------------------------
 struct WaveView {  // host pointers to the packed data of one wave
   uint32_t flags = 0;  // ZKW_PACK_* of the block
-  uint32_t L = 0, max_cyc = 0, n_delta = 0, n_mem = 0, n_val = 0, n_log = 0, n_aux = 0, aux_units = 0;
+  uint32_t L = 0, max_cyc = 0, n_delta = 0, n_mem = 0, n_val = 0, n_log = 0, n_aux = 0, aux_units = 0, n_page = 0;
   const uint32_t* dir = nullptr;
   const uint4 *tails = nullptr, *dlo = nullptr, *dhi = nullptr;
   const uint32_t *m_page = nullptr, *m_index = nullptr, *m_misc = nullptr;
@@ -1500,12 +1506,14 @@ static bool wave_view(const uint4* block, const zkw_pack_wave& e, uint32_t L, ui
   if (e.off == 0) return false;
   v.flags = flags;
   v.L = L; v.max_cyc = e.max_cyc; v.n_delta = e.n_delta; v.n_mem = e.n_mem; v.n_val = e.n_val; v.n_log = e.n_log; v.n_aux = e.n_aux; v.aux_units = e.aux_units;
+  v.n_page = e.n_page;
   const uint4* d = block + e.off;
   v.dir = (const uint32_t*)d; d += e.max_cyc + 1;
   v.tails = d; d += (size_t)e.max_cyc * L;
   v.dlo = d; v.dhi = d + e.n_delta; d += 2 * (size_t)e.n_delta;
   const uint32_t q4 = zkw_ceil4(e.n_mem);
-  v.m_page = (const uint32_t*)d; v.m_index = (const uint32_t*)(d + q4); v.m_misc = (const uint32_t*)(d + 2 * (size_t)q4); d += 3 * (size_t)q4;
+  v.m_page = (const uint32_t*)d; d += zkw_ceil4(e.n_page);  // the page list: the queries that carry their page, in stream order
+  v.m_index = (const uint32_t*)d; v.m_misc = (const uint32_t*)(d + q4); d += 2 * (size_t)q4;
   v.v_lo = d; v.v_hi = d + e.n_val; d += 2 * (size_t)e.n_val;
   v.log = d; d += (size_t)e.n_log * 8;
   v.aux = d;
@@ -1644,6 +1652,19 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
       pg.image_words = in.heap_words;
       shadow[l].pages.push_back(std::move(pg));
     }
+  // Implied pages (ZKW_PACK_IMPLIED_PAGES): the callstack of every lane as (base page, code page) — the inner entries it was staged
+  // with, its current entry, then the FRAME_START / FRAME_FINISH events of the aux stream applied at the END of their cycle (a frame
+  // changes behind the cycle's last memory query: far_call.rs:562, ret.rs:196-243, near_call.rs:60-67 come after the operand reads).
+  const bool implied = (v.flags & ZKW_PACK_IMPLIED_PAGES) != 0;
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> frames(implied ? L : 0);
+  if (implied)
+    for (uint32_t l = 0; l < L; l++) {
+      const uint32_t inst = w * L + l;
+      if (inst >= n_inst) continue;
+      if (inst < code.frames0.size()) frames[l] = code.frames0[inst];
+      frames[l].emplace_back(in.states[inst].current.base_memory_page, in.states[inst].current.code_page);
+    }
+  uint32_t ppos = 0;  // next entry of the page list
   std::vector<uint32_t> mask(L), cnt_m(L + 1), cnt_l(L + 1), cnt_a(L + 1), fill(L);
   std::vector<zkw_mem_query> cm;
   std::vector<zkw_log_query> cl;
@@ -1691,18 +1712,29 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
     for (uint32_t l = 0; l < L; l++) { cnt_m[l + 1] += cnt_m[l]; cnt_l[l + 1] += cnt_l[l]; cnt_a[l + 1] += cnt_a[l]; }
     cm.resize(cnt_m[L]); cl.resize(cnt_l[L]); ca.resize(cnt_a[L]);
     // (memory queries of earlier stream positions that belong to no cycle range cannot exist: the ranges tile the stream)
-    for (; pm < m0; pm++) if (zkw_pack_has_value(v.m_misc[pm], v.flags)) vpos++;
+    for (; pm < m0; pm++) {
+      if (zkw_pack_has_value(v.m_misc[pm], v.flags)) vpos++;
+      if (zkw_pack_has_page(v.m_misc[pm], v.flags)) ppos++;
+    }
     std::fill(fill.begin(), fill.end(), 0u);
     for (uint32_t p = m0; p < m1; p++, pm++) {
       const uint32_t misc = v.m_misc[p], l = misc & 0xffu, meta = (misc >> 16) & 0xffu;
       const bool is_code = (meta & ZKW_MQ_TYPE_MASK) == ZKW_MEM_CODE;
-      const bool has_value = zkw_pack_has_value(misc, v.flags);
+      const bool has_value = zkw_pack_has_value(misc, v.flags), has_page = zkw_pack_has_page(misc, v.flags);
       const uint32_t vi = has_value ? vpos++ : 0u;
+      const uint32_t pi = has_page ? ppos++ : 0u;
       if (!live(l)) continue;
       zkw_mem_query& q = cm[cnt_m[l] + fill[l]++];
       const uint32_t cycle_ts = slow[l].timestamp;  // the lane's timestamp at the start of this cycle
       q.timestamp = cycle_ts + (((misc >> 24) - cycle_ts) & 0xffu);
-      q.page = v.m_page[p]; q.index = v.m_index[p];
+      if (has_page) {
+        q.page = pi < v.n_page ? v.m_page[pi] : 0u;
+      } else {  // a query of the VM itself on a page of its current frame (execution_stack.rs:67-81)
+        const uint32_t type = meta & ZKW_MQ_TYPE_MASK;
+        const std::pair<uint32_t, uint32_t> top = frames[l].empty() ? std::pair<uint32_t, uint32_t>(0u, 0u) : frames[l].back();
+        q.page = type == ZKW_MEM_CODE ? top.second : top.first + (type == ZKW_MEM_STACK ? 1u : type == ZKW_MEM_HEAP ? 2u : 3u);
+      }
+      q.index = v.m_index[p];
       q.lane = 0; q.seq = (uint8_t)(misc >> 8); q.meta = (uint8_t)meta; q.reserved0 = 0;
       if (is_code) code_word(l, q.page, q.index, &q.value);
       else if (!has_value) shadow[l].read(q.page, q.index, &q.value);  // a read under ZKW_PACK_NO_READ_VALUES
@@ -1726,6 +1758,10 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
       zkw_aux_event& q = ca[cnt_a[l] + fill[l]++];
       q = aux[p];
       q.lane = 0;
+      if (implied) {  // (applied here, behind the cycle's memory queries: they were resolved above)
+        if (q.type == ZKW_AUX_FRAME_START) frames[l].emplace_back(q.u.frame.next.base_memory_page, q.u.frame.next.code_page);
+        else if (q.type == ZKW_AUX_FRAME_FINISH && !frames[l].empty()) frames[l].pop_back();
+      }
     }
     // ---- the tails, then the sink ----
     for (uint32_t l = 0; l < L; l++) {
@@ -1803,10 +1839,10 @@ static void fill_final_state(zkw_vm_local_state* out, const zkw_dev_scalars& sc,
 // The link flags of a block: memory reads travel without their values when the host holds, for EVERY batch of the block, the heap
 // images the step ran on (the shadow memory of walk_wave starts from them)
 static uint32_t pack_flags(const zkw_ctx* c, zkw_batch* const* bs, uint32_t n) {
-  if (c->opt_read_values) return 0;
+  if (c->opt_read_values) return 0;  // (the round-5 format: every page, every value)
   for (uint32_t i = 0; i < n; i++)
-    if (!bs[i]->inputs || !bs[i]->inputs->heaps_known) return 0;
-  return ZKW_PACK_NO_READ_VALUES;
+    if (!bs[i]->inputs || !bs[i]->inputs->heaps_known) return ZKW_PACK_IMPLIED_PAGES;
+  return ZKW_PACK_NO_READ_VALUES | ZKW_PACK_IMPLIED_PAGES;
 }
 
 // The on-demand path of zkw_batch_get_instance_trace: ONE wave of a synced batch through the pack kernel into a pinned block
@@ -1824,7 +1860,7 @@ static int build_wave(zkw_batch* b, uint32_t w) {
   const uint32_t* hc = &b->h_cursors[(size_t)w * 4];
   const uint32_t n_mem = std::min(hc[0], b->cap_mem), n_log = std::min(hc[1], b->cap_log), n_aux = std::min(hc[2], b->cap_aux), n_delta = std::min(hc[3], b->cap_delta);
   const uint64_t fixed = ZKW_PACK_HEADER_UNITS + ZKW_PACK_BATCH_UNITS + ZKW_PACK_WAVE_UNITS;
-  const uint64_t need = fixed + zkw_pack_wave_units(b->lim.max_cycles, L, n_delta, n_mem, n_mem, n_log, 16u * n_aux) + 16;
+  const uint64_t need = fixed + zkw_pack_wave_units(b->lim.max_cycles, L, n_delta, n_mem, n_mem, n_mem, n_log, 16u * n_aux) + 16;
   if (need >= (1ull << 32)) {
     c->last_error = "wave trace beyond 64 GB";
     return ZKW_ERR_LIMIT;
@@ -2024,7 +2060,7 @@ int zkw_delivery_slot_bytes(zkw_batch* const* batches, uint32_t n_batches, uint6
     const zkw_batch* b = batches[i];
     if (!b || !b->uploaded) return ZKW_ERR_INVALID;
     units += (uint64_t)b->n_waves * ZKW_PACK_WAVE_UNITS + (uint64_t)b->n * 16 + (uint64_t)b->n_waves * ZKW_REG_CHUNKS * b->L;
-    units += (uint64_t)b->n_waves * zkw_pack_wave_units(b->lim.max_cycles, b->L, b->cap_delta, b->cap_mem, b->cap_mem, b->cap_log, 16u * b->cap_aux);
+    units += (uint64_t)b->n_waves * zkw_pack_wave_units(b->lim.max_cycles, b->L, b->cap_delta, b->cap_mem, b->cap_mem, b->cap_mem, b->cap_log, 16u * b->cap_aux);
   }
   *worst_case = units * 16;
   return ZKW_OK;
