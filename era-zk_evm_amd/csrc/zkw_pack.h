@@ -34,7 +34,8 @@
 //     entries  [n_instances] x 8 units      callstack.current of the final state (zkw_dev_entry)
 //   wave data, allocated in the order the workgroups get to them (zkw_pack_wave.off):
 //     dir      (max_cyc + 1)                stream cursors at every cycle start
-//     tails    max_cyc x L
+//     tails    max_cyc x L x 16 B — or, slim: planes x | y | z of ceil4(max_cyc x L) units each (ptr bitmap, flags, low delta mask | pc, sp |
+//              ergs) and one plane of ceil16(max_cyc x L) units with the high byte of the delta mask
 //     deltas   n_delta (low plane), n_delta (high plane)
 //     mem      the page list (ceil4(n_page) units of u32: the pages of the queries that carry one, zkw_pack_has_page, in stream
 //              order — every query when pages are not implied), 2 planes of ceil4(n_mem) u32 (index | misc), then n_val (value
@@ -52,6 +53,8 @@
 #define ZKW_PACK_VERSION 2u
 #define ZKW_PACK_NO_READ_VALUES 1u /* zkw_pack_header.flags / zkw_pack_args.flags: the value planes hold the values of WRITES only */
 #define ZKW_PACK_IMPLIED_PAGES 2u  /* ... the page list holds the pages of fat-pointer and precompile queries only */
+#define ZKW_PACK_SLIM_TAILS 4u     /* ... the record tails travel as 13 bytes (three u32 planes + one byte plane) instead of 16: the three
+                                      event counts of a cycle are the numbers of its queries in the streams, which the rebuild counts anyway */
 #define ZKW_PACK_HEADER_UNITS 4u
 #define ZKW_PACK_BATCH_UNITS 2u
 #define ZKW_PACK_WAVE_UNITS 4u
@@ -89,8 +92,13 @@ ZKW_HD static inline uint32_t zkw_aux_used_units(uint32_t type) {
 }
 ZKW_HD static inline uint32_t zkw_ceil4(uint32_t n) { return (n + 3u) >> 2; }
 /* units of a wave's data */
-ZKW_HD static inline uint64_t zkw_pack_wave_units(uint32_t max_cyc, uint32_t L, uint32_t n_delta, uint32_t n_mem, uint32_t n_page, uint32_t n_val, uint32_t n_log, uint32_t aux_units) {
-  return (uint64_t)(max_cyc + 1u) + (uint64_t)max_cyc * L + 2ull * n_delta + zkw_ceil4(n_page) + 2ull * zkw_ceil4(n_mem) + 2ull * n_val + 8ull * n_log + aux_units;
+/* units of the tails of n_t lane-cycles: 16 bytes each, or (slim) three u32 planes + one byte plane — never more than n_t + 4 */
+ZKW_HD static inline uint64_t zkw_pack_tail_units(uint64_t n_t, uint32_t flags) {
+  return (flags & ZKW_PACK_SLIM_TAILS) ? 3ull * ((n_t + 3ull) >> 2) + ((n_t + 15ull) >> 4) : n_t;
+}
+/* (worst-case callers pass flags = 0 and add 4 units per wave) */
+ZKW_HD static inline uint64_t zkw_pack_wave_units(uint32_t max_cyc, uint32_t L, uint32_t n_delta, uint32_t n_mem, uint32_t n_page, uint32_t n_val, uint32_t n_log, uint32_t aux_units, uint32_t flags) {
+  return (uint64_t)(max_cyc + 1u) + zkw_pack_tail_units((uint64_t)max_cyc * L, flags) + 2ull * n_delta + zkw_ceil4(n_page) + 2ull * zkw_ceil4(n_mem) + 2ull * n_val + 8ull * n_log + aux_units;
 }
 
 /* by-value arguments of one launch of the pack kernel */

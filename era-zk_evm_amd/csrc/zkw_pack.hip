@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(ZKW_PACK_THREADS) zkw_pack_kernel(zkw_pack_arg
     for (u32 i = 0; i < nt; i++) n_page += s_sums[i];
     __syncthreads();
     // ---- allocate the wave's extent ----
-    const u64 units64 = zkw_pack_wave_units(max_cyc, L, n_delta, n_mem, n_page, n_val, n_log, aux_units);
+    const u64 units64 = zkw_pack_wave_units(max_cyc, L, n_delta, n_mem, n_page, n_val, n_log, aux_units, A.flags);
     if (t == 0) {
       u32 off = 0;
       if (units64 < 0xffffffffull) {
@@ -149,8 +149,35 @@ __global__ void __launch_bounds__(ZKW_PACK_THREADS) zkw_pack_kernel(zkw_pack_arg
     // ---- directory, tails, register deltas: plain extents ----
     pack_copy(d, (const uint4*)(P.dir + ((u64)w * (P.max_cycles + 1)) * 4), (u64)max_cyc + 1, t, nt);
     d += max_cyc + 1;
-    pack_copy(d, P.tails + (u64)w * P.max_cycles * L, (u64)max_cyc * L, t, nt);
-    d += (u64)max_cyc * L;
+    {
+      const uint4* tsrc = P.tails + (u64)w * P.max_cycles * L;
+      const u64 n_t = (u64)max_cyc * L;
+      if (A.flags & ZKW_PACK_SLIM_TAILS) {  // x | y | z as u32 planes, the top byte of w (delta mask, high half) as a byte plane; the counts stay behind
+        const u64 t4 = (n_t + 3ull) >> 2, t16 = (n_t + 15ull) >> 4;
+        uint4 *px = d, *py = d + t4, *pz = d + 2ull * t4, *pb = d + 3ull * t4;
+        for (u64 g = t; g < t16; g += nt) {  // sixteen consecutive tails per thread: one 16-byte store of the byte plane
+          u32 bytes[4];
+          for (u32 q = 0; q < 4; q++) {
+            uint4 e[4];
+            for (u32 j = 0; j < 4; j++) {
+              const u64 i = 16ull * g + 4u * q + j;
+              e[j] = i < n_t ? tsrc[i] : make_uint4(0, 0, 0, 0);
+            }
+            const u64 u = 4ull * g + q;
+            if (u < t4) {
+              px[u] = make_uint4(e[0].x, e[1].x, e[2].x, e[3].x);
+              py[u] = make_uint4(e[0].y, e[1].y, e[2].y, e[3].y);
+              pz[u] = make_uint4(e[0].z, e[1].z, e[2].z, e[3].z);
+            }
+            bytes[q] = (e[0].w >> 24) | ((e[1].w >> 24) << 8) | ((e[2].w >> 24) << 16) | ((e[3].w >> 24) << 24);
+          }
+          pb[g] = make_uint4(bytes[0], bytes[1], bytes[2], bytes[3]);
+        }
+      } else {
+        pack_copy(d, tsrc, n_t, t, nt);
+      }
+      d += zkw_pack_tail_units(n_t, A.flags);
+    }
     pack_copy(d, P.deltas + (u64)w * P.cap_delta * 2, n_delta, t, nt);
     pack_copy(d + n_delta, P.deltas + (u64)w * P.cap_delta * 2 + P.cap_delta, n_delta, t, nt);
     d += 2ull * n_delta;

@@ -1498,6 +1498,10 @@ struct WaveView {  // host pointers to the packed data of one wave
   uint32_t L = 0, max_cyc = 0, n_delta = 0, n_mem = 0, n_val = 0, n_log = 0, n_aux = 0, aux_units = 0, n_page = 0;
   const uint32_t* dir = nullptr;
   const uint4 *tails = nullptr, *dlo = nullptr, *dhi = nullptr;
+  const uint32_t *tx = nullptr, *ty = nullptr, *tz = nullptr;  // slim tails (ZKW_PACK_SLIM_TAILS): planes x | y | z ...
+  const uint8_t* tb = nullptr;                                 // ... and the high byte of the delta mask
+  // the 16-byte tail of lane-cycle i as the cycle kernel stored it, but for the event counts (not on the link when slim: tail_counts)
+  uint4 tail(size_t i) const { return tails ? tails[i] : make_uint4(tx[i], ty[i], tz[i], (uint32_t)tb[i] << 24); }
   const uint32_t *m_page = nullptr, *m_index = nullptr, *m_misc = nullptr;
   const uint4 *v_lo = nullptr, *v_hi = nullptr, *log = nullptr, *aux = nullptr;
 };
@@ -1509,7 +1513,17 @@ static bool wave_view(const uint4* block, const zkw_pack_wave& e, uint32_t L, ui
   v.n_page = e.n_page;
   const uint4* d = block + e.off;
   v.dir = (const uint32_t*)d; d += e.max_cyc + 1;
-  v.tails = d; d += (size_t)e.max_cyc * L;
+  {
+    const uint64_t n_t = (uint64_t)e.max_cyc * L;
+    if (flags & ZKW_PACK_SLIM_TAILS) {
+      const uint64_t t4 = (n_t + 3) >> 2;
+      v.tails = nullptr;
+      v.tx = (const uint32_t*)d; v.ty = (const uint32_t*)(d + t4); v.tz = (const uint32_t*)(d + 2 * t4); v.tb = (const uint8_t*)(d + 3 * t4);
+    } else {
+      v.tails = d;
+    }
+    d += zkw_pack_tail_units(n_t, flags);
+  }
   v.dlo = d; v.dhi = d + e.n_delta; d += 2 * (size_t)e.n_delta;
   const uint32_t q4 = zkw_ceil4(e.n_mem);
   v.m_page = (const uint32_t*)d; d += zkw_ceil4(e.n_page);  // the page list: the queries that carry their page, in stream order
@@ -1679,7 +1693,7 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
     for (uint32_t l = 0; l < L; l++) {
       mask[l] = 0;
       if (k >= ncyc[l]) continue;
-      const uint4 t0 = v.tails[(size_t)k * L + l];
+      const uint4 t0 = v.tail((size_t)k * L + l);
       mask[l] = (t0.x >> 24) | ((t0.w >> 24) << 8);
       any |= mask[l];
     }
@@ -1766,7 +1780,11 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
     // ---- the tails, then the sink ----
     for (uint32_t l = 0; l < L; l++) {
       if (k >= ncyc[l]) continue;
-      const uint4 t0 = v.tails[(size_t)k * L + l];
+      uint4 t0 = v.tail((size_t)k * L + l);
+      if (!v.tails) {  // the event counts of the cycle: the numbers of its queries in the three streams, saturating bytes (Lane::counts)
+        const uint32_t nm = cnt_m[l + 1] - cnt_m[l], nl = cnt_l[l + 1] - cnt_l[l], na = cnt_a[l + 1] - cnt_a[l];
+        t0.w = (t0.w & 0xff000000u) | std::min(nm, 255u) | (std::min(nl, 255u) << 8) | (std::min(na, 255u) << 16);
+      }
       const uint32_t super_pc = (slow[l].pc & 0xffffu) >> 2;  // of the pc this cycle started from
       slow[l].timestamp += time_delta;
       slow[l].pc = t0.y & 0xffffu;
@@ -1841,8 +1859,8 @@ static void fill_final_state(zkw_vm_local_state* out, const zkw_dev_scalars& sc,
 static uint32_t pack_flags(const zkw_ctx* c, zkw_batch* const* bs, uint32_t n) {
   if (c->opt_read_values) return 0;  // (the round-5 format: every page, every value)
   for (uint32_t i = 0; i < n; i++)
-    if (!bs[i]->inputs || !bs[i]->inputs->heaps_known) return ZKW_PACK_IMPLIED_PAGES;
-  return ZKW_PACK_NO_READ_VALUES | ZKW_PACK_IMPLIED_PAGES;
+    if (!bs[i]->inputs || !bs[i]->inputs->heaps_known) return ZKW_PACK_IMPLIED_PAGES | ZKW_PACK_SLIM_TAILS;
+  return ZKW_PACK_NO_READ_VALUES | ZKW_PACK_IMPLIED_PAGES | ZKW_PACK_SLIM_TAILS;
 }
 
 // The on-demand path of zkw_batch_get_instance_trace: ONE wave of a synced batch through the pack kernel into a pinned block
@@ -1860,7 +1878,7 @@ static int build_wave(zkw_batch* b, uint32_t w) {
   const uint32_t* hc = &b->h_cursors[(size_t)w * 4];
   const uint32_t n_mem = std::min(hc[0], b->cap_mem), n_log = std::min(hc[1], b->cap_log), n_aux = std::min(hc[2], b->cap_aux), n_delta = std::min(hc[3], b->cap_delta);
   const uint64_t fixed = ZKW_PACK_HEADER_UNITS + ZKW_PACK_BATCH_UNITS + ZKW_PACK_WAVE_UNITS;
-  const uint64_t need = fixed + zkw_pack_wave_units(b->lim.max_cycles, L, n_delta, n_mem, n_mem, n_mem, n_log, 16u * n_aux) + 16;
+  const uint64_t need = fixed + zkw_pack_wave_units(b->lim.max_cycles, L, n_delta, n_mem, n_mem, n_mem, n_log, 16u * n_aux, 0) + 4 + 16;
   if (need >= (1ull << 32)) {
     c->last_error = "wave trace beyond 64 GB";
     return ZKW_ERR_LIMIT;
@@ -2060,7 +2078,7 @@ int zkw_delivery_slot_bytes(zkw_batch* const* batches, uint32_t n_batches, uint6
     const zkw_batch* b = batches[i];
     if (!b || !b->uploaded) return ZKW_ERR_INVALID;
     units += (uint64_t)b->n_waves * ZKW_PACK_WAVE_UNITS + (uint64_t)b->n * 16 + (uint64_t)b->n_waves * ZKW_REG_CHUNKS * b->L;
-    units += (uint64_t)b->n_waves * zkw_pack_wave_units(b->lim.max_cycles, b->L, b->cap_delta, b->cap_mem, b->cap_mem, b->cap_mem, b->cap_log, 16u * b->cap_aux);
+    units += (uint64_t)b->n_waves * (zkw_pack_wave_units(b->lim.max_cycles, b->L, b->cap_delta, b->cap_mem, b->cap_mem, b->cap_mem, b->cap_log, 16u * b->cap_aux, 0) + 4);
   }
   *worst_case = units * 16;
   return ZKW_OK;

@@ -200,8 +200,8 @@ def check_restage_after_a_ragged_upload(oracle, emu, isa):
 def check_reads_travel_without_their_values(oracle, emu, isa):
     """Link format 2: memory reads cross the link as headers only, the rebuild fills their values from a shadow of the pages
     (staged heap image + the writes of the stream).  Every workload, both ways (ZKW_OPT_READ_VALUES = 1 is the old format):
-    the same traces, fewer bytes — cfg 2 on 64-lane waves: 79.5 B per VM cycle instead of 104.2 (reads without values 84.6; pages
-    implied by the frame, i.e. 8-byte headers, the rest)."""
+    the same traces, fewer bytes — cfg 2 on 64-lane waves: 76.5 B per VM cycle instead of 104.2 (reads without values 84.6; pages
+    implied by the frame, i.e. 8-byte headers, 79.5; 13-byte record tails the rest)."""
     names = ["cfg2", "cfg4", "cfg3", "fuzz", "far_calls", "ended"]
     wls = [WORKLOADS[n](isa) for n in names] + [synth.make(2, isa, n_instances=128)]
     bos = [_run(oracle, WORKLOADS[n](isa)) for n in names] + [_run(oracle, synth.make(2, isa, n_instances=128))]
