@@ -492,7 +492,7 @@ ZKW_CFV(heap_bound, "v129")
 ZKW_CFV(aux_bound, "v130")
 ZKW_CFV(slot, "v134")
 ZKW_CFV(heap_hwm, "v135")
-#else  // single-lane emulation build (and the A/B partner): the LDS rows
+#else  // CPU emulation builds (and the A/B partner): the LDS rows
 #define ZKW_CFV_EMU(name, field)                                                      \
   ZD u32 cfv_##name(const Shared& sh, const Lane& s) { return CF(sh, s, field); }     \
   ZD void cfv_set_##name(const Shared& sh, const Lane& s, u32 v) { CF(sh, s, field) = v; }
@@ -695,7 +695,7 @@ ZD void rf_set(RegFileVec&, u32 reg, const u256& v) {
     todo &= ~zkw_ballot(m);
   }
 }
-#else  // single-lane CPU emulation build of tests/emu
+#else  // CPU emulation builds of tests/emu: the register file is a struct in the lane's (fiber's) kernel frame
 struct RegFile {
   u256 r[16];
 };
@@ -2481,7 +2481,7 @@ static __device__ __noinline__ zkw_v16 zkw_vec_exec(zkw_v16 a, zkw_v16 b) {
   return lane_pack(s);
 #else
   (void)b;
-  return a;  // never reached in the single-lane emulation build
+  return a;  // never reached in the one-lane emulation build
 #endif
 }
 

@@ -1,9 +1,11 @@
 """Host-logic + kernel-logic checks that need no GPU.
 
-The product sources (era-zk_evm_amd/csrc/*.hip|cpp) are compiled UNMODIFIED by g++ against a
-single-lane stand-in for hip_runtime.h (tests/emu/, test infrastructure only) and driven through
-the same C ABI as the real library; every record must be bit-identical to the oracle's.  The real
-64-lane behaviour is covered by the `-m gpu` tests (tests/test_gpu_parity.py)."""
+The product sources (era-zk_evm_amd/csrc/*.hip|cpp) are compiled UNMODIFIED by g++ against a stand-in for hip_runtime.h
+(tests/emu/, test infrastructure only) and driven through the same C ABI as the real library; every record must be
+bit-identical to the oracle's.  Every test runs twice (the `emu` fixture): on one-lane waves executed sequentially, and on
+64-lane waves on the SIMT engine of tests/emu/emu_simt.cpp — the device's geometry, with ballots, ranks, the short cycle,
+variant groups, helper waves and the 256- / 320-thread pack and expand kernels (tests/test_emu64_lanes.py runs the GPU suite's
+own tests on that build).  Inline assembly, timing and the memory system are covered by the `-m gpu` tests alone."""
 import hashlib
 import os
 import sys
