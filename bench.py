@@ -703,7 +703,9 @@ def delivered_leg(dev, prod, flow, st, steps_min=200, dfuse=None, n_slots=3):
     return {"cycles_per_s": cycles_seen[0] / wall, "pcie_GBps": total_bytes / max(pack_ms, 1e-9) / 1e6, "pcie_GBps_over_the_region": link,
             # the leg's own roofline: the host link (MI355X_MICROARCH.md: PCIe Gen5 x16, 63 GB/s by the spec), achieved = link-format bytes over the whole region
             "roofline": {"bound": "pcie", "achieved": link, "peak": 63.0, "unit": "GB/s", "frac": link / 63.0},
-            "host_threads": threads, "cgroup_cpu_quota": _cpu_quota(), "bytes_per_cycle": total_bytes / max(1, cycles_seen[0]), "steps": steps, "batches_per_delivery": dfuse, "ring_slots": n_slots,
+            "host_threads": threads, "cgroup_cpu_quota": _cpu_quota(), "bytes_per_cycle": total_bytes / max(1, cycles_seen[0]), "link_flags": (infos[-1].get("link_flags") if infos else None),
+            "link_format": "zkw_pack.h version 2: bit 0 = memory reads without values (host shadow memory), bit 1 = pages implied by the frame (8-byte query headers), bit 2 = 13-byte record tails; 0 = the round-5 format",
+            "steps": steps, "batches_per_delivery": dfuse, "ring_slots": n_slots,
             "slot_MB": slot_bytes / 1e6, "ms_per_step": 1e3 * wall / steps, "pack_kernel_ms_per_step": pack_ms / steps,
             "host_replay_cycles_per_s": cycles_seen[0] / max(replay_s[0], 1e-9), "cycles_delivered": cycles_seen[0], "per_ticket_wait_replay_pack_ms_first_and_last": per_ticket[:4] + per_ticket[-4:],
             "steady_state_cycles_per_s": dfuse * int(st["cycles"]) / (1e-3 * sorted(w + r for w, r, _ in per_ticket)[len(per_ticket) // 2]),

@@ -376,7 +376,7 @@ class Backend:
 
 
 class DeliveredC(C.Structure):
-    _fields_ = [("bytes", C.c_uint64), ("pack_ms", C.c_double), ("n_batches", C.c_uint32), ("n_waves", C.c_uint32), ("overflow", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("bytes", C.c_uint64), ("pack_ms", C.c_double), ("n_batches", C.c_uint32), ("n_waves", C.c_uint32), ("overflow", C.c_uint32), ("link_flags", C.c_uint32)]
 
 
 CYCLE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32)
@@ -427,7 +427,7 @@ class Delivery:
     def wait(self, ticket):
         info = DeliveredC()
         self.be.call("delivery_wait", self.h, C.c_uint32(ticket), C.byref(info))
-        return {"bytes": info.bytes, "pack_ms": info.pack_ms, "n_batches": info.n_batches, "n_waves": info.n_waves, "overflow": info.overflow}
+        return {"bytes": info.bytes, "pack_ms": info.pack_ms, "n_batches": info.n_batches, "n_waves": info.n_waves, "overflow": info.overflow, "link_flags": info.link_flags}
 
     def trace(self, ticket, batch_index, i):
         t = InstanceTraceC()

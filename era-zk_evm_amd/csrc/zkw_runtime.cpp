@@ -2234,7 +2234,7 @@ int zkw_delivery_wait(zkw_delivery* d, uint32_t ticket, zkw_delivered* info) {
     HIP_TRY(c, hipEventElapsedTime(&ms, sl->ev_k0, sl->ev_k1));
     info->bytes = (uint64_t)std::min<uint64_t>(hd->used_units, sl->units) * 16;
     info->pack_ms = ms;
-    info->n_batches = hd->n_batches; info->n_waves = hd->n_waves; info->overflow = hd->overflow; info->reserved = 0;
+    info->n_batches = hd->n_batches; info->n_waves = hd->n_waves; info->overflow = hd->overflow; info->link_flags = hd->flags;
   }
   if (hd->overflow) {
     c->last_error = "zkw_delivery_wait: the step did not fit its slot (slot_bytes too small)";

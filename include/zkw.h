@@ -670,7 +670,8 @@ typedef struct zkw_delivered {
   double pack_ms;     /* device time of the pack kernel (HIP events on the delivery's stream) */
   uint32_t n_batches, n_waves;
   uint32_t overflow;  /* != 0: the step did not fit the slot (slot_bytes too small): nothing of it can be read */
-  uint32_t reserved;
+  uint32_t link_flags; /* what did NOT travel because the rebuild derives it (link format, csrc/zkw_pack.h): 1 = the values of memory
+                          reads, 2 = the pages of the VM's own stack / heap / code queries, 4 = the event counts of the record tails */
 } zkw_delivered;
 /* n_slots >= 1 slots of slot_bytes each (hipHostMalloc, once); host_threads >= 1 worker threads for the replay / rebuild */
 int zkw_delivery_create(zkw_ctx* ctx, uint32_t n_slots, uint64_t slot_bytes, uint32_t host_threads, zkw_delivery** out);

@@ -312,7 +312,7 @@ pub struct zkw_delivered {
     pub n_batches: u32,
     pub n_waves: u32,
     pub overflow: u32,
-    pub reserved: u32,
+    pub link_flags: u32,
 }
 pub type zkw_cycle_fn = unsafe extern "C" fn(user: *mut c_void, thread: u32, batch_index: u32, instance: u32, cycle: u32, state_after: *const zkw_cycle_record, mem: *const zkw_mem_query,
                                             n_mem: u32, log: *const zkw_log_query, n_log: u32, aux: *const zkw_aux_event, n_aux: u32);
