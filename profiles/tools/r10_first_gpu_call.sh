@@ -1,0 +1,22 @@
+#!/bin/bash
+# The first GPU call of a round that had none: is HEAD green on an MI355X, and what does the driver's
+# command print?   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash profiles/tools/r10_first_gpu_call.sh'
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+OUT=gpurun_out/r10_first; mkdir -p $OUT
+(python -m pytest tests -m gpu -x -q 2>&1 | tail -25) > $OUT/pytest.log
+python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_full.log 2>&1; grep '^{' $OUT/bench_full.log > $OUT/driver_full_line.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_driver -o r10 -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-other-configs --no-host-legs > $OUT/trace_driver.log 2>&1
+grep '^{' $OUT/trace_driver.log > $OUT/driver_bench.json
+find $OUT/trace_driver -name "*kernel_stats.csv" -exec cp {} $OUT/driver_kernel_stats.csv \;
+tail -3 $OUT/pytest.log; tail -1 $OUT/smoke.log
+python - <<'PY'
+import json
+for f in ("driver_full_line.json", "driver_bench.json"):
+    try:
+        j = json.loads(open("gpurun_out/r10_first/" + f).read().splitlines()[-1])
+        d = j.get("delivered") or {}
+        print(f, "value %.3g" % j["value"], "frac %.3f" % j["roofline"]["frac"], "kernel_ms %.4f" % j["kernel_ms"], "delivered %s B/cycle %s flags %s" % (d.get("cycles_per_s"), d.get("bytes_per_cycle"), d.get("link_flags")))
+    except Exception as e:
+        print(f, "unreadable:", e)
+PY
