@@ -15,8 +15,9 @@
 //                                       page a lane touches — the heap image it staged, zero elsewhere (SimpleMemory: fresh pages are
 //                                       zero-filled, reference_impls/memory.rs:15-148, 413-521), every write query of the stream applied
 //                                       in order — and fills `MemoryQuery.value` of the reads itself; only WRITES carry their value.
-//                                       Used when the host holds the heap images the step ran on (always after an upload; after a
-//                                       restage with heap images only under ZKW_OPT_KEEP_RESTAGED_HEAPS — else reads keep their values)
+//                                       Used when the host holds the heap images the step ran on: a copy made at upload, or the pinned
+//                                       staging buffer a restage handed them over in (kept by the step's ticket, ZKW_OPT_STAGING_BUFFERS);
+//                                       a batch restaged through a ring of ONE buffer keeps its read values
 //   memory-query page    implied        (version 2, ZKW_PACK_IMPLIED_PAGES) the page of a stack / heap / aux-heap / code query of the VM itself is
 //                                       base + 1 / + 2 / + 3 / the code page of the frame that is current in that cycle (execution_stack.rs:67-81,
 //                                       mem_ops.rs:51-121, uma.rs:100-135): the rebuild tracks the frames (initial callstack + the FRAME_START /

@@ -59,7 +59,8 @@ struct zkw_ctx {
   std::string last_error;
   // test hooks / ablations (zkw_ctx_set_option; the environment is read once, in zkw_ctx_create)
   uint32_t opt_debug_flags = 0, opt_reset_skip = 0, opt_waves_per_group = 0, opt_lanes_per_wave = 0, opt_pack_blocks = 0;
-  bool opt_keep_restaged_heaps = false, opt_read_values = false;
+  bool opt_read_values = false;
+  uint32_t opt_staging_buffers = 0;
   bool opt_no_inline_decommit = false, opt_debug_sync = false, opt_no_graph = false;
   // digests of code blobs already hashed on this context, keyed by a 128-bit content hash + length: batches that
   // share bytecode (the usual case) skip the sequential blob chain (~0.1 s for a 2000-word blob) at upload
@@ -109,10 +110,28 @@ struct BatchInputs {
   std::shared_ptr<const CodeInputs> code;
   // the heap images the step ran on ([n][heap_words], zero-padded) — what the shadow memory of the rebuild starts from when the
   // values of memory reads did not travel (ZKW_PACK_NO_READ_VALUES); heaps_known = false: the host does not hold them (a restage
-  // with heap images without ZKW_OPT_KEEP_RESTAGED_HEAPS) and every value has to travel
-  std::shared_ptr<const std::vector<zkw_u256>> heaps;
+  // with heap images through a ring of one staging buffer) and every value has to travel
+  const zkw_u256* heap_data = nullptr;       // [n][heap_words]
+  std::shared_ptr<const void> heap_owner;    // what keeps heap_data alive and unchanged: a vector (upload) or the pinned staging
+                                             // buffer the images were restaged from (StageMem) — no copy either way
   uint32_t heap_words = 0;
   bool heaps_known = false;
+};
+
+// One pinned staging buffer of zkw_batch_restage / zkw_batch_staging ([states | heap images], instance-major).  Reference-counted:
+// the batch holds it, and so does every BatchInputs whose heap images live in it — the batch does not hand such a buffer out again
+// (zkw_batch_staging takes another one of its ring), and the memory is freed when the last of them is gone.
+struct StageMem {
+  uint8_t* h = nullptr;
+  size_t bytes = 0;
+  ~StageMem() {
+    if (h) (void)hipHostFree(h);
+  }
+};
+struct StageBuf {
+  std::shared_ptr<StageMem> mem;
+  hipEvent_t ev = nullptr;  // behind the H2D copies of the last restage out of it
+  bool busy = false;
 };
 
 struct WaveTrace {  // de-interleaved streams of one wave
@@ -216,12 +235,11 @@ struct zkw_batch {
   std::vector<zkw_log_query> ns_st_hist, ns_ev_hist;
   std::vector<zkw_event_message> ns_events, ns_l1;
   std::vector<zkw_storage_slot> ns_final;
-  uint8_t* h_stage = nullptr;    // pinned staging of zkw_batch_restage ([states | heap images], instance-major) ...
+  std::vector<StageBuf> stage;   // pinned staging of zkw_batch_restage: a small ring (ZKW_OPT_STAGING_BUFFERS), `stage_cur` the one in use ...
+  uint32_t stage_cur = 0;
   DevBuf<uint8_t> d_stage;       // ... and where its H2D copies land (zkw_restage_kernel brings them into the device layouts)
+  size_t d_stage_bytes = 0;
   bool heaps_restaged = false;   // the staged heap vectors are older than the device's images
-  size_t h_stage_bytes = 0;
-  hipEvent_t ev_stage = nullptr;
-  bool stage_busy = false;
   uint4* h_pack = nullptr;       // pinned block of the on-demand pack (one wave at a time: zkw_batch_get_instance_trace)
   uint64_t h_pack_units = 0;
   DevBuf<uint32_t> d_pack_state;  // allocation cursor + overflow flag of the pack kernel
@@ -293,7 +311,7 @@ int zkw_ctx_set_option(zkw_ctx* c, uint32_t option, uint64_t value) {
       c->opt_waves_per_group = (uint32_t)value;
       break;
     case ZKW_OPT_LANES_PER_WAVE: c->opt_lanes_per_wave = (uint32_t)value; break;
-    case ZKW_OPT_KEEP_RESTAGED_HEAPS: c->opt_keep_restaged_heaps = value != 0; break;
+    case ZKW_OPT_STAGING_BUFFERS: c->opt_staging_buffers = (uint32_t)std::min<uint64_t>(value, 64); break;
     case ZKW_OPT_READ_VALUES: c->opt_read_values = value != 0; break;
     case ZKW_OPT_PACK_BLOCKS: c->opt_pack_blocks = (uint32_t)value; break;
     default: c->last_error = "unknown option"; return ZKW_ERR_INVALID;
@@ -509,9 +527,12 @@ void zkw_batch_destroy(zkw_batch* b) {
   b->d_ns_bucket_params.release(); b->d_ns_params.release(); b->d_commit.release(); b->d_rc.release(); b->d_blob_digests.release(); b->d_leaves.release(); b->d_midstates.release();
   b->d_idx.release(); b->d_counts.release(); b->d_dq_count.release(); b->d_dq_prev.release(); b->d_pack_state.release();
   if (b->h_pack) (void)hipHostFree(b->h_pack);
-  if (b->h_stage) (void)hipHostFree(b->h_stage);
+  for (StageBuf& sb : b->stage) {
+    if (sb.busy && sb.ev) (void)hipEventSynchronize(sb.ev);
+    if (sb.ev) (void)hipEventDestroy(sb.ev);
+  }
+  b->stage.clear();  // (a buffer a delivered step still reads heap images from lives on until that ticket is released)
   b->d_stage.release();
-  if (b->ev_stage) (void)hipEventDestroy(b->ev_stage);
   if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
   if (b->graph) (void)hipGraphDestroy(b->graph);
   for (hipEvent_t e : b->evs) (void)hipEventDestroy(e);
@@ -1068,7 +1089,8 @@ int zkw_batch_upload(zkw_batch* b) {
         const auto& h = b->staged[i].heap;
         if (!h.empty()) std::memcpy(hv->data() + (size_t)i * b->heap_image_words, h.data(), std::min<size_t>(h.size(), b->heap_image_words) * 32);
       }
-      in->heaps = hv;
+      in->heap_data = hv->data();
+      in->heap_owner = hv;
       in->heap_words = b->heap_image_words;
       in->heaps_known = true;  // (an upload is refused while the staged heaps are older than a restage's)
     }
@@ -1656,13 +1678,13 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
     }
   };
   std::vector<Shadow> shadow(shadowed ? L : 0);
-  if (shadowed && in.heaps && in.heap_words)
+  if (shadowed && in.heap_data && in.heap_words)
     for (uint32_t l = 0; l < L; l++) {
       const uint32_t inst = w * L + l;
       if (inst >= n_inst) continue;
       ShadowPage pg;
       pg.page = in.states[inst].current.base_memory_page + 2u;  // heap_page_from_base of the frame the image was staged for
-      pg.image = in.heaps->data() + (size_t)inst * in.heap_words;
+      pg.image = in.heap_data + (size_t)inst * in.heap_words;
       pg.image_words = in.heap_words;
       shadow[l].pages.push_back(std::move(pg));
     }
@@ -2330,21 +2352,47 @@ int zkw_delivery_release(zkw_delivery* d, uint32_t ticket) {
   return ZKW_OK;
 }
 
-// pinned staging of a batch's fresh inputs ([states | heap images], instance-major as the C ABI takes them) + the device
-// buffers the H2D copies land in: allocated on first use
-static int ensure_stage(zkw_batch* b) {
+// Pinned staging of a batch's fresh inputs ([states | heap images], instance-major as the C ABI takes them) + the device buffer the
+// H2D copies land in.  The host side is a small ring of buffers: a buffer whose heap images a BatchInputs still reads (the current
+// staging of the batch, or a delivered step whose ticket is held) is not handed out again — the shadow memory of the rebuild reads
+// the images right there, nothing is copied to keep them.  acquire_stage picks the buffer the next restage writes into.
+static int acquire_stage(zkw_batch* b) {
   zkw_ctx* c = b->ctx;
   const size_t bytes = (size_t)b->n * sizeof(zkw_vm_local_state) + (size_t)b->n * b->heap_image_words * 32 + 16;
-  if (b->h_stage_bytes >= bytes) return ZKW_OK;
-  if (b->stage_busy) HIP_TRY(c, hipEventSynchronize(b->ev_stage));
-  b->stage_busy = false;
-  if (b->h_stage) (void)hipHostFree(b->h_stage);
-  b->h_stage = nullptr;
-  b->d_stage.release();
-  HIP_TRY(c, hipHostMalloc((void**)&b->h_stage, bytes, hipHostMallocDefault));
-  HIP_TRY(c, b->d_stage.alloc(bytes));
-  b->h_stage_bytes = bytes;
-  if (!b->ev_stage) HIP_TRY(c, hipEventCreate(&b->ev_stage));
+  const uint32_t cap = c->opt_staging_buffers ? c->opt_staging_buffers : 4u;
+  if (b->d_stage_bytes < bytes) {
+    b->d_stage.release();
+    HIP_TRY(c, b->d_stage.alloc(bytes));
+    b->d_stage_bytes = bytes;
+  }
+  uint32_t pick = 0xffffffffu;
+  const uint32_t N = (uint32_t)b->stage.size();
+  for (uint32_t k = 0; k < N && pick == 0xffffffffu; k++) {
+    const uint32_t j = (b->stage_cur + k) % N;
+    if (!b->stage[j].mem || b->stage[j].mem.use_count() == 1) pick = j;  // nobody but the batch holds it
+  }
+  if (pick == 0xffffffffu) {
+    if (N >= cap) {
+      c->last_error = "zkw_batch_restage / zkw_batch_staging: all " + std::to_string(N) + " staging buffers of the batch still hold the heap images of steps whose delivery "
+                      "tickets are held — release tickets first (or raise ZKW_OPT_STAGING_BUFFERS)";
+      return ZKW_ERR_LIMIT;
+    }
+    b->stage.emplace_back();
+    pick = N;
+  }
+  StageBuf& sb = b->stage[pick];
+  if (sb.busy) {  // the copies of the restage that used it last still read it
+    HIP_TRY(c, hipEventSynchronize(sb.ev));
+    sb.busy = false;
+  }
+  if (!sb.mem || sb.mem->bytes < bytes) {
+    auto m = std::make_shared<StageMem>();
+    HIP_TRY(c, hipHostMalloc((void**)&m->h, bytes, hipHostMallocDefault));
+    m->bytes = bytes;
+    sb.mem = m;
+  }
+  if (!sb.ev) HIP_TRY(c, hipEventCreate(&sb.ev));
+  b->stage_cur = pick;
   return ZKW_OK;
 }
 
@@ -2356,14 +2404,11 @@ int zkw_batch_staging(zkw_batch* b, zkw_vm_local_state** states, zkw_u256** heap
     return ZKW_ERR_INVALID;
   }
   HIP_TRY(c, hipSetDevice(c->device));
-  int rc = ensure_stage(b);
+  int rc = acquire_stage(b);
   if (rc != ZKW_OK) return rc;
-  if (b->stage_busy) {  // the copies of the previous restage still read the staging memory
-    HIP_TRY(c, hipEventSynchronize(b->ev_stage));
-    b->stage_busy = false;
-  }
-  *states = (zkw_vm_local_state*)b->h_stage;
-  if (heap_words) *heap_words = (zkw_u256*)(b->h_stage + (((size_t)b->n * sizeof(zkw_vm_local_state) + 15) & ~(size_t)15));
+  uint8_t* h = b->stage[b->stage_cur].mem->h;
+  *states = (zkw_vm_local_state*)h;
+  if (heap_words) *heap_words = (zkw_u256*)(h + (((size_t)b->n * sizeof(zkw_vm_local_state) + 15) & ~(size_t)15));
   if (n_heap_words) *n_heap_words = b->heap_image_words;
   return ZKW_OK;
 }
@@ -2390,18 +2435,29 @@ int zkw_batch_restage(zkw_batch* b, const zkw_vm_local_state* states, const zkw_
     }
   }
   HIP_TRY(c, hipSetDevice(c->device));
-  int rc = ensure_stage(b);
-  if (rc != ZKW_OK) return rc;
   const size_t st_bytes = (size_t)n * sizeof(zkw_vm_local_state), heap_off = (st_bytes + 15) & ~(size_t)15, heap_bytes = (size_t)n * himg * 32;
-  const bool in_place = (const uint8_t*)states == b->h_stage;  // the caller filled the staging memory of zkw_batch_staging: nothing to copy
+  // the caller filled the staging buffer zkw_batch_staging handed out: nothing to copy
+  const bool in_place = !b->stage.empty() && b->stage[b->stage_cur].mem && (const uint8_t*)states == b->stage[b->stage_cur].mem->h;
   if (!in_place) {
-    if (b->stage_busy) {
-      HIP_TRY(c, hipEventSynchronize(b->ev_stage));
-      b->stage_busy = false;
+    int rc = acquire_stage(b);  // a buffer nobody reads any more
+    if (rc != ZKW_OK) return rc;
+    std::memcpy(b->stage[b->stage_cur].mem->h, states, st_bytes);
+  } else {
+    // The caller wrote into the buffer zkw_batch_staging handed out.  If it kept the pointers from an EARLIER call and a delivered
+    // step still reads its heap images out of this very buffer, they have just been overwritten under it: refuse instead of
+    // rebuilding that step's memory reads from the wrong images.  (Holders: the batch, and its own current inputs.)
+    const std::shared_ptr<StageMem>& m = b->stage[b->stage_cur].mem;
+    const bool mine = b->inputs && b->inputs->heap_owner.get() == (const void*)m.get();
+    const long expected = 1 + (mine ? 1 : 0);
+    if (m.use_count() > expected || (mine && b->inputs.use_count() > 1)) {  // (a ticket shares the batch's inputs OBJECT, not the buffer)
+      c->last_error = "zkw_batch_restage: the staging buffer passed in still holds the heap images of a delivered step whose ticket is held: "
+                      "call zkw_batch_staging again for every restage (it hands out a buffer nobody reads)";
+      return ZKW_ERR_INVALID;
     }
-    std::memcpy(b->h_stage, states, st_bytes);
   }
-  if (heap_words && (const uint8_t*)heap_words != b->h_stage + heap_off) std::memcpy(b->h_stage + heap_off, heap_words, heap_bytes);
+  StageBuf& sb = b->stage[b->stage_cur];
+  uint8_t* const h_stage = sb.mem->h;
+  if (heap_words && (const uint8_t*)heap_words != h_stage + heap_off) std::memcpy(h_stage + heap_off, heap_words, heap_bytes);
   // the library's own copy of the initial states (what a trace is rebuilt onto); the staged heap vectors are not kept in step —
   // a later zkw_batch_upload needs zkw_batch_set_heap again
   for (uint32_t i = 0; i < n; i++) b->staged[i].state = states[i];
@@ -2411,20 +2467,24 @@ int zkw_batch_restage(zkw_batch* b, const zkw_vm_local_state* states, const zkw_
     in->code = b->inputs->code;
     in->heap_words = himg;
     if (!heap_words) {  // the images stay what they were
-      in->heaps = b->inputs->heaps;
+      in->heap_data = b->inputs->heap_data;
+      in->heap_owner = b->inputs->heap_owner;
       in->heaps_known = b->inputs->heaps_known;
-    } else if (c->opt_keep_restaged_heaps) {
-      in->heaps = std::make_shared<std::vector<zkw_u256>>((const zkw_u256*)(b->h_stage + heap_off), (const zkw_u256*)(b->h_stage + heap_off) + (size_t)n * himg);
+    } else if ((c->opt_staging_buffers ? c->opt_staging_buffers : 4u) > 1) {
+      // the images stay where they were handed over: the inputs hold the staging buffer (no copy), the batch takes another one
+      // of its ring for the next restage
+      in->heap_data = (const zkw_u256*)(h_stage + heap_off);
+      in->heap_owner = sb.mem;
       in->heaps_known = true;
-    }
+    }  // (a ring of ONE buffer is overwritten by the next restage: the images are then not kept, memory reads travel with values)
     b->inputs = in;
   }
   if (heap_words) b->heaps_restaged = true;
   hipStream_t st = (hipStream_t)hip_stream;
-  HIP_TRY(c, hipMemcpyAsync(b->d_stage.p, b->h_stage, st_bytes, hipMemcpyHostToDevice, st));
-  if (heap_words && heap_bytes) HIP_TRY(c, hipMemcpyAsync(b->d_stage.p + heap_off, b->h_stage + heap_off, heap_bytes, hipMemcpyHostToDevice, st));
-  HIP_TRY(c, hipEventRecord(b->ev_stage, st));
-  b->stage_busy = true;
+  HIP_TRY(c, hipMemcpyAsync(b->d_stage.p, h_stage, st_bytes, hipMemcpyHostToDevice, st));
+  if (heap_words && heap_bytes) HIP_TRY(c, hipMemcpyAsync(b->d_stage.p + heap_off, h_stage + heap_off, heap_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipEventRecord(sb.ev, st));
+  sb.busy = true;
   zkw_restage_params R;
   std::memset(&R, 0, sizeof R);
   R.states = (const zkw_vm_local_state*)b->d_stage.p;

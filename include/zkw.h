@@ -446,9 +446,12 @@ int zkw_ctx_set_isa(zkw_ctx* ctx, const zkw_isa_table* table); /* copies */
 #define ZKW_OPT_WAVES_PER_GROUP 7u     /* 1 .. 8 waves per workgroup of the cycle kernel instead of the choice made per launch (0) */
 #define ZKW_OPT_LANES_PER_WAVE 8u      /* overrides zkw_limits.lanes_per_wave (batches created afterwards) */
 #define ZKW_OPT_PACK_BLOCKS 9u         /* workgroups of the pack kernel of deliveries created afterwards (0 = 64: the link, not the chip, bounds it) */
-#define ZKW_OPT_KEEP_RESTAGED_HEAPS 10u /* 1 = zkw_batch_restage keeps a host copy of the heap images it is given, so that steps run on them are
-                                          delivered without the values of memory reads too (link format: csrc/zkw_pack.h); 0 = no copy, such steps
-                                          carry every value */
+#define ZKW_OPT_STAGING_BUFFERS 10u     /* pinned staging buffers a batch may hold for zkw_batch_restage / zkw_batch_staging (0 = default: 4).  The heap images of
+                                          a restage stay in the buffer they were handed over in for as long as something reads them — the batch's current
+                                          inputs, a delivered step whose ticket is held (its memory reads travel without values and are rebuilt from the
+                                          images: csrc/zkw_pack.h) — and the next restage takes another buffer of the ring; all of them taken:
+                                          ZKW_ERR_LIMIT (release tickets).  1 = one buffer, overwritten by every restage: steps that ran on restaged heap
+                                          images then carry the values of their memory reads on the link */
 #define ZKW_OPT_READ_VALUES 11u        /* 1 = the values of memory reads always travel (the round-5 link format: A/B, tests) */
 int zkw_ctx_set_option(zkw_ctx* ctx, uint32_t option, uint64_t value);
 
@@ -712,8 +715,9 @@ int zkw_delivery_release(zkw_delivery* d, uint32_t ticket);
  * The interleaved device layouts are produced ON the device (zkw_restage_kernel): the host only copies the caller's arrays
  * into pinned memory — or not even that: zkw_batch_staging hands out the pinned buffers themselves (states [n_instances],
  * heap_words [n_instances][*n_heap_words]), a caller that builds its inputs there passes those pointers to zkw_batch_restage
- * and nothing is copied on the host.  (zkw_batch_staging waits until the copies of the previous restage have left the
- * buffers.)  After a restage with heap images the library no longer holds the batch's heaps on the host: another
+ * and nothing is copied on the host.  The pointers are good for ONE restage: a batch holds a small ring of staging buffers
+ * (ZKW_OPT_STAGING_BUFFERS), the heap images of a restage stay in their buffer while a delivered step still rebuilds its memory
+ * reads from them, and every zkw_batch_staging hands out a buffer nobody reads (waiting for the H2D copies that last used it).  After a restage with heap images the library no longer holds the batch's heaps on the host: another
  * zkw_batch_upload needs zkw_batch_set_heap again.
  * The uploaded image length is the LONGEST heap any instance was given (zkw_batch_set_heap); a restaged image has that length
  * for every instance, whatever the instance itself had uploaded — all of its words are readable afterwards.

@@ -304,7 +304,9 @@ def check_end_to_end_pipeline(oracle, prod, isa, n_instances, n_groups=3, per_gr
 
     def consume(it):
         t, k = tickets.pop(it)
-        assert dv.wait(t)["overflow"] == 0
+        info = dv.wait(t)
+        assert info["overflow"] == 0
+        assert info["link_flags"] == 7  # restaged heap images stay in their staging buffer: the reads of this step travel without values too
         for bi in range(per_group):
             for i in pick:
                 ok, why = K.traces_equal(refs[k].trace(i), dv.trace(t, bi, i))
@@ -334,6 +336,88 @@ def check_end_to_end_pipeline(oracle, prod, isa, n_instances, n_groups=3, per_gr
 
 def test_end_to_end_pipeline_restage_run_deliver_replay(oracle, emu, isa):
     check_end_to_end_pipeline(oracle, emu, isa, n_instances=4)
+
+
+def check_staging_ring(oracle, prod, isa):
+    """The ring of staging buffers: (a) a held ticket keeps the buffer its heap images were restaged from — the next
+    zkw_batch_staging hands out another one, and the ticket's memory reads are still rebuilt correctly after that one was filled
+    with other images; (b) a restage through the pointers of an EARLIER zkw_batch_staging call, into a buffer a held ticket reads, is refused; (c) with every
+    buffer of the ring held, a restage reports ZKW_ERR_LIMIT until a ticket is released; (d) a ring of one buffer
+    (ZKW_OPT_STAGING_BUFFERS = 1) works as in round 5: the step's reads carry their values."""
+    n = 4
+    wl = synth.make(2, isa, n_instances=n)
+    sets, refs = [], []
+    for k in range(5):
+        w = synth.make(2, isa, n_instances=n, seed=0x5EED9900 + k)
+        wr = synth.make(2, isa, n_instances=n)
+        wr.states, wr.heaps = w.states, w.heaps
+        bo = _run(oracle, wr); bo.sync()
+        sets.append(w); refs.append(bo)
+    b = _run(prod, wl)
+    dv = K.Delivery(prod, 8, K.Delivery.worst_case_bytes(prod, [b]), 2)
+
+    def step_in_place(k):
+        sv, hv = b.staging()
+        sv[:] = sets[k].states; hv[:] = sets[k].heaps
+        b.restage(sv, hv)
+        b.run(wl.n_cycles)
+        return dv.submit([b]), (sv, hv)
+
+    def check(t, k, what):
+        info = dv.wait(t)
+        for i in range(n):
+            ok, why = K.traces_equal(refs[k].trace(i), dv.trace(t, 0, i))
+            assert ok, "%s, instance %d: %s" % (what, i, why)
+        return info
+
+    t0, views0 = step_in_place(0)
+    t1, _ = step_in_place(1)  # another buffer: ticket 0 still reads the images of set 0
+    assert check(t0, 0, "ticket 0 after the next in-place restage")["link_flags"] == 7
+    assert check(t1, 1, "ticket 1")["link_flags"] == 7
+    sv, hv = b.staging()  # a third buffer
+    sv[:] = sets[2].states; hv[:] = sets[2].heaps
+    b.restage(sv, hv); b.run(wl.n_cycles)
+    t2 = dv.submit([b])
+    check(t2, 2, "ticket 2")
+    dv.release(t0)
+    # (c) the ring is 4 by default: tickets 1, 2 + two more held -> the fifth restage finds no free buffer
+    t3, _ = step_in_place(3)
+    t4, views4 = step_in_place(4)
+    with pytest.raises(K.ZkwError) as e:
+        b.staging()
+    assert "staging buffers" in str(e.value)
+    with pytest.raises(K.ZkwError) as e:  # (b) the pointers of the LAST staging call, reused while ticket 4 reads that buffer
+        b.restage(views4[0], views4[1])
+    assert "zkw_batch_staging again" in str(e.value)
+    check(t3, 3, "ticket 3"); check(t4, 4, "ticket 4")
+    dv.release(t1)
+    sv, hv = b.staging()  # ticket 1's buffer is free again
+    for t in (t2, t3, t4):
+        dv.release(t)
+    dv.close()
+    b.destroy()
+    # (d) one buffer
+    prod.set_option(K.OPT_STAGING_BUFFERS, 1)
+    try:
+        b = _run(prod, synth.make(2, isa, n_instances=n))
+        dv = K.Delivery(prod, 2, K.Delivery.worst_case_bytes(prod, [b]), 1)
+        b.restage(sets[0].states, sets[0].heaps); b.run(wl.n_cycles)
+        t = dv.submit([b])
+        b.restage(sets[1].states, sets[1].heaps)  # overwrites the one buffer: harmless, ticket t carries its read values
+        info = dv.wait(t)
+        assert info["link_flags"] == 6
+        for i in range(n):
+            ok, why = K.traces_equal(refs[0].trace(i), dv.trace(t, 0, i))
+            assert ok, "one staging buffer, instance %d: %s" % (i, why)
+        dv.release(t); dv.close(); b.destroy()
+    finally:
+        prod.set_option(K.OPT_STAGING_BUFFERS, 0)
+    for bo in refs:
+        bo.destroy()
+
+
+def test_staging_ring(oracle, emu, isa):
+    check_staging_ring(oracle, emu, isa)
 
 
 # (the bodies above take any backend: tests/test_gpu_parity.py runs them on the device)

@@ -998,6 +998,11 @@ def test_restage_after_a_ragged_upload_on_gpu(oracle, product, isa):
     check_restage_after_a_ragged_upload(oracle, product, isa)
 
 
+def test_staging_ring_on_gpu(oracle, product, isa):
+    from test_delivery import check_staging_ring
+    check_staging_ring(oracle, product, isa)
+
+
 def test_a_ticket_outlives_the_restage_and_the_destruction_of_its_batch_on_gpu(oracle, product, isa):
     from test_delivery import check_a_ticket_outlives_the_restage_and_the_destruction_of_its_batch
     check_a_ticket_outlives_the_restage_and_the_destruction_of_its_batch(oracle, product, isa)
