@@ -44,6 +44,17 @@
 // (defined in zkw_device.h; ZKW_LOCKSTEP() marks a place where the code relies on the lanes of a wave running in lockstep
 // through wave-shared memory: nothing on the device, a rendezvous of the lanes in the emulation.)
 
+// The HOST pass of the device build parses the device functions below and never runs them: stand-ins for what only the
+// emulation build's hip_runtime.h provides to the non-device branches (the wave's cursor registers, the yield of a waiting wave).
+#if !defined(__HIP_DEVICE_COMPILE__) && !defined(ZKW_EMU_BUILD)
+static __host__ __device__ inline uint32_t* zkw_emu_wave_sregs() { return nullptr; }
+#define ZKW_EMU_FETCH_ADD(reg, n) (zkw_emu_wave_sregs()[(reg)] + (n))
+#define ZKW_EMU_YIELD() ((void)0)
+#endif
+#ifndef ZKW_EMU_BUILD
+extern __shared__ uint4 zkw_lds[];  // the dynamic LDS segment of the cycle kernel's workgroups (layout: ZKW_LDS_WAVES0 below)
+#endif  // (the emulation build's stand-in header declares the segment)
+
 // Test hook of the CPU emulation builds (tests/emu): lane-cycles by path, so that a test can assert that a tape really
 // went through the short cycle / a variant group.  Nothing in the product.
 #ifdef ZKW_EMU_BUILD
@@ -506,9 +517,6 @@ ZKW_CFV_EMU(heap_hwm, CF_HEAP_HWM)
 #else
 #define ZKW_PIN_SGPR(x) ((void)0)
 #endif
-#ifndef ZKW_EMU_BUILD
-extern __shared__ uint4 zkw_lds[];
-#endif  // (the emulation build's stand-in header declares the segment)
 // dynamic LDS of a workgroup, in 16-byte units: ISA table | 256-byte sink of the prefetches (prefetch_page_words; kept below
 // 64 KB whatever the workgroup size) | one area per cycle wave | the hand-over areas of the helper waves
 #define ZKW_LDS_SINK_UNITS 16u
