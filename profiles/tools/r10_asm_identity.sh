@@ -17,7 +17,10 @@ for f in zkw_kernels zkw_commit zkw_expand zkw_blake2s zkw_pack; do
   lines=$(grep -vc '^\s*;' $T/$f.new.s)
   if [ "$n" = "0" ]; then echo "  $f.hip: IDENTICAL ($lines lines of assembly)"; else echo "  $f.hip: differs in $n lines"; fi
 done
-grep -A3 "^_Z16zkw_cycle_kernel" $T/zkw_kernels.new.s > /dev/null
+# the host pass of the same translation units (hipcc compiles every .hip twice: a tree whose device pass is fine can still fail to build)
+for f in zkw_kernels zkw_commit zkw_expand zkw_blake2s zkw_pack; do
+  if hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c --cuda-host-only -I include -I era-zk_evm_amd/csrc -o $T/$f.host.o era-zk_evm_amd/csrc/$f.hip 2>$T/$f.host.log; then echo "  $f.hip: host pass compiles"; else echo "  $f.hip: HOST PASS FAILS"; grep " error" $T/$f.host.log | head -3; fi
+done
 echo "cycle kernel code object (working tree):"
 awk '/\.name: *_Z16zkw_cycle_kernel/{f=1} f&&/sgpr_spill_count|vgpr_spill_count|private_segment_fixed_size|\.vgpr_count|\.sgpr_count|agpr_count/{print "  " $0} /\.name:/{if(f&&!/zkw_cycle_kernel/)f=0}' $T/zkw_kernels.new.s | sort -u
 rm -rf $T
