@@ -10,3 +10,6 @@ EMULIB=/tmp/libzkw_emu1_asan.so LD_PRELOAD=$(gcc -print-file-name=libasan.so) AS
 echo "== 64-lane emulation build (SIMT engine), -fsanitize=undefined (-fno-sanitize-recover)"
 g++ $COMMON -fsanitize=undefined -fno-sanitize-recover=undefined -DZKW_EMU_WAVE=64 -o /tmp/libzkw_emu64_ubsan.so $SRC || exit 1
 EMULIB=/tmp/libzkw_emu64_ubsan.so LD_PRELOAD=$(gcc -print-file-name=libubsan.so) python profiles/tools/r10_sanitizer_run.py; echo "exit code $?"
+echo "== one-lane emulation build, -fsanitize=thread (the delivery ring's worker threads replay beside the caller's thread)"
+g++ $COMMON -fsanitize=thread -DZKW_EMU_WAVE=1 -o /tmp/libzkw_emu1_tsan.so $SRC || exit 1
+EMULIB=/tmp/libzkw_emu1_tsan.so LD_PRELOAD=$(gcc -print-file-name=libtsan.so) TSAN_OPTIONS="halt_on_error=1 report_signal_unsafe=0" python profiles/tools/r10_sanitizer_run.py; echo "exit code $?"
