@@ -55,6 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-legs", action="store_true", help="run the two host legs on a workload that is not the headline one (tests)")
     ap.add_argument("--no-host-legs", action="store_true", help="skip the two host legs the headline command runs after its timed regions: `delivered` (pipelined steps packed into the pinned ring and replayed on the host's cores) and `upload` (fresh inputs for every step)")
+    ap.add_argument("--link-flags-off", type=int, default=0, help="parts of the link format the host legs leave out (ZKW_OPT_LINK_FLAGS_OFF: 1 read values travel, 2 every page travels, 4 | 16 16-byte record tails, 8 32-byte register deltas; 31 = the round-5 format): the A/B partner of the `delivered` / `end_to_end` figures")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the other BASELINE configurations that the headline command runs after its timed region")
     ap.add_argument("--repeats", type=int, default=-1, help="further timed regions of the same K steps behind the first (value_min / median / max); default 4 on the headline workload, else 0")
     ap.add_argument("--restore", choices=["between-uses", "every-step"], default="between-uses",
@@ -522,6 +523,8 @@ def measure(dev, prod, isa, args, rank, world, comm, collective, transport, with
         # untimed for the headline: the two host legs (N = 1: the link and the host cores are per box)
         delivered = upload = upload_in_place = end_to_end = None
         if getattr(args, "host_legs", False) and world == 1 and rank == 0:
+            if getattr(args, "link_flags_off", 0):
+                prod.set_option(K.OPT_LINK_FLAGS_OFF, args.link_flags_off)
             try:
                 delivered = delivered_leg(dev, prod, flow, st)
             except Exception as e:  # noqa: BLE001  (an auxiliary measurement must not take the headline line with it)
@@ -662,12 +665,14 @@ def delivered_leg(dev, prod, flow, st, steps_min=200, dfuse=None, n_slots=3):
     main = flow.main_stream
     flow.prepare()
     tickets, infos, replay_s, cycles_seen = {}, [], [0.0], [0]
+    wait_s = [0.0]
     per_ticket = []
 
     def consume(it):
         t_w = time.perf_counter()
         info = dv.wait(tickets[it])
         t_r = time.perf_counter()
+        wait_s[0] += t_r - t_w
         n, _ = dv.replay(tickets[it])
         replay_s[0] += time.perf_counter() - t_r
         per_ticket.append((round(1e3 * (t_r - t_w), 2), round(1e3 * (time.perf_counter() - t_r), 2), round(info["pack_ms"], 2)))
@@ -704,7 +709,9 @@ def delivered_leg(dev, prod, flow, st, steps_min=200, dfuse=None, n_slots=3):
             # the leg's own roofline: the host link (MI355X_MICROARCH.md: PCIe Gen5 x16, 63 GB/s by the spec), achieved = link-format bytes over the whole region
             "roofline": {"bound": "pcie", "achieved": link, "peak": 63.0, "unit": "GB/s", "frac": link / 63.0},
             "host_threads": threads, "cgroup_cpu_quota": _cpu_quota(), "bytes_per_cycle": total_bytes / max(1, cycles_seen[0]), "link_flags": (infos[-1].get("link_flags") if infos else None),
-            "link_format": "zkw_pack.h version 2: bit 0 = memory reads without values (host shadow memory), bit 1 = pages implied by the frame (8-byte query headers), bit 2 = 13-byte record tails; 0 = the round-5 format",
+            "link_format": "zkw_pack.h version 2: bit 0 = memory reads without values (host shadow memory), bit 1 = pages implied by the frame (8-byte query headers), bit 2 = record tails without event counts, bit 3 = register deltas without their zero upper bytes, bit 4 = record tails as differences (one u32 + exceptions); 0 = the round-5 format",
+            # what the leg waits for: the host thread blocked in zkw_delivery_wait (the block is still crossing the link / being packed) against the time it spent in zkw_delivery_replay
+            "bound_by": ("host replay on %d threads" % threads) if replay_s[0] > wait_s[0] else "link (pack kernel + PCIe)", "host_wait_s": wait_s[0], "host_replay_s": replay_s[0], "region_s": wall,
             "steps": steps, "batches_per_delivery": dfuse, "ring_slots": n_slots,
             "slot_MB": slot_bytes / 1e6, "ms_per_step": 1e3 * wall / steps, "pack_kernel_ms_per_step": pack_ms / steps,
             "host_replay_cycles_per_s": cycles_seen[0] / max(replay_s[0], 1e-9), "cycles_delivered": cycles_seen[0], "per_ticket_wait_replay_pack_ms_first_and_last": per_ticket[:4] + per_ticket[-4:],
@@ -902,7 +909,7 @@ def end_to_end_leg(dev, prod, flow, st, in_place, steps_min=200, dfuse=None, n_s
     return {"cycles_per_s": cycles_seen[0] / wall, "steps": steps, "ms_per_step": 1e3 * wall / steps, "in_place": in_place, "d2h_GBps": d2h / wall / 1e9, "h2d_GBps": h2d / wall / 1e9,
             "d2h_bytes_per_cycle": d2h / max(1, cycles_seen[0]), "h2d_bytes_per_cycle": h2d / max(1, cycles_seen[0]), "host_threads": threads, "restage_threads": pool_threads,
             "host_restage_ms_per_step": 1e3 * t_host[0] / steps, "batches_per_delivery": dfuse, "ring_slots": n_slots, "cycles_delivered": cycles_seen[0],
-            "link_flags": (infos[-1].get("link_flags") if infos else None)}  # (7: the restaged heap images stayed in their staging buffers — reads without values on this leg too)
+            "link_flags": (infos[-1].get("link_flags") if infos else None)}  # (31: the restaged heap images stayed in their staging buffers — reads without values on this leg too)
 
 
 K_VM_STATE_BYTES = 680

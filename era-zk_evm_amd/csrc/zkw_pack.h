@@ -36,8 +36,13 @@
 //   wave data, allocated in the order the workgroups get to them (zkw_pack_wave.off):
 //     dir      (max_cyc + 1)                stream cursors at every cycle start
 //     tails    max_cyc x L x 16 B — or, slim: planes x | y | z of ceil4(max_cyc x L) units each (ptr bitmap, flags, low delta mask | pc, sp |
-//              ergs) and one plane of ceil16(max_cyc x L) units with the high byte of the delta mask
-//     deltas   n_delta (low plane), n_delta (high plane)
+//              ergs) and one plane of ceil16(max_cyc x L) units with the high byte of the delta mask — or, as differences
+//              (ZKW_PACK_DELTA_TAILS): one plane of u32 (zkw_pack_tail_word: delta mask | ergs spent in the cycle | flags | "pc went on by
+//              one and sp stayed" | "the pointer bitmap stayed"), then three lists of u32 with what was not as predicted, each in
+//              lane-cycle order: ptr bitmap | flags, pc | sp, ergs (n_tx, n_ty, n_tz entries; every lane's first cycle is in all three)
+//     deltas   n_delta (low plane), n_delta (high plane) — or sparse (ZKW_PACK_SPARSE_DELTAS, zkw_pack_delta_units): bit planes, bytes 0..7 of
+//              every delta, bytes 8..15 of those that have any, bytes 16..31 of those that have any (addresses, counters, lengths and
+//              flags are most of what a VM writes to its registers: half of the deltas of the headline tape fit 16 bytes, 0.4 fit 8)
 //     mem      the page list (ceil4(n_page) units of u32: the pages of the queries that carry one, zkw_pack_has_page, in stream
 //              order — every query when pages are not implied), 2 planes of ceil4(n_mem) u32 (index | misc), then n_val (value
 //              low), n_val (value high): the values of
@@ -56,6 +61,9 @@
 #define ZKW_PACK_IMPLIED_PAGES 2u  /* ... the page list holds the pages of fat-pointer and precompile queries only */
 #define ZKW_PACK_SLIM_TAILS 4u     /* ... the record tails travel as 13 bytes (three u32 planes + one byte plane) instead of 16: the three
                                       event counts of a cycle are the numbers of its queries in the streams, which the rebuild counts anyway */
+#define ZKW_PACK_SPARSE_DELTAS 8u /* ... a register delta travels as its low 8 bytes + bytes 8..15 if any is set + bytes 16..31 if any is set (two bit planes say which) */
+#define ZKW_PACK_DELTA_TAILS 16u   /* ... a record tail travels as ONE u32 (delta mask | ergs spent | flags | "pc, sp, pointer bitmap as predicted") and the words
+                                      that were not as predicted in three lists */
 #define ZKW_PACK_HEADER_UNITS 4u
 #define ZKW_PACK_BATCH_UNITS 2u
 #define ZKW_PACK_WAVE_UNITS 4u
@@ -84,7 +92,9 @@ typedef struct zkw_pack_wave { /* 64 B */
   uint32_t n_delta, n_mem, n_val, n_log, n_aux, aux_units;
   uint32_t units;     /* units of the wave's data */
   uint32_t n_page;    /* entries of the page list */
-  uint32_t reserved[6];
+  uint32_t n_d1, n_d2; /* sparse deltas: entries of the plane of bytes 8..15, of the plane of bytes 16..31 */
+  uint32_t n_tx, n_ty, n_tz; /* delta tails: entries of the three lists (pointer bitmap | flags, pc | sp, ergs) */
+  uint32_t reserved;
 } zkw_pack_wave;
 
 /* units a record of the aux stream uses, by type (the kernel writes only those: zkw_kernels.hip start_frame / op_far_call) */
@@ -92,15 +102,58 @@ ZKW_HD static inline uint32_t zkw_aux_used_units(uint32_t type) {
   return type == ZKW_AUX_FRAME_START ? 15u : type == ZKW_AUX_DECOMMIT ? 4u : type == ZKW_AUX_COLD_STATE ? 3u : 1u;
 }
 ZKW_HD static inline uint32_t zkw_ceil4(uint32_t n) { return (n + 3u) >> 2; }
-/* units of a wave's data */
-/* units of the tails of n_t lane-cycles: 16 bytes each, or (slim) three u32 planes + one byte plane — never more than n_t + 4 */
-ZKW_HD static inline uint64_t zkw_pack_tail_units(uint64_t n_t, uint32_t flags) {
+/* what the size of a wave's data follows from (the wave's table entry holds the same numbers) */
+typedef struct zkw_pack_counts {
+  uint32_t max_cyc, L, n_delta, n_mem, n_page, n_val, n_log, aux_units;
+  uint32_t n_d1, n_d2;       /* ZKW_PACK_SPARSE_DELTAS */
+  uint32_t n_tx, n_ty, n_tz; /* ZKW_PACK_DELTA_TAILS */
+} zkw_pack_counts;
+ZKW_HD static inline uint64_t zkw_ceil2_64(uint64_t n) { return (n + 1ull) >> 1; }
+ZKW_HD static inline uint64_t zkw_ceil4_64(uint64_t n) { return (n + 3ull) >> 2; }
+/* units of the tails of n_t lane-cycles: 16 bytes each; slim: three u32 planes + one byte plane; as differences: one u32 plane + the three lists */
+ZKW_HD static inline uint64_t zkw_pack_tail_units(uint64_t n_t, const zkw_pack_counts* c, uint32_t flags) {
+  if (flags & ZKW_PACK_DELTA_TAILS) return zkw_ceil4_64(n_t) + zkw_ceil4_64(c->n_tx) + zkw_ceil4_64(c->n_ty) + zkw_ceil4_64(c->n_tz);
   return (flags & ZKW_PACK_SLIM_TAILS) ? 3ull * ((n_t + 3ull) >> 2) + ((n_t + 15ull) >> 4) : n_t;
 }
-/* (worst-case callers pass flags = 0 and add 4 units per wave) */
-ZKW_HD static inline uint64_t zkw_pack_wave_units(uint32_t max_cyc, uint32_t L, uint32_t n_delta, uint32_t n_mem, uint32_t n_page, uint32_t n_val, uint32_t n_log, uint32_t aux_units, uint32_t flags) {
-  return (uint64_t)(max_cyc + 1u) + zkw_pack_tail_units((uint64_t)max_cyc * L, flags) + 2ull * n_delta + zkw_ceil4(n_page) + 2ull * zkw_ceil4(n_mem) + 2ull * n_val + 8ull * n_log + aux_units;
+/* units of the register deltas.  Sparse: per 256 deltas 4 units of bit planes (below), then the plane of bytes 0..7 (u64 each), the plane of
+ * bytes 8..15 of the deltas that have any (u64 each), the plane of bytes 16..31 of the deltas that have any (16 B each).
+ * Bit planes: delta i = 256 * blk + 4 * lane + j is bit `lane` of u64 word 8 * blk + j ("bytes 8..15 present") and of word 8 * blk + 4 + j
+ * ("bytes 16..31 present"): what four ballots of a 64-lane wave that holds four consecutive deltas per lane produce. */
+ZKW_HD static inline uint64_t zkw_pack_delta_units(const zkw_pack_counts* c, uint32_t flags) {
+  if (!(flags & ZKW_PACK_SPARSE_DELTAS)) return 2ull * c->n_delta;
+  return 4ull * (((uint64_t)c->n_delta + 255ull) >> 8) + zkw_ceil2_64(c->n_delta) + zkw_ceil2_64(c->n_d1) + c->n_d2;
 }
+/* units of a wave's data */
+ZKW_HD static inline uint64_t zkw_pack_wave_units(const zkw_pack_counts* c, uint32_t flags) {
+  return (uint64_t)(c->max_cyc + 1u) + zkw_pack_tail_units((uint64_t)c->max_cyc * c->L, c, flags) + zkw_pack_delta_units(c, flags) + zkw_ceil4(c->n_page) +
+         2ull * zkw_ceil4(c->n_mem) + 2ull * c->n_val + 8ull * c->n_log + c->aux_units;
+}
+/* ... at most, whatever the flags, with streams of these capacities */
+ZKW_HD static inline uint64_t zkw_pack_wave_units_worst(uint32_t max_cyc, uint32_t L, uint32_t cap_delta, uint32_t cap_mem, uint32_t cap_log, uint32_t cap_aux) {
+  const uint64_t n_t = (uint64_t)max_cyc * L;
+  return (uint64_t)(max_cyc + 1u) + (n_t + 16ull) + (2ull * cap_delta + 4ull * (((uint64_t)cap_delta + 255ull) >> 8) + 2ull) + zkw_ceil4(cap_mem) + 2ull * zkw_ceil4(cap_mem) +
+         2ull * cap_mem + 8ull * cap_log + 16ull * cap_aux;
+}
+
+/* The u32 a record tail travels as under ZKW_PACK_DELTA_TAILS.  `t`: the tail as the cycle kernel stored it (x = ptr bitmap | flags << 16 | low delta
+ * mask << 24, y = pc | sp << 16, z = ergs, w = event counts | high delta mask << 24); `prev`: the tail of the lane's cycle before; `first`: there is
+ * none (the lane's first cycle since the reset: everything travels).
+ *   bits 0..15 delta mask   16..23 ergs spent in the cycle, 255 = see the ergs list (a refund, a far call's stipend, a price >= 255)
+ *   24..27 flags (lt | eq | gt | pending exception)   28 pc = previous pc + 1 and sp unchanged, else see the pc | sp list
+ *   30 pointer bitmap unchanged (and the flags fit their four bits), else see the ptr bitmap | flags list */
+#define ZKW_TW_Y_PRED (1u << 28)
+#define ZKW_TW_X_SAME (1u << 30)
+ZKW_HD static inline uint32_t zkw_pack_tail_word(uint4 t, uint4 prev, bool first) {
+  const uint32_t dmask = (t.x >> 24) | ((t.w >> 24) << 8);
+  const uint32_t spent = prev.z - t.z;
+  const bool z_in = !first && spent < 255u;
+  const bool y_pred = !first && (t.y & 0xffffu) == ((prev.y + 1u) & 0xffffu) && (t.y >> 16) == (prev.y >> 16);
+  const bool x_same = !first && (t.x & 0xffffu) == (prev.x & 0xffffu) && ((t.x >> 16) & 0xf0u) == 0;
+  return dmask | ((z_in ? spent : 255u) << 16) | (((t.x >> 16) & 0xfu) << 24) | (y_pred ? ZKW_TW_Y_PRED : 0u) | (x_same ? ZKW_TW_X_SAME : 0u);
+}
+ZKW_HD static inline bool zkw_tw_has_x(uint32_t w) { return !(w & ZKW_TW_X_SAME); }
+ZKW_HD static inline bool zkw_tw_has_y(uint32_t w) { return !(w & ZKW_TW_Y_PRED); }
+ZKW_HD static inline bool zkw_tw_has_z(uint32_t w) { return ((w >> 16) & 0xffu) == 255u; }
 
 /* by-value arguments of one launch of the pack kernel */
 typedef struct zkw_pack_args {

@@ -61,10 +61,54 @@ static __device__ __forceinline__ u32 pack_flag_scan(bool f, u32* wave_counts, u
   return off + below;
 }
 
+// the same for three small counts per thread at once (c[k] <= 4): exclusive ranks off[k] in thread order, totals tot[k].  The wave-level
+// prefix sums run on the counts packed into one u32 (10-bit fields: a wave's total is at most 256)
+static __device__ __forceinline__ void pack_count_scan3(const u32 c[3], u32 (*wave_tot)[3], u32 t, u32 nt, u32 off[3], u32 tot[3]) {
+  const u32 lane = ZKW_PACK_LANE(t), wv = ZKW_PACK_WAVE_OF(t);
+  const u32 packed = c[0] | (c[1] << 10) | (c[2] << 20);
+  u32 v = packed;
+#ifdef ZKW_WIDE
+  for (u32 d = 1; d < 64u; d <<= 1) {
+    const u32 o = (u32)__shfl((int)v, (int)(lane >= d ? lane - d : lane));
+    if (lane >= d) v += o;
+  }
+  const u32 wt = (u32)__shfl((int)v, 63);
+#else
+  const u32 wt = v;
+#endif
+  const u32 excl = v - packed;
+  if (lane == 0) { wave_tot[wv][0] = wt & 1023u; wave_tot[wv][1] = (wt >> 10) & 1023u; wave_tot[wv][2] = wt >> 20; }
+  __syncthreads();
+  const u32 nw = (nt + 63u) / 64u;
+  for (int k = 0; k < 3; k++) { off[k] = (excl >> (10 * k)) & 1023u; tot[k] = 0; }
+  for (u32 i = 0; i < nw; i++)
+    for (int k = 0; k < 3; k++) {
+      const u32 x = wave_tot[i][k];
+      if (i < wv) off[k] += x;
+      tot[k] += x;
+    }
+  __syncthreads();
+}
+
+// sum of one value per thread over the workgroup
+static __device__ __forceinline__ u32 pack_block_sum(u32 mine, u32* sums, u32 t, u32 nt) {
+  sums[t] = mine;
+  __syncthreads();
+  u32 n = 0;
+  for (u32 i = 0; i < nt; i++) n += sums[i];
+  __syncthreads();
+  return n;
+}
+
+// which of its parts a register delta (bytes 0..15 `lo`, bytes 16..31 `hi`) travels with under ZKW_PACK_SPARSE_DELTAS
+static __device__ __forceinline__ bool pack_delta_has1(uint4 lo) { return (lo.z | lo.w) != 0; }
+static __device__ __forceinline__ bool pack_delta_has2(uint4 hi) { return (hi.x | hi.y | hi.z | hi.w) != 0; }
+
 __global__ void __launch_bounds__(ZKW_PACK_THREADS) zkw_pack_kernel(zkw_pack_args A) {
   __shared__ u32 s_wave_counts[4][ZKW_PACK_MAX_WAVES + 1];
   __shared__ u32 s_sums[ZKW_PACK_THREADS];
   __shared__ u32 s_bcast[4];
+  __shared__ u32 s_wave_tot[ZKW_PACK_MAX_WAVES + 1][3];
   const u32 t = threadIdx.x, nt = blockDim.x;
   const bool one = A.only_wave != 0xffffffffu;
   const u32 total_waves = one ? 1u : A.wave_base[A.n_batches];
@@ -95,23 +139,38 @@ __global__ void __launch_bounds__(ZKW_PACK_THREADS) zkw_pack_kernel(zkw_pack_arg
       my_page += zkw_pack_has_page(hw, A.flags) ? 1u : 0u;
     }
     for (u32 i = t; i < n_aux; i += nt) my_aux += zkw_aux_used_units(aux_src[(u64)i * 16].x & 0xffu);
-    s_sums[t] = my_val;
-    __syncthreads();
-    u32 n_val = 0;
-    for (u32 i = 0; i < nt; i++) n_val += s_sums[i];
-    __syncthreads();
-    s_sums[t] = my_aux;
-    __syncthreads();
-    u32 aux_units = 0;
-    for (u32 i = 0; i < nt; i++) aux_units += s_sums[i];
-    __syncthreads();
-    s_sums[t] = my_page;
-    __syncthreads();
-    u32 n_page = 0;
-    for (u32 i = 0; i < nt; i++) n_page += s_sums[i];
-    __syncthreads();
+    const u32 n_val = pack_block_sum(my_val, s_sums, t, nt);
+    const u32 aux_units = pack_block_sum(my_aux, s_sums, t, nt);
+    const u32 n_page = pack_block_sum(my_page, s_sums, t, nt);
+    const uint4* dsrc_lo = P.deltas + (u64)w * P.cap_delta * 2;
+    const uint4* dsrc_hi = dsrc_lo + P.cap_delta;
+    const uint4* tsrc = P.tails + (u64)w * P.max_cycles * L;
+    const u64 n_t = (u64)max_cyc * L;
+    zkw_pack_counts C;
+    C.max_cyc = max_cyc; C.L = L; C.n_delta = n_delta; C.n_mem = n_mem; C.n_page = n_page; C.n_val = n_val; C.n_log = n_log; C.aux_units = aux_units;
+    C.n_d1 = C.n_d2 = C.n_tx = C.n_ty = C.n_tz = 0;
+    if (A.flags & ZKW_PACK_SPARSE_DELTAS) {  // deltas with bytes 8..15, with bytes 16..31
+      u32 m1 = 0, m2 = 0;
+      for (u32 i = t; i < n_delta; i += nt) {
+        m1 += pack_delta_has1(dsrc_lo[i]) ? 1u : 0u;
+        m2 += pack_delta_has2(dsrc_hi[i]) ? 1u : 0u;
+      }
+      C.n_d1 = pack_block_sum(m1, s_sums, t, nt);
+      C.n_d2 = pack_block_sum(m2, s_sums, t, nt);
+    }
+    if (A.flags & ZKW_PACK_DELTA_TAILS) {  // tails whose pointer bitmap / pc, sp / ergs are not what their predecessor predicts
+      u32 mx = 0, my = 0, mz = 0;
+      for (u64 i = t; i < n_t; i += nt) {
+        const uint4 prev = i >= L ? tsrc[i - L] : make_uint4(0, 0, 0, 0);
+        const u32 tw = zkw_pack_tail_word(tsrc[i], prev, i < L);
+        mx += zkw_tw_has_x(tw) ? 1u : 0u; my += zkw_tw_has_y(tw) ? 1u : 0u; mz += zkw_tw_has_z(tw) ? 1u : 0u;
+      }
+      C.n_tx = pack_block_sum(mx, s_sums, t, nt);
+      C.n_ty = pack_block_sum(my, s_sums, t, nt);
+      C.n_tz = pack_block_sum(mz, s_sums, t, nt);
+    }
     // ---- allocate the wave's extent ----
-    const u64 units64 = zkw_pack_wave_units(max_cyc, L, n_delta, n_mem, n_page, n_val, n_log, aux_units, A.flags);
+    const u64 units64 = zkw_pack_wave_units(&C, A.flags);
     if (t == 0) {
       u32 off = 0;
       if (units64 < 0xffffffffull) {
@@ -128,8 +187,8 @@ __global__ void __launch_bounds__(ZKW_PACK_THREADS) zkw_pack_kernel(zkw_pack_arg
       uint4* e = A.dst + A.wave_table + (u64)(one ? 0u : gw) * ZKW_PACK_WAVE_UNITS;
       e[0] = make_uint4(off, max_cyc, n_delta, n_mem);
       e[1] = make_uint4(n_val, n_log, n_aux, aux_units);
-      e[2] = make_uint4((u32)units64, n_page, 0, 0);
-      e[3] = make_uint4(0, 0, 0, 0);
+      e[2] = make_uint4((u32)units64, n_page, C.n_d1, C.n_d2);
+      e[3] = make_uint4(C.n_tx, C.n_ty, C.n_tz, 0);
     }
     // ---- the per-instance sections of this wave's instances ----
     if (A.with_instances) {
@@ -150,9 +209,37 @@ __global__ void __launch_bounds__(ZKW_PACK_THREADS) zkw_pack_kernel(zkw_pack_arg
     pack_copy(d, (const uint4*)(P.dir + ((u64)w * (P.max_cycles + 1)) * 4), (u64)max_cyc + 1, t, nt);
     d += max_cyc + 1;
     {
-      const uint4* tsrc = P.tails + (u64)w * P.max_cycles * L;
-      const u64 n_t = (u64)max_cyc * L;
-      if (A.flags & ZKW_PACK_SLIM_TAILS) {  // x | y | z as u32 planes, the top byte of w (delta mask, high half) as a byte plane; the counts stay behind
+      if (A.flags & ZKW_PACK_DELTA_TAILS) {  // one u32 per tail (four consecutive tails per thread) + the three lists
+        const u64 t4 = zkw_ceil4_64(n_t);
+        uint4* pa = d;
+        u32* lst[3];
+        lst[0] = (u32*)(d + t4);
+        lst[1] = (u32*)(d + t4 + zkw_ceil4_64(C.n_tx));
+        lst[2] = (u32*)(d + t4 + zkw_ceil4_64(C.n_tx) + zkw_ceil4_64(C.n_ty));
+        u32 lbase[3] = {0, 0, 0};
+        for (u64 base = 0; base < t4; base += nt) {
+          const u64 g = base + t;
+          u32 tw[4], c[3] = {0, 0, 0};
+          uint4 e[4];
+          for (u32 j = 0; j < 4; j++) {
+            const u64 i = 4ull * g + j;
+            const bool in = g < t4 && i < n_t;
+            e[j] = in ? tsrc[i] : make_uint4(0, 0, 0, 0);
+            const uint4 prev = in && i >= L ? tsrc[i - L] : make_uint4(0, 0, 0, 0);
+            tw[j] = in ? zkw_pack_tail_word(e[j], prev, i < L) : (ZKW_TW_X_SAME | ZKW_TW_Y_PRED);
+            c[0] += zkw_tw_has_x(tw[j]) ? 1u : 0u; c[1] += zkw_tw_has_y(tw[j]) ? 1u : 0u; c[2] += zkw_tw_has_z(tw[j]) ? 1u : 0u;
+          }
+          if (g < t4) pa[g] = make_uint4(tw[0], tw[1], tw[2], tw[3]);
+          u32 off3[3], tot3[3];
+          pack_count_scan3(c, s_wave_tot, t, nt, off3, tot3);
+          for (u32 j = 0; j < 4; j++) {
+            if (zkw_tw_has_x(tw[j])) lst[0][lbase[0] + off3[0]++] = e[j].x & 0x00ffffffu;
+            if (zkw_tw_has_y(tw[j])) lst[1][lbase[1] + off3[1]++] = e[j].y;
+            if (zkw_tw_has_z(tw[j])) lst[2][lbase[2] + off3[2]++] = e[j].z;
+          }
+          for (int k = 0; k < 3; k++) lbase[k] += tot3[k];
+        }
+      } else if (A.flags & ZKW_PACK_SLIM_TAILS) {  // x | y | z as u32 planes, the top byte of w (delta mask, high half) as a byte plane; the counts stay behind
         const u64 t4 = (n_t + 3ull) >> 2, t16 = (n_t + 15ull) >> 4;
         uint4 *px = d, *py = d + t4, *pz = d + 2ull * t4, *pb = d + 3ull * t4;
         for (u64 g = t; g < t16; g += nt) {  // sixteen consecutive tails per thread: one 16-byte store of the byte plane
@@ -176,11 +263,69 @@ __global__ void __launch_bounds__(ZKW_PACK_THREADS) zkw_pack_kernel(zkw_pack_arg
       } else {
         pack_copy(d, tsrc, n_t, t, nt);
       }
-      d += zkw_pack_tail_units(n_t, A.flags);
+      d += zkw_pack_tail_units(n_t, &C, A.flags);
     }
-    pack_copy(d, P.deltas + (u64)w * P.cap_delta * 2, n_delta, t, nt);
-    pack_copy(d + n_delta, P.deltas + (u64)w * P.cap_delta * 2 + P.cap_delta, n_delta, t, nt);
-    d += 2ull * n_delta;
+    if (A.flags & ZKW_PACK_SPARSE_DELTAS) {  // (layout: zkw_pack_delta_units)
+      const u32 nblk = (n_delta + 255u) >> 8;
+      uint4* bits = d;
+      uint4* p0 = d + 4ull * nblk;                                  // u64 [n_delta]
+      unsigned long long* p1 = (unsigned long long*)(p0 + zkw_ceil2_64(n_delta));  // u64 [n_d1]
+      uint4* p2 = p0 + zkw_ceil2_64(n_delta) + zkw_ceil2_64(C.n_d1);  // 16 B [n_d2]
+      u32 base1 = 0, base2 = 0;
+      const u32 g4 = zkw_ceil4(n_delta);
+#ifdef ZKW_WIDE
+      for (u32 base = 0; base < g4; base += nt) {  // a thread takes four consecutive deltas; a wave one block of the bit planes
+        const u32 g = base + t;
+        uint4 lo[4], hi[4];
+        bool h1[4], h2[4];
+        u32 c[3] = {0, 0, 0};
+        for (u32 j = 0; j < 4; j++) {
+          const u32 i = 4u * g + j;
+          const bool in = g < g4 && i < n_delta;
+          lo[j] = in ? dsrc_lo[i] : make_uint4(0, 0, 0, 0);
+          hi[j] = in ? dsrc_hi[i] : make_uint4(0, 0, 0, 0);
+          h1[j] = pack_delta_has1(lo[j]); h2[j] = pack_delta_has2(hi[j]);
+          c[0] += h1[j] ? 1u : 0u; c[1] += h2[j] ? 1u : 0u;
+        }
+        unsigned long long m[8];
+        for (u32 j = 0; j < 4; j++) { m[j] = __ballot(h1[j] ? 1 : 0); m[4 + j] = __ballot(h2[j] ? 1 : 0); }
+        const u32 lane = ZKW_PACK_LANE(t), blk = g >> 6;
+        if (lane < 4u && blk < nblk) bits[4ull * blk + lane] = make_uint4((u32)m[2 * lane], (u32)(m[2 * lane] >> 32), (u32)m[2 * lane + 1], (u32)(m[2 * lane + 1] >> 32));
+        if (g < g4) {
+          const u64 u = 2ull * g;  // units of the plane of bytes 0..7
+          if (u < zkw_ceil2_64(n_delta)) p0[u] = make_uint4(lo[0].x, lo[0].y, lo[1].x, lo[1].y);
+          if (u + 1 < zkw_ceil2_64(n_delta)) p0[u + 1] = make_uint4(lo[2].x, lo[2].y, lo[3].x, lo[3].y);
+        }
+        u32 off3[3], tot3[3];
+        pack_count_scan3(c, s_wave_tot, t, nt, off3, tot3);
+        for (u32 j = 0; j < 4; j++) {
+          if (h1[j]) p1[base1 + off3[0]++] = (unsigned long long)lo[j].z | ((unsigned long long)lo[j].w << 32);
+          if (h2[j]) p2[base2 + off3[1]++] = hi[j];
+        }
+        base1 += tot3[0]; base2 += tot3[1];
+      }
+#else  // (one thread: the same layout, delta by delta)
+      (void)g4;
+      for (u32 blk = 0; blk < nblk; blk++) {
+        unsigned long long m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (u32 r = 0; r < 256u; r++) {
+          const u32 i = 256u * blk + r;
+          if (i >= n_delta) break;
+          const uint4 lo = dsrc_lo[i], hi = dsrc_hi[i];
+          ((unsigned long long*)p0)[i] = (unsigned long long)lo.x | ((unsigned long long)lo.y << 32);
+          if (pack_delta_has1(lo)) { m[r & 3u] |= 1ull << (r >> 2); p1[base1++] = (unsigned long long)lo.z | ((unsigned long long)lo.w << 32); }
+          if (pack_delta_has2(hi)) { m[4u + (r & 3u)] |= 1ull << (r >> 2); p2[base2++] = hi; }
+        }
+        for (u32 u = 0; u < 4u; u++) bits[4ull * blk + u] = make_uint4((u32)m[2 * u], (u32)(m[2 * u] >> 32), (u32)m[2 * u + 1], (u32)(m[2 * u + 1] >> 32));
+      }
+      if (n_delta & 1u) ((unsigned long long*)p0)[n_delta] = 0;
+#endif
+      d += zkw_pack_delta_units(&C, A.flags);
+    } else {
+      pack_copy(d, dsrc_lo, n_delta, t, nt);
+      pack_copy(d + n_delta, dsrc_hi, n_delta, t, nt);
+      d += 2ull * n_delta;
+    }
     // ---- memory queries: 12-byte headers as three u32 planes, values of the non-code queries only ----
     {
       const u32 q4 = zkw_ceil4(n_mem), p4 = zkw_ceil4(n_page);

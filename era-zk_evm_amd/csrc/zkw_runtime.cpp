@@ -61,6 +61,7 @@ struct zkw_ctx {
   uint32_t opt_debug_flags = 0, opt_reset_skip = 0, opt_waves_per_group = 0, opt_lanes_per_wave = 0, opt_pack_blocks = 0;
   bool opt_read_values = false;
   uint32_t opt_staging_buffers = 0;
+  uint32_t opt_link_flags_off = 0;
   bool opt_no_inline_decommit = false, opt_debug_sync = false, opt_no_graph = false;
   // digests of code blobs already hashed on this context, keyed by a 128-bit content hash + length: batches that
   // share bytecode (the usual case) skip the sequential blob chain (~0.1 s for a 2000-word blob) at upload
@@ -313,6 +314,7 @@ int zkw_ctx_set_option(zkw_ctx* c, uint32_t option, uint64_t value) {
     case ZKW_OPT_LANES_PER_WAVE: c->opt_lanes_per_wave = (uint32_t)value; break;
     case ZKW_OPT_STAGING_BUFFERS: c->opt_staging_buffers = (uint32_t)std::min<uint64_t>(value, 64); break;
     case ZKW_OPT_READ_VALUES: c->opt_read_values = value != 0; break;
+    case ZKW_OPT_LINK_FLAGS_OFF: c->opt_link_flags_off = (uint32_t)value; break;
     case ZKW_OPT_PACK_BLOCKS: c->opt_pack_blocks = (uint32_t)value; break;
     default: c->last_error = "unknown option"; return ZKW_ERR_INVALID;
   }
@@ -1522,8 +1524,21 @@ struct WaveView {  // host pointers to the packed data of one wave
   const uint4 *tails = nullptr, *dlo = nullptr, *dhi = nullptr;
   const uint32_t *tx = nullptr, *ty = nullptr, *tz = nullptr;  // slim tails (ZKW_PACK_SLIM_TAILS): planes x | y | z ...
   const uint8_t* tb = nullptr;                                 // ... and the high byte of the delta mask
+  const uint32_t *tw = nullptr, *lx = nullptr, *ly = nullptr, *lz = nullptr;  // tails as differences (ZKW_PACK_DELTA_TAILS): zkw_pack_tail_word + the three lists
+  uint32_t n_tx = 0, n_ty = 0, n_tz = 0;
   // the 16-byte tail of lane-cycle i as the cycle kernel stored it, but for the event counts (not on the link when slim: tail_counts)
   uint4 tail(size_t i) const { return tails ? tails[i] : make_uint4(tx[i], ty[i], tz[i], (uint32_t)tb[i] << 24); }
+  uint32_t delta_mask(size_t i) const {
+    if (tw) return tw[i] & 0xffffu;
+    const uint4 t0 = tail(i);
+    return (t0.x >> 24) | ((t0.w >> 24) << 8);
+  }
+  // sparse deltas (ZKW_PACK_SPARSE_DELTAS, zkw_pack_delta_units): the bit planes, bytes 0..7 of every delta, bytes 8..15 / 16..31 of those that have any
+  const uint64_t *dbits = nullptr, *d0 = nullptr, *d1 = nullptr;
+  const uint4* d2 = nullptr;
+  uint32_t n_d1 = 0, n_d2 = 0;
+  bool delta_has1(uint32_t i) const { return (dbits[8u * (i >> 8) + (i & 3u)] >> ((i & 255u) >> 2)) & 1u; }
+  bool delta_has2(uint32_t i) const { return (dbits[8u * (i >> 8) + 4u + (i & 3u)] >> ((i & 255u) >> 2)) & 1u; }
   const uint32_t *m_page = nullptr, *m_index = nullptr, *m_misc = nullptr;
   const uint4 *v_lo = nullptr, *v_hi = nullptr, *log = nullptr, *aux = nullptr;
 };
@@ -1533,20 +1548,39 @@ static bool wave_view(const uint4* block, const zkw_pack_wave& e, uint32_t L, ui
   v.flags = flags;
   v.L = L; v.max_cyc = e.max_cyc; v.n_delta = e.n_delta; v.n_mem = e.n_mem; v.n_val = e.n_val; v.n_log = e.n_log; v.n_aux = e.n_aux; v.aux_units = e.aux_units;
   v.n_page = e.n_page;
+  zkw_pack_counts C;
+  C.max_cyc = e.max_cyc; C.L = L; C.n_delta = e.n_delta; C.n_mem = e.n_mem; C.n_page = e.n_page; C.n_val = e.n_val; C.n_log = e.n_log; C.aux_units = e.aux_units;
+  C.n_d1 = e.n_d1; C.n_d2 = e.n_d2; C.n_tx = e.n_tx; C.n_ty = e.n_ty; C.n_tz = e.n_tz;
+  v.n_d1 = e.n_d1; v.n_d2 = e.n_d2; v.n_tx = e.n_tx; v.n_ty = e.n_ty; v.n_tz = e.n_tz;
   const uint4* d = block + e.off;
   v.dir = (const uint32_t*)d; d += e.max_cyc + 1;
   {
     const uint64_t n_t = (uint64_t)e.max_cyc * L;
-    if (flags & ZKW_PACK_SLIM_TAILS) {
+    if (flags & ZKW_PACK_DELTA_TAILS) {
+      const uint64_t t4 = zkw_ceil4_64(n_t);
+      v.tails = nullptr;
+      v.tw = (const uint32_t*)d;
+      v.lx = (const uint32_t*)(d + t4); v.ly = (const uint32_t*)(d + t4 + zkw_ceil4_64(e.n_tx)); v.lz = (const uint32_t*)(d + t4 + zkw_ceil4_64(e.n_tx) + zkw_ceil4_64(e.n_ty));
+    } else if (flags & ZKW_PACK_SLIM_TAILS) {
       const uint64_t t4 = (n_t + 3) >> 2;
       v.tails = nullptr;
       v.tx = (const uint32_t*)d; v.ty = (const uint32_t*)(d + t4); v.tz = (const uint32_t*)(d + 2 * t4); v.tb = (const uint8_t*)(d + 3 * t4);
     } else {
       v.tails = d;
     }
-    d += zkw_pack_tail_units(n_t, flags);
+    d += zkw_pack_tail_units(n_t, &C, flags);
   }
-  v.dlo = d; v.dhi = d + e.n_delta; d += 2 * (size_t)e.n_delta;
+  if (flags & ZKW_PACK_SPARSE_DELTAS) {
+    const uint64_t nblk = ((uint64_t)e.n_delta + 255) >> 8;
+    v.dlo = v.dhi = nullptr;
+    v.dbits = (const uint64_t*)d;
+    v.d0 = (const uint64_t*)(d + 4 * nblk);
+    v.d1 = (const uint64_t*)(d + 4 * nblk + zkw_ceil2_64(e.n_delta));
+    v.d2 = d + 4 * nblk + zkw_ceil2_64(e.n_delta) + zkw_ceil2_64(e.n_d1);
+    d += zkw_pack_delta_units(&C, flags);
+  } else {
+    v.dlo = d; v.dhi = d + e.n_delta; d += 2 * (size_t)e.n_delta;
+  }
   const uint32_t q4 = zkw_ceil4(e.n_mem);
   v.m_page = (const uint32_t*)d; d += zkw_ceil4(e.n_page);  // the page list: the queries that carry their page, in stream order
   v.m_index = (const uint32_t*)d; v.m_misc = (const uint32_t*)(d + q4); d += 2 * (size_t)q4;
@@ -1700,6 +1734,10 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
       if (inst < code.frames0.size()) frames[l] = code.frames0[inst];
       frames[l].emplace_back(in.states[inst].current.base_memory_page, in.states[inst].current.code_page);
     }
+  const bool sparse = (v.flags & ZKW_PACK_SPARSE_DELTAS) != 0;
+  uint32_t dseen = 0, p1 = 0, p2 = 0;  // sparse deltas: deltas passed, entries of the two sparse planes passed
+  const bool dtails = v.tw != nullptr;
+  uint32_t qx = 0, qy = 0, qz = 0;     // tails as differences: entries of the three lists passed
   uint32_t ppos = 0;  // next entry of the page list
   std::vector<uint32_t> mask(L), cnt_m(L + 1), cnt_l(L + 1), cnt_a(L + 1), fill(L);
   std::vector<zkw_mem_query> cm;
@@ -1715,23 +1753,30 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
     for (uint32_t l = 0; l < L; l++) {
       mask[l] = 0;
       if (k >= ncyc[l]) continue;
-      const uint4 t0 = v.tail((size_t)k * L + l);
-      mask[l] = (t0.x >> 24) | ((t0.w >> 24) << 8);
+      mask[l] = v.delta_mask((size_t)k * L + l);
       any |= mask[l];
     }
     uint32_t pos = d0[3];
+    if (sparse)  // (the planes of bytes 8..15 / 16..31 are in stream order: skip what no live lane owns)
+      for (const uint32_t upto = std::min(pos, v.n_delta); dseen < upto; dseen++) { p1 += v.delta_has1(dseen) ? 1u : 0u; p2 += v.delta_has2(dseen) ? 1u : 0u; }
     for (uint32_t r = 0; r < ZKW_REGISTERS_COUNT + 1 && (any >> r); r++) {
       if (!((any >> r) & 1u)) continue;
       for (uint32_t l = 0; l < L; l++) {
         if (!((mask[l] >> r) & 1u)) continue;
         if (pos < v.n_delta) {
-          if (r < ZKW_REGISTERS_COUNT) {
-            std::memcpy(&cur[l].registers[r].l[0], &v.dlo[pos], 16);
-            std::memcpy(&cur[l].registers[r].l[2], &v.dhi[pos], 16);
+          uint64_t sv[4];  // (r == 15: the slow fields — heap bound | aux-heap bound | depth — travel like a register)
+          uint64_t* dst = r < ZKW_REGISTERS_COUNT ? cur[l].registers[r].l : sv;
+          if (sparse) {
+            for (; dseen < pos; dseen++) { p1 += v.delta_has1(dseen) ? 1u : 0u; p2 += v.delta_has2(dseen) ? 1u : 0u; }
+            dst[0] = v.d0[pos];
+            if (v.delta_has1(pos)) { dst[1] = p1 < v.n_d1 ? v.d1[p1] : 0; p1++; } else dst[1] = 0;
+            if (v.delta_has2(pos)) { if (p2 < v.n_d2) std::memcpy(&dst[2], &v.d2[p2], 16); else dst[2] = dst[3] = 0; p2++; } else dst[2] = dst[3] = 0;
+            dseen = pos + 1;
           } else {
-            const uint4 sv = v.dlo[pos];
-            slow[l].heap_bound = sv.x; slow[l].aux_bound = sv.y; slow[l].depth = sv.z;
+            std::memcpy(&dst[0], &v.dlo[pos], 16);
+            std::memcpy(&dst[2], &v.dhi[pos], 16);
           }
+          if (r >= ZKW_REGISTERS_COUNT) { slow[l].heap_bound = (uint32_t)sv[0]; slow[l].aux_bound = (uint32_t)(sv[0] >> 32); slow[l].depth = (uint32_t)sv[1]; }
         }
         pos++;
       }
@@ -1801,8 +1846,20 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
     }
     // ---- the tails, then the sink ----
     for (uint32_t l = 0; l < L; l++) {
-      if (k >= ncyc[l]) continue;
-      uint4 t0 = v.tail((size_t)k * L + l);
+      uint4 t0;
+      if (dtails) {  // (every lane-cycle of the wave has its word: the lists are passed in lane-cycle order, whoever lives)
+        const uint32_t tw = v.tw[(size_t)k * L + l];
+        const uint32_t ex = zkw_tw_has_x(tw) ? qx++ : 0xffffffffu, ey = zkw_tw_has_y(tw) ? qy++ : 0xffffffffu, ez = zkw_tw_has_z(tw) ? qz++ : 0xffffffffu;
+        if (k >= ncyc[l]) continue;
+        const uint32_t* pt = (const uint32_t*)&cur[l].tail;  // the lane's previous tail (x | y | z as below)
+        t0.x = ex != 0xffffffffu ? (ex < v.n_tx ? v.lx[ex] : 0u) : ((pt[0] & 0xffffu) | (((tw >> 24) & 0xfu) << 16));
+        t0.y = ey != 0xffffffffu ? (ey < v.n_ty ? v.ly[ey] : 0u) : (((pt[1] + 1u) & 0xffffu) | (pt[1] & 0xffff0000u));
+        t0.z = ez != 0xffffffffu ? (ez < v.n_tz ? v.lz[ez] : 0u) : pt[2] - ((tw >> 16) & 0xffu);
+        t0.w = 0;
+      } else {
+        if (k >= ncyc[l]) continue;
+        t0 = v.tail((size_t)k * L + l);
+      }
       if (!v.tails) {  // the event counts of the cycle: the numbers of its queries in the three streams, saturating bytes (Lane::counts)
         const uint32_t nm = cnt_m[l + 1] - cnt_m[l], nl = cnt_l[l + 1] - cnt_l[l], na = cnt_a[l + 1] - cnt_a[l];
         t0.w = (t0.w & 0xff000000u) | std::min(nm, 255u) | (std::min(nl, 255u) << 8) | (std::min(na, 255u) << 16);
@@ -1880,9 +1937,10 @@ static void fill_final_state(zkw_vm_local_state* out, const zkw_dev_scalars& sc,
 // images the step ran on (the shadow memory of walk_wave starts from them)
 static uint32_t pack_flags(const zkw_ctx* c, zkw_batch* const* bs, uint32_t n) {
   if (c->opt_read_values) return 0;  // (the round-5 format: every page, every value)
+  uint32_t flags = ZKW_PACK_NO_READ_VALUES | ZKW_PACK_IMPLIED_PAGES | ZKW_PACK_SLIM_TAILS | ZKW_PACK_SPARSE_DELTAS | ZKW_PACK_DELTA_TAILS;
   for (uint32_t i = 0; i < n; i++)
-    if (!bs[i]->inputs || !bs[i]->inputs->heaps_known) return ZKW_PACK_IMPLIED_PAGES | ZKW_PACK_SLIM_TAILS;
-  return ZKW_PACK_NO_READ_VALUES | ZKW_PACK_IMPLIED_PAGES | ZKW_PACK_SLIM_TAILS;
+    if (!bs[i]->inputs || !bs[i]->inputs->heaps_known) flags &= ~ZKW_PACK_NO_READ_VALUES;
+  return flags & ~c->opt_link_flags_off;
 }
 
 // The on-demand path of zkw_batch_get_instance_trace: ONE wave of a synced batch through the pack kernel into a pinned block
@@ -1900,7 +1958,7 @@ static int build_wave(zkw_batch* b, uint32_t w) {
   const uint32_t* hc = &b->h_cursors[(size_t)w * 4];
   const uint32_t n_mem = std::min(hc[0], b->cap_mem), n_log = std::min(hc[1], b->cap_log), n_aux = std::min(hc[2], b->cap_aux), n_delta = std::min(hc[3], b->cap_delta);
   const uint64_t fixed = ZKW_PACK_HEADER_UNITS + ZKW_PACK_BATCH_UNITS + ZKW_PACK_WAVE_UNITS;
-  const uint64_t need = fixed + zkw_pack_wave_units(b->lim.max_cycles, L, n_delta, n_mem, n_mem, n_mem, n_log, 16u * n_aux, 0) + 4 + 16;
+  const uint64_t need = fixed + zkw_pack_wave_units_worst(b->lim.max_cycles, L, n_delta, n_mem, n_log, n_aux) + 4 + 16;
   if (need >= (1ull << 32)) {
     c->last_error = "wave trace beyond 64 GB";
     return ZKW_ERR_LIMIT;
@@ -2008,11 +2066,18 @@ struct FoldSink {  // the built-in consumer of zkw_delivery_replay: reads every 
   // sum_j (u64[j] ^ K (j + 1 + w0)), K = 2^64 / phi: position-sensitive, and a plain sum over the records — the order in which
   // threads get to the waves does not matter.  An XOR and an add per word (two vector operations per 16 bytes even with the
   // baseline x86-64 instruction set this file is compiled for): the stand-in tracer should not cost more than the walk.
-  static uint64_t fold(const void* p, uint32_t words, uint64_t w0) {
+  static inline __attribute__((always_inline)) uint64_t fold_body(const void* p, uint32_t words, uint64_t w0) {
     const uint64_t* u = (const uint64_t*)p;
     uint64_t a = 0, k = 0x9E3779B97F4A7C15ull * (w0 + 1);
     for (uint32_t j = 0; j < words; j++, k += 0x9E3779B97F4A7C15ull) a += u[j] ^ k;
     return a;
+  }
+  static uint64_t fold_base(const void* p, uint32_t words, uint64_t w0) { return fold_body(p, words, w0); }
+  // (the same loop compiled for 256-bit integer vectors where the host has them: the file itself is built for the baseline instruction set)
+  __attribute__((target("avx2"))) static uint64_t fold_avx2(const void* p, uint32_t words, uint64_t w0) { return fold_body(p, words, w0); }
+  static uint64_t fold(const void* p, uint32_t words, uint64_t w0) {
+    static const bool wide = __builtin_cpu_supports("avx2") != 0;
+    return wide ? fold_avx2(p, words, w0) : fold_base(p, words, w0);
   }
   void cycle(const CycleView& cv) {
     acc += fold(cv.record, 64, 1);
@@ -2100,7 +2165,7 @@ int zkw_delivery_slot_bytes(zkw_batch* const* batches, uint32_t n_batches, uint6
     const zkw_batch* b = batches[i];
     if (!b || !b->uploaded) return ZKW_ERR_INVALID;
     units += (uint64_t)b->n_waves * ZKW_PACK_WAVE_UNITS + (uint64_t)b->n * 16 + (uint64_t)b->n_waves * ZKW_REG_CHUNKS * b->L;
-    units += (uint64_t)b->n_waves * (zkw_pack_wave_units(b->lim.max_cycles, b->L, b->cap_delta, b->cap_mem, b->cap_mem, b->cap_mem, b->cap_log, 16u * b->cap_aux, 0) + 4);
+    units += (uint64_t)b->n_waves * (zkw_pack_wave_units_worst(b->lim.max_cycles, b->L, b->cap_delta, b->cap_mem, b->cap_log, b->cap_aux) + 4);
   }
   *worst_case = units * 16;
   return ZKW_OK;

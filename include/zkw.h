@@ -453,6 +453,7 @@ int zkw_ctx_set_isa(zkw_ctx* ctx, const zkw_isa_table* table); /* copies */
                                           ZKW_ERR_LIMIT (release tickets).  1 = one buffer, overwritten by every restage: steps that ran on restaged heap
                                           images then carry the values of their memory reads on the link */
 #define ZKW_OPT_READ_VALUES 11u        /* 1 = the values of memory reads always travel (the round-5 link format: A/B, tests) */
+#define ZKW_OPT_LINK_FLAGS_OFF 12u     /* bits of zkw_delivered.link_flags that deliveries submitted afterwards leave out (A/B of the link format's parts, tests) */
 int zkw_ctx_set_option(zkw_ctx* ctx, uint32_t option, uint64_t value);
 
 int zkw_batch_create(zkw_ctx* ctx, uint32_t n_instances, const zkw_limits* limits, zkw_batch** out);
@@ -674,7 +675,8 @@ typedef struct zkw_delivered {
   uint32_t n_batches, n_waves;
   uint32_t overflow;  /* != 0: the step did not fit the slot (slot_bytes too small): nothing of it can be read */
   uint32_t link_flags; /* what did NOT travel because the rebuild derives it (link format, csrc/zkw_pack.h): 1 = the values of memory
-                          reads, 2 = the pages of the VM's own stack / heap / code queries, 4 = the event counts of the record tails */
+                          reads, 2 = the pages of the VM's own stack / heap / code queries, 4 = the event counts of the record tails, 8 = the zero upper
+                          bytes of register deltas, 16 = pc / sp / ergs / pointer bitmap of a record tail where the previous tail predicts them */
 } zkw_delivered;
 /* n_slots >= 1 slots of slot_bytes each (hipHostMalloc, once); host_threads >= 1 worker threads for the replay / rebuild */
 int zkw_delivery_create(zkw_ctx* ctx, uint32_t n_slots, uint64_t slot_bytes, uint32_t host_threads, zkw_delivery** out);
