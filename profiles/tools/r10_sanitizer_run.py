@@ -25,7 +25,17 @@ for wl in cases:
     c_eq = np.array_equal(bo.commitments(), be.commitments())
     # delivery + restage + expand + net state paths
     dv = K.Delivery(emu, 2, K.Delivery.worst_case_bytes(emu, [be]), 2)
-    t = dv.submit([be]); dv.wait(t); n, acc = dv.replay(t); dv.release(t); dv.close()
+    for off in (31, 24, 16, 8, 0):  # every part of the link format on its own (ZKW_OPT_LINK_FLAGS_OFF), the traces rebuilt from the ring against the oracle
+        emu.set_option(K.OPT_LINK_FLAGS_OFF, off)
+        t = dv.submit([be]); dv.wait(t); n, acc = dv.replay(t)
+        for i in range(wl.n_instances):
+            tp = dv.trace(t, 0, i)
+            if int(tp["status"]) == K.STATUS_LIMIT: continue
+            ok, why = K.traces_equal(bo.trace(i), tp)
+            bad += 0 if ok else 1
+        dv.release(t)
+    emu.set_option(K.OPT_LINK_FLAGS_OFF, 0)
+    dv.close()
     be.net_state(0)
     print(wl.name, "mismatches", bad, "commitments", c_eq, "replayed", n, flush=True)
     bo.destroy(); be.destroy()
