@@ -133,10 +133,17 @@ __global__ void __launch_bounds__(ZKW_PACK_THREADS) zkw_pack_kernel(zkw_pack_arg
     const uint4* aux_src = P.aux_stream + (u64)w * P.cap_aux * 16;
     // ---- count: memory queries that carry a value (zkw_pack_has_value), units of the aux records ----
     u32 my_val = 0, my_aux = 0, my_page = 0;
-    for (u32 i = t; i < n_mem; i += nt) {
-      const u32 hw = mem_hdr[i].w;
-      my_val += zkw_pack_has_value(hw, A.flags) ? 1u : 0u;
-      my_page += zkw_pack_has_page(hw, A.flags) ? 1u : 0u;
+    for (u32 base = 0; base < n_mem; base += 4u * nt) {
+      u32 hw[4];
+      for (u32 j = 0; j < 4; j++) {
+        const u32 i = base + j * nt + t;
+        hw[j] = i < n_mem ? mem_hdr[i].w : (ZKW_MEM_CODE << 16);  // (beyond the end: a Code read of the VM itself — no value, no page)
+      }
+      for (u32 j = 0; j < 4; j++) {
+        const u32 i = base + j * nt + t;
+        my_val += i < n_mem && zkw_pack_has_value(hw[j], A.flags) ? 1u : 0u;
+        my_page += i < n_mem && zkw_pack_has_page(hw[j], A.flags) ? 1u : 0u;
+      }
     }
     for (u32 i = t; i < n_aux; i += nt) my_aux += zkw_aux_used_units(aux_src[(u64)i * 16].x & 0xffu);
     const u32 n_val = pack_block_sum(my_val, s_sums, t, nt);
@@ -149,21 +156,41 @@ __global__ void __launch_bounds__(ZKW_PACK_THREADS) zkw_pack_kernel(zkw_pack_arg
     zkw_pack_counts C;
     C.max_cyc = max_cyc; C.L = L; C.n_delta = n_delta; C.n_mem = n_mem; C.n_page = n_page; C.n_val = n_val; C.n_log = n_log; C.aux_units = aux_units;
     C.n_d1 = C.n_d2 = C.n_tx = C.n_ty = C.n_tz = 0;
+    // (the counting passes keep four records per thread in flight: the link leaves the kernel time to read its input twice, but only
+    // if the reads overlap — a few dozen workgroups, each load a trip to HBM)
     if (A.flags & ZKW_PACK_SPARSE_DELTAS) {  // deltas with bytes 8..15, with bytes 16..31
       u32 m1 = 0, m2 = 0;
-      for (u32 i = t; i < n_delta; i += nt) {
-        m1 += pack_delta_has1(dsrc_lo[i]) ? 1u : 0u;
-        m2 += pack_delta_has2(dsrc_hi[i]) ? 1u : 0u;
+      for (u32 base = 0; base < n_delta; base += 4u * nt) {
+        uint4 lo[4], hi[4];
+        for (u32 j = 0; j < 4; j++) {
+          const u32 i = base + j * nt + t;
+          lo[j] = i < n_delta ? dsrc_lo[i] : make_uint4(0, 0, 0, 0);
+          hi[j] = i < n_delta ? dsrc_hi[i] : make_uint4(0, 0, 0, 0);
+        }
+        for (u32 j = 0; j < 4; j++) {
+          m1 += pack_delta_has1(lo[j]) ? 1u : 0u;
+          m2 += pack_delta_has2(hi[j]) ? 1u : 0u;
+        }
       }
       C.n_d1 = pack_block_sum(m1, s_sums, t, nt);
       C.n_d2 = pack_block_sum(m2, s_sums, t, nt);
     }
     if (A.flags & ZKW_PACK_DELTA_TAILS) {  // tails whose pointer bitmap / pc, sp / ergs are not what their predecessor predicts
       u32 mx = 0, my = 0, mz = 0;
-      for (u64 i = t; i < n_t; i += nt) {
-        const uint4 prev = i >= L ? tsrc[i - L] : make_uint4(0, 0, 0, 0);
-        const u32 tw = zkw_pack_tail_word(tsrc[i], prev, i < L);
-        mx += zkw_tw_has_x(tw) ? 1u : 0u; my += zkw_tw_has_y(tw) ? 1u : 0u; mz += zkw_tw_has_z(tw) ? 1u : 0u;
+      for (u64 base = 0; base < n_t; base += 4ull * nt) {
+        uint4 e[4], prev[4];
+        bool in[4];
+        for (u32 j = 0; j < 4; j++) {
+          const u64 i = base + (u64)j * nt + t;
+          in[j] = i < n_t;
+          e[j] = in[j] ? tsrc[i] : make_uint4(0, 0, 0, 0);
+          prev[j] = in[j] && i >= L ? tsrc[i - L] : make_uint4(0, 0, 0, 0);
+        }
+        for (u32 j = 0; j < 4; j++) {
+          const u64 i = base + (u64)j * nt + t;
+          const u32 tw = in[j] ? zkw_pack_tail_word(e[j], prev[j], i < L) : (ZKW_TW_X_SAME | ZKW_TW_Y_PRED);
+          mx += zkw_tw_has_x(tw) ? 1u : 0u; my += zkw_tw_has_y(tw) ? 1u : 0u; mz += zkw_tw_has_z(tw) ? 1u : 0u;
+        }
       }
       C.n_tx = pack_block_sum(mx, s_sums, t, nt);
       C.n_ty = pack_block_sum(my, s_sums, t, nt);
