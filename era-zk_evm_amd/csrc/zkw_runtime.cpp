@@ -1599,8 +1599,73 @@ struct CycleView {
   const zkw_aux_event* aux; uint32_t n_aux;
 };
 
+// The containers of walk_wave: a replay thread walks thousands of waves, and what a wave needs — the lanes' live records, their
+// shadow pages, the per-cycle buckets — keeps its capacity from one wave to the next instead of going through malloc / free per
+// wave and lane (an eighth of the walk's time, profiles/r10_host_replay.txt).
+struct WalkShadowPage {
+  uint32_t page = 0;
+  const zkw_u256* image = nullptr;  // the staged heap image of this page (copied into `w` when the page is first touched)
+  uint32_t image_words = 0;
+  std::vector<zkw_u256> w;          // dense; words at and beyond w.size() are zero
+};
+struct WalkShadow {  // the pages one lane has touched
+  std::vector<WalkShadowPage> pages;  // (the first `n` are in use: the others keep their buffers for the next wave)
+  uint32_t n = 0, last = 0;
+  void reset() { n = 0; last = 0; }
+  WalkShadowPage* add(uint32_t page) {
+    if (n == pages.size()) pages.emplace_back();
+    WalkShadowPage* p = &pages[n];
+    last = n++;
+    p->page = page; p->image = nullptr; p->image_words = 0;
+    p->w.clear();
+    return p;
+  }
+  WalkShadowPage* find(uint32_t page) {
+    if (last < n && pages[last].page == page) return &pages[last];
+    for (uint32_t i = 0; i < n; i++)
+      if (pages[i].page == page) { last = i; return &pages[i]; }
+    return nullptr;
+  }
+  static void materialise(WalkShadowPage* p) {
+    if (p->image) {
+      p->w.assign(p->image, p->image + p->image_words);
+      p->image = nullptr;
+    }
+  }
+  void read(uint32_t page, uint32_t index, zkw_u256* out) {
+    WalkShadowPage* p = find(page);
+    if (p) {
+      materialise(p);
+      if (index < p->w.size()) { *out = p->w[index]; return; }
+    }
+    std::memset(out, 0, sizeof *out);
+  }
+  void write(uint32_t page, uint32_t index, const zkw_u256& val) {
+    WalkShadowPage* p = find(page);
+    if (!p) p = add(page);
+    materialise(p);
+    if (index >= p->w.size()) {
+      zkw_u256 zero;
+      std::memset(&zero, 0, sizeof zero);
+      p->w.resize(std::max<size_t>((size_t)index + 1, p->w.size() * 2), zero);
+    }
+    p->w[index] = val;
+  }
+};
+struct WalkSlow { uint32_t heap_bound, aux_bound, depth, timestamp, pc; };
+struct WalkScratch {
+  std::vector<zkw_aux_event> aux, ca;
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> pages, frames;
+  std::vector<zkw_cycle_record> cur;
+  std::vector<WalkSlow> slow;
+  std::vector<WalkShadow> shadow;
+  std::vector<uint32_t> mask, cnt_m, cnt_l, cnt_a, fill;
+  std::vector<zkw_mem_query> cm;
+  std::vector<zkw_log_query> cl;
+};
+
 template <class Sink>
-static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, const uint32_t* ncyc, Sink& sink) {
+static void walk_wave(WalkScratch& S, const BatchInputs& in, uint32_t w, const WaveView& v, const uint32_t* ncyc, Sink& sink) {
   const CodeInputs& code = *in.code;
   const uint32_t n_inst = (uint32_t)in.states.size();
   const uint32_t L = v.L;
@@ -1608,7 +1673,8 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
   for (uint32_t l = 0; l < L; l++) max_cycles_lane = std::max(max_cycles_lane, ncyc[l]);
   max_cycles_lane = std::min(max_cycles_lane, v.max_cyc);
   // aux records sit back to back, each as long as its type uses: expand them once (zeros behind the used part, as the ABI has it)
-  std::vector<zkw_aux_event> aux(v.n_aux);
+  std::vector<zkw_aux_event>& aux = S.aux;
+  aux.resize(v.n_aux);
   {
     const uint4* a = v.aux;
     for (uint32_t i = 0; i < v.n_aux; i++) {
@@ -1621,8 +1687,10 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
   // code pages of every lane: what the host staged + what the run decommitted (page -> blob; a page number is never reused).
   // A Code query's value does not travel (zkw_pack.h): it is word `index` of the page's blob, zero beyond its length
   // (memory.rs:556-569 read_code_query on a page populated by populate_code / the decommitter, decommitter.rs:81-96).
-  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> pages(L);
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>>& pages = S.pages;
+  if (pages.size() < L) pages.resize(L);
   for (uint32_t l = 0; l < L; l++) {
+    pages[l].clear();
     const uint32_t inst = w * L + l;
     if (inst >= n_inst) continue;
     for (const auto& pg : code.pages[inst]) pages[l].push_back(pg);  // (later registrations win: searched from the back)
@@ -1644,9 +1712,11 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
       }
   };
   // the live snapshots: registers from the staged initial state, the slow tail fields beside them
-  std::vector<zkw_cycle_record> cur(L);
-  struct Slow { uint32_t heap_bound, aux_bound, depth, timestamp, pc; };
-  std::vector<Slow> slow(L);
+  typedef WalkSlow Slow;
+  std::vector<zkw_cycle_record>& cur = S.cur;
+  std::vector<Slow>& slow = S.slow;
+  cur.resize(L);
+  slow.resize(L);
   const uint32_t time_delta = code.time_delta;
   for (uint32_t l = 0; l < L; l++) {
     std::memset(&cur[l], 0, sizeof(zkw_cycle_record));
@@ -1665,73 +1735,30 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
   // query of the lane in stream order.  A page is a dense array grown on demand (zero-filled); the page that holds the staged heap
   // image starts as a copy of it, made when the lane first touches the page.
   const bool shadowed = (v.flags & ZKW_PACK_NO_READ_VALUES) != 0;
-  struct ShadowPage {
-    uint32_t page = 0;
-    const zkw_u256* image = nullptr;  // the staged heap image of this page (copied into `w` when the page is first touched)
-    uint32_t image_words = 0;
-    std::vector<zkw_u256> w;          // dense; words at and beyond w.size() are zero
-  };
-  struct Shadow {
-    std::vector<ShadowPage> pages;
-    uint32_t last = 0;
-    ShadowPage* find(uint32_t page) {
-      if (last < pages.size() && pages[last].page == page) return &pages[last];
-      for (uint32_t i = 0; i < pages.size(); i++)
-        if (pages[i].page == page) { last = i; return &pages[i]; }
-      return nullptr;
-    }
-    static void materialise(ShadowPage* p) {
-      if (p->image) {
-        p->w.assign(p->image, p->image + p->image_words);
-        p->image = nullptr;
-      }
-    }
-    void read(uint32_t page, uint32_t index, zkw_u256* out) {
-      ShadowPage* p = find(page);
-      if (p) {
-        materialise(p);
-        if (index < p->w.size()) { *out = p->w[index]; return; }
-      }
-      std::memset(out, 0, sizeof *out);
-    }
-    void write(uint32_t page, uint32_t index, const zkw_u256& val) {
-      ShadowPage* p = find(page);
-      if (!p) {
-        pages.emplace_back();
-        last = (uint32_t)pages.size() - 1;
-        p = &pages[last];
-        p->page = page;
-      }
-      materialise(p);
-      if (index >= p->w.size()) {
-        zkw_u256 zero;
-        std::memset(&zero, 0, sizeof zero);
-        p->w.resize(std::max<size_t>((size_t)index + 1, p->w.size() * 2), zero);
-      }
-      p->w[index] = val;
-    }
-  };
-  std::vector<Shadow> shadow(shadowed ? L : 0);
-  if (shadowed && in.heap_data && in.heap_words)
+  std::vector<WalkShadow>& shadow = S.shadow;
+  if (shadowed) {
+    if (shadow.size() < L) shadow.resize(L);
     for (uint32_t l = 0; l < L; l++) {
+      shadow[l].reset();
       const uint32_t inst = w * L + l;
-      if (inst >= n_inst) continue;
-      ShadowPage pg;
-      pg.page = in.states[inst].current.base_memory_page + 2u;  // heap_page_from_base of the frame the image was staged for
-      pg.image = in.heap_data + (size_t)inst * in.heap_words;
-      pg.image_words = in.heap_words;
-      shadow[l].pages.push_back(std::move(pg));
+      if (inst >= n_inst || !in.heap_data || !in.heap_words) continue;
+      WalkShadowPage* pg = shadow[l].add(in.states[inst].current.base_memory_page + 2u);  // heap_page_from_base of the frame the image was staged for
+      pg->image = in.heap_data + (size_t)inst * in.heap_words;
+      pg->image_words = in.heap_words;
     }
+  }
   // Implied pages (ZKW_PACK_IMPLIED_PAGES): the callstack of every lane as (base page, code page) — the inner entries it was staged
   // with, its current entry, then the FRAME_START / FRAME_FINISH events of the aux stream applied at the END of their cycle (a frame
   // changes behind the cycle's last memory query: far_call.rs:562, ret.rs:196-243, near_call.rs:60-67 come after the operand reads).
   const bool implied = (v.flags & ZKW_PACK_IMPLIED_PAGES) != 0;
-  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> frames(implied ? L : 0);
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>>& frames = S.frames;
+  if (implied && frames.size() < L) frames.resize(L);
   if (implied)
     for (uint32_t l = 0; l < L; l++) {
+      frames[l].clear();
       const uint32_t inst = w * L + l;
       if (inst >= n_inst) continue;
-      if (inst < code.frames0.size()) frames[l] = code.frames0[inst];
+      if (inst < code.frames0.size()) frames[l].assign(code.frames0[inst].begin(), code.frames0[inst].end());
       frames[l].emplace_back(in.states[inst].current.base_memory_page, in.states[inst].current.code_page);
     }
   const bool sparse = (v.flags & ZKW_PACK_SPARSE_DELTAS) != 0;
@@ -1739,10 +1766,11 @@ static void walk_wave(const BatchInputs& in, uint32_t w, const WaveView& v, cons
   const bool dtails = v.tw != nullptr;
   uint32_t qx = 0, qy = 0, qz = 0;     // tails as differences: entries of the three lists passed
   uint32_t ppos = 0;  // next entry of the page list
-  std::vector<uint32_t> mask(L), cnt_m(L + 1), cnt_l(L + 1), cnt_a(L + 1), fill(L);
-  std::vector<zkw_mem_query> cm;
-  std::vector<zkw_log_query> cl;
-  std::vector<zkw_aux_event> ca;
+  std::vector<uint32_t>&mask = S.mask, &cnt_m = S.cnt_m, &cnt_l = S.cnt_l, &cnt_a = S.cnt_a, &fill = S.fill;
+  mask.assign(L, 0u); cnt_m.assign(L + 1, 0u); cnt_l.assign(L + 1, 0u); cnt_a.assign(L + 1, 0u); fill.assign(L, 0u);
+  std::vector<zkw_mem_query>& cm = S.cm;
+  std::vector<zkw_log_query>& cl = S.cl;
+  std::vector<zkw_aux_event>& ca = S.ca;
   uint32_t vpos = 0;  // next entry of the value planes (the queries that are no Code reads, in stream order)
   uint32_t pm = 0;    // next memory query of the stream
   for (uint32_t k = 0; k < max_cycles_lane; k++) {
@@ -1906,7 +1934,8 @@ static std::unique_ptr<WaveTrace> materialise_wave(const BatchInputs& in, uint32
     wt->mem_off[l].assign(1, 0); wt->log_off[l].assign(1, 0); wt->aux_off[l].assign(1, 0);
   }
   MaterialiseSink sink{*wt};
-  walk_wave(in, w, v, ncyc, sink);
+  WalkScratch scratch;
+  walk_wave(scratch, in, w, v, ncyc, sink);
   return wt;
 }
 
@@ -2370,6 +2399,7 @@ int zkw_delivery_replay(zkw_delivery* d, uint32_t ticket, zkw_cycle_fn fn, void*
   delivery_run(d, [&](uint32_t t) {
     uint64_t my_cycles = 0, my_acc = 0;
     std::vector<uint32_t> ncyc(ZKW_WAVE, 0);
+    WalkScratch scratch;
     for (;;) {
       const uint32_t gw = next.fetch_add(1);
       if (gw >= sl->n_waves) break;
@@ -2383,11 +2413,11 @@ int zkw_delivery_replay(zkw_delivery* d, uint32_t ticket, zkw_cycle_fn fn, void*
       }
       if (fn) {
         CallbackSink sink{fn, user, t, bi, w * pbs[bi].L};
-        walk_wave(*sl->inputs[bi], w, v, ncyc.data(), sink);
+        walk_wave(scratch, *sl->inputs[bi], w, v, ncyc.data(), sink);
         my_cycles += sink.cycles;
       } else {
         FoldSink sink;
-        walk_wave(*sl->inputs[bi], w, v, ncyc.data(), sink);
+        walk_wave(scratch, *sl->inputs[bi], w, v, ncyc.data(), sink);
         my_cycles += sink.cycles;
         my_acc += sink.acc;
       }
