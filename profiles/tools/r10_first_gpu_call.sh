@@ -10,11 +10,11 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_d
 grep '^{' $OUT/trace_driver.log > $OUT/driver_bench.json
 find $OUT/trace_driver -name "*kernel_stats.csv" -exec cp {} $OUT/driver_kernel_stats.csv \;
 # the link format's A/B: the same host legs in the round-5 format and with each round-6 part left out
-for off in 31 24 8 16; do python bench.py --gpus 1 --steps 20 --warmup 5 --no-other-configs --no-cpu-baseline --link-flags-off $off 2>/dev/null | grep '^{' > $OUT/link_off_$off.json; done
+for off in 31 24 8 16 1; do python bench.py --gpus 1 --steps 20 --warmup 5 --no-other-configs --no-cpu-baseline --link-flags-off $off 2>/dev/null | grep '^{' > $OUT/link_off_$off.json; done
 tail -3 $OUT/pytest.log; tail -1 $OUT/smoke.log
 python - <<'PY'
 import json
-for f in ("driver_full_line.json", "driver_bench.json", "link_off_31.json", "link_off_24.json", "link_off_8.json", "link_off_16.json"):
+for f in ("driver_full_line.json", "driver_bench.json", "link_off_31.json", "link_off_24.json", "link_off_8.json", "link_off_16.json", "link_off_1.json"):
     try:
         j = json.loads(open("gpurun_out/r10_first/" + f).read().splitlines()[-1])
         d = j.get("delivered") or {}
