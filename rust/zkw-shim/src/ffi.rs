@@ -327,12 +327,18 @@ pub const ZKW_STATUS_ENDED: u32 = 1;
 pub const ZKW_STATUS_UNKNOWN_CODE_HASH: u32 = 2;
 pub const ZKW_STATUS_REFERENCE_PANIC: u32 = 3;
 pub const ZKW_STATUS_LIMIT: u32 = 4;
+/* zkw_ctx_set_option (include/zkw.h): the options a caller of the delivery ring tunes */
+pub const ZKW_OPT_PACK_BLOCKS: u32 = 9;
+pub const ZKW_OPT_STAGING_BUFFERS: u32 = 10;
+pub const ZKW_OPT_READ_VALUES: u32 = 11;
+pub const ZKW_OPT_LINK_FLAGS_OFF: u32 = 12;
 
 extern "C" {
     pub fn zkw_ctx_create(device: c_int, out: *mut *mut zkw_ctx) -> c_int;
     pub fn zkw_ctx_destroy(ctx: *mut zkw_ctx);
     pub fn zkw_last_error(ctx: *mut zkw_ctx) -> *const c_char;
     pub fn zkw_ctx_set_isa(ctx: *mut zkw_ctx, table: *const zkw_isa_table) -> c_int;
+    pub fn zkw_ctx_set_option(ctx: *mut zkw_ctx, option: u32, value: u64) -> c_int;
     pub fn zkw_batch_create(ctx: *mut zkw_ctx, n_instances: u32, limits: *const zkw_limits, out: *mut *mut zkw_batch) -> c_int;
     pub fn zkw_batch_destroy(batch: *mut zkw_batch);
     pub fn zkw_batch_add_code_blob(batch: *mut zkw_batch, words: *const zkw_u256, n_words: u32, blob_id: *mut u32) -> c_int;

@@ -308,6 +308,12 @@ impl Context {
         let msg = unsafe { CStr::from_ptr(zkw_last_error(self.raw)) }.to_string_lossy().into_owned();
         anyhow::bail!("{} -> {}: {}", what, rc, msg)
     }
+    /// zkw_ctx_set_option: `ZKW_OPT_STAGING_BUFFERS` (restaged heap images a held ticket may keep alive), `ZKW_OPT_LINK_FLAGS_OFF`
+    /// (parts of the link format deliveries leave out: 1 = the values of memory reads travel again — cheaper for a host whose
+    /// replay threads, not the link, are the bound), `ZKW_OPT_PACK_BLOCKS`
+    pub fn set_option(&self, option: u32, value: u64) -> anyhow::Result<()> {
+        self.check(unsafe { zkw_ctx_set_option(self.raw, option, value) }, "zkw_ctx_set_option")
+    }
     /// `Blake2s256::digest` of the re-exported `zk_evm::blake2` (reference src/lib.rs:21) for a batch of messages,
     /// one message per GPU lane (zkw_blake2s256)
     pub fn blake2s256_batch(&self, messages: &[&[u8]]) -> anyhow::Result<Vec<[u8; 32]>> {
