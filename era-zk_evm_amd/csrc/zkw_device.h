@@ -38,6 +38,21 @@
 #define ZKW_ATTR_PROPS(a) (((a) >> 15) & 63u)
 #define ZKW_ATTR_PACK(op, var, s0, d0, fl, pr) \
   ((uint32_t)(op) | ((uint32_t)(var) << 4) | ((uint32_t)(s0) << 8) | ((uint32_t)(d0) << 11) | ((uint32_t)(fl) << 13) | ((uint32_t)(pr) << 15))
+/* bits 21..25: what the cycle kernel's short cycle asks about an instruction, answered once when the table is packed (zkw_short_class) —
+ * functions of the fields above, so two entries with equal fields stay equal words */
+#define ZKW_ATTR_SHORT_OK (1u << 21)   /* the instruction can run in the short cycle at all (opcode, operand modes, no explicit panic) */
+#define ZKW_ATTR_SHORT_MEM (1u << 22)  /* ... and emits memory queries there (a heap access, a code-page operand): needs room in the memory stream */
+#define ZKW_ATTR_SHORT_UMA (1u << 23)  /* ... a heap / aux-heap access */
+#define ZKW_ATTR_SHORT_CODE (1u << 24) /* ... an ALU instruction whose src0 is a constant from the code page */
+#define ZKW_ATTR_SHORT_ALU (1u << 25)  /* ... nop / add / sub / mul / jump / shift / binop */
+static inline uint32_t zkw_short_class(uint32_t op, uint32_t var, uint32_t s0, uint32_t d0, uint32_t pr) {
+  const int alu = op == ZKW_OP_NOP || op == ZKW_OP_ADD || op == ZKW_OP_SUB || op == ZKW_OP_MUL || op == ZKW_OP_JUMP || op == ZKW_OP_SHIFT || op == ZKW_OP_BINOP;
+  const int uma = op == ZKW_OP_UMA && var <= ZKW_UMA_AUX_WRITE && !(pr & ZKW_PROP_SWAP);
+  const int code = s0 == ZKW_MODE_CODE && alu && op != ZKW_OP_NOP;
+  const int ok = (alu || uma) && d0 == ZKW_MODE_REG && (s0 == ZKW_MODE_REG || s0 == ZKW_MODE_IMM || code) && !(pr & ZKW_PROP_EXPLICIT_PANIC);
+  return (ok ? ZKW_ATTR_SHORT_OK : 0u) | (ok && (uma || code) ? ZKW_ATTR_SHORT_MEM : 0u) | (uma ? ZKW_ATTR_SHORT_UMA : 0u) | (code ? ZKW_ATTR_SHORT_CODE : 0u) |
+         (alu ? ZKW_ATTR_SHORT_ALU : 0u);
+}
 
 /* callstack entry as kept on device: the ABI struct + what the device needs to re-enter the frame */
 typedef struct zkw_dev_entry {

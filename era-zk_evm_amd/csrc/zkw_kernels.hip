@@ -3285,6 +3285,21 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
           const u32 u_lo = (u32)__builtin_amdgcn_readfirstlane((int)me.x), u_hi = (u32)__builtin_amdgcn_readfirstlane((int)me.y);
           const u32 u_attr = (u32)__builtin_amdgcn_readfirstlane((int)me.z), u_price = (u32)__builtin_amdgcn_readfirstlane((int)me.w);
           const u32 opcode = ZKW_ATTR_OPCODE(u_attr), props = ZKW_ATTR_PROPS(u_attr), src0_mode = ZKW_ATTR_SRC0(u_attr), variant = ZKW_ATTR_VARIANT(u_attr);
+#ifdef ZKW_SHORT_CLASS /* (-DZKW_SHORT_CLASS, the A/B partner of round 6: the class of the instruction from the bits the host packed into its
+                          ISA entry — zkw_short_class, zkw_device.h — instead of 22 compare / select pairs per cycle: profiles/r10_short_cycle_census.txt) */
+          const bool alu = (u_attr & ZKW_ATTR_SHORT_ALU) != 0;
+          const bool two_regs = opcode == ZKW_OP_MUL;  // (dst0 and dst1)
+          const bool code_operand = (u_attr & ZKW_ATTR_SHORT_CODE) != 0;
+#ifndef ZKW_NO_FAST_UMA
+          const bool uma = (u_attr & ZKW_ATTR_SHORT_UMA) != 0;
+          const bool light = (u_attr & ZKW_ATTR_SHORT_OK) && delta_cur + 2u * ZKW_WAVE <= cap_delta && (!(u_attr & ZKW_ATTR_SHORT_MEM) || zkw_cursor_get<0>() + 4u * ZKW_WAVE <= sh.cap_mem);
+#else
+          const bool uma = false;
+          const bool light = (u_attr & ZKW_ATTR_SHORT_OK) && !(u_attr & ZKW_ATTR_SHORT_UMA) && delta_cur + 2u * ZKW_WAVE <= cap_delta &&
+                             (!code_operand || zkw_cursor_get<0>() + 4u * ZKW_WAVE <= sh.cap_mem);
+#endif
+          (void)alu;
+#else
           // (div stays with the general path: a second inlined u256_divmod in the loop made the driver's command 0.7 % slower, profiles/r08_ab_log.txt)
           const bool alu = ((1u << opcode) & ((1u << ZKW_OP_NOP) | (1u << ZKW_OP_ADD) | (1u << ZKW_OP_SUB) | (1u << ZKW_OP_MUL) | (1u << ZKW_OP_JUMP) | (1u << ZKW_OP_SHIFT) |
                                               (1u << ZKW_OP_BINOP))) != 0;
@@ -3298,6 +3313,7 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
           const bool light = (alu || uma) && ZKW_ATTR_DST0(u_attr) == ZKW_MODE_REG && (src0_mode == ZKW_MODE_REG || src0_mode == ZKW_MODE_IMM || code_operand) &&
                              !(props & ZKW_PROP_EXPLICIT_PANIC) && delta_cur + 2u * ZKW_WAVE <= cap_delta &&
                              (!(uma || code_operand) || zkw_cursor_get<0>() + 4u * ZKW_WAVE <= sh.cap_mem);  // (its four queries at most cannot run out of stream)
+#endif
           if (light) {
             const u32 r_src0 = (u_lo >> 16) & 15u, r_src1 = (u_lo >> 20) & 15u, r_dst0 = (u_lo >> 24) & 15u, r_dst1 = u_lo >> 28;
             const bool run = condition_resolved(cond_lut, (u_lo >> 13) & 7u, s.flags);          // :193-217: a lane whose condition fails runs a nop

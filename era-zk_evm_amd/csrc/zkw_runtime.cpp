@@ -451,7 +451,7 @@ int zkw_ctx_set_isa(zkw_ctx* c, const zkw_isa_table* t) {
       c->last_error = "ISA table: entry " + std::to_string(i) + " out of range";
       return ZKW_ERR_INVALID;
     }
-    packed[i].x = ZKW_ATTR_PACK(e.opcode, e.variant, e.src0_mode, e.dst0_mode, e.flags, e.props);
+    packed[i].x = ZKW_ATTR_PACK(e.opcode, e.variant, e.src0_mode, e.dst0_mode, e.flags, e.props) | zkw_short_class(e.opcode, e.variant, e.src0_mode, e.dst0_mode, e.props);
     packed[i].y = e.price;
   }
   HIP_TRY(c, hipSetDevice(c->device));

@@ -11,16 +11,19 @@ OUT = os.path.join(HERE, "libzkw_emu.so")
 OUT64 = os.path.join(HERE, "libzkw_emu64.so")
 
 
-def build(force=False, wave=1):
-    """wave = 1: one-lane waves (fast); wave = 64: the SIMT engine (every lane a fiber, cross-lane operations emulated)"""
+def build(force=False, wave=1, defines=(), tag=""):
+    """wave = 1: one-lane waves (fast); wave = 64: the SIMT engine (every lane a fiber, cross-lane operations emulated);
+    defines / tag: a variant build of the kernels (-D...) under its own file name"""
     out = OUT if wave == 1 else OUT64
+    if tag:
+        out = out[:-3] + "_" + tag + ".so"
     srcs = [os.path.join(CSRC, "zkw_kernels.hip"), os.path.join(CSRC, "zkw_commit.hip"), os.path.join(CSRC, "zkw_blake2s.hip"), os.path.join(CSRC, "zkw_expand.hip"), os.path.join(CSRC, "zkw_pack.hip"), os.path.join(CSRC, "zkw_runtime.cpp"), os.path.join(CSRC, "isa_default.cpp"),
             os.path.join(HERE, "emu_glue.cpp"), os.path.join(HERE, "emu_simt.cpp")]
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "zkw.h"),
                                                                 os.path.join(HERE, "emu_glue.cpp"), os.path.join(HERE, "emu_simt.cpp")]
     if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
-    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", "-DZKW_EMU_WAVE=%d" % wave, "-I", HERE, "-I", os.path.join(ROOT, "include"), "-o", out]
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", "-DZKW_EMU_WAVE=%d" % wave] + ["-D" + d for d in defines] + ["-I", HERE, "-I", os.path.join(ROOT, "include"), "-o", out]
     for s in srcs:
         cmd += ["-x", "c++", s]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

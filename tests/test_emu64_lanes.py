@@ -110,6 +110,33 @@ def test_one_lane_waves_take_the_short_cycle_too(oracle, isa):
         emu1.close()
 
 
+def test_short_class_bits_select_the_same_cycles(oracle, isa):
+    """-DZKW_SHORT_CLASS (the A/B partner of round 6, profiles/r10_short_cycle_census.txt): the short cycle reads the class of an
+    instruction from the bits the host packs into its ISA entry instead of decoding it every cycle.  The same cycles qualify (path
+    counters equal to the default build's) and the witness is the oracle's — under the default table and under tables with other
+    variant numbering / prices / conventions (the bits are packed from whatever table the caller uploads)."""
+    import build_emu
+    import _metamorphic as M
+    from _oracle import load_oracle
+    for mk in (lambda: isa, lambda: M.renumbered(0x7AB1E), lambda: M.estranged(0xE57A)):
+        isa_v = mk()
+        orc = oracle if isa_v is isa else load_oracle().open(isa_v)
+        emu_d = K.Backend(build_emu.build(wave=1), "zkw_").open(isa_v)
+        emu_c = K.Backend(build_emu.build(wave=1, defines=("ZKW_SHORT_CLASS",), tag="short_class"), "zkw_").open(isa_v)
+        try:
+            for wl in (synth.make(2, isa_v, n_instances=4), synth.uniform_fuzz(isa_v, n_instances=6, n_ops=192, seed=0xF1A2), synth.make(4, isa_v, n_instances=3, n_cycles=512)):
+                bo = _run(orc, wl)
+                path_counts(emu_d); bd = _run(emu_d, wl); cd = path_counts(emu_d)
+                path_counts(emu_c); bc = _run(emu_c, wl); cc = path_counts(emu_c)
+                _equal(bo, bc, wl, wl.name + " (short class bits)")
+                assert cc == cd and cc["short"] > 0, (cc, cd)
+                bo.destroy(); bd.destroy(); bc.destroy()
+        finally:
+            emu_d.close(); emu_c.close()
+            if isa_v is not isa:
+                orc.close()
+
+
 def test_diverged_lanes_form_variant_groups(oracle, product, isa):
     """Every lane of a wave runs its own program.  (a) fuzz tapes: whatever the lanes hold; (b) one sequence of opcodes with
     per-lane register numbers and immediates — the shape variant grouping exists for: the group loop widens the word groups to
