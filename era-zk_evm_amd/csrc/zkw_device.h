@@ -45,13 +45,19 @@
 #define ZKW_ATTR_SHORT_UMA (1u << 23)  /* ... a heap / aux-heap access */
 #define ZKW_ATTR_SHORT_CODE (1u << 24) /* ... an ALU instruction whose src0 is a constant from the code page */
 #define ZKW_ATTR_SHORT_ALU (1u << 25)  /* ... nop / add / sub / mul / jump / shift / binop */
+#define ZKW_ATTR_SHORT_STACK (1u << 26) /* an ALU instruction with a stack operand (src0 read from / dst0 written to the stack, sp moved): short only in
+                                          -DZKW_SHORT_STACK builds, and never together with ZKW_ATTR_SHORT_OK */
 static inline uint32_t zkw_short_class(uint32_t op, uint32_t var, uint32_t s0, uint32_t d0, uint32_t pr) {
   const int alu = op == ZKW_OP_NOP || op == ZKW_OP_ADD || op == ZKW_OP_SUB || op == ZKW_OP_MUL || op == ZKW_OP_JUMP || op == ZKW_OP_SHIFT || op == ZKW_OP_BINOP;
   const int uma = op == ZKW_OP_UMA && var <= ZKW_UMA_AUX_WRITE && !(pr & ZKW_PROP_SWAP);
   const int code = s0 == ZKW_MODE_CODE && alu && op != ZKW_OP_NOP;
   const int ok = (alu || uma) && d0 == ZKW_MODE_REG && (s0 == ZKW_MODE_REG || s0 == ZKW_MODE_IMM || code) && !(pr & ZKW_PROP_EXPLICIT_PANIC);
+  const int s0_stack = s0 == ZKW_MODE_STACK_PP || s0 == ZKW_MODE_STACK_OFF || s0 == ZKW_MODE_STACK_ABS;
+  const int d0_stack = d0 == ZKW_MODE_STACK_PP || d0 == ZKW_MODE_STACK_OFF || d0 == ZKW_MODE_STACK_ABS;
+  const int stack = alu && (s0_stack || d0_stack) && (s0_stack || s0 == ZKW_MODE_REG || s0 == ZKW_MODE_IMM) && (d0_stack || d0 == ZKW_MODE_REG) &&
+                    !(op == ZKW_OP_JUMP && d0_stack) && !(pr & ZKW_PROP_EXPLICIT_PANIC);
   return (ok ? ZKW_ATTR_SHORT_OK : 0u) | (ok && (uma || code) ? ZKW_ATTR_SHORT_MEM : 0u) | (uma ? ZKW_ATTR_SHORT_UMA : 0u) | (code ? ZKW_ATTR_SHORT_CODE : 0u) |
-         (alu ? ZKW_ATTR_SHORT_ALU : 0u);
+         (alu ? ZKW_ATTR_SHORT_ALU : 0u) | (stack ? ZKW_ATTR_SHORT_STACK : 0u);
 }
 
 /* callstack entry as kept on device: the ABI struct + what the device needs to re-enter the frame */

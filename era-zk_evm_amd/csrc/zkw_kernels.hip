@@ -3292,7 +3292,13 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
           const bool code_operand = (u_attr & ZKW_ATTR_SHORT_CODE) != 0;
 #ifndef ZKW_NO_FAST_UMA
           const bool uma = (u_attr & ZKW_ATTR_SHORT_UMA) != 0;
+#ifdef ZKW_SHORT_STACK /* (-DZKW_SHORT_STACK, A/B partner: ALU instructions with stack operands — mem_ops.rs:51-121 — run in the short cycle too) */
+          const bool stack_op = (u_attr & ZKW_ATTR_SHORT_STACK) != 0;
+          const bool light = (u_attr & (ZKW_ATTR_SHORT_OK | ZKW_ATTR_SHORT_STACK)) && delta_cur + 2u * ZKW_WAVE <= cap_delta &&
+                             (!(u_attr & (ZKW_ATTR_SHORT_MEM | ZKW_ATTR_SHORT_STACK)) || zkw_cursor_get<0>() + 4u * ZKW_WAVE <= sh.cap_mem);
+#else
           const bool light = (u_attr & ZKW_ATTR_SHORT_OK) && delta_cur + 2u * ZKW_WAVE <= cap_delta && (!(u_attr & ZKW_ATTR_SHORT_MEM) || zkw_cursor_get<0>() + 4u * ZKW_WAVE <= sh.cap_mem);
+#endif
 #else
           const bool uma = false;
           const bool light = (u_attr & ZKW_ATTR_SHORT_OK) && !(u_attr & ZKW_ATTR_SHORT_UMA) && delta_cur + 2u * ZKW_WAVE <= cap_delta &&
@@ -3322,7 +3328,29 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
             const bool uma_heap = variant == ZKW_UMA_HEAP_READ || variant == ZKW_UMA_HEAP_WRITE;
             const bool uma_write = variant == ZKW_UMA_HEAP_WRITE || variant == ZKW_UMA_AUX_WRITE;
             u256 a = u256_zero();
+#if defined(ZKW_SHORT_CLASS) && defined(ZKW_SHORT_STACK)
+            // stack operands (MemOpsProcessor::compute_addresses_and_select_operands, mem_ops.rs:14-125): src0's location first, then dst0's, each
+            // from its register + immediate; push / pop move sp.  A NOP moves sp and touches no memory (cycle.rs:298-301).
+            const u32 dst0_mode = ZKW_ATTR_DST0(u_attr);
+            const bool src0_stack = stack_op && src0_mode != ZKW_MODE_REG && src0_mode != ZKW_MODE_IMM, dst0_stack = stack_op && dst0_mode != ZKW_MODE_REG;
+            u32 sp_new = s.sp, idx0 = 0, idx1 = 0;
+            if (opcode != ZKW_OP_NOP || stack_op) a = src0_mode == ZKW_MODE_IMM ? u256_from_u32(u_hi & 0xffffu) : rf_get(rf, r_src0);
+            if (src0_stack) {
+              const u32 vaddr = (clip16(sh, a) + (u_hi & 0xffffu)) & 0xffffu;
+              if (src0_mode == ZKW_MODE_STACK_PP) { sp_new = (sp_new - vaddr) & 0xffffu; idx0 = sp_new; }
+              else if (src0_mode == ZKW_MODE_STACK_OFF) idx0 = (sp_new - vaddr) & 0xffffu;
+              else idx0 = vaddr;
+            }
+            if (dst0_stack) {
+              const u32 vaddr = (clip16(sh, rf_get(rf, r_dst0)) + (u_hi >> 16)) & 0xffffu;
+              if (dst0_mode == ZKW_MODE_STACK_PP) { idx1 = sp_new; sp_new = (sp_new + vaddr) & 0xffffu; }
+              else if (dst0_mode == ZKW_MODE_STACK_OFF) idx1 = (sp_new - vaddr) & 0xffffu;
+              else idx1 = vaddr;
+              bad |= run & (opcode != ZKW_OP_NOP) & (idx1 >= sh.S);  // (a write beyond the stack's capacity is a limit status: the general path reports it)
+            }
+#else
             if (opcode != ZKW_OP_NOP) a = src0_mode == ZKW_MODE_IMM ? u256_from_u32(u_hi & 0xffffu) : rf_get(rf, r_src0);  // (a code operand: the register part of its address)
+#endif
             if (uma) {  // uma.rs:121-207: the offset dereferenceable, no overflow of the increment, inside the bound paid for, inside the arena
               const u32 off = a.w[0], inc = off + 32u;
               const u32 bound = uma_heap ? cfv_heap_bound(sh, s) : cfv_aux_bound(sh, s);
@@ -3459,6 +3487,15 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
                     emit_mem(P, sh, s, s.timestamp, ZKW_MEM_CODE, CF(sh, s, CF_CODE_PAGE), idx, a, false, false, 0);
                   }
                 }
+#if defined(ZKW_SHORT_CLASS) && defined(ZKW_SHORT_STACK)
+                if (src0_stack) {  // cycle.rs:304-325: the operand from the stack of the current frame, and its query
+                  ZKW_DIV_IF(run) {
+                    u32 tag;
+                    a = stack_read(P, sh, s, idx0, tag);
+                    emit_mem(P, sh, s, s.timestamp, ZKW_MEM_STACK, CF(sh, s, CF_BASE_PAGE) + 1u, idx0, a, tag != 0, false, 0);
+                  }
+                }
+#endif
                 u256 b = rf_get(rf, r_src1);
                 if (props & ZKW_PROP_SWAP) {  // :341-345 (wave-uniform)
                   const u256 t = a;
@@ -3494,9 +3531,21 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
                     if (run) u256_mul(a, b, res, res1);
                     of = !u256_is_zero(res1); eq = u256_is_zero(res); gt = !of && !eq;
                   }
+#if defined(ZKW_SHORT_CLASS) && defined(ZKW_SHORT_STACK)
+                  if (dst0_stack) {  // perform_dst0_update, helpers.rs:266-283: the result goes to the stack, with its query
+                    ZKW_DIV_IF(run) {
+                      stack_write(P, sh, s, idx1, res, false);
+                      emit_mem(P, sh, s, s.timestamp + 3u, ZKW_MEM_STACK, CF(sh, s, CF_BASE_PAGE) + 1u, idx1, res, false, true, 0);
+                    }
+                  }
+#endif
                   if (run) {
                     if (ZKW_ATTR_FLAGS(u_attr) & 1u) set_flags3(s, of, eq, gt);
+#if defined(ZKW_SHORT_CLASS) && defined(ZKW_SHORT_STACK)
+                    if (r_dst0 != 0 && !dst0_stack) {
+#else
                     if (r_dst0 != 0) {
+#endif
                       rf_set(rf, r_dst0, res);
                       dm = 1u << (r_dst0 - 1u);
                     }
@@ -3513,6 +3562,9 @@ __global__ void __launch_bounds__(ZKW_WAVE * ZKW_MAX_WAVES_PER_GROUP, ZKW_MIN_WA
 #endif
               s.lane = zkw_lane_id();
               s.pc = new_pc;
+#if defined(ZKW_SHORT_CLASS) && defined(ZKW_SHORT_STACK)
+              if (stack_op && run) s.sp = sp_new;  // cycle.rs:297
+#endif
 #ifdef __HIP_DEVICE_COMPILE__
               asm("v_add_u32 %0, %1, %0" : "+v"(s.timestamp) : "s"(time_delta));  // :408-411
 #else

@@ -3,6 +3,7 @@
 # 212 -> 187 instructions per short NOP in the assembly, profiles/r10_short_cycle_census.txt) against the default build, same box.
 # HERE, before the call (the libraries travel with the snapshot):
 #   python profiles/tools/build_ab.py a_base WORK; python profiles/tools/build_ab.py b_short_class WORK -DZKW_SHORT_CLASS
+#   python profiles/tools/build_ab.py c_short_stack WORK -DZKW_SHORT_CLASS -DZKW_SHORT_STACK      (the census says this one does not pay)
 # then   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash profiles/tools/r10_second_gpu_call.sh'
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 OUT=gpurun_out/r10_ab_short_class; mkdir -p $OUT

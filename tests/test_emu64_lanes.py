@@ -110,11 +110,14 @@ def test_one_lane_waves_take_the_short_cycle_too(oracle, isa):
         emu1.close()
 
 
-def test_short_class_bits_select_the_same_cycles(oracle, isa):
-    """-DZKW_SHORT_CLASS (the A/B partner of round 6, profiles/r10_short_cycle_census.txt): the short cycle reads the class of an
-    instruction from the bits the host packs into its ISA entry instead of decoding it every cycle.  The same cycles qualify (path
-    counters equal to the default build's) and the witness is the oracle's — under the default table and under tables with other
-    variant numbering / prices / conventions (the bits are packed from whatever table the caller uploads)."""
+def test_short_cycle_ab_partners(oracle, isa):
+    """The two A/B partners of round 6 (profiles/r10_short_cycle_census.txt; the default build is untouched by their #ifdefs).
+    -DZKW_SHORT_CLASS: the short cycle reads the class of an instruction from the bits the host packs into its ISA entry instead of
+    decoding it every cycle — the same cycles qualify (path counters equal to the default build's).  + -DZKW_SHORT_STACK: ALU
+    instructions with stack operands (mem_ops.rs:51-121: push / pop / sp-relative / absolute, src0 read and dst0 written with their
+    queries, sp moved) run in the short cycle too — more cycles qualify (the headline tape: 207 of 256 instead of 189).  Either way the
+    witness is the oracle's, under the default table and under tables with other variant numbering / prices / conventions (the bits
+    are packed from whatever table the caller uploads)."""
     import build_emu
     import _metamorphic as M
     from _oracle import load_oracle
@@ -123,16 +126,22 @@ def test_short_class_bits_select_the_same_cycles(oracle, isa):
         orc = oracle if isa_v is isa else load_oracle().open(isa_v)
         emu_d = K.Backend(build_emu.build(wave=1), "zkw_").open(isa_v)
         emu_c = K.Backend(build_emu.build(wave=1, defines=("ZKW_SHORT_CLASS",), tag="short_class"), "zkw_").open(isa_v)
+        emu_s = K.Backend(build_emu.build(wave=1, defines=("ZKW_SHORT_CLASS", "ZKW_SHORT_STACK"), tag="short_stack"), "zkw_").open(isa_v)
         try:
             for wl in (synth.make(2, isa_v, n_instances=4), synth.uniform_fuzz(isa_v, n_instances=6, n_ops=192, seed=0xF1A2), synth.make(4, isa_v, n_instances=3, n_cycles=512)):
                 bo = _run(orc, wl)
                 path_counts(emu_d); bd = _run(emu_d, wl); cd = path_counts(emu_d)
                 path_counts(emu_c); bc = _run(emu_c, wl); cc = path_counts(emu_c)
+                path_counts(emu_s); bs = _run(emu_s, wl); cs = path_counts(emu_s)
                 _equal(bo, bc, wl, wl.name + " (short class bits)")
+                _equal(bo, bs, wl, wl.name + " (stack operands in the short cycle)")
                 assert cc == cd and cc["short"] > 0, (cc, cd)
-                bo.destroy(); bd.destroy(); bc.destroy()
+                assert cs["short"] > cd["short"] and cs["short"] + cs["general"] == cd["short"] + cd["general"], (cs, cd)
+                if wl.name.startswith("cfg2") and isa_v is isa:
+                    assert cs["short"] * 256 >= 205 * int(bs.stats()["cycles"]), cs
+                bo.destroy(); bd.destroy(); bc.destroy(); bs.destroy()
         finally:
-            emu_d.close(); emu_c.close()
+            emu_d.close(); emu_c.close(); emu_s.close()
             if isa_v is not isa:
                 orc.close()
 
