@@ -274,7 +274,7 @@ class ZkwError(RuntimeError):
 
 
 OPT_DEBUG_FLAGS, OPT_RESET_SKIP, OPT_NO_INLINE_DECOMMIT, OPT_DEBUG_SYNC, OPT_NO_GRAPH, OPT_WAVES_PER_GROUP, OPT_LANES_PER_WAVE = 1, 2, 3, 5, 6, 7, 8
-OPT_PACK_BLOCKS, OPT_STAGING_BUFFERS, OPT_READ_VALUES, OPT_LINK_FLAGS_OFF = 9, 10, 11, 12
+OPT_PACK_BLOCKS, OPT_STAGING_BUFFERS, OPT_READ_VALUES, OPT_LINK_FLAGS_OFF, OPT_LINK_SELFCHECK = 9, 10, 11, 12, 13
 
 
 class Backend:

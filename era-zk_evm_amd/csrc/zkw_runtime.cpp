@@ -62,6 +62,8 @@ struct zkw_ctx {
   bool opt_read_values = false;
   uint32_t opt_staging_buffers = 0;
   uint32_t opt_link_flags_off = 0;
+  uint32_t opt_link_selfcheck = 1;  // ZKW_OPT_LINK_SELFCHECK
+  bool link_checked = false;        // the self-check of the link format has run on this context
   bool opt_no_inline_decommit = false, opt_debug_sync = false, opt_no_graph = false;
   // digests of code blobs already hashed on this context, keyed by a 128-bit content hash + length: batches that
   // share bytecode (the usual case) skip the sequential blob chain (~0.1 s for a 2000-word blob) at upload
@@ -315,6 +317,7 @@ int zkw_ctx_set_option(zkw_ctx* c, uint32_t option, uint64_t value) {
     case ZKW_OPT_STAGING_BUFFERS: c->opt_staging_buffers = (uint32_t)std::min<uint64_t>(value, 64); break;
     case ZKW_OPT_READ_VALUES: c->opt_read_values = value != 0; break;
     case ZKW_OPT_LINK_FLAGS_OFF: c->opt_link_flags_off = (uint32_t)value; break;
+    case ZKW_OPT_LINK_SELFCHECK: c->opt_link_selfcheck = (uint32_t)value; c->link_checked = false; break;
     case ZKW_OPT_PACK_BLOCKS: c->opt_pack_blocks = (uint32_t)value; break;
     default: c->last_error = "unknown option"; return ZKW_ERR_INVALID;
   }
@@ -1975,7 +1978,7 @@ static uint32_t pack_flags(const zkw_ctx* c, zkw_batch* const* bs, uint32_t n) {
 // The on-demand path of zkw_batch_get_instance_trace: ONE wave of a synced batch through the pack kernel into a pinned block
 // of the batch (grown on demand), then the same rebuild as a delivered step — every parity test that reads a trace runs the
 // pack kernel and the link-format rebuild.
-static int build_wave(zkw_batch* b, uint32_t w) {
+static int pack_one_wave(zkw_batch* b, uint32_t w, uint32_t flags, std::unique_ptr<WaveTrace>& out) {
   zkw_ctx* c = b->ctx;
   const uint32_t L = b->L;
   std::vector<uint32_t> ncyc(L, 0);
@@ -2007,7 +2010,7 @@ static int build_wave(zkw_batch* b, uint32_t w) {
   A.wave_base[1] = b->n_waves;
   A.dst = b->h_pack; A.state = b->d_pack_state.p; A.dst_units = (uint32_t)need; A.n_batches = 1;
   A.wave_table = ZKW_PACK_HEADER_UNITS + ZKW_PACK_BATCH_UNITS; A.with_instances = 0; A.only_wave = w;
-  A.flags = pack_flags(c, &b, 1);
+  A.flags = flags;
   HIP_TRY(c, zkw_launch_pack(&A, (uint32_t)c->wave_width, 1, b->run_stream));
   uint32_t state1[4] = {0, 0, 0, 0};
   HIP_TRY(c, hipMemcpyAsync(state1, b->d_pack_state.p, sizeof state1, hipMemcpyDeviceToHost, b->run_stream));
@@ -2019,7 +2022,42 @@ static int build_wave(zkw_batch* b, uint32_t w) {
     c->last_error = "pack kernel: the wave did not fit its block";
     return ZKW_ERR_LIMIT;
   }
-  b->wave_cache[w] = materialise_wave(*b->inputs, w, v, ncyc.data());
+  out = materialise_wave(*b->inputs, w, v, ncyc.data());
+  return ZKW_OK;
+}
+
+template <class T>
+static bool same_rows(const std::vector<std::vector<T>>& a, const std::vector<std::vector<T>>& b) {
+  if (a.size() != b.size()) return false;
+  for (size_t i = 0; i < a.size(); i++)
+    if (a[i].size() != b[i].size() || (!a[i].empty() && std::memcmp(a[i].data(), b[i].data(), a[i].size() * sizeof(T)) != 0)) return false;
+  return true;
+}
+
+static int build_wave(zkw_batch* b, uint32_t w) {
+  zkw_ctx* c = b->ctx;
+  const uint32_t flags = pack_flags(c, &b, 1);
+  std::unique_ptr<WaveTrace> wt;
+  const int rc = pack_one_wave(b, w, flags, wt);
+  if (rc != ZKW_OK) return rc;
+  // Self-check of the link format, once per context, on the first wave anybody reads: the same wave packed in the plain format
+  // (every page, every value, 16-byte tails, 32-byte deltas: nothing for the rebuild to derive) must rebuild to the same trace.
+  // If it does not — a device this format's scans were never run on — the context says so on stderr and keeps the plain format.
+  if (!c->link_checked && c->opt_link_selfcheck && flags != 0) {
+    c->link_checked = true;
+    std::unique_ptr<WaveTrace> plain;
+    const int rc0 = pack_one_wave(b, w, 0, plain);
+    if (rc0 != ZKW_OK) return rc0;
+    const bool same = c->opt_link_selfcheck != 2 /* (2: the test hook — behave as after a mismatch) */ && same_rows(wt->records, plain->records) && same_rows(wt->mem, plain->mem) &&
+                      same_rows(wt->log, plain->log) && same_rows(wt->aux, plain->aux) && same_rows(wt->mem_off, plain->mem_off);
+    if (!same) {
+      std::fprintf(stderr, "zkw: LINK FORMAT SELF-CHECK FAILED (flags %u): wave %u rebuilds differently from the plain format; this context keeps the plain format "
+                           "(zkw_delivered.link_flags = 0). Please report.\n", flags, w);
+      c->opt_link_flags_off = 0xffffffffu;
+      wt = std::move(plain);
+    }
+  }
+  b->wave_cache[w] = std::move(wt);
   return ZKW_OK;
 }
 

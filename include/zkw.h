@@ -454,6 +454,9 @@ int zkw_ctx_set_isa(zkw_ctx* ctx, const zkw_isa_table* table); /* copies */
                                           images then carry the values of their memory reads on the link */
 #define ZKW_OPT_READ_VALUES 11u        /* 1 = the values of memory reads always travel (the round-5 link format: A/B, tests) */
 #define ZKW_OPT_LINK_FLAGS_OFF 12u     /* bits of zkw_delivered.link_flags that deliveries submitted afterwards leave out (A/B of the link format's parts, tests) */
+#define ZKW_OPT_LINK_SELFCHECK 13u      /* 1 (default): the first wave a context rebuilds is packed twice — in the link format in use and in the plain one (every
+                                          page, every value) — and the two rebuilds must agree; if not, the context reports it on stderr and keeps the plain
+                                          format.  0 = off.  2 = behave as after a mismatch (test hook) */
 int zkw_ctx_set_option(zkw_ctx* ctx, uint32_t option, uint64_t value);
 
 int zkw_batch_create(zkw_ctx* ctx, uint32_t n_instances, const zkw_limits* limits, zkw_batch** out);

@@ -332,6 +332,7 @@ pub const ZKW_OPT_PACK_BLOCKS: u32 = 9;
 pub const ZKW_OPT_STAGING_BUFFERS: u32 = 10;
 pub const ZKW_OPT_READ_VALUES: u32 = 11;
 pub const ZKW_OPT_LINK_FLAGS_OFF: u32 = 12;
+pub const ZKW_OPT_LINK_SELFCHECK: u32 = 13;
 
 extern "C" {
     pub fn zkw_ctx_create(device: c_int, out: *mut *mut zkw_ctx) -> c_int;

@@ -436,3 +436,38 @@ def test_reads_travel_without_their_values(oracle, emu, isa):
 
 def test_a_ticket_outlives_the_restage_and_the_destruction_of_its_batch(oracle, emu, isa):
     check_a_ticket_outlives_the_restage_and_the_destruction_of_its_batch(oracle, emu, isa)
+
+
+def test_link_format_self_check(oracle, emu, isa, capfd):
+    """The first wave a context rebuilds is packed twice — in the link format in use and in the plain one — and the two rebuilds must
+    agree (ZKW_OPT_LINK_SELFCHECK).  Here they do (nothing on stderr, deliveries carry the full flags); with the test hook (= 2: behave
+    as after a mismatch) the context says so on stderr, keeps the plain format for its deliveries, and its traces are still the oracle's."""
+    import build_emu
+    wl = synth.make(2, isa, n_instances=6)
+    bo = _run(oracle, wl)
+    for hook in (1, 2):
+        be = K.Backend(build_emu.build(wave=emu.emu_wave), "zkw_").open(isa)  # (a fresh context: the check runs once per context)
+        try:
+            be.set_option(K.OPT_LINK_SELFCHECK, hook)
+            bp = _run(be, wl)
+            capfd.readouterr()
+            for i in range(wl.n_instances):
+                ok, why = K.traces_equal(bo.trace(i), bp.trace(i))
+                assert ok, "hook %d instance %d: %s" % (hook, i, why)
+            err = capfd.readouterr().err
+            dv = K.Delivery(be, 1, K.Delivery.worst_case_bytes(be, [bp]), 1)
+            t = dv.submit([bp])
+            info = dv.wait(t)
+            for i in range(wl.n_instances):
+                ok, why = K.traces_equal(bo.trace(i), dv.trace(t, 0, i))
+                assert ok, "hook %d delivered instance %d: %s" % (hook, i, why)
+            dv.release(t)
+            dv.close()
+            if hook == 1:
+                assert "SELF-CHECK" not in err and info["link_flags"] == 31
+            else:
+                assert "LINK FORMAT SELF-CHECK FAILED" in err and info["link_flags"] == 0
+            bp.destroy()
+        finally:
+            be.close()
+    bo.destroy()
