@@ -1555,6 +1555,7 @@ static bool wave_view(const uint4* block, const zkw_pack_wave& e, uint32_t L, ui
   C.max_cyc = e.max_cyc; C.L = L; C.n_delta = e.n_delta; C.n_mem = e.n_mem; C.n_page = e.n_page; C.n_val = e.n_val; C.n_log = e.n_log; C.aux_units = e.aux_units;
   C.n_d1 = e.n_d1; C.n_d2 = e.n_d2; C.n_tx = e.n_tx; C.n_ty = e.n_ty; C.n_tz = e.n_tz;
   v.n_d1 = e.n_d1; v.n_d2 = e.n_d2; v.n_tx = e.n_tx; v.n_ty = e.n_ty; v.n_tz = e.n_tz;
+  if (zkw_pack_wave_units(&C, flags) != e.units) return false;  // (the entry does not describe its own extent: nothing of it can be trusted)
   const uint4* d = block + e.off;
   v.dir = (const uint32_t*)d; d += e.max_cyc + 1;
   {
@@ -2038,7 +2039,15 @@ static int build_wave(zkw_batch* b, uint32_t w) {
   zkw_ctx* c = b->ctx;
   const uint32_t flags = pack_flags(c, &b, 1);
   std::unique_ptr<WaveTrace> wt;
-  const int rc = pack_one_wave(b, w, flags, wt);
+  int rc = pack_one_wave(b, w, flags, wt);
+  if (rc != ZKW_OK && !c->link_checked && c->opt_link_selfcheck && flags != 0) {  // (the format in use could not even be read back: the self-check below, failed)
+    c->link_checked = true;
+    rc = pack_one_wave(b, w, 0, wt);
+    if (rc == ZKW_OK) {
+      std::fprintf(stderr, "zkw: LINK FORMAT SELF-CHECK FAILED (flags %u): wave %u could not be rebuilt; this context keeps the plain format (zkw_delivered.link_flags = 0). Please report.\n", flags, w);
+      c->opt_link_flags_off = 0xffffffffu;
+    }
+  }
   if (rc != ZKW_OK) return rc;
   // Self-check of the link format, once per context, on the first wave anybody reads: the same wave packed in the plain format
   // (every page, every value, 16-byte tails, 32-byte deltas: nothing for the rebuild to derive) must rebuild to the same trace.
