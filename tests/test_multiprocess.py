@@ -200,6 +200,10 @@ def test_bench_host_legs_on_the_emulation_build(tmp_path, isa):
     assert "error" not in d and "error" not in u, (d, u)
     assert d["steps"] >= 20 and d["cycles_delivered"] == d["steps"] * 3 * 256 and d["host_threads"] == 3 and 60 < d["bytes_per_cycle"] < 400
     assert u["steps"] >= 20 and u["bytes_per_step"] == 3 * (680 + 32 * 256) and not u["in_place"] and ui["in_place"]
+    # the delivered leg ran in both link formats: the smallest one, and with the read values left on the link (more bytes, less host work)
+    alt = d["with_read_values_on_the_link"]
+    assert d["link_flags"] == 31 and alt["link_flags"] == 30 and alt["bytes_per_cycle"] > d["bytes_per_cycle"] and d["best_cycles_per_s"] >= d["cycles_per_s"]
+    assert d["bound_by"].startswith(("host replay", "link"))
     e = j["end_to_end"]
     assert "error" not in e, e
     for form in ("copying", "in_place"):  # fresh inputs, run, delivery and replay in one pipeline
