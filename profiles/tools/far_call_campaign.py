@@ -22,7 +22,8 @@ def _campaign_backend():
     if which in ("emu64", "emu1"):
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "emu"))
         import build_emu
-        return K.Backend(build_emu.build(wave=64 if which == "emu64" else 1), "zkw_")
+        defs = tuple(d for d in os.environ.get("ZKW_CAMPAIGN_DEFINES", "").split(",") if d)  # (an A/B partner: e.g. ZKW_SHORT_CLASS,ZKW_SHORT_STACK)
+        return K.Backend(build_emu.build(wave=64 if which == "emu64" else 1, defines=defs, tag="_".join(d.lower() for d in defs)), "zkw_")
     return K.load_product()
 
 from tests._oracle import load_oracle  # noqa: E402
