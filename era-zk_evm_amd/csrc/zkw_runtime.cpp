@@ -1546,8 +1546,8 @@ struct WaveView {  // host pointers to the packed data of one wave
   const uint4 *v_lo = nullptr, *v_hi = nullptr, *log = nullptr, *aux = nullptr;
 };
 
-static bool wave_view(const uint4* block, const zkw_pack_wave& e, uint32_t L, uint32_t flags, WaveView& v) {
-  if (e.off == 0) return false;
+static bool wave_view(const uint4* block, uint64_t block_units, const zkw_pack_wave& e, uint32_t L, uint32_t flags, WaveView& v) {
+  if (e.off == 0 || (uint64_t)e.off + e.units > block_units) return false;  // (not packed, or an extent that is not inside the block)
   v.flags = flags;
   v.L = L; v.max_cyc = e.max_cyc; v.n_delta = e.n_delta; v.n_mem = e.n_mem; v.n_val = e.n_val; v.n_log = e.n_log; v.n_aux = e.n_aux; v.aux_units = e.aux_units;
   v.n_page = e.n_page;
@@ -2019,7 +2019,7 @@ static int pack_one_wave(zkw_batch* b, uint32_t w, uint32_t flags, std::unique_p
   zkw_pack_wave e;
   std::memcpy(&e, b->h_pack + A.wave_table, sizeof e);
   WaveView v;
-  if (state1[1] != 0 || !wave_view(b->h_pack, e, L, A.flags, v)) {
+  if (state1[1] != 0 || !wave_view(b->h_pack, b->h_pack_units, e, L, A.flags, v)) {
     c->last_error = "pack kernel: the wave did not fit its block";
     return ZKW_ERR_LIMIT;
   }
@@ -2185,7 +2185,7 @@ static bool delivery_wave(const DeliverySlot& sl, uint32_t bi, uint32_t w, WaveV
   const zkw_pack_batch* pbs = (const zkw_pack_batch*)(sl.h + ZKW_PACK_HEADER_UNITS);
   const zkw_pack_batch& pb = pbs[bi];
   const zkw_pack_wave* wt = (const zkw_pack_wave*)(sl.h + sl.wave_table);
-  if (!wave_view(sl.h, wt[pb.first_wave + w], pb.L, ((const zkw_pack_header*)sl.h)->flags, v)) return false;
+  if (!wave_view(sl.h, sl.units, wt[pb.first_wave + w], pb.L, ((const zkw_pack_header*)sl.h)->flags, v)) return false;
   const zkw_dev_scalars* sc = (const zkw_dev_scalars*)(sl.h + pb.scalars_off);
   for (uint32_t l = 0; l < pb.L; l++) {
     const uint32_t i = w * pb.L + l;
